@@ -1,0 +1,69 @@
+"""ctypes binding of libafan_hip.so (the C-ABI declared in include/afan_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libafan_hip.so")
+
+AFAN_F32, AFAN_BF16 = 0, 1
+_ERRORS = {-1: "AFAN_EDTYPE (unknown dtype code)", -2: "AFAN_EALIGN (misaligned pointer)",
+           -3: "AFAN_ESHAPE (bad sizes)", -4: "AFAN_ENULL (required pointer is NULL)"}
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); mirrors include/afan_hip.h one to one
+SIGNATURES = {
+    "afan_version": (_i, []),
+    "afan_arch": (C.c_char_p, []),
+    "afan_pgd_step": (_i, [_p, _p, _i, _p, _p, _l, _f, _f, _i, _p]),
+    "afan_tensor_clamp": (_i, [_p, _p, _p, _l, _p]),
+    "afan_norms_workspace_floats": (_l, [_l, _l]),
+    "afan_pgd_step_norms": (_i, [_p, _p, _i, _p, _p, _l, _l, _f, _f, _i, _p, _p, _p, _p]),
+    "afan_perturb_norms": (_i, [_p, _p, _l, _l, _p, _p, _p, _p]),
+    "afan_axpy_noise": (_i, [_p, _p, _l, _f, _p, _p]),
+    "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
+    "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
+    "afan_bn_workspace_floats": (_l, [_l]),
+    "afan_bn_stats": (_i, [_p, _i, _l, _l, _l, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "afan_bn_train_forward": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "afan_bn_apply": (_i, [_p, _p, _p, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p]),
+    "afan_bn_backward": (_i, [_p, _p, _p, _p, _p, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
+    "afan_cast_bf16": (_i, [_p, _p, _l, _p]),
+    "afan_normalize_nchw": (_i, [_p, _p, _i, _l, _l, _l, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class AfanLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libafan_hip.so once; raise loudly (no fallback) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfanLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cv_a-fan_amd/csrc`). There is no CPU or PyTorch fallback for the A-FAN kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise AfanLibraryError(f"{what}: {_ERRORS.get(rc, rc)}")
+    raise AfanLibraryError(f"{what}: HIP launch failed with hipError_t={rc}")

@@ -1,0 +1,94 @@
+"""A-FAN operators, MI355X-native: drop-in for the reference's `attack_algo` modules.
+
+Same names, argument meaning and return contract as
+  Classification/attack_algo.py:9-58   tensor_clamp, linfball_proj, PGD
+  Segmentation/attack_algo.py:108-130  get_sample_points, mix_feature   (== Detection/attack_algo.py:236-265)
+but every arithmetic step is a hand-written HIP kernel from libafan_hip.so (sign-step + projection +
+per-sample norms fused in one pass; channel-moment re-normalisation in one pass).  `model` may be any
+nn.Module on the GPU that follows the slice protocol `model(t, end_point=, start_point=)`; for the
+models of `resnet_s.py` the tail additionally runs its fused BN kernels with parameter gradients
+switched off (the reference asks autograd for the feature gradient only, attack_algo.py:52).
+"""
+import torch
+
+from . import ops
+from .resnet_s import dgrad_only
+
+__all__ = ["PGD", "tensor_clamp", "linfball_proj", "mix_feature", "get_sample_points", "last_norms"]
+
+_last = {"l2": None, "linf": None}
+
+
+def last_norms():
+    """Per-sample (L2, Linf) of the perturbation produced by the most recent PGD(..., with_norms=True) call:
+    device tensors, no host sync (main_perturb.py:188-192 computes them on the host from a D2H copy)."""
+    return _last["l2"], _last["linf"]
+
+
+def tensor_clamp(t, min, max, in_place=True):
+    """attack_algo.py:9-19: element-wise clamp between two tensors, lower bound first."""
+    res = t if in_place else t.clone()
+    ops.tensor_clamp_(res.data, min.contiguous(), max.contiguous())
+    return res
+
+
+def linfball_proj(center, radius, t, in_place=True):
+    """attack_algo.py:35-36: project t onto the L-inf ball of `radius` around `center` (one HIP launch)."""
+    res = t if in_place else t.clone()
+    zero = torch.zeros_like(res.data)
+    ops.pgd_step_(res.data, zero, 0.0, x_clean=center.contiguous(), eps=float(radius), clip=True)
+    return res
+
+
+def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_number=16, eps=(2 / 255),
+        randinit=False, clip=False, with_norms=False):
+    """K-step sign-gradient ascent on the feature map `x` (attack_algo.py:38-58).
+
+    Returns a NEW fp32 leaf tensor with requires_grad=True; `x` is not modified.  `with_norms=True`
+    (an addition) fuses the per-sample L2/Linf perturbation norms into the last step; read them with
+    `last_norms()`.
+    """
+    if x.device.type != "cuda":
+        raise ops.AfanLibraryError("PGD: x must live on the MI355X (no CPU path in this build)")
+    x = x.detach().contiguous().float()
+    x_adv = x.clone()
+    lp = getattr(model, "compute_dtype", torch.float32) == torch.bfloat16
+    shadow = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lp else None
+    if randinit:
+        # the reference draws the noise on the CPU default generator (attack_algo.py:44); same stream here
+        u = torch.rand(x_adv.shape).to(x.device, non_blocking=True)
+        ops.axpy_noise_(x_adv, u, eps, shadow)
+    elif lp:
+        ops.cast_bf16(x_adv, shadow)
+    l2 = linf = None
+    for t in range(steps):
+        # the tail consumes the bf16 shadow written by the previous step's kernel (no separate cast)
+        xin = (shadow if lp else x_adv).detach().requires_grad_(True)
+        with dgrad_only():
+            out = model(xin, end_point=layer_number, start_point=start_idx)
+            loss = loss_fn(out, y)
+            grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
+        grad = grad.contiguous()
+        if with_norms and t == steps - 1:
+            l2, linf = ops.pgd_step_norms_(x_adv, grad, gamma, x, eps, clip, shadow)
+        else:
+            ops.pgd_step_(x_adv, grad, gamma, x, eps, clip, shadow)
+    if with_norms:
+        if l2 is None:
+            l2, linf = ops.perturb_norms(x_adv, x)
+        _last["l2"], _last["linf"] = l2, linf
+    x_adv.requires_grad_(True)
+    if lp:
+        x_adv._afan_shadow = shadow  # bf16 copy of the final x_adv for the adv tail forward
+    return x_adv
+
+
+def mix_feature(clean_feature, adv_feature):
+    """Segmentation/attack_algo.py:121-130: re-normalise clean features to the adversarial channel statistics."""
+    return ops.mix_feature(clean_feature.contiguous(), adv_feature.contiguous(), 1e-5)
+
+
+def get_sample_points(pointx, pointy, number):
+    """Segmentation/attack_algo.py:108-118: [x, lerp(x,y,1/(n-1)), ..., y]; interior points in one launch."""
+    inner = ops.lerp_points(pointx.contiguous(), pointy.contiguous(), number)
+    return [pointx] + inner + [pointy]

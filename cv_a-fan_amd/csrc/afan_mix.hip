@@ -1,0 +1,193 @@
+// mix_feature (the "N" of A-FAN) and SAT sample points for gfx950.
+// Reference behaviour: Segmentation/attack_algo.py:108-118 (get_sample_points) and :121-130
+// (mix_feature) == Detection/attack_algo.py:236-265.  Statistics run over the CHANNEL dimension per
+// pixel, so in NCHW the reduction strides by H*W: lanes run along the pixel index (coalesced),
+// each thread walks a subset of the channels, the clean column is parked in LDS so HBM sees the
+// algorithmic 12 B/elt (read clean, read adv, write out) instead of eager PyTorch's ~48 B/elt.
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_LDS_BYTES = 128 * 1024;
+
+// Workgroup = PIX consecutive pixels of one sample x all C channels.  Thread (grp, px): px = tid % PIX,
+// grp = tid / PIX walks channels grp, grp+G, ...  (G = BLOCK / PIX).
+template <typename T, bool STAGE>
+__global__ __launch_bounds__(BLOCK) void mix_feature_kernel(const T* __restrict__ clean,
+                                                            const T* __restrict__ adv, T* __restrict__ out,
+                                                            int C, int64_t HW, int PIX, int tiles_per_sample,
+                                                            float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = BLOCK / PIX;
+    float* stats = lds;                  // [2][G][PIX][3] partial moments, then [4][PIX] final stats
+    float* tile = lds + 2 * G * PIX * 3; // [C][PIX] staged clean values (STAGE only)
+    const int px = threadIdx.x % PIX, grp = threadIdx.x / PIX;
+    const int64_t n = blockIdx.x / tiles_per_sample;
+    const int64_t p0 = (int64_t)(blockIdx.x % tiles_per_sample) * PIX;
+    const int64_t p = p0 + px;
+    const bool live = p < HW;
+    const int64_t base = n * (int64_t)C * HW + p;
+
+    // pass 1: shifted sums over this thread's channels
+    float sh_c = 0.f, s_c = 0.f, q_c = 0.f, sh_a = 0.f, s_a = 0.f, q_a = 0.f, cnt = 0.f;
+    if (live) {
+        bool first = true;
+#pragma unroll 4
+        for (int c = grp; c < C; c += G) {
+            const float vc = Elt<T>::ld(clean + base + (int64_t)c * HW);
+            const float va = Elt<T>::ld(adv + base + (int64_t)c * HW);
+            if (STAGE) tile[c * PIX + px] = vc;
+            if (first) { sh_c = vc; sh_a = va; first = false; }
+            const float dc = vc - sh_c, da = va - sh_a;
+            s_c += dc; q_c += dc * dc;
+            s_a += da; q_a += da * da;
+            cnt += 1.f;
+        }
+    }
+    Moments mc{cnt, 0.f, 0.f}, ma{cnt, 0.f, 0.f};
+    if (cnt > 0.f) {
+        const float dmc = s_c / cnt, dma = s_a / cnt;
+        mc.mean = sh_c + dmc; mc.m2 = fmaxf(q_c - s_c * dmc, 0.f);
+        ma.mean = sh_a + dma; ma.m2 = fmaxf(q_a - s_a * dma, 0.f);
+    }
+    float* pc = stats + ((0 * G + grp) * PIX + px) * 3;
+    float* pa = stats + ((1 * G + grp) * PIX + px) * 3;
+    pc[0] = mc.n; pc[1] = mc.mean; pc[2] = mc.m2;
+    pa[0] = ma.n; pa[1] = ma.mean; pa[2] = ma.m2;
+    __syncthreads();
+    float mean_c = 0.f, std_c = 1.f, mean_a = 0.f, std_a = 1.f;
+    {
+        // every thread folds its pixel's G partials (identical order => identical result in all groups)
+        Moments tc{0.f, 0.f, 0.f}, ta{0.f, 0.f, 0.f};
+        for (int g = 0; g < G; ++g) {
+            const float* qc = stats + ((0 * G + g) * PIX + px) * 3;
+            const float* qa = stats + ((1 * G + g) * PIX + px) * 3;
+            tc = merge(tc, Moments{qc[0], qc[1], qc[2]});
+            ta = merge(ta, Moments{qa[0], qa[1], qa[2]});
+        }
+        const float denom = (float)C - 1.0f;  // unbiased: torch.var default (C == 1 -> NaN, like the reference)
+        mean_c = tc.mean; std_c = sqrtf(tc.m2 / denom + eps);
+        mean_a = ta.mean; std_a = sqrtf(ta.m2 / denom + eps);
+    }
+    if (!live) return;
+    // pass 2: (clean - mean_c) / std_c * std_a + mean_a, op by op as attack_algo.py:128-129
+#pragma unroll 4
+    for (int c = grp; c < C; c += G) {
+        const float vc = STAGE ? tile[c * PIX + px] : Elt<T>::ld(clean + base + (int64_t)c * HW);
+        float t = (vc - mean_c) / std_c;
+        t = t * std_a;
+        t = t + mean_a;
+        Elt<T>::st(out + base + (int64_t)c * HW, t);
+    }
+}
+
+struct LerpW {
+    float w[8];
+};
+
+__global__ __launch_bounds__(BLOCK) void lerp_points_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ y,
+                                                            float* __restrict__ out, int64_t n, LerpW lw,
+                                                            int k_int, int vec) {
+    const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * BLOCK;
+    int64_t done = 0;
+    if (vec) {
+        const int64_t nvec = n >> 2;
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            const int64_t i = v << 2;
+            float a[4], b[4];
+            Elt<float>::ldv(x + i, a);
+            Elt<float>::ldv(y + i, b);
+            for (int k = 0; k < k_int; ++k) {
+                const float w = lw.w[k];
+                const bool small = fabsf(w) < 0.5f;  // ATen lerp: two forms around 0.5
+                const float coeff = small ? w : w - 1.0f;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(coeff, b[e] - a[e], small ? a[e] : b[e]);
+                Elt<float>::stv(out + (int64_t)k * n + i, o);
+            }
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        const float a = x[i], b = y[i];
+        for (int k = 0; k < k_int; ++k) {
+            const float w = lw.w[k];
+            const bool small = fabsf(w) < 0.5f;
+            out[(int64_t)k * n + i] = fmaf(small ? w : w - 1.0f, b - a, small ? a : b);
+        }
+    }
+}
+
+template <typename T>
+int mix_impl(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw, float eps,
+             hipStream_t st) {
+    // largest power-of-two pixel tile (<= 64) whose staged clean column fits the LDS budget
+    int pix = 64;
+    while (pix >= 8 && (int64_t)c * pix * 4 + 2 * (BLOCK / pix) * pix * 3 * 4 > 64 * 1024) pix >>= 1;
+    bool stage = pix >= 8;
+    if (!stage) {
+        pix = 64;
+        while (pix >= 8 && (int64_t)c * pix * 4 + 2 * (BLOCK / pix) * pix * 3 * 4 > MAX_LDS_BYTES) pix >>= 1;
+        stage = pix >= 8;
+        if (!stage) pix = 64;
+    }
+    while (pix > 8 && pix / 2 >= hw) pix >>= 1;  // tiny planes: do not waste lanes
+    const int tiles = (int)((hw + pix - 1) / pix);
+    const int64_t blocks = n * tiles;
+    if (blocks > 0x7fffffffLL) return AFAN_ESHAPE;
+    const size_t stats_bytes = (size_t)2 * (BLOCK / pix) * pix * 3 * 4;
+    const size_t lds = stats_bytes + (stage ? (size_t)c * pix * 4 : 0);
+    if (stage) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)mix_feature_kernel<T, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        mix_feature_kernel<T, true><<<(unsigned)blocks, BLOCK, lds, st>>>(
+            (const T*)clean, (const T*)adv, (T*)out, (int)c, hw, pix, tiles, eps);
+    } else {
+        mix_feature_kernel<T, false><<<(unsigned)blocks, BLOCK, lds, st>>>(
+            (const T*)clean, (const T*)adv, (T*)out, (int)c, hw, pix, tiles, eps);
+    }
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw,
+                     float eps, int dtype, afan_stream_t stream) {
+    if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n < 0 || c <= 0 || hw < 0 || c > 0x7fffffffLL) return AFAN_ESHAPE;
+    if (n == 0 || hw == 0) return AFAN_OK;
+    if (!clean || !adv || !out) return AFAN_ENULL;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(clean, a) || !aligned(adv, a) || !aligned(out, a)) return AFAN_EALIGN;
+    if (dtype == AFAN_F32) return mix_impl<float>(clean, adv, out, n, c, hw, eps, (hipStream_t)stream);
+    return mix_impl<uint16_t>(clean, adv, out, n, c, hw, eps, (hipStream_t)stream);
+}
+
+int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, const float* weights,
+                     int n_interior, afan_stream_t stream) {
+    if (n < 0 || n_interior < 0 || n_interior > 8) return AFAN_ESHAPE;
+    if (n == 0 || n_interior == 0) return AFAN_OK;
+    if (!x || !y || !out || !weights) return AFAN_ENULL;
+    if (!aligned(x, 4) || !aligned(y, 4) || !aligned(out, 4)) return AFAN_EALIGN;
+    LerpW lw;
+    for (int k = 0; k < 8; ++k) lw.w[k] = k < n_interior ? weights[k] : 0.f;
+    const int vec = aligned(x, 16) && aligned(y, 16) && aligned(out, 16) && (n % 4 == 0);
+    const int grid = grid_for(vec ? n / 4 : n, BLOCK);
+    lerp_points_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, y, out, n, lw, n_interior, vec);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // extern "C"

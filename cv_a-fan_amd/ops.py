@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C-ABI (include/afan_hip.h).  torch is plumbing here: it owns the
+device memory and the stream; every arithmetic op below runs in libafan_hip.so.  No fallbacks: a CPU
+tensor, a non-contiguous tensor or a missing library raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import AFAN_BF16, AFAN_F32, AfanLibraryError, check
+
+_DT = {torch.float32: AFAN_F32, torch.bfloat16: AFAN_BF16}
+_ws_cache = {}
+
+
+def _need(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.device.type != "cuda":
+        raise AfanLibraryError(f"{name}: tensor is on '{t.device}'. The A-FAN kernels are MI355X-only; "
+                               "there is no CPU path (the CPU restatement under oracle/ is test infrastructure).")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous (dense NCHW)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _workspace(ref, nfloats, tag):
+    """Per (device, stream, tag) fp32 scratch, grown on demand, never shrunk (graph-capture safe once warm)."""
+    key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream, tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=ref.device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _nchw(t):
+    if t.dim() < 2:
+        raise ValueError("expected a tensor of shape [N, C, ...]")
+    n, c = t.shape[0], t.shape[1]
+    hw = 1
+    for s in t.shape[2:]:
+        hw *= s
+    return n, c, hw
+
+
+# ---------------------------------------------------------------------------------------------- PGD
+def pgd_step_(x_adv, grad, gamma, x_clean=None, eps=0.0, clip=False, shadow=None):
+    """In place: x_adv += gamma*sign(grad) [then project onto the eps-ball around x_clean]."""
+    lib = _lib.load()
+    _need(x_adv, "x_adv", torch.float32)
+    _need(grad, "grad")
+    if grad.dtype not in _DT or grad.numel() != x_adv.numel():
+        raise TypeError("grad must be fp32/bf16 with x_adv's number of elements")
+    if clip:
+        _need(x_clean, "x_clean", torch.float32)
+        if x_clean.numel() != x_adv.numel():
+            raise ValueError("x_clean must match x_adv")
+    if shadow is not None:
+        _need(shadow, "shadow", torch.bfloat16)
+    check(lib.afan_pgd_step(_ptr(x_adv), _ptr(grad), _DT[grad.dtype], _ptr(x_clean) if clip else None,
+                            _ptr(shadow), x_adv.numel(), float(gamma), float(eps), int(bool(clip)),
+                            _stream(x_adv)), "afan_pgd_step")
+    return x_adv
+
+
+def tensor_clamp_(t, lo, hi):
+    lib = _lib.load()
+    _need(t, "t", torch.float32)
+    _need(lo, "min", torch.float32)
+    _need(hi, "max", torch.float32)
+    if lo.numel() != t.numel() or hi.numel() != t.numel():
+        raise ValueError("min/max must match t")
+    check(lib.afan_tensor_clamp(_ptr(t), _ptr(lo), _ptr(hi), t.numel(), _stream(t)), "afan_tensor_clamp")
+    return t
+
+
+def pgd_step_norms_(x_adv, grad, gamma, x_clean, eps=0.0, clip=False, shadow=None):
+    """Last PGD step fused with per-sample L2/Linf norms of (x_adv - x_clean). Returns (l2, linf) [N]."""
+    lib = _lib.load()
+    _need(x_adv, "x_adv", torch.float32)
+    _need(grad, "grad")
+    _need(x_clean, "x_clean", torch.float32)
+    if grad.dtype not in _DT or grad.numel() != x_adv.numel() or x_clean.numel() != x_adv.numel():
+        raise TypeError("grad/x_clean must match x_adv")
+    if shadow is not None:
+        _need(shadow, "shadow", torch.bfloat16)
+    batch = x_adv.shape[0]
+    per = x_adv.numel() // max(batch, 1)
+    out = torch.empty(2, batch, dtype=torch.float32, device=x_adv.device)
+    if batch == 0:
+        return out[0], out[1]
+    ws = _workspace(x_adv, lib.afan_norms_workspace_floats(batch, per), "norms")
+    check(lib.afan_pgd_step_norms(_ptr(x_adv), _ptr(grad), _DT[grad.dtype], _ptr(x_clean), _ptr(shadow),
+                                  batch, per, float(gamma), float(eps), int(bool(clip)), _ptr(ws),
+                                  _ptr(out[0]), _ptr(out[1]), _stream(x_adv)), "afan_pgd_step_norms")
+    return out[0], out[1]
+
+
+def perturb_norms(x_adv, x_clean):
+    lib = _lib.load()
+    _need(x_adv, "x_adv", torch.float32)
+    _need(x_clean, "x_clean", torch.float32)
+    if x_clean.numel() != x_adv.numel():
+        raise ValueError("x_clean must match x_adv")
+    batch = x_adv.shape[0]
+    per = x_adv.numel() // max(batch, 1)
+    out = torch.empty(2, batch, dtype=torch.float32, device=x_adv.device)
+    if batch == 0:
+        return out[0], out[1]
+    ws = _workspace(x_adv, lib.afan_norms_workspace_floats(batch, per), "norms")
+    check(lib.afan_perturb_norms(_ptr(x_adv), _ptr(x_clean), batch, per, _ptr(ws), _ptr(out[0]),
+                                 _ptr(out[1]), _stream(x_adv)), "afan_perturb_norms")
+    return out[0], out[1]
+
+
+def axpy_noise_(x_adv, u, eps, shadow=None):
+    """In place: x_adv += (2u-1)*eps with host-drawn u already uploaded."""
+    lib = _lib.load()
+    _need(x_adv, "x_adv", torch.float32)
+    _need(u, "u", torch.float32)
+    if u.numel() != x_adv.numel():
+        raise ValueError("u must match x_adv")
+    if shadow is not None:
+        _need(shadow, "shadow", torch.bfloat16)
+    check(lib.afan_axpy_noise(_ptr(x_adv), _ptr(u), x_adv.numel(), float(eps), _ptr(shadow),
+                              _stream(x_adv)), "afan_axpy_noise")
+    return x_adv
+
+
+def cast_bf16(src, out=None):
+    lib = _lib.load()
+    _need(src, "src", torch.float32)
+    if out is None:
+        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    _need(out, "out", torch.bfloat16)
+    check(lib.afan_cast_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "afan_cast_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------ mix_feature / lerp
+def mix_feature(clean, adv, eps=1e-5):
+    lib = _lib.load()
+    _need(clean, "clean")
+    _need(adv, "adv", clean.dtype)
+    if clean.dtype not in _DT or clean.shape != adv.shape:
+        raise TypeError("clean/adv must be fp32 or bf16 tensors of the same shape")
+    n, c, hw = _nchw(clean)
+    out = torch.empty_like(clean)
+    check(lib.afan_mix_feature(_ptr(clean), _ptr(adv), _ptr(out), n, c, hw, float(eps), _DT[clean.dtype],
+                               _stream(clean)), "afan_mix_feature")
+    return out
+
+
+def lerp_points(x, y, number):
+    """Interior points of get_sample_points(x, y, number): list of number-2 tensors."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    _need(y, "y", torch.float32)
+    if x.shape != y.shape:
+        raise ValueError("x/y shape mismatch")
+    k = number - 2
+    if k <= 0:
+        return []
+    if k > 8:
+        raise ValueError("at most 10 sample points")
+    percent = 1.0 / (number - 1)  # python double, as the reference
+    w = (C.c_float * k)(*[i * percent for i in range(1, number - 1)])
+    out = torch.empty((k,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+    check(lib.afan_lerp_points(_ptr(x), _ptr(y), _ptr(out), x.numel(), w, k, _stream(x)), "afan_lerp_points")
+    return [out[i] for i in range(k)]
+
+
+# ------------------------------------------------------------------------------------- BatchNorm
+def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None):
+    lib = _lib.load()
+    _need(x, "x")
+    n, c, hw = _nchw(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
+    check(lib.afan_bn_stats(_ptr(x), _DT[x.dtype], n, c, hw, float(eps), float(momentum), _ptr(ws), _ptr(mean),
+                            _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(num_batches),
+                            _stream(x)), "afan_bn_stats")
+    return mean, invstd
+
+
+def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches):
+    lib = _lib.load()
+    _need(x, "x")
+    if x.dtype not in _DT:
+        raise TypeError("x must be fp32 or bf16")
+    if residual is not None:
+        _need(residual, "residual", x.dtype)
+    n, c, hw = _nchw(x)
+    y = torch.empty_like(x)
+    stats = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
+    check(lib.afan_bn_train_forward(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, float(eps),
+                                    float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws),
+                                    _ptr(stats[0]), _ptr(stats[1]), _ptr(running_mean), _ptr(running_var),
+                                    _ptr(num_batches), _stream(x)), "afan_bn_train_forward")
+    return y, stats[0], stats[1]
+
+
+def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
+    lib = _lib.load()
+    _need(x, "x")
+    if residual is not None:
+        _need(residual, "residual", x.dtype)
+    n, c, hw = _nchw(x)
+    y = torch.empty_like(x)
+    check(lib.afan_bn_apply(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, _ptr(mean), _ptr(invstd),
+                            _ptr(weight), _ptr(bias), int(bool(relu)), _stream(x)), "afan_bn_apply")
+    return y
+
+
+def bn_backward(dy, x, y, mean, invstd, weight, bias, relu, want_dres, dweight=None, dbias=None,
+                accumulate=False):
+    """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given."""
+    lib = _lib.load()
+    _need(dy, "dy", x.dtype)
+    _need(x, "x")
+    if y is not None:
+        _need(y, "y", x.dtype)
+    n, c, hw = _nchw(x)
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
+    check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
+                               _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws),
+                               _ptr(dweight), _ptr(dbias), int(bool(accumulate)), _stream(x)), "afan_bn_backward")
+    return dx, dres
+
+
+# ------------------------------------------------------------------------------------------- SGD
+def sgd_step_(param, grad, momentum_buf, lr_dev, momentum, weight_decay, grad_scale=1.0, shadow=None):
+    lib = _lib.load()
+    _need(param, "param", torch.float32)
+    _need(grad, "grad", torch.float32)
+    _need(momentum_buf, "momentum_buf", torch.float32)
+    _need(lr_dev, "lr_dev", torch.float32)
+    if shadow is not None:
+        _need(shadow, "shadow", torch.bfloat16)
+    check(lib.afan_sgd_step(_ptr(param), _ptr(grad), _ptr(momentum_buf), _ptr(shadow), param.numel(),
+                            _ptr(lr_dev), float(momentum), float(weight_decay), float(grad_scale), 0,
+                            _stream(param)), "afan_sgd_step")
+
+
+def normalize_nchw(x, mean, std, out_dtype=torch.float32):
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    n, c, hw = _nchw(x)
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib.afan_normalize_nchw(_ptr(x), _ptr(y), _DT[out_dtype], n, c, hw, _ptr(mean), _ptr(std),
+                                  _stream(x)), "afan_normalize_nchw")
+    return y

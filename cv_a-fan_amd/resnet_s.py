@@ -1,0 +1,287 @@
+"""Split-forward ResNets for the A-FAN hot path, MI355X-native.
+
+Host-side mirror of the reference's model interface (Classification/resnet_s.py:79-124):
+  * one flat `sequential_model`, `model(x, end_point=E, start_point=S)` == `sequential_model[S:E](x)`
+    (resnet_s.py:119-121) — the protocol `PGD` calls back into;
+  * state_dict keys identical to the reference's (`w`, `sequential_model.0.mean/std`,
+    `sequential_model.<i>.{conv1,bn1,conv2,bn2}.*`, ...), so checkpoints interchange.
+What differs is how it executes: BatchNorm (+residual, +ReLU) runs as fused HIP kernels from
+libafan_hip.so (two launches forward, two backward, instead of ~6 eager ones), convolutions go to
+MIOpen's MFMA kernels in the model's compute dtype (bf16 by default) from cached low-precision weights,
+and the slice executor fuses BN->ReLU pairs that sit at adjacent indices of the Sequential.
+ResNet-18 (CIFAR stem) is build-defined: the reference ships only resnet56 (SURVEY.md warning 3).
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+__all__ = ["ResNet", "BasicBlock", "resnet20", "resnet56", "resnet18", "ARCHS", "dgrad_only"]
+
+
+class _Flags:
+    param_grads = True  # False inside PGD: only d(loss)/d(feature) is needed (attack_algo.py:52 only_inputs=True)
+
+
+@contextlib.contextmanager
+def dgrad_only():
+    """Inside this context the HIP-backed layers skip weight/affine gradients (the PGD inner loop)."""
+    old = _Flags.param_grads
+    _Flags.param_grads = False
+    try:
+        yield
+    finally:
+        _Flags.param_grads = old
+
+
+# ------------------------------------------------------------------------------------------------ ops
+class _CastFn(torch.autograd.Function):
+    """fp32 -> bf16 through afan_cast_bf16; the gradient flows back in fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.cast_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float()
+
+
+def _to_compute(x, dtype):
+    if x.dtype == dtype:
+        return x
+    if x.dtype == torch.float32 and dtype == torch.bfloat16:
+        return _CastFn.apply(x.contiguous())
+    return x.to(dtype)
+
+
+class _ConvFn(torch.autograd.Function):
+    """MIOpen convolution on the low-precision weight copy; wgrad is returned for the fp32 master."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, w_lp, stride, padding, want_wgrad):
+        ctx.stride, ctx.padding, ctx.want_wgrad = stride, padding, want_wgrad
+        ctx.save_for_backward(x, w_lp)
+        return torch.ops.aten.convolution(x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_lp = ctx.saved_tensors
+        mask = [ctx.needs_input_grad[0], ctx.want_wgrad and ctx.needs_input_grad[1], False]
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy.contiguous(), x, w_lp, None, ctx.stride, ctx.padding,
+                                                        (1, 1), False, (0, 0), 1, mask)
+        if gw is not None and gw.dtype != torch.float32:
+            gw = gw.float()
+        return gx, gw, None, None, None, None
+
+
+class _BNTrainFn(torch.autograd.Function):
+    """y = [relu](bn_train(x) [+ residual]) via afan_bn_train_forward / afan_bn_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        y, mean, invstd = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt)
+        ctx.relu, ctx.has_res, ctx.want_pgrad = relu, residual is not None, want_pgrad
+        # the ReLU mask is recomputed from x when there is no residual; otherwise y carries it
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, mean, invstd, weight, bias = ctx.saved_tensors
+        want_p = ctx.want_pgrad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dw = db = None
+        if want_p:
+            dwb = torch.empty(2, x.shape[1], dtype=torch.float32, device=x.device)
+            dw, db = dwb[0], dwb[1]
+        dx, dres = ops.bn_backward(gy.contiguous(), x, y, mean, invstd, weight, bias, ctx.relu,
+                                   ctx.has_res and ctx.needs_input_grad[3], dw, db)
+        return dx, dw, db, dres, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- layers
+class NormalizeByChannelMeanStd(nn.Module):
+    """(x - mean[c]) / std[c] with `mean`/`std` buffers (advertorch's module, used at resnet_s.py:87).
+    Input images are constants of the graph (no gradient), output is in the model's compute dtype."""
+
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32))
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float32))
+        self.out_dtype = torch.float32
+
+    def forward(self, x):
+        if x.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the input image are not on the A-FAN feature path")
+        return ops.normalize_nchw(x.contiguous().float(), self.mean, self.std, self.out_dtype)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameters (fp32 master `weight`); runs in `compute_dtype` from a cached low-precision copy."""
+
+    compute_dtype = torch.float32
+    _lp = None
+    _lp_version = -1
+
+    def lp_weight(self):
+        if self.compute_dtype == torch.float32:
+            return self.weight
+        shadow = getattr(self, "_arena_shadow", None)
+        if shadow is not None:  # kept fresh by afan_sgd_step (ParamArena)
+            return shadow
+        if self._lp is None or self._lp_version != self.weight._version or self._lp.device != self.weight.device:
+            self._lp = ops.cast_bf16(self.weight.detach().contiguous())
+            self._lp_version = self.weight._version
+        return self._lp
+
+    def forward(self, x):
+        x = _to_compute(x, self.compute_dtype)
+        return _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.stride, self.padding,
+                             _Flags.param_grads)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d parameters/buffers; fused HIP execution."""
+
+    def fused(self, x, residual=None, relu=False):
+        if self.training:
+            mom = self.momentum if self.momentum is not None else 0.1
+            return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, mom, self.running_mean,
+                                    self.running_var, self.num_batches_tracked, _Flags.param_grads)
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad and _Flags.param_grads):
+            if x.requires_grad:
+                raise NotImplementedError("eval-mode BatchNorm backward is not on the A-FAN path (the reference "
+                                          "runs PGD and the joint step in train mode, main_perturb.py:159)")
+        with torch.no_grad():
+            invstd = torch.rsqrt(self.running_var + self.eps)
+            return ops.bn_apply(x.contiguous(), self.running_mean, invstd, self.weight, self.bias,
+                                None if residual is None else residual.contiguous(), relu)
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class _PadShortcut(nn.Module):
+    """Option-A identity (resnet_s.py:64-65): stride-2 subsample, zero-pad planes//4 channels per side."""
+
+    def __init__(self, planes):
+        super().__init__()
+        self.pad = planes // 4
+
+    def forward(self, x):
+        return F.pad(x[:, :, ::2, ::2], (0, 0, 0, 0, self.pad, self.pad), "constant", 0)
+
+
+class BasicBlock(nn.Module):
+    """conv3x3-BN-ReLU-conv3x3-BN-(+shortcut)-ReLU (resnet_s.py:48-77); BN+ReLU and BN+add+ReLU fused."""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1, option="A"):
+        super().__init__()
+        self.conv1 = Conv2d(in_planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != planes:
+            if option == "A":
+                self.shortcut = _PadShortcut(planes)
+            else:
+                self.shortcut = nn.Sequential(
+                    Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=stride, bias=False),
+                    BatchNorm2d(self.expansion * planes))
+
+    def forward(self, x):
+        x = _to_compute(x, self.conv1.compute_dtype)
+        out = self.bn1.fused(self.conv1(x), None, True)
+        out = self.conv2(out)
+        return self.bn2.fused(out, self.shortcut(x), True)
+
+
+class _HeadPool(nn.AdaptiveAvgPool2d):
+    """Global average pool; accumulates and returns fp32 (the classifier head runs in fp32)."""
+
+    def forward(self, x):
+        return x.float().mean(dim=(2, 3), keepdim=True)
+
+
+class ResNet(nn.Module):
+    """Flat-Sequential ResNet with the slice protocol.  `widths`/`option` generalise the reference class
+    (16-32-64, option A) to the build-defined ResNet-18-CIFAR (64-128-256-512, option B)."""
+
+    def __init__(self, block, num_blocks, num_classes=10, init_weight=1, widths=(16, 32, 64), option="A"):
+        super().__init__()
+        self.all_layers = 9
+        layers = [NormalizeByChannelMeanStd(mean=[0.4914, 0.4822, 0.4465], std=[0.2470, 0.2435, 0.2616]),
+                  Conv2d(3, widths[0], kernel_size=3, stride=1, padding=1, bias=False),
+                  BatchNorm2d(widths[0]), nn.ReLU()]
+        in_planes = widths[0]
+        for stage, (planes, nb) in enumerate(zip(widths, num_blocks)):
+            for b in range(nb):
+                layers.append(block(in_planes, planes, 2 if (stage > 0 and b == 0) else 1, option))
+                in_planes = planes * block.expansion
+        layers += [_HeadPool((1, 1)), nn.Flatten(), nn.Linear(in_planes, num_classes)]
+        self.sequential_model = nn.Sequential(*layers)
+        self.w = nn.Parameter(torch.full((self.all_layers,), float(init_weight)), requires_grad=True)
+        for m in self.modules():  # same leaf order as resnet_s.py:116 `self.apply(_weights_init)`
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight)
+        self.compute_dtype = torch.float32
+
+    @property
+    def layer_number(self):
+        return len(self.sequential_model)
+
+    def set_compute_dtype(self, dtype):
+        """fp32 (parity mode) or bf16 (MFMA convs, bf16 activations, fp32 statistics / master weights)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.compute_dtype = dtype
+            elif isinstance(m, NormalizeByChannelMeanStd):
+                m.out_dtype = dtype
+        return self
+
+    def forward(self, x, end_point=34, start_point=0):
+        layers = list(self.sequential_model[start_point:end_point])
+        i, n = 0, len(layers)
+        while i < n:
+            L = layers[i]
+            if isinstance(L, BatchNorm2d):
+                x = _to_compute(x, self.compute_dtype)
+                if i + 1 < n and isinstance(layers[i + 1], nn.ReLU):
+                    x = L.fused(x, None, True)
+                    i += 2
+                    continue
+                x = L.fused(x)
+            elif isinstance(L, nn.Linear):
+                x = L(x.float())
+            else:
+                x = L(x)
+            i += 1
+        return x
+
+
+def resnet20(init_weight_eta=1):
+    return ResNet(BasicBlock, [3, 3, 3], init_weight=init_weight_eta)
+
+
+def resnet56(init_weight_eta=1):  # resnet_s.py:123-124
+    return ResNet(BasicBlock, [9, 9, 9], init_weight=init_weight_eta)
+
+
+def resnet18(init_weight_eta=1, num_classes=10):
+    return ResNet(BasicBlock, [2, 2, 2, 2], num_classes=num_classes, init_weight=init_weight_eta,
+                  widths=(64, 128, 256, 512), option="B")
+
+
+# name -> (constructor, default --perturb_idx): end of stage 1 in each flat index map
+ARCHS = {"resnet20s": (resnet20, 7), "resnet56s": (resnet56, 13), "resnet18": (resnet18, 6)}

@@ -1,0 +1,159 @@
+"""The A-FAN joint training step (Classification/main_perturb.py:165-209), one process per MI355X.
+
+    head fwd (detached) -> K-step feature PGD -> [norms fused in the last PGD step, kept on device]
+    -> adv tail fwd + clean full fwd -> (CE_adv + CE_clean)/2 -> backward -> SGD
+
+Order of the forwards, train-mode BN side effects (head BN: 2 updates, tail BN: K+2 updates per
+iteration) and the optimizer semantics follow the reference line by line; what changes is
+execution: no host synchronisation inside the step (the reference copies the whole perturbation to the
+host every iteration, main_perturb.py:190, and calls .item() twice, :208-209), fused HIP kernels for
+everything that is not a convolution, one fused SGD launch over the parameter arena, and — with
+world_size > 1 — a chunked RCCL all-reduce of the flat gradient arena that overlaps the rest of the
+backward (data parallel: the PGD loop itself needs no communication).
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .arena import ArenaSGD, ParamArena
+from .attack_algo import PGD, last_norms
+
+
+def warmup_lr(step, optimizer, warm_up_steps=200, max_lr=0.1):
+    """main_perturb.py:288-293."""
+    lr = step * max_lr / (warm_up_steps - 1)
+    lr = min(lr, max_lr)
+    for p in optimizer.param_groups:
+        p["lr"] = lr
+    return lr
+
+
+class GradAllReducer:
+    """Chunked all-reduce (SUM; the 1/world factor is folded into afan_sgd_step's grad_scale) of the flat
+    gradient arena on a side stream.  A chunk is launched as soon as autograd has accumulated the gradient
+    of the chunk's FIRST parameter (the last one the backward reaches), so the exchange of the deep layers
+    overlaps the backward of the shallow ones.  Few, large, contiguous messages: xGMI links are
+    point-to-point (~153 GB/s each), per-message latency matters more than on a switch."""
+
+    def __init__(self, arena, n_chunks=4, group=None):
+        self.arena, self.group = arena, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.chunks = _cut_chunks(arena, n_chunks)
+        self.on_cuda = arena.grad.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=arena.grad.device) if self.on_cuda else None
+        self._pending = []
+        self._hooks = []
+        self._need, self._done = [], []
+        if self.world > 1:
+            # a chunk is ready when EVERY parameter in it has its final gradient (head parameters finish during the
+            # clean pass, tail parameters only after the adv pass too), so count completions per chunk.
+            bounds = arena.offsets + [arena.numel]
+            for ci, (start, end, first_param) in enumerate(self.chunks):
+                members = [i for i in range(len(arena.params)) if start <= bounds[i] < end]
+                self._need.append(len(members))
+                self._done.append(0)
+                for i in members:
+                    self._hooks.append(arena.params[i].register_post_accumulate_grad_hook(self._make_hook(ci)))
+
+    enabled = False
+
+    def _make_hook(self, ci):
+        def hook(_param):
+            if not self.enabled:
+                return
+            self._done[ci] += 1
+            if self._done[ci] == self._need[ci]:
+                start, end, _ = self.chunks[ci]
+                self._launch(start, end)
+        return hook
+
+    def begin(self):
+        self.enabled = True
+        self._done = [0] * len(self.chunks)
+
+    def _launch(self, start, end):
+        buf = self.arena.grad[start:end]
+        if self.on_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(buf.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(w)
+
+    def finish(self):
+        self.enabled = False
+        for ci, (start, end, _) in enumerate(self.chunks):  # parameters that got no gradient this step
+            if self._done[ci] < self._need[ci]:
+                self._launch(start, end)
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+        if self.on_cuda:
+            torch.cuda.current_stream(self.arena.grad.device).wait_stream(self.stream)
+
+
+def _cut_chunks(arena, n_chunks):
+    """[start, end, first_param_index) ranges cut at tensor boundaries, roughly equal in size."""
+    bounds = arena.offsets + [arena.numel]
+    target = arena.numel / max(n_chunks, 1)
+    cuts, end = [], arena.numel
+    for i in range(len(arena.offsets) - 1, -1, -1):
+        if end - bounds[i] >= target or i == 0:
+            cuts.append((bounds[i], end, i))
+            end = bounds[i]
+    return cuts
+
+
+class AfanTrainer:
+    """Owns the arena, the optimizer and the per-step schedule of one rank."""
+
+    def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
+                 randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
+                 group=None):
+        self.model, self.criterion = model, criterion
+        self.steps, self.gamma, self.eps = steps, gamma, eps
+        self.perturb_idx = perturb_idx
+        self.layer_number = layer_number if layer_number is not None else model.layer_number
+        self.randinit, self.clip = randinit, clip
+        self.arena = ParamArena(model)
+        self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer = GradAllReducer(self.arena, allreduce_chunks, group) if self.world > 1 else None
+        if self.world > 1:
+            self.optimizer.grad_scale = 1.0 / self.world
+
+    def step(self, inp, target):
+        """One iteration. Returns device tensors only: loss, loss_adv, loss_clean, prec1, l2[N], linf[N]."""
+        m, idx, ln = self.model, self.perturb_idx, self.layer_number
+        with torch.no_grad():  # main_perturb.py:173 (.detach()): values and BN side effects are identical
+            feature_map = m(inp, end_point=idx, start_point=0)
+        feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
+        feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
+                              gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
+                              randinit=self.randinit, clip=self.clip, with_norms=True)
+        l2, linf = last_norms()
+        # The reference feeds the requires_grad leaf itself and so also computes a never-used d(loss)/d(x_adv)
+        # (SURVEY.md §9.7); feeding the detached tensor (its bf16 shadow on the bf16 path) is parity-neutral.
+        adv_in = getattr(feature_map_adv, "_afan_shadow", None)
+        if adv_in is None:
+            adv_in = feature_map_adv.detach()
+        output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
+        output_clean = m(inp, end_point=ln, start_point=0)                   # main_perturb.py:196
+        loss_adv = self.criterion(output_adv, target)
+        loss_clean = self.criterion(output_clean, target)
+        loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
+        self.optimizer.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        with torch.no_grad():
+            prec1 = (output_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
+        return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
+                "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
+                "feature_map": feature_map, "out_clean": output_clean.detach()}

@@ -1,0 +1,164 @@
+/*
+ * afan_hip.h — C-ABI of libafan_hip.so: the MI355X (gfx950) kernels of the A-FAN hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + an explicit HIP stream,
+ * allocates nothing, never synchronises, is re-entrant and hipGraph-capturable.  Return value:
+ * 0 on success, a positive hipError_t if the launch failed, or a negative AFAN_E* argument error.
+ *
+ * The reference (VITA-Group/CV_A-FAN) is Python on PyTorch; the interfaces these symbols replace are
+ * cited per function as `path:line` relative to the reference root.  The ctypes binding a reference
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Layout contract: all activation tensors are dense, contiguous NCHW (the reference's layout,
+ * Classification/resnet_s.py:119-121); `hw` = H*W, one (n,c) plane is `hw` consecutive elements.
+ */
+#ifndef AFAN_HIP_H
+#define AFAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* stream handle: a hipStream_t passed as an opaque pointer (0 = the null stream) */
+typedef void* afan_stream_t;
+
+/* element types of activation / gradient buffers */
+enum { AFAN_F32 = 0, AFAN_BF16 = 1 };
+
+/* argument errors (negative so they never collide with hipError_t) */
+enum {
+    AFAN_OK = 0,
+    AFAN_EDTYPE = -1,  /* unknown dtype code */
+    AFAN_EALIGN = -2,  /* pointer not aligned to its element type */
+    AFAN_ESHAPE = -3,  /* non-positive / inconsistent sizes */
+    AFAN_ENULL = -4    /* required pointer is NULL */
+};
+
+/* Library identification: version = 10000*major + 100*minor + patch; arch string is "gfx950". */
+int afan_version(void);
+const char* afan_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * PGD ascent step.  Replaces Classification/attack_algo.py:53 (+ :55-56 → :35-36 → :9-19 when clip).
+ *   x_adv[i] <- fl32(x_adv[i] + fl32(gamma) * sign(grad[i]))            sign(0)=0, sign(NaN)=NaN
+ *   if clip:  lo = fl32(x_clean[i]-eps), hi = fl32(x_clean[i]+eps); t<lo -> lo; then t>hi -> hi
+ * x_adv: fp32, updated in place.  grad: `grad_dtype` (fp32 or bf16 — only its sign is used).
+ * x_clean: fp32, required iff clip != 0.  shadow_bf16: optional (may be NULL) bf16 copy of the new
+ * x_adv written in the same pass (the tail's conv input when the backbone runs in bf16).
+ * Algorithmic HBM bytes: 12 B/elt (fp32 grad), 16 B/elt with clip; +2 with the bf16 shadow.
+ */
+int afan_pgd_step(float* x_adv, const void* grad, int grad_dtype, const float* x_clean,
+                  uint16_t* shadow_bf16, int64_t n, float gamma, float eps, int clip,
+                  afan_stream_t stream);
+
+/* tensor_clamp with arbitrary bound tensors.  Replaces Classification/attack_algo.py:9-19 (in place:
+ * t<lo -> lo, then t>hi -> hi; NaN passes through).  linfball_proj (:35-36) is afan_pgd_step with gamma=0. */
+int afan_tensor_clamp(float* t, const float* lo, const float* hi, int64_t n, afan_stream_t stream);
+
+/* Last PGD step fused with the perturbation norms.  Replaces attack_algo.py:53-56 plus
+ * Classification/main_perturb.py:188-192 (per-sample ||x_adv-x||_2 and ||.||_inf over C*H*W, which
+ * the reference computes on the host after a full-tensor D2H copy).
+ * batch*per_sample elements; x_clean is always required (it is the norm's centre).
+ * partial: workspace of afan_norms_workspace_floats(batch, per_sample) floats.
+ * l2_out/linf_out: [batch] fp32.  Deterministic (no float atomics): two launches on `stream`.
+ */
+int64_t afan_norms_workspace_floats(int64_t batch, int64_t per_sample);
+int afan_pgd_step_norms(float* x_adv, const void* grad, int grad_dtype, const float* x_clean,
+                        uint16_t* shadow_bf16, int64_t batch, int64_t per_sample, float gamma,
+                        float eps, int clip, float* partial, float* l2_out, float* linf_out,
+                        afan_stream_t stream);
+
+/* Stand-alone perturbation norms (main_perturb.py:188-192) for callers that run 0 PGD steps. */
+int afan_perturb_norms(const float* x_adv, const float* x_clean, int64_t batch, int64_t per_sample,
+                       float* partial, float* l2_out, float* linf_out, afan_stream_t stream);
+
+/* Random start.  Replaces attack_algo.py:42-44:  x_adv += (2.0*u - 1.0) * eps  with u ~ U[0,1) drawn by
+ * the caller on the HOST generator (the reference draws it on the CPU, so parity needs the host's
+ * stream of numbers) and uploaded to `u`.  Rounding: fl(fl(fl(2u)-1)*eps) then one add, no FMA.
+ */
+int afan_axpy_noise(float* x_adv, const float* u, int64_t n, float eps, uint16_t* shadow_bf16,
+                    afan_stream_t stream);
+
+/* mix_feature.  Replaces Segmentation/attack_algo.py:121-130 == Detection/attack_algo.py:254-265:
+ * per (n,h,w): mean and unbiased variance over the C channels of clean and adv;
+ *   out = (clean - mean_c) / sqrt(var_c + 1e-5) * sqrt(var_a + 1e-5) + mean_a
+ * clean/adv/out: [N, C, HW] of `dtype`.  eps is the 1e-5 above.  Algorithmic bytes 12 B/elt (fp32).
+ */
+int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw,
+                     float eps, int dtype, afan_stream_t stream);
+
+/* SAT sample points.  Replaces Segmentation/attack_algo.py:108-118 (torch.lerp semantics:
+ * w<0.5: x + w*(y-x); else y - (y-x)*(1-w)).  Writes the n_points-2 interior points, point k (1-based)
+ * at out + (k-1)*n elements, weight k*(1/(n_points-1)) computed as the reference does in double and
+ * rounded to fp32 by the caller into `weights`[n_points-2] (host array, read at launch time).
+ */
+int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, const float* weights,
+                     int n_interior, afan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm, training mode (per-channel moments over N*HW) — the "feature-norm stats" the backbone
+ * runs K+2 times per iteration in the tail and twice in the head (main_perturb.py:173,195-196 through
+ * torch.nn.BatchNorm2d in resnet_s.py:52-55,88).
+ *
+ * afan_bn_stats: partial (count, mean, M2) per (channel, slice) then a finalize launch producing
+ *   mean[C], invstd[C] = 1/sqrt(var_biased + eps) and, if running_mean != NULL, the running-stat
+ *   update  r <- (1-momentum)*r + momentum*batch  with the UNBIASED variance, and ++(*num_batches).
+ * workspace: afan_bn_workspace_floats(c) floats.
+ */
+int64_t afan_bn_workspace_floats(int64_t c);
+int afan_bn_stats(const void* x, int dtype, int64_t n, int64_t c, int64_t hw, float eps,
+                  float momentum, float* workspace, float* mean, float* invstd, float* running_mean,
+                  float* running_var, int64_t* num_batches, afan_stream_t stream);
+
+/* Fused training forward: stats launch + (fold, normalise, affine, [+residual], [ReLU]) launch.
+ *   y = [relu]( (x-mean)*invstd*weight + bias [+ residual] )
+ * Saves mean/invstd for the backward, updates running stats (if given) and ++(*num_batches).
+ * x,y,residual: `dtype` [N,C,HW]; weight/bias (nullable = 1/0) and all statistics fp32 [C]. */
+int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
+                          int64_t hw, float eps, float momentum, const float* weight, const float* bias,
+                          int relu, float* workspace, float* save_mean, float* save_invstd,
+                          float* running_mean, float* running_var, int64_t* num_batches,
+                          afan_stream_t stream);
+
+/* Same transform with GIVEN statistics (eval mode: mean = running_mean, invstd = rsqrt(running_var+eps)). */
+int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
+                  int64_t hw, const float* mean, const float* invstd, const float* weight,
+                  const float* bias, int relu, afan_stream_t stream);
+
+/* Backward of the fused training forward (two launches, same (slice, channel) mapping).
+ *   g   = dy * (act > 0) when relu, else dy;  act = y if y != NULL, else recomputed from x (no residual)
+ *   sum_g[c] = sum g ;  sum_gx[c] = sum g * xhat ;  M = N*HW
+ *   dx  = weight*invstd * ( g - sum_g/M - xhat*sum_gx/M )
+ *   d_residual = g (written iff d_residual != NULL; may alias dy)
+ * dweight[c] = sum_gx[c], dbias[c] = sum_g[c] (added into them iff accumulate != 0; NULL skips them —
+ * the PGD inner loop only needs dx: attack_algo.py:52 `only_inputs=True`). */
+int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual,
+                     int dtype, int64_t n, int64_t c, int64_t hw, const float* mean,
+                     const float* invstd, const float* weight, const float* bias, int relu,
+                     float* workspace, float* dweight, float* dbias, int accumulate,
+                     afan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SGD with momentum over ONE flat parameter arena.  Replaces torch.optim.SGD.step as configured at
+ * main_perturb.py:72-74 (momentum, weight_decay, no nesterov/dampening) on every tensor at once:
+ *   g' = g + wd*p ;  buf = first ? g' : momentum*buf + g' ;  p -= lr*buf
+ * lr is read from DEVICE memory (warm-up changes it every step, main_perturb.py:288-293, and the
+ * step may be replayed from a hipGraph).  grad_scale multiplies g first (1/world_size after a sum
+ * all-reduce).  shadow_bf16 (nullable): bf16 copy of the updated parameters for the bf16 backbone.
+ */
+int afan_sgd_step(float* param, const float* grad, float* momentum_buf, uint16_t* shadow_bf16,
+                  int64_t n, const float* lr_dev, float momentum, float weight_decay,
+                  float grad_scale, int first_step, afan_stream_t stream);
+
+/* fp32 -> bf16 (round-to-nearest-even, NaN-preserving) and per-channel input normalisation
+ * (resnet_s.py:87: (x - mean[c]) / std[c]), used on the bf16 path. */
+int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t stream);
+int afan_normalize_nchw(const float* x, void* y, int out_dtype, int64_t n, int64_t c, int64_t hw,
+                        const float* mean, const float* std, afan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFAN_HIP_H */

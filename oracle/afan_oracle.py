@@ -1,0 +1,269 @@
+"""CPU ORACLE for the A-FAN hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this file; the shipped
+package (cv_a-fan_amd/) never does.  It restates, in plain torch-CPU fp32 ops, what the reference
+(VITA-Group/CV_A-FAN) computes on the path BASELINE.json names, each function citing the reference
+file:line it follows (paths relative to the reference root).
+
+Parity status: PINNED.  The reference's own tests hold nothing for this path (its only
+test is Detection NMS), so the pin is `oracle/gen_golden.py`: it imports the reference's
+Classification/{attack_algo,resnet_s}.py and Segmentation/attack_algo.py in the build container, runs
+fixed-seed cases and stores inputs + outputs under tests/golden/*.npz; tests/test_oracle_golden.py
+checks every function below against those vectors bit for bit (CPU fp32 is run-to-run deterministic).
+The conv / BN / CE / SGD arithmetic itself lives in PyTorch (a third-party dependency of the reference,
+README.md:39 pins torch 1.5.0; this image has 2.10.0) — parity is against this image's torch CPU kernels.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# model protocol: model(x, end_point, start_point) == sequential_model[start_point:end_point](x)
+# --------------------------------------------------------------------------------------------------
+class ChannelNormalize(nn.Module):
+    """advertorch.utils.NormalizeByChannelMeanStd as used at Classification/resnet_s.py:87:
+    buffers `mean`, `std`; (x - mean[None,:,None,None]) / std[None,:,None,None]."""
+
+    def __init__(self, mean, std):
+        super().__init__()
+        self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32))
+        self.register_buffer("std", torch.tensor(std, dtype=torch.float32))
+
+    def forward(self, t):
+        return (t - self.mean[None, :, None, None]) / self.std[None, :, None, None]
+
+
+class _PadShortcut(nn.Module):
+    """Option-A shortcut, Classification/resnet_s.py:64-65: subsample by 2, zero-pad planes//4 channels each side."""
+
+    def __init__(self, planes):
+        super().__init__()
+        self.pad = planes // 4
+
+    def forward(self, t):
+        return F.pad(t[:, :, ::2, ::2], (0, 0, 0, 0, self.pad, self.pad), "constant", 0)
+
+
+class Block(nn.Module):
+    """BasicBlock, Classification/resnet_s.py:48-77 (option 'A' pad shortcut or 'B' 1x1 conv + BN)."""
+
+    def __init__(self, cin, cout, stride, option):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or cin != cout:
+            if option == "A":
+                self.shortcut = _PadShortcut(cout)
+            else:
+                self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, t):
+        o = F.relu(self.bn1(self.conv1(t)))
+        o = self.bn2(self.conv2(o))
+        o += self.shortcut(t)  # resnet_s.py:75 (in-place add, then relu)
+        return F.relu(o)
+
+
+class SlicedResNet(nn.Module):
+    """Flat nn.Sequential ResNet with the slice-forward protocol of Classification/resnet_s.py:79-121.
+    widths/blocks/option select ResNet-20s/56s (16-32-64, option A: the reference's class) or the
+    build-defined ResNet-18-CIFAR (64-128-256-512, option B; SURVEY.md warning 3).  State-dict keys match the
+    reference's (`w`, `sequential_model.<i>...`)."""
+
+    def __init__(self, widths, blocks, option, num_classes=10, init_weight=1):
+        super().__init__()
+        layers = [ChannelNormalize([0.4914, 0.4822, 0.4465], [0.2470, 0.2435, 0.2616]),
+                  nn.Conv2d(3, widths[0], 3, 1, 1, bias=False), nn.BatchNorm2d(widths[0]), nn.ReLU()]
+        cin = widths[0]
+        for si, (wd, nb) in enumerate(zip(widths, blocks)):
+            for bi in range(nb):
+                layers.append(Block(cin, wd, 2 if (bi == 0 and si > 0) else 1, option))
+                cin = wd
+        layers += [nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(cin, num_classes)]
+        self.sequential_model = nn.Sequential(*layers)
+        self.all_layers = 9
+        self.w = nn.Parameter(torch.full((self.all_layers,), float(init_weight)))  # resnet_s.py:113-114
+        for m in self.modules():  # resnet_s.py:34-38 via self.apply(_weights_init): module traversal order
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x, end_point=None, start_point=0):
+        if end_point is None:
+            end_point = len(self.sequential_model)
+        return self.sequential_model[start_point:end_point](x)
+
+
+def resnet20s():
+    return SlicedResNet([16, 32, 64], [3, 3, 3], "A")
+
+
+def resnet56s():  # Classification/resnet_s.py:123-124
+    return SlicedResNet([16, 32, 64], [9, 9, 9], "A")
+
+
+def resnet18_cifar():
+    return SlicedResNet([64, 128, 256, 512], [2, 2, 2, 2], "B")
+
+
+ARCHS = {"resnet20s": (resnet20s, 7), "resnet56s": (resnet56s, 13), "resnet18": (resnet18_cifar, 6)}
+
+
+# --------------------------------------------------------------------------------------------------
+# operators
+# --------------------------------------------------------------------------------------------------
+def tensor_clamp_(t, lo, hi):
+    """Classification/attack_algo.py:9-19: lower clamp first, then upper; NaN passes through."""
+    t.copy_(torch.where(t < lo, lo, t))
+    t.copy_(torch.where(t > hi, hi, t))
+    return t
+
+
+def linf_project_(center, radius, t):
+    """Classification/attack_algo.py:35-36: the two bounds are materialised (one rounding each) first."""
+    return tensor_clamp_(t, center - radius, center + radius)
+
+
+def pgd_step_(x_adv, grad, gamma, x_clean=None, eps=0.0, clip=False):
+    """One iteration body of Classification/attack_algo.py:53-56 given the gradient."""
+    x_adv.add_(gamma * torch.sign(grad))
+    if clip:
+        linf_project_(x_clean, eps, x_adv)
+    return x_adv
+
+
+def randinit_(x_adv, eps, u=None):
+    """Classification/attack_algo.py:42-44; `u` = torch.rand(x_adv.shape) from the CPU default generator."""
+    if u is None:
+        u = torch.rand(x_adv.shape)
+    x_adv += (2.0 * u - 1.0) * eps
+    return x_adv
+
+
+def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_number=16, eps=(2 / 255),
+        randinit=False, clip=False, trace=None):
+    """Classification/attack_algo.py:38-58 restated; `trace` (list) collects (grad, x_adv) per step."""
+    x_adv = x.clone()
+    if randinit:
+        randinit_(x_adv, eps)
+    x_adv.requires_grad_(True)
+    for _ in range(steps):
+        out = model(x_adv, end_point=layer_number, start_point=start_idx)
+        loss = loss_fn(out, y)
+        g = torch.autograd.grad(loss, x_adv, only_inputs=True)[0]
+        with torch.no_grad():
+            pgd_step_(x_adv.data, g.data, gamma, x, eps, clip)
+        if trace is not None:
+            trace.append((g.detach().clone(), x_adv.detach().clone()))
+    return x_adv
+
+
+def perturb_norms(x_adv, x):
+    """Classification/main_perturb.py:188-192: per-sample L2 and Linf of the perturbation."""
+    d = (x_adv - x).clone().detach().reshape(x.shape[0], -1)
+    return torch.norm(d, p=2, dim=1), torch.norm(d, p=float("inf"), dim=1)
+
+
+def mix_feature(clean, adv, eps=1e-5):
+    """Segmentation/attack_algo.py:121-130 (== Detection/attack_algo.py:254-265)."""
+    mc = clean.mean(dim=1, keepdim=True)
+    sc = (clean.var(dim=1, keepdim=True) + eps).sqrt()
+    ma = adv.mean(dim=1, keepdim=True)
+    sa = (adv.var(dim=1, keepdim=True) + eps).sqrt()
+    return (clean - mc) / sc * sa + ma
+
+
+def get_sample_points(px, py, number):
+    """Segmentation/attack_algo.py:108-118."""
+    percent = 1.0 / (number - 1)
+    pts = [px]
+    for i in range(1, number - 1):
+        pts.append(torch.lerp(px, py, i * percent))
+    pts.append(py)
+    return pts
+
+
+# --------------------------------------------------------------------------------------------------
+# training step (Classification/main_perturb.py:165-209) and its schedule helpers
+# --------------------------------------------------------------------------------------------------
+def setup_seed(seed):
+    """Classification/main_perturb.py:310-315."""
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def warmup_lr(step, optimizer, warm_up_steps, max_lr):
+    """Classification/main_perturb.py:288-293."""
+    lr = min(step * max_lr / (warm_up_steps - 1), max_lr)
+    for g in optimizer.param_groups:
+        g["lr"] = lr
+    return lr
+
+
+def make_optimizer(model, lr=0.1, momentum=0.9, weight_decay=5e-4):
+    """Classification/main_perturb.py:72-74."""
+    return torch.optim.SGD(model.parameters(), lr, momentum=momentum, weight_decay=weight_decay)
+
+
+def afan_train_step(model, optimizer, criterion, inp, target, *, steps, gamma, eps, perturb_idx, layer_number,
+                    randinit=False, clip=False):
+    """One iteration of Classification/main_perturb.py:173-201 (model already in train mode).
+    gamma/eps are the raw flags (divided by 255 here, lines 180/183). Returns a dict of observables."""
+    feature_map = model(inp, end_point=perturb_idx, start_point=0).detach()
+    feature_map_adv = PGD(feature_map, criterion, y=target, model=model, steps=steps, gamma=gamma / 255,
+                          start_idx=perturb_idx, layer_number=layer_number, eps=eps / 255, randinit=randinit,
+                          clip=clip)
+    l2, linf = perturb_norms(feature_map_adv, feature_map)
+    out_adv = model(feature_map_adv, end_point=layer_number, start_point=perturb_idx)
+    out_clean = model(inp, end_point=layer_number, start_point=0)
+    loss_adv = criterion(out_adv, target)
+    loss_clean = criterion(out_clean, target)
+    loss = (loss_adv + loss_clean) / 2
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    prec1 = (out_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
+    return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
+            "l2": l2, "linf": linf, "prec1": prec1, "x_adv": feature_map_adv.detach(),
+            "feature_map": feature_map, "out_clean": out_clean.detach()}
+
+
+def sharded_train_step(model, optimizer, criterion, inp, target, world, **kw):
+    """N-GPU data-parallel emulation: each rank runs the step on its shard with per-shard BN
+    statistics from the SAME starting weights, parameter gradients are averaged, one SGD update is applied.
+    BN buffers of rank 0 persist (mirrors nn.DataParallel's replica-0 rule)."""
+    import copy
+    n = inp.shape[0] // world
+    grads, outs, buffers0 = None, [], None
+    state0 = copy.deepcopy(model.state_dict())
+    for r in range(world):
+        model.load_state_dict(state0)
+        xs, ys = inp[r * n:(r + 1) * n], target[r * n:(r + 1) * n]
+        fm = model(xs, end_point=kw["perturb_idx"], start_point=0).detach()
+        fa = PGD(fm, criterion, y=ys, model=model, steps=kw["steps"], gamma=kw["gamma"] / 255,
+                 start_idx=kw["perturb_idx"], layer_number=kw["layer_number"], eps=kw["eps"] / 255,
+                 randinit=False, clip=kw.get("clip", False))
+        oa = model(fa, end_point=kw["layer_number"], start_point=kw["perturb_idx"])
+        oc = model(xs, end_point=kw["layer_number"], start_point=0)
+        loss = (criterion(oa, ys) + criterion(oc, ys)) / 2
+        optimizer.zero_grad()
+        loss.backward()
+        g = [None if p.grad is None else p.grad.detach().clone() for p in model.parameters()]
+        grads = g if grads is None else [a if b is None else a + b for a, b in zip(grads, g)]
+        outs.append(loss.detach())
+        if r == 0:
+            buffers0 = {k: v.clone() for k, v in model.named_buffers()}
+    for p, g in zip(model.parameters(), grads):
+        p.grad = None if g is None else g / world
+    for k, v in model.named_buffers():
+        v.copy_(buffers0[k])
+    optimizer.step()
+    return torch.stack(outs)

@@ -1,0 +1,254 @@
+"""Golden-vector generator — runs ONLY in the build container, where /root/reference exists.
+
+It imports the reference's own Python (Classification/attack_algo.py, Classification/resnet_s.py,
+Segmentation/attack_algo.py) with two arithmetic-neutral shims:
+  1. a stand-in for `advertorch.utils.NormalizeByChannelMeanStd` (absent from the image; 3-line formula),
+  2. `.cuda()` -> identity, because Classification/attack_algo.py:44-46 hard-codes it,
+runs fixed-seed cases through the REFERENCE functions and writes inputs + outputs to tests/golden/*.npz.
+Only those arrays travel to the GPU box; no reference source does.  `main_perturb.py` itself cannot be
+imported (top-level torchvision/matplotlib imports, main_perturb.py:15-23), so its loop body (lines
+173-201, 288-293) is driven here line by line around the reference's PGD and ResNet.
+
+Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("AFAN_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def _shims():
+    class NormalizeByChannelMeanStd(nn.Module):
+        def __init__(self, mean, std):
+            super().__init__()
+            self.register_buffer("mean", torch.tensor(mean))
+            self.register_buffer("std", torch.tensor(std))
+
+        def forward(self, t):
+            return (t - self.mean[None, :, None, None]) / self.std[None, :, None, None]
+
+    adv = types.ModuleType("advertorch")
+    adv_utils = types.ModuleType("advertorch.utils")
+    adv_utils.NormalizeByChannelMeanStd = NormalizeByChannelMeanStd
+    adv.utils = adv_utils
+    sys.modules["advertorch"] = adv
+    sys.modules["advertorch.utils"] = adv_utils
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()  # copy: live parameters are updated in place by the SGD step
+
+
+def _state_np(model, prefix="sd/"):
+    return {prefix + k: _np(v) for k, v in model.state_dict().items()}
+
+
+def _checksums(model):
+    """per-tensor (sum, abs-sum) in float64 — a compact fingerprint of the whole state_dict"""
+    keys = list(model.state_dict().keys())
+    vals = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in model.state_dict().values()])
+    return keys, vals
+
+
+def _ref_step(ref_attack, model, optimizer, criterion, inp, target, steps, gamma, eps, idx, layer_number,
+              randinit, clip):
+    """Classification/main_perturb.py:173-201, the reference's PGD and model called exactly as there."""
+    feature_map = model(inp, end_point=idx, start_point=0).detach()
+    feature_map_adv = ref_attack.PGD(feature_map, criterion, y=target, model=model, steps=steps,
+                                     gamma=(gamma / 255), start_idx=idx, layer_number=layer_number,
+                                     eps=(eps / 255), randinit=randinit, clip=clip)
+    batch_size = inp.shape[0]
+    perturbation = (feature_map_adv - feature_map).clone()
+    perturbation = perturbation.detach().cpu().reshape(batch_size, -1)
+    l2 = torch.norm(perturbation, p=2, dim=1)
+    linf = torch.norm(perturbation, p=float("inf"), dim=1)
+    output_adv = model(feature_map_adv, end_point=layer_number, start_point=idx)
+    output_clean = model(inp, end_point=layer_number, start_point=0)
+    loss_adv = criterion(output_adv, target)
+    loss_clean = criterion(output_clean, target)
+    loss = (loss_adv + loss_clean) / 2
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return dict(feature_map=feature_map, x_adv=feature_map_adv.detach(), l2=l2, linf=linf, loss=loss.detach(),
+                loss_adv=loss_adv.detach(), loss_clean=loss_clean.detach(), out_clean=output_clean.detach())
+
+
+def _pgd_trace(ref_attack, model, criterion, fm, target, steps, gamma, eps, idx, layer_number, clip):
+    """Per-step gradients of the reference PGD (no randinit): re-run it with steps=1..K from identical model
+    buffers is not possible (BN running stats move), so instead wrap the model to record what PGD feeds it and
+    derive grads from consecutive x_adv snapshots.  Returns list of x_adv inputs seen by the tail forward."""
+    seen = []
+
+    class Spy(nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, end_point=None, start_point=0):
+            seen.append(x.detach().clone())
+            return self.m(x, end_point=end_point, start_point=start_point)
+
+    out = ref_attack.PGD(fm, criterion, y=target, model=Spy(model), steps=steps, gamma=gamma / 255,
+                         start_idx=idx, layer_number=layer_number, eps=eps / 255, randinit=False, clip=clip)
+    seen.append(out.detach().clone())
+    return seen  # K+1 snapshots: x_adv before step 0 ... after step K-1
+
+
+def main():
+    assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+    _shims()
+    os.makedirs(OUT, exist_ok=True)
+    ref_attack = _load("ref_cls_attack_algo", "Classification/attack_algo.py")
+    ref_resnet = _load("ref_cls_resnet_s", "Classification/resnet_s.py")
+    ref_seg = _load("ref_seg_attack_algo", "Segmentation/attack_algo.py")
+    from oracle import afan_oracle as orc  # only for the build-defined ResNet-18 module (no reference class exists)
+
+    crit = nn.CrossEntropyLoss()
+
+    def build(arch):
+        if arch == "resnet20s":
+            return ref_resnet.ResNet(ref_resnet.BasicBlock, [3, 3, 3]), 7, 16
+        if arch == "resnet56s":
+            return ref_resnet.resnet56(), 13, 34
+        if arch == "resnet18":
+            return orc.resnet18_cifar(), 6, 15
+        raise KeyError(arch)
+
+    # ---- single-step cases: reference PGD + joint step -------------------------------------------
+    cases = [
+        # name, arch, batch, K, gamma, eps, randinit, clip, store_weights
+        ("step_r20s_k1", "resnet20s", 4, 1, 0.5, 2.0, False, False, True),
+        ("step_r20s_k5", "resnet20s", 4, 5, 0.5, 2.0, False, False, False),
+        ("step_r20s_k5_clip", "resnet20s", 4, 5, 1.5, 2.0, False, True, False),
+        ("step_r20s_k3_clip_rand", "resnet20s", 4, 3, 1.5, 2.0, True, True, False),
+        ("step_r56s_k5", "resnet56s", 2, 5, 0.5, 2.0, False, False, False),
+        ("step_r18_k5", "resnet18", 2, 5, 0.5, 2.0, False, False, False),
+    ]
+    for name, arch, bs, K, gamma, eps, randinit, clip, store_w in cases:
+        torch.manual_seed(3)
+        model, idx, ln = build(arch)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+        x = torch.rand(bs, 3, 32, 32)
+        y = torch.randint(0, 10, (bs,))
+        rec = {"x": _np(x), "y": _np(y), "meta": np.array([K, idx, ln, int(randinit), int(clip)]),
+               "gamma_eps": np.array([gamma, eps], dtype=np.float64)}
+        if store_w:
+            rec.update(_state_np(model, "sd0/"))
+        k0, c0 = _checksums(model)
+        rec["ck0"] = c0
+        if randinit:
+            # the noise PGD draws is the next torch.rand(feature shape) of the CPU generator (attack_algo.py:44):
+            # peek it, then rewind the generator so the reference draws the same numbers.
+            model.eval()  # eval-mode probe: BN buffers untouched
+            with torch.no_grad():
+                fm_shape = model(x, end_point=idx, start_point=0).shape
+            model.train()
+            gstate = torch.get_rng_state()
+            rec["u"] = _np(torch.rand(fm_shape))
+            torch.set_rng_state(gstate)
+        r = _ref_step(ref_attack, model, opt, crit, x, y, K, gamma, eps, idx, ln, randinit, clip)
+        for k in ("feature_map", "x_adv", "l2", "linf", "loss", "loss_adv", "loss_clean", "out_clean"):
+            rec[k] = _np(r[k])
+        k1, c1 = _checksums(model)
+        assert k0 == k1
+        rec["keys"] = np.array(k1)
+        rec["ck1"] = c1
+        sd = model.state_dict()
+        for k in (f"sequential_model.2.running_mean", f"sequential_model.2.running_var",
+                  f"sequential_model.2.num_batches_tracked", f"sequential_model.{idx}.bn1.running_mean",
+                  f"sequential_model.{idx}.bn1.running_var", f"sequential_model.{idx}.bn1.num_batches_tracked",
+                  "sequential_model.1.weight", f"sequential_model.{ln - 1}.weight", f"sequential_model.{ln - 1}.bias"):
+            rec["sd1/" + k] = _np(sd[k])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+        print(name, "loss", float(r["loss"]), "l2", r["l2"].tolist())
+
+    # ---- per-step PGD trace (kernel-level golden: x_adv before/after every step, with its gradient) ----
+    for name, K, gamma, clip in (("pgd_trace_r20s_k3", 3, 0.5, False), ("pgd_trace_r20s_k3_clip", 3, 1.5, True)):
+        torch.manual_seed(3)
+        model, idx, ln = build("resnet20s")
+        model.train()
+        x = torch.rand(2, 3, 32, 32)
+        y = torch.randint(0, 10, (2,))
+        fm = model(x, end_point=idx, start_point=0).detach()
+        import copy
+        model_b = copy.deepcopy(model)
+        snaps = _pgd_trace(ref_attack, model, crit, fm, y, K, gamma, 2.0, idx, ln, clip)
+        # gradients the reference saw: recompute with an identical twin model fed the recorded inputs in order
+        grads = []
+        for t in range(K):
+            xin = snaps[t].clone().requires_grad_(True)
+            loss = crit(model_b(xin, end_point=ln, start_point=idx), y)
+            grads.append(torch.autograd.grad(loss, xin)[0])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), fm=_np(fm), y=_np(y),
+                            gamma_eps=np.array([gamma, 2.0]), clip=np.array(int(clip)),
+                            snaps=np.stack([_np(s) for s in snaps]), grads=np.stack([_np(g) for g in grads]))
+        print(name, "ok")
+
+    # ---- 3-iteration trajectory with warm-up lr (main_perturb.py:167-168,288-293) ----------------------
+    torch.manual_seed(3)
+    model, idx, ln = build("resnet20s")
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+    xs = torch.rand(3, 8, 3, 32, 32)
+    ys = torch.randint(0, 10, (3, 8))
+    wp = 5
+    losses, lrs = [], []
+    for i in range(3):
+        lr = min(i * 0.1 / (wp - 1), 0.1)  # main_perturb.py:288-293
+        for p in opt.param_groups:
+            p["lr"] = lr
+        lrs.append(lr)
+        r = _ref_step(ref_attack, model, opt, crit, xs[i], ys[i], 2, 0.5, 2.0, idx, ln, False, False)
+        losses.append(float(r["loss"]))
+    keys, ck = _checksums(model)
+    np.savez_compressed(os.path.join(OUT, "traj_r20s.npz"), xs=_np(xs), ys=_np(ys), losses=np.array(losses),
+                        lrs=np.array(lrs), ck=ck, keys=np.array(keys), wp=np.array(wp),
+                        fc_w=_np(model.state_dict()["sequential_model.15.weight"]))
+    print("traj", losses)
+
+    # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
+    torch.manual_seed(7)
+    rec = {}
+    for tag, shape in (("a", (2, 19, 7, 9)), ("b", (1, 304, 5, 5)), ("c", (3, 64, 1, 33))):
+        clean = torch.randn(shape) * 1.7 + 0.3
+        adv = clean + torch.randn(shape) * 0.2 + 0.05
+        rec[f"mix_{tag}_clean"] = _np(clean)
+        rec[f"mix_{tag}_adv"] = _np(adv)
+        rec[f"mix_{tag}_out"] = _np(ref_seg.mix_feature(clean, adv))
+        for n in (3, 5):
+            pts = ref_seg.get_sample_points(clean, adv, n)
+            rec[f"lerp_{tag}_{n}"] = np.stack([_np(p) for p in pts])
+    np.savez_compressed(os.path.join(OUT, "seg_ops.npz"), **rec)
+    print("seg_ops ok")
+
+    # ---- tensor_clamp / linfball_proj edge cases (reference functions, direct) ------------------------
+    t = torch.tensor([0.0, 1.0, -1.0, float("nan"), 5.0, -5.0, 0.5, 0.25], dtype=torch.float32)
+    c = torch.tensor([0.0, 0.0, 0.0, 0.0, 1.0, -1.0, float("nan"), 0.25], dtype=torch.float32)
+    out = ref_attack.linfball_proj(c, 0.5, t.clone(), in_place=True)
+    np.savez_compressed(os.path.join(OUT, "clamp_edges.npz"), t=_np(t), c=_np(c), radius=np.array(0.5, dtype=np.float32),
+                        out=_np(out))
+    print("clamp ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+import ctypes
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_pkg():
+    """The package directory is `cv_a-fan_amd` (hyphen): import it by string."""
+    return importlib.import_module("cv_a-fan_amd")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+_f = ctypes.c_float
+_l = ctypes.c_int64
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+
+
+def _c_oracle():
+    """ctypes handle of oracle/_ref/liboracle.so (the plain-C checker); built on demand with gcc."""
+    path = os.path.join(ROOT, "oracle", "_ref", "liboracle.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(path)
+    lib.oracle_pgd_step.argtypes = [_p, _p, _p, _l, _f, _f, _i]
+    lib.oracle_axpy_noise.argtypes = [_p, _p, _l, _f]
+    lib.oracle_perturb_norms.argtypes = [_p, _p, _l, _l, _p, _p]
+    lib.oracle_mix_feature.argtypes = [_p, _p, _p, _l, _l, _l, _f]
+    lib.oracle_lerp_points.argtypes = [_p, _p, _p, _l, _p, _i]
+    lib.oracle_bn_train_forward.argtypes = [_p, _p, _p, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p]
+    lib.oracle_bn_backward.argtypes = [_p, _p, _p, _p, _p, _l, _l, _l, _p, _p, _p, _i, _p, _p]
+    lib.oracle_sgd_step.argtypes = [_p, _p, _p, _l, _f, _f, _f, _f]
+    for n in ("oracle_pgd_step", "oracle_axpy_noise", "oracle_perturb_norms", "oracle_mix_feature",
+              "oracle_lerp_points", "oracle_bn_train_forward", "oracle_bn_backward", "oracle_sgd_step"):
+        getattr(lib, n).restype = None
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_p)
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    return _c_oracle()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import afan_oracle
+    return afan_oracle
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("test is marked gpu but no GPU is visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,150 @@
+"""The oracle (oracle/afan_oracle.py, oracle/afan_oracle.c) against the golden vectors produced by the
+reference's own Python (oracle/gen_golden.py).  CPU only; bit-exact unless stated."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import golden, ptr
+
+STEP_CASES = ["step_r20s_k1", "step_r20s_k5", "step_r20s_k5_clip", "step_r20s_k3_clip_rand", "step_r56s_k5",
+              "step_r18_k5"]
+ARCH = {"r20s": "resnet20s", "r56s": "resnet56s", "r18": "resnet18"}
+
+
+def _arch_of(case):
+    return ARCH[case.split("_")[1]]
+
+
+def _checks(model):
+    return np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in model.state_dict().values()])
+
+
+@pytest.mark.parametrize("case", STEP_CASES)
+def test_train_step_matches_reference(orc, case):
+    g = golden(case)
+    K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]
+    gamma, eps = [float(v) for v in g["gamma_eps"]]
+    torch.manual_seed(3)
+    model = orc.ARCHS[_arch_of(case)][0]()
+    model.train()
+    # same seed + same construction order => the reference's initial weights, tensor for tensor
+    assert list(model.state_dict().keys()) == [str(k) for k in g["keys"]]
+    np.testing.assert_array_equal(_checks(model), g["ck0"])
+    opt = orc.make_optimizer(model)
+    x = torch.rand(g["x"].shape)
+    y = torch.randint(0, 10, (g["x"].shape[0],))
+    np.testing.assert_array_equal(x.numpy(), g["x"])
+    np.testing.assert_array_equal(y.numpy(), g["y"])
+    r = orc.afan_train_step(model, opt, nn.CrossEntropyLoss(), x, y, steps=K, gamma=gamma, eps=eps,
+                            perturb_idx=idx, layer_number=ln, randinit=bool(randinit), clip=bool(clip))
+    for k in ("feature_map", "x_adv", "l2", "linf", "loss", "loss_adv", "loss_clean", "out_clean"):
+        np.testing.assert_array_equal(r[k].numpy(), g[k], err_msg=k)
+    np.testing.assert_array_equal(_checks(model), g["ck1"])  # every weight and BN buffer after the SGD step
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("sd1/"):
+            np.testing.assert_array_equal(sd[k[4:]].numpy(), g[k], err_msg=k)
+    # BN side effect: head BN 2 updates, tail BN K+2 updates per iteration
+    assert int(sd["sequential_model.2.num_batches_tracked"]) == 2
+    assert int(sd[f"sequential_model.{idx}.bn1.num_batches_tracked"]) == K + 2
+
+
+def test_stored_initial_weights_equal_seeded_construction(orc):
+    g = golden("step_r20s_k1")
+    torch.manual_seed(3)
+    sd = orc.resnet20s().state_dict()
+    for k, v in sd.items():
+        np.testing.assert_array_equal(v.numpy(), g["sd0/" + k], err_msg=k)
+
+
+def test_trajectory_with_warmup(orc):
+    g = golden("traj_r20s")
+    torch.manual_seed(3)
+    model = orc.resnet20s()
+    model.train()
+    opt = orc.make_optimizer(model)
+    xs, ys = torch.from_numpy(g["xs"]), torch.from_numpy(g["ys"])
+    losses = []
+    for i in range(3):
+        lr = orc.warmup_lr(i, opt, int(g["wp"]), 0.1)
+        assert lr == float(g["lrs"][i])
+        r = orc.afan_train_step(model, opt, nn.CrossEntropyLoss(), xs[i], ys[i], steps=2, gamma=0.5, eps=2.0,
+                                perturb_idx=7, layer_number=16)
+        losses.append(float(r["loss"]))
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    np.testing.assert_array_equal(_checks(model), g["ck"])
+
+
+@pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip"])
+def test_pgd_step_kernels_python_and_c(orc, c_oracle, case):
+    """x_adv(t+1) from x_adv(t) and the reference's gradient: python restatement and C restatement, bit-exact."""
+    g = golden(case)
+    gamma, eps = float(g["gamma_eps"][0]) / 255, float(g["gamma_eps"][1]) / 255
+    clip = int(g["clip"])
+    snaps, grads, fm = g["snaps"], g["grads"], g["fm"]
+    np.testing.assert_array_equal(snaps[0], fm)
+    for t in range(grads.shape[0]):
+        xa = torch.from_numpy(snaps[t].copy())
+        orc.pgd_step_(xa, torch.from_numpy(grads[t]), gamma, torch.from_numpy(fm), eps, bool(clip))
+        np.testing.assert_array_equal(xa.numpy(), snaps[t + 1])
+        xc = snaps[t].copy()
+        c_oracle.oracle_pgd_step(ptr(xc), ptr(np.ascontiguousarray(grads[t])), ptr(fm), xc.size,
+                                 np.float32(gamma), np.float32(eps), clip)
+        np.testing.assert_array_equal(xc, snaps[t + 1])
+
+
+def test_randinit_noise_c(c_oracle):
+    g = golden("step_r20s_k3_clip_rand")
+    fm, u = g["feature_map"], g["u"]
+    x = fm.copy()
+    c_oracle.oracle_axpy_noise(ptr(x), ptr(u), x.size, np.float32(2.0 / 255))
+    ref = torch.from_numpy(fm.copy())
+    ref += (2.0 * torch.from_numpy(u) - 1.0) * (2.0 / 255)  # attack_algo.py:44 on the stored draw
+    np.testing.assert_array_equal(x, ref.numpy())
+
+
+def test_norms_c(c_oracle):
+    g = golden("step_r20s_k5")
+    xa, x = g["x_adv"], g["feature_map"]
+    b = xa.shape[0]
+    l2, linf = np.zeros(b, np.float32), np.zeros(b, np.float32)
+    c_oracle.oracle_perturb_norms(ptr(xa), ptr(x), b, xa.size // b, ptr(l2), ptr(linf))
+    # torch.norm accumulates d*d in fp32 (16384 nearly equal terms): ~5e-6 relative off the double sum
+    np.testing.assert_allclose(l2, g["l2"], rtol=1e-5)
+    np.testing.assert_array_equal(linf, g["linf"])
+
+
+def test_clamp_edges(orc, c_oracle):
+    g = golden("clamp_edges")
+    t, c, r = g["t"], g["c"], float(g["radius"])
+    out = orc.linf_project_(torch.from_numpy(c), r, torch.from_numpy(t.copy())).numpy()
+    np.testing.assert_array_equal(out, g["out"])
+    tc = t.copy()
+    c_oracle.oracle_pgd_step(ptr(tc), ptr(np.zeros_like(t)), ptr(c), t.size, np.float32(0), np.float32(r), 1)
+    # gamma=0: x + 0*sign(0) = x (except -0.0 -> +0.0, not in the vector), then the projection
+    np.testing.assert_array_equal(tc, g["out"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mix_feature_and_lerp(orc, c_oracle, tag):
+    g = golden("seg_ops")
+    clean, adv = g[f"mix_{tag}_clean"], g[f"mix_{tag}_adv"]
+    out = orc.mix_feature(torch.from_numpy(clean), torch.from_numpy(adv)).numpy()
+    np.testing.assert_array_equal(out, g[f"mix_{tag}_out"])
+    n, c = clean.shape[:2]
+    hw = clean.size // (n * c)
+    oc = np.zeros_like(clean)
+    c_oracle.oracle_mix_feature(ptr(clean), ptr(adv), ptr(oc), n, c, hw, np.float32(1e-5))
+    np.testing.assert_allclose(oc, g[f"mix_{tag}_out"], rtol=2e-5, atol=2e-6)  # C sums in double
+    for npts in (3, 5):
+        pts = orc.get_sample_points(torch.from_numpy(clean), torch.from_numpy(adv), npts)
+        np.testing.assert_array_equal(np.stack([p.numpy() for p in pts]), g[f"lerp_{tag}_{npts}"])
+        k = npts - 2
+        w = np.array([i * (1.0 / (npts - 1)) for i in range(1, npts - 1)], dtype=np.float32)
+        oc = np.zeros((k,) + clean.shape, np.float32)
+        c_oracle.oracle_lerp_points(ptr(clean), ptr(adv), ptr(oc), clean.size, ptr(w), k)
+        ref = g[f"lerp_{tag}_{npts}"][1:-1]
+        # ATen's vectorised body is one FMA; its scalar tail may round twice: allow 1 ulp there
+        np.testing.assert_allclose(oc, ref, rtol=1.2e-7, atol=1e-7)
+        assert (oc == ref).mean() > 0.95
