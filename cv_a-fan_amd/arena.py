@@ -21,14 +21,21 @@ _ALIGN = 64  # floats: every tensor starts on a 256-byte boundary of the arena
 
 
 class ParamArena:
-    def __init__(self, model, skip=("w",), bf16_shadow=None):
-        named = [(n, p) for n, p in model.named_parameters() if n not in skip and p.requires_grad]
+    def __init__(self, model, skip=("w",), bf16_shadow=None, allow_cpu=False):
+        all_named = list(model.named_parameters())
+        named = [(n, p) for n, p in all_named if n not in skip and p.requires_grad]
         if not named:
             raise ValueError("no parameters to manage")
         dev = named[0][1].device
-        if dev.type != "cuda":
-            raise ops.AfanLibraryError("ParamArena needs the model on the MI355X")
+        if dev.type != "cuda" and not allow_cpu:
+            raise ops.AfanLibraryError("ParamArena needs the model on the MI355X (allow_cpu=True only lays out the "
+                                       "buffers for host-side tests; no kernel can run on them)")
         self.names = [n for n, _ in named]
+        # index of every managed parameter in model.parameters() order (what torch.optim.SGD(model.parameters())
+        # uses as state keys, main_perturb.py:72 — the skipped `w` is index 0 there)
+        all_names = [n for n, _ in all_named]
+        self.model_index = [all_names.index(n) for n in self.names]
+        self.n_model_params = len(all_names)
         self.offsets, off = [], 0
         for _, p in named:
             self.offsets.append(off)
@@ -49,12 +56,21 @@ class ParamArena:
             p.grad = self.grad[o:o + p.numel()].view_as(p)
             self.params.append(p)
         if self.shadow is not None:
-            ops.cast_bf16(self.param, self.shadow)
+            self.refresh_shadow()
             mods = dict(model.named_modules())
             for (n, p), o in zip(named, self.offsets):
                 m = mods.get(n.rsplit(".", 1)[0])
                 if isinstance(m, Conv2d) and n.endswith(".weight"):
                     m._arena_shadow = self.shadow[o:o + p.numel()].view_as(p)
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 shadow from the fp32 parameters (after load_state_dict / manual edits)."""
+        if self.shadow is not None:
+            ops.cast_bf16(self.param, self.shadow)
+
+    def view(self, buf, i):
+        p, o = self.params[i], self.offsets[i]
+        return buf[o:o + p.numel()].view_as(p)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -62,29 +78,15 @@ class ParamArena:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
-    def chunks(self, n_chunks):
-        """Contiguous [start, end) ranges of the arena, cut at tensor boundaries, in BACKWARD order of use
-        (last layers first) — the units of the overlapped gradient all-reduce."""
-        bounds = self.offsets + [self.numel]
-        target = self.numel / max(n_chunks, 1)
-        cuts, acc_start = [], len(self.offsets)
-        end = self.numel
-        i = len(self.offsets) - 1
-        while i >= 0:
-            if end - bounds[i] >= target or i == 0:
-                cuts.append((bounds[i], end, i))
-                end = bounds[i]
-            i -= 1
-        return cuts  # (start, end, index of the first parameter in the chunk)
 
-
-class ArenaSGD:
-    """torch.optim.SGD-compatible surface (param_groups[0]['lr'], step, zero_grad, state_dict) on a ParamArena."""
+class ArenaSGD(torch.optim.Optimizer):
+    """torch.optim.SGD's surface (param_groups, step, zero_grad, state_dict in the SAME layout, so lr schedulers
+    and the reference's checkpoints work) executed as ONE afan_sgd_step launch over the arena."""
 
     def __init__(self, arena, lr, momentum=0.9, weight_decay=5e-4):
         self.arena = arena
-        self.param_groups = [{"lr": float(lr), "momentum": float(momentum), "weight_decay": float(weight_decay),
-                              "dampening": 0, "nesterov": False, "params": list(range(len(arena.params)))}]
+        super().__init__(arena.params, dict(lr=float(lr), momentum=float(momentum), dampening=0,
+                                            weight_decay=float(weight_decay), nesterov=False))
         self._lr_on_device = None
         self.grad_scale = 1.0
 
@@ -97,7 +99,8 @@ class ArenaSGD:
             self.arena.lr.fill_(lr)
             self._lr_on_device = lr
 
-    def step(self):
+    @torch.no_grad()
+    def step(self, closure=None):
         g = self.param_groups[0]
         self._sync_lr()
         a = self.arena
@@ -105,22 +108,25 @@ class ArenaSGD:
                       a.shadow)
 
     def state_dict(self):
-        """Same layout torch.optim.SGD.state_dict() produces (main_perturb.py:124,132 stores it in checkpoints)."""
+        """Layout of torch.optim.SGD(model.parameters()).state_dict() (main_perturb.py:124,132 store it): state keyed
+        by the parameter's index in model.parameters(); parameters outside the arena (`w`) have no state."""
         a = self.arena
-        state = {i: {"momentum_buffer": a.momentum_buf[o:o + p.numel()].view_as(p).clone()}
-                 for i, (p, o) in enumerate(zip(a.params, a.offsets))}
-        groups = [dict(self.param_groups[0])]
-        return {"state": state, "param_groups": groups}
+        state = {mi: {"momentum_buffer": a.view(a.momentum_buf, i).clone()} for i, mi in enumerate(a.model_index)}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(a.n_model_params))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         a = self.arena
-        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
-            st = sd["state"].get(i)
-            buf = a.momentum_buf[o:o + p.numel()].view_as(p)
+        for i, mi in enumerate(a.model_index):
+            st = sd["state"].get(mi)
+            buf = a.view(a.momentum_buf, i)
             if st is not None and st.get("momentum_buffer") is not None:
                 buf.copy_(st["momentum_buffer"])
             else:
                 buf.zero_()
         for k in ("lr", "momentum", "weight_decay"):
             self.param_groups[0][k] = sd["param_groups"][0][k]
+        if "initial_lr" in sd["param_groups"][0]:
+            self.param_groups[0]["initial_lr"] = sd["param_groups"][0]["initial_lr"]
         self._lr_on_device = None

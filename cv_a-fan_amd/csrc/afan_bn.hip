@@ -306,6 +306,7 @@ struct Plan {
     Geo g;
     int vec;  // elements per access
     dim3 grid;
+    double tensor_bytes;  // bytes of one full activation tensor (algorithmic-traffic unit for the profiler)
 };
 
 template <typename T>
@@ -330,6 +331,7 @@ bool make_plan(int64_t n, int64_t c, int64_t hw, std::initializer_list<const voi
     if (S > MAX_SLICES) S = MAX_SLICES;
     if (S < 1) S = 1;
     p.grid = dim3((unsigned)S, (unsigned)c);
+    p.tensor_bytes = (double)n * (double)c * (double)hw * sizeof(T);
     return true;
 }
 
@@ -338,11 +340,15 @@ int bn_stats_impl(const void* x, int64_t n, int64_t c, int64_t hw, float eps, fl
                   float* mean, float* invstd, float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
     Plan p;
     if (!make_plan<T>(n, c, hw, {x}, p)) return AFAN_ESHAPE;
-    if (p.vec == 1)
-        bn_stats_kernel<T, 1><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
-    else
-        bn_stats_kernel<T, Elt<T>::VEC><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+    {
+        AFAN_PROF("bn_stats_kernel", p.tensor_bytes, st);
+        if (p.vec == 1)
+            bn_stats_kernel<T, 1><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+        else
+            bn_stats_kernel<T, Elt<T>::VEC><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+    }
     AFAN_LAUNCH_CHECK();
+    AFAN_PROF("bn_finalize_kernel", 16.0 * c * p.grid.x, st);
     bn_finalize_kernel<<<(unsigned)c, AFAN_WAVE, 0, st>>>(ws, (int)p.grid.x, eps, momentum, mean, invstd,
                                                           rmean, rvar, nbt);
     AFAN_LAUNCH_CHECK();
@@ -353,6 +359,7 @@ template <typename T, int VEC, bool TRAIN>
 void launch_apply(const Plan& p, const void* x, const void* res, void* y, const float* ws, float eps,
                   float momentum, const float* weight, const float* bias, float* mean, float* invstd,
                   float* rmean, float* rvar, int64_t* nbt, int relu, hipStream_t st) {
+    AFAN_PROF("bn_apply_kernel", p.tensor_bytes * (res ? 3 : 2), st);
 #define AFAN_GO(RES, RELU)                                                                          \
     bn_apply_kernel<T, VEC, RES, RELU, TRAIN><<<p.grid, BLOCK, 0, st>>>(                            \
         (const T*)x, (const T*)res, (T*)y, p.g, ws, eps, momentum, weight, bias, mean, invstd, rmean, \
@@ -374,8 +381,11 @@ int bn_forward_impl(const void* x, const void* res, void* y, int64_t n, int64_t 
     if (!make_plan<T>(n, c, hw, {x, res, y}, p)) return AFAN_ESHAPE;
     constexpr int NV = Elt<T>::VEC;
     if (train) {
-        if (p.vec == 1) bn_stats_kernel<T, 1><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
-        else bn_stats_kernel<T, NV><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+        {
+            AFAN_PROF("bn_stats_kernel", p.tensor_bytes, st);
+            if (p.vec == 1) bn_stats_kernel<T, 1><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+            else bn_stats_kernel<T, NV><<<p.grid, BLOCK, 0, st>>>((const T*)x, p.g, ws);
+        }
         AFAN_LAUNCH_CHECK();
         if (p.vec == 1) launch_apply<T, 1, true>(p, x, res, y, ws, eps, momentum, weight, bias, mean, invstd, rmean, rvar, nbt, relu, st);
         else launch_apply<T, NV, true>(p, x, res, y, ws, eps, momentum, weight, bias, mean, invstd, rmean, rvar, nbt, relu, st);
@@ -395,14 +405,18 @@ int bn_backward_vec(const Plan& p, const void* dy, const void* x, const void* y,
     const T* dy_ = (const T*)dy; const T* x_ = (const T*)x; const T* y_ = (const T*)y;
 #define AFAN_RED(RELU, HY) \
     bn_bwd_reduce_kernel<T, VEC, RELU, HY><<<p.grid, BLOCK, 0, st>>>(dy_, x_, y_, p.g, mean, invstd, weight, bias, ws)
-    if (!relu) AFAN_RED(false, false);
-    else if (y) AFAN_RED(true, true);
-    else AFAN_RED(true, false);
+    {
+        AFAN_PROF("bn_bwd_reduce_kernel", p.tensor_bytes * ((relu && y) ? 3 : 2), st);
+        if (!relu) AFAN_RED(false, false);
+        else if (y) AFAN_RED(true, true);
+        else AFAN_RED(true, false);
+    }
 #undef AFAN_RED
     AFAN_LAUNCH_CHECK();
 #define AFAN_APP(RELU, HY, DR)                                                                         \
     bn_bwd_apply_kernel<T, VEC, RELU, HY, DR><<<p.grid, BLOCK, 0, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, p.g, \
         mean, invstd, weight, bias, ws, inv_m, dweight, dbias, accumulate)
+    AFAN_PROF("bn_bwd_apply_kernel", p.tensor_bytes * (3 + ((relu && y) ? 1 : 0) + (dres ? 1 : 0)), st);
     if (!relu) { if (dres) AFAN_APP(false, false, true); else AFAN_APP(false, false, false); }
     else if (y) { if (dres) AFAN_APP(true, true, true); else AFAN_APP(true, true, false); }
     else { if (dres) AFAN_APP(true, false, true); else AFAN_APP(true, false, false); }
@@ -507,6 +521,7 @@ int afan_normalize_nchw(const float* x, void* y, int out_dtype, int64_t n, int64
     if (!x || !y || !mean || !std) return AFAN_ENULL;
     const int64_t total = n * c * hw;
     const int grid = grid_for(total, BLOCK);
+    AFAN_PROF("normalize_kernel", total * (4.0 + (out_dtype == AFAN_F32 ? 4 : 2)), (hipStream_t)stream);
     if (out_dtype == AFAN_F32)
         normalize_kernel<float><<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, (float*)y, total, c, hw, mean, std);
     else

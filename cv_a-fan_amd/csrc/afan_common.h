@@ -104,6 +104,22 @@ static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<u
 
 }  // namespace afan
 
+// ---- optional per-launch event timing (afan_prof.hip) ----
+namespace afan { namespace prof {
+extern int g_enabled;
+void begin(const char* name, double bytes, hipStream_t st, size_t* slot);
+void end(size_t slot, hipStream_t st);
+struct Scope {
+    size_t slot; hipStream_t st; bool on;
+    Scope(const char* name, double bytes, hipStream_t s) : slot((size_t)-1), st(s), on(g_enabled != 0) {
+        if (on) begin(name, bytes, st, &slot);
+    }
+    ~Scope() { if (on) end(slot, st); }
+};
+} }
+// time the launches issued in the rest of the enclosing block as kernel `name` moving `bytes` algorithmic bytes
+#define AFAN_PROF(name, bytes, st) afan::prof::Scope afan_prof_scope__(name, (double)(bytes), st)
+
 #define AFAN_LAUNCH_CHECK()                     \
     do {                                        \
         hipError_t e__ = hipGetLastError();     \

@@ -143,6 +143,7 @@ int mix_impl(const void* clean, const void* adv, void* out, int64_t n, int64_t c
     if (blocks > 0x7fffffffLL) return AFAN_ESHAPE;
     const size_t stats_bytes = (size_t)2 * (BLOCK / pix) * pix * 3 * 4;
     const size_t lds = stats_bytes + (stage ? (size_t)c * pix * 4 : 0);
+    AFAN_PROF("mix_feature_kernel", 3.0 * sizeof(T) * n * c * hw, st);
     if (stage) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)mix_feature_kernel<T, true>,
@@ -185,6 +186,7 @@ int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, cons
     for (int k = 0; k < 8; ++k) lw.w[k] = k < n_interior ? weights[k] : 0.f;
     const int vec = aligned(x, 16) && aligned(y, 16) && aligned(out, 16) && (n % 4 == 0);
     const int grid = grid_for(vec ? n / 4 : n, BLOCK);
+    AFAN_PROF("lerp_points_kernel", 4.0 * n * (2 + n_interior), (hipStream_t)stream);
     lerp_points_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, y, out, n, lw, n_interior, vec);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;

@@ -91,7 +91,10 @@ __device__ __forceinline__ void block_reduce_store(float ss, float mx, float* __
     __shared__ float s_ss[BLOCK / AFAN_WAVE];
     __shared__ float s_mx[BLOCK / AFAN_WAVE];
     ss = wave_sum(ss);
-    mx = wave_max(mx);
+    // fmaxf drops NaNs: carry "saw a NaN" separately so the max stays NaN-propagating like torch.norm(p=inf)
+    const float nanflag = wave_max((mx != mx) ? 1.f : 0.f);
+    mx = wave_max((mx != mx) ? 0.f : mx);
+    if (nanflag > 0.f) mx = __builtin_nanf("");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
         s_ss[w] = ss;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void block_reduce_store(float ss, float mx, float* __
 #pragma unroll
         for (int k = 0; k < BLOCK / AFAN_WAVE; ++k) {
             a += s_ss[k];
-            b = fmaxf(b, s_mx[k]);
+            b = (b != b || s_mx[k] != s_mx[k]) ? __builtin_nanf("") : fmaxf(b, s_mx[k]);
         }
         partial[2 * slot] = a;
         partial[2 * slot + 1] = b;
@@ -270,6 +273,7 @@ int launch_step(float* x_adv, const void* grad, const float* x_clean, uint16_t* 
     const bool vec = aligned(x_adv, 16) && aligned(grad, 4 * sizeof(G)) &&
                      (!CLIP || aligned(x_clean, 16)) && (!SHADOW || aligned(shadow, 8));
     const int grid = grid_for(vec ? (n + 3) / 4 : n, BLOCK);
+    AFAN_PROF("pgd_step_kernel", n * (8.0 + sizeof(G) + (CLIP ? 4 : 0) + (SHADOW ? 2 : 0)), st);
     if (vec)
         pgd_step_kernel<G, CLIP, SHADOW, true><<<grid, BLOCK, 0, st>>>(
             x_adv, (const G*)grad, x_clean, shadow, n, gamma, eps);
@@ -288,13 +292,19 @@ int launch_step_norms(float* x_adv, const void* grad, const float* x_clean, uint
                      (!STEP || aligned(grad, 4 * sizeof(G))) && (!SHADOW || aligned(shadow, 8));
     const int slices = (int)((per_sample + NORM_CHUNK - 1) / NORM_CHUNK);
     dim3 grid(slices, (unsigned)batch);
-    if (vec)
-        pgd_step_norms_kernel<G, CLIP, SHADOW, true, STEP><<<grid, BLOCK, 0, st>>>(
-            x_adv, (const G*)grad, x_clean, shadow, per_sample, gamma, eps, partial);
-    else
-        pgd_step_norms_kernel<G, CLIP, SHADOW, false, STEP><<<grid, BLOCK, 0, st>>>(
-            x_adv, (const G*)grad, x_clean, shadow, per_sample, gamma, eps, partial);
+    {
+        const double elts = (double)batch * (double)per_sample;
+        AFAN_PROF(STEP ? "pgd_step_norms_kernel" : "perturb_norms_kernel",
+                  elts * (STEP ? (12.0 + sizeof(G) + (SHADOW ? 2 : 0)) : 8.0), st);
+        if (vec)
+            pgd_step_norms_kernel<G, CLIP, SHADOW, true, STEP><<<grid, BLOCK, 0, st>>>(
+                x_adv, (const G*)grad, x_clean, shadow, per_sample, gamma, eps, partial);
+        else
+            pgd_step_norms_kernel<G, CLIP, SHADOW, false, STEP><<<grid, BLOCK, 0, st>>>(
+                x_adv, (const G*)grad, x_clean, shadow, per_sample, gamma, eps, partial);
+    }
     AFAN_LAUNCH_CHECK();
+    AFAN_PROF("norms_finalize_kernel", 8.0 * batch * slices, st);
     norms_finalize_kernel<<<(unsigned)batch, AFAN_WAVE, 0, st>>>(partial, slices, l2, linf);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
@@ -386,6 +396,7 @@ int afan_axpy_noise(float* x_adv, const float* u, int64_t n, float eps, uint16_t
     if (!aligned(x_adv, 4) || !aligned(u, 4) || (shadow_bf16 && !aligned(shadow_bf16, 2))) return AFAN_EALIGN;
     const int vec = aligned(x_adv, 16) && aligned(u, 16) && (!shadow_bf16 || aligned(shadow_bf16, 8));
     const int grid = grid_for(vec ? (n + 3) / 4 : n, BLOCK);
+    AFAN_PROF("axpy_noise_kernel", n * (12.0 + (shadow_bf16 ? 2 : 0)), (hipStream_t)stream);
     axpy_noise_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(x_adv, u, n, eps, shadow_bf16, vec);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
@@ -396,6 +407,7 @@ int afan_tensor_clamp(float* t, const float* lo, const float* hi, int64_t n, afa
     if (n == 0) return AFAN_OK;
     if (!t || !lo || !hi) return AFAN_ENULL;
     if (!aligned(t, 4) || !aligned(lo, 4) || !aligned(hi, 4)) return AFAN_EALIGN;
+    AFAN_PROF("tensor_clamp_kernel", n * 16.0, (hipStream_t)stream);
     tensor_clamp_kernel<<<grid_for(n, BLOCK), BLOCK, 0, (hipStream_t)stream>>>(t, lo, hi, n);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
@@ -408,6 +420,7 @@ int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t str
     if (!aligned(src, 4) || !aligned(dst, 2)) return AFAN_EALIGN;
     const int vec = aligned(src, 16) && aligned(dst, 16);
     const int grid = grid_for(vec ? (n + 7) / 8 : n, BLOCK);
+    AFAN_PROF("cast_bf16_kernel", n * 6.0, (hipStream_t)stream);
     cast_bf16_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(src, dst, n, vec);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;

@@ -69,6 +69,7 @@ extern "C" int afan_sgd_step(float* param, const float* grad, float* momentum_bu
                     (!shadow_bf16 || aligned(shadow_bf16, 8));
     const int grid = grid_for(vec ? (n + 3) / 4 : n, BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("sgd_kernel", n * (20.0 + (shadow_bf16 ? 2 : 0)), st);
 #define AFAN_GO(F, S) \
     sgd_kernel<F, S><<<grid, BLOCK, 0, st>>>(param, grad, momentum_buf, shadow_bf16, n, lr_dev, momentum, weight_decay, grad_scale, vec)
     if (first_step) { if (shadow_bf16) AFAN_GO(true, true); else AFAN_GO(true, false); }

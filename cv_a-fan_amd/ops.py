@@ -265,3 +265,23 @@ def normalize_nchw(x, mean, std, out_dtype=torch.float32):
     check(lib.afan_normalize_nchw(_ptr(x), _ptr(y), _DT[out_dtype], n, c, hw, _ptr(mean), _ptr(std),
                                   _stream(x)), "afan_normalize_nchw")
     return y
+
+
+# ------------------------------------------------------------------------------------- measurement
+def profile_enable(on=True):
+    check(_lib.load().afan_profile_enable(int(bool(on))), "afan_profile_enable")
+
+
+def profile_collect(max_kernels=32):
+    """{kernel: {"launches", "ms", "bytes"}} for the launches recorded since profile_enable(True)."""
+    lib = _lib.load()
+    names = C.create_string_buffer(64 * max_kernels)
+    launches = (C.c_int64 * max_kernels)()
+    ms = (C.c_double * max_kernels)()
+    nbytes = (C.c_double * max_kernels)()
+    k = lib.afan_profile_collect(names, launches, ms, nbytes, max_kernels)
+    out = {}
+    for i in range(k):
+        name = names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()
+        out[name] = {"launches": int(launches[i]), "ms": float(ms[i]), "bytes": float(nbytes[i])}
+    return out

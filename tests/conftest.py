@@ -78,3 +78,14 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail("test is marked gpu but no GPU is visible")
     return torch.device("cuda:0")
+
+
+def assert_close_frac(got, ref, rtol, atol, max_bad_frac=0.0, msg=""):
+    """allclose with an allowance for a tiny FRACTION of outliers (elements whose ReLU mask or sign() flips
+    because an fp32 value sits within rounding distance of zero — SURVEY.md §7 'sign() is discontinuous')."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    bad = ~(np.abs(got - ref) <= atol + rtol * np.abs(ref))
+    bad &= ~(np.isnan(got) & np.isnan(ref))
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, f"{msg}: {bad.sum()} / {bad.size} elements off (frac {frac:.3e} > {max_bad_frac:.1e}); " \
+                                 f"max abs diff {np.nanmax(np.abs(got - ref)):.3e}"
