@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--pgd_steps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"], help="internal activation layout")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_steps", type=int, default=2)
@@ -93,7 +94,7 @@ def main():
     torch.manual_seed(3)                      # same initial weights on every rank (reference --seed 3)
     model = ctor()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.set_compute_dtype(dtype).to(dev).train()
+    model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
     trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
                                          perturb_idx=idx, lr=0.1)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
@@ -158,7 +159,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.arch} CIFAR-10-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
-                                   f"{args.batch}/GPU, perturb_idx {idx}, 1xMI355X per rank (BASELINE configs[1])",
+                                   f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
+                                   f"(BASELINE configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -9,8 +9,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libafan_hip.so")
 
 AFAN_F32, AFAN_BF16 = 0, 1
+AFAN_NCHW, AFAN_NHWC = 0, 1
 _ERRORS = {-1: "AFAN_EDTYPE (unknown dtype code)", -2: "AFAN_EALIGN (misaligned pointer)",
-           -3: "AFAN_ESHAPE (bad sizes)", -4: "AFAN_ENULL (required pointer is NULL)"}
+           -3: "AFAN_ESHAPE (bad sizes)", -4: "AFAN_ENULL (required pointer is NULL)",
+           -5: "AFAN_ELAYOUT (unknown layout code)"}
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -27,13 +29,13 @@ SIGNATURES = {
     "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
     "afan_bn_workspace_floats": (_l, [_l]),
-    "afan_bn_stats": (_i, [_p, _i, _l, _l, _l, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "afan_bn_train_forward": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "afan_bn_apply": (_i, [_p, _p, _p, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p]),
-    "afan_bn_backward": (_i, [_p, _p, _p, _p, _p, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "afan_bn_stats": (_i, [_p, _i, _i, _l, _l, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "afan_bn_train_forward": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "afan_bn_apply": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p, _p]),
+    "afan_bn_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),
-    "afan_normalize_nchw": (_i, [_p, _p, _i, _l, _l, _l, _p, _p, _p]),
+    "afan_normalize_nchw": (_i, [_p, _p, _i, _i, _l, _l, _l, _p, _p, _p]),
     "afan_profile_enable": (_i, [_i]),
     "afan_profile_collect": (_i, [C.c_char_p, C.POINTER(_l), C.POINTER(C.c_double), C.POINTER(C.c_double), _i]),
 }

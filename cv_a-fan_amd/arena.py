@@ -21,7 +21,7 @@ _ALIGN = 64  # floats: every tensor starts on a 256-byte boundary of the arena
 
 
 class ParamArena:
-    def __init__(self, model, skip=("w",), bf16_shadow=None, allow_cpu=False):
+    def __init__(self, model, skip=("w",), bf16_shadow=None, allow_cpu=False, channels_last=None):
         all_named = list(model.named_parameters())
         named = [(n, p) for n, p in all_named if n not in skip and p.requires_grad]
         if not named:
@@ -49,11 +49,16 @@ class ParamArena:
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if bf16_shadow else None
         self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
         self.params = []
+        # 4-D (convolution) weights live in the arena in KRSC order (logical [K,C,R,S] with channels-last strides):
+        # K = (r, s, c) contiguous is what the implicit-GEMM convolutions read; SGD is element-wise, so it does not care.
+        if channels_last is None:
+            channels_last = bool(getattr(model, "channels_last", False))
+        self.channels_last = channels_last
         for (n, p), o in zip(named, self.offsets):
-            view = self.param[o:o + p.numel()].view_as(p)
+            view = self._view(self.param, o, p)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p.grad = self._view(self.grad, o, p)
             self.params.append(p)
         if self.shadow is not None:
             self.refresh_shadow()
@@ -61,22 +66,28 @@ class ParamArena:
             for (n, p), o in zip(named, self.offsets):
                 m = mods.get(n.rsplit(".", 1)[0])
                 if isinstance(m, Conv2d) and n.endswith(".weight"):
-                    m._arena_shadow = self.shadow[o:o + p.numel()].view_as(p)
+                    m._arena_shadow = self._view(self.shadow, o, p)
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow from the fp32 parameters (after load_state_dict / manual edits)."""
         if self.shadow is not None:
             ops.cast_bf16(self.param, self.shadow)
 
+    def _view(self, buf, o, p):
+        flat = buf[o:o + p.numel()]
+        if self.channels_last and p.dim() == 4:
+            k, c, r, s_ = p.shape
+            return flat.view(k, r, s_, c).permute(0, 3, 1, 2)
+        return flat.view(p.shape)
+
     def view(self, buf, i):
-        p, o = self.params[i], self.offsets[i]
-        return buf[o:o + p.numel()].view_as(p)
+        return self._view(buf, self.offsets[i], self.params[i])
 
     def zero_grad(self):
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):  # re-attach views if someone set .grad = None
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view_as(p)
+                p.grad = self._view(self.grad, o, p)
 
 
 class ArenaSGD(torch.optim.Optimizer):

@@ -15,6 +15,17 @@
 
 using namespace afan;
 
+namespace afan_nhwc {  // afan_bn_nhwc.hip
+int fwd(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom, const float* w,
+        const float* b, int relu, float* ws, float* stats, const float* mean_in, const float* invstd_in, float* rm,
+        float* rv, int64_t* nbt, bool train, hipStream_t st);
+int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, float* ws, float* stats_out, float* rm,
+          float* rv, int64_t* nbt, hipStream_t st);
+int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
+        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st);
+int64_t workspace_floats(int64_t c);
+}
+
 namespace {
 
 constexpr int BLOCK = 256;
@@ -290,14 +301,23 @@ __global__ __launch_bounds__(BLOCK) void bn_bwd_apply_kernel(
 }
 
 // ---- per-channel input normalisation (resnet_s.py:87) ----------------------------------------------
-template <typename TO>
+// i indexes the OUTPUT; NHWC output gathers from the NCHW input image
+template <typename TO, bool NHWC_OUT>
 __global__ __launch_bounds__(BLOCK) void normalize_kernel(const float* __restrict__ x, TO* __restrict__ y,
                                                           int64_t total, int64_t c, int64_t hw,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ std) {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
-        const int64_t ch = (i / hw) % c;
-        Elt<TO>::st(y + i, (x[i] - mean[ch]) / std[ch]);
+        int64_t ch, src;
+        if (NHWC_OUT) {
+            ch = i % c;
+            const int64_t pix = i / c;            // n*hw + p
+            src = (pix / hw) * c * hw + ch * hw + (pix % hw);
+        } else {
+            ch = (i / hw) % c;
+            src = i;
+        }
+        Elt<TO>::st(y + i, (x[src] - mean[ch]) / std[ch]);
     }
 }
 
@@ -438,6 +458,8 @@ int bn_backward_impl(const void* dy, const void* x, const void* y, void* dx, voi
     return bn_backward_vec<T, Elt<T>::VEC>(p, dy, x, y, dx, dres, mean, invstd, weight, bias, relu, ws, inv_m, dweight, dbias, accumulate, st);
 }
 
+int check_layout(int layout) { return (layout == AFAN_NCHW || layout == AFAN_NHWC) ? AFAN_OK : AFAN_ELAYOUT; }
+
 int check_common(int dtype, int64_t n, int64_t c, int64_t hw) {
     if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
     if (n <= 0 || c <= 0 || hw <= 0) return AFAN_ESHAPE;
@@ -448,84 +470,110 @@ int check_common(int dtype, int64_t n, int64_t c, int64_t hw) {
 
 extern "C" {
 
-int64_t afan_bn_workspace_floats(int64_t c) { return c > 0 ? c * MAX_SLICES * WS_STRIDE : 0; }
+int64_t afan_bn_workspace_floats(int64_t c) {
+    if (c <= 0) return 0;
+    const int64_t a = c * MAX_SLICES * WS_STRIDE, b = afan_nhwc::workspace_floats(c);
+    return a > b ? a : b;
+}
 
-int afan_bn_stats(const void* x, int dtype, int64_t n, int64_t c, int64_t hw, float eps, float momentum,
-                  float* workspace, float* mean, float* invstd, float* running_mean, float* running_var,
-                  int64_t* num_batches, afan_stream_t stream) {
+int afan_bn_stats(const void* x, int dtype, int layout, int64_t n, int64_t c, int64_t hw, float eps, float momentum,
+                  float* workspace, float* stats, float* running_mean, float* running_var, int64_t* num_batches,
+                  afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
-    if (!x || !workspace || !mean || !invstd) return AFAN_ENULL;
+    if ((e = check_layout(layout))) return e;
+    if (!x || !workspace || !stats) return AFAN_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return AFAN_ENULL;
     if (!aligned(x, dtype == AFAN_F32 ? 4 : 2)) return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (layout == AFAN_NHWC)
+        return afan_nhwc::stats(dtype, x, n * hw, c, eps, momentum, workspace, stats, running_mean, running_var, num_batches, st);
     if (dtype == AFAN_F32)
-        return bn_stats_impl<float>(x, n, c, hw, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches, st);
-    return bn_stats_impl<uint16_t>(x, n, c, hw, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches, st);
+        return bn_stats_impl<float>(x, n, c, hw, eps, momentum, workspace, stats, stats + c, running_mean, running_var, num_batches, st);
+    return bn_stats_impl<uint16_t>(x, n, c, hw, eps, momentum, workspace, stats, stats + c, running_mean, running_var, num_batches, st);
 }
 
-int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
-                          int64_t hw, float eps, float momentum, const float* weight, const float* bias,
-                          int relu, float* workspace, float* save_mean, float* save_invstd,
-                          float* running_mean, float* running_var, int64_t* num_batches,
-                          afan_stream_t stream) {
+int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n, int64_t c,
+                          int64_t hw, float eps, float momentum, const float* weight, const float* bias, int relu,
+                          float* workspace, float* save_stats, float* running_mean, float* running_var,
+                          int64_t* num_batches, afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
-    if (!x || !y || !workspace || !save_mean || !save_invstd) return AFAN_ENULL;
+    if ((e = check_layout(layout))) return e;
+    if (!x || !y || !workspace || !save_stats) return AFAN_ENULL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return AFAN_ENULL;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(x, a) || !aligned(y, a) || (residual && !aligned(residual, a))) return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (layout == AFAN_NHWC)
+        return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, eps, momentum, weight, bias, relu, workspace, save_stats,
+                              nullptr, nullptr, running_mean, running_var, num_batches, true, st);
     if (dtype == AFAN_F32)
-        return bn_forward_impl<float>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_mean, save_invstd, running_mean, running_var, num_batches, true, st);
-    return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_mean, save_invstd, running_mean, running_var, num_batches, true, st);
+        return bn_forward_impl<float>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
+    return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
 }
 
-int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
+int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw,
                   const float* mean, const float* invstd, const float* weight, const float* bias, int relu,
-                  afan_stream_t stream) {
+                  float* workspace, afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
+    if ((e = check_layout(layout))) return e;
     if (!x || !y || !mean || !invstd) return AFAN_ENULL;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(x, a) || !aligned(y, a) || (residual && !aligned(residual, a))) return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     float* m = const_cast<float*>(mean);
     float* is = const_cast<float*>(invstd);
+    if (layout == AFAN_NHWC) {
+        if (!workspace) return AFAN_ENULL;
+        float* stats = workspace + afan_nhwc::workspace_floats(c) - 4 * c;   // tail of the workspace
+        return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, 0.f, 0.f, weight, bias, relu, workspace, stats, mean, invstd,
+                              nullptr, nullptr, nullptr, false, st);
+    }
     if (dtype == AFAN_F32)
         return bn_forward_impl<float>(x, residual, y, n, c, hw, 0.f, 0.f, weight, bias, relu, nullptr, m, is, nullptr, nullptr, nullptr, false, st);
     return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, 0.f, 0.f, weight, bias, relu, nullptr, m, is, nullptr, nullptr, nullptr, false, st);
 }
 
-int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
-                     int64_t n, int64_t c, int64_t hw, const float* mean, const float* invstd,
-                     const float* weight, const float* bias, int relu, float* workspace, float* dweight,
-                     float* dbias, int accumulate, afan_stream_t stream) {
+int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype, int layout,
+                     int64_t n, int64_t c, int64_t hw, const float* save_stats, const float* weight, const float* bias,
+                     int relu, float* workspace, float* dweight, float* dbias, int accumulate, afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
-    if (!dy || !x || !dx || !mean || !invstd || !workspace) return AFAN_ENULL;
+    if ((e = check_layout(layout))) return e;
+    if (!dy || !x || !dx || !save_stats || !workspace) return AFAN_ENULL;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(dy, a) || !aligned(x, a) || !aligned(dx, a) || (y && !aligned(y, a)) ||
         (d_residual && !aligned(d_residual, a)))
         return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (layout == AFAN_NHWC)
+        return afan_nhwc::bwd(dtype, dy, x, y, dx, d_residual, n * hw, c, save_stats, relu, workspace, dweight, dbias, accumulate, st);
+    const float* mean = save_stats;
+    const float* invstd = save_stats + c;
     if (dtype == AFAN_F32)
         return bn_backward_impl<float>(dy, x, y, dx, d_residual, n, c, hw, mean, invstd, weight, bias, relu, workspace, dweight, dbias, accumulate, st);
     return bn_backward_impl<uint16_t>(dy, x, y, dx, d_residual, n, c, hw, mean, invstd, weight, bias, relu, workspace, dweight, dbias, accumulate, st);
 }
 
-int afan_normalize_nchw(const float* x, void* y, int out_dtype, int64_t n, int64_t c, int64_t hw,
+int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, int64_t n, int64_t c, int64_t hw,
                         const float* mean, const float* std, afan_stream_t stream) {
     int e = check_common(out_dtype, n, c, hw);
     if (e) return e;
+    if ((e = check_layout(out_layout))) return e;
     if (!x || !y || !mean || !std) return AFAN_ENULL;
     const int64_t total = n * c * hw;
     const int grid = grid_for(total, BLOCK);
-    AFAN_PROF("normalize_kernel", total * (4.0 + (out_dtype == AFAN_F32 ? 4 : 2)), (hipStream_t)stream);
-    if (out_dtype == AFAN_F32)
-        normalize_kernel<float><<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, (float*)y, total, c, hw, mean, std);
-    else
-        normalize_kernel<uint16_t><<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, (uint16_t*)y, total, c, hw, mean, std);
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("normalize_kernel", total * (4.0 + (out_dtype == AFAN_F32 ? 4 : 2)), st);
+    if (out_dtype == AFAN_F32) {
+        if (out_layout == AFAN_NHWC) normalize_kernel<float, true><<<grid, BLOCK, 0, st>>>(x, (float*)y, total, c, hw, mean, std);
+        else normalize_kernel<float, false><<<grid, BLOCK, 0, st>>>(x, (float*)y, total, c, hw, mean, std);
+    } else {
+        if (out_layout == AFAN_NHWC) normalize_kernel<uint16_t, true><<<grid, BLOCK, 0, st>>>(x, (uint16_t*)y, total, c, hw, mean, std);
+        else normalize_kernel<uint16_t, false><<<grid, BLOCK, 0, st>>>(x, (uint16_t*)y, total, c, hw, mean, std);
+    }
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -1,0 +1,500 @@
+// Training-mode BatchNorm for NHWC (channels-last) activations on gfx950.
+// The bf16 backbone keeps activations channels-last because the MFMA convolutions want K = (r, s, c)
+// contiguous; the tensor is then one dense [M = N*H*W][C] matrix and BN statistics are column sums.
+//
+// Mapping: a thread owns ONE 16-byte channel vector (8 bf16 / 4 fp32 channels) for its whole life:
+// flat vector index v = b*256 + t, stride G*256, and 256 % (C/VEC) == 0, so v % (C/VEC) is constant per
+// thread.  Every wave-instruction therefore reads 1 KiB of consecutive memory.  Per-channel partial sums
+// are shifted by the tensor's first row (kills the E[x^2]-mean^2 cancellation), reduced across the threads
+// of a block that share a channel vector through LDS, and written as ONE partial per (block, channel):
+// additive, so the finalize launch (one wave per channel) is a plain deterministic sum — no float atomics.
+//   forward : stats -> finalize (mean, invstd, running stats) -> apply (+residual, +ReLU)
+//   backward: reduce -> finalize (sum_g, sum_gx, dweight, dbias) -> dx (+d_residual)
+// Channel counts that do not fit the mapping (C/VEC not a divisor of 256, e.g. C = 304) take the generic
+// kernels: one thread per channel walking rows, lanes across channels (still coalesced, narrower accesses).
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace afan_nhwc {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_G = 512;  // partials per channel
+
+template <typename T, int VEC> struct LdV {
+    __device__ static __forceinline__ void ld(const T* p, float (&v)[VEC]) {
+        if constexpr (VEC == 1) v[0] = Elt<T>::ld(p); else Elt<T>::ldv(p, v);
+    }
+    __device__ static __forceinline__ void st(T* p, const float (&v)[VEC]) {
+        if constexpr (VEC == 1) Elt<T>::st(p, v[0]); else Elt<T>::stv(p, v);
+    }
+};
+
+// per-channel coefficient vector of this thread's VEC channels, loaded as 16-byte accesses (a per-lane scalar
+// gather here costs 10x the tensor's own traffic: 64 lanes x 32-byte stride = 16 cache lines per instruction)
+template <int VEC>
+__device__ __forceinline__ void ld_coef(const float* __restrict__ p, int c0, float (&v)[VEC]) {
+    if constexpr (VEC % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + c0 + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = p[c0 + k];
+    }
+}
+
+__device__ __forceinline__ void affine_coeffs(float mu, float is, float w, float b, float& alpha, float& beta) {
+    alpha = is * w;
+    beta = fmaf(-mu, alpha, b);
+}
+
+// Reduce per-thread values across the threads of the block that own the same channel vector (t % CV) and let
+// the first CV threads write the block partial to ws[(q*C + c)*G + blockIdx.x], q = 0..NQ-1.
+template <int VEC, int NQ>
+__device__ __forceinline__ void block_fold_store(float (&acc)[NQ][VEC], int CV, int C, int G,
+                                                 float* __restrict__ ws) {
+    __shared__ float sh[NQ * VEC][BLOCK];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sh[q * VEC + k][threadIdx.x] = acc[q][k];
+    __syncthreads();
+    if ((int)threadIdx.x < CV) {
+        const int R = BLOCK / CV;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += sh[q * VEC + k][threadIdx.x + r * CV];
+                const int c = threadIdx.x * VEC + k;
+                ws[((int64_t)q * C + c) * G + blockIdx.x] = s;
+            }
+    }
+}
+
+// ---- forward 1: shifted column sums -----------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, int64_t nvec, int CV, int C,
+                                                      float* __restrict__ ws) {
+    const int cv = threadIdx.x % CV;
+    float shift[VEC];
+    LdV<T, VEC>::ld(x + (int64_t)cv * VEC, shift);  // first row of the tensor: same shift in every block
+    float acc[2][VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float e[VEC];
+        LdV<T, VEC>::ld(x + v * VEC, e);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float d = e[k] - shift[k];
+            acc[0][k] += d;
+            acc[1][k] += d * d;
+        }
+    }
+    block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+}
+
+// generic: thread per channel, block per row slab
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void stats_generic_kernel(const T* __restrict__ x, int64_t M, int C,
+                                                              float* __restrict__ ws) {
+    const int G = gridDim.x;
+    const int64_t rows_per = (M + G - 1) / G;
+    const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        const float shift = Elt<T>::ld(x + c);
+        float s1 = 0.f, s2 = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const float d = Elt<T>::ld(x + r * C + c) - shift;
+            s1 += d;
+            s2 += d * d;
+        }
+        ws[((int64_t)0 * C + c) * G + blockIdx.x] = s1;
+        ws[((int64_t)1 * C + c) * G + blockIdx.x] = s2;
+    }
+}
+
+// ---- finalize: one wave per channel sums the G partials ----------------------------------------------
+// MODE 0 (forward): stats[0..3][C] = mean, invstd, alpha = invstd*w, beta = b - mean*alpha (+ running stats).
+// MODE 1 (backward): sum_g = sum g, sum_gx = invstd * sum g*(x-mean) -> dbias/dweight, and the dx coefficients
+//   coef[0][c] = B = -alpha*invstd*sum_gx/M,  coef[1][c] = D = -alpha*sum_g/M     (dx = g*alpha + (x-mean)*B + D)
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict__ ws, int G, int C, const T* x,
+                                                         float inv_m, float m_count, float eps, float momentum,
+                                                         const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* stats, float* coef,
+                                                         float* rmean, float* rvar, int64_t* nbt, float* dweight,
+                                                         float* dbias, int accumulate) {
+    const int c = blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int g = lane; g < G; g += AFAN_WAVE) {
+        a += ws[((int64_t)0 * C + c) * G + g];
+        b += ws[((int64_t)1 * C + c) * G + g];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane != 0) return;
+    if (MODE == 0) {
+        const float shift = Elt<T>::ld(x + c);
+        const float dm = a * inv_m;
+        const float mean = shift + dm;
+        const float m2 = fmaxf(b - a * dm, 0.f);
+        const float is = 1.0f / sqrtf(m2 * inv_m + eps);
+        float alpha, beta;
+        affine_coeffs(mean, is, weight ? weight[c] : 1.f, bias ? bias[c] : 0.f, alpha, beta);
+        stats[c] = mean;
+        stats[C + c] = is;
+        stats[2 * C + c] = alpha;
+        stats[3 * C + c] = beta;
+        if (rmean) {
+            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (m2 / (m_count - 1.0f));
+        }
+        if (c == 0 && nbt) *nbt += 1;
+    } else {
+        const float is = stats[C + c], alpha = stats[2 * C + c];
+        const float sum_g = a, sum_gx = b * is;
+        coef[c] = -alpha * is * (sum_gx * inv_m);
+        coef[C + c] = -alpha * (sum_g * inv_m);
+        if (dbias) dbias[c] = accumulate ? dbias[c] + sum_g : sum_g;
+        if (dweight) dweight[c] = accumulate ? dweight[c] + sum_gx : sum_gx;
+    }
+}
+
+// eval mode: alpha/beta from given mean/invstd (running stats), one thread per channel
+__global__ __launch_bounds__(BLOCK) void coef_kernel(int C, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd,
+                                                     const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, float* __restrict__ stats) {
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= C) return;
+    float alpha, beta;
+    affine_coeffs(mean[c], invstd[c], weight ? weight[c] : 1.f, bias ? bias[c] : 0.f, alpha, beta);
+    stats[c] = mean[c];
+    stats[C + c] = invstd[c];
+    stats[2 * C + c] = alpha;
+    stats[3 * C + c] = beta;
+}
+
+// ---- forward 2: y = [relu](x*alpha + beta [+ res]) ------------------------------------------------------
+template <typename T, int VEC, bool RES, bool RELU>
+__global__ __launch_bounds__(BLOCK) void apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                      T* __restrict__ y, int64_t nvec, int CV, int C,
+                                                      const float* __restrict__ stats) {
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float alpha[VEC], beta[VEC];
+    ld_coef<VEC>(stats + 2 * C, c0, alpha);
+    ld_coef<VEC>(stats + 3 * C, c0, beta);
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float e[VEC], r[VEC];
+        LdV<T, VEC>::ld(x + v * VEC, e);
+        if (RES) LdV<T, VEC>::ld(res + v * VEC, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float t = fmaf(e[k], alpha[k], beta[k]);
+            if (RES) t += r[k];
+            if (RELU) t = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+            e[k] = t;
+        }
+        LdV<T, VEC>::st(y + v * VEC, e);
+    }
+}
+
+template <typename T, bool RES, bool RELU>
+__global__ __launch_bounds__(BLOCK) void apply_generic_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              T* __restrict__ y, int64_t total, int C,
+                                                              const float* __restrict__ stats) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int c = (int)(i % C);
+        const float alpha = stats[2 * C + c], beta = stats[3 * C + c];
+        float t = fmaf(Elt<T>::ld(x + i), alpha, beta);
+        if (RES) t += Elt<T>::ld(res + i);
+        if (RELU) t = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+        Elt<T>::st(y + i, t);
+    }
+}
+
+// ---- backward 1: partial sums of g and g*xhat -------------------------------------------------------------
+template <typename T, int VEC, bool RELU, bool HAVE_Y>
+__global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, int64_t nvec, int CV, int C,
+                                                           const float* __restrict__ stats, float* __restrict__ ws) {
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float mu[VEC], alpha[VEC], beta[VEC];
+    ld_coef<VEC>(stats, c0, mu);
+    if (RELU && !HAVE_Y) {
+        ld_coef<VEC>(stats + 2 * C, c0, alpha);
+        ld_coef<VEC>(stats + 3 * C, c0, beta);
+    }
+    float acc[2][VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 2
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float d[VEC], e[VEC], o[VEC];
+        LdV<T, VEC>::ld(dy + v * VEC, d);
+        LdV<T, VEC>::ld(x + v * VEC, e);
+        if (RELU && HAVE_Y) LdV<T, VEC>::ld(y + v * VEC, o);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float g = d[k];
+            if (RELU) {
+                const float act = HAVE_Y ? o[k] : fmaf(e[k], alpha[k], beta[k]);
+                g = (act > 0.f) ? g : 0.f;
+            }
+            acc[0][k] += g;
+            acc[1][k] += g * (e[k] - mu[k]);   // invstd is applied once per channel in the finalize
+        }
+    }
+    block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+}
+
+template <typename T, bool RELU, bool HAVE_Y>
+__global__ __launch_bounds__(BLOCK) void bwd_reduce_generic_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                   const T* __restrict__ y, int64_t M, int C,
+                                                                   const float* __restrict__ stats,
+                                                                   float* __restrict__ ws) {
+    const int G = gridDim.x;
+    const int64_t rows_per = (M + G - 1) / G;
+    const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        const float mu = stats[c], alpha = stats[2 * C + c], beta = stats[3 * C + c];
+        float sg = 0.f, sgx = 0.f;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t i = r * C + c;
+            const float e = Elt<T>::ld(x + i);
+            float g = Elt<T>::ld(dy + i);
+            if (RELU) {
+                const float act = HAVE_Y ? Elt<T>::ld(y + i) : fmaf(e, alpha, beta);
+                g = (act > 0.f) ? g : 0.f;
+            }
+            sg += g;
+            sgx += g * (e - mu);
+        }
+        ws[((int64_t)0 * C + c) * G + blockIdx.x] = sg;
+        ws[((int64_t)1 * C + c) * G + blockIdx.x] = sgx;
+    }
+}
+
+// ---- backward 2: dx = g*alpha + (x-mean)*B + D (+ d_residual = g) ---------------------------------------------
+template <typename T, int VEC, bool RELU, bool HAVE_Y, bool DRES>
+__global__ __launch_bounds__(BLOCK) void bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const T* __restrict__ y, T* __restrict__ dx,
+                                                          T* __restrict__ dres, int64_t nvec, int CV, int C,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ coef) {
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float mu[VEC], alpha[VEC], beta[VEC], B[VEC], D[VEC];
+    ld_coef<VEC>(stats, c0, mu);
+    ld_coef<VEC>(stats + 2 * C, c0, alpha);
+    if (RELU && !HAVE_Y) ld_coef<VEC>(stats + 3 * C, c0, beta);
+    ld_coef<VEC>(coef, c0, B);
+    ld_coef<VEC>(coef + C, c0, D);
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float d[VEC], e[VEC], o[VEC];
+        LdV<T, VEC>::ld(dy + v * VEC, d);
+        LdV<T, VEC>::ld(x + v * VEC, e);
+        if (RELU && HAVE_Y) LdV<T, VEC>::ld(y + v * VEC, o);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float g = d[k];
+            if (RELU) {
+                const float act = HAVE_Y ? o[k] : fmaf(e[k], alpha[k], beta[k]);
+                g = (act > 0.f) ? g : 0.f;
+            }
+            d[k] = g;
+            e[k] = fmaf(g, alpha[k], fmaf(e[k] - mu[k], B[k], D[k]));
+        }
+        LdV<T, VEC>::st(dx + v * VEC, e);
+        if (DRES) LdV<T, VEC>::st(dres + v * VEC, d);
+    }
+}
+
+template <typename T, bool RELU, bool HAVE_Y, bool DRES>
+__global__ __launch_bounds__(BLOCK) void bwd_apply_generic_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ dx,
+    T* __restrict__ dres, int64_t total, int C, const float* __restrict__ stats, const float* __restrict__ coef) {
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (int64_t)gridDim.x * BLOCK) {
+        const int c = (int)(i % C);
+        const float mu = stats[c], alpha = stats[2 * C + c], beta = stats[3 * C + c];
+        const float e = Elt<T>::ld(x + i);
+        float g = Elt<T>::ld(dy + i);
+        if (RELU) {
+            const float act = HAVE_Y ? Elt<T>::ld(y + i) : fmaf(e, alpha, beta);
+            g = (act > 0.f) ? g : 0.f;
+        }
+        Elt<T>::st(dx + i, fmaf(g, alpha, fmaf(e - mu, coef[c], coef[C + c])));
+        if (DRES) Elt<T>::st(dres + i, g);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+struct Plan {
+    bool vec;      // vector mapping usable
+    int CV;        // channel vectors per row
+    int64_t nvec;  // total vectors
+    int G;         // blocks == partials per channel
+    double tensor_bytes;
+};
+
+template <typename T>
+bool make_plan(int64_t M, int64_t C, std::initializer_list<const void*> ptrs, Plan& p) {
+    constexpr int NV = Elt<T>::VEC;
+    if (M <= 0 || C <= 0 || C > (1 << 20)) return false;
+    bool ok = (C % NV == 0) && (C / NV <= BLOCK) && (BLOCK % (C / NV) == 0);
+    for (const void* q : ptrs)
+        if (q && !aligned(q, 16)) ok = false;
+    p.vec = ok;
+    p.CV = ok ? (int)(C / NV) : 0;
+    p.nvec = ok ? M * (C / NV) : 0;
+    int64_t work = ok ? (p.nvec + BLOCK - 1) / BLOCK : (M + 15) / 16;  // >= 1 vector/thread or >= 16 rows/block
+    int64_t G = (work + 3) / 4;                                           // ~4 iterations per thread
+    if (G > MAX_G) G = MAX_G;
+    if (G < 1) G = 1;
+    p.G = (int)G;
+    p.tensor_bytes = (double)M * (double)C * sizeof(T);
+    return true;
+}
+
+static inline int apply_grid(const Plan& p, int64_t total) {
+    // ~4 vectors per thread: amortises the per-thread coefficient loads, still >= 2 blocks per CU on the big tensors
+    return grid_for(p.vec ? (p.nvec + 3) / 4 : total, BLOCK, 2048);
+}
+
+template <typename T>
+int run_stats(const Plan& p, const T* x_, int64_t M, int64_t C, float eps, float momentum, const float* weight,
+              const float* bias, float* ws, float* stats, float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
+    {
+        AFAN_PROF("bn_nhwc_stats_kernel", p.tensor_bytes, st);
+        if (p.vec) stats_kernel<T, Elt<T>::VEC><<<p.G, BLOCK, 0, st>>>(x_, p.nvec, p.CV, (int)C, ws);
+        else stats_generic_kernel<T><<<p.G, BLOCK, 0, st>>>(x_, M, (int)C, ws);
+    }
+    AFAN_LAUNCH_CHECK();
+    AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
+    finalize_kernel<T, 0><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(ws, p.G, (int)C, x_, 1.0f / (float)M, (float)M, eps,
+                                                                      momentum, weight, bias, stats, nullptr, rmean,
+                                                                      rvar, nbt, nullptr, nullptr, 0);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// stats: [4][C] = mean, invstd, alpha, beta.  train: computed here; eval: mean/invstd given, alpha/beta derived.
+template <typename T>
+int forward(const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float momentum,
+            const float* weight, const float* bias, int relu, float* ws, float* stats, const float* mean_in,
+            const float* invstd_in, float* rmean, float* rvar, int64_t* nbt, bool train, hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {x, res, y}, p)) return AFAN_ESHAPE;
+    p.vec = p.vec && aligned(stats, 16);
+    constexpr int NV = Elt<T>::VEC;
+    const T* x_ = (const T*)x; const T* r_ = (const T*)res; T* y_ = (T*)y;
+    if (train) {
+        int e = run_stats<T>(p, x_, M, C, eps, momentum, weight, bias, ws, stats, rmean, rvar, nbt, st);
+        if (e) return e;
+    } else {
+        AFAN_PROF("bn_nhwc_coef_kernel", 24.0 * C, st);
+        coef_kernel<<<(unsigned)((C + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>((int)C, mean_in, invstd_in, weight, bias, stats);
+        AFAN_LAUNCH_CHECK();
+    }
+    AFAN_PROF("bn_nhwc_apply_kernel", p.tensor_bytes * (res ? 3 : 2), st);
+    const int grid = apply_grid(p, M * C);
+#define AFAN_GO(RES, RELU)                                                                                         \
+    do {                                                                                                           \
+        if (p.vec) apply_kernel<T, NV, RES, RELU><<<grid, BLOCK, 0, st>>>(x_, r_, y_, p.nvec, p.CV, (int)C, stats); \
+        else apply_generic_kernel<T, RES, RELU><<<grid, BLOCK, 0, st>>>(x_, r_, y_, M * C, (int)C, stats);          \
+    } while (0)
+    if (res) { if (relu) AFAN_GO(true, true); else AFAN_GO(true, false); }
+    else { if (relu) AFAN_GO(false, true); else AFAN_GO(false, false); }
+#undef AFAN_GO
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+template <typename T>
+int stats_only(const void* x, int64_t M, int64_t C, float eps, float momentum, float* ws, float* stats,
+               float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {x}, p)) return AFAN_ESHAPE;
+    return run_stats<T>(p, (const T*)x, M, C, eps, momentum, nullptr, nullptr, ws, stats, rmean, rvar, nbt, st);
+}
+
+template <typename T>
+int backward(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
+             const float* stats, int relu, float* ws, float* dweight, float* dbias, int accumulate, hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {dy, x, y, dx, dres}, p)) return AFAN_ESHAPE;
+    p.vec = p.vec && aligned(stats, 16);
+    constexpr int NV = Elt<T>::VEC;
+    const T* dy_ = (const T*)dy; const T* x_ = (const T*)x; const T* y_ = (const T*)y;
+    float* coef = ws + (int64_t)2 * C * MAX_G;  // [2][C] after the partials (16-byte aligned: C*MAX_G*8 bytes)
+    {
+        AFAN_PROF("bn_nhwc_bwd_reduce_kernel", p.tensor_bytes * ((relu && y) ? 3 : 2), st);
+#define AFAN_RED(RELU, HY)                                                                                        \
+    do {                                                                                                          \
+        if (p.vec) bwd_reduce_kernel<T, NV, RELU, HY><<<p.G, BLOCK, 0, st>>>(dy_, x_, y_, p.nvec, p.CV, (int)C, stats, ws); \
+        else bwd_reduce_generic_kernel<T, RELU, HY><<<p.G, BLOCK, 0, st>>>(dy_, x_, y_, M, (int)C, stats, ws);      \
+    } while (0)
+        if (!relu) AFAN_RED(false, false);
+        else if (y) AFAN_RED(true, true);
+        else AFAN_RED(true, false);
+#undef AFAN_RED
+    }
+    AFAN_LAUNCH_CHECK();
+    {
+        AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
+        finalize_kernel<T, 1><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
+            ws, p.G, (int)C, nullptr, 1.0f / (float)M, (float)M, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(stats),
+            coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate);
+    }
+    AFAN_LAUNCH_CHECK();
+    const int grid = apply_grid(p, M * C);
+    AFAN_PROF("bn_nhwc_bwd_apply_kernel", p.tensor_bytes * (3 + ((relu && y) ? 1 : 0) + (dres ? 1 : 0)), st);
+#define AFAN_APP(RELU, HY, DR)                                                                                    \
+    do {                                                                                                          \
+        if (p.vec) bwd_apply_kernel<T, NV, RELU, HY, DR><<<grid, BLOCK, 0, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, p.nvec, p.CV, (int)C, stats, coef); \
+        else bwd_apply_generic_kernel<T, RELU, HY, DR><<<grid, BLOCK, 0, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, M * C, (int)C, stats, coef); \
+    } while (0)
+    if (!relu) { if (dres) AFAN_APP(false, false, true); else AFAN_APP(false, false, false); }
+    else if (y) { if (dres) AFAN_APP(true, true, true); else AFAN_APP(true, true, false); }
+    else { if (dres) AFAN_APP(true, false, true); else AFAN_APP(true, false, false); }
+#undef AFAN_APP
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// entry points used by afan_bn.hip's extern "C" dispatch (dtype: 0 = f32, 1 = bf16)
+int fwd(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom, const float* w,
+        const float* b, int relu, float* ws, float* stats, const float* mean_in, const float* invstd_in, float* rm,
+        float* rv, int64_t* nbt, bool train, hipStream_t st) {
+    return dtype == AFAN_F32
+               ? forward<float>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st)
+               : forward<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st);
+}
+int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, float* ws, float* stats_out, float* rm,
+          float* rv, int64_t* nbt, hipStream_t st) {
+    return dtype == AFAN_F32 ? stats_only<float>(x, M, C, eps, mom, ws, stats_out, rm, rv, nbt, st)
+                             : stats_only<uint16_t>(x, M, C, eps, mom, ws, stats_out, rm, rv, nbt, st);
+}
+int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
+        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st) {
+    return dtype == AFAN_F32 ? backward<float>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st)
+                             : backward<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st);
+}
+// partials [2][C][MAX_G] + coef [2][C] + eval-mode stats [4][C]
+int64_t workspace_floats(int64_t c) { return c > 0 ? 2 * c * MAX_G + 2 * c + 4 * c : 0; }
+
+}  // namespace afan_nhwc

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import AFAN_BF16, AFAN_F32, AfanLibraryError, check
+from ._lib import AFAN_BF16, AFAN_F32, AFAN_NCHW, AFAN_NHWC, AfanLibraryError, check
 
 _DT = {torch.float32: AFAN_F32, torch.bfloat16: AFAN_BF16}
 _ws_cache = {}
@@ -19,11 +19,29 @@ def _need(t, name, dtype=None):
     if t.device.type != "cuda":
         raise AfanLibraryError(f"{name}: tensor is on '{t.device}'. The A-FAN kernels are MI355X-only; "
                                "there is no CPU path (the CPU restatement under oracle/ is test infrastructure).")
-    if not t.is_contiguous():
-        raise ValueError(f"{name}: tensor must be contiguous (dense NCHW)")
+    if not _dense(t):
+        raise ValueError(f"{name}: tensor must be dense (contiguous NCHW or channels_last)")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     return t
+
+
+def _dense(t):
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def layout_of(t):
+    """AFAN_NHWC for a channels_last 4-D tensor, else AFAN_NCHW (degenerate shapes count as NCHW)."""
+    if t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last):
+        return AFAN_NHWC
+    return AFAN_NCHW
+
+
+def _same_layout(ref, *others):
+    for o in others:
+        if o is not None and ref.numel() > 0 and (o.shape != ref.shape or o.stride() != ref.stride()):
+            raise ValueError("operands must share shape and memory layout (strides): "
+                             f"{tuple(ref.shape)}/{ref.stride()} vs {tuple(o.shape)}/{o.stride()}")
 
 
 def _ptr(t):
@@ -68,6 +86,7 @@ def pgd_step_(x_adv, grad, gamma, x_clean=None, eps=0.0, clip=False, shadow=None
             raise ValueError("x_clean must match x_adv")
     if shadow is not None:
         _need(shadow, "shadow", torch.bfloat16)
+    _same_layout(x_adv, grad, x_clean if clip else None, shadow)
     check(lib.afan_pgd_step(_ptr(x_adv), _ptr(grad), _DT[grad.dtype], _ptr(x_clean) if clip else None,
                             _ptr(shadow), x_adv.numel(), float(gamma), float(eps), int(bool(clip)),
                             _stream(x_adv)), "afan_pgd_step")
@@ -95,6 +114,7 @@ def pgd_step_norms_(x_adv, grad, gamma, x_clean, eps=0.0, clip=False, shadow=Non
         raise TypeError("grad/x_clean must match x_adv")
     if shadow is not None:
         _need(shadow, "shadow", torch.bfloat16)
+    _same_layout(x_adv, grad, x_clean, shadow)
     batch = x_adv.shape[0]
     per = x_adv.numel() // max(batch, 1)
     out = torch.empty(2, batch, dtype=torch.float32, device=x_adv.device)
@@ -113,6 +133,7 @@ def perturb_norms(x_adv, x_clean):
     _need(x_clean, "x_clean", torch.float32)
     if x_clean.numel() != x_adv.numel():
         raise ValueError("x_clean must match x_adv")
+    _same_layout(x_adv, x_clean)
     batch = x_adv.shape[0]
     per = x_adv.numel() // max(batch, 1)
     out = torch.empty(2, batch, dtype=torch.float32, device=x_adv.device)
@@ -133,6 +154,9 @@ def axpy_noise_(x_adv, u, eps, shadow=None):
         raise ValueError("u must match x_adv")
     if shadow is not None:
         _need(shadow, "shadow", torch.bfloat16)
+    _same_layout(x_adv, shadow)
+    if u.shape == x_adv.shape and u.stride() != x_adv.stride():
+        u = u.contiguous(memory_format=torch.channels_last) if layout_of(x_adv) == AFAN_NHWC else u.contiguous()
     check(lib.afan_axpy_noise(_ptr(x_adv), _ptr(u), x_adv.numel(), float(eps), _ptr(shadow),
                               _stream(x_adv)), "afan_axpy_noise")
     return x_adv
@@ -142,8 +166,9 @@ def cast_bf16(src, out=None):
     lib = _lib.load()
     _need(src, "src", torch.float32)
     if out is None:
-        out = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+        out = torch.empty_like(src, dtype=torch.bfloat16)
     _need(out, "out", torch.bfloat16)
+    _same_layout(src, out)
     check(lib.afan_cast_bf16(_ptr(src), _ptr(out), src.numel(), _stream(src)), "afan_cast_bf16")
     return out
 
@@ -155,6 +180,8 @@ def mix_feature(clean, adv, eps=1e-5):
     _need(adv, "adv", clean.dtype)
     if clean.dtype not in _DT or clean.shape != adv.shape:
         raise TypeError("clean/adv must be fp32 or bf16 tensors of the same shape")
+    if layout_of(clean) != AFAN_NCHW or layout_of(adv) != AFAN_NCHW:
+        clean, adv = clean.contiguous(), adv.contiguous()   # TODO(N1): channels-last mix_feature kernel
     n, c, hw = _nchw(clean)
     out = torch.empty_like(clean)
     check(lib.afan_mix_feature(_ptr(clean), _ptr(adv), _ptr(out), n, c, hw, float(eps), _DT[clean.dtype],
@@ -169,6 +196,7 @@ def lerp_points(x, y, number):
     _need(y, "y", torch.float32)
     if x.shape != y.shape:
         raise ValueError("x/y shape mismatch")
+    _same_layout(x, y)
     k = number - 2
     if k <= 0:
         return []
@@ -176,41 +204,45 @@ def lerp_points(x, y, number):
         raise ValueError("at most 10 sample points")
     percent = 1.0 / (number - 1)  # python double, as the reference
     w = (C.c_float * k)(*[i * percent for i in range(1, number - 1)])
-    out = torch.empty((k,) + tuple(x.shape), dtype=torch.float32, device=x.device)
-    check(lib.afan_lerp_points(_ptr(x), _ptr(y), _ptr(out), x.numel(), w, k, _stream(x)), "afan_lerp_points")
-    return [out[i] for i in range(k)]
+    # k dense blocks of x.numel() elements, each carrying x's own strides
+    flat = torch.empty(k * x.numel(), dtype=torch.float32, device=x.device)
+    out = [flat[i * x.numel():(i + 1) * x.numel()].as_strided(x.shape, x.stride()) for i in range(k)]
+    check(lib.afan_lerp_points(_ptr(x), _ptr(y), _ptr(flat), x.numel(), w, k, _stream(x)), "afan_lerp_points")
+    return out
 
 
 # ------------------------------------------------------------------------------------- BatchNorm
 def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None):
+    """Per-channel batch mean and 1/sqrt(var_biased + eps) (optionally updating running statistics)."""
     lib = _lib.load()
     _need(x, "x")
     n, c, hw = _nchw(x)
-    mean = torch.empty(c, dtype=torch.float32, device=x.device)
-    invstd = torch.empty_like(mean)
+    stats = torch.empty(4, c, dtype=torch.float32, device=x.device)
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
-    check(lib.afan_bn_stats(_ptr(x), _DT[x.dtype], n, c, hw, float(eps), float(momentum), _ptr(ws), _ptr(mean),
-                            _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(num_batches),
-                            _stream(x)), "afan_bn_stats")
-    return mean, invstd
+    check(lib.afan_bn_stats(_ptr(x), _DT[x.dtype], layout_of(x), n, c, hw, float(eps), float(momentum), _ptr(ws),
+                            _ptr(stats), _ptr(running_mean), _ptr(running_var), _ptr(num_batches), _stream(x)),
+          "afan_bn_stats")
+    return stats[0], stats[1]
 
 
 def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches):
+    """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward)."""
     lib = _lib.load()
     _need(x, "x")
     if x.dtype not in _DT:
         raise TypeError("x must be fp32 or bf16")
     if residual is not None:
         _need(residual, "residual", x.dtype)
+        _same_layout(x, residual)
     n, c, hw = _nchw(x)
     y = torch.empty_like(x)
-    stats = torch.empty(2, c, dtype=torch.float32, device=x.device)
+    stats = torch.empty(4, c, dtype=torch.float32, device=x.device)
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
-    check(lib.afan_bn_train_forward(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, float(eps),
-                                    float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws),
-                                    _ptr(stats[0]), _ptr(stats[1]), _ptr(running_mean), _ptr(running_var),
-                                    _ptr(num_batches), _stream(x)), "afan_bn_train_forward")
-    return y, stats[0], stats[1]
+    check(lib.afan_bn_train_forward(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, float(eps),
+                                    float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _ptr(stats),
+                                    _ptr(running_mean), _ptr(running_var), _ptr(num_batches), _stream(x)),
+          "afan_bn_train_forward")
+    return y, stats
 
 
 def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
@@ -218,28 +250,31 @@ def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
     _need(x, "x")
     if residual is not None:
         _need(residual, "residual", x.dtype)
+        _same_layout(x, residual)
     n, c, hw = _nchw(x)
     y = torch.empty_like(x)
-    check(lib.afan_bn_apply(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, _ptr(mean), _ptr(invstd),
-                            _ptr(weight), _ptr(bias), int(bool(relu)), _stream(x)), "afan_bn_apply")
+    ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
+    check(lib.afan_bn_apply(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, _ptr(mean),
+                            _ptr(invstd), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _stream(x)),
+          "afan_bn_apply")
     return y
 
 
-def bn_backward(dy, x, y, mean, invstd, weight, bias, relu, want_dres, dweight=None, dbias=None,
-                accumulate=False):
+def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False):
     """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given."""
     lib = _lib.load()
     _need(dy, "dy", x.dtype)
     _need(x, "x")
     if y is not None:
         _need(y, "y", x.dtype)
+    _same_layout(x, dy, y)
     n, c, hw = _nchw(x)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
-    check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
-                               _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws),
-                               _ptr(dweight), _ptr(dbias), int(bool(accumulate)), _stream(x)), "afan_bn_backward")
+    check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], layout_of(x), n, c, hw,
+                               _ptr(stats), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _ptr(dweight),
+                               _ptr(dbias), int(bool(accumulate)), _stream(x)), "afan_bn_backward")
     return dx, dres
 
 
@@ -257,12 +292,16 @@ def sgd_step_(param, grad, momentum_buf, lr_dev, momentum, weight_decay, grad_sc
                             _stream(param)), "afan_sgd_step")
 
 
-def normalize_nchw(x, mean, std, out_dtype=torch.float32):
+def normalize_nchw(x, mean, std, out_dtype=torch.float32, channels_last=False):
+    """(x - mean[c]) / std[c] of an NCHW fp32 image batch; output optionally bf16 and/or channels_last."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
+    if layout_of(x) != AFAN_NCHW:
+        x = x.contiguous()
     n, c, hw = _nchw(x)
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    check(lib.afan_normalize_nchw(_ptr(x), _ptr(y), _DT[out_dtype], n, c, hw, _ptr(mean), _ptr(std),
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device,
+                    memory_format=torch.channels_last if (channels_last and x.dim() == 4) else torch.contiguous_format)
+    check(lib.afan_normalize_nchw(_ptr(x), _ptr(y), _DT[out_dtype], layout_of(y), n, c, hw, _ptr(mean), _ptr(std),
                                   _stream(x)), "afan_normalize_nchw")
     return y
 

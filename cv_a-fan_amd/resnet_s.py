@@ -54,8 +54,24 @@ def _to_compute(x, dtype):
     if x.dtype == dtype:
         return x
     if x.dtype == torch.float32 and dtype == torch.bfloat16:
-        return _CastFn.apply(x.contiguous())
+        return _CastFn.apply(_dense(x))
     return x.to(dtype)
+
+
+def _dense(t):
+    """Dense NCHW or dense channels_last, whichever `t` already is (copy only if it is neither)."""
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+        return t
+    return t.contiguous()
+
+
+def _like_layout(t, ref):
+    """`t` with `ref`'s memory layout (BN operands and incoming gradients must share strides)."""
+    if t.stride() == ref.stride():
+        return t
+    if ref.dim() == 4 and ops.layout_of(ref) == ops.AFAN_NHWC:
+        return t.contiguous(memory_format=torch.channels_last)
+    return t.contiguous()
 
 
 class _ConvFn(torch.autograd.Function):
@@ -71,7 +87,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w_lp = ctx.saved_tensors
         mask = [ctx.needs_input_grad[0], ctx.want_wgrad and ctx.needs_input_grad[1], False]
-        gx, gw, _ = torch.ops.aten.convolution_backward(gy.contiguous(), x, w_lp, None, ctx.stride, ctx.padding,
+        gx, gw, _ = torch.ops.aten.convolution_backward(_dense(gy), x, w_lp, None, ctx.stride, ctx.padding,
                                                         (1, 1), False, (0, 0), 1, mask)
         if gw is not None and gw.dtype != torch.float32:
             gw = gw.float()
@@ -83,24 +99,24 @@ class _BNTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad):
-        x = x.contiguous()
+        x = _dense(x)
         if residual is not None:
-            residual = residual.contiguous()
-        y, mean, invstd = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt)
+            residual = _like_layout(residual, x)
+        y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt)
         ctx.relu, ctx.has_res, ctx.want_pgrad = relu, residual is not None, want_pgrad
         # the ReLU mask is recomputed from x when there is no residual; otherwise y carries it
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, mean, invstd, weight, bias)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats, weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, mean, invstd, weight, bias = ctx.saved_tensors
+        x, y, stats, weight, bias = ctx.saved_tensors
         want_p = ctx.want_pgrad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dw = db = None
         if want_p:
             dwb = torch.empty(2, x.shape[1], dtype=torch.float32, device=x.device)
             dw, db = dwb[0], dwb[1]
-        dx, dres = ops.bn_backward(gy.contiguous(), x, y, mean, invstd, weight, bias, ctx.relu,
+        dx, dres = ops.bn_backward(_like_layout(gy, x), x, y, stats, weight, bias, ctx.relu,
                                    ctx.has_res and ctx.needs_input_grad[3], dw, db)
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
@@ -115,11 +131,12 @@ class NormalizeByChannelMeanStd(nn.Module):
         self.register_buffer("mean", torch.tensor(mean, dtype=torch.float32))
         self.register_buffer("std", torch.tensor(std, dtype=torch.float32))
         self.out_dtype = torch.float32
+        self.channels_last = False
 
     def forward(self, x):
         if x.requires_grad:
             raise NotImplementedError("gradients w.r.t. the input image are not on the A-FAN feature path")
-        return ops.normalize_nchw(x.contiguous().float(), self.mean, self.std, self.out_dtype)
+        return ops.normalize_nchw(x.contiguous().float(), self.mean, self.std, self.out_dtype, self.channels_last)
 
 
 class Conv2d(nn.Conv2d):
@@ -160,8 +177,9 @@ class BatchNorm2d(nn.BatchNorm2d):
                                           "runs PGD and the joint step in train mode, main_perturb.py:159)")
         with torch.no_grad():
             invstd = torch.rsqrt(self.running_var + self.eps)
-            return ops.bn_apply(x.contiguous(), self.running_mean, invstd, self.weight, self.bias,
-                                None if residual is None else residual.contiguous(), relu)
+            x = _dense(x)
+            return ops.bn_apply(x, self.running_mean, invstd, self.weight, self.bias,
+                                None if residual is None else _like_layout(residual, x), relu)
 
     def forward(self, x):
         return self.fused(x)
@@ -233,6 +251,16 @@ class ResNet(nn.Module):
             if isinstance(m, (nn.Linear, nn.Conv2d)):
                 nn.init.kaiming_normal_(m.weight)
         self.compute_dtype = torch.float32
+        self.channels_last = False
+
+    def set_channels_last(self, on=True):
+        """Keep activations (and, with a ParamArena, conv weights) channels-last: the layout the MFMA convolutions
+        consume without transposes.  Logical shapes stay NCHW, so the slice protocol and PGD are unchanged."""
+        self.channels_last = bool(on)
+        for m in self.modules():
+            if isinstance(m, NormalizeByChannelMeanStd):
+                m.channels_last = self.channels_last
+        return self
 
     @property
     def layer_number(self):
@@ -252,6 +280,9 @@ class ResNet(nn.Module):
 
     def forward(self, x, end_point=34, start_point=0):
         layers = list(self.sequential_model[start_point:end_point])
+        if self.channels_last and x.dim() == 4 and x.is_floating_point():
+            x = x if x.is_contiguous(memory_format=torch.channels_last) else \
+                x.contiguous(memory_format=torch.channels_last)   # no-op inside the step: tensors already are
         i, n = 0, len(layers)
         while i < n:
             L = layers[i]

@@ -27,13 +27,19 @@ typedef void* afan_stream_t;
 /* element types of activation / gradient buffers */
 enum { AFAN_F32 = 0, AFAN_BF16 = 1 };
 
+/* memory layout of an activation tensor of logical shape [N, C, H, W]:
+ * AFAN_NCHW = dense planes (the reference's layout), AFAN_NHWC = channels-last, one dense [N*H*W][C] matrix
+ * (what the bf16 MFMA backbone uses internally; torch calls it memory_format=channels_last). */
+enum { AFAN_NCHW = 0, AFAN_NHWC = 1 };
+
 /* argument errors (negative so they never collide with hipError_t) */
 enum {
     AFAN_OK = 0,
     AFAN_EDTYPE = -1,  /* unknown dtype code */
     AFAN_EALIGN = -2,  /* pointer not aligned to its element type */
     AFAN_ESHAPE = -3,  /* non-positive / inconsistent sizes */
-    AFAN_ENULL = -4    /* required pointer is NULL */
+    AFAN_ENULL = -4,   /* required pointer is NULL */
+    AFAN_ELAYOUT = -5  /* unknown layout code */
 };
 
 /* Library identification: version = 10000*major + 100*minor + patch; arch string is "gfx950". */
@@ -98,47 +104,50 @@ int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, cons
                      int n_interior, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * BatchNorm, training mode (per-channel moments over N*HW) — the "feature-norm stats" the backbone
- * runs K+2 times per iteration in the tail and twice in the head (main_perturb.py:173,195-196 through
- * torch.nn.BatchNorm2d in resnet_s.py:52-55,88).
+ * BatchNorm, training mode (per-channel moments over N*H*W) — the "feature-norm stats" the backbone runs
+ * K+2 times per iteration in the tail and twice in the head (main_perturb.py:173,195-196 through
+ * torch.nn.BatchNorm2d in resnet_s.py:52-55,88).  Both layouts; fp32 or bf16 activations; fp32 statistics.
  *
- * afan_bn_stats: partial (count, mean, M2) per (channel, slice) then a finalize launch producing
- *   mean[C], invstd[C] = 1/sqrt(var_biased + eps) and, if running_mean != NULL, the running-stat
- *   update  r <- (1-momentum)*r + momentum*batch  with the UNBIASED variance, and ++(*num_batches).
- * workspace: afan_bn_workspace_floats(c) floats.
+ * A per-layer statistics block `stats` is 4*C floats: [mean | invstd | alpha | beta] with
+ *   invstd = 1/sqrt(var_biased + eps), alpha = invstd*weight, beta = bias - mean*alpha   (y = x*alpha + beta).
+ * (The NCHW kernels fill and read only mean/invstd; the NHWC kernels use all four, 16-byte aligned.)
+ * workspace: afan_bn_workspace_floats(c) floats, private to the stream.  No float atomics: bitwise reproducible.
+ *
+ * afan_bn_stats: statistics only (+ running-stat update  r <- (1-momentum)*r + momentum*batch  with the UNBIASED
+ *   variance, and ++(*num_batches), when running_mean != NULL).
  */
 int64_t afan_bn_workspace_floats(int64_t c);
-int afan_bn_stats(const void* x, int dtype, int64_t n, int64_t c, int64_t hw, float eps,
-                  float momentum, float* workspace, float* mean, float* invstd, float* running_mean,
-                  float* running_var, int64_t* num_batches, afan_stream_t stream);
+int afan_bn_stats(const void* x, int dtype, int layout, int64_t n, int64_t c, int64_t hw, float eps,
+                  float momentum, float* workspace, float* stats, float* running_mean, float* running_var,
+                  int64_t* num_batches, afan_stream_t stream);
 
-/* Fused training forward: stats launch + (fold, normalise, affine, [+residual], [ReLU]) launch.
- *   y = [relu]( (x-mean)*invstd*weight + bias [+ residual] )
- * Saves mean/invstd for the backward, updates running stats (if given) and ++(*num_batches).
- * x,y,residual: `dtype` [N,C,HW]; weight/bias (nullable = 1/0) and all statistics fp32 [C]. */
-int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
-                          int64_t hw, float eps, float momentum, const float* weight, const float* bias,
-                          int relu, float* workspace, float* save_mean, float* save_invstd,
+/* Fused training forward:  y = [relu]( (x-mean)*invstd*weight + bias [+ residual] ), statistics saved in
+ * save_stats for the backward, running stats updated.  x,y,residual: `dtype`, `layout`, [N,C,HW];
+ * weight/bias nullable (= 1/0). */
+int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n,
+                          int64_t c, int64_t hw, float eps, float momentum, const float* weight,
+                          const float* bias, int relu, float* workspace, float* save_stats,
                           float* running_mean, float* running_var, int64_t* num_batches,
                           afan_stream_t stream);
 
-/* Same transform with GIVEN statistics (eval mode: mean = running_mean, invstd = rsqrt(running_var+eps)). */
-int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
-                  int64_t hw, const float* mean, const float* invstd, const float* weight,
-                  const float* bias, int relu, afan_stream_t stream);
+/* Same transform with GIVEN statistics (eval mode: mean = running_mean, invstd = rsqrt(running_var+eps)).
+ * workspace is required for AFAN_NHWC (may be NULL for AFAN_NCHW). */
+int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n, int64_t c,
+                  int64_t hw, const float* mean, const float* invstd, const float* weight, const float* bias,
+                  int relu, float* workspace, afan_stream_t stream);
 
-/* Backward of the fused training forward (two launches, same (slice, channel) mapping).
+/* Backward of the fused training forward.
  *   g   = dy * (act > 0) when relu, else dy;  act = y if y != NULL, else recomputed from x (no residual)
  *   sum_g[c] = sum g ;  sum_gx[c] = sum g * xhat ;  M = N*HW
  *   dx  = weight*invstd * ( g - sum_g/M - xhat*sum_gx/M )
  *   d_residual = g (written iff d_residual != NULL; may alias dy)
  * dweight[c] = sum_gx[c], dbias[c] = sum_g[c] (added into them iff accumulate != 0; NULL skips them —
- * the PGD inner loop only needs dx: attack_algo.py:52 `only_inputs=True`). */
-int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual,
-                     int dtype, int64_t n, int64_t c, int64_t hw, const float* mean,
-                     const float* invstd, const float* weight, const float* bias, int relu,
-                     float* workspace, float* dweight, float* dbias, int accumulate,
-                     afan_stream_t stream);
+ * the PGD inner loop only needs dx: attack_algo.py:52 `only_inputs=True`).
+ * weight/bias: the forward's (read by the NCHW kernels; the NHWC kernels take alpha/beta from save_stats). */
+int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
+                     int layout, int64_t n, int64_t c, int64_t hw, const float* save_stats,
+                     const float* weight, const float* bias, int relu, float* workspace, float* dweight,
+                     float* dbias, int accumulate, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGD with momentum over ONE flat parameter arena.  Replaces torch.optim.SGD.step as configured at
@@ -153,9 +162,9 @@ int afan_sgd_step(float* param, const float* grad, float* momentum_buf, uint16_t
                   float grad_scale, int first_step, afan_stream_t stream);
 
 /* fp32 -> bf16 (round-to-nearest-even, NaN-preserving) and per-channel input normalisation
- * (resnet_s.py:87: (x - mean[c]) / std[c]), used on the bf16 path. */
+ * (resnet_s.py:87: (x - mean[c]) / std[c]); the input image is NCHW fp32, the output may be NHWC and/or bf16. */
 int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t stream);
-int afan_normalize_nchw(const float* x, void* y, int out_dtype, int64_t n, int64_t c, int64_t hw,
+int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, int64_t n, int64_t c, int64_t hw,
                         const float* mean, const float* std, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

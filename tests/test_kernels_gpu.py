@@ -203,7 +203,8 @@ def test_bn_forward_backward_fp32_vs_c_oracle(pkg, gpu, c_oracle, shape, res, re
     xt, rt = _dev(x, gpu), (_dev(r, gpu) if res else None)
     wt, bt, rmt, rvt = _dev(w, gpu), _dev(b, gpu), _dev(rm, gpu), _dev(rv, gpu)
     nbt = torch.zeros((), dtype=torch.int64, device=gpu)
-    y, mean, invstd = pkg.ops.bn_train_forward(xt, wt, bt, rt, relu, 1e-5, 0.1, rmt, rvt, nbt)
+    y, stats = pkg.ops.bn_train_forward(xt, wt, bt, rt, relu, 1e-5, 0.1, rmt, rvt, nbt)
+    mean, invstd = stats[0], stats[1]
     assert int(nbt) == 1
     np.testing.assert_allclose(mean.cpu().numpy(), mean_ref, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(invstd.cpu().numpy(), is_ref, rtol=1e-5)
@@ -212,7 +213,7 @@ def test_bn_forward_backward_fp32_vs_c_oracle(pkg, gpu, c_oracle, shape, res, re
     np.testing.assert_allclose(y.cpu().numpy(), y_ref, rtol=1e-5, atol=3e-5)
     dwb = torch.zeros(2, c, device=gpu)
     y_for_mask = y if (relu and res) else None
-    dx, dres = pkg.ops.bn_backward(_dev(dy, gpu), xt, y_for_mask, mean, invstd, wt, bt, relu, res, dwb[0], dwb[1])
+    dx, dres = pkg.ops.bn_backward(_dev(dy, gpu), xt, y_for_mask, stats, wt, bt, relu, res, dwb[0], dwb[1])
     scale = max(1.0, float(np.abs(dw_ref).max()))
     np.testing.assert_allclose(dwb[0].cpu().numpy(), dw_ref, rtol=1e-4, atol=1e-4 * scale)
     np.testing.assert_allclose(dwb[1].cpu().numpy(), db_ref, rtol=1e-4, atol=1e-4 * scale)
@@ -256,9 +257,9 @@ def test_bn_bf16_close_to_fp32(pkg, gpu):
     torch.manual_seed(2)
     x = (torch.randn(8, 32, 16, 16) + 0.5).bfloat16()
     w, b = torch.rand(32) + 0.5, torch.randn(32)
-    y32, m32, i32 = pkg.ops.bn_train_forward(x.float().to(gpu), w.to(gpu), b.to(gpu), None, True, 1e-5, 0.1, None,
-                                             None, None)
-    y16, m16, i16 = pkg.ops.bn_train_forward(x.to(gpu), w.to(gpu), b.to(gpu), None, True, 1e-5, 0.1, None, None, None)
+    y32, s32 = pkg.ops.bn_train_forward(x.float().to(gpu), w.to(gpu), b.to(gpu), None, True, 1e-5, 0.1, None, None, None)
+    y16, s16 = pkg.ops.bn_train_forward(x.to(gpu), w.to(gpu), b.to(gpu), None, True, 1e-5, 0.1, None, None, None)
+    (m32, i32), (m16, i16) = (s32[0], s32[1]), (s16[0], s16[1])
     np.testing.assert_allclose(m16.cpu().numpy(), m32.cpu().numpy(), rtol=1e-5, atol=1e-6)  # stats are fp32 in both
     np.testing.assert_allclose(i16.cpu().numpy(), i32.cpu().numpy(), rtol=1e-5)
     np.testing.assert_allclose(y16.float().cpu().numpy(), y32.cpu().numpy(), rtol=8e-3, atol=8e-3)
@@ -306,3 +307,105 @@ def test_ops_reject_cpu_tensors_and_missing_fallback(pkg):
         pkg.ops.pgd_step_(torch.zeros(4), torch.zeros(4), 0.1)
     with pytest.raises(pkg.AfanLibraryError):
         pkg.attack_algo.PGD(torch.zeros(1, 2, 2, 2), None, model=None, gamma=0.1)
+
+
+# ------------------------------------------------------------------------- channels-last (NHWC) variants
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+NHWC_SHAPES = [(4, 16, 32, 32), (2, 64, 16, 16), (8, 512, 4, 4), (3, 304, 5, 7), (2, 3, 9, 9), (64, 128, 16, 16),
+               (2, 1024, 3, 3), (1, 8, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", NHWC_SHAPES)
+@pytest.mark.parametrize("res,relu", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_bn_nhwc_matches_nchw_kernels(pkg, gpu, shape, res, relu, dt):
+    """The channels-last kernels against the NCHW kernels (already pinned to the C oracle) on the same values."""
+    torch.manual_seed(sum(shape) + relu)
+    n, c = shape[:2]
+    x = (torch.randn(shape) * 2 + 3).to(gpu, dt)
+    r = torch.randn(shape).to(gpu, dt) if res else None
+    w, b = (torch.rand(c) + 0.5).to(gpu), torch.randn(c).to(gpu)
+    dy = torch.randn(shape).to(gpu, dt)
+    outs = []
+    for cl in (False, True):
+        conv = _cl if cl else (lambda t: t)
+        rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        xx = conv(x)
+        y, stats = pkg.ops.bn_train_forward(xx, w, b, None if r is None else conv(r), relu, 1e-5, 0.1, rm, rv, nbt)
+        mean, invstd = stats[0], stats[1]
+        assert y.stride() == xx.stride() and int(nbt) == 1
+        dwb = torch.zeros(2, c, device=gpu)
+        dx, dres = pkg.ops.bn_backward(conv(dy), xx, y if (relu and res) else None, stats, w, b, relu, res,
+                                       dwb[0], dwb[1])
+        outs.append([t.float().cpu().numpy() for t in (y, mean, invstd, rm, rv, dx, dwb)] +
+                    [dres.float().cpu().numpy() if res else None])
+    a, bb = outs
+    lo = dt == torch.bfloat16
+    tol = dict(rtol=2e-2, atol=2e-2) if lo else dict(rtol=1e-4, atol=1e-4)
+    for i, name in enumerate(["y", "mean", "invstd", "rmean", "rvar", "dx", "dwb"]):
+        stat = name in ("mean", "invstd", "rmean", "rvar")
+        t = dict(rtol=2e-5, atol=2e-6) if stat else tol
+        if name == "dwb":
+            t = dict(rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(np.abs(a[i]).max())))
+        if name in ("dx", "y") and not stat:
+            assert_close_frac(bb[i], a[i], t["rtol"], t["atol"], 1e-4, name)
+        else:
+            np.testing.assert_allclose(bb[i], a[i], err_msg=name, **t)
+    if res:
+        assert_close_frac(bb[7], a[7], 0, 0, 1e-4, "dres")
+
+
+def test_bn_nhwc_module_autograd_vs_torch(pkg, gpu):
+    torch.manual_seed(4)
+    x = torch.randn(6, 32, 10, 10) * 1.5 + 0.7
+    res = torch.randn_like(x)
+    ref_bn = torch.nn.BatchNorm2d(32)
+    ref_bn.weight.data.uniform_(0.5, 1.5)
+    ref_bn.bias.data.normal_()
+    bn = pkg.resnet_s.BatchNorm2d(32)
+    bn.load_state_dict(ref_bn.state_dict())
+    bn.to(gpu)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    yr = torch.relu(ref_bn(xr) + rr)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xg = _cl(x.to(gpu)).requires_grad_(True)
+    rg = res.to(gpu).requires_grad_(True)            # NCHW residual: converted to the conv output's layout
+    yg = bn.fused(xg, rg, True)
+    assert yg.is_contiguous(memory_format=torch.channels_last)
+    yg.backward(gy.to(gpu))                          # NCHW incoming gradient: converted too
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(rg.grad.cpu().numpy(), rr.grad.numpy())
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref_bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref_bn.running_var.numpy(), rtol=1e-5)
+
+
+def test_elementwise_kernels_accept_channels_last(pkg, gpu, c_oracle):
+    """PGD step / norms / noise are layout-agnostic as long as all operands share strides; mixed strides raise."""
+    torch.manual_seed(5)
+    x = _cl(torch.randn(3, 8, 5, 5, device=gpu))
+    g = _cl(torch.randn(3, 8, 5, 5, device=gpu))
+    xa = x.clone()
+    assert xa.stride() == x.stride()
+    pkg.ops.pgd_step_(xa, g, 0.01, x, 0.02, True)
+    ref = x.cpu().contiguous().numpy().copy()
+    c_oracle.oracle_pgd_step(ptr(ref), ptr(g.cpu().contiguous().numpy()), ptr(x.cpu().contiguous().numpy()), ref.size,
+                             np.float32(0.01), np.float32(0.02), 1)
+    np.testing.assert_array_equal(xa.cpu().numpy(), ref)
+    l2, linf = pkg.ops.perturb_norms(xa, x)
+    d = (xa - x).reshape(3, -1)
+    np.testing.assert_allclose(l2.cpu().numpy(), d.norm(dim=1).cpu().numpy(), rtol=1e-6)
+    with pytest.raises(ValueError):
+        pkg.ops.pgd_step_(xa, g.contiguous(), 0.01)
+    img = torch.rand(2, 3, 6, 6, device=gpu)
+    m, s = torch.tensor([0.4914, 0.4822, 0.4465], device=gpu), torch.tensor([0.2470, 0.2435, 0.2616], device=gpu)
+    a = pkg.ops.normalize_nchw(img, m, s)
+    b = pkg.ops.normalize_nchw(img, m, s, torch.float32, channels_last=True)
+    assert b.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_array_equal(a.cpu().numpy(), ((img - m[None, :, None, None]) / s[None, :, None, None]).cpu().numpy())

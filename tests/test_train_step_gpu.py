@@ -76,9 +76,11 @@ def test_joint_step_fp32_matches_reference(pkg, orc, gpu, case):
     sd1 = model.state_dict()
     assert int(sd1["sequential_model.2.num_batches_tracked"]) == 2
     assert int(sd1[f"sequential_model.{idx}.bn1.num_batches_tracked"]) == K + 2
+    # parameters after one lr=0.1 SGD step: gradients went through the whole (batch 2-4, train-mode BN) net
+    wtol = 2e-4 if arch == "resnet20s" else 2e-3
     for k in g.files:
         if k.startswith("sd1/") and "num_batches" not in k:
-            np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=2e-4, err_msg=k)
+            np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=wtol, err_msg=k)
     ck1 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd1.values()])
     # per-tensor abs-sum fingerprint of EVERY tensor after the SGD step (lr 0.1 applied to gradients that went
     # through the whole net, batch 2-4): a coarse "nothing is missing / mis-scaled" check
@@ -182,3 +184,34 @@ def test_state_dict_roundtrip_with_reference_layout(pkg, orc, gpu):
         a = model(x.to(gpu), end_point=34, start_point=0).cpu()
         b = ref(x, end_point=34, start_point=0)
     np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["step_r20s_k5", "step_r20s_k3_clip_rand", "step_r18_k5"])
+def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, case):
+    """Same parity bar with the backbone in its channels-last execution layout (what bench.py runs)."""
+    g = golden(case)
+    K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]
+    gamma, eps = [float(v) for v in g["gamma_eps"]]
+    arch = ARCH[case.split("_")[1]]
+    model = _build(pkg, orc, arch, gpu, sd=_sd0(golden("step_r20s_k1")) if arch == "resnet20s" else None)
+    model.set_channels_last(True)
+    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=gamma, eps=eps, perturb_idx=idx,
+                                    layer_number=ln, randinit=bool(randinit), clip=bool(clip), lr=0.1)
+    assert tr.arena.channels_last and model.sequential_model[1].weight.is_contiguous(memory_format=torch.channels_last)
+    if randinit:
+        torch.manual_seed(3)
+        _ = orc.ARCHS[arch][0]()
+        _ = torch.rand(g["x"].shape), torch.randint(0, 10, (g["x"].shape[0],))
+    r = tr.step(torch.from_numpy(g["x"]).to(gpu), torch.from_numpy(g["y"]).to(gpu))
+    assert r["x_adv"].shape == tuple(g["x_adv"].shape)          # logical NCHW at the boundary
+    for k in ("loss", "loss_adv", "loss_clean"):
+        assert abs(float(r[k]) - float(g[k])) <= LOSS_TOL * max(1.0, abs(float(g[k]))), (k, float(r[k]), float(g[k]))
+    d_got = (r["x_adv"] - r["feature_map"]).cpu().numpy()
+    assert_close_frac(d_got, g["x_adv"] - g["feature_map"], 0, 2e-6, FLIP_BOUND[arch], "perturbation")
+    np.testing.assert_allclose(r["l2"].cpu().numpy(), g["l2"], rtol=5e-3)
+    sd1 = model.state_dict()
+    assert int(sd1[f"sequential_model.{idx}.bn1.num_batches_tracked"]) == K + 2
+    wtol = 2e-4 if arch == "resnet20s" else 2e-3
+    for k in g.files:
+        if k.startswith("sd1/") and "num_batches" not in k:
+            np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=wtol, err_msg=k)
