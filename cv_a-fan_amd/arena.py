@@ -15,7 +15,7 @@ as torch.optim.SGD skips tensors whose .grad is None.
 import torch
 
 from . import ops
-from .resnet_s import Conv2d
+from .resnet_s import Conv2d, _Flags
 
 _ALIGN = 64  # floats: every tensor starts on a 256-byte boundary of the arena
 
@@ -72,6 +72,7 @@ class ParamArena:
         """Re-derive the bf16 shadow from the fp32 parameters (after load_state_dict / manual edits)."""
         if self.shadow is not None:
             ops.cast_bf16(self.param, self.shadow)
+        _Flags.weight_epoch += 1
 
     def _view(self, buf, o, p):
         flat = buf[o:o + p.numel()]
@@ -117,6 +118,7 @@ class ArenaSGD(torch.optim.Optimizer):
         a = self.arena
         ops.sgd_step_(a.param, a.grad, a.momentum_buf, a.lr, g["momentum"], g["weight_decay"], self.grad_scale,
                       a.shadow)
+        _Flags.weight_epoch += 1   # cached transposed weights (dgrad operands) are stale now
 
     def state_dict(self):
         """Layout of torch.optim.SGD(model.parameters()).state_dict() (main_perturb.py:124,132 store it): state keyed

@@ -1,0 +1,322 @@
+// Implicit-GEMM convolution for the bf16 channels-last backbone on gfx950 (MFMA 32x32x16 bf16, fp32 accumulate).
+// The A-FAN step is >95 % convolution FLOPs — 4H + (2K+6)T forward-equivalents per image — and the
+// PGD inner loop (Classification/attack_algo.py:50-52) runs the tail forward and its input-gradient K times per
+// iteration, so forward and dgrad are the two kernels that matter; both are THIS kernel with different tap lists.
+//
+// GEMM view:  Y[m, co] = sum_t sum_c  X[pixel(m) + (dh_t, dw_t), c] * W_t[co, c]
+//   m  -> (n, h', w') over an N x Hg x Wg grid of output positions; input pixel = (h'*in_s + dh_t, w'*in_s + dw_t)
+//         (zero outside the image), output pixel = (h'*out_s + out_h0, w'*out_s + out_w0)
+//   W_t -> tap t of a [rows][taps][c] weight tensor whose innermost dimension is the reduction channel
+// which covers: forward 3x3/1x1 at stride 1 or 2 (KRSC weights), dgrad at stride 1 (CRSK = transposed weights,
+// mirrored tap offsets), dgrad at stride 2 as four output-parity classes with 1/2/2/4 taps each (no multiplications
+// by the zeros a "dilated" formulation would insert).
+//
+// Tile: BM x BN outputs per 256-thread workgroup (2x2 waves, each (BM/2)x(BN/2) = 32x32 MFMA tiles), BK = 64 channels of
+// one tap per step.  Operands are staged global -> VGPR -> LDS (rows padded to 144 B: conflict-free ds_read_b128
+// fragments), double buffered, one barrier per step, next step's global loads in flight under the MFMAs.  The epilogue
+// rounds to bf16 through LDS so that every store is a 16-byte piece of a channels-last row.
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int BK = 64;           // reduction channels per step
+constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes
+constexpr int MAX_TAPS = 9;
+
+struct ConvP {
+    const uint16_t* x;
+    const uint16_t* w;
+    uint16_t* y;
+    int N, Hi, Wi, Ci;           // input tensor [N, Hi, Wi, Ci]
+    int Ho, Wo, Co;              // output tensor [N, Ho, Wo, Co]
+    int Hg, Wg;                  // grid of output positions handled by this launch
+    int in_s;                    // input coordinate = g * in_s + d
+    int out_s, out_h0, out_w0;   // output coordinate = g * out_s + out_0
+    int T;                       // number of taps
+    int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
+    int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP p) {
+    constexpr int TM = BM / 2, TN = BN / 2;          // wave tile
+    constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
+    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
+    constexpr int STAGE = (BM + BN) * LDK;           // elements per buffer
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    __shared__ int out_off[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+
+    // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each ------------------------
+    const int piece = tid & 7, row0 = tid >> 3;
+    int64_t a_base[A_ROWS];
+    uint32_t a_valid[A_ROWS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        const int64_t m = m0 + row0 + 32 * i;
+        a_base[i] = 0;
+        a_valid[i] = 0;
+        if (m < M) {
+            const int wg = (int)(m % p.Wg);
+            const int64_t t1 = m / p.Wg;
+            const int hg = (int)(t1 % p.Hg);
+            const int n = (int)(t1 / p.Hg);
+            const int hi0 = hg * p.in_s, wi0 = wg * p.in_s;
+            a_base[i] = (((int64_t)n * p.Hi + hi0) * p.Wi + wi0) * p.Ci + piece * 8;
+            uint32_t v = 0;
+            for (int t = 0; t < p.T; ++t) {
+                const int hi = hi0 + p.dh[t], wi = wi0 + p.dw[t];
+                if (hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi) v |= 1u << t;
+            }
+            a_valid[i] = v;
+        }
+    }
+    // output row offsets (elements) for the epilogue, -1 = row outside M
+    for (int r = tid; r < BM; r += THREADS) {
+        const int64_t m = m0 + r;
+        int off = -1;
+        if (m < M) {
+            const int wg = (int)(m % p.Wg);
+            const int64_t t1 = m / p.Wg;
+            const int hg = (int)(t1 % p.Hg);
+            const int n = (int)(t1 / p.Hg);
+            off = (int)((((int64_t)n * p.Ho + hg * p.out_s + p.out_h0) * p.Wo + wg * p.out_s + p.out_w0) * p.Co);
+        }
+        out_off[r] = off;
+    }
+    const int64_t b_base = (int64_t)(n0 + row0) * p.w_row_stride + piece * 8;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int chunks = p.Ci / BK;
+    const int KS = p.T * chunks;
+    u32x4 ra[A_ROWS], rb[B_ROWS];
+
+    auto gload = [&](int ks) {
+        const int t = ks / chunks, q = ks - t * chunks;
+        const int64_t a_tap = ((int64_t)p.dh[t] * p.Wi + p.dw[t]) * p.Ci + q * BK;
+        const int64_t b_tap = (int64_t)p.wofs[t] + q * BK;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((a_valid[i] >> t) & 1u) v = *reinterpret_cast<const u32x4*>(p.x + a_base[i] + a_tap);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i)
+            rb[i] = *reinterpret_cast<const u32x4*>(p.w + b_base + (int64_t)(32 * i) * p.w_row_stride + b_tap);
+    };
+    auto lstore = [&](int buf) {
+        uint16_t* A = lds + buf * STAGE;
+        uint16_t* B = A + BM * LDK;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i)
+            *reinterpret_cast<u32x4*>(A + (row0 + 32 * i) * LDK + piece * 8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i)
+            *reinterpret_cast<u32x4*>(B + (row0 + 32 * i) * LDK + piece * 8) = rb[i];
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int ks = 0; ks < KS; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < KS) gload(ks + 1);  // in flight under this step's MFMAs
+        const uint16_t* A = lds + buf * STAGE;
+        const uint16_t* B = A + BM * LDK;
+        const int frow = lane & 31, fk = (lane >> 5) * 8;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDK + kk * 16 + fk);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDK + kk * 16 + fk);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < KS) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: fp32 accumulators -> bf16 tile in LDS -> 16-byte channels-last stores ---------------------
+    constexpr int LDC = BN + 8;
+    uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wc * TN + j * 32 + (lane & 31);
+                C[row * LDC + col] = f2bf(acc[i][j][r]);
+            }
+    __syncthreads();
+    constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
+    constexpr int ROWS_PER_PASS = THREADS / PIECES;
+    const int pc = tid % PIECES, pr = tid / PIECES;
+#pragma unroll
+    for (int r = pr; r < BM; r += ROWS_PER_PASS) {
+        const int off = out_off[r];
+        if (off >= 0)
+            *reinterpret_cast<u32x4*>(p.y + (int64_t)off + n0 + pc * 8) =
+                *reinterpret_cast<const u32x4*>(C + r * LDC + pc * 8);
+    }
+}
+
+template <int BM, int BN>
+int launch(const ConvP& p, hipStream_t st) {
+    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
+    dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM));
+    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LDK * 2;
+    constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
+    constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    conv_igemm_kernel<BM, BN><<<grid, THREADS, lds, st>>>(p);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// tile choice: fill >= ~256 workgroups when the problem allows it
+int dispatch(const ConvP& p, hipStream_t st) {
+    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
+    const bool n128 = (p.Co % 128 == 0);
+    const int64_t wg_128 = ((M + 127) / 128) * (p.Co / (n128 ? 128 : 64));
+    if (n128) {
+        if (wg_128 >= 384) return launch<128, 128>(p, st);
+        return launch<64, 128>(p, st);
+    }
+    if (wg_128 >= 384) return launch<128, 64>(p, st);
+    return launch<64, 64>(p, st);
+}
+
+int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
+    if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // caller falls back for the 3-channel stem
+    if (!(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
+    if (n * hi * wi * (ci > co ? ci : co) > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit output offsets
+    return AFAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
+    return (ci % BK == 0 && co % 64 == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
+}
+
+// y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding k/2, stride 1 or 2; all bf16, channels-last.
+int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                            int64_t co, int k, int stride, afan_stream_t stream) {
+    int e = check_dims(n, hi, wi, ci, co, k, stride);
+    if (e) return e;
+    if (!x || !w || !y) return AFAN_ENULL;
+    if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 16)) return AFAN_EALIGN;
+    const int pad = k / 2;
+    ConvP p{};
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y;
+    p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
+    p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
+    p.Hg = p.Ho; p.Wg = p.Wo; p.in_s = stride; p.out_s = 1; p.out_h0 = 0; p.out_w0 = 0;
+    p.T = k * k; p.w_row_stride = (int)(k * k * ci);
+    for (int r = 0; r < k; ++r)
+        for (int s = 0; s < k; ++s) {
+            const int t = r * k + s;
+            p.dh[t] = r - pad; p.dw[t] = s - pad; p.wofs[t] = (int)(t * ci);
+        }
+    hipStream_t st = (hipStream_t)stream;
+    const double M = (double)n * p.Ho * p.Wo;
+    AFAN_PROF("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci), st);
+    return dispatch(p, st);
+}
+
+// dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w) given wt[Ci,k,k,Co] = w[Co,k,k,Ci] transposed (CRSK).
+int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                              int64_t co, int k, int stride, afan_stream_t stream) {
+    int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
+    if (e) return e;
+    if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
+    if (!dy || !wt || !dx) return AFAN_ENULL;
+    if (!aligned(dy, 16) || !aligned(wt, 16) || !aligned(dx, 16)) return AFAN_EALIGN;
+    const int pad = k / 2;
+    const int ho = (int)((hi + 2 * pad - k) / stride + 1), wo = (int)((wi + 2 * pad - k) / stride + 1);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p{};
+    p.x = (const uint16_t*)dy; p.w = (const uint16_t*)wt; p.y = (uint16_t*)dx;
+    p.N = (int)n; p.Hi = ho; p.Wi = wo; p.Ci = (int)co;      // GEMM input = dy
+    p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
+    p.w_row_stride = (int)(k * k * co);
+    const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
+    AFAN_PROF("conv_igemm_dgrad_kernel", bytes, st);
+    if (stride == 1) {
+        // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]
+        p.Hg = (int)hi; p.Wg = (int)wi; p.in_s = 1; p.out_s = 1; p.out_h0 = 0; p.out_w0 = 0;
+        p.T = k * k;
+        for (int r = 0; r < k; ++r)
+            for (int s = 0; s < k; ++s) {
+                const int t = r * k + s;
+                p.dh[t] = pad - r; p.dw[t] = pad - s; p.wofs[t] = (int)(t * co);
+            }
+        return dispatch(p, st);
+    }
+    // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
+    // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four launches, 1/2/2/4 taps for k = 3.
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            p.Hg = (int)((hi - ph + 1) / 2); p.Wg = (int)((wi - pw + 1) / 2);
+            if (p.Hg <= 0 || p.Wg <= 0) continue;
+            p.in_s = 1; p.out_s = 2; p.out_h0 = ph; p.out_w0 = pw;
+            int T = 0;
+            for (int r = 0; r < k; ++r)
+                for (int s = 0; s < k; ++s) {
+                    const int a = ph + pad - r, b = pw + pad - s;
+                    if ((a & 1) || (b & 1)) continue;
+                    p.dh[T] = a / 2; p.dw[T] = b / 2; p.wofs[T] = (int)((r * k + s) * co);
+                    ++T;
+                }
+            p.T = T;
+            if (T == 0) {
+                // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  Keep one all-invalid tap so
+                // the kernel writes zeros through its normal path.
+                p.T = 1; p.dh[0] = -(1 << 20); p.dw[0] = 0; p.wofs[0] = 0;
+            }
+            int rc = dispatch(p, st);
+            if (rc) return rc;
+        }
+    return AFAN_OK;
+}
+
+}  // extern "C"

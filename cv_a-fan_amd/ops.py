@@ -278,6 +278,49 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     return dx, dres
 
 
+# ----------------------------------------------------------------------------------- convolutions
+def conv_supported(ci, co, k, stride):
+    return bool(_lib.load().afan_conv_supported(int(ci), int(co), int(k), int(stride)))
+
+
+def _cl4(t, name):
+    _need(t, name, torch.bfloat16)
+    if t.dim() != 4 or not t.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError(f"{name}: expected a channels_last 4-D bf16 tensor")
+    return t
+
+
+def conv_fwd(x, w, stride):
+    """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last."""
+    lib = _lib.load()
+    _cl4(x, "x"), _cl4(w, "w")
+    n, ci, hi, wi = x.shape
+    co, ci2, k, k2 = w.shape
+    if ci2 != ci or k != k2:
+        raise ValueError("weight shape does not match the input")
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    y = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride, _stream(x)),
+          "afan_conv_fwd_nhwc_bf16")
+    return y
+
+
+def conv_dgrad(dy, wt, in_hw, stride):
+    """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory)."""
+    lib = _lib.load()
+    _cl4(dy, "dy"), _cl4(wt, "wt")
+    n, co, ho, wo = dy.shape
+    ci, co2, k, _ = wt.shape
+    if co2 != co:
+        raise ValueError("transposed weight shape does not match dy")
+    hi, wi = in_hw
+    dx = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _stream(dy)),
+          "afan_conv_dgrad_nhwc_bf16")
+    return dx
+
+
 # ------------------------------------------------------------------------------------------- SGD
 def sgd_step_(param, grad, momentum_buf, lr_dev, momentum, weight_decay, grad_scale=1.0, shadow=None):
     lib = _lib.load()

@@ -24,6 +24,7 @@ __all__ = ["ResNet", "BasicBlock", "resnet20", "resnet56", "resnet18", "ARCHS", 
 
 class _Flags:
     param_grads = True  # False inside PGD: only d(loss)/d(feature) is needed (attack_algo.py:52 only_inputs=True)
+    weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
 
 
 @contextlib.contextmanager
@@ -75,23 +76,49 @@ def _like_layout(t, ref):
 
 
 class _ConvFn(torch.autograd.Function):
-    """MIOpen convolution on the low-precision weight copy; wgrad is returned for the fp32 master."""
+    """Convolution on the low-precision weight copy.  bf16 channels-last tensors of supported shapes run the
+    library's implicit-GEMM MFMA kernels for forward and input-gradient (afan_conv_*_nhwc_bf16); the weight
+    gradient (3 of the step's ~24 conv-equivalents) and everything else (fp32 parity mode, the 3-channel stem) goes
+    to MIOpen through aten.  wgrad is returned for the fp32 master weight."""
 
     @staticmethod
-    def forward(ctx, x, w_master, w_lp, stride, padding, want_wgrad):
-        ctx.stride, ctx.padding, ctx.want_wgrad = stride, padding, want_wgrad
+    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad):
+        ctx.stride, ctx.padding, ctx.want_wgrad, ctx.wt_fn = stride, padding, want_wgrad, wt_fn
+        ctx.own = _own_conv_ok(x, w_lp, stride, padding)
         ctx.save_for_backward(x, w_lp)
+        if ctx.own:
+            return ops.conv_fwd(x, w_lp, stride[0])
         return torch.ops.aten.convolution(x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1)
 
     @staticmethod
     def backward(ctx, gy):
         x, w_lp = ctx.saved_tensors
-        mask = [ctx.needs_input_grad[0], ctx.want_wgrad and ctx.needs_input_grad[1], False]
-        gx, gw, _ = torch.ops.aten.convolution_backward(_dense(gy), x, w_lp, None, ctx.stride, ctx.padding,
-                                                        (1, 1), False, (0, 0), 1, mask)
+        need_gx = ctx.needs_input_grad[0]
+        need_gw = ctx.want_wgrad and ctx.needs_input_grad[1]
+        gy = _like_layout(gy, x) if x.dim() == 4 and gy.shape[2:] == x.shape[2:] else _dense(gy)
+        gx = gw = None
+        if need_gx and ctx.own and gy.is_contiguous(memory_format=torch.channels_last):
+            gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0])
+            need_gx = False
+        if need_gx or need_gw:
+            g2, gw, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, (1, 1), False,
+                                                            (0, 0), 1, [need_gx, need_gw, False])
+            if need_gx:
+                gx = g2
         if gw is not None and gw.dtype != torch.float32:
             gw = gw.float()
-        return gx, gw, None, None, None, None
+        return gx, gw, None, None, None, None, None
+
+
+def _own_conv_ok(x, w, stride, padding):
+    if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    if not w.is_contiguous(memory_format=torch.channels_last) or w.shape[2] != w.shape[3]:
+        return False
+    k = w.shape[2]
+    if stride[0] != stride[1] or padding[0] != k // 2 or padding[1] != k // 2:
+        return False
+    return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0])
 
 
 class _BNTrainFn(torch.autograd.Function):
@@ -157,9 +184,22 @@ class Conv2d(nn.Conv2d):
             self._lp_version = self.weight._version
         return self._lp
 
+    def lp_weight_t(self):
+        """[Ci, Co, k, k] channels-last (CRSK memory) copy of the low-precision weight for the dgrad kernel; rebuilt
+        when the weights change (once per SGD step: the K+2 input-gradient passes of an iteration share it)."""
+        w = self.lp_weight()
+        key = (w.data_ptr(), self.weight._version, _Flags.weight_epoch)
+        if self._wt is None or self._wt_key != key:
+            self._wt = w.detach().permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+            self._wt_key = key
+        return self._wt
+
+    _wt = None
+    _wt_key = None
+
     def forward(self, x):
         x = _to_compute(x, self.compute_dtype)
-        return _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.stride, self.padding,
+        return _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.lp_weight_t, self.stride, self.padding,
                              _Flags.param_grads)
 
 

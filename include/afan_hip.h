@@ -150,6 +150,20 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
                      float* dbias, int accumulate, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside
+ * `model(x_adv, end_point, start_point)` (attack_algo.py:50; resnet_s.py:52-54,66,72-73) and its input-gradient
+ * (attack_algo.py:52), implicit-GEMM kernels of this library.  k in {1,3}, padding k/2, stride in {1,2},
+ * Ci % 64 == 0 and Co % 64 == 0 (afan_conv_supported() tells; the 3-channel stem stays with the vendor library).
+ *   fwd  : y[N,Ho,Wo,Co]  = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci])
+ *   dgrad: dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w)  given  wt[Ci,k,k,Co] = w transposed
+ */
+int afan_conv_supported(int64_t ci, int64_t co, int k, int stride);
+int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                            int64_t co, int k, int stride, afan_stream_t stream);
+int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
+                              int64_t ci, int64_t co, int k, int stride, afan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * SGD with momentum over ONE flat parameter arena.  Replaces torch.optim.SGD.step as configured at
  * main_perturb.py:72-74 (momentum, weight_decay, no nesterov/dampening) on every tensor at once:
  *   g' = g + wd*p ;  buf = first ? g' : momentum*buf + g' ;  p -= lr*buf

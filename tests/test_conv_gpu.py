@@ -1,0 +1,62 @@
+"""Implicit-GEMM MFMA convolutions (afan_conv_*_nhwc_bf16) against torch's convolution on the same bf16 values."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # n, ci, co, h, k, stride
+    (4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 128, 128, 16, 3, 1), (2, 64, 128, 32, 1, 2),
+    (5, 128, 256, 16, 3, 2), (2, 256, 256, 8, 3, 1), (2, 256, 512, 8, 3, 2), (3, 512, 512, 4, 3, 1),
+    (2, 256, 512, 8, 1, 2), (1, 64, 64, 7, 3, 1), (2, 64, 64, 9, 3, 2), (1, 128, 64, 5, 1, 1), (64, 128, 128, 16, 3, 1),
+]
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", CASES)
+def test_conv_fwd_and_dgrad_match_torch(pkg, gpu, n, ci, co, h, k, stride):
+    torch.manual_seed(n * 1000 + ci + co + h + k + stride)
+    x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, device=gpu) / (ci * k * k) ** 0.5).bfloat16())
+    assert pkg.ops.conv_supported(ci, co, k, stride)
+    y = pkg.ops.conv_fwd(x, w, stride)
+    ref = F.conv2d(x.float(), w.float(), None, stride, k // 2)          # fp32 reference on the same bf16 values
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    # one bf16 rounding of an fp32-accumulated sum: |err| <= 2^-8 |ref| + accumulation noise
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    dy = _cl(torch.randn_like(ref).bfloat16())
+    wt = _cl(w.permute(1, 0, 2, 3))
+    dx = pkg.ops.conv_dgrad(dy, wt, (h, h), stride)
+    dref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w.float(), None, (stride, stride), (k // 2, k // 2),
+                                               (1, 1), False, (0, 0), 1, [True, False, False])[0]
+    assert dx.shape == dref.shape
+    scale = float(dref.abs().max())
+    np.testing.assert_allclose(dx.float().cpu().numpy(), dref.cpu().numpy(), rtol=1e-2, atol=1e-2 * max(scale, 1.0))
+
+
+def test_conv_identity_kernel_is_exact(pkg, gpu):
+    """A = I check with an asymmetric pattern: a centre-tap identity 3x3 kernel must return the input bit for bit,
+    and a one-pixel-shift kernel the shifted input with zero padding (catches row/col or tap-order swaps)."""
+    x = _cl(torch.randn(2, 64, 6, 6, device=gpu).bfloat16())
+    w = torch.zeros(64, 64, 3, 3, device=gpu)
+    w[torch.arange(64), torch.arange(64), 1, 1] = 1.0
+    y = pkg.ops.conv_fwd(x, _cl(w.bfloat16()), 1)
+    assert torch.equal(y, x)
+    w = torch.zeros(64, 64, 3, 3, device=gpu)
+    w[torch.arange(64), (torch.arange(64) + 1) % 64, 0, 2] = 1.0     # out c <- in c+1 at (h-1, w+1)
+    y = pkg.ops.conv_fwd(x, _cl(w.bfloat16()), 1)
+    ref = torch.zeros_like(x)
+    ref[:, :, 1:, :-1] = x[:, :, :-1, 1:].roll(-1, dims=1)
+    assert torch.equal(y, ref)
+
+
+def test_conv_rejects_unsupported(pkg, gpu):
+    assert not pkg.ops.conv_supported(3, 64, 3, 1)
+    x = _cl(torch.randn(1, 3, 8, 8, device=gpu).bfloat16())
+    w = _cl(torch.randn(64, 3, 3, 3, device=gpu).bfloat16())
+    with pytest.raises(pkg.AfanLibraryError):
+        pkg.ops.conv_fwd(x, w, 1)

@@ -1,0 +1,34 @@
+"""GPU microbench (not product code): afan implicit-GEMM conv vs MIOpen (channels_last bf16) per ResNet-18 layer shape."""
+import importlib, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("cv_a-fan_amd")
+dev = torch.device("cuda:0")
+N = int(os.environ.get("N", 256))
+shapes = [(64, 64, 32, 3, 1), (64, 128, 32, 3, 2), (128, 128, 16, 3, 1), (64, 128, 32, 1, 2), (128, 256, 16, 3, 2),
+          (256, 256, 8, 3, 1), (128, 256, 16, 1, 2), (256, 512, 8, 3, 2), (512, 512, 4, 3, 1), (256, 512, 8, 1, 2)]
+cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+
+def timeit(fn, iters=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+tot = dict(af=0, mf=0, ad=0, md=0)
+for (ci, co, h, k, s) in shapes:
+    x = cl(torch.randn(N, ci, h, h, device=dev).bfloat16()); w = cl((torch.randn(co, ci, k, k, device=dev) * 0.05).bfloat16())
+    p = k // 2
+    y = torch.ops.aten.convolution(x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1)
+    dy = cl(torch.randn_like(y)); wt = cl(w.permute(1, 0, 2, 3))
+    flops = 2.0 * N * co * ci * k * k * (h // s) ** 2
+    af = timeit(lambda: pkg.ops.conv_fwd(x, w, s))
+    mf = timeit(lambda: torch.ops.aten.convolution(x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1))
+    ad = timeit(lambda: pkg.ops.conv_dgrad(dy, wt, (h, h), s))
+    md = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1, [True, False, False]))
+    tot["af"] += af; tot["mf"] += mf; tot["ad"] += ad; tot["md"] += md
+    print(f"ci{ci:4d} co{co:4d} h{h:3d} k{k} s{s}: fwd afan {af:7.1f}us ({flops/af/1e6:6.1f} TF) miopen {mf:7.1f}us ({flops/mf/1e6:6.1f} TF) | "
+          f"dgrad afan {ad:7.1f}us ({flops/ad/1e6:6.1f} TF) miopen {md:7.1f}us ({flops/md/1e6:6.1f} TF)", flush=True)
+print("sum:", {k: round(v) for k, v in tot.items()})
