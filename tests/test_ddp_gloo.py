@@ -1,0 +1,99 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the flat-arena gradient all-reduce (GradAllReducer), the
+1/world scaling contract and the per-rank sharding of a global batch.  No GPU kernels run here: the model is plain
+torch modules (the reducer is generic over any nn.Module's parameters); the fused SGD step itself is covered on the GPU."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_pkg
+        pkg = load_pkg()
+        model = _make_model()
+        arena = pkg.arena.ParamArena(model, skip=(), bf16_shadow=False, allow_cpu=True)
+        reducer = pkg.train_step.GradAllReducer(arena, n_chunks=3)
+        assert reducer.world == world and len(reducer.chunks) >= 2
+        # the global batch, and this rank's shard of it (main_perturb.DeviceLoader slices the same way)
+        g = torch.Generator().manual_seed(11)
+        xs, ys = torch.randn(8, 3, 6, 6, generator=g), torch.randint(0, 5, (8,), generator=g)
+        per = 8 // world
+        x, y = xs[rank * per:(rank + 1) * per], ys[rank * per:(rank + 1) * per]
+        crit = torch.nn.CrossEntropyLoss()
+        for it in range(2):                      # two iterations: hooks must re-arm
+            arena.zero_grad()
+            reducer.begin()
+            crit(model(x), y).backward()
+            reducer.finish()
+            local_sum = arena.grad.clone()       # SUM over ranks; the SGD kernel applies grad_scale = 1/world
+            # reference: every rank recomputes both shards' gradients itself
+            ref = torch.zeros_like(arena.grad)
+            for r in range(world):
+                m2 = _make_model()
+                m2.load_state_dict(model.state_dict())
+                a2 = pkg.arena.ParamArena(m2, skip=(), bf16_shadow=False, allow_cpu=True)
+                crit(m2(xs[r * per:(r + 1) * per]), ys[r * per:(r + 1) * per]).backward()
+                ref += a2.grad
+            torch.testing.assert_close(local_sum, ref, rtol=1e-5, atol=1e-6)
+        # every rank holds the same reduced gradient
+        gathered = [torch.zeros_like(arena.grad) for _ in range(world)]
+        dist.all_gather(gathered, arena.grad)
+        assert all(torch.equal(gathered[0], t) for t in gathered)
+        # a chunk whose parameters got no gradient this step is still reduced by finish()
+        arena.zero_grad()
+        reducer.begin()
+        reducer.finish()
+        assert float(arena.grad.abs().sum()) == 0.0
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001 — report to the parent
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_grad_allreduce_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        if p.is_alive():
+            p.kill()
+    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def test_trainer_sets_grad_scale_from_world(pkg):
+    """1/world lives in the fused SGD kernel's grad_scale (the all-reduce is a plain SUM)."""
+    import inspect
+    src = inspect.getsource(pkg.train_step.AfanTrainer.__init__)
+    assert "grad_scale = 1.0 / self.world" in src
