@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--pgd_steps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"], help="internal activation layout")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_steps", type=int, default=2)
@@ -96,7 +97,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
     trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
-                                         perturb_idx=idx, lr=0.1)
+                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4
     xs = [torch.rand(args.batch, 3, 32, 32, generator=g).to(dev) for _ in range(nbuf)]
@@ -124,10 +125,12 @@ def main():
 
     # ---- instrumented pass (not part of `value`): per-launch HIP-event timing of the hand-written kernels ----
     roof, kernels = None, None
+    graphed = trainer._graph is not None
     if rank == 0 and not args.no_roofline:
+        # per-launch event timing needs eager launches: the same step body, un-captured
         pkg.ops.profile_enable(True)
         for i in range(2):
-            trainer.step(xs[i % nbuf], ys[i % nbuf])
+            trainer._step_eager(xs[i % nbuf], ys[i % nbuf])
         torch.cuda.synchronize()
         prof = pkg.ops.profile_collect()
         pkg.ops.profile_enable(False)
@@ -161,7 +164,8 @@ def main():
             "config": {"workload": f"{args.arch} CIFAR-10-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
                                    f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
                                    f"(BASELINE configs[1])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4)},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
+                       "hipgraph": graphed},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if gf is not None and args.pgd_steps == 5:

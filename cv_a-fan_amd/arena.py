@@ -59,20 +59,41 @@ class ParamArena:
             view.copy_(p.data)
             p.data = view
             p.grad = self._view(self.grad, o, p)
+            p._afan_arena_grad = not allow_cpu   # kernels may accumulate straight into .grad (resnet_s._accumulates_in_place)
             self.params.append(p)
+        self.shadow_t, self._tdesc, self._t_ndesc, self._t_tiles = None, None, 0, 0
         if self.shadow is not None:
-            self.refresh_shadow()
             mods = dict(model.named_modules())
+            desc, t_off, tiles = [], 0, 0
             for (n, p), o in zip(named, self.offsets):
                 m = mods.get(n.rsplit(".", 1)[0])
                 if isinstance(m, Conv2d) and n.endswith(".weight"):
                     m._arena_shadow = self._view(self.shadow, o, p)
+                    k_, c_, r_, s_ = p.shape
+                    if self.channels_last and k_ % 64 == 0 and c_ % 64 == 0:   # the shapes the MFMA dgrad kernel takes
+                        desc.append((o, t_off, k_, r_ * s_, c_, tiles, m, p))
+                        t_off += p.numel()
+                        tiles += (k_ // 64) * r_ * s_ * (c_ // 64)
+            if desc:
+                # CRSK copies of the conv weights (dgrad operands), rebuilt by ONE launch after every SGD step
+                self.shadow_t = torch.zeros(t_off, dtype=torch.bfloat16, device=dev)
+                self._tdesc = torch.tensor([d[:6] for d in desc], dtype=torch.int64, device=dev).contiguous()
+                self._t_ndesc, self._t_tiles = len(desc), tiles
+                for (o, to, k_, rs, c_, _, m, p) in desc:
+                    r_ = p.shape[2]
+                    m._arena_wt = self.shadow_t[to:to + p.numel()].view(c_, r_, rs // r_, k_).permute(0, 3, 1, 2)
+            self.refresh_shadow()
 
     def refresh_shadow(self):
         """Re-derive the bf16 shadow from the fp32 parameters (after load_state_dict / manual edits)."""
         if self.shadow is not None:
             ops.cast_bf16(self.param, self.shadow)
+            self.refresh_transposed()
         _Flags.weight_epoch += 1
+
+    def refresh_transposed(self):
+        if self.shadow_t is not None:
+            ops.transpose_weights(self.shadow, self.shadow_t, self._tdesc, self._t_ndesc, self._t_tiles)
 
     def _view(self, buf, o, p):
         flat = buf[o:o + p.numel()]
@@ -114,11 +135,13 @@ class ArenaSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self._sync_lr()
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_lr()     # (inside a capture the fill would be frozen into the graph: callers sync before replay)
         a = self.arena
         ops.sgd_step_(a.param, a.grad, a.momentum_buf, a.lr, g["momentum"], g["weight_decay"], self.grad_scale,
                       a.shadow)
-        _Flags.weight_epoch += 1   # cached transposed weights (dgrad operands) are stale now
+        a.refresh_transposed()
+        _Flags.weight_epoch += 1   # module-level caches of transposed weights (no arena) are stale now
 
     def state_dict(self):
         """Layout of torch.optim.SGD(model.parameters()).state_dict() (main_perturb.py:124,132 store it): state keyed

@@ -18,7 +18,8 @@ using namespace afan;
 namespace afan_nhwc {  // afan_bn_nhwc.hip
 int fwd(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom, const float* w,
         const float* b, int relu, float* ws, float* stats, const float* mean_in, const float* invstd_in, float* rm,
-        float* rv, int64_t* nbt, bool train, hipStream_t st);
+        float* rv, int64_t* nbt, bool train, hipStream_t st, const float* partials, int64_t partials_g,
+        const float* partials_shift);
 int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, float* ws, float* stats_out, float* rm,
           float* rv, int64_t* nbt, hipStream_t st);
 int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
@@ -507,10 +508,27 @@ int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtyp
     hipStream_t st = (hipStream_t)stream;
     if (layout == AFAN_NHWC)
         return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, eps, momentum, weight, bias, relu, workspace, save_stats,
-                              nullptr, nullptr, running_mean, running_var, num_batches, true, st);
+                              nullptr, nullptr, running_mean, running_var, num_batches, true, st, nullptr, 0, nullptr);
     if (dtype == AFAN_F32)
         return bn_forward_impl<float>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
     return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
+}
+
+int afan_bn_train_forward_partials(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
+                                   int64_t hw, float eps, float momentum, const float* weight, const float* bias,
+                                   int relu, const float* partials, int64_t partials_g, const float* partials_shift,
+                                   float* save_stats, float* running_mean, float* running_var, int64_t* num_batches,
+                                   afan_stream_t stream) {
+    int e = check_common(dtype, n, c, hw);
+    if (e) return e;
+    if (!x || !y || !partials || !save_stats) return AFAN_ENULL;
+    if (partials_g <= 0) return AFAN_ESHAPE;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return AFAN_ENULL;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(x, a) || !aligned(y, a) || (residual && !aligned(residual, a))) return AFAN_EALIGN;
+    return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, eps, momentum, weight, bias, relu, nullptr, save_stats, nullptr,
+                          nullptr, running_mean, running_var, num_batches, true, (hipStream_t)stream, partials,
+                          partials_g, partials_shift);
 }
 
 int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw,
@@ -529,7 +547,7 @@ int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int l
         if (!workspace) return AFAN_ENULL;
         float* stats = workspace + afan_nhwc::workspace_floats(c) - 4 * c;   // tail of the workspace
         return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, 0.f, 0.f, weight, bias, relu, workspace, stats, mean, invstd,
-                              nullptr, nullptr, nullptr, false, st);
+                              nullptr, nullptr, nullptr, false, st, nullptr, 0, nullptr);
     }
     if (dtype == AFAN_F32)
         return bn_forward_impl<float>(x, residual, y, n, c, hw, 0.f, 0.f, weight, bias, relu, nullptr, m, is, nullptr, nullptr, nullptr, false, st);

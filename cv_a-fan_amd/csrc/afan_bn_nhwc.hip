@@ -131,7 +131,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
                                                          const float* __restrict__ weight,
                                                          const float* __restrict__ bias, float* stats, float* coef,
                                                          float* rmean, float* rvar, int64_t* nbt, float* dweight,
-                                                         float* dbias, int accumulate) {
+                                                         float* dbias, int accumulate, const float* shift_ptr) {
     const int c = blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
     b = wave_sum(b);
     if (lane != 0) return;
     if (MODE == 0) {
-        const float shift = Elt<T>::ld(x + c);
+        // the shift the partial sums were taken around: given explicitly (conv-epilogue partials), else row 0 of x
+        const float shift = shift_ptr ? shift_ptr[c] : (x ? Elt<T>::ld(x + c) : 0.f);
         const float dm = a * inv_m;
         const float mean = shift + dm;
         const float m2 = fmaxf(b - a * dm, 0.f);
@@ -387,7 +388,7 @@ int run_stats(const Plan& p, const T* x_, int64_t M, int64_t C, float eps, float
     AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
     finalize_kernel<T, 0><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(ws, p.G, (int)C, x_, 1.0f / (float)M, (float)M, eps,
                                                                       momentum, weight, bias, stats, nullptr, rmean,
-                                                                      rvar, nbt, nullptr, nullptr, 0);
+                                                                      rvar, nbt, nullptr, nullptr, 0, nullptr);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -396,13 +397,21 @@ int run_stats(const Plan& p, const T* x_, int64_t M, int64_t C, float eps, float
 template <typename T>
 int forward(const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float momentum,
             const float* weight, const float* bias, int relu, float* ws, float* stats, const float* mean_in,
-            const float* invstd_in, float* rmean, float* rvar, int64_t* nbt, bool train, hipStream_t st) {
+            const float* invstd_in, float* rmean, float* rvar, int64_t* nbt, bool train, hipStream_t st,
+            const float* partials = nullptr, int64_t partials_g = 0, const float* partials_shift = nullptr) {
     Plan p;
     if (!make_plan<T>(M, C, {x, res, y}, p)) return AFAN_ESHAPE;
     p.vec = p.vec && aligned(stats, 16);
     constexpr int NV = Elt<T>::VEC;
     const T* x_ = (const T*)x; const T* r_ = (const T*)res; T* y_ = (T*)y;
-    if (train) {
+    if (train && partials) {
+        // moments already summed per tile by the producing convolution's epilogue: only the fold is left
+        AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * partials_g, st);
+        finalize_kernel<T, 0><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
+            partials, (int)partials_g, (int)C, nullptr, 1.0f / (float)M, (float)M, eps, momentum, weight, bias, stats,
+            nullptr, rmean, rvar, nbt, nullptr, nullptr, 0, partials_shift);
+        AFAN_LAUNCH_CHECK();
+    } else if (train) {
         int e = run_stats<T>(p, x_, M, C, eps, momentum, weight, bias, ws, stats, rmean, rvar, nbt, st);
         if (e) return e;
     } else {
@@ -458,7 +467,7 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
         AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
         finalize_kernel<T, 1><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
             ws, p.G, (int)C, nullptr, 1.0f / (float)M, (float)M, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(stats),
-            coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate);
+            coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate, nullptr);
     }
     AFAN_LAUNCH_CHECK();
     const int grid = apply_grid(p, M * C);
@@ -479,10 +488,11 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
 // entry points used by afan_bn.hip's extern "C" dispatch (dtype: 0 = f32, 1 = bf16)
 int fwd(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom, const float* w,
         const float* b, int relu, float* ws, float* stats, const float* mean_in, const float* invstd_in, float* rm,
-        float* rv, int64_t* nbt, bool train, hipStream_t st) {
+        float* rv, int64_t* nbt, bool train, hipStream_t st, const float* partials, int64_t partials_g,
+        const float* partials_shift) {
     return dtype == AFAN_F32
-               ? forward<float>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st)
-               : forward<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st);
+               ? forward<float>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st, partials, partials_g, partials_shift)
+               : forward<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, ws, stats, mean_in, invstd_in, rm, rv, nbt, train, st, partials, partials_g, partials_shift);
 }
 int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, float* ws, float* stats_out, float* rm,
           float* rv, int64_t* nbt, hipStream_t st) {

@@ -30,22 +30,44 @@ constexpr int BK = 64;           // reduction channels per step
 constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes
 constexpr int MAX_TAPS = 9;
 
+// One "class" = one set of output positions with its tap list.  A forward conv or a stride-1 dgrad has one class;
+// a stride-2 dgrad has four (output-pixel parity), run as blockIdx.z of ONE launch.
+struct ConvClass {
+    int Hg, Wg;                  // grid of output positions of this class
+    int out_h0, out_w0;          // output coordinate = g * out_s + out_0
+    int T;                       // number of taps
+    int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
+};
+
 struct ConvP {
     const uint16_t* x;
     const uint16_t* w;
     uint16_t* y;
     int N, Hi, Wi, Ci;           // input tensor [N, Hi, Wi, Ci]
     int Ho, Wo, Co;              // output tensor [N, Ho, Wo, Co]
-    int Hg, Wg;                  // grid of output positions handled by this launch
     int in_s;                    // input coordinate = g * in_s + d
-    int out_s, out_h0, out_w0;   // output coordinate = g * out_s + out_0
-    int T;                       // number of taps
+    int out_s;
     int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
-    int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
+    int n_classes;
+    float* stats;                // optional [2][Co][gridDim.y] per-tile column sums of (y - shift), (y - shift)^2
+    const float* shift;          // optional [Co] shift of those sums (the BN layer's running mean), NULL = 0
+    ConvClass cls[4];
 };
 
 template <int BM, int BN>
-__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
+    // flatten the class selected by blockIdx.z into the names the body uses
+    struct {
+        const uint16_t* x; const uint16_t* w; uint16_t* y;
+        int N, Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, in_s, out_s, out_h0, out_w0, T, w_row_stride;
+        const int *dh, *dw, *wofs;
+    } p;
+    const ConvClass& cc = pp.cls[blockIdx.z];
+    p.x = pp.x; p.w = pp.w; p.y = pp.y; p.N = pp.N; p.Hi = pp.Hi; p.Wi = pp.Wi; p.Ci = pp.Ci;
+    p.Ho = pp.Ho; p.Wo = pp.Wo; p.Co = pp.Co; p.in_s = pp.in_s; p.out_s = pp.out_s; p.w_row_stride = pp.w_row_stride;
+    p.Hg = cc.Hg; p.Wg = cc.Wg; p.out_h0 = cc.out_h0; p.out_w0 = cc.out_w0; p.T = cc.T;
+    p.dh = cc.dh; p.dw = cc.dw; p.wofs = cc.wofs;
+    if ((int64_t)blockIdx.y * BM >= (int64_t)p.N * p.Hg * p.Wg) return;   // smaller class than the grid's tallest
     constexpr int TM = BM / 2, TN = BN / 2;          // wave tile
     constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
@@ -181,19 +203,77 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP p) {
     constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
     constexpr int ROWS_PER_PASS = THREADS / PIECES;
     const int pc = tid % PIECES, pr = tid / PIECES;
+    // Optional BatchNorm statistics of THIS tile, taken from the bf16 values on their way out (same LDS reads as the
+    // stores): the following train-mode BN then needs no pass over the tensor for its moments — one partial per
+    // (tile, channel), summed by its finalize.
+    const bool want_stats = pp.stats != nullptr;
+    float s1[8], s2[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = s2[j] = 0.f;
+        sh[j] = (want_stats && pp.shift) ? pp.shift[n0 + pc * 8 + j] : 0.f;
+    }
 #pragma unroll
     for (int r = pr; r < BM; r += ROWS_PER_PASS) {
         const int off = out_off[r];
-        if (off >= 0)
-            *reinterpret_cast<u32x4*>(p.y + (int64_t)off + n0 + pc * 8) =
-                *reinterpret_cast<const u32x4*>(C + r * LDC + pc * 8);
+        if (off >= 0) {
+            const u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+            *reinterpret_cast<u16x8*>(p.y + (int64_t)off + n0 + pc * 8) = v;
+            if (want_stats) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f(v[j]) - sh[j];
+                    s1[j] += f;
+                    s2[j] += f * f;
+                }
+            }
+        }
     }
+    if (want_stats) {
+        // lanes l, l+PIECES, l+2*PIECES, ... of a wave hold the same 8 columns: butterfly over those, then over waves
+#pragma unroll
+        for (int o = PIECES; o < 64; o <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+        __shared__ float red[THREADS / 64][2][BN];
+        if (lane < PIECES) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[wave][0][lane * 8 + j] = s1[j];
+                red[wave][1][lane * 8 + j] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) {
+                a += red[w][0][tid];
+                b += red[w][1][tid];
+            }
+            const int64_t G = gridDim.y;
+            pp.stats[((int64_t)0 * p.Co + n0 + tid) * G + blockIdx.y] = a;
+            pp.stats[((int64_t)1 * p.Co + n0 + tid) * G + blockIdx.y] = b;
+        }
+    }
+}
+
+static int64_t max_rows(const ConvP& p) {
+    int64_t m = 0;
+    for (int c = 0; c < p.n_classes; ++c) {
+        const int64_t v = (int64_t)p.N * p.cls[c].Hg * p.cls[c].Wg;
+        if (v > m) m = v;
+    }
+    return m;
 }
 
 template <int BM, int BN>
 int launch(const ConvP& p, hipStream_t st) {
-    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
-    dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM));
+    const int64_t M = max_rows(p);
+    dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
     constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LDK * 2;
     constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
@@ -210,16 +290,16 @@ int launch(const ConvP& p, hipStream_t st) {
 }
 
 // tile choice: fill >= ~256 workgroups when the problem allows it
+int choose_bm(int64_t M, int co, int n_classes) {
+    const bool n128 = (co % 128 == 0);
+    const int64_t wg_128 = ((M + 127) / 128) * (co / (n128 ? 128 : 64)) * n_classes;
+    return wg_128 >= 384 ? 128 : 64;
+}
+
 int dispatch(const ConvP& p, hipStream_t st) {
-    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
-    const bool n128 = (p.Co % 128 == 0);
-    const int64_t wg_128 = ((M + 127) / 128) * (p.Co / (n128 ? 128 : 64));
-    if (n128) {
-        if (wg_128 >= 384) return launch<128, 128>(p, st);
-        return launch<64, 128>(p, st);
-    }
-    if (wg_128 >= 384) return launch<128, 64>(p, st);
-    return launch<64, 64>(p, st);
+    const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
+    if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128>(p, st) : launch<64, 128>(p, st);
+    return bm == 128 ? launch<128, 64>(p, st) : launch<64, 64>(p, st);
 }
 
 int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
@@ -238,9 +318,19 @@ int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
     return (ci % BK == 0 && co % 64 == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
 }
 
+// number of row tiles (= BN-statistics partials per channel) the forward launch of this problem uses
+int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+    if (check_dims(n, hi, wi, ci, co, k, stride)) return 0;
+    const int pad = k / 2;
+    const int64_t M = n * ((hi + 2 * pad - k) / stride + 1) * ((wi + 2 * pad - k) / stride + 1);
+    const int bm = choose_bm(M, (int)co, 1);
+    return (M + bm - 1) / bm;
+}
+
 // y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding k/2, stride 1 or 2; all bf16, channels-last.
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                            int64_t co, int k, int stride, afan_stream_t stream) {
+                            int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
+                            afan_stream_t stream) {
     int e = check_dims(n, hi, wi, ci, co, k, stride);
     if (e) return e;
     if (!x || !w || !y) return AFAN_ENULL;
@@ -250,12 +340,14 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
     p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
-    p.Hg = p.Ho; p.Wg = p.Wo; p.in_s = stride; p.out_s = 1; p.out_h0 = 0; p.out_w0 = 0;
-    p.T = k * k; p.w_row_stride = (int)(k * k * ci);
+    p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = 1;
+    p.stats = stats_partials; p.shift = stats_shift;
+    ConvClass& c0 = p.cls[0];
+    c0.Hg = p.Ho; c0.Wg = p.Wo; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
     for (int r = 0; r < k; ++r)
         for (int s = 0; s < k; ++s) {
             const int t = r * k + s;
-            p.dh[t] = r - pad; p.dw[t] = s - pad; p.wofs[t] = (int)(t * ci);
+            c0.dh[t] = r - pad; c0.dw[t] = s - pad; c0.wofs[t] = (int)(t * ci);
         }
     hipStream_t st = (hipStream_t)stream;
     const double M = (double)n * p.Ho * p.Wo;
@@ -281,41 +373,94 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.w_row_stride = (int)(k * k * co);
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF("conv_igemm_dgrad_kernel", bytes, st);
+    p.in_s = 1;
     if (stride == 1) {
         // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]
-        p.Hg = (int)hi; p.Wg = (int)wi; p.in_s = 1; p.out_s = 1; p.out_h0 = 0; p.out_w0 = 0;
-        p.T = k * k;
+        p.out_s = 1; p.n_classes = 1;
+        ConvClass& c0 = p.cls[0];
+        c0.Hg = (int)hi; c0.Wg = (int)wi; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
         for (int r = 0; r < k; ++r)
             for (int s = 0; s < k; ++s) {
                 const int t = r * k + s;
-                p.dh[t] = pad - r; p.dw[t] = pad - s; p.wofs[t] = (int)(t * co);
+                c0.dh[t] = pad - r; c0.dw[t] = pad - s; c0.wofs[t] = (int)(t * co);
             }
         return dispatch(p, st);
     }
     // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
-    // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four launches, 1/2/2/4 taps for k = 3.
+    // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four classes (1/2/2/4 taps for k = 3) in ONE launch.
+    p.out_s = 2;
+    int nc = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
-            p.Hg = (int)((hi - ph + 1) / 2); p.Wg = (int)((wi - pw + 1) / 2);
-            if (p.Hg <= 0 || p.Wg <= 0) continue;
-            p.in_s = 1; p.out_s = 2; p.out_h0 = ph; p.out_w0 = pw;
+            ConvClass& c = p.cls[nc];
+            c.Hg = (int)((hi - ph + 1) / 2); c.Wg = (int)((wi - pw + 1) / 2);
+            if (c.Hg <= 0 || c.Wg <= 0) continue;
+            c.out_h0 = ph; c.out_w0 = pw;
             int T = 0;
             for (int r = 0; r < k; ++r)
                 for (int s = 0; s < k; ++s) {
                     const int a = ph + pad - r, b = pw + pad - s;
                     if ((a & 1) || (b & 1)) continue;
-                    p.dh[T] = a / 2; p.dw[T] = b / 2; p.wofs[T] = (int)((r * k + s) * co);
+                    c.dh[T] = a / 2; c.dw[T] = b / 2; c.wofs[T] = (int)((r * k + s) * co);
                     ++T;
                 }
-            p.T = T;
             if (T == 0) {
-                // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  Keep one all-invalid tap so
-                // the kernel writes zeros through its normal path.
-                p.T = 1; p.dh[0] = -(1 << 20); p.dw[0] = 0; p.wofs[0] = 0;
+                // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  One all-invalid tap makes
+                // the kernel write zeros through its normal path.
+                T = 1; c.dh[0] = -(1 << 20); c.dw[0] = 0; c.wofs[0] = 0;
             }
-            int rc = dispatch(p, st);
-            if (rc) return rc;
+            c.T = T;
+            ++nc;
         }
+    p.n_classes = nc;
+    return dispatch(p, st);
+}
+
+// ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------
+// desc[i] = {src_off, dst_off, K, RS, C, first_tile}; tiles of 64(k) x 64(c) at fixed rs; K % 64 == 0, C % 64 == 0.
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const uint16_t* __restrict__ src,
+                                                                uint16_t* __restrict__ dst,
+                                                                const int64_t* __restrict__ desc, int n_desc) {
+    __shared__ uint16_t tile[64][64 + 8];
+    int d = 0;
+    while (d + 1 < n_desc && (int64_t)blockIdx.x >= desc[(d + 1) * 6 + 5]) ++d;
+    const int64_t* D = desc + d * 6;
+    const int64_t K = D[2], RS = D[3], Cc = D[4];
+    int64_t t = blockIdx.x - D[5];
+    const int64_t ct = t % (Cc / 64); t /= (Cc / 64);
+    const int64_t rs = t % RS;
+    const int64_t kt = t / RS;
+    const uint16_t* s = src + D[0];
+    uint16_t* o = dst + D[1];
+    const int piece = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = r0 + 32 * i;
+        *reinterpret_cast<u32x4*>(&tile[k][piece * 8]) =
+            *reinterpret_cast<const u32x4*>(s + ((kt * 64 + k) * RS + rs) * Cc + ct * 64 + piece * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = r0 + 32 * i;
+        u16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[piece * 8 + j][c];
+        *reinterpret_cast<u16x8*>(o + ((ct * 64 + c) * RS + rs) * K + kt * 64 + piece * 8) = v;
+    }
+}
+
+int afan_transpose_weights(const void* src_arena, void* dst_arena, const int64_t* desc_dev, int n_desc,
+                           int64_t total_tiles, afan_stream_t stream) {
+    if (n_desc < 0 || total_tiles < 0) return AFAN_ESHAPE;
+    if (n_desc == 0 || total_tiles == 0) return AFAN_OK;
+    if (!src_arena || !dst_arena || !desc_dev) return AFAN_ENULL;
+    if (!aligned(src_arena, 16) || !aligned(dst_arena, 16)) return AFAN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("transpose_weights_kernel", (double)total_tiles * 64 * 64 * 4, st);
+    transpose_weights_kernel<<<(unsigned)total_tiles, 256, 0, st>>>((const uint16_t*)src_arena, (uint16_t*)dst_arena,
+                                                                    desc_dev, n_desc);
+    AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
 

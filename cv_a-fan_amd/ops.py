@@ -225,8 +225,10 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num
     return stats[0], stats[1]
 
 
-def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches):
-    """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward)."""
+def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches,
+                     conv_stats=None):
+    """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward).
+    conv_stats: ConvStats from the producing convolution -> the moments pass over x is skipped."""
     lib = _lib.load()
     _need(x, "x")
     if x.dtype not in _DT:
@@ -237,6 +239,15 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
     n, c, hw = _nchw(x)
     y = torch.empty_like(x)
     stats = torch.empty(4, c, dtype=torch.float32, device=x.device)
+    if conv_stats is not None:
+        if layout_of(x) != AFAN_NHWC and not (x.shape[2] == 1 and x.shape[3] == 1):
+            raise ValueError("conv_stats need a channels_last x")
+        check(lib.afan_bn_train_forward_partials(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, float(eps),
+                                                 float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)),
+                                                 _ptr(conv_stats.partials), int(conv_stats.g), _ptr(conv_stats.shift),
+                                                 _ptr(stats), _ptr(running_mean), _ptr(running_var), _ptr(num_batches),
+                                                 _stream(x)), "afan_bn_train_forward_partials")
+        return y, stats
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
     check(lib.afan_bn_train_forward(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, float(eps),
                                     float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _ptr(stats),
@@ -290,8 +301,17 @@ def _cl4(t, name):
     return t
 
 
-def conv_fwd(x, w, stride):
-    """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last."""
+class ConvStats:
+    """Per-tile BatchNorm moment partials written by a convolution's epilogue (consumed by bn_train_forward)."""
+    __slots__ = ("partials", "g", "shift")
+
+    def __init__(self, partials, g, shift):
+        self.partials, self.g, self.shift = partials, g, shift
+
+
+def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
+    """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last.
+    want_stats=True also returns a ConvStats (moments of y around stats_shift[c], e.g. the BN running mean)."""
     lib = _lib.load()
     _cl4(x, "x"), _cl4(w, "w")
     n, ci, hi, wi = x.shape
@@ -301,9 +321,16 @@ def conv_fwd(x, w, stride):
     pad = k // 2
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     y = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride, _stream(x)),
-          "afan_conv_fwd_nhwc_bf16")
-    return y
+    st = None
+    if want_stats:
+        g = lib.afan_conv_fwd_tiles(n, hi, wi, ci, co, k, stride)
+        if stats_buf is None or stats_buf.numel() < 2 * co * g:
+            stats_buf = torch.empty(2 * co * g, dtype=torch.float32, device=x.device)
+        st = ConvStats(stats_buf, g, stats_shift)
+    check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride,
+                                      _ptr(st.partials) if st else None, _ptr(stats_shift) if st else None,
+                                      _stream(x)), "afan_conv_fwd_nhwc_bf16")
+    return (y, st) if want_stats else y
 
 
 def conv_dgrad(dy, wt, in_hw, stride):
@@ -319,6 +346,16 @@ def conv_dgrad(dy, wt, in_hw, stride):
     check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _stream(dy)),
           "afan_conv_dgrad_nhwc_bf16")
     return dx
+
+
+def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):
+    """Batched KRSC -> CRSK transpose of all convolution weights listed in desc_dev (see include/afan_hip.h)."""
+    lib = _lib.load()
+    _need(src_arena, "src_arena", torch.bfloat16)
+    _need(dst_arena, "dst_arena", torch.bfloat16)
+    _need(desc_dev, "desc_dev", torch.int64)
+    check(lib.afan_transpose_weights(_ptr(src_arena), _ptr(dst_arena), _ptr(desc_dev), int(n_desc), int(total_tiles),
+                                     _stream(src_arena)), "afan_transpose_weights")
 
 
 # ------------------------------------------------------------------------------------------- SGD

@@ -82,11 +82,17 @@ class _ConvFn(torch.autograd.Function):
     to MIOpen through aten.  wgrad is returned for the fp32 master weight."""
 
     @staticmethod
-    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad):
+    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad, stats_req=None):
         ctx.stride, ctx.padding, ctx.want_wgrad, ctx.wt_fn = stride, padding, want_wgrad, wt_fn
+        ctx.w_master = w_master
         ctx.own = _own_conv_ok(x, w_lp, stride, padding)
         ctx.save_for_backward(x, w_lp)
         if ctx.own:
+            if stats_req is not None:   # [shift tensor | None, reusable partials buffer | None] -> filled with ConvStats
+                y, st = ops.conv_fwd(x, w_lp, stride[0], stats_shift=stats_req[0], want_stats=True,
+                                     stats_buf=stats_req[1])
+                stats_req.append(st)
+                return y
             return ops.conv_fwd(x, w_lp, stride[0])
         return torch.ops.aten.convolution(x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1)
 
@@ -105,9 +111,20 @@ class _ConvFn(torch.autograd.Function):
                                                             (0, 0), 1, [need_gx, need_gw, False])
             if need_gx:
                 gx = g2
-        if gw is not None and gw.dtype != torch.float32:
-            gw = gw.float()
-        return gx, gw, None, None, None, None, None
+        if gw is not None:
+            w_master = ctx.w_master
+            if _accumulates_in_place(w_master):
+                w_master.grad.add_(gw)      # bf16 wgrad summed straight into the fp32 arena view: one launch
+                gw = None
+            elif gw.dtype != torch.float32:
+                gw = gw.float()
+        return gx, gw, None, None, None, None, None, None
+
+
+def _accumulates_in_place(p):
+    """True for a leaf parameter whose .grad buffer is pre-attached and owned by a ParamArena (train_step zeroes it
+    at the start of every step), so a kernel may add into it directly instead of going through AccumulateGrad."""
+    return isinstance(p, torch.nn.Parameter) and p.grad is not None and getattr(p, "_afan_arena_grad", False)
 
 
 def _own_conv_ok(x, w, stride, padding):
@@ -125,11 +142,11 @@ class _BNTrainFn(torch.autograd.Function):
     """y = [relu](bn_train(x) [+ residual]) via afan_bn_train_forward / afan_bn_backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad):
+    def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad, conv_stats=None):
         x = _dense(x)
         if residual is not None:
             residual = _like_layout(residual, x)
-        y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt)
+        y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, conv_stats)
         ctx.relu, ctx.has_res, ctx.want_pgrad = relu, residual is not None, want_pgrad
         # the ReLU mask is recomputed from x when there is no residual; otherwise y carries it
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats, weight, bias)
@@ -140,12 +157,21 @@ class _BNTrainFn(torch.autograd.Function):
         x, y, stats, weight, bias = ctx.saved_tensors
         want_p = ctx.want_pgrad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dw = db = None
+        direct = False
         if want_p:
-            dwb = torch.empty(2, x.shape[1], dtype=torch.float32, device=x.device)
-            dw, db = dwb[0], dwb[1]
+            # parameters whose .grad is pre-attached (ParamArena views) are accumulated by the kernel itself:
+            # no temporary, no AccumulateGrad add launch.  Otherwise hand the gradients to autograd as usual.
+            direct = _accumulates_in_place(weight) and _accumulates_in_place(bias)
+            if direct:
+                dw, db = weight.grad, bias.grad
+            else:
+                dwb = torch.empty(2, x.shape[1], dtype=torch.float32, device=x.device)
+                dw, db = dwb[0], dwb[1]
         dx, dres = ops.bn_backward(_like_layout(gy, x), x, y, stats, weight, bias, ctx.relu,
-                                   ctx.has_res and ctx.needs_input_grad[3], dw, db)
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+                                   ctx.has_res and ctx.needs_input_grad[3], dw, db, accumulate=direct)
+        if direct:
+            dw = db = None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- layers
@@ -187,6 +213,9 @@ class Conv2d(nn.Conv2d):
     def lp_weight_t(self):
         """[Ci, Co, k, k] channels-last (CRSK memory) copy of the low-precision weight for the dgrad kernel; rebuilt
         when the weights change (once per SGD step: the K+2 input-gradient passes of an iteration share it)."""
+        wt = getattr(self, "_arena_wt", None)
+        if wt is not None:   # kept fresh by ParamArena.refresh_transposed (one launch per SGD step)
+            return wt
         w = self.lp_weight()
         key = (w.data_ptr(), self.weight._version, _Flags.weight_epoch)
         if self._wt is None or self._wt_key != key:
@@ -202,15 +231,31 @@ class Conv2d(nn.Conv2d):
         return _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.lp_weight_t, self.stride, self.padding,
                              _Flags.param_grads)
 
+    _stats_buf = None
+
+    def forward_with_stats(self, x, bn):
+        """Convolution whose epilogue also sums the moments the train-mode BatchNorm `bn` is about to need.
+        Returns (y, ConvStats | None): None whenever the fused path does not apply (eval mode, fp32, MIOpen conv)."""
+        if not (bn.training and self.compute_dtype == torch.bfloat16):
+            return self.forward(x), None
+        x = _to_compute(x, self.compute_dtype)
+        req = [bn.running_mean if bn.track_running_stats else None, self._stats_buf]
+        y = _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.lp_weight_t, self.stride, self.padding,
+                          _Flags.param_grads, req)
+        st = req[2] if len(req) > 2 else None
+        if st is not None:
+            self._stats_buf = st.partials
+        return y, st
+
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameters/buffers; fused HIP execution."""
 
-    def fused(self, x, residual=None, relu=False):
+    def fused(self, x, residual=None, relu=False, conv_stats=None):
         if self.training:
             mom = self.momentum if self.momentum is not None else 0.1
             return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, mom, self.running_mean,
-                                    self.running_var, self.num_batches_tracked, _Flags.param_grads)
+                                    self.running_var, self.num_batches_tracked, _Flags.param_grads, conv_stats)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad and _Flags.param_grads):
             if x.requires_grad:
                 raise NotImplementedError("eval-mode BatchNorm backward is not on the A-FAN path (the reference "
@@ -257,9 +302,16 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
-        out = self.bn1.fused(self.conv1(x), None, True)
-        out = self.conv2(out)
-        return self.bn2.fused(out, self.shortcut(x), True)
+        out, st = self.conv1.forward_with_stats(x, self.bn1)
+        out = self.bn1.fused(out, None, True, st)
+        out, st = self.conv2.forward_with_stats(out, self.bn2)
+        sc = self.shortcut
+        if isinstance(sc, nn.Sequential) and len(sc) == 2:     # option B: 1x1 conv + BN
+            r, st_sc = sc[0].forward_with_stats(x, sc[1])
+            res = sc[1].fused(r, None, False, st_sc)
+        else:
+            res = sc(x)
+        return self.bn2.fused(out, res, True, st)
 
 
 class _HeadPool(nn.AdaptiveAvgPool2d):

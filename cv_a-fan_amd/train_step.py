@@ -108,11 +108,18 @@ def _cut_chunks(arena, n_chunks):
 
 
 class AfanTrainer:
-    """Owns the arena, the optimizer and the per-step schedule of one rank."""
+    """Owns the arena, the optimizer and the per-step schedule of one rank.
+
+    use_graph=True (default): after `graph_warmup` eager iterations the whole iteration body — head forward, K PGD
+    steps, both final forwards, backward and (single GPU) the SGD step, ~1300 launches — is captured once into a
+    hipGraph and replayed from then on: static shapes, the learning rate in device memory and on-device metrics make
+    the step capturable, and replay removes the host launch cost that otherwise bounds the step (PyTorch's eager
+    dispatch + autograd tape is ~15 us per launch).  With world_size > 1 the graph stops after the backward and the
+    gradient all-reduce + SGD run eagerly.  randinit draws on the host generator every step, so it stays eager."""
 
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
-                 group=None):
+                 group=None, use_graph=True, graph_warmup=3):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -120,13 +127,23 @@ class AfanTrainer:
         self.randinit, self.clip = randinit, clip
         self.arena = ParamArena(model)
         self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay)
+        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = GradAllReducer(self.arena, allreduce_chunks, group) if self.world > 1 else None
         if self.world > 1:
             self.optimizer.grad_scale = 1.0 / self.world
+        self.use_graph = bool(use_graph) and not randinit
+        self.graph_warmup = graph_warmup
+        self._graph = None
+        self._graph_failed = None
+        self._eager_steps = 0
+        self._static_in = None
+        self._static_out = None
+        self._shape_key = None
+        self._stream = None
 
-    def step(self, inp, target):
-        """One iteration. Returns device tensors only: loss, loss_adv, loss_clean, prec1, l2[N], linf[N]."""
+    # ------------------------------------------------------------------------------------------------ body
+    def _forward_backward(self, inp, target, overlap_allreduce):
         m, idx, ln = self.model, self.perturb_idx, self.layer_number
         with torch.no_grad():  # main_perturb.py:173 (.detach()): values and BN side effects are identical
             feature_map = m(inp, end_point=idx, start_point=0)
@@ -146,14 +163,63 @@ class AfanTrainer:
         loss_clean = self.criterion(output_clean, target)
         loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
         self.optimizer.zero_grad()
-        if self.reducer is not None:
+        if overlap_allreduce:
             self.reducer.begin()
         loss.backward()
-        if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step()
         with torch.no_grad():
             prec1 = (output_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
                 "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
                 "feature_map": feature_map, "out_clean": output_clean.detach()}
+
+    def _step_eager(self, inp, target):
+        self.optimizer._sync_lr()
+        out = self._forward_backward(inp, target, overlap_allreduce=self.reducer is not None)
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return out
+
+    # ----------------------------------------------------------------------------------------------- graph
+    def _capture(self, inp, target):
+        dev = inp.device
+        self._stream = torch.cuda.Stream(device=dev)
+        self._static_in = (inp.clone(), target.clone())
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._stream):
+            out = self._forward_backward(self._static_in[0], self._static_in[1], overlap_allreduce=False)
+            if self.world == 1:
+                self.optimizer.step()
+        self._graph, self._static_out = g, out
+        self._shape_key = (tuple(inp.shape), inp.dtype, tuple(target.shape))
+
+    def _step_graph(self, inp, target):
+        self._static_in[0].copy_(inp, non_blocking=True)
+        self._static_in[1].copy_(target, non_blocking=True)
+        self.optimizer._sync_lr()          # lr lives in device memory: the graph reads it, the host only writes it here
+        self._graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self.optimizer.step()
+        small = ("loss", "loss_adv", "loss_clean", "prec1", "l2", "linf")
+        # graph-owned outputs are overwritten by the next replay: hand out copies of the small ones
+        return {k: (v.clone() if k in small else v) for k, v in self._static_out.items()}
+
+    def step(self, inp, target):
+        """One iteration. Returns device tensors only: loss, loss_adv, loss_clean, prec1, l2[N], linf[N] (+ x_adv,
+        feature_map, out_clean — in graph mode these three are views of graph-owned buffers, valid until the next step)."""
+        if self._graph is not None and self._shape_key == (tuple(inp.shape), inp.dtype, tuple(target.shape)):
+            return self._step_graph(inp, target)
+        if (self.use_graph and self._graph is None and self._graph_failed is None
+                and self._eager_steps >= self.graph_warmup and inp.is_cuda and self.model.training):
+            try:
+                self._capture(inp, target)
+                return self._step_graph(inp, target)
+            except Exception as e:  # noqa: BLE001 — stay correct: fall back to eager launches, loudly
+                import warnings
+                self._graph, self._graph_failed = None, e
+                warnings.warn(f"hipGraph capture of the A-FAN step failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize()
+        self._eager_steps += 1
+        return self._step_eager(inp, target)

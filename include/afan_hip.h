@@ -130,6 +130,14 @@ int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtyp
                           float* running_mean, float* running_var, int64_t* num_batches,
                           afan_stream_t stream);
 
+/* afan_bn_train_forward for a channels-last x whose per-tile moments were already written by the producing
+ * convolution (see afan_conv_fwd_nhwc_bf16): fold of the partials_g partials per channel + normalise; no stats pass. */
+int afan_bn_train_forward_partials(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
+                                   int64_t hw, float eps, float momentum, const float* weight, const float* bias,
+                                   int relu, const float* partials, int64_t partials_g, const float* partials_shift,
+                                   float* save_stats, float* running_mean, float* running_var,
+                                   int64_t* num_batches, afan_stream_t stream);
+
 /* Same transform with GIVEN statistics (eval mode: mean = running_mean, invstd = rsqrt(running_var+eps)).
  * workspace is required for AFAN_NHWC (may be NULL for AFAN_NCHW). */
 int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int layout, int64_t n, int64_t c,
@@ -159,9 +167,21 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
  */
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride);
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                            int64_t co, int k, int stride, afan_stream_t stream);
+                            int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
+                            afan_stream_t stream);
+/* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
+ * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
+ * sum((y - shift[c])^2) at [(1*Co + c)*G + g], G = afan_conv_fwd_tiles(...), over the bf16 values it stores
+ * (shift = the BN layer's running mean, NULL = 0).  afan_bn_train_forward_partials() consumes them. */
+int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, afan_stream_t stream);
+
+/* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
+ * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
+ * offsets into src_arena / dst_arena, K % 64 == 0, C % 64 == 0, first_tile = running sum of (K/64)*RS*(C/64)). */
+int afan_transpose_weights(const void* src_arena, void* dst_arena, const int64_t* desc_dev, int n_desc,
+                           int64_t total_tiles, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * SGD with momentum over ONE flat parameter arena.  Replaces torch.optim.SGD.step as configured at

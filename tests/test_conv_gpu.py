@@ -60,3 +60,29 @@ def test_conv_rejects_unsupported(pkg, gpu):
     w = _cl(torch.randn(64, 3, 3, 3, device=gpu).bfloat16())
     with pytest.raises(pkg.AfanLibraryError):
         pkg.ops.conv_fwd(x, w, 1)
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 256, 512, 8, 1, 2),
+                                                 (64, 128, 128, 16, 3, 1), (1, 64, 64, 7, 3, 1)])
+def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, n, ci, co, h, k, stride):
+    """conv (+ epilogue moment partials) -> BN(train) must equal conv -> stand-alone BN on the stored bf16 tensor."""
+    torch.manual_seed(ci + co + h)
+    x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, device=gpu) / (ci * k * k) ** 0.5).bfloat16())
+    shift = torch.randn(co, device=gpu) * 0.1
+    y, st = pkg.ops.conv_fwd(x, w, stride, stats_shift=shift, want_stats=True)
+    y_plain = pkg.ops.conv_fwd(x, w, stride)
+    assert torch.equal(y, y_plain) and st.g >= 1
+    gamma, beta = torch.rand(co, device=gpu) + 0.5, torch.randn(co, device=gpu)
+    outs = []
+    for cs in (None, st):
+        rm, rv = shift.clone(), torch.ones(co, device=gpu)
+        nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+        o, stats = pkg.ops.bn_train_forward(y, gamma, beta, None, True, 1e-5, 0.1, rm, rv, nbt, cs)
+        outs.append((o.float().cpu().numpy(), stats.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy(), int(nbt)))
+    a, b = outs
+    np.testing.assert_allclose(b[1][:2], a[1][:2], rtol=2e-5, atol=2e-6)     # mean, invstd
+    np.testing.assert_allclose(b[2], a[2], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(b[3], a[3], rtol=2e-5)
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-2, atol=1e-2)
+    assert a[4] == b[4] == 1

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids > gpurun_out/pytest_gpu.log
 tail -4 gpurun_out/pytest_gpu.log; grep -n "^E  " gpurun_out/pytest_gpu.log | head -20
 for L in nhwc nchw; do
-  timeout 600 python bench.py --steps 10 --warmup 3 --no_cpu_baseline --layout $L 2>&1 | grep -v amdgpu.ids > gpurun_out/bench_$L.log
+  timeout 600 python bench.py --steps 20 --warmup 6 --no_cpu_baseline --layout $L $EXTRA 2>&1 | grep -v amdgpu.ids > gpurun_out/bench_$L.log
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/bench_$L.log") if x.startswith("{")]
