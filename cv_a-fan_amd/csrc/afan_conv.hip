@@ -16,6 +16,7 @@
 // fragments), double buffered, one barrier per step, next step's global loads in flight under the MFMAs.  The epilogue
 // rounds to bf16 through LDS so that every store is a 16-byte piece of a channels-last row.
 #include "afan_common.h"
+#include <stdlib.h>
 
 using namespace afan;
 
@@ -54,21 +55,14 @@ struct ConvP {
     ConvClass cls[4];
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>   // PF = global-load prefetch distance in K-steps (1 or 2 register sets)
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
-    // flatten the class selected by blockIdx.z into the names the body uses
-    struct {
-        const uint16_t* x; const uint16_t* w; uint16_t* y;
-        int N, Hi, Wi, Ci, Ho, Wo, Co, Hg, Wg, in_s, out_s, out_h0, out_w0, T, w_row_stride;
-        const int *dh, *dw, *wofs;
-    } p;
     const ConvClass& cc = pp.cls[blockIdx.z];
-    p.x = pp.x; p.w = pp.w; p.y = pp.y; p.N = pp.N; p.Hi = pp.Hi; p.Wi = pp.Wi; p.Ci = pp.Ci;
-    p.Ho = pp.Ho; p.Wo = pp.Wo; p.Co = pp.Co; p.in_s = pp.in_s; p.out_s = pp.out_s; p.w_row_stride = pp.w_row_stride;
-    p.Hg = cc.Hg; p.Wg = cc.Wg; p.out_h0 = cc.out_h0; p.out_w0 = cc.out_w0; p.T = cc.T;
-    p.dh = cc.dh; p.dw = cc.dw; p.wofs = cc.wofs;
-    if ((int64_t)blockIdx.y * BM >= (int64_t)p.N * p.Hg * p.Wg) return;   // smaller class than the grid's tallest
-    constexpr int TM = BM / 2, TN = BN / 2;          // wave tile
+    const uint32_t Wg = (uint32_t)cc.Wg, Hg = (uint32_t)cc.Hg;
+    const uint32_t M = (uint32_t)pp.N * Hg * Wg;
+    const uint32_t m0 = blockIdx.y * BM;
+    if (m0 >= M) return;   // smaller class than the grid's tallest
+    constexpr int TM = BM / 2, TN = BN / 2;          // wave tile (pixels x channels)
     constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
     constexpr int STAGE = (BM + BN) * LDK;           // elements per buffer
@@ -77,76 +71,82 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int64_t M = (int64_t)p.N * p.Hg * p.Wg;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
+    const int T = cc.T, Ci = pp.Ci, Hi = pp.Hi, Wi = pp.Wi;
 
-    // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each ------------------------
+    // Buffer descriptors: out-of-range offsets read as zero in hardware, so the zero padding of the convolution (and
+    // rows beyond M) costs one v_cndmask per load instead of a branch around it.  All offsets are 32-bit bytes.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(pp.x), 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(pp.w), 0, (int)((int64_t)pp.Co * pp.w_row_stride * 2), 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+
+    // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each (32-bit index math) -------
     const int piece = tid & 7, row0 = tid >> 3;
-    int64_t a_base[A_ROWS];
+    uint32_t a_off[A_ROWS];   // byte offset of (n, hi0, wi0, piece*8)
     uint32_t a_valid[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const int64_t m = m0 + row0 + 32 * i;
-        a_base[i] = 0;
+        const uint32_t m = m0 + row0 + 32 * i;
+        a_off[i] = 0;
         a_valid[i] = 0;
         if (m < M) {
-            const int wg = (int)(m % p.Wg);
-            const int64_t t1 = m / p.Wg;
-            const int hg = (int)(t1 % p.Hg);
-            const int n = (int)(t1 / p.Hg);
-            const int hi0 = hg * p.in_s, wi0 = wg * p.in_s;
-            a_base[i] = (((int64_t)n * p.Hi + hi0) * p.Wi + wi0) * p.Ci + piece * 8;
+            const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
+            const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
+            const int hi0 = (int)hg * pp.in_s, wi0 = (int)wg * pp.in_s;
+            a_off[i] = (((n * Hi + hi0) * Wi + wi0) * Ci + piece * 8) * 2u;
             uint32_t v = 0;
-            for (int t = 0; t < p.T; ++t) {
-                const int hi = hi0 + p.dh[t], wi = wi0 + p.dw[t];
-                if (hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi) v |= 1u << t;
+#pragma unroll
+            for (int t = 0; t < MAX_TAPS; ++t) {
+                const int hi = hi0 + cc.dh[t], wi = wi0 + cc.dw[t];
+                if (t < T && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v |= 1u << t;
             }
             a_valid[i] = v;
         }
     }
     // output row offsets (elements) for the epilogue, -1 = row outside M
     for (int r = tid; r < BM; r += THREADS) {
-        const int64_t m = m0 + r;
+        const uint32_t m = m0 + r;
         int off = -1;
         if (m < M) {
-            const int wg = (int)(m % p.Wg);
-            const int64_t t1 = m / p.Wg;
-            const int hg = (int)(t1 % p.Hg);
-            const int n = (int)(t1 / p.Hg);
-            off = (int)((((int64_t)n * p.Ho + hg * p.out_s + p.out_h0) * p.Wo + wg * p.out_s + p.out_w0) * p.Co);
+            const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
+            const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
+            off = (int)(((n * pp.Ho + hg * pp.out_s + cc.out_h0) * pp.Wo + wg * pp.out_s + cc.out_w0) * pp.Co);
         }
         out_off[r] = off;
     }
-    const int64_t b_base = (int64_t)(n0 + row0) * p.w_row_stride + piece * 8;
+    const uint32_t b_off = ((uint32_t)(n0 + row0) * pp.w_row_stride + piece * 8) * 2u;
+    const uint32_t b_row32 = 32u * pp.w_row_stride * 2u;
 
-    f32x16 acc[MI][NI];
+    // accumulators: acc[j][i] = channels tile j x pixels tile i (weights are the MFMA A operand, so a lane ends up
+    // with 4 consecutive CHANNELS of one pixel per register quad: 8-byte packed bf16 on the way out)
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    const int chunks = p.Ci / BK;
-    const int KS = p.T * chunks;
-    u32x4 ra[A_ROWS], rb[B_ROWS];
+    const int chunks = Ci / BK;
+    const int KS = T * chunks;
+    u32x4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
 
-    auto gload = [&](int ks) {
+    auto gload = [&](int ks, u32x4 (&ra)[A_ROWS], u32x4 (&rb)[B_ROWS]) {
         const int t = ks / chunks, q = ks - t * chunks;
-        const int64_t a_tap = ((int64_t)p.dh[t] * p.Wi + p.dw[t]) * p.Ci + q * BK;
-        const int64_t b_tap = (int64_t)p.wofs[t] + q * BK;
+        const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK) * 2);   // may be "negative": wraps
+        const uint32_t b_tap = (uint32_t)((cc.wofs[t] + q * BK) * 2);
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((a_valid[i] >> t) & 1u) v = *reinterpret_cast<const u32x4*>(p.x + a_base[i] + a_tap);
-            ra[i] = v;
+            const uint32_t off = ((a_valid[i] >> t) & 1u) ? a_off[i] + a_tap : OOB;
+            ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            rb[i] = *reinterpret_cast<const u32x4*>(p.w + b_base + (int64_t)(32 * i) * p.w_row_stride + b_tap);
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(b_off + i * b_row32), (int)b_tap, 0));
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const u32x4 (&ra)[A_ROWS], const u32x4 (&rb)[B_ROWS]) {
         uint16_t* A = lds + buf * STAGE;
         uint16_t* B = A + BM * LDK;
 #pragma unroll
@@ -156,49 +156,76 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         for (int i = 0; i < B_ROWS; ++i)
             *reinterpret_cast<u32x4*>(B + (row0 + 32 * i) * LDK + piece * 8) = rb[i];
     };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
-    for (int ks = 0; ks < KS; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < KS) gload(ks + 1);  // in flight under this step's MFMAs
+    auto compute = [&](int buf) {
         const uint16_t* A = lds + buf * STAGE;
         const uint16_t* B = A + BM * LDK;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fa[MI], fb[NI];
+            bf16x8 fx[MI], fw[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDK + kk * 16 + fk);
+                fx[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDK + kk * 16 + fk);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                fb[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDK + kk * 16 + fk);
+                fw[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDK + kk * 16 + fk);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
         }
-        if (ks + 1 < KS) lstore(buf ^ 1);
+    };
+
+    if constexpr (PF == 1) {
+        gload(0, ra0, rb0);
+        lstore(0, ra0, rb0);
         __syncthreads();
+        for (int ks = 0; ks < KS; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < KS) gload(ks + 1, ra0, rb0);  // in flight under this step's MFMAs
+            compute(buf);
+            if (ks + 1 < KS) lstore(buf ^ 1, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        // two register sets: the loads of step k+2 are issued at the top of step k and written to LDS at the bottom of
+        // step k+1, so they have a whole step (MFMAs + barrier) more to land.  Unrolled by 2: static register sets.
+        gload(0, ra0, rb0);
+        lstore(0, ra0, rb0);
+        if (KS > 1) gload(1, ra1, rb1);
+        __syncthreads();
+        for (int ks = 0; ks < KS; ks += 2) {
+            if (ks + 2 < KS) gload(ks + 2, ra0, rb0);
+            compute(0);
+            if (ks + 1 < KS) lstore(1, ra1, rb1);
+            __syncthreads();
+            if (ks + 1 < KS) {
+                if (ks + 3 < KS) gload(ks + 3, ra1, rb1);
+                compute(1);
+                if (ks + 2 < KS) lstore(0, ra0, rb0);
+                __syncthreads();
+            }
+        }
     }
 
-    // ---- epilogue: fp32 accumulators -> bf16 tile in LDS -> 16-byte channels-last stores ---------------------
+    // ---- epilogue: fp32 accumulators -> packed bf16 tile [pixel][channel] in LDS -> 16-byte channels-last stores ------
     constexpr int LDC = BN + 8;
     uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i) {
+            const int pix = wr * TM + i * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = wc * TN + j * 32 + (lane & 31);
-                C[row * LDC + col] = f2bf(acc[i][j][r]);
+            for (int g = 0; g < 4; ++g) {
+                const int ch = wc * TN + j * 32 + 8 * g + 4 * (lane >> 5);
+                u16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = f2bf(acc[j][i][4 * g + e]);
+                *reinterpret_cast<u16x4*>(C + pix * LDC + ch) = v;
             }
+        }
     __syncthreads();
     constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
     constexpr int ROWS_PER_PASS = THREADS / PIECES;
@@ -218,7 +245,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         const int off = out_off[r];
         if (off >= 0) {
             const u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
-            *reinterpret_cast<u16x8*>(p.y + (int64_t)off + n0 + pc * 8) = v;
+            *reinterpret_cast<u16x8*>(pp.y + (int64_t)off + n0 + pc * 8) = v;
             if (want_stats) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -255,8 +282,8 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
                 b += red[w][1][tid];
             }
             const int64_t G = gridDim.y;
-            pp.stats[((int64_t)0 * p.Co + n0 + tid) * G + blockIdx.y] = a;
-            pp.stats[((int64_t)1 * p.Co + n0 + tid) * G + blockIdx.y] = b;
+            pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + blockIdx.y] = a;
+            pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + blockIdx.y] = b;
         }
     }
 }
@@ -270,7 +297,7 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 int launch(const ConvP& p, hipStream_t st) {
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
@@ -279,12 +306,12 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv_igemm_kernel<BM, BN><<<grid, THREADS, lds, st>>>(p);
+    conv_igemm_kernel<BM, BN, PF><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -296,17 +323,27 @@ int choose_bm(int64_t M, int co, int n_classes) {
     return wg_128 >= 384 ? 128 : 64;
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 int dispatch(const ConvP& p, hipStream_t st) {
+    static const int pf = env_int("AFAN_CONV_PF", 1);   // tuning knob (tools/conv_bench.py A/B); measured: no gain from 2
     const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
-    if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128>(p, st) : launch<64, 128>(p, st);
-    return bm == 128 ? launch<128, 64>(p, st) : launch<64, 64>(p, st);
+    if (pf == 1) {
+        if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128, 1>(p, st) : launch<64, 128, 1>(p, st);
+        return bm == 128 ? launch<128, 64, 1>(p, st) : launch<64, 64, 1>(p, st);
+    }
+    if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128, 2>(p, st) : launch<64, 128, 2>(p, st);
+    return bm == 128 ? launch<128, 64, 2>(p, st) : launch<64, 64, 2>(p, st);
 }
 
 int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
     if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // caller falls back for the 3-channel stem
     if (!(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
-    if (n * hi * wi * (ci > co ? ci : co) > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit output offsets
+    if (n * hi * wi * (ci > co ? ci : co) * 2 > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit byte offsets / buffer descriptors
     return AFAN_OK;
 }
 
