@@ -1,0 +1,266 @@
+// Weight-gradient convolution for the bf16 channels-last backbone on gfx950 (MFMA 32x32x16 bf16, fp32 accumulate).
+// Part of the joint backward of the A-FAN step (Classification/main_perturb.py:200 `loss.backward()`): every tail
+// convolution gets two weight-gradient passes per iteration (adv branch + clean branch), every head convolution one.
+//
+//   dW[co][r][s][ci] += sum over output pixels p of  dy[p][co] * x[pixel(p) + (r - pad, s - pad)][ci]
+//
+// GEMM view per tap: rows = co, cols = ci, reduction = pixels.  Both operands are stored pixel-major (channels-last), i.e.
+// the reduction index is the SLOW index in memory — the transpose an MFMA operand needs is done by the LDS read itself:
+// tiles are staged row-major ([pixel][channel], plain 16-byte coalesced copies, hardware zero-fill for the padding)
+// and fragments are fetched with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered
+// channel-per-lane).  Row stride = channels + 32 elements puts the 4 pixel rows of a read on disjoint bank quarters.
+//
+// Work split: one workgroup = one (co tile, ci tile, tap, pixel slice); it writes an fp32 partial tile to a slab
+// [slice][tap][co][ci]; a second launch sums the slices IN ORDER (deterministic, no float atomics) and ADDS the result
+// into the fp32 gradient arena (KRSC), so autograd's AccumulateGrad, the bf16->fp32 cast and the split-K workspace
+// zero/cast passes of the vendor path all disappear.
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int BKP = 64;   // pixels per step
+
+struct FastDiv {  // q = x / d for x < 2^31 (Granlund-Montgomery): (umulhi(x, m) + x) >> l
+    uint32_t m, l;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1u << l) < d) ++l;
+    f.l = l;
+    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t x, FastDiv f) { return (__umulhi(x, f.m) + x) >> f.l; }
+
+struct WgradP {
+    const uint16_t* x;   // [N, Hi, Wi, Ci]
+    const uint16_t* dy;  // [N, Ho, Wo, Co]
+    float* slab;         // [S][taps][Co][Ci]
+    int N, Hi, Wi, Ci, Ho, Wo, Co;
+    int k, stride, pad;
+    int S;               // pixel slices
+    int steps_per_slice; // BKP-pixel steps per slice (last slice may be ragged; rows beyond P read as zero)
+    uint32_t P;          // N*Ho*Wo
+    FastDiv dWo, dHo;
+};
+
+template <int BM, int BN>   // BM = co tile, BN = ci tile
+__global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
+    constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 32, NI = TN / 32;
+    constexpr int LDA = BM + 32, LDB = BN + 32;            // elements per LDS row
+    constexpr int PA = BM / 8, PB = BN / 8;                // 16-byte pieces per row
+    constexpr int RA = THREADS / PA, RB = THREADS / PB;    // rows covered per pass
+    constexpr int NA = BKP / RA, NB = BKP / RB;            // pieces per thread per step
+    __shared__ __attribute__((aligned(16))) uint16_t As[BKP * LDA];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[BKP * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = p.Ci / BN;
+    const int co0 = (blockIdx.x / tiles_n) * BM, ci0 = (blockIdx.x % tiles_n) * BN;
+    const int tap = blockIdx.y, slice = blockIdx.z;
+    const int dh = tap / p.k - p.pad, dw = tap % p.k - p.pad;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.Ci * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.dy), 0, (int)((int64_t)p.P * p.Co * 2), 0x00020000);
+    constexpr uint32_t OOB = 0x80000000u;
+
+    const int pa = tid % PA, ra0 = tid / PA;   // dy tile: piece / first row
+    const int pb = tid % PB, rb0 = tid / PB;   // x tile
+    const uint32_t p_begin = (uint32_t)slice * p.steps_per_slice * BKP;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 va[NA], vb[NB];
+    auto gload = [&](int ks) {
+        const uint32_t pbase = p_begin + ks * BKP;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const uint32_t pix = pbase + ra0 + i * RA;
+            const uint32_t off = pix < p.P ? (pix * p.Co + co0 + pa * 8) * 2u : OOB;
+            va[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t pix = pbase + rb0 + i * RB;
+            const uint32_t t1 = fdiv(pix, p.dWo), wo = pix - t1 * p.Wo;
+            const uint32_t n = fdiv(t1, p.dHo), ho = t1 - n * p.Ho;
+            const int hi = (int)ho * p.stride + dh, wi = (int)wo * p.stride + dw;
+            const bool ok = pix < p.P && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
+            const uint32_t off = ok ? (((n * p.Hi + hi) * p.Wi + wi) * p.Ci + ci0 + pb * 8) * 2u : OOB;
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(As + (ra0 + i * RA) * LDA + pa * 8) = va[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(Bs + (rb0 + i * RB) * LDB + pb * 8) = vb[i];
+    };
+    // transposed fragment: lane l gets channel c_base + (l & 31), pixels kbase + 8*(l >> 5) + 0..7
+    const int fr = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int fc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto frag = [&](const uint16_t* T, int ld, int kbase, int cbase) -> bf16x8 {
+        typedef s16x4 __attribute__((address_space(3))) * lptr;
+        const uint16_t* a0 = T + (kbase + fr) * ld + cbase + fc;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * ld));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // ragged last slice: steps that start beyond P contribute nothing
+    int KS = p.steps_per_slice;
+    {
+        const int64_t remaining = (int64_t)p.P - (int64_t)p_begin;
+        const int64_t need = remaining <= 0 ? 0 : (remaining + BKP - 1) / BKP;
+        if (need < KS) KS = (int)need;
+    }
+    if (KS > 0) gload(0);
+    for (int ks = 0; ks < KS; ++ks) {
+        lstore();
+        __syncthreads();
+        if (ks + 1 < KS) gload(ks + 1);   // in flight under the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BKP / 16; ++kk) {
+            bf16x8 fa[MI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = frag(As, LDA, kk * 16, wr * TM + i * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = frag(Bs, LDB, kk * 16, wc * TN + j * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // partial tile -> slab[slice][tap][co][ci] (ci contiguous: 32 lanes write 128 consecutive bytes)
+    const int taps = p.k * p.k;
+    float* out = p.slab + (((int64_t)slice * taps + tap) * p.Co) * p.Ci;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ci = ci0 + wc * TN + j * 32 + (lane & 31);
+                out[(int64_t)co * p.Ci + ci] = acc[i][j][r];
+            }
+}
+
+// grad[co][tap][ci] (+)= sum_s slab[s][tap][co][ci], slices added in index order
+__global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad,
+                                                               int S, int taps, int Co, int Ci, int accumulate) {
+    const int64_t per = (int64_t)taps * Co * Ci;
+    const int64_t nvec = per / 4;
+    for (int64_t v = (int64_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * THREADS) {
+        const int64_t e = v * 4;                       // index into [tap][co][ci]
+        const int ci = (int)(e % Ci);
+        const int64_t t2 = e / Ci;
+        const int co = (int)(t2 % Co);
+        const int tap = (int)(t2 / Co);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slab + k * per + e);
+        float* g = grad + ((int64_t)co * taps + tap) * Ci + ci;
+        if (accumulate) s += *reinterpret_cast<const f32x4*>(g);
+        *reinterpret_cast<f32x4*>(g) = s;
+    }
+}
+
+struct Plan {
+    int bm, bn, S, steps;
+};
+
+Plan make_plan(int64_t P, int co, int ci, int taps) {
+    Plan pl;
+    pl.bm = (co % 128 == 0) ? 128 : 64;
+    pl.bn = (ci % 128 == 0) ? 128 : 64;
+    const int64_t tiles = (int64_t)(co / pl.bm) * (ci / pl.bn) * taps;
+    const int64_t total_steps = (P + BKP - 1) / BKP;
+    int64_t S = 320 / tiles;                       // ~1.25 workgroups per CU
+    const int64_t max_s = total_steps / 16 > 0 ? total_steps / 16 : 1;   // >= 16 steps per workgroup
+    if (S > max_s) S = max_s;
+    if (S < 1) S = 1;
+    pl.steps = (int)((total_steps + S - 1) / S);
+    pl.S = (int)((total_steps + pl.steps - 1) / pl.steps);
+    return pl;
+}
+
+template <int BM, int BN>
+int launch(const WgradP& p, int taps, hipStream_t st) {
+    dim3 grid((unsigned)((p.Co / BM) * (p.Ci / BN)), (unsigned)taps, (unsigned)p.S);
+    wgrad_kernel<BM, BN><<<grid, THREADS, 0, st>>>(p);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of workspace the call below needs for its partial slabs
+int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2))
+        return 0;
+    const int pad = k / 2;
+    const int64_t P = n * ((hi + 2 * pad - k) / stride + 1) * ((wi + 2 * pad - k) / stride + 1);
+    const Plan pl = make_plan(P, (int)co, (int)ci, k * k);
+    return (int64_t)pl.S * k * k * co * ci;
+}
+
+// grad[Co,k,k,Ci] (fp32, KRSC) (+)= wgrad(x[N,Hi,Wi,Ci], dy[N,Ho,Wo,Co]); bf16 channels-last operands.
+int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                              int64_t co, int k, int stride, float* workspace, int accumulate, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
+    if (ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
+    if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
+    if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 16) || !aligned(workspace, 16)) return AFAN_EALIGN;
+    const int pad = k / 2;
+    const int64_t ho = (hi + 2 * pad - k) / stride + 1, wo = (wi + 2 * pad - k) / stride + 1;
+    const int64_t P = n * ho * wo;
+    if (P * co * 2 > 0x7fffffffLL || n * hi * wi * ci * 2 > 0x7fffffffLL) return AFAN_ESHAPE;
+    const int taps = k * k;
+    const Plan pl = make_plan(P, (int)co, (int)ci, taps);
+    WgradP p{};
+    p.x = (const uint16_t*)x; p.dy = (const uint16_t*)dy; p.slab = workspace;
+    p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
+    p.k = k; p.stride = stride; p.pad = pad; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
+    p.dWo = make_fastdiv((uint32_t)wo); p.dHo = make_fastdiv((uint32_t)ho);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    {
+        AFAN_PROF("conv_wgrad_kernel", 2.0 * (double)taps * (P * co + P * ci) + 4.0 * pl.S * taps * co * ci, st);
+        if (pl.bm == 128) rc = pl.bn == 128 ? launch<128, 128>(p, taps, st) : launch<128, 64>(p, taps, st);
+        else rc = pl.bn == 128 ? launch<64, 128>(p, taps, st) : launch<64, 64>(p, taps, st);
+    }
+    if (rc) return rc;
+    const int64_t per = (int64_t)taps * co * ci;
+    AFAN_PROF("conv_wgrad_reduce_kernel", 4.0 * per * (pl.S + 1 + (accumulate ? 1 : 0)), st);
+    wgrad_reduce_kernel<<<grid_for(per / 4, THREADS, 1024), THREADS, 0, st>>>(workspace, grad, pl.S, taps, (int)co, (int)ci,
+                                                                              accumulate);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // extern "C"

@@ -348,6 +348,25 @@ def conv_dgrad(dy, wt, in_hw, stride):
     return dx
 
 
+def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False):
+    """Weight gradient of y = conv2d(x, w, padding=k//2, stride): returns / adds into an fp32 [Co,Ci,k,k] tensor with
+    channels_last strides (KRSC memory, the parameter arena's layout)."""
+    lib = _lib.load()
+    _cl4(x, "x"), _cl4(dy, "dy")
+    n, ci, hi, wi = x.shape
+    co = dy.shape[1]
+    if grad is None:
+        grad = torch.empty((co, ci, k, k), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        accumulate = False
+    _need(grad, "grad", torch.float32)
+    if tuple(grad.shape) != (co, ci, k, k) or not (grad.is_contiguous(memory_format=torch.channels_last) or k == 1 or ci == 1):
+        raise ValueError("grad must be an fp32 [Co,Ci,k,k] tensor in KRSC (channels_last) memory order")
+    ws = _workspace(x, lib.afan_conv_wgrad_workspace_floats(n, hi, wi, ci, co, k, stride), "wgrad")
+    check(lib.afan_conv_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, ci, co, k, stride, _ptr(ws),
+                                        int(bool(accumulate)), _stream(x)), "afan_conv_wgrad_nhwc_bf16")
+    return grad
+
+
 def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):
     """Batched KRSC -> CRSK transpose of all convolution weights listed in desc_dev (see include/afan_hip.h)."""
     lib = _lib.load()

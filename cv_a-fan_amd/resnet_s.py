@@ -103,21 +103,32 @@ class _ConvFn(torch.autograd.Function):
         need_gw = ctx.want_wgrad and ctx.needs_input_grad[1]
         gy = _like_layout(gy, x) if x.dim() == 4 and gy.shape[2:] == x.shape[2:] else _dense(gy)
         gx = gw = None
-        if need_gx and ctx.own and gy.is_contiguous(memory_format=torch.channels_last):
+        own = ctx.own and gy.is_contiguous(memory_format=torch.channels_last)
+        if need_gx and own:
             gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0])
             need_gx = False
+        if need_gw and own:
+            w_master = ctx.w_master
+            k = w_lp.shape[2]
+            if _accumulates_in_place(w_master) and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
+                # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd
+                ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
+            else:
+                gw = ops.conv_wgrad(x, gy, k, ctx.stride[0])
+            need_gw = False
         if need_gx or need_gw:
-            g2, gw, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, (1, 1), False,
+            g2, g3, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, (1, 1), False,
                                                             (0, 0), 1, [need_gx, need_gw, False])
             if need_gx:
                 gx = g2
-        if gw is not None:
-            w_master = ctx.w_master
-            if _accumulates_in_place(w_master):
-                w_master.grad.add_(gw)      # bf16 wgrad summed straight into the fp32 arena view: one launch
-                gw = None
-            elif gw.dtype != torch.float32:
-                gw = gw.float()
+            if need_gw:
+                gw = g3
+                w_master = ctx.w_master
+                if _accumulates_in_place(w_master):
+                    w_master.grad.add_(gw)      # bf16 wgrad summed straight into the fp32 arena view: one launch
+                    gw = None
+                elif gw.dtype != torch.float32:
+                    gw = gw.float()
         return gx, gw, None, None, None, None, None, None
 
 

@@ -177,6 +177,15 @@ int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, afan_stream_t stream);
 
+/* Weight gradient: grad[Co,k,k,Ci] (fp32, KRSC — the layout of the parameter arena) (+)= sum over output pixels of
+ * dy[p][co] * x[pixel(p) + tap][ci]; bf16 channels-last operands, the `loss.backward()` of main_perturb.py:200 for the
+ * conv weights.  Deterministic two-launch split over pixel slices (partials in `workspace`, summed in order);
+ * accumulate != 0 adds into grad (the two branches of the joint loss both contribute to tail weights). */
+int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
+int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
+                              int64_t ci, int64_t co, int k, int stride, float* workspace, int accumulate,
+                              afan_stream_t stream);
+
 /* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
  * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
  * offsets into src_arena / dst_arena, K % 64 == 0, C % 64 == 0, first_tile = running sum of (K/64)*RS*(C/64)). */

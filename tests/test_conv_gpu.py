@@ -86,3 +86,25 @@ def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, n, ci, co, h, k, stride)
     np.testing.assert_allclose(b[3], a[3], rtol=2e-5)
     np.testing.assert_allclose(b[0], a[0], rtol=1e-2, atol=1e-2)
     assert a[4] == b[4] == 1
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", CASES + [(256, 128, 128, 16, 3, 1), (7, 64, 64, 5, 3, 1)])
+def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
+    torch.manual_seed(n + ci + co + h + k + stride)
+    x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    dy = _cl((torch.randn(n, co, ho, ho, device=gpu) / (n * ho * ho) ** 0.5).bfloat16())
+    w = torch.zeros(co, ci, k, k, device=gpu)
+    ref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (stride, stride), (k // 2, k // 2), (1, 1),
+                                              False, (0, 0), 1, [False, True, False])[1]
+    g = pkg.ops.conv_wgrad(x, dy, k, stride)
+    assert g.shape == ref.shape and g.dtype == torch.float32
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(g.cpu().numpy(), ref.cpu().numpy(), rtol=2e-3, atol=2e-3 * scale)   # fp32 accumulation both sides
+    # accumulate into an existing KRSC buffer (the arena's gradient view), twice: the two branches of the joint loss
+    acc = torch.ones((co, ci, k, k), device=gpu).contiguous(memory_format=torch.channels_last)
+    pkg.ops.conv_wgrad(x, dy, k, stride, acc, accumulate=True)
+    pkg.ops.conv_wgrad(x, dy, k, stride, acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 1 + 2 * ref.cpu().numpy(), rtol=2e-3, atol=4e-3 * scale)
+    # bitwise reproducible (deterministic slice order, no atomics)
+    assert torch.equal(pkg.ops.conv_wgrad(x, dy, k, stride), g)

@@ -32,7 +32,10 @@ for (ci, co, h, k, s) in shapes:
     mf = timeit(lambda: torch.ops.aten.convolution(x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1)) if not os.environ.get("NO_MIOPEN") else 0.0
     ad = timeit(lambda: pkg.ops.conv_dgrad(dy, wt, (h, h), s))
     md = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1, [True, False, False])) if not os.environ.get("NO_MIOPEN") else 0.0
-    tot["af"] += af; tot["mf"] += mf; tot["ad"] += ad; tot["md"] += md
+    aw = timeit(lambda: pkg.ops.conv_wgrad(x, dy, k, s))
+    mw = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1, [False, True, False])) if not os.environ.get("NO_MIOPEN") else 0.0
+    tot["af"] += af; tot["mf"] += mf; tot["ad"] += ad; tot["md"] += md; tot["aw"] = tot.get("aw", 0) + aw; tot["mw"] = tot.get("mw", 0) + mw
+    print(f"      wgrad afan {aw:7.1f}us ({flops/aw/1e6:6.1f} TF) miopen {mw:7.1f}us")
     print(f"ci{ci:4d} co{co:4d} h{h:3d} k{k} s{s}: fwd afan {af:7.1f}us ({flops/af/1e6:6.1f} TF) miopen {mf:7.1f}us ({flops/max(mf,1e-9)/1e6:6.1f} TF) | "
           f"dgrad afan {ad:7.1f}us ({flops/ad/1e6:6.1f} TF) miopen {md:7.1f}us ({flops/max(md,1e-9)/1e6:6.1f} TF)", flush=True)
 print("sum:", {k: round(v) for k, v in tot.items()})
