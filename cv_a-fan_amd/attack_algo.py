@@ -12,7 +12,7 @@ switched off (the reference asks autograd for the feature gradient only, attack_
 import torch
 
 from . import ops
-from .resnet_s import dgrad_only
+from .resnet_s import _dense, _like_layout, dgrad_only
 
 __all__ = ["PGD", "tensor_clamp", "linfball_proj", "mix_feature", "get_sample_points", "last_norms"]
 
@@ -50,13 +50,15 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
     """
     if x.device.type != "cuda":
         raise ops.AfanLibraryError("PGD: x must live on the MI355X (no CPU path in this build)")
-    x = x.detach().contiguous().float()
+    # keep whatever dense layout the feature map has (the bf16 backbone hands over channels-last tensors: a
+    # .contiguous() here would transpose 64 MB to NCHW and the tail would transpose it back every PGD step)
+    x = _dense(x.detach()).float()
     x_adv = x.clone()
     lp = getattr(model, "compute_dtype", torch.float32) == torch.bfloat16
-    shadow = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if lp else None
+    shadow = torch.empty_like(x, dtype=torch.bfloat16) if lp else None
     if randinit:
         # the reference draws the noise on the CPU default generator (attack_algo.py:44); same stream here
-        u = torch.rand(x_adv.shape).to(x.device, non_blocking=True)
+        u = _like_layout(torch.rand(x_adv.shape).to(x.device, non_blocking=True), x_adv)
         ops.axpy_noise_(x_adv, u, eps, shadow)
     elif lp:
         ops.cast_bf16(x_adv, shadow)
@@ -68,7 +70,7 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
             out = model(xin, end_point=layer_number, start_point=start_idx)
             loss = loss_fn(out, y)
             grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
-        grad = grad.contiguous()
+        grad = _like_layout(grad, x_adv)
         if with_norms and t == steps - 1:
             l2, linf = ops.pgd_step_norms_(x_adv, grad, gamma, x, eps, clip, shadow)
         else:

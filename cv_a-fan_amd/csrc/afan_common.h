@@ -107,18 +107,20 @@ static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<u
 // ---- optional per-launch event timing (afan_prof.hip) ----
 namespace afan { namespace prof {
 extern int g_enabled;
-void begin(const char* name, double bytes, hipStream_t st, size_t* slot);
+void begin(const char* name, double bytes, double flops, hipStream_t st, size_t* slot);
 void end(size_t slot, hipStream_t st);
 struct Scope {
     size_t slot; hipStream_t st; bool on;
-    Scope(const char* name, double bytes, hipStream_t s) : slot((size_t)-1), st(s), on(g_enabled != 0) {
-        if (on) begin(name, bytes, st, &slot);
+    Scope(const char* name, double bytes, hipStream_t s, double flops = 0.0) : slot((size_t)-1), st(s), on(g_enabled != 0) {
+        if (on) begin(name, bytes, flops, st, &slot);
     }
     ~Scope() { if (on) end(slot, st); }
 };
 } }
 // time the launches issued in the rest of the enclosing block as kernel `name` moving `bytes` algorithmic bytes
 #define AFAN_PROF(name, bytes, st) afan::prof::Scope afan_prof_scope__(name, (double)(bytes), st)
+// same, for MFMA-bound kernels: also records the launch's algorithmic FLOPs
+#define AFAN_PROF_FLOPS(name, bytes, flops, st) afan::prof::Scope afan_prof_scope__(name, (double)(bytes), st, (double)(flops))
 
 #define AFAN_LAUNCH_CHECK()                     \
     do {                                        \

@@ -388,7 +388,8 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
         }
     hipStream_t st = (hipStream_t)stream;
     const double M = (double)n * p.Ho * p.Wo;
-    AFAN_PROF("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci), st);
+    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
+                    2.0 * M * co * k * k * ci, st);
     return dispatch(p, st);
 }
 
@@ -409,7 +410,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
     p.w_row_stride = (int)(k * k * co);
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
-    AFAN_PROF("conv_igemm_dgrad_kernel", bytes, st);
+    AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
     p.in_s = 1;
     if (stride == 1) {
         // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]

@@ -12,7 +12,7 @@ namespace prof {
 
 struct Rec {
     const char* name;
-    double bytes;
+    double bytes, flops;
     hipEvent_t a, b;
 };
 
@@ -20,9 +20,9 @@ static std::mutex g_mu;
 static std::vector<Rec> g_recs;
 int g_enabled = 0;
 
-void begin(const char* name, double bytes, hipStream_t st, size_t* slot) {
+void begin(const char* name, double bytes, double flops, hipStream_t st, size_t* slot) {
     std::lock_guard<std::mutex> lk(g_mu);
-    Rec r{name, bytes, nullptr, nullptr};
+    Rec r{name, bytes, flops, nullptr, nullptr};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { *slot = (size_t)-1; return; }
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
@@ -49,7 +49,7 @@ int afan_profile_enable(int on) {
 // Synchronises the recorded events, aggregates per kernel name and clears the records.
 // names_out: caller buffer of max_kernels * 64 chars; returns the number of distinct kernels written.
 int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, double* total_bytes,
-                         int max_kernels) {
+                         double* total_flops, int max_kernels) {
     using namespace afan::prof;
     std::lock_guard<std::mutex> lk(g_mu);
     std::vector<std::string> names;
@@ -62,10 +62,10 @@ int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, d
         if (k < 0 && (int)names.size() < max_kernels) {
             names.emplace_back(r.name);
             k = (int)names.size() - 1;
-            launches[k] = 0; total_ms[k] = 0; total_bytes[k] = 0;
+            launches[k] = 0; total_ms[k] = 0; total_bytes[k] = 0; total_flops[k] = 0;
             snprintf(names_out + 64 * k, 64, "%s", r.name);
         }
-        if (k >= 0) { launches[k] += 1; total_ms[k] += ms; total_bytes[k] += r.bytes; }
+        if (k >= 0) { launches[k] += 1; total_ms[k] += ms; total_bytes[k] += r.bytes; total_flops[k] += r.flops; }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }

@@ -250,7 +250,8 @@ int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_
     hipStream_t st = (hipStream_t)stream;
     int rc;
     {
-        AFAN_PROF("conv_wgrad_kernel", 2.0 * (double)taps * (P * co + P * ci) + 4.0 * pl.S * taps * co * ci, st);
+        AFAN_PROF_FLOPS("conv_wgrad_kernel", 2.0 * (double)(P * co + n * hi * wi * ci) + 4.0 * pl.S * taps * co * ci,
+                        2.0 * (double)P * co * ci * taps, st);
         if (pl.bm == 128) rc = pl.bn == 128 ? launch<128, 128>(p, taps, st) : launch<128, 64>(p, taps, st);
         else rc = pl.bn == 128 ? launch<64, 128>(p, taps, st) : launch<64, 64>(p, taps, st);
     }

@@ -417,9 +417,11 @@ def profile_collect(max_kernels=32):
     launches = (C.c_int64 * max_kernels)()
     ms = (C.c_double * max_kernels)()
     nbytes = (C.c_double * max_kernels)()
-    k = lib.afan_profile_collect(names, launches, ms, nbytes, max_kernels)
+    nflops = (C.c_double * max_kernels)()
+    k = lib.afan_profile_collect(names, launches, ms, nbytes, nflops, max_kernels)
     out = {}
     for i in range(k):
         name = names.raw[64 * i:64 * (i + 1)].split(b"\0", 1)[0].decode()
-        out[name] = {"launches": int(launches[i]), "ms": float(ms[i]), "bytes": float(nbytes[i])}
+        out[name] = {"launches": int(launches[i]), "ms": float(ms[i]), "bytes": float(nbytes[i]),
+                     "flops": float(nflops[i])}
     return out

@@ -187,7 +187,7 @@ class AfanTrainer:
         self._static_in = (inp.clone(), target.clone())
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._stream):
+        with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
             out = self._forward_backward(self._static_in[0], self._static_in[1], overlap_allreduce=False)
             if self.world == 1:
                 self.optimizer.step()

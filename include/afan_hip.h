@@ -214,12 +214,12 @@ int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, 
  * Measurement aid (no reference counterpart): per-launch HIP-event timing of the kernels above, recorded
  * on the launch stream.  afan_profile_enable(1) starts recording (launches are then not graph-capturable),
  * afan_profile_collect() synchronises, aggregates per kernel name and clears: names_out holds max_kernels
- * 64-byte C strings; launches/total_ms/total_bytes are per-kernel launch counts, summed durations and summed
- * ALGORITHMIC bytes (DESIGN.md lists the per-element figures).  Returns the number of kernels written.
+ * 64-byte C strings; launches/total_ms/total_bytes/total_flops are per-kernel launch counts, summed durations, summed
+ * ALGORITHMIC bytes (DESIGN.md lists the per-element figures) and, for the MFMA kernels, summed algorithmic FLOPs.  Returns the number of kernels written.
  */
 int afan_profile_enable(int on);
 int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, double* total_bytes,
-                         int max_kernels);
+                         double* total_flops, int max_kernels);
 
 #ifdef __cplusplus
 }
