@@ -85,10 +85,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if os.environ.get("AFAN_BENCH_ONE_DEVICE"):     # functional test of the N>1 path on a 1-GPU box (gloo, all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        backend = os.environ.get("AFAN_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm (over xGMI)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     ctor, idx = pkg.resnet_s.ARCHS[args.arch]
@@ -126,12 +132,15 @@ def main():
     # ---- instrumented pass (not part of `value`): per-launch HIP-event timing of the hand-written kernels ----
     roof, kernels = None, None
     graphed = trainer._graph is not None
-    if rank == 0 and not args.no_roofline:
-        # per-launch event timing needs eager launches: the same step body, un-captured
-        pkg.ops.profile_enable(True)
+    if not args.no_roofline:
+        # per-launch event timing needs eager launches: the same step body, un-captured.  EVERY rank runs it (the step
+        # contains the gradient all-reduce); only rank 0 records.
+        if rank == 0:
+            pkg.ops.profile_enable(True)
         for i in range(2):
             trainer._step_eager(xs[i % nbuf], ys[i % nbuf])
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         prof = pkg.ops.profile_collect()
         pkg.ops.profile_enable(False)
         def _k(v):
