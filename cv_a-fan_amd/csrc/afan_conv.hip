@@ -28,8 +28,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int THREADS = 256;
 constexpr int BK = 64;           // reduction channels per step
-constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes
+constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes (register-staged variants)
 constexpr int MAX_TAPS = 9;
+
+// landing zone for the padding rows of the LDS-DMA variant (a DMA lane has to read SOMETHING: zeros)
+__device__ const uint4 conv_zero_page[4] = {};
 
 // One "class" = one set of output positions with its tap list.  A forward conv or a stride-1 dgrad has one class;
 // a stride-2 dgrad has four (output-pixel parity), run as blockIdx.z of ONE launch.
@@ -65,7 +68,9 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     constexpr int TM = BM / 2, TN = BN / 2;          // wave tile (pixels x channels)
     constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
-    constexpr int STAGE = (BM + BN) * LDK;           // elements per buffer
+    constexpr bool GLDS = (PF == 3);                 // operands go global -> LDS by DMA (no VGPR staging, no ds_write)
+    constexpr int LDR = GLDS ? BK : LDK;             // LDS row length: DMA rows are unpadded 128 B, XOR-swizzled instead
+    constexpr int STAGE = (BM + BN) * LDR;           // elements per buffer
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     __shared__ int out_off[BM];
 
@@ -83,7 +88,12 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     constexpr uint32_t OOB = 0x80000000u;
 
     // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each (32-bit index math) -------
-    const int piece = tid & 7, row0 = tid >> 3;
+    // LDS-DMA: the destination of a wave instruction is 1 KiB of consecutive LDS (8 unpadded rows), so the bank-conflict
+    // fix is a swizzle instead of padding: row r keeps its 16-byte piece q at position q ^ ((r >> 1) & 7).  Seen from
+    // the source side, thread t (linear LDS position: row t/8 + 32 i, slot t & 7) fetches logical piece
+    // (t & 7) ^ ((t >> 4) & 7) — the same for all its rows.
+    const int piece = GLDS ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
+    const int row0 = tid >> 3;
     uint32_t a_off[A_ROWS];   // byte offset of (n, hi0, wi0, piece*8)
     uint32_t a_valid[A_ROWS];
 #pragma unroll
@@ -158,17 +168,19 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     };
     auto compute = [&](int buf) {
         const uint16_t* A = lds + buf * STAGE;
-        const uint16_t* B = A + BM * LDK;
+        const uint16_t* B = A + BM * LDR;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
+        const int sw = (frow >> 1) & 7;     // GLDS swizzle of this lane's row (tile bases are multiples of 32 rows)
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 fx[MI], fw[NI];
+            const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ sw) * 8) : (kk * 16 + fk);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                fx[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDK + kk * 16 + fk);
+                fx[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                fw[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDK + kk * 16 + fk);
+                fw[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -177,7 +189,40 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         }
     };
 
-    if constexpr (PF == 1) {
+    // LDS-DMA issue of one K-step into buffer `buf`: A_ROWS + B_ROWS wave instructions, each 64 lanes x 16 B = 1 KiB of
+    // consecutive LDS; padding rows read the zero page
+    auto gdma = [&](int ks, int buf) {
+        const int t = ks / chunks, q = ks - t * chunks;
+        const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK) * 2);
+        const uint32_t b_tap = (uint32_t)((cc.wofs[t] + q * BK) * 2);
+        uint16_t* A = lds + buf * STAGE + wave * 512;          // wave-uniform: M0 base; hardware adds lane * 16 B
+        uint16_t* B = A + BM * LDR;
+        typedef __attribute__((address_space(1))) const void* gptr;
+        typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) {
+            const char* src = ((a_valid[i] >> t) & 1u)
+                                  ? reinterpret_cast<const char*>(pp.x) + (uint32_t)(a_off[i] + a_tap)
+                                  : reinterpret_cast<const char*>(conv_zero_page);
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(A + i * 2048), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) {
+            const char* src = reinterpret_cast<const char*>(pp.w) + (uint32_t)(b_off + i * b_row32 + b_tap);
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(B + i * 2048), 16, 0, 0);
+        }
+    };
+
+    if constexpr (GLDS) {
+        gdma(0, 0);
+        __syncthreads();                     // (the compiler drains vmcnt before the barrier)
+        for (int ks = 0; ks < KS; ++ks) {
+            const int buf = ks & 1;
+            if (ks + 1 < KS) gdma(ks + 1, buf ^ 1);   // lands while this step's MFMAs run
+            compute(buf);
+            __syncthreads();
+        }
+    } else if constexpr (PF == 1) {
         gload(0, ra0, rb0);
         lstore(0, ra0, rb0);
         __syncthreads();
@@ -301,7 +346,7 @@ template <int BM, int BN, int PF>
 int launch(const ConvP& p, hipStream_t st) {
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
-    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * LDK * 2;
+    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (PF == 3 ? BK : LDK) * 2;
     constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
@@ -329,14 +374,20 @@ static int env_int(const char* name, int dflt) {
 }
 
 int dispatch(const ConvP& p, hipStream_t st) {
-    static const int pf = env_int("AFAN_CONV_PF", 1);   // tuning knob (tools/conv_bench.py A/B); measured: no gain from 2
-    const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
-    if (pf == 1) {
-        if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128, 1>(p, st) : launch<64, 128, 1>(p, st);
-        return bm == 128 ? launch<128, 64, 1>(p, st) : launch<64, 64, 1>(p, st);
-    }
-    if (p.Co % 128 == 0) return bm == 128 ? launch<128, 128, 2>(p, st) : launch<64, 128, 2>(p, st);
-    return bm == 128 ? launch<128, 64, 2>(p, st) : launch<64, 64, 2>(p, st);
+    // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
+    static const int mode = env_int("AFAN_CONV_MODE", 3);
+    static const int force_bm = env_int("AFAN_CONV_BM", 0);   // tuning knob
+    const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
+    const bool n128 = p.Co % 128 == 0;
+#define AFAN_CONV_GO(M)                                                                                      \
+    do {                                                                                                     \
+        if (n128) return bm == 128 ? launch<128, 128, M>(p, st) : launch<64, 128, M>(p, st);                 \
+        return bm == 128 ? launch<128, 64, M>(p, st) : launch<64, 64, M>(p, st);                             \
+    } while (0)
+    if (mode == 1) AFAN_CONV_GO(1);
+    if (mode == 2) AFAN_CONV_GO(2);
+    AFAN_CONV_GO(3);
+#undef AFAN_CONV_GO
 }
 
 int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {

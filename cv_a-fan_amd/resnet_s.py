@@ -25,6 +25,13 @@ __all__ = ["ResNet", "BasicBlock", "resnet20", "resnet56", "resnet18", "ARCHS", 
 class _Flags:
     param_grads = True  # False inside PGD: only d(loss)/d(feature) is needed (attack_algo.py:52 only_inputs=True)
     weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
+    wgrad_stream = None  # side stream for weight-gradient kernels (set by AfanTrainer; None = same stream)
+
+
+def join_wgrad_stream():
+    """Make the current stream wait for the weight-gradient kernels issued on the side stream (before SGD / all-reduce)."""
+    if _Flags.wgrad_stream is not None:
+        torch.cuda.current_stream().wait_stream(_Flags.wgrad_stream)
 
 
 @contextlib.contextmanager
@@ -111,8 +118,18 @@ class _ConvFn(torch.autograd.Function):
             w_master = ctx.w_master
             k = w_lp.shape[2]
             if _accumulates_in_place(w_master) and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
-                # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd
-                ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
+                # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd.
+                # Weight gradients are off the backward's critical path (the dgrad -> BN-backward chain), so they go to
+                # a side stream and fill the SIMD slots the latency-bound chain leaves idle; joined before the SGD step.
+                side = _Flags.wgrad_stream
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
+                    x.record_stream(side)
+                    gy.record_stream(side)
+                else:
+                    ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
             else:
                 gw = ops.conv_wgrad(x, gy, k, ctx.stride[0])
             need_gw = False

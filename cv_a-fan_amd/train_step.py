@@ -119,7 +119,7 @@ class AfanTrainer:
 
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
-                 group=None, use_graph=True, graph_warmup=3):
+                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -132,6 +132,8 @@ class AfanTrainer:
         self.reducer = GradAllReducer(self.arena, allreduce_chunks, group) if self.world > 1 else None
         if self.world > 1:
             self.optimizer.grad_scale = 1.0 / self.world
+        self.async_wgrad = bool(async_wgrad)
+        self._wgrad_stream = None
         self.use_graph = bool(use_graph) and not randinit
         self.graph_warmup = graph_warmup
         self._graph = None
@@ -165,7 +167,17 @@ class AfanTrainer:
         self.optimizer.zero_grad()
         if overlap_allreduce:
             self.reducer.begin()
-        loss.backward()
+        from . import resnet_s
+        if self.async_wgrad and inp.is_cuda:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=inp.device)
+            resnet_s._Flags.wgrad_stream = self._wgrad_stream
+            self._wgrad_stream.wait_stream(torch.cuda.current_stream())   # zero_grad before any accumulation
+        try:
+            loss.backward()
+        finally:
+            resnet_s.join_wgrad_stream()
+            resnet_s._Flags.wgrad_stream = None
         with torch.no_grad():
             prec1 = (output_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
