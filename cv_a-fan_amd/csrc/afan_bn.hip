@@ -23,7 +23,8 @@ int fwd(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C
 int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, float* ws, float* stats_out, float* rm,
           float* rv, int64_t* nbt, hipStream_t st);
 int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
-        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st);
+        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st,
+        const float* partials, int64_t partials_g);
 int64_t workspace_floats(int64_t c);
 }
 
@@ -556,18 +557,21 @@ int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int l
 
 int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype, int layout,
                      int64_t n, int64_t c, int64_t hw, const float* save_stats, const float* weight, const float* bias,
-                     int relu, float* workspace, float* dweight, float* dbias, int accumulate, afan_stream_t stream) {
+                     int relu, float* workspace, float* dweight, float* dbias, int accumulate, const float* partials,
+                     int64_t partials_g, afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
     if ((e = check_layout(layout))) return e;
     if (!dy || !x || !dx || !save_stats || !workspace) return AFAN_ENULL;
+    if (partials && (layout != AFAN_NHWC || partials_g <= 0)) return AFAN_ESHAPE;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(dy, a) || !aligned(x, a) || !aligned(dx, a) || (y && !aligned(y, a)) ||
         (d_residual && !aligned(d_residual, a)))
         return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (layout == AFAN_NHWC)
-        return afan_nhwc::bwd(dtype, dy, x, y, dx, d_residual, n * hw, c, save_stats, relu, workspace, dweight, dbias, accumulate, st);
+        return afan_nhwc::bwd(dtype, dy, x, y, dx, d_residual, n * hw, c, save_stats, relu, workspace, dweight, dbias, accumulate, st,
+                              partials, partials_g);
     const float* mean = save_stats;
     const float* invstd = save_stats + c;
     if (dtype == AFAN_F32)

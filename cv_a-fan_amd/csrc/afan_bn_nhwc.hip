@@ -443,14 +443,20 @@ int stats_only(const void* x, int64_t M, int64_t C, float eps, float momentum, f
 
 template <typename T>
 int backward(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
-             const float* stats, int relu, float* ws, float* dweight, float* dbias, int accumulate, hipStream_t st) {
+             const float* stats, int relu, float* ws, float* dweight, float* dbias, int accumulate, hipStream_t st,
+             const float* partials = nullptr, int64_t partials_g = 0) {
     Plan p;
     if (!make_plan<T>(M, C, {dy, x, y, dx, dres}, p)) return AFAN_ESHAPE;
     p.vec = p.vec && aligned(stats, 16);
     constexpr int NV = Elt<T>::VEC;
     const T* dy_ = (const T*)dy; const T* x_ = (const T*)x; const T* y_ = (const T*)y;
     float* coef = ws + (int64_t)2 * C * MAX_G;  // [2][C] after the partials (16-byte aligned: C*MAX_G*8 bytes)
-    {
+    const float* red = ws;
+    int red_g = p.G;
+    if (partials) {   // the producing dgrad's epilogue already took the sums
+        red = partials;
+        red_g = (int)partials_g;
+    } else {
         AFAN_PROF("bn_nhwc_bwd_reduce_kernel", p.tensor_bytes * ((relu && y) ? 3 : 2), st);
 #define AFAN_RED(RELU, HY)                                                                                        \
     do {                                                                                                          \
@@ -464,9 +470,9 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
     }
     AFAN_LAUNCH_CHECK();
     {
-        AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
+        AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * red_g, st);
         finalize_kernel<T, 1><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
-            ws, p.G, (int)C, nullptr, 1.0f / (float)M, (float)M, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(stats),
+            red, red_g, (int)C, nullptr, 1.0f / (float)M, (float)M, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(stats),
             coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate, nullptr);
     }
     AFAN_LAUNCH_CHECK();
@@ -500,9 +506,11 @@ int stats(int dtype, const void* x, int64_t M, int64_t C, float eps, float mom, 
                              : stats_only<uint16_t>(x, M, C, eps, mom, ws, stats_out, rm, rv, nbt, st);
 }
 int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
-        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st) {
-    return dtype == AFAN_F32 ? backward<float>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st)
-                             : backward<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st);
+        const float* stats_in, int relu, float* ws, float* dw, float* db, int acc, hipStream_t st,
+        const float* partials, int64_t partials_g) {
+    return dtype == AFAN_F32
+               ? backward<float>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g)
+               : backward<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g);
 }
 // partials [2][C][MAX_G] + coef [2][C] + eval-mode stats [4][C]
 int64_t workspace_floats(int64_t c) { return c > 0 ? 2 * c * MAX_G + 2 * c + 4 * c : 0; }

@@ -53,8 +53,12 @@ struct ConvP {
     int out_s;
     int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
     int n_classes;
-    float* stats;                // optional [2][Co][gridDim.y] per-tile column sums of (y - shift), (y - shift)^2
-    const float* shift;          // optional [Co] shift of those sums (the BN layer's running mean), NULL = 0
+    float* stats;                // optional [2][Co][G] per-tile column sums, G = gridDim.y * gridDim.z; meaning by `bnx`:
+    const float* shift;          //   bnx == NULL: sum (y - shift), sum (y - shift)^2      (moments for a following BN forward)
+    const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):
+    const float* bn_stats;       //     g = relu-masked y, sums g and g*(bnx - mean) from bn_stats[4][Co] = mean|invstd|alpha|beta
+    int bn_relu;                 //     (the reduction pass of that BN's backward, fused here)
+    const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
     ConvClass cls[4];
 };
 
@@ -64,7 +68,15 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     const uint32_t Wg = (uint32_t)cc.Wg, Hg = (uint32_t)cc.Hg;
     const uint32_t M = (uint32_t)pp.N * Hg * Wg;
     const uint32_t m0 = blockIdx.y * BM;
-    if (m0 >= M) return;   // smaller class than the grid's tallest
+    if (m0 >= M) {         // smaller class than the grid's tallest: nothing to compute, but its partial slots must read 0
+        if (pp.stats && threadIdx.x < BN) {
+            const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+            const int c = blockIdx.x * BN + threadIdx.x;
+            pp.stats[((int64_t)0 * pp.Co + c) * G + slot] = 0.f;
+            pp.stats[((int64_t)1 * pp.Co + c) * G + slot] = 0.f;
+        }
+        return;
+    }
     constexpr int TM = BM / 2, TN = BN / 2;          // wave tile (pixels x channels)
     constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
@@ -275,23 +287,44 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
     constexpr int ROWS_PER_PASS = THREADS / PIECES;
     const int pc = tid % PIECES, pr = tid / PIECES;
-    // Optional BatchNorm statistics of THIS tile, taken from the bf16 values on their way out (same LDS reads as the
-    // stores): the following train-mode BN then needs no pass over the tensor for its moments — one partial per
-    // (tile, channel), summed by its finalize.
+    // Optional fusions on the way out (same LDS reads as the stores):
+    //  * addend: y += addend (the other branch of a residual gradient), rounded to bf16 like a separate add would;
+    //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
+    //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
     const bool want_stats = pp.stats != nullptr;
-    float s1[8], s2[8], sh[8];
+    const bool bn_bwd = want_stats && pp.bnx != nullptr;
+    float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
-        sh[j] = (want_stats && pp.shift) ? pp.shift[n0 + pc * 8 + j] : 0.f;
+        const int c = n0 + pc * 8 + j;
+        sh[j] = bn_bwd ? pp.bn_stats[c] : ((want_stats && pp.shift) ? pp.shift[c] : 0.f);   // mean or shift
+        al[j] = bn_bwd ? pp.bn_stats[2 * pp.Co + c] : 0.f;
+        be[j] = bn_bwd ? pp.bn_stats[3 * pp.Co + c] : 0.f;
     }
 #pragma unroll
     for (int r = pr; r < BM; r += ROWS_PER_PASS) {
         const int off = out_off[r];
         if (off >= 0) {
-            const u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
-            *reinterpret_cast<u16x8*>(pp.y + (int64_t)off + n0 + pc * 8) = v;
-            if (want_stats) {
+            u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+            const int64_t go = (int64_t)off + n0 + pc * 8;
+            if (pp.addend) {
+                const u16x8 a = *reinterpret_cast<const u16x8*>(pp.addend + go);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
+            }
+            *reinterpret_cast<u16x8*>(pp.y + go) = v;
+            if (bn_bwd) {
+                const u16x8 xv = *reinterpret_cast<const u16x8*>(pp.bnx + go);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xf = bf2f(xv[j]);
+                    float g = bf2f(v[j]);
+                    if (pp.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;   // mask recomputed exactly as the forward
+                    s1[j] += g;
+                    s2[j] += g * (xf - sh[j]);
+                }
+            } else if (want_stats) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float f = bf2f(v[j]) - sh[j];
@@ -326,9 +359,9 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
                 a += red[w][0][tid];
                 b += red[w][1][tid];
             }
-            const int64_t G = gridDim.y;
-            pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + blockIdx.y] = a;
-            pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + blockIdx.y] = b;
+            const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+            pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
+            pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + slot] = b;
         }
     }
 }
@@ -444,9 +477,33 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     return dispatch(p, st);
 }
 
+// number of partial slots per channel the dgrad launch of this problem writes when asked for fused BN-backward sums
+int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+    if (check_dims(n, hi, wi, co, ci, k, stride)) return 0;
+    if (stride == 1) {
+        const int64_t M = n * hi * wi;
+        const int bm = choose_bm(M, (int)ci, 1);
+        return (M + bm - 1) / bm;
+    }
+    int nc = 0;
+    int64_t mmax = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int64_t hg = (hi - ph + 1) / 2, wg = (wi - pw + 1) / 2;
+            if (hg <= 0 || wg <= 0) continue;
+            ++nc;
+            if (n * hg * wg > mmax) mmax = n * hg * wg;
+        }
+    const int bm = choose_bm(mmax, (int)ci, nc);
+    return ((mmax + bm - 1) / bm) * nc;
+}
+
 // dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w) given wt[Ci,k,k,Co] = w[Co,k,k,Ci] transposed (CRSK).
+// Optional epilogue fusions: dx += addend (same shape as dx);  bn_x/bn_stats/bn_partials: dx is the gradient entering
+// the backward of the BatchNorm whose input was bn_x — its reduction sums are written to bn_partials[2][Ci][G].
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                              int64_t co, int k, int stride, afan_stream_t stream) {
+                              int64_t co, int k, int stride, const void* addend, const void* bn_x,
+                              const float* bn_stats, int bn_relu, float* bn_partials, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
     if (e) return e;
     if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
@@ -460,6 +517,11 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.N = (int)n; p.Hi = ho; p.Wi = wo; p.Ci = (int)co;      // GEMM input = dy
     p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
     p.w_row_stride = (int)(k * k * co);
+    p.addend = (const uint16_t*)addend;
+    if (bn_partials) {
+        if (!bn_x || !bn_stats) return AFAN_ENULL;
+        p.stats = bn_partials; p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu;
+    }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
     p.in_s = 1;

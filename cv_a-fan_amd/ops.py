@@ -271,8 +271,10 @@ def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
     return y
 
 
-def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False):
-    """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given."""
+def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False,
+                partials=None):
+    """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given.
+    partials: ConvStats written by the dgrad that produced dy (conv_dgrad(..., bn_bwd=...)): skips the reduction pass."""
     lib = _lib.load()
     _need(dy, "dy", x.dtype)
     _need(x, "x")
@@ -285,7 +287,8 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
     check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], layout_of(x), n, c, hw,
                                _ptr(stats), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _ptr(dweight),
-                               _ptr(dbias), int(bool(accumulate)), _stream(x)), "afan_bn_backward")
+                               _ptr(dbias), int(bool(accumulate)), _ptr(partials.partials) if partials else None,
+                               int(partials.g) if partials else 0, _stream(x)), "afan_bn_backward")
     return dx, dres
 
 
@@ -333,8 +336,10 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
     return (y, st) if want_stats else y
 
 
-def conv_dgrad(dy, wt, in_hw, stride):
-    """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory)."""
+def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None):
+    """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
+    addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient
+    entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward)."""
     lib = _lib.load()
     _cl4(dy, "dy"), _cl4(wt, "wt")
     n, co, ho, wo = dy.shape
@@ -343,9 +348,26 @@ def conv_dgrad(dy, wt, in_hw, stride):
         raise ValueError("transposed weight shape does not match dy")
     hi, wi = in_hw
     dx = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
-    check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _stream(dy)),
-          "afan_conv_dgrad_nhwc_bf16")
-    return dx
+    if addend is not None:
+        _cl4(addend, "addend")
+        if addend.shape != dx.shape:
+            raise ValueError("addend must have dx's shape")
+    st = bnx = bstats = None
+    relu = 0
+    if bn_bwd is not None:
+        bnx, bstats, relu = bn_bwd
+        _cl4(bnx, "bn_x")
+        _need(bstats, "bn_stats", torch.float32)
+        if bnx.shape != dx.shape or bstats.numel() != 4 * ci:
+            raise ValueError("bn_x / bn_stats do not match dx")
+        g = lib.afan_conv_dgrad_tiles(n, hi, wi, ci, co, k, stride)
+        if partials_buf is None or partials_buf.numel() < 2 * ci * g:
+            partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
+        st = ConvStats(partials_buf, g, None)
+    check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _ptr(addend),
+                                        _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(st.partials) if st else None,
+                                        _stream(dy)), "afan_conv_dgrad_nhwc_bf16")
+    return (dx, st) if bn_bwd is not None else dx
 
 
 def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False):

@@ -26,6 +26,7 @@ class _Flags:
     param_grads = True  # False inside PGD: only d(loss)/d(feature) is needed (attack_algo.py:52 only_inputs=True)
     weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
     wgrad_stream = None  # side stream for weight-gradient kernels (set by AfanTrainer; None = same stream)
+    block_fusion = True  # BasicBlock as one autograd node on the bf16 channels-last fast path (_BlockFn)
 
 
 def join_wgrad_stream():
@@ -155,15 +156,21 @@ def _accumulates_in_place(p):
     return isinstance(p, torch.nn.Parameter) and p.grad is not None and getattr(p, "_afan_arena_grad", False)
 
 
-def _own_conv_ok(x, w, stride, padding):
-    if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
-        return False
-    if not w.is_contiguous(memory_format=torch.channels_last) or w.shape[2] != w.shape[3]:
+def _own_conv_ok_shape(w, stride, padding):
+    if w.dtype != torch.bfloat16 or w.shape[2] != w.shape[3]:
         return False
     k = w.shape[2]
+    if not (w.is_contiguous(memory_format=torch.channels_last) or k == 1):
+        return False
     if stride[0] != stride[1] or padding[0] != k // 2 or padding[1] != k // 2:
         return False
     return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0])
+
+
+def _own_conv_ok(x, w, stride, padding):
+    if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    return _own_conv_ok_shape(w, stride, padding)
 
 
 class _BNTrainFn(torch.autograd.Function):
@@ -200,6 +207,77 @@ class _BNTrainFn(torch.autograd.Function):
         if direct:
             dw = db = None
         return dx, dw, db, dres, None, None, None, None, None, None, None, None
+
+
+class _BlockFn(torch.autograd.Function):
+    """A whole BasicBlock as ONE autograd node on the bf16 channels-last fast path:
+         raw1 = conv1(x) [+moments] -> a1 = relu(bn1) -> raw2 = conv2(a1) [+moments] -> out = relu(bn2(raw2) + shortcut(x))
+    The hand-ordered backward fuses what autograd's per-op graph cannot: the reduction pass of bn1's backward rides in
+    conv2's dgrad epilogue, the sum of the two gradient branches arriving at the block input rides in conv1's dgrad
+    epilogue (no separate add launches), parameter gradients are accumulated by the kernels into the arena views.
+    `params` only tell autograd which leaves the node depends on; values are read from the modules."""
+
+    @staticmethod
+    def forward(ctx, x, blk, want_pgrad, *params):
+        c1, b1, c2, b2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
+        s = c1.stride[0]
+        mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
+        raw1, st = ops.conv_fwd(x, c1.lp_weight(), s, stats_shift=b1.running_mean, want_stats=True, stats_buf=c1._stats_buf)
+        c1._stats_buf = st.partials
+        a1, s1 = ops.bn_train_forward(raw1, b1.weight, b1.bias, None, True, b1.eps, mom(b1), b1.running_mean,
+                                      b1.running_var, b1.num_batches_tracked, st)
+        raw2, st = ops.conv_fwd(a1, c2.lp_weight(), 1, stats_shift=b2.running_mean, want_stats=True, stats_buf=c2._stats_buf)
+        c2._stats_buf = st.partials
+        rawsc = ssc = None
+        if blk._sc_kind == "conv":
+            csc, bsc = blk.shortcut[0], blk.shortcut[1]
+            rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
+                                      stats_buf=csc._stats_buf)
+            csc._stats_buf = stc.partials
+            res, ssc = ops.bn_train_forward(rawsc, bsc.weight, bsc.bias, None, False, bsc.eps, mom(bsc), bsc.running_mean,
+                                            bsc.running_var, bsc.num_batches_tracked, stc)
+        else:
+            res = x
+        out, s2 = ops.bn_train_forward(raw2, b2.weight, b2.bias, res, True, b2.eps, mom(b2), b2.running_mean,
+                                       b2.running_var, b2.num_batches_tracked, st)
+        ctx.blk, ctx.want_pgrad = blk, want_pgrad
+        ctx.save_for_backward(x, raw1, a1, raw2, out, s1, s2, rawsc, ssc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, raw1, a1, raw2, out, s1, s2, rawsc, ssc = ctx.saved_tensors
+        blk, pg = ctx.blk, ctx.want_pgrad
+        c1, b1, c2, b2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
+        need_dx = ctx.needs_input_grad[0]
+        g = lambda p: p.grad if pg else None
+        gout = _like_layout(gout, out)
+        # bn2 (+residual, ReLU mask from `out`): gradient to raw2 and to the shortcut branch
+        d_raw2, dres = ops.bn_backward(gout, raw2, out, s2, b2.weight, b2.bias, True, True, g(b2.weight), g(b2.bias), pg)
+        # conv2: dgrad carries bn1's backward reduction in its epilogue; wgrad straight into the arena
+        d_a1, part = ops.conv_dgrad(d_raw2, c2.lp_weight_t(), a1.shape[2:], 1, bn_bwd=(raw1, s1, True),
+                                    partials_buf=c2._bwd_buf)
+        c2._bwd_buf = part.partials
+        if pg:
+            ops.conv_wgrad(a1, d_raw2, c2.kernel_size[0], 1, c2.weight.grad, accumulate=True)
+        d_raw1, _ = ops.bn_backward(d_a1, raw1, None, s1, b1.weight, b1.bias, True, False, g(b1.weight), g(b1.bias), pg,
+                                    partials=part)
+        if pg:
+            ops.conv_wgrad(x, d_raw1, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
+        dx = None
+        if blk._sc_kind == "conv":
+            csc, bsc = blk.shortcut[0], blk.shortcut[1]
+            if pg or need_dx:
+                d_rawsc, _ = ops.bn_backward(dres, rawsc, None, ssc, bsc.weight, bsc.bias, False, False, g(bsc.weight),
+                                             g(bsc.bias), pg)
+                if pg:
+                    ops.conv_wgrad(x, d_rawsc, csc.kernel_size[0], csc.stride[0], csc.weight.grad, accumulate=True)
+                if need_dx:
+                    dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
+                    dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc)
+        elif need_dx:
+            dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres)
+        return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
 # ---------------------------------------------------------------------------------------------- layers
@@ -260,6 +338,7 @@ class Conv2d(nn.Conv2d):
                              _Flags.param_grads)
 
     _stats_buf = None
+    _bwd_buf = None
 
     def forward_with_stats(self, x, bn):
         """Convolution whose epilogue also sums the moments the train-mode BatchNorm `bn` is about to need.
@@ -320,16 +399,54 @@ class BasicBlock(nn.Module):
         self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
         self.bn2 = BatchNorm2d(planes)
         self.shortcut = nn.Sequential()
+        self._sc_kind = "identity"
         if stride != 1 or in_planes != planes:
             if option == "A":
                 self.shortcut = _PadShortcut(planes)
+                self._sc_kind = "pad"
             else:
                 self.shortcut = nn.Sequential(
                     Conv2d(in_planes, self.expansion * planes, kernel_size=1, stride=stride, bias=False),
                     BatchNorm2d(self.expansion * planes))
+                self._sc_kind = "conv"
+
+    def _fast_path_ok(self, x):
+        """bf16 channels-last training step with every convolution on the library's MFMA kernels and every parameter's
+        gradient buffer owned by the arena (or parameter gradients switched off, as inside PGD)."""
+        c1, c2 = self.conv1, self.conv2
+        if c1.compute_dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != 4:
+            return False
+        if not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda:
+            return False
+        mods = [self.bn1, self.bn2]
+        convs = [c1, c2]
+        if self._sc_kind == "conv":
+            convs.append(self.shortcut[0])
+            mods.append(self.shortcut[1])
+        elif self._sc_kind != "identity":
+            return False
+        if not all(m.training and m.track_running_stats for m in mods):
+            return False
+        for c in convs:
+            w = c.lp_weight()
+            if not _own_conv_ok_shape(w, c.stride, c.padding):
+                return False
+        if _Flags.param_grads and torch.is_grad_enabled():
+            ps = [c.weight for c in convs] + [m.weight for m in mods] + [m.bias for m in mods]
+            if not all(_accumulates_in_place(p) for p in ps):
+                return False
+        return True
+
+    def _params(self):
+        ps = [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias]
+        if self._sc_kind == "conv":
+            ps += [self.shortcut[0].weight, self.shortcut[1].weight, self.shortcut[1].bias]
+        return ps
 
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
+        if _Flags.block_fusion and self._fast_path_ok(x):
+            return _BlockFn.apply(x, self, _Flags.param_grads, *self._params())
         out, st = self.conv1.forward_with_stats(x, self.bn1)
         out = self.bn1.fused(out, None, True, st)
         out, st = self.conv2.forward_with_stats(out, self.bn2)

@@ -155,7 +155,10 @@ int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int l
 int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
                      int layout, int64_t n, int64_t c, int64_t hw, const float* save_stats,
                      const float* weight, const float* bias, int relu, float* workspace, float* dweight,
-                     float* dbias, int accumulate, afan_stream_t stream);
+                     float* dbias, int accumulate, const float* partials, int64_t partials_g,
+                     afan_stream_t stream);
+/* partials != NULL (AFAN_NHWC only): the reduction sums were already taken by the producing dgrad's epilogue
+ * ([2][C][partials_g], see afan_conv_dgrad_nhwc_bf16): only finalize + apply run. */
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside
@@ -175,7 +178,16 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
  * (shift = the BN layer's running mean, NULL = 0).  afan_bn_train_forward_partials() consumes them. */
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
-                              int64_t ci, int64_t co, int k, int stride, afan_stream_t stream);
+                              int64_t ci, int64_t co, int k, int stride, const void* addend, const void* bn_x,
+                              const float* bn_stats, int bn_relu, float* bn_partials, afan_stream_t stream);
+/* dgrad epilogue fusions (all optional, NULL = off):
+ *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
+ *               both the main branch and the shortcut;
+ *   bn_x, bn_stats, bn_relu, bn_partials: dx is the gradient arriving at the output of the BatchNorm(+ReLU) whose INPUT
+ *               was bn_x and whose saved statistics block is bn_stats[4*Ci]; the reduction pass of that BN's backward
+ *               (sum g, sum g*(x-mean), g = ReLU-masked dx) is taken here: bn_partials[2][Ci][G],
+ *               G = afan_conv_dgrad_tiles(...), consumed by afan_bn_backward(..., partials, G). */
+int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 
 /* Weight gradient: grad[Co,k,k,Ci] (fp32, KRSC — the layout of the parameter arena) (+)= sum over output pixels of
  * dy[p][co] * x[pixel(p) + tap][ci]; bf16 channels-last operands, the `loss.backward()` of main_perturb.py:200 for the

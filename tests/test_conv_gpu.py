@@ -108,3 +108,33 @@ def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
     np.testing.assert_allclose(acc.cpu().numpy(), 1 + 2 * ref.cpu().numpy(), rtol=2e-3, atol=4e-3 * scale)
     # bitwise reproducible (deterministic slice order, no atomics)
     assert torch.equal(pkg.ops.conv_wgrad(x, dy, k, stride), g)
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 128, 256, 16, 1, 2),
+                                                 (64, 128, 128, 16, 3, 1), (3, 256, 512, 9, 3, 2)])
+def test_dgrad_epilogue_fusions(pkg, gpu, n, ci, co, h, k, stride):
+    """dgrad + addend == dgrad then add; dgrad's fused BN-backward partials == the stand-alone reduction pass."""
+    torch.manual_seed(ci + co + h + k)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    dy = _cl(torch.randn(n, co, ho, ho, device=gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, device=gpu) / (co * k * k) ** 0.5).bfloat16())
+    wt = _cl(w.permute(1, 0, 2, 3))
+    plain = pkg.ops.conv_dgrad(dy, wt, (h, h), stride)
+    addend = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    fused = pkg.ops.conv_dgrad(dy, wt, (h, h), stride, addend=addend)
+    assert torch.equal(fused, plain + addend)                       # same fp32 add + one bf16 rounding
+    # a BN(+ReLU) whose input was bn_x; its backward receives `plain` as dy
+    bn_x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    gamma, beta = torch.rand(ci, device=gpu) + 0.5, torch.randn(ci, device=gpu) * 0.3
+    for relu in (True, False):
+        y, stats = pkg.ops.bn_train_forward(bn_x, gamma, beta, None, relu, 1e-5, 0.1, None, None, None)
+        dx2, st = pkg.ops.conv_dgrad(dy, wt, (h, h), stride, bn_bwd=(bn_x, stats, relu))
+        assert torch.equal(dx2, plain)
+        outs = []
+        for partials in (None, st):
+            dwb = torch.zeros(2, ci, device=gpu)
+            dxb, _ = pkg.ops.bn_backward(plain, bn_x, None, stats, gamma, beta, relu, False, dwb[0], dwb[1], partials=partials)
+            outs.append((dxb.float().cpu().numpy(), dwb.cpu().numpy()))
+        scale = max(1.0, float(np.abs(outs[0][1]).max()))
+        np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-4 * scale)      # dweight, dbias
+        np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(outs[0][0]).max())))

@@ -221,3 +221,34 @@ def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, case):
     for k in g.files:
         if k.startswith("sd1/") and "num_batches" not in k:
             np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=wtol, err_msg=k)
+
+
+def test_block_fusion_matches_per_op_path(pkg, orc, gpu):
+    """The one-node BasicBlock (_BlockFn: fused dgrad epilogues, in-kernel gradient accumulation) against the per-op
+    autograd path on the same bf16 kernels.  K = 0 isolates the joint forward/backward (no sign() amplification):
+    gradients agree at bf16 level; K = 3 compares the losses and the BN side effects of a full step."""
+    res = {}
+    for K in (0, 3):
+        for fused in (False, True):
+            pkg.resnet_s._Flags.block_fusion = fused
+            try:
+                model = _build(pkg, orc, "resnet18", gpu, dtype=torch.bfloat16)
+                model.set_channels_last(True)
+                tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=6,
+                                                lr=0.1, use_graph=False)
+                torch.manual_seed(0)
+                x, y = torch.rand(32, 3, 32, 32, device=gpu), torch.randint(0, 10, (32,), device=gpu)
+                r = tr.step(x, y)
+                res[(K, fused)] = (float(r["loss"]), float(r["loss_adv"]), tr.arena.grad.clone().cpu().numpy(),
+                                   {k: v.clone().cpu() for k, v in model.state_dict().items()})
+            finally:
+                pkg.resnet_s._Flags.block_fusion = True
+    a, b = res[(0, False)], res[(0, True)]
+    assert abs(a[0] - b[0]) < 1e-3 and abs(a[1] - b[1]) < 1e-3
+    rel = np.linalg.norm(b[2] - a[2]) / np.linalg.norm(a[2])
+    assert rel < 2e-2, rel                       # whole gradient arena: bf16-level agreement
+    a, b = res[(3, False)], res[(3, True)]
+    assert abs(a[0] - b[0]) < 5e-3 and abs(a[1] - b[1]) < 1e-2
+    for k in a[3]:
+        if "num_batches" in k:
+            assert int(a[3][k]) == int(b[3][k]), k     # same BN side effects (K+2 / 2 updates)
