@@ -31,6 +31,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 BF16_DENSE_PEAK_TFLOPS = 2500.0
 GFLOP_PER_IMAGE = {"resnet18": 14.1, "resnet20s": None, "resnet56s": 2.99}   # 4H + (2K+6)T at K=5
+GFLOP_PER_IMAGE_K3 = {"resnet50": 85.5}                                       # K=3, 224^2, perturb after layer1
+ARCH_INPUT = {"resnet50": (224, 1000)}                                        # (image side, classes); default (32, 10)
 
 
 def parse():
@@ -62,7 +64,8 @@ def cpu_baseline(arch, batch, pgd_steps, idx, timed_steps):
     opt = orc.make_optimizer(model)
     crit = nn.CrossEntropyLoss()
     ln = len(model.sequential_model)
-    x, y = torch.rand(batch, 3, 32, 32), torch.randint(0, 10, (batch,))
+    side, ncls = ARCH_INPUT.get(arch, (32, 10))
+    x, y = torch.rand(batch, 3, side, side), torch.randint(0, ncls, (batch,))
     kw = dict(steps=pgd_steps, gamma=0.5, eps=2.0, perturb_idx=idx, layer_number=ln)
     orc.afan_train_step(model, opt, crit, x[:16], y[:16], **kw)      # thread-pool / allocator warm-up (small)
     t0 = time.perf_counter()
@@ -108,8 +111,9 @@ def main():
                                          async_wgrad=args.async_wgrad)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4
-    xs = [torch.rand(args.batch, 3, 32, 32, generator=g).to(dev) for _ in range(nbuf)]
-    ys = [torch.randint(0, 10, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]
+    side, ncls = ARCH_INPUT.get(args.arch, (32, 10))
+    xs = [torch.rand(args.batch, 3, side, side, generator=g).to(dev) for _ in range(nbuf)]
+    ys = [torch.randint(0, ncls, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]
 
     def sync():
         if world > 1:
@@ -188,20 +192,24 @@ def main():
 
     if rank == 0:
         ips = args.batch * world * args.steps / dt
-        gf = GFLOP_PER_IMAGE.get(args.arch)
+        gf = GFLOP_PER_IMAGE.get(args.arch) if args.pgd_steps == 5 else None
+        if gf is None and args.pgd_steps == 3:
+            gf = GFLOP_PER_IMAGE_K3.get(args.arch)
+        default_cfg = args.arch == "resnet18" and args.pgd_steps == 5
         line = {
-            "metric": "images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10",
+            "metric": "images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10" if default_cfg else
+                      f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}",
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.arch} CIFAR-10-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
+            "config": {"workload": f"{args.arch} {'CIFAR-10' if side == 32 else 'ImageNet'}-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
                                    f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
                                    f"(BASELINE configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
                        "hipgraph": graphed},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if gf is not None and args.pgd_steps == 5:
+        if gf is not None:
             tf = gf * 1e9 * ips / 1e12
             line["conv_mfma"] = {"achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": BF16_DENSE_PEAK_TFLOPS,
                                  "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),

@@ -133,12 +133,12 @@ class DeviceLoader:
 class SyntheticLoader:
     """U[0,1) images / uniform labels (SURVEY.md §8d synthetic inputs), generated once, resident in HBM."""
 
-    def __init__(self, n, batch, device, rank=0, world=1, seed=3):
+    def __init__(self, n, batch, device, rank=0, world=1, seed=3, side=32, classes=10):
         g = torch.Generator().manual_seed(seed + 1000 * rank)
         per = batch // world
         self.n_batches = max(n // batch, 1)
-        self.x = [torch.rand(per, 3, 32, 32, generator=g).to(device) for _ in range(min(self.n_batches, 8))]
-        self.y = [torch.randint(0, 10, (per,), generator=g).to(device) for _ in range(min(self.n_batches, 8))]
+        self.x = [torch.rand(per, 3, side, side, generator=g).to(device) for _ in range(min(self.n_batches, 8))]
+        self.y = [torch.randint(0, classes, (per,), generator=g).to(device) for _ in range(min(self.n_batches, 8))]
 
     def __len__(self):
         return self.n_batches
@@ -226,6 +226,8 @@ def main(argv=None):
     log(args)
     if args.seed:
         setup_seed(args.seed)
+    if args.arch == "resnet50" and not args.synthetic:
+        raise SystemExit("--arch resnet50 is the ImageNet-shape synthetic configuration: pass --synthetic N")
     ctor, _ = resnet_s.ARCHS[args.arch]
     model = ctor()                      # constructed after seeding, on the host generator, like main_perturb.py:64
     layer_number = model.layer_number
@@ -240,8 +242,10 @@ def main(argv=None):
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=decreasing_lr, gamma=0.1)
 
     if args.synthetic:
-        train_loader = SyntheticLoader(args.synthetic, args.batch_size, dev, rank, world)
-        val_loader = test_loader = SyntheticLoader(max(args.synthetic // 10, args.batch_size), args.batch_size, dev)
+        side, classes = (224, 1000) if args.arch == "resnet50" else (32, 10)
+        train_loader = SyntheticLoader(args.synthetic, args.batch_size, dev, rank, world, side=side, classes=classes)
+        val_loader = test_loader = SyntheticLoader(max(args.synthetic // 10, args.batch_size), args.batch_size, dev,
+                                                   side=side, classes=classes)
     else:
         tr, va, te = _load_cifar10(args.data)
         train_loader = DeviceLoader(tr[0], tr[1], args.batch_size, dev, True, rank, world)

@@ -19,7 +19,8 @@ import torch.nn.functional as F
 
 from . import ops
 
-__all__ = ["ResNet", "BasicBlock", "resnet20", "resnet56", "resnet18", "ARCHS", "dgrad_only"]
+__all__ = ["ResNet", "ResNet50", "BasicBlock", "Bottleneck", "resnet20", "resnet56", "resnet18", "resnet50", "ARCHS",
+           "dgrad_only"]
 
 
 class _Flags:
@@ -459,6 +460,41 @@ class BasicBlock(nn.Module):
         return self.bn2.fused(out, res, True, st)
 
 
+class Bottleneck(nn.Module):
+    """ResNet-v1.5 bottleneck (1x1 -> 3x3 (stride) -> 1x1 x4; projection shortcut when the shape changes) for the
+    build-defined ImageNet-shape ResNet-50 (BASELINE config 3).  Every conv -> BN pair uses the fused moments epilogue;
+    BN+ReLU and BN+add+ReLU are single fused launches."""
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1, option="B"):
+        super().__init__()
+        out_planes = planes * 4
+        self.conv1 = Conv2d(in_planes, planes, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, out_planes, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn3 = BatchNorm2d(out_planes)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_planes != out_planes:
+            self.shortcut = nn.Sequential(Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False),
+                                          BatchNorm2d(out_planes))
+
+    def forward(self, x):
+        x = _to_compute(x, self.conv1.compute_dtype)
+        out, st = self.conv1.forward_with_stats(x, self.bn1)
+        out = self.bn1.fused(out, None, True, st)
+        out, st = self.conv2.forward_with_stats(out, self.bn2)
+        out = self.bn2.fused(out, None, True, st)
+        out, st = self.conv3.forward_with_stats(out, self.bn3)
+        if len(self.shortcut) == 2:
+            r, st_sc = self.shortcut[0].forward_with_stats(x, self.shortcut[1])
+            res = self.shortcut[1].fused(r, None, False, st_sc)
+        else:
+            res = x
+        return self.bn3.fused(out, res, True, st)
+
+
 class _HeadPool(nn.AdaptiveAvgPool2d):
     """Global average pool; accumulates and returns fp32 (the classifier head runs in fp32)."""
 
@@ -538,6 +574,36 @@ class ResNet(nn.Module):
         return x
 
 
+class ResNet50(ResNet):
+    """ImageNet-shape ResNet-50, same flat-Sequential slice protocol: 0 normalise, 1 conv7x7/2, 2 BN, 3 ReLU, 4 maxpool,
+    5-7 layer1, 8-11 layer2, 12-17 layer3, 18-20 layer4, 21 avgpool, 22 flatten, 23 fc (perturb_idx 8 = after layer1:
+    256 x 56 x 56 at 224^2)."""
+
+    def __init__(self, num_classes=1000, blocks=(3, 4, 6, 3), init_weight=1):
+        nn.Module.__init__(self)
+        self.all_layers = 9
+        layers = [NormalizeByChannelMeanStd(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
+                  Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), BatchNorm2d(64), nn.ReLU(),
+                  nn.MaxPool2d(3, 2, 1)]
+        in_planes = 64
+        for stage, (planes, nb) in enumerate(zip((64, 128, 256, 512), blocks)):
+            for b in range(nb):
+                layers.append(Bottleneck(in_planes, planes, 2 if (stage > 0 and b == 0) else 1))
+                in_planes = planes * 4
+        layers += [_HeadPool((1, 1)), nn.Flatten(), nn.Linear(in_planes, num_classes)]
+        self.sequential_model = nn.Sequential(*layers)
+        self.w = nn.Parameter(torch.full((self.all_layers,), float(init_weight)), requires_grad=True)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight)
+        self.compute_dtype = torch.float32
+        self.channels_last = False
+
+
+def resnet50(init_weight_eta=1, num_classes=1000):
+    return ResNet50(num_classes=num_classes, init_weight=init_weight_eta)
+
+
 def resnet20(init_weight_eta=1):
     return ResNet(BasicBlock, [3, 3, 3], init_weight=init_weight_eta)
 
@@ -552,4 +618,4 @@ def resnet18(init_weight_eta=1, num_classes=10):
 
 
 # name -> (constructor, default --perturb_idx): end of stage 1 in each flat index map
-ARCHS = {"resnet20s": (resnet20, 7), "resnet56s": (resnet56, 13), "resnet18": (resnet18, 6)}
+ARCHS = {"resnet20s": (resnet20, 7), "resnet56s": (resnet56, 13), "resnet18": (resnet18, 6), "resnet50": (resnet50, 8)}

@@ -72,6 +72,60 @@ class Block(nn.Module):
         return F.relu(o)
 
 
+class Bottleneck(nn.Module):
+    """torchvision-style ResNet-v1.5 bottleneck (1x1 -> 3x3 (stride) -> 1x1 x4, projection shortcut when the shape
+    changes).  Build-defined: the reference has no ImageNet-shape classifier (SURVEY.md warning 3); it follows the
+    same slice protocol so the reference's PGD drives it unchanged."""
+    expansion = 4
+
+    def __init__(self, cin, planes, stride):
+        super().__init__()
+        cout = planes * 4
+        self.conv1 = nn.Conv2d(cin, planes, 1, 1, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, cout, 1, 1, 0, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.shortcut = nn.Sequential()
+        if stride != 1 or cin != cout:
+            self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, t):
+        o = F.relu(self.bn1(self.conv1(t)))
+        o = F.relu(self.bn2(self.conv2(o)))
+        o = self.bn3(self.conv3(o))
+        o += self.shortcut(t)
+        return F.relu(o)
+
+
+class SlicedResNet50(nn.Module):
+    """ImageNet-shape ResNet-50 as one flat Sequential with the slice protocol: 0 normalise, 1 conv7x7/2, 2 BN, 3 ReLU,
+    4 maxpool, 5-7 layer1, 8-11 layer2, 12-17 layer3, 18-20 layer4, 21 avgpool, 22 flatten, 23 fc."""
+
+    def __init__(self, num_classes=1000, blocks=(3, 4, 6, 3)):
+        super().__init__()
+        layers = [ChannelNormalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]),
+                  nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1)]
+        cin = 64
+        for si, (planes, nb) in enumerate(zip((64, 128, 256, 512), blocks)):
+            for bi in range(nb):
+                layers.append(Bottleneck(cin, planes, 2 if (bi == 0 and si > 0) else 1))
+                cin = planes * 4
+        layers += [nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten(), nn.Linear(cin, num_classes)]
+        self.sequential_model = nn.Sequential(*layers)
+        self.all_layers = 9
+        self.w = nn.Parameter(torch.full((self.all_layers,), 1.0))
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x, end_point=None, start_point=0):
+        if end_point is None:
+            end_point = len(self.sequential_model)
+        return self.sequential_model[start_point:end_point](x)
+
+
 class SlicedResNet(nn.Module):
     """Flat nn.Sequential ResNet with the slice-forward protocol of Classification/resnet_s.py:79-121.
     widths/blocks/option select ResNet-20s/56s (16-32-64, option A: the reference's class) or the
@@ -113,7 +167,12 @@ def resnet18_cifar():
     return SlicedResNet([64, 128, 256, 512], [2, 2, 2, 2], "B")
 
 
-ARCHS = {"resnet20s": (resnet20s, 7), "resnet56s": (resnet56s, 13), "resnet18": (resnet18_cifar, 6)}
+def resnet50(num_classes=1000):
+    return SlicedResNet50(num_classes)
+
+
+ARCHS = {"resnet20s": (resnet20s, 7), "resnet56s": (resnet56s, 13), "resnet18": (resnet18_cifar, 6),
+         "resnet50": (resnet50, 8)}
 
 
 # --------------------------------------------------------------------------------------------------

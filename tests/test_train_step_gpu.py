@@ -252,3 +252,44 @@ def test_block_fusion_matches_per_op_path(pkg, orc, gpu):
     for k in a[3]:
         if "num_batches" in k:
             assert int(a[3][k]) == int(b[3][k]), k     # same BN side effects (K+2 / 2 updates)
+
+
+def test_resnet50_imagenet_shape_step(pkg, orc, gpu):
+    """BASELINE config 3 (build-defined ResNet-50, perturbation after layer1) at a size the CPU oracle finishes in
+    seconds: fp32 product vs oracle on identical weights/inputs (K = 1: one sign() step, so the adversarial loss is not
+    yet dominated by compounding sign flips through 2x2-pixel BatchNorm statistics), then K = 3 on the bf16
+    channels-last execution path (BN side effects, norms, loss sanity)."""
+    torch.manual_seed(3)
+    ref = orc.resnet50(num_classes=16)
+    ref.train()
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    x, y = torch.rand(4, 3, 64, 64), torch.randint(0, 16, (4,))
+    r_ref = orc.afan_train_step(ref, orc.make_optimizer(ref), nn.CrossEntropyLoss(), x, y, steps=1, gamma=0.5, eps=2.0,
+                                perturb_idx=8, layer_number=24)
+    assert r_ref["feature_map"].shape == (4, 256, 16, 16)
+    torch.backends.cudnn.deterministic = True
+    m = pkg.resnet_s.resnet50(num_classes=16)
+    m.load_state_dict(sd)
+    m.to(gpu).train()
+    tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, perturb_idx=8, lr=0.1, use_graph=False)
+    r = tr.step(x.to(gpu), y.to(gpu))
+    # clean branch: the 1e-4 bar.  Adversarial branch: behind one sign() of a gradient that is exactly/nearly zero on a
+    # sizeable part of this post-ReLU, 1x1-conv-fed feature map (sign(0) = 0 vs sign(+-1e-12) = +-1 is summation-order
+    # noise on ANY two machines), so it is bounded through the measured mismatch fraction instead.
+    assert abs(float(r["loss_clean"]) - float(r_ref["loss_clean"])) <= 1e-4 * max(1.0, abs(float(r_ref["loss_clean"])))
+    d_got = (r["x_adv"] - r["feature_map"]).cpu().numpy()
+    d_ref = (r_ref["x_adv"] - r_ref["feature_map"]).numpy()
+    assert_close_frac(d_got, d_ref, 0, 2e-6, 0.1, "first-step perturbation")
+    for k, tol in (("loss", 3e-3), ("loss_adv", 6e-3)):
+        assert abs(float(r[k]) - float(r_ref[k])) <= tol * max(1.0, abs(float(r_ref[k]))), (k, float(r[k]), float(r_ref[k]))
+    np.testing.assert_allclose(r["linf"].cpu().numpy(), r_ref["linf"].numpy(), rtol=0, atol=1e-6)
+    # bf16 channels-last, K = 3
+    m = pkg.resnet_s.resnet50(num_classes=16)
+    m.load_state_dict(sd)
+    m.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+    tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=3, gamma=0.5, eps=2.0, perturb_idx=8, lr=0.1, use_graph=False)
+    r = tr.step(x.to(gpu), y.to(gpu))
+    assert int(m.state_dict()["sequential_model.8.bn1.num_batches_tracked"]) == 3 + 2
+    assert int(m.state_dict()["sequential_model.2.num_batches_tracked"]) == 2
+    assert abs(float(r["loss_clean"]) - float(r_ref["loss_clean"])) <= 5e-2 * max(1.0, abs(float(r_ref["loss_clean"])))
+    assert float(r["linf"].max()) <= 3 * 0.5 / 255 + 1e-6 and torch.isfinite(r["loss"])
