@@ -293,3 +293,48 @@ def test_resnet50_imagenet_shape_step(pkg, orc, gpu):
     assert int(m.state_dict()["sequential_model.2.num_batches_tracked"]) == 2
     assert abs(float(r["loss_clean"]) - float(r_ref["loss_clean"])) <= 5e-2 * max(1.0, abs(float(r_ref["loss_clean"])))
     assert float(r["linf"].max()) <= 3 * 0.5 / 255 + 1e-6 and torch.isfinite(r["loss"])
+
+
+def test_two_rank_sharded_step_matches_sharded_oracle(pkg, orc, gpu):
+    """SURVEY.md §8e parity definition for N GPUs: every rank runs the step on its shard with per-shard BN statistics
+    from the same starting weights, parameter gradients are summed by the all-reduce, ONE SGD update with
+    grad_scale = 1/N, rank 0's BN buffers persist.  The two ranks are played in turn on one GPU (the collective itself
+    is covered by tests/test_ddp_gloo.py) and compared with oracle.sharded_train_step on the CPU."""
+    world, K = 2, 2
+    g = golden("step_r20s_k1")
+    sd0 = _sd0(g)
+    torch.manual_seed(11)
+    x, y = torch.rand(8, 3, 32, 32), torch.randint(0, 10, (8,))
+    ref = orc.resnet20s()
+    ref.load_state_dict(sd0)
+    ref.train()
+    ref_losses = orc.sharded_train_step(ref, orc.make_optimizer(ref), nn.CrossEntropyLoss(), x, y, world, steps=K,
+                                        gamma=0.5, eps=2.0, perturb_idx=7, layer_number=16)
+    model = _build(pkg, orc, "resnet20s", gpu, sd=sd0)
+    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=7,
+                                    layer_number=16, lr=0.1, use_graph=False)
+    state0 = {k: v.clone() for k, v in model.state_dict().items()}
+    per = x.shape[0] // world
+    gsum, losses, bufs0 = torch.zeros_like(tr.arena.grad), [], None
+    for r in range(world):
+        model.load_state_dict(state0)
+        out = tr._forward_backward(x[r * per:(r + 1) * per].to(gpu), y[r * per:(r + 1) * per].to(gpu), overlap_allreduce=False)
+        gsum += tr.arena.grad                       # what the SUM all-reduce leaves on every rank
+        losses.append(float(out["loss"]))
+        if r == 0:
+            bufs0 = {k: v.clone() for k, v in model.named_buffers()}
+    model.load_state_dict(state0)
+    for k, v in model.named_buffers():
+        v.copy_(bufs0[k])
+    tr.arena.grad.copy_(gsum)
+    tr.optimizer.grad_scale = 1.0 / world
+    tr.optimizer._sync_lr()
+    tr.optimizer.step()
+    for r in range(world):
+        assert abs(losses[r] - float(ref_losses[r])) <= LOSS_TOL * max(1.0, abs(float(ref_losses[r]))), (r, losses[r])
+    sd_ref, sd = ref.state_dict(), model.state_dict()
+    for k in sd_ref:
+        if "num_batches" in k:
+            assert int(sd[k]) == int(sd_ref[k]), k
+        else:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), sd_ref[k].numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
