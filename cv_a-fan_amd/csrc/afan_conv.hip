@@ -26,7 +26,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int THREADS = 256;
+constexpr int TRANSPOSE_THREADS = 256;
 constexpr int BK = 64;           // reduction channels per step
 constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes (register-staged variants)
 constexpr int MAX_TAPS = 9;
@@ -62,8 +62,13 @@ struct ConvP {
     ConvClass cls[4];
 };
 
-template <int BM, int BN, int PF>   // PF = global-load prefetch distance in K-steps (1 or 2 register sets)
-__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
+// PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
+// the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
+template <int BM, int BN, int PF, int WM, int WN>   // WM x WN waves: pixels x channels
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp) {
+    constexpr int NW = WM * WN;
+    constexpr int THREADS = 64 * NW;
+    constexpr int RPP = THREADS / 8;                  // rows staged per pass of the workgroup
     const ConvClass& cc = pp.cls[blockIdx.z];
     const uint32_t Wg = (uint32_t)cc.Wg, Hg = (uint32_t)cc.Hg;
     const uint32_t M = (uint32_t)pp.N * Hg * Wg;
@@ -77,9 +82,11 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         }
         return;
     }
-    constexpr int TM = BM / 2, TN = BN / 2;          // wave tile (pixels x channels)
+    constexpr int TM = BM / WM, TN = BN / WN;        // wave tile (pixels x channels)
     constexpr int MI = TM / 32, NI = TN / 32;        // 32x32 MFMA tiles per wave
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;  // 16-byte pieces per thread per step (rows t/8 + 32*i)
+    static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // 16-byte pieces per thread per step (rows t/8 + RPP*i)
     constexpr bool GLDS = (PF == 3);                 // operands go global -> LDS by DMA (no VGPR staging, no ds_write)
     constexpr int LDR = GLDS ? BK : LDK;             // LDS row length: DMA rows are unpadded 128 B, XOR-swizzled instead
     constexpr int STAGE = (BM + BN) * LDR;           // elements per buffer
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     __shared__ int out_off[BM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
     const int n0 = blockIdx.x * BN;
     const int T = cc.T, Ci = pp.Ci, Hi = pp.Hi, Wi = pp.Wi;
 
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
     uint32_t a_valid[A_ROWS];
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        const uint32_t m = m0 + row0 + 32 * i;
+        const uint32_t m = m0 + row0 + RPP * i;
         a_off[i] = 0;
         a_valid[i] = 0;
         if (m < M) {
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         out_off[r] = off;
     }
     const uint32_t b_off = ((uint32_t)(n0 + row0) * pp.w_row_stride + piece * 8) * 2u;
-    const uint32_t b_row32 = 32u * pp.w_row_stride * 2u;
+    const uint32_t b_row32 = (uint32_t)RPP * pp.w_row_stride * 2u;
 
     // accumulators: acc[j][i] = channels tile j x pixels tile i (weights are the MFMA A operand, so a lane ends up
     // with 4 consecutive CHANNELS of one pixel per register quad: 8-byte packed bf16 on the way out)
@@ -173,10 +180,10 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
         uint16_t* B = A + BM * LDK;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i)
-            *reinterpret_cast<u32x4*>(A + (row0 + 32 * i) * LDK + piece * 8) = ra[i];
+            *reinterpret_cast<u32x4*>(A + (row0 + RPP * i) * LDK + piece * 8) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            *reinterpret_cast<u32x4*>(B + (row0 + 32 * i) * LDK + piece * 8) = rb[i];
+            *reinterpret_cast<u32x4*>(B + (row0 + RPP * i) * LDK + piece * 8) = rb[i];
     };
     auto compute = [&](int buf) {
         const uint16_t* A = lds + buf * STAGE;
@@ -216,12 +223,12 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvP pp) {
             const char* src = ((a_valid[i] >> t) & 1u)
                                   ? reinterpret_cast<const char*>(pp.x) + (uint32_t)(a_off[i] + a_tap)
                                   : reinterpret_cast<const char*>(conv_zero_page);
-            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(A + i * 2048), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(A + i * (RPP * 64)), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) {
             const char* src = reinterpret_cast<const char*>(pp.w) + (uint32_t)(b_off + i * b_row32 + b_tap);
-            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(B + i * 2048), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(B + i * (RPP * 64)), 16, 0, 0);
         }
     };
 
@@ -375,8 +382,9 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF>
+template <int BM, int BN, int PF, int WM, int WN>
 int launch(const ConvP& p, hipStream_t st) {
+    constexpr int THREADS = 64 * WM * WN;
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
     constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (PF == 3 ? BK : LDK) * 2;
@@ -384,12 +392,12 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv_igemm_kernel<BM, BN, PF><<<grid, THREADS, lds, st>>>(p);
+    conv_igemm_kernel<BM, BN, PF, WM, WN><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -409,13 +417,19 @@ static int env_int(const char* name, int dflt) {
 int dispatch(const ConvP& p, hipStream_t st) {
     // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
     static const int mode = env_int("AFAN_CONV_MODE", 3);
-    static const int force_bm = env_int("AFAN_CONV_BM", 0);   // tuning knob
+    static const int force_bm = env_int("AFAN_CONV_BM", 0);   // tuning knobs (tools/conv_bench.py A/B)
+    static const int nw = env_int("AFAN_CONV_NW", 8);          // waves per workgroup where the tile allows it
     const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
     const bool n128 = p.Co % 128 == 0;
+    if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
+    if (mode == 3 && nw >= 8) {
+        if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st) : launch<64, 128, 3, 2, 4>(p, st);
+        if (bm == 128) return launch<128, 64, 3, 4, 2>(p, st);
+    }
 #define AFAN_CONV_GO(M)                                                                                      \
     do {                                                                                                     \
-        if (n128) return bm == 128 ? launch<128, 128, M>(p, st) : launch<64, 128, M>(p, st);                 \
-        return bm == 128 ? launch<128, 64, M>(p, st) : launch<64, 64, M>(p, st);                             \
+        if (n128) return bm == 128 ? launch<128, 128, M, 2, 2>(p, st) : launch<64, 128, M, 2, 2>(p, st);     \
+        return bm == 128 ? launch<128, 64, M, 2, 2>(p, st) : launch<64, 64, M, 2, 2>(p, st);                 \
     } while (0)
     if (mode == 1) AFAN_CONV_GO(1);
     if (mode == 2) AFAN_CONV_GO(2);
@@ -569,7 +583,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
 
 // ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------
 // desc[i] = {src_off, dst_off, K, RS, C, first_tile}; tiles of 64(k) x 64(c) at fixed rs; K % 64 == 0, C % 64 == 0.
-__global__ __launch_bounds__(256) void transpose_weights_kernel(const uint16_t* __restrict__ src,
+__global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(const uint16_t* __restrict__ src,
                                                                 uint16_t* __restrict__ dst,
                                                                 const int64_t* __restrict__ desc, int n_desc) {
     __shared__ uint16_t tile[64][64 + 8];
