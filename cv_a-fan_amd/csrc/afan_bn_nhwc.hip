@@ -10,6 +10,8 @@
 // additive, so the finalize launch (one wave per channel) is a plain deterministic sum — no float atomics.
 //   forward : stats -> finalize (mean, invstd, running stats) -> apply (+residual, +ReLU)
 //   backward: reduce -> finalize (sum_g, sum_gx, dweight, dbias) -> dx (+d_residual)
+// Where a convolution epilogue already took the sums (afan_conv.hip), the "accumulator" variants further down skip the
+// slab and the finalize launch: f64 atomics into a few copies per channel, folded in the prologue of the apply pass.
 // Channel counts that do not fit the mapping (C/VEC not a divisor of 256, e.g. C = 304) take the generic
 // kernels: one thread per channel walking rows, lanes across channels (still coalesced, narrower accesses).
 #include "afan_common.h"
@@ -76,10 +78,43 @@ __device__ __forceinline__ void block_fold_store(float (&acc)[NQ][VEC], int CV, 
     }
 }
 
+// Accumulator variant: the block's column sums are added into double-precision accumulators acc[slot][q][C] (zeroed
+// by the caller) with native f64 atomics, slot = blockIdx.x % NS: atomics on ONE address serialise at the L2 (~100 ns
+// each), so the adds of a launch are spread over NS copies and the consumer sums the copies.  The consumers
+// (apply_acc / bwd_apply_acc kernels) derive their coefficients from the accumulators themselves, so neither a partial
+// slab nor a finalize launch exists on this path.  fp32 block sums widened to f64 add exactly unless they differ by
+// > 2^29 in magnitude, so the result is order-independent to ~1e-16 relative — far below the fp32 statistics.
+__host__ __device__ inline int acc_slots(int64_t C) {   // NS * C <= 1024, 1 <= NS <= 16, power of two
+    int ns = 16;
+    while (ns > 1 && (int64_t)ns * C > 1024) ns >>= 1;
+    return ns;
+}
+
+template <int VEC, int NQ>
+__device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV, int C, int NS,
+                                                  double* __restrict__ out) {
+    __shared__ float sh[NQ * VEC][BLOCK];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) sh[q * VEC + k][threadIdx.x] = acc[q][k];
+    __syncthreads();
+    // all 256 threads take part: thread t sums column (t % CV) of quantity/element (t / CV) when it exists
+    const int R = BLOCK / CV;
+    double* dst = out + (int64_t)(blockIdx.x & (NS - 1)) * NQ * C;
+    for (int item = threadIdx.x; item < NQ * VEC * CV; item += BLOCK) {
+        const int cv = item % CV, qk = item / CV;
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += sh[qk][cv + r * CV];
+        const int q = qk / VEC, k = qk % VEC;
+        unsafeAtomicAdd(dst + (int64_t)q * C + cv * VEC + k, (double)s);
+    }
+}
+
 // ---- forward 1: shifted column sums -----------------------------------------------------------------
-template <typename T, int VEC>
+template <typename T, int VEC, bool ATOMIC = false>
 __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, int64_t nvec, int CV, int C,
-                                                      float* __restrict__ ws) {
+                                                      float* __restrict__ ws, double* __restrict__ accd = nullptr) {
     const int cv = threadIdx.x % CV;
     float shift[VEC];
     LdV<T, VEC>::ld(x + (int64_t)cv * VEC, shift);  // first row of the tensor: same shift in every block
@@ -98,7 +133,8 @@ __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, i
             acc[1][k] += d * d;
         }
     }
-    block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, acc_slots(C), accd);
+    else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
 }
 
 // generic: thread per channel, block per row slab
@@ -227,10 +263,11 @@ __global__ __launch_bounds__(BLOCK) void apply_generic_kernel(const T* __restric
 }
 
 // ---- backward 1: partial sums of g and g*xhat -------------------------------------------------------------
-template <typename T, int VEC, bool RELU, bool HAVE_Y>
+template <typename T, int VEC, bool RELU, bool HAVE_Y, bool ATOMIC = false>
 __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, int64_t nvec, int CV, int C,
-                                                           const float* __restrict__ stats, float* __restrict__ ws) {
+                                                           const float* __restrict__ stats, float* __restrict__ ws,
+                                                           double* __restrict__ accd = nullptr) {
     const int c0 = (threadIdx.x % CV) * VEC;
     float mu[VEC], alpha[VEC], beta[VEC];
     ld_coef<VEC>(stats, c0, mu);
@@ -259,7 +296,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__
             acc[1][k] += g * (e[k] - mu[k]);   // invstd is applied once per channel in the finalize
         }
     }
-    block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, acc_slots(C), accd);
+    else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
 }
 
 template <typename T, bool RELU, bool HAVE_Y>
@@ -340,6 +378,137 @@ __global__ __launch_bounds__(BLOCK) void bwd_apply_generic_kernel(
         }
         Elt<T>::st(dx + i, fmaf(g, alpha, fmaf(e - mu, coef[c], coef[C + c])));
         if (DRES) Elt<T>::st(dres + i, g);
+    }
+}
+
+// sum of the NS accumulator copies of channel c; all loads are issued before the first add (NS <= 16)
+__device__ __forceinline__ void fold_slots(const double* __restrict__ acc, int C, int NS, int c, double& a, double& b) {
+    double av[16], bv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        av[s] = (s < NS) ? acc[(int64_t)(2 * s) * C + c] : 0.0;
+        bv[s] = (s < NS) ? acc[(int64_t)(2 * s + 1) * C + c] : 0.0;
+    }
+    a = b = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        a += av[s];
+        b += bv[s];
+    }
+}
+
+// ---- accumulator path: coefficients derived in the prologue of the streaming kernels themselves ----------------
+// forward: acc[slot][0][c] = sum (x - shift), acc[slot][1][c] = sum (x - shift)^2 (f64); shift = given [C] floats, or
+// row 0 of x.  Each block folds the NS copies and derives alpha/beta for all C channels once (one channel per thread,
+// coalesced f64 loads), parks them in LDS, and its threads pick up their own VEC channels from there; block 0 also
+// publishes stats[4][C] for the backward and updates the running statistics.  `shift` is never the live running_mean
+// buffer (the producing convolution snapshots it behind the accumulators), so that in-place update races with nothing.
+template <typename T, int VEC, bool RES, bool RELU>
+__global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                          T* __restrict__ y, int64_t nvec, int CV, int C, int NS,
+                                                          const double* __restrict__ acc,
+                                                          const float* __restrict__ shift, double inv_m, float unbias,
+                                                          float eps, float momentum, const float* __restrict__ weight,
+                                                          const float* __restrict__ bias, float* __restrict__ stats,
+                                                          float* rmean, float* rvar, int64_t* nbt) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];   // [2][C]: alpha | beta
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        double a, b;
+        fold_slots(acc, C, NS, c, a, b);
+        const float sh = shift ? shift[c] : Elt<T>::ld(x + c);
+        const double dm = a * inv_m;
+        const double m2 = fmax(b - a * dm, 0.0);
+        const float mean = sh + (float)dm;
+        const float varb = (float)(m2 * inv_m);
+        const float is = 1.0f / sqrtf(varb + eps);
+        float alpha, beta;
+        affine_coeffs(mean, is, weight ? weight[c] : 1.f, bias ? bias[c] : 0.f, alpha, beta);
+        coef[c] = alpha;
+        coef[C + c] = beta;
+        if (blockIdx.x == 0) {
+            stats[c] = mean;
+            stats[C + c] = is;
+            stats[2 * C + c] = alpha;
+            stats[3 * C + c] = beta;
+            if (rmean) {
+                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
+            }
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    }
+    __syncthreads();
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float alpha[VEC], beta[VEC];
+    ld_coef<VEC>(coef, c0, alpha);
+    ld_coef<VEC>(coef + C, c0, beta);
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float e[VEC], r[VEC];
+        LdV<T, VEC>::ld(x + v * VEC, e);
+        if (RES) LdV<T, VEC>::ld(res + v * VEC, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float t = fmaf(e[k], alpha[k], beta[k]);
+            if (RES) t += r[k];
+            if (RELU) t = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+            e[k] = t;
+        }
+        LdV<T, VEC>::st(y + v * VEC, e);
+    }
+}
+
+// backward: acc[slot][0][c] = sum g, acc[slot][1][c] = sum g*(x - mean) (f64) -> B, D per channel, same block-level
+// prologue; block 0 writes dweight / dbias.
+template <typename T, int VEC, bool RELU, bool HAVE_Y, bool DRES>
+__global__ __launch_bounds__(BLOCK) void bwd_apply_acc_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                              const T* __restrict__ y, T* __restrict__ dx,
+                                                              T* __restrict__ dres, int64_t nvec, int CV, int C, int NS,
+                                                              const float* __restrict__ stats,
+                                                              const double* __restrict__ acc, double inv_m,
+                                                              float* dweight, float* dbias, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];   // [2][C]: B | D
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        double a, b;
+        fold_slots(acc, C, NS, c, a, b);
+        const float is = stats[C + c], alpha = stats[2 * C + c];
+        const float sum_g = (float)a;
+        const float sum_gx = (float)b * is;
+        coef[c] = -alpha * is * (float)((double)sum_gx * inv_m);
+        coef[C + c] = -alpha * (float)((double)sum_g * inv_m);
+        if (blockIdx.x == 0) {
+            if (dbias) dbias[c] = accumulate ? dbias[c] + sum_g : sum_g;
+            if (dweight) dweight[c] = accumulate ? dweight[c] + sum_gx : sum_gx;
+        }
+    }
+    __syncthreads();
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float mu[VEC], alpha[VEC], beta[VEC], B[VEC], D[VEC];
+    ld_coef<VEC>(stats, c0, mu);
+    ld_coef<VEC>(stats + 2 * C, c0, alpha);
+    if (RELU && !HAVE_Y) ld_coef<VEC>(stats + 3 * C, c0, beta);
+    ld_coef<VEC>(coef, c0, B);
+    ld_coef<VEC>(coef + C, c0, D);
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float d[VEC], e[VEC], o[VEC];
+        LdV<T, VEC>::ld(dy + v * VEC, d);
+        LdV<T, VEC>::ld(x + v * VEC, e);
+        if (RELU && HAVE_Y) LdV<T, VEC>::ld(y + v * VEC, o);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float g = d[k];
+            if (RELU) {
+                const float act = HAVE_Y ? o[k] : fmaf(e[k], alpha[k], beta[k]);
+                g = (act > 0.f) ? g : 0.f;
+            }
+            d[k] = g;
+            e[k] = fmaf(g, alpha[k], fmaf(e[k] - mu[k], B[k], D[k]));
+        }
+        LdV<T, VEC>::st(dx + v * VEC, e);
+        if (DRES) LdV<T, VEC>::st(dres + v * VEC, d);
     }
 }
 
@@ -489,6 +658,97 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
 #undef AFAN_APP
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
+}
+
+// ---- accumulator path, host side.  acc: double[acc_doubles(C)] — NS = acc_slots(C) copies of [2][C] accumulators
+// (zeroed by the caller before the producer ran), then C floats: the shift the producer used (written by the producing
+// convolution's epilogue).
+template <typename T>
+int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float momentum,
+                const float* weight, const float* bias, int relu, double* acc, int acc_ready, float* stats,
+                float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {x, res, y}, p)) return AFAN_ESHAPE;
+    if (!p.vec || !aligned(stats, 16) || !aligned(acc, 16)) return AFAN_ESHAPE;
+    constexpr int NV = Elt<T>::VEC;
+    const T* x_ = (const T*)x; const T* r_ = (const T*)res; T* y_ = (T*)y;
+    if (!acc_ready) {
+        AFAN_PROF("bn_nhwc_stats_kernel", p.tensor_bytes, st);
+        stats_kernel<T, NV, true><<<p.G, BLOCK, 0, st>>>(x_, p.nvec, p.CV, (int)C, nullptr, acc);
+        AFAN_LAUNCH_CHECK();
+    }
+    const int NS = acc_slots(C);
+    const float* shift = acc_ready ? reinterpret_cast<const float*>(acc + (int64_t)2 * NS * C) : nullptr;
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    const double inv_m = 1.0 / (double)M;
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+    AFAN_PROF("bn_nhwc_apply_kernel", p.tensor_bytes * (res ? 3 : 2), st);
+    const int grid = apply_grid(p, M * C);
+#define AFAN_GO(RES, RELU)                                                                                        \
+    apply_acc_kernel<T, NV, RES, RELU><<<grid, BLOCK, lds, st>>>(x_, r_, y_, p.nvec, p.CV, (int)C, NS, acc, shift, inv_m, \
+                                                               unbias, eps, momentum, weight, bias, stats, rmean,  \
+                                                               rvar, nbt)
+    if (res) { if (relu) AFAN_GO(true, true); else AFAN_GO(true, false); }
+    else { if (relu) AFAN_GO(false, true); else AFAN_GO(false, false); }
+#undef AFAN_GO
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+template <typename T>
+int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
+                 const float* stats, int relu, double* acc, int acc_ready, float* dweight, float* dbias,
+                 int accumulate, hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {dy, x, y, dx, dres}, p)) return AFAN_ESHAPE;
+    if (!p.vec || !aligned(stats, 16) || !aligned(acc, 16)) return AFAN_ESHAPE;
+    constexpr int NV = Elt<T>::VEC;
+    const T* dy_ = (const T*)dy; const T* x_ = (const T*)x; const T* y_ = (const T*)y;
+    if (!acc_ready) {
+        AFAN_PROF("bn_nhwc_bwd_reduce_kernel", p.tensor_bytes * ((relu && y) ? 3 : 2), st);
+#define AFAN_RED(RELU, HY)                                                                                        \
+    bwd_reduce_kernel<T, NV, RELU, HY, true><<<p.G, BLOCK, 0, st>>>(dy_, x_, y_, p.nvec, p.CV, (int)C, stats, nullptr, acc)
+        if (!relu) AFAN_RED(false, false);
+        else if (y) AFAN_RED(true, true);
+        else AFAN_RED(true, false);
+#undef AFAN_RED
+        AFAN_LAUNCH_CHECK();
+    }
+    const int grid = apply_grid(p, M * C);
+    const double inv_m = 1.0 / (double)M;
+    const int NS = acc_slots(C);
+    const size_t lds = (size_t)2 * C * sizeof(float);
+    AFAN_PROF("bn_nhwc_bwd_apply_kernel", p.tensor_bytes * (3 + ((relu && y) ? 1 : 0) + (dres ? 1 : 0)), st);
+#define AFAN_APP(RELU, HY, DR)                                                                                    \
+    bwd_apply_acc_kernel<T, NV, RELU, HY, DR><<<grid, BLOCK, lds, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, p.nvec, p.CV, \
+                                                                        (int)C, NS, stats, acc, inv_m, dweight,     \
+                                                                        dbias, accumulate)
+    if (!relu) { if (dres) AFAN_APP(false, false, true); else AFAN_APP(false, false, false); }
+    else if (y) { if (dres) AFAN_APP(true, true, true); else AFAN_APP(true, true, false); }
+    else { if (dres) AFAN_APP(true, false, true); else AFAN_APP(true, false, false); }
+#undef AFAN_APP
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int fwd_acc(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom,
+            const float* w, const float* b, int relu, double* acc, int acc_ready, float* stats, float* rm, float* rv,
+            int64_t* nbt, hipStream_t st) {
+    return dtype == AFAN_F32 ? forward_acc<float>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st)
+                             : forward_acc<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st);
+}
+int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
+            const float* stats_in, int relu, double* acc, int acc_ready, float* dw, float* db, int accumulate,
+            hipStream_t st) {
+    return dtype == AFAN_F32 ? backward_acc<float>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st)
+                             : backward_acc<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st);
+}
+int64_t acc_doubles(int64_t C) { return C > 0 ? (int64_t)2 * acc_slots(C) * C + (C + 1) / 2 : 0; }
+int acc_slot_count(int64_t C) { return acc_slots(C); }
+// can the accumulator path take this channel count (vector mapping: C/VEC divides the block)
+int acc_supported(int dtype, int64_t C) {
+    const int nv = dtype == AFAN_F32 ? Elt<float>::VEC : Elt<uint16_t>::VEC;
+    return C > 0 && C % nv == 0 && C / nv <= BLOCK && BLOCK % (C / nv) == 0;
 }
 
 // entry points used by afan_bn.hip's extern "C" dispatch (dtype: 0 = f32, 1 = bf16)

@@ -20,6 +20,8 @@
 
 using namespace afan;
 
+namespace afan_nhwc { int acc_slot_count(int64_t C); }   // afan_bn_nhwc.hip: accumulator copies per channel
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -58,6 +60,8 @@ struct ConvP {
     const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):
     const float* bn_stats;       //     g = relu-masked y, sums g and g*(bnx - mean) from bn_stats[4][Co] = mean|invstd|alpha|beta
     int bn_relu;                 //     (the reduction pass of that BN's backward, fused here)
+    double* acc;                 // alternative to `stats`: the same column sums added into f64 accumulators [NS][2][Co]
+    int acc_ns;                  //   with native atomics, copy = row tile % NS (+ [Co] floats after them: the shift used)
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
     ConvClass cls[4];
 };
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     //  * addend: y += addend (the other branch of a residual gradient), rounded to bf16 like a separate add would;
     //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
     //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
-    const bool want_stats = pp.stats != nullptr;
+    const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
@@ -366,9 +370,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
                 a += red[w][0][tid];
                 b += red[w][1][tid];
             }
-            const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
-            pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
-            pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + slot] = b;
+            if (pp.acc) {
+                double* dst = pp.acc + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
+                unsafeAtomicAdd(dst + n0 + tid, (double)a);
+                unsafeAtomicAdd(dst + pp.Co + n0 + tid, (double)b);
+                if (!bn_bwd && blockIdx.y == 0 && blockIdx.z == 0)   // snapshot of the shift for the BN that consumes the sums
+                    reinterpret_cast<float*>(pp.acc + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = pp.shift ? pp.shift[n0 + tid] : 0.f;
+            } else {
+                const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
+                pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
+                pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + slot] = b;
+            }
         }
     }
 }
@@ -465,7 +477,7 @@ int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64
 // y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding k/2, stride 1 or 2; all bf16, channels-last.
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                             int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
-                            afan_stream_t stream) {
+                            double* stats_acc, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, ci, co, k, stride);
     if (e) return e;
     if (!x || !w || !y) return AFAN_ENULL;
@@ -476,7 +488,9 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
     p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
     p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = 1;
-    p.stats = stats_partials; p.shift = stats_shift;
+    if (stats_partials && stats_acc) return AFAN_ESHAPE;   // one destination for the moments, not both
+    if (stats_acc && !aligned(stats_acc, 16)) return AFAN_EALIGN;
+    p.stats = stats_partials; p.shift = stats_shift; p.acc = stats_acc; p.acc_ns = afan_nhwc::acc_slot_count(co);
     ConvClass& c0 = p.cls[0];
     c0.Hg = p.Ho; c0.Wg = p.Wo; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
     for (int r = 0; r < k; ++r)
@@ -514,10 +528,12 @@ int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int
 
 // dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w) given wt[Ci,k,k,Co] = w[Co,k,k,Ci] transposed (CRSK).
 // Optional epilogue fusions: dx += addend (same shape as dx);  bn_x/bn_stats/bn_partials: dx is the gradient entering
-// the backward of the BatchNorm whose input was bn_x — its reduction sums are written to bn_partials[2][Ci][G].
+// the backward of the BatchNorm whose input was bn_x — its reduction sums are written to bn_partials[2][Ci][G], or
+// added into the f64 accumulators bn_acc[2][Ci] (zeroed by the caller; see afan_bn_backward_acc).
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                               int64_t co, int k, int stride, const void* addend, const void* bn_x,
-                              const float* bn_stats, int bn_relu, float* bn_partials, afan_stream_t stream) {
+                              const float* bn_stats, int bn_relu, float* bn_partials, double* bn_acc,
+                              afan_stream_t stream) {
     int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
     if (e) return e;
     if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
@@ -532,9 +548,12 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
     p.w_row_stride = (int)(k * k * co);
     p.addend = (const uint16_t*)addend;
-    if (bn_partials) {
+    if (bn_partials && bn_acc) return AFAN_ESHAPE;
+    if (bn_partials || bn_acc) {
         if (!bn_x || !bn_stats) return AFAN_ENULL;
-        p.stats = bn_partials; p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu;
+        if (bn_acc && !aligned(bn_acc, 16)) return AFAN_EALIGN;
+        p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
+        p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu;
     }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);

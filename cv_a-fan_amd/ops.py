@@ -3,6 +3,7 @@ device memory and the stream; every arithmetic op below runs in libafan_hip.so. 
 tensor, a non-contiguous tensor or a missing library raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -60,6 +61,62 @@ def _workspace(ref, nfloats, tag):
         ws = torch.empty(max(int(nfloats), 1024), dtype=torch.float32, device=ref.device)
         _ws_cache[key] = ws
     return ws
+
+
+# BatchNorm sums in f64 accumulators (no partial slabs, no finalize launches) where the channel count allows it;
+# AFAN_BN_ACC=0 selects the partial-slab path everywhere (bitwise run-to-run reproducible, ~0.45 more launches per BN).
+BN_ACC = os.environ.get("AFAN_BN_ACC", "1") != "0"
+_ACC_DOUBLES = 1 << 20
+_acc_arenas = {}
+
+
+class _AccArena:
+    __slots__ = ("buf", "off")
+
+    def __init__(self, device):
+        self.buf = torch.zeros(_ACC_DOUBLES, dtype=torch.float64, device=device)
+        self.off = 0
+
+
+def _acc_arena(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    a = _acc_arenas.get(key)
+    if a is None:
+        a = _acc_arenas[key] = _AccArena(device)
+    return a
+
+
+def acc_reset(device):
+    """Zero the accumulator arena of the current stream and rewind it (once per training step; one memset)."""
+    a = _acc_arena(torch.device(device))
+    a.buf.zero_()
+    a.off = 0
+
+
+def acc_take(device, c):
+    """A zeroed accumulator block for one BatchNorm pass over c channels (see afan_bn_acc_doubles).  Blocks are cut
+    from a per-stream arena; when it runs out the arena is zeroed in stream order and reused — every block is consumed
+    by the launch right after its producer, so nothing live is lost."""
+    a = _acc_arena(device)
+    n = (int(_lib.load().afan_bn_acc_doubles(int(c))) + 1) & ~1
+    if n > _ACC_DOUBLES:
+        raise ValueError("too many channels for the accumulator arena")
+    if a.off + n > _ACC_DOUBLES:
+        a.buf.zero_()
+        a.off = 0
+    blk = a.buf[a.off:a.off + n]
+    a.off += n
+    return blk
+
+
+def bn_acc_ok(x):
+    """Accumulator path usable for BatchNorm over x: channels-last memory (or 1x1 spatial) and a channel count whose
+    16-byte vectors tile a 256-thread block."""
+    if not BN_ACC or x.dim() != 4 or x.dtype not in _DT:
+        return False
+    if layout_of(x) != AFAN_NHWC and not (x.shape[2] == 1 and x.shape[3] == 1):
+        return False
+    return bool(_lib.load().afan_bn_acc_supported(_DT[x.dtype], int(x.shape[1])))
 
 
 def _nchw(t):
@@ -239,6 +296,18 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
     n, c, hw = _nchw(x)
     y = torch.empty_like(x)
     stats = torch.empty(4, c, dtype=torch.float32, device=x.device)
+    acc = conv_stats.acc if conv_stats is not None else None
+    ready = acc is not None
+    if acc is None and conv_stats is None and bn_acc_ok(x):
+        acc = acc_take(x.device, c)
+    if acc is not None:
+        if layout_of(x) != AFAN_NHWC and not (x.shape[2] == 1 and x.shape[3] == 1):
+            raise ValueError("accumulator statistics need a channels_last x")
+        check(lib.afan_bn_train_forward_acc(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, float(eps),
+                                            float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(acc),
+                                            int(ready), _ptr(stats), _ptr(running_mean), _ptr(running_var),
+                                            _ptr(num_batches), _stream(x)), "afan_bn_train_forward_acc")
+        return y, stats
     if conv_stats is not None:
         if layout_of(x) != AFAN_NHWC and not (x.shape[2] == 1 and x.shape[3] == 1):
             raise ValueError("conv_stats need a channels_last x")
@@ -284,6 +353,15 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     n, c, hw = _nchw(x)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
+    # stand-alone reductions keep the slab + finalize kernels: their blocks all finish together, so the accumulator
+    # atomics would arrive as one burst and serialise per address (measured 2x slower); a dgrad epilogue spreads them
+    acc = partials.acc if partials is not None else None
+    ready = acc is not None
+    if acc is not None:
+        check(lib.afan_bn_backward_acc(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
+                                       _ptr(stats), int(bool(relu)), _ptr(acc), int(ready), _ptr(dweight), _ptr(dbias),
+                                       int(bool(accumulate)), _stream(x)), "afan_bn_backward_acc")
+        return dx, dres
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
     check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], layout_of(x), n, c, hw,
                                _ptr(stats), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(ws), _ptr(dweight),
@@ -305,11 +383,16 @@ def _cl4(t, name):
 
 
 class ConvStats:
-    """Per-tile BatchNorm moment partials written by a convolution's epilogue (consumed by bn_train_forward)."""
-    __slots__ = ("partials", "g", "shift")
+    """BatchNorm sums taken by a convolution's epilogue (consumed by bn_train_forward / bn_backward): either an f64
+    accumulator block (`acc`) or per-tile fp32 partials (`partials`, `g` of them per channel)."""
+    __slots__ = ("partials", "g", "shift", "acc")
 
-    def __init__(self, partials, g, shift):
-        self.partials, self.g, self.shift = partials, g, shift
+    def __init__(self, partials, g, shift, acc=None):
+        self.partials, self.g, self.shift, self.acc = partials, g, shift, acc
+
+
+def _conv_acc_ok(c):
+    return BN_ACC and bool(_lib.load().afan_bn_acc_supported(AFAN_BF16, int(c)))
 
 
 def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
@@ -325,14 +408,16 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     y = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     st = None
-    if want_stats:
+    if want_stats and _conv_acc_ok(co):
+        st = ConvStats(None, 0, stats_shift, acc_take(x.device, co))
+    elif want_stats:
         g = lib.afan_conv_fwd_tiles(n, hi, wi, ci, co, k, stride)
         if stats_buf is None or stats_buf.numel() < 2 * co * g:
             stats_buf = torch.empty(2 * co * g, dtype=torch.float32, device=x.device)
         st = ConvStats(stats_buf, g, stats_shift)
     check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride,
                                       _ptr(st.partials) if st else None, _ptr(stats_shift) if st else None,
-                                      _stream(x)), "afan_conv_fwd_nhwc_bf16")
+                                      _ptr(st.acc) if st else None, _stream(x)), "afan_conv_fwd_nhwc_bf16")
     return (y, st) if want_stats else y
 
 
@@ -360,13 +445,16 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
         _need(bstats, "bn_stats", torch.float32)
         if bnx.shape != dx.shape or bstats.numel() != 4 * ci:
             raise ValueError("bn_x / bn_stats do not match dx")
-        g = lib.afan_conv_dgrad_tiles(n, hi, wi, ci, co, k, stride)
-        if partials_buf is None or partials_buf.numel() < 2 * ci * g:
-            partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
-        st = ConvStats(partials_buf, g, None)
+        if _conv_acc_ok(ci):
+            st = ConvStats(None, 0, None, acc_take(dy.device, ci))
+        else:
+            g = lib.afan_conv_dgrad_tiles(n, hi, wi, ci, co, k, stride)
+            if partials_buf is None or partials_buf.numel() < 2 * ci * g:
+                partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
+            st = ConvStats(partials_buf, g, None)
     check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _ptr(addend),
                                         _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(st.partials) if st else None,
-                                        _stream(dy)), "afan_conv_dgrad_nhwc_bf16")
+                                        _ptr(st.acc) if st else None, _stream(dy)), "afan_conv_dgrad_nhwc_bf16")
     return (dx, st) if bn_bwd is not None else dx
 
 

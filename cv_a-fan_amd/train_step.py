@@ -147,6 +147,9 @@ class AfanTrainer:
     # ------------------------------------------------------------------------------------------------ body
     def _forward_backward(self, inp, target, overlap_allreduce):
         m, idx, ln = self.model, self.perturb_idx, self.layer_number
+        if inp.is_cuda:
+            from . import ops
+            ops.acc_reset(inp.device)   # BatchNorm accumulator arena: one memset per step, blocks are bump-allocated
         with torch.no_grad():  # main_perturb.py:173 (.detach()): values and BN side effects are identical
             feature_map = m(inp, end_point=idx, start_point=0)
         feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map

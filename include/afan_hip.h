@@ -160,6 +160,25 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
 /* partials != NULL (AFAN_NHWC only): the reduction sums were already taken by the producing dgrad's epilogue
  * ([2][C][partials_g], see afan_conv_dgrad_nhwc_bf16): only finalize + apply run. */
 
+/* Accumulator variants (channels-last only): the two per-channel sums of a BatchNorm pass live in a caller-provided
+ * block acc = double[afan_bn_acc_doubles(c)] (16-byte aligned), ZEROED by the caller before its producer runs:
+ *   NS copies of [2][c]      f64 sums, added with native f64 atomics (order-independent to ~1e-16 relative); NS =
+ *                            min(16, 1024/c) copies spread same-address atomics, the consumer sums the copies
+ *   then c floats            the shift the forward moments were taken around (written by the producer)
+ * acc_ready != 0: a convolution epilogue already filled acc (afan_conv_fwd_nhwc_bf16 stats_acc / afan_conv_dgrad_nhwc_bf16
+ * bn_acc) and ONE launch remains (the normalise / dx pass derives its coefficients from acc in its prologue; its first
+ * block publishes save_stats, running statistics, dweight/dbias).  acc_ready == 0: the sums are taken here first (two
+ * launches).  No partial slabs, no finalize launch.  afan_bn_acc_supported(): c / (8 bf16 | 4 fp32) must divide 256. */
+int64_t afan_bn_acc_doubles(int64_t c);
+int afan_bn_acc_supported(int dtype, int64_t c);
+int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
+                              int64_t hw, float eps, float momentum, const float* weight, const float* bias,
+                              int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,
+                              float* running_var, int64_t* num_batches, afan_stream_t stream);
+int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
+                         int64_t n, int64_t c, int64_t hw, const float* save_stats, int relu, double* acc,
+                         int acc_ready, float* dweight, float* dbias, int accumulate, afan_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside
  * `model(x_adv, end_point, start_point)` (attack_algo.py:50; resnet_s.py:52-54,66,72-73) and its input-gradient
@@ -171,22 +190,27 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride);
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                             int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
-                            afan_stream_t stream);
+                            double* stats_acc, afan_stream_t stream);
 /* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
  * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
  * sum((y - shift[c])^2) at [(1*Co + c)*G + g], G = afan_conv_fwd_tiles(...), over the bf16 values it stores
- * (shift = the BN layer's running mean, NULL = 0).  afan_bn_train_forward_partials() consumes them. */
+ * (shift = the BN layer's running mean, NULL = 0).  afan_bn_train_forward_partials() consumes them.
+ * stats_acc != NULL (instead of stats_partials): the same sums are added into the zeroed accumulator block
+ * stats_acc[afan_bn_acc_doubles(Co)] and the shift is copied behind them; afan_bn_train_forward_acc() consumes it. */
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, const void* addend, const void* bn_x,
-                              const float* bn_stats, int bn_relu, float* bn_partials, afan_stream_t stream);
+                              const float* bn_stats, int bn_relu, float* bn_partials, double* bn_acc,
+                              afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
  *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
  *               both the main branch and the shortcut;
  *   bn_x, bn_stats, bn_relu, bn_partials: dx is the gradient arriving at the output of the BatchNorm(+ReLU) whose INPUT
  *               was bn_x and whose saved statistics block is bn_stats[4*Ci]; the reduction pass of that BN's backward
  *               (sum g, sum g*(x-mean), g = ReLU-masked dx) is taken here: bn_partials[2][Ci][G],
- *               G = afan_conv_dgrad_tiles(...), consumed by afan_bn_backward(..., partials, G). */
+ *               G = afan_conv_dgrad_tiles(...), consumed by afan_bn_backward(..., partials, G);
+ *   bn_acc      (instead of bn_partials) the same sums added into the zeroed accumulator block bn_acc[afan_bn_acc_doubles(Ci)], consumed by
+ *               afan_bn_backward_acc(..., acc_ready = 1). */
 int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 
 /* Weight gradient: grad[Co,k,k,Ci] (fp32, KRSC — the layout of the parameter arena) (+)= sum over output pixels of

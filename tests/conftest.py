@@ -80,6 +80,15 @@ def gpu():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=["acc", "slab"])
+def bn_mode(request, pkg):
+    """Run a test under both BatchNorm reduction schemes: f64 accumulators (default) and per-tile partial slabs."""
+    old = pkg.ops.BN_ACC
+    pkg.ops.BN_ACC = request.param == "acc"
+    yield request.param
+    pkg.ops.BN_ACC = old
+
+
 def assert_close_frac(got, ref, rtol, atol, max_bad_frac=0.0, msg=""):
     """allclose with an allowance for a tiny FRACTION of outliers (elements whose ReLU mask or sign() flips
     because an fp32 value sits within rounding distance of zero — SURVEY.md §7 'sign() is discontinuous')."""

@@ -321,7 +321,7 @@ NHWC_SHAPES = [(4, 16, 32, 32), (2, 64, 16, 16), (8, 512, 4, 4), (3, 304, 5, 7),
 @pytest.mark.parametrize("shape", NHWC_SHAPES)
 @pytest.mark.parametrize("res,relu", [(False, False), (False, True), (True, True)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_bn_nhwc_matches_nchw_kernels(pkg, gpu, shape, res, relu, dt):
+def test_bn_nhwc_matches_nchw_kernels(pkg, gpu, bn_mode, shape, res, relu, dt):
     """The channels-last kernels against the NCHW kernels (already pinned to the C oracle) on the same values."""
     torch.manual_seed(sum(shape) + relu)
     n, c = shape[:2]
@@ -359,7 +359,37 @@ def test_bn_nhwc_matches_nchw_kernels(pkg, gpu, shape, res, relu, dt):
         assert_close_frac(bb[7], a[7], 0, 0, 1e-4, "dres")
 
 
-def test_bn_nhwc_module_autograd_vs_torch(pkg, gpu):
+@pytest.mark.parametrize("shape", [(4, 64, 16, 16), (2, 256, 8, 8), (64, 128, 16, 16)])
+def test_bn_backward_acc_self_reducing_matches_slab_path(pkg, gpu, shape):
+    """afan_bn_backward_acc with acc_ready = 0 (takes its own sums with f64 atomics) against the slab + finalize path."""
+    import ctypes
+    torch.manual_seed(sum(shape))
+    c = shape[1]
+    x = _cl((torch.randn(shape) * 2 + 1).to(gpu, torch.bfloat16))
+    dy = _cl(torch.randn(shape).to(gpu, torch.bfloat16))
+    w, b = (torch.rand(c) + 0.5).to(gpu), torch.randn(c).to(gpu)
+    old = pkg.ops.BN_ACC
+    pkg.ops.BN_ACC = False
+    try:
+        y, stats = pkg.ops.bn_train_forward(x, w, b, None, True, 1e-5, 0.1, None, None, None)
+        dwb0 = torch.zeros(2, c, device=gpu)
+        dx0, _ = pkg.ops.bn_backward(dy, x, None, stats, w, b, True, False, dwb0[0], dwb0[1])
+    finally:
+        pkg.ops.BN_ACC = old
+    lib = pkg._lib.load()
+    acc = torch.zeros(lib.afan_bn_acc_doubles(c), dtype=torch.float64, device=gpu)
+    dx1, dwb1 = torch.empty_like(x), torch.ones(2, c, device=gpu)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.afan_bn_backward_acc(P(dy), P(x), None, P(dx1), None, pkg._lib.AFAN_BF16, shape[0], c, shape[2] * shape[3],
+                                  P(stats), 1, P(acc), 0, P(dwb1[0]), P(dwb1[1]), 1,
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    scale = max(1.0, float(dwb0.abs().max()))
+    np.testing.assert_allclose(dwb1.cpu().numpy() - 1.0, dwb0.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)   # accumulate=1
+    assert_close_frac(dx1.float().cpu().numpy(), dx0.float().cpu().numpy(), 2e-2, 2e-3, 1e-4, "dx")
+
+
+def test_bn_nhwc_module_autograd_vs_torch(pkg, gpu, bn_mode):
     torch.manual_seed(4)
     x = torch.randn(6, 32, 10, 10) * 1.5 + 0.7
     res = torch.randn_like(x)

@@ -162,7 +162,7 @@ def test_clip_projection_invariant_full_size(pkg, orc, gpu):
     assert float((k % 2 == 0).float().mean()) < 5e-3
 
 
-def test_bf16_step_loss_close_to_fp32(pkg, orc, gpu):
+def test_bf16_step_loss_close_to_fp32(pkg, orc, gpu, bn_mode):
     """bf16 backbone vs the fp32 reference numbers: loss only (bf16 has 8 mantissa bits; tolerance 3e-2)."""
     g = golden("step_r20s_k5")
     model = _build(pkg, orc, "resnet20s", gpu, dtype=torch.bfloat16, sd=_sd0(golden("step_r20s_k1")))
@@ -191,7 +191,7 @@ def test_state_dict_roundtrip_with_reference_layout(pkg, orc, gpu):
 
 
 @pytest.mark.parametrize("case", ["step_r20s_k5", "step_r20s_k3_clip_rand", "step_r18_k5"])
-def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, case):
+def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode, case):
     """Same parity bar with the backbone in its channels-last execution layout (what bench.py runs)."""
     g = golden(case)
     K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]
@@ -223,7 +223,7 @@ def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, case):
             np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=wtol, err_msg=k)
 
 
-def test_block_fusion_matches_per_op_path(pkg, orc, gpu):
+def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode):
     """The one-node BasicBlock (_BlockFn: fused dgrad epilogues, in-kernel gradient accumulation) against the per-op
     autograd path on the same bf16 kernels.  K = 0 isolates the joint forward/backward (no sign() amplification):
     gradients agree at bf16 level; K = 3 compares the losses and the BN side effects of a full step."""
