@@ -16,6 +16,7 @@
 // fragments), double buffered, one barrier per step, next step's global loads in flight under the MFMAs.  The epilogue
 // rounds to bf16 through LDS so that every store is a 16-byte piece of a channels-last row.
 #include "afan_common.h"
+#include "afan_conv_c64.h"
 #include <stdlib.h>
 
 using namespace afan;
@@ -502,6 +503,12 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     const double M = (double)n * p.Ho * p.Wo;
     AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
                     2.0 * M * co * k * k * ci, st);
+    if (!stats_partials && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
+        afan_c64::Params q{};
+        q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.flip = 0;
+        q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
+        return afan_c64::launch(q, st);
+    }
     return dispatch(p, st);
 }
 
@@ -558,6 +565,13 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
     p.in_s = 1;
+    if (!bn_partials && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
+        afan_c64::Params q{};
+        q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
+        q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu;
+        q.addend = p.addend;
+        return afan_c64::launch(q, st);
+    }
     if (stride == 1) {
         // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]
         p.out_s = 1; p.n_classes = 1;

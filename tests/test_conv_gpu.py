@@ -10,6 +10,8 @@ CASES = [  # n, ci, co, h, k, stride
     (4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 128, 128, 16, 3, 1), (2, 64, 128, 32, 1, 2),
     (5, 128, 256, 16, 3, 2), (2, 256, 256, 8, 3, 1), (2, 256, 512, 8, 3, 2), (3, 512, 512, 4, 3, 1),
     (2, 256, 512, 8, 1, 2), (1, 64, 64, 7, 3, 1), (2, 64, 64, 9, 3, 2), (1, 128, 64, 5, 1, 1), (64, 128, 128, 16, 3, 1),
+    # the weights-in-registers kernel (afan_conv_c64.hip): W in {32, 16, 8, 4}, one and several tiles per workgroup
+    (1, 64, 64, 32, 3, 1), (3, 64, 64, 16, 3, 1), (5, 64, 64, 8, 3, 1), (32, 64, 64, 4, 3, 1), (160, 64, 64, 32, 3, 1),
 ]
 
 

@@ -7,6 +7,8 @@ dev = torch.device("cuda:0")
 N = int(os.environ.get("N", 256))
 shapes = [(64, 64, 32, 3, 1), (64, 128, 32, 3, 2), (128, 128, 16, 3, 1), (64, 128, 32, 1, 2), (128, 256, 16, 3, 2),
           (256, 256, 8, 3, 1), (128, 256, 16, 1, 2), (256, 512, 8, 3, 2), (512, 512, 4, 3, 1), (256, 512, 8, 1, 2)]
+if os.environ.get("ONLY_FIRST"):
+    shapes = shapes[:1]
 cl = lambda t: t.contiguous(memory_format=torch.channels_last)
 
 def timeit(fn, iters=50):
