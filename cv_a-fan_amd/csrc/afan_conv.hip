@@ -67,6 +67,9 @@ struct ConvP {
     ConvClass cls[4];
 };
 
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
 // PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
 // the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
 template <int BM, int BN, int PF, int WM, int WN>   // WM x WN waves: pixels x channels
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     static_assert(MI >= 1 && NI >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP;  // 16-byte pieces per thread per step (rows t/8 + RPP*i)
-    constexpr bool GLDS = (PF == 3);                 // operands go global -> LDS by DMA (no VGPR staging, no ds_write)
+    constexpr bool GLDS = (PF >= 3);                 // operands go global -> LDS by DMA (no VGPR staging, no ds_write)
+    constexpr int NS = PF <= 3 ? 2 : PF - 1;         // LDS stages: PF 3 -> 2, PF 4 -> 3, PF 5 -> 4 (tiles in flight: NS - 1)
     constexpr int LDR = GLDS ? BK : LDK;             // LDS row length: DMA rows are unpadded 128 B, XOR-swizzled instead
     constexpr int STAGE = (BM + BN) * LDR;           // elements per buffer
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -237,7 +241,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         }
     };
 
-    if constexpr (GLDS) {
+    if constexpr (GLDS && NS > 2) {
+        // Deep pipeline for launches of about one workgroup per CU (the 8x8 and 4x4 stages: few, long K loops): with two
+        // buffers and __syncthreads() every DMA has to land within ONE step's MFMAs (a few hundred cycles against
+        // 1-2 k of memory latency).  Here NS - 1 tiles are in flight; the wait is counted (vmcnt(N) leaves the younger
+        // tiles outstanding) and the barrier is the bare instruction — __syncthreads() would drain the DMA queue.
+        constexpr int LPT = A_ROWS + B_ROWS;             // DMA instructions per thread per tile
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < KS) gdma(s, s);
+        int buf = 0;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int rem = KS - 1 - ks;                 // tiles after this one; min(rem, NS - 2) of them are in flight
+            if (rem >= NS - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * (NS - 2)));
+            else if (NS == 4 && rem == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            __builtin_amdgcn_s_barrier();                // tile ks is in LDS for everyone; buffer of tile ks-1 is free
+            if (ks + NS - 1 < KS) gdma(ks + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+            compute(buf);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
+        __syncthreads();
+    } else if constexpr (GLDS) {
         gdma(0, 0);
         __syncthreads();                     // (the compiler drains vmcnt before the barrier)
         for (int ks = 0; ks < KS; ++ks) {
@@ -400,7 +425,7 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr int THREADS = 64 * WM * WN;
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
-    constexpr size_t stage_bytes = (size_t)2 * (BM + BN) * (PF == 3 ? BK : LDK) * 2;
+    constexpr size_t stage_bytes = (size_t)(PF <= 3 ? 2 : PF - 1) * (BM + BN) * (PF >= 3 ? BK : LDK) * 2;
     constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
@@ -434,6 +459,17 @@ int dispatch(const ConvP& p, hipStream_t st) {
     static const int nw = env_int("AFAN_CONV_NW", 8);          // waves per workgroup where the tile allows it
     const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
     const bool n128 = p.Co % 128 == 0;
+    // launches of about one workgroup per CU (8x8 / 4x4 stages): deep DMA pipeline (3 or 4 LDS stages, counted vmcnt)
+    // In the training step every layer's weights are cold (44 MB of bf16 weights cycle through a 32 MB L2 between two
+    // uses), so each K-step's weight tile is a first-touch miss that all row tiles of the launch wait for together:
+    // measured 70 us in the step against 37 us back-to-back for the 512-channel layers.  Tiles in flight hide that.
+    // Only for launches of about one workgroup per CU: with two or more resident workgroups the second one already
+    // covers the first one's wait, and the deeper pipeline measured slower (8x8 stage, 512 workgroups: -5 % step rate).
+    static const int deep = env_int("AFAN_CONV_DEEP", 1);     // 0: two LDS stages everywhere
+    if (mode == 3 && nw >= 8 && n128 && bm == 64 && deep >= 1) {
+        const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + 63) / 64) * p.n_classes;
+        if (wgs <= 384) return launch<64, 128, 5, 2, 4>(p, st);     // 4 stages, 96 KiB of LDS
+    }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
     if (mode == 3 && nw >= 8) {
         if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st) : launch<64, 128, 3, 2, 4>(p, st);

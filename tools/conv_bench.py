@@ -34,6 +34,15 @@ for (ci, co, h, k, s) in shapes:
     mf = timeit(lambda: torch.ops.aten.convolution(x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1)) if not os.environ.get("NO_MIOPEN") else 0.0
     ad = timeit(lambda: pkg.ops.conv_dgrad(dy, wt, (h, h), s))
     md = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1, [True, False, False])) if not os.environ.get("NO_MIOPEN") else 0.0
+    if os.environ.get("FUSED"):
+        shift = torch.zeros(co, device=dev)
+        afs = timeit(lambda: pkg.ops.conv_fwd(x, w, s, stats_shift=shift, want_stats=True))
+        gamma, beta = torch.ones(ci, device=dev), torch.zeros(ci, device=dev)
+        _, st4 = pkg.ops.bn_train_forward(x, gamma, beta, None, True, 1e-5, 0.1, None, None, None)
+        add = cl(torch.randn_like(x))
+        ads = timeit(lambda: pkg.ops.conv_dgrad(dy, wt, (h, h), s, bn_bwd=(x, st4, True)))
+        ada = timeit(lambda: pkg.ops.conv_dgrad(dy, wt, (h, h), s, addend=add, bn_bwd=(x, st4, True)))
+        print(f"      fused: fwd+moments {afs:7.1f}us  dgrad+bn_bwd {ads:7.1f}us  dgrad+addend+bn_bwd {ada:7.1f}us")
     aw = timeit(lambda: pkg.ops.conv_wgrad(x, dy, k, s))
     mw = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (s, s), (p, p), (1, 1), False, (0, 0), 1, [False, True, False])) if not os.environ.get("NO_MIOPEN") else 0.0
     tot["af"] += af; tot["mf"] += mf; tot["ad"] += ad; tot["md"] += md; tot["aw"] = tot.get("aw", 0) + aw; tot["mw"] = tot.get("mw", 0) + mw

@@ -1,0 +1,28 @@
+#!/bin/bash
+# per-dispatch durations of the default bench, aggregated by (kernel, grid): gpurun_out/trace_by_grid.txt
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no_cpu_baseline --no_roofline > /tmp/bench_trace.log 2>&1
+cd $GRAFT_REPO_ROOT
+python3 - <<'PY'
+import csv, glob, collections
+f = glob.glob('/tmp/trace_out/**/*kernel_trace.csv', recursive=True)[0]
+agg = collections.defaultdict(list)
+rows = list(csv.DictReader(open(f)))
+print(rows[0].keys())
+for r in rows:
+    name = r['Kernel_Name']
+    if 'conv' not in name and 'wgrad' not in name: continue
+    short = name.split('(')[0][-60:]
+    key = (short, r.get('Grid_Size_X', r.get('Grid_Size')), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'), r.get('Workgroup_Size_X', r.get('Workgroup_Size')))
+    agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+out = []
+for k, v in agg.items():
+    v = sorted(v)
+    out.append((sum(v), k, len(v), v[len(v)//2], v[0], v[-1]))
+out.sort(reverse=True)
+with open('gpurun_out/trace_by_grid.txt', 'w') as fo:
+    for tot, k, n, med, lo, hi in out[:60]:
+        line = f"{tot/1e6:9.3f} ms  n={n:5d} med={med/1e3:7.1f}us min={lo/1e3:7.1f} max={hi/1e3:7.1f}  {k}"
+        print(line); fo.write(line + "\n")
+PY
