@@ -440,17 +440,24 @@ int launch(const ConvP& p, hipStream_t st) {
     return AFAN_OK;
 }
 
-// tile choice: fill >= ~256 workgroups when the problem allows it
-int choose_bm(int64_t M, int co, int n_classes) {
-    const bool n128 = (co % 128 == 0);
-    const int64_t wg_128 = ((M + 127) / 128) * (co / (n128 ? 128 : 64)) * n_classes;
-    return wg_128 >= 384 ? 128 : 64;
-}
-
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+
+// tile choice: fill >= ~256 workgroups when the problem allows it
+int choose_bm(int64_t M, int co, int n_classes) {
+    const bool n128 = (co % 128 == 0);
+    const int64_t wg_128 = ((M + 127) / 128) * (co / (n128 ? 128 : 64)) * n_classes;
+    if (wg_128 >= 384) return 128;
+    // 385..768 workgroups of 64 rows (the 8x8 stage) would be two per CU on the two-stage pipeline; 128-row tiles bring
+    // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
+    static const int tall = env_int("AFAN_CONV_TALL", 1);
+    const int64_t wg_64 = ((M + 63) / 64) * (co / (n128 ? 128 : 64)) * n_classes;
+    if (tall && n128 && n_classes == 1 && wg_64 > 384 && wg_64 <= 768) return 128;
+    return 64;
+}
+
 
 int dispatch(const ConvP& p, hipStream_t st) {
     // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
@@ -466,9 +473,9 @@ int dispatch(const ConvP& p, hipStream_t st) {
     // Only for launches of about one workgroup per CU: with two or more resident workgroups the second one already
     // covers the first one's wait, and the deeper pipeline measured slower (8x8 stage, 512 workgroups: -5 % step rate).
     static const int deep = env_int("AFAN_CONV_DEEP", 1);     // 0: two LDS stages everywhere
-    if (mode == 3 && nw >= 8 && n128 && bm == 64 && deep >= 1) {
-        const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + 63) / 64) * p.n_classes;
-        if (wgs <= 384) return launch<64, 128, 5, 2, 4>(p, st);     // 4 stages, 96 KiB of LDS
+    if (mode == 3 && nw >= 8 && n128 && deep >= 1) {
+        const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
+        if (wgs <= 384) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
     }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
     if (mode == 3 && nw >= 8) {

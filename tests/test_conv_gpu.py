@@ -65,7 +65,8 @@ def test_conv_rejects_unsupported(pkg, gpu):
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 256, 512, 8, 1, 2),
-                                                 (64, 128, 128, 16, 3, 1), (1, 64, 64, 7, 3, 1)])
+                                                 (64, 128, 128, 16, 3, 1), (1, 64, 64, 7, 3, 1),
+                                                 (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1)])   # tall / deep tiles
 def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     """conv (+ epilogue moment partials) -> BN(train) must equal conv -> stand-alone BN on the stored bf16 tensor."""
     torch.manual_seed(ci + co + h)
