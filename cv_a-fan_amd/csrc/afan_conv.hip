@@ -61,6 +61,8 @@ struct ConvP {
     const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):
     const float* bn_stats;       //     g = relu-masked y, sums g and g*(bnx - mean) from bn_stats[4][Co] = mean|invstd|alpha|beta
     int bn_relu;                 //     (the reduction pass of that BN's backward, fused here)
+    const uint16_t* bny;         //     optional: that BN layer's OUTPUT after residual add + ReLU — the mask is (bny > 0)
+                                 //     instead of the recomputed bnx*alpha+beta > 0 (a BN whose ReLU follows a residual add)
     double* acc;                 // alternative to `stats`: the same column sums added into f64 accumulators [NS][2][Co]
     int acc_ns;                  //   with native atomics, copy = row tile % NS (+ [Co] floats after them: the shift used)
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
@@ -321,15 +323,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
             }
         }
     __syncthreads();
+    // The epilogue's own global reads (residual addend, BN input, BN output) are requested for all of this thread's
+    // output rows before the first is used.  Buffer loads: a row outside the tensor, or a fusion that is off (zero
+    // records), is an out-of-range offset — no divergent branch to serialise the requests.  (Requesting them before
+    // the K loop instead measured slower: they sit in front of the first operand tiles in the in-order return queue.)
     constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
     constexpr int ROWS_PER_PASS = THREADS / PIECES;
+    constexpr int EPI_ROWS = BM / ROWS_PER_PASS;
     const int pc = tid % PIECES, pr = tid / PIECES;
+    const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
+    const bool bn_bwd = want_stats && pp.bnx != nullptr;
+    u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];
+    {
+        const int out_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.addend), 0, pp.addend ? out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bnx), 0, bn_bwd ? out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bny), 0, (bn_bwd && pp.bny) ? out_bytes : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < EPI_ROWS; ++q) {
+            const int off = out_off[pr + q * ROWS_PER_PASS];
+            const uint32_t bo = off >= 0 ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
+            if (pp.addend) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
+            if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
+            if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
+        }
+    }
     // Optional fusions on the way out (same LDS reads as the stores):
     //  * addend: y += addend (the other branch of a residual gradient), rounded to bf16 like a separate add would;
     //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
     //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
-    const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
-    const bool bn_bwd = want_stats && pp.bnx != nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -340,24 +362,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         be[j] = bn_bwd ? pp.bn_stats[3 * pp.Co + c] : 0.f;
     }
 #pragma unroll
-    for (int r = pr; r < BM; r += ROWS_PER_PASS) {
+    for (int q = 0; q < EPI_ROWS; ++q) {
+        const int r = pr + q * ROWS_PER_PASS;
         const int off = out_off[r];
         if (off >= 0) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
             if (pp.addend) {
-                const u16x8 a = *reinterpret_cast<const u16x8*>(pp.addend + go);
+                const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
             }
             *reinterpret_cast<u16x8*>(pp.y + go) = v;
             if (bn_bwd) {
-                const u16x8 xv = *reinterpret_cast<const u16x8*>(pp.bnx + go);
+                const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
+                u16x8 yv = xv;
+                if (pp.bny) yv = __builtin_bit_cast(u16x8, pre_y[q]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xf = bf2f(xv[j]);
                     float g = bf2f(v[j]);
-                    if (pp.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;   // mask recomputed exactly as the forward
+                    if (pp.bny) g = (bf2f(yv[j]) > 0.f) ? g : 0.f;                       // mask from the stored activation
+                    else if (pp.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;   // mask recomputed exactly as the forward
                     s1[j] += g;
                     s2[j] += g * (xf - sh[j]);
                 }
@@ -582,8 +608,8 @@ int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int
 // added into the f64 accumulators bn_acc[2][Ci] (zeroed by the caller; see afan_bn_backward_acc).
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                               int64_t co, int k, int stride, const void* addend, const void* bn_x,
-                              const float* bn_stats, int bn_relu, float* bn_partials, double* bn_acc,
-                              afan_stream_t stream) {
+                              const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
+                              double* bn_acc, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
     if (e) return e;
     if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
@@ -603,7 +629,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
         if (!bn_x || !bn_stats) return AFAN_ENULL;
         if (bn_acc && !aligned(bn_acc, 16)) return AFAN_EALIGN;
         p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
-        p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu;
+        p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
@@ -611,7 +637,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     if (!bn_partials && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
-        q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu;
+        q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu; q.bny = p.bny;
         q.addend = p.addend;
         return afan_c64::launch(q, st);
     }

@@ -17,6 +17,7 @@ struct Params {
     const uint16_t* bnx;
     const float* bn_stats;
     int bn_relu;
+    const uint16_t* bny;
     const uint16_t* addend;
 };
 

@@ -228,11 +228,14 @@ void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps) {
             *reinterpret_cast<u16x8*>(p.y + go) = v;
             if (bn_bwd) {
                 const u16x8 xv = *reinterpret_cast<const u16x8*>(p.bnx + go);
+                u16x8 yv = xv;
+                if (p.bny) yv = *reinterpret_cast<const u16x8*>(p.bny + go);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xf = bf2f(xv[j]);
                     float g = bf2f(v[j]);
-                    if (p.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;
+                    if (p.bny) g = (bf2f(yv[j]) > 0.f) ? g : 0.f;
+                    else if (p.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;
                     s1[j] += g;
                     s2[j] += g * (xf - sh[j]);
                 }

@@ -421,10 +421,11 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
     return (y, st) if want_stats else y
 
 
-def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None):
+def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient
-    entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward)."""
+    entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward).
+    bn_y: that BatchNorm's output after residual add + ReLU (dx's shape): the ReLU mask is bn_y > 0 instead of recomputed."""
     lib = _lib.load()
     _cl4(dy, "dy"), _cl4(wt, "wt")
     n, co, ho, wo = dy.shape
@@ -445,6 +446,10 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
         _need(bstats, "bn_stats", torch.float32)
         if bnx.shape != dx.shape or bstats.numel() != 4 * ci:
             raise ValueError("bn_x / bn_stats do not match dx")
+        if bn_y is not None:
+            _cl4(bn_y, "bn_y")
+            if bn_y.shape != dx.shape:
+                raise ValueError("bn_y must have dx's shape")
         if _conv_acc_ok(ci):
             st = ConvStats(None, 0, None, acc_take(dy.device, ci))
         else:
@@ -453,8 +458,9 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
                 partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
             st = ConvStats(partials_buf, g, None)
     check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _ptr(addend),
-                                        _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(st.partials) if st else None,
-                                        _ptr(st.acc) if st else None, _stream(dy)), "afan_conv_dgrad_nhwc_bf16")
+                                        _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(bn_y) if st else None,
+                                        _ptr(st.partials) if st else None, _ptr(st.acc) if st else None, _stream(dy)),
+          "afan_conv_dgrad_nhwc_bf16")
     return (dx, st) if bn_bwd is not None else dx
 
 

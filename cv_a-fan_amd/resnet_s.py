@@ -242,7 +242,11 @@ class _BlockFn(torch.autograd.Function):
         out, s2 = ops.bn_train_forward(raw2, b2.weight, b2.bias, res, True, b2.eps, mom(b2), b2.running_mean,
                                        b2.running_var, b2.num_batches_tracked, st)
         ctx.blk, ctx.want_pgrad = blk, want_pgrad
+        # cross-block fusion: when x is the output of another _BlockFn, this block's input-gradient dgrad also takes the
+        # reduction sums of THAT block's bn2 backward (its ReLU mask is x > 0) — see backward
+        ctx.prev_bn2 = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
         ctx.save_for_backward(x, raw1, a1, raw2, out, s1, s2, rawsc, ssc)
+        out._afan_bn2 = (raw2, s2)
         return out
 
     @staticmethod
@@ -252,9 +256,11 @@ class _BlockFn(torch.autograd.Function):
         c1, b1, c2, b2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
         need_dx = ctx.needs_input_grad[0]
         g = lambda p: p.grad if pg else None
+        pre = getattr(gout, "_afan_bn_sums", None)     # taken by the consumer block's dgrad epilogue (same tensor object)
         gout = _like_layout(gout, out)
         # bn2 (+residual, ReLU mask from `out`): gradient to raw2 and to the shortcut branch
-        d_raw2, dres = ops.bn_backward(gout, raw2, out, s2, b2.weight, b2.bias, True, True, g(b2.weight), g(b2.bias), pg)
+        d_raw2, dres = ops.bn_backward(gout, raw2, out, s2, b2.weight, b2.bias, True, True, g(b2.weight), g(b2.bias), pg,
+                                       partials=pre)
         # conv2: dgrad carries bn1's backward reduction in its epilogue; wgrad straight into the arena
         d_a1, part = ops.conv_dgrad(d_raw2, c2.lp_weight_t(), a1.shape[2:], 1, bn_bwd=(raw1, s1, True),
                                     partials_buf=c2._bwd_buf)
@@ -266,6 +272,8 @@ class _BlockFn(torch.autograd.Function):
         if pg:
             ops.conv_wgrad(x, d_raw1, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
         dx = None
+        prev = ctx.prev_bn2
+        fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x) if (prev is not None and need_dx) else {}
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             if pg or need_dx:
@@ -275,9 +283,12 @@ class _BlockFn(torch.autograd.Function):
                     ops.conv_wgrad(x, d_rawsc, csc.kernel_size[0], csc.stride[0], csc.weight.grad, accumulate=True)
                 if need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
-                    dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc)
+                    dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
-            dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres)
+            dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
+        if fuse and dx is not None:
+            dx, sums = dx
+            dx._afan_bn_sums = sums
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 

@@ -200,8 +200,8 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, const void* addend, const void* bn_x,
-                              const float* bn_stats, int bn_relu, float* bn_partials, double* bn_acc,
-                              afan_stream_t stream);
+                              const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
+                              double* bn_acc, afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
  *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
  *               both the main branch and the shortcut;
@@ -209,6 +209,9 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
  *               was bn_x and whose saved statistics block is bn_stats[4*Ci]; the reduction pass of that BN's backward
  *               (sum g, sum g*(x-mean), g = ReLU-masked dx) is taken here: bn_partials[2][Ci][G],
  *               G = afan_conv_dgrad_tiles(...), consumed by afan_bn_backward(..., partials, G);
+ *   bn_y        optional [N,Hi,Wi,Ci] bf16: the OUTPUT of that BatchNorm after its residual add and ReLU (the next
+ *               block's input): the ReLU mask is (bn_y > 0) instead of the recomputed bn_x*alpha+beta > 0 — the form a
+ *               BasicBlock's second BatchNorm needs (resnet_s.py:54-55: relu(bn2(conv2(.)) + shortcut(x)));
  *   bn_acc      (instead of bn_partials) the same sums added into the zeroed accumulator block bn_acc[afan_bn_acc_doubles(Ci)], consumed by
  *               afan_bn_backward_acc(..., acc_ready = 1). */
 int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);

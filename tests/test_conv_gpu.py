@@ -141,3 +141,17 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
         scale = max(1.0, float(np.abs(outs[0][1]).max()))
         np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-4 * scale)      # dweight, dbias
         np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(outs[0][0]).max())))
+    # a BN whose ReLU follows a residual add (a BasicBlock's bn2): the mask comes from the stored output, bn_y > 0
+    res = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    y, stats = pkg.ops.bn_train_forward(bn_x, gamma, beta, res, True, 1e-5, 0.1, None, None, None)
+    dx3, st = pkg.ops.conv_dgrad(dy, wt, (h, h), stride, addend=addend, bn_bwd=(bn_x, stats, True), bn_y=y)
+    assert torch.equal(dx3, fused)
+    outs = []
+    for partials in (None, st):
+        dwb = torch.zeros(2, ci, device=gpu)
+        dxb, dres = pkg.ops.bn_backward(fused, bn_x, y, stats, gamma, beta, True, True, dwb[0], dwb[1], partials=partials)
+        outs.append((dxb.float().cpu().numpy(), dwb.cpu().numpy(), dres.float().cpu().numpy()))
+    scale = max(1.0, float(np.abs(outs[0][1]).max()))
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-4 * scale)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(outs[0][0]).max())))
+    np.testing.assert_array_equal(outs[1][2], outs[0][2])
