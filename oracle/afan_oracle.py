@@ -159,8 +159,8 @@ def resnet20s():
     return SlicedResNet([16, 32, 64], [3, 3, 3], "A")
 
 
-def resnet56s():  # Classification/resnet_s.py:123-124
-    return SlicedResNet([16, 32, 64], [9, 9, 9], "A")
+def resnet56s(init_weight_eta=1):  # Classification/resnet_s.py:123-124
+    return SlicedResNet([16, 32, 64], [9, 9, 9], "A", init_weight=init_weight_eta)
 
 
 def resnet18_cifar():
@@ -293,6 +293,61 @@ def afan_train_step(model, optimizer, criterion, inp, target, *, steps, gamma, e
     return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
             "l2": l2, "linf": linf, "prec1": prec1, "x_adv": feature_map_adv.detach(),
             "feature_map": feature_map, "out_clean": out_clean.detach()}
+
+
+# ---------------------------------------------------------------------------------- learnable multi-layer A-FAN (N3)
+LEARNABLE_IDX = (4, 8, 11, 14, 18, 21, 24, 28, 31)   # Classification/main_learnable.py:59 (ResNet-56s, layer_number 34)
+
+
+def sum_project(b, K=9):
+    """Classification/main_learnable.py:369-378: shift so that the entries sum to one."""
+    return b - (torch.sum(b, dim=0) - 1) / K
+
+
+def make_learnable_optimizers(model, lr=0.1, w_lr=0.01, momentum=0.9, weight_decay=5e-4):
+    """Classification/main_learnable.py:82-90: backbone SGD over sequential_model only; a second SGD for the 9 mixing
+    weights `w` (own lr, no weight decay)."""
+    opt = torch.optim.SGD(model.sequential_model.parameters(), lr, momentum=momentum, weight_decay=weight_decay)
+    opt_w = torch.optim.SGD([{"params": model.w, "lr": w_lr, "weight_decay": 0}], w_lr, momentum=momentum, weight_decay=0)
+    return opt, opt_w
+
+
+def learnable_train_step(model, optimizer, optimizer_w, criterion, inp, target, *, steps, gamma, eps,
+                         idx_list=LEARNABLE_IDX, layer_number=34, l1_coef=1.0, randinit=False, clip=False):
+    """One iteration of Classification/main_learnable.py:196-252 (model in train mode): 9 x (head forward, K-step PGD),
+    9 mixed tail forwards `clean + w[i]*(adv - clean)` (:226-227), clean forward, loss = (clean + adv/9)/2 + l1*|w|_1
+    (:240-245), both optimizers step, `w` projected back onto sum = 1 (:254-255)."""
+    clean, adv = [], []
+    for num in idx_list:
+        fea = model(inp, end_point=num, start_point=0).detach()
+        clean.append(fea)
+        adv.append(PGD(fea, criterion, y=target, model=model, steps=steps, gamma=gamma / 255, start_idx=num,
+                       layer_number=layer_number, eps=eps / 255, randinit=randinit, clip=clip))
+    outs, l2s, linfs = [], [], []
+    for i, num in enumerate(idx_list):
+        l2, linf = perturb_norms(adv[i], clean[i])
+        l2s.append(l2)
+        linfs.append(linf)
+        mixed = clean[i] + model.w[i] * (adv[i] - clean[i])
+        outs.append(model(mixed, end_point=layer_number, start_point=num))
+    out_clean = model(inp, end_point=layer_number, start_point=0)
+    loss_adv = 0
+    for o in outs:
+        loss_adv = loss_adv + criterion(o, target)
+    loss_clean = criterion(out_clean, target)
+    l1 = torch.norm(model.w, p=1)
+    loss = (loss_clean + loss_adv / len(idx_list)) / 2 + l1 * l1_coef
+    optimizer.zero_grad()
+    optimizer_w.zero_grad()
+    loss.backward()
+    optimizer.step()
+    optimizer_w.step()
+    with torch.no_grad():
+        model.w.data = sum_project(model.w.data, K=len(idx_list))
+    prec1 = (out_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
+    return {"loss": loss.detach(), "loss_clean": loss_clean.detach(), "loss_adv": loss_adv.detach(), "l1": l1.detach(),
+            "l2": torch.stack(l2s), "linf": torch.stack(linfs), "prec1": prec1, "w": model.w.detach().clone(),
+            "out_clean": out_clean.detach()}
 
 
 def sharded_train_step(model, optimizer, criterion, inp, target, world, **kw):

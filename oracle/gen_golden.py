@@ -1,7 +1,7 @@
 """Golden-vector generator — runs ONLY in the build container, where /root/reference exists.
 
 It imports the reference's own Python (Classification/attack_algo.py, Classification/resnet_s.py,
-Segmentation/attack_algo.py) with two arithmetic-neutral shims:
+Classification/main_learnable.py, Segmentation/attack_algo.py) with arithmetic-neutral shims:
   1. a stand-in for `advertorch.utils.NormalizeByChannelMeanStd` (absent from the image; 3-line formula),
   2. `.cuda()` -> identity, because Classification/attack_algo.py:44-46 hard-codes it,
 runs fixed-seed cases through the REFERENCE functions and writes inputs + outputs to tests/golden/*.npz.
@@ -225,6 +225,41 @@ def main():
                         lrs=np.array(lrs), ck=ck, keys=np.array(keys), wp=np.array(wp),
                         fc_w=_np(model.state_dict()["sequential_model.15.weight"]))
     print("traj", losses)
+
+    # ---- learnable multi-layer A-FAN: the reference's own train() (main_learnable.py:175-277), one batch ------------
+    # The module's top-level imports of torchvision / matplotlib / PIL / its CIFAR loader are absent here and unused by
+    # train(): empty stand-in modules let the file import; every line of arithmetic that runs is the reference's.
+    import argparse
+    for name in ("matplotlib", "matplotlib.pyplot", "PIL", "PIL.Image", "torchvision", "torchvision.models",
+                 "torchvision.transforms", "torchvision.datasets", "dataset"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["dataset"].cifar10_dataloaders = None
+    sys.modules["resnet_s"], sys.modules["attack_algo"] = ref_resnet, ref_attack
+    ref_learn = _load("ref_cls_main_learnable", "Classification/main_learnable.py")
+    for name, bs, K, gamma, clip in (("learn_r56s_k1", 4, 1, 0.5, False), ("learn_r56s_k2_clip", 2, 2, 1.5, True)):
+        torch.manual_seed(3)
+        model = ref_resnet.resnet56(init_weight_eta=1 / 9)
+        model.train()
+        opt = torch.optim.SGD(model.sequential_model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+        opt_w = torch.optim.SGD([{"params": model.w, "lr": 0.01, "weight_decay": 0}], 0.01, momentum=0.9, weight_decay=0)
+        x = torch.rand(bs, 3, 32, 32)
+        y = torch.randint(0, 10, (bs,))
+        ref_learn.args = argparse.Namespace(steps=K, gamma=gamma, eps=2.0, randinit=False, clip=clip, print_freq=1000,
+                                            l1_coef=1.0, lr=0.1)
+        k0, c0 = _checksums(model)
+        acc, loss, l2m, linfm = ref_learn.train([(x, y)], model, crit, opt, 1, opt_w)     # epoch 1: no warm-up branch
+        k1, c1 = _checksums(model)
+        sd = model.state_dict()
+        rec = {"x": _np(x), "y": _np(y), "meta": np.array([K, int(clip)]), "gamma_eps": np.array([gamma, 2.0]),
+               "idx_list": np.array(ref_learn.perturb_idx_list), "layer_number": np.array(ref_learn.layer_number),
+               "ck0": c0, "ck1": c1, "keys": np.array(k1), "loss": np.array(loss), "acc": np.array(acc),
+               "l2_mean": np.asarray(l2m), "linf_mean": np.asarray(linfm), "w1": _np(sd["w"]),
+               "sd1/fc_w": _np(sd["sequential_model.33.weight"]), "sd1/conv1_w": _np(sd["sequential_model.1.weight"]),
+               "sd1/bn1_rm": _np(sd["sequential_model.2.running_mean"]),
+               "sd1/bn1_nbt": _np(sd["sequential_model.2.num_batches_tracked"])}
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+        print(name, "loss", loss, "w", sd["w"].tolist())
 
     # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
     torch.manual_seed(7)

@@ -50,6 +50,36 @@ def test_train_step_matches_reference(orc, case):
     assert int(sd[f"sequential_model.{idx}.bn1.num_batches_tracked"]) == K + 2
 
 
+@pytest.mark.parametrize("case", ["learn_r56s_k1", "learn_r56s_k2_clip"])
+def test_learnable_step_matches_reference_train(orc, case):
+    """oracle.learnable_train_step against ONE batch through the reference's own train() (main_learnable.py:175-277)."""
+    g = golden(case)
+    K, clip = [int(v) for v in g["meta"]]
+    gamma, eps = [float(v) for v in g["gamma_eps"]]
+    assert tuple(int(v) for v in g["idx_list"]) == orc.LEARNABLE_IDX and int(g["layer_number"]) == 34
+    torch.manual_seed(3)
+    model = orc.resnet56s(init_weight_eta=1 / 9)
+    model.train()
+    assert list(model.state_dict().keys()) == [str(k) for k in g["keys"]]
+    np.testing.assert_array_equal(_checks(model), g["ck0"])
+    opt, opt_w = orc.make_learnable_optimizers(model)
+    x = torch.rand(g["x"].shape)
+    y = torch.randint(0, 10, (g["x"].shape[0],))
+    np.testing.assert_array_equal(x.numpy(), g["x"])
+    r = orc.learnable_train_step(model, opt, opt_w, nn.CrossEntropyLoss(), x, y, steps=K, gamma=gamma, eps=eps,
+                                 clip=bool(clip))
+    assert float(r["loss"]) == float(g["loss"])
+    np.testing.assert_array_equal(r["l2"].mean(dim=1).numpy(), g["l2_mean"])
+    np.testing.assert_array_equal(r["linf"].mean(dim=1).numpy(), g["linf_mean"])
+    np.testing.assert_array_equal(model.w.detach().numpy(), g["w1"])
+    np.testing.assert_array_equal(_checks(model), g["ck1"])
+    sd = model.state_dict()
+    np.testing.assert_array_equal(sd["sequential_model.33.weight"].numpy(), g["sd1/fc_w"])
+    np.testing.assert_array_equal(sd["sequential_model.2.running_mean"].numpy(), g["sd1/bn1_rm"])
+    assert int(sd["sequential_model.2.num_batches_tracked"]) == int(g["sd1/bn1_nbt"]) == 10   # 9 head passes + clean
+    assert abs(float(model.w.sum()) - 1.0) < 1e-6                                              # sum_project
+
+
 def test_stored_initial_weights_equal_seeded_construction(orc):
     g = golden("step_r20s_k1")
     torch.manual_seed(3)
