@@ -28,6 +28,9 @@ SIGNATURES = {
     "afan_axpy_noise": (_i, [_p, _p, _l, _f, _p, _p]),
     "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
+    "afan_mix_w_workspace_floats": (_l, []),
+    "afan_mix_w": (_i, [_p, _p, _p, _p, _i, _l, _p]),
+    "afan_mix_w_backward": (_i, [_p, _i, _p, _p, _l, _p, _p, _i, _p]),
     "afan_bn_workspace_floats": (_l, [_l]),
     "afan_bn_acc_doubles": (_l, [_l]),
     "afan_bn_acc_supported": (_i, [_i, _l]),

@@ -162,6 +162,50 @@ int mix_impl(const void* clean, const void* adv, void* out, int64_t n, int64_t c
 
 }  // namespace
 
+// ---- learnable mixing (Classification/main_learnable.py:226): out = clean + w*(adv - clean), three fp32 roundings like
+// the eager expression; w is read from device memory (the i-th entry of the model's `w` parameter).  Backward: only
+// d(loss)/dw = sum g*(adv - clean) is needed (clean is detached, adv's gradient is never used): block partials in
+// fixed order, one wave folds them — deterministic.
+template <typename TO>
+__global__ __launch_bounds__(BLOCK) void mix_w_kernel(const float* __restrict__ clean, const float* __restrict__ adv,
+                                                      const float* __restrict__ w, TO* __restrict__ out, int64_t n) {
+    const float wv = *w;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const float c = clean[i];
+        const float d = adv[i] - c;
+        const float m = wv * d;
+        Elt<TO>::st(out + i, c + m);
+    }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(BLOCK) void mix_w_dot_kernel(const TG* __restrict__ g, const float* __restrict__ clean,
+                                                          const float* __restrict__ adv, int64_t n,
+                                                          float* __restrict__ partial) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK)
+        s += Elt<TG>::ld(g + i) * (adv[i] - clean[i]);
+    __shared__ float sh[BLOCK / AFAN_WAVE];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < BLOCK / AFAN_WAVE; ++k) t += sh[k];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(AFAN_WAVE) void mix_w_dot_finalize_kernel(const float* __restrict__ partial, int G,
+                                                                       float* __restrict__ dw, int accumulate) {
+    float s = 0.f;
+    for (int g = threadIdx.x; g < G; g += AFAN_WAVE) s += partial[g];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *dw = accumulate ? *dw + s : s;
+}
+
+constexpr int MIXW_MAX_BLOCKS = 1024;
+
 extern "C" {
 
 int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw,
@@ -188,6 +232,46 @@ int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, cons
     const int grid = grid_for(vec ? n / 4 : n, BLOCK);
     AFAN_PROF("lerp_points_kernel", 4.0 * n * (2 + n_interior), (hipStream_t)stream);
     lerp_points_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, y, out, n, lw, n_interior, vec);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int64_t afan_mix_w_workspace_floats(void) { return MIXW_MAX_BLOCKS; }
+
+int afan_mix_w(const float* clean, const float* adv, const float* w, void* out, int out_dtype, int64_t n,
+               afan_stream_t stream) {
+    if (out_dtype != AFAN_F32 && out_dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n < 0) return AFAN_ESHAPE;
+    if (n == 0) return AFAN_OK;
+    if (!clean || !adv || !w || !out) return AFAN_ENULL;
+    if (!aligned(clean, 4) || !aligned(adv, 4) || !aligned(w, 4) || !aligned(out, out_dtype == AFAN_F32 ? 4 : 2)) return AFAN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(n, BLOCK);
+    AFAN_PROF("mix_w_kernel", (8.0 + (out_dtype == AFAN_F32 ? 4 : 2)) * n, st);
+    if (out_dtype == AFAN_F32) mix_w_kernel<float><<<grid, BLOCK, 0, st>>>(clean, adv, w, (float*)out, n);
+    else mix_w_kernel<uint16_t><<<grid, BLOCK, 0, st>>>(clean, adv, w, (uint16_t*)out, n);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_mix_w_backward(const void* grad_out, int grad_dtype, const float* clean, const float* adv, int64_t n,
+                        float* workspace, float* dw, int accumulate, afan_stream_t stream) {
+    if (grad_dtype != AFAN_F32 && grad_dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n < 0) return AFAN_ESHAPE;
+    if (!dw || !workspace) return AFAN_ENULL;
+    if (n > 0 && (!grad_out || !clean || !adv)) return AFAN_ENULL;
+    if (!aligned(clean, 4) || !aligned(adv, 4) || !aligned(dw, 4) || !aligned(workspace, 4) ||
+        !aligned(grad_out, grad_dtype == AFAN_F32 ? 4 : 2))
+        return AFAN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = n > 0 ? grid_for(n, BLOCK, MIXW_MAX_BLOCKS) : 1;
+    {
+        AFAN_PROF("mix_w_dot_kernel", (8.0 + (grad_dtype == AFAN_F32 ? 4 : 2)) * n, st);
+        if (grad_dtype == AFAN_F32) mix_w_dot_kernel<float><<<grid, BLOCK, 0, st>>>((const float*)grad_out, clean, adv, n, workspace);
+        else mix_w_dot_kernel<uint16_t><<<grid, BLOCK, 0, st>>>((const uint16_t*)grad_out, clean, adv, n, workspace);
+    }
+    AFAN_LAUNCH_CHECK();
+    mix_w_dot_finalize_kernel<<<1, AFAN_WAVE, 0, st>>>(workspace, grid, dw, accumulate);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -268,6 +268,34 @@ def lerp_points(x, y, number):
     return out
 
 
+def mix_w(clean, adv, w_elem, out_dtype=torch.float32):
+    """clean + w * (adv - clean) (main_learnable.py:226): clean/adv fp32 with identical strides, w_elem a 1-element
+    fp32 DEVICE tensor (a view of the model's `w`), output in `out_dtype` with the inputs' memory layout."""
+    lib = _lib.load()
+    _need(clean, "clean", torch.float32), _need(adv, "adv", torch.float32), _need(w_elem, "w", torch.float32)
+    _same_layout(clean, adv)
+    if w_elem.numel() != 1 or out_dtype not in _DT:
+        raise ValueError("w must be a single fp32 element; out_dtype fp32 or bf16")
+    out = torch.empty_like(clean, dtype=out_dtype)
+    check(lib.afan_mix_w(_ptr(clean), _ptr(adv), _ptr(w_elem), _ptr(out), _DT[out_dtype], clean.numel(),
+                         _stream(clean)), "afan_mix_w")
+    return out
+
+
+def mix_w_backward(grad_out, clean, adv, dw_elem, accumulate=False):
+    """d(loss)/dw = sum grad_out * (adv - clean) into the 1-element fp32 tensor dw_elem."""
+    lib = _lib.load()
+    _need(grad_out, "grad_out"), _need(clean, "clean", torch.float32), _need(adv, "adv", torch.float32)
+    _need(dw_elem, "dw", torch.float32)
+    _same_layout(clean, adv, grad_out)
+    if grad_out.dtype not in _DT or dw_elem.numel() != 1:
+        raise TypeError("grad_out must be fp32 or bf16, dw a single fp32 element")
+    ws = _workspace(clean, lib.afan_mix_w_workspace_floats(), "mixw")
+    check(lib.afan_mix_w_backward(_ptr(grad_out), _DT[grad_out.dtype], _ptr(clean), _ptr(adv), clean.numel(), _ptr(ws),
+                                  _ptr(dw_elem), int(bool(accumulate)), _stream(clean)), "afan_mix_w_backward")
+    return dw_elem
+
+
 # ------------------------------------------------------------------------------------- BatchNorm
 def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None):
     """Per-channel batch mean and 1/sqrt(var_biased + eps) (optionally updating running statistics)."""

@@ -103,6 +103,18 @@ int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, i
 int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, const float* weights,
                      int n_interior, afan_stream_t stream);
 
+/* Learnable feature mixing of the multi-layer A-FAN (Classification/main_learnable.py:226):
+ *   out[i] = clean[i] + w * (adv[i] - clean[i])      three fp32 roundings, like the eager expression
+ * clean/adv fp32 [n] (same memory layout), w = one fp32 on the DEVICE (an entry of the model's `w` parameter), out in
+ * `out_dtype` (the backbone's compute dtype).  Backward: d(loss)/dw = sum_i grad_out[i] * (adv[i] - clean[i]) written
+ * (accumulate = 0) or added (1) to *dw; clean is detached and adv's gradient is never used (:205-215), so nothing else
+ * is produced.  Deterministic: block partials in workspace[afan_mix_w_workspace_floats()], folded by one wave. */
+int64_t afan_mix_w_workspace_floats(void);
+int afan_mix_w(const float* clean, const float* adv, const float* w, void* out, int out_dtype, int64_t n,
+               afan_stream_t stream);
+int afan_mix_w_backward(const void* grad_out, int grad_dtype, const float* clean, const float* adv, int64_t n,
+                        float* workspace, float* dw, int accumulate, afan_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm, training mode (per-channel moments over N*H*W) — the "feature-norm stats" the backbone runs
  * K+2 times per iteration in the tail and twice in the head (main_perturb.py:173,195-196 through
