@@ -211,24 +211,20 @@ class _BNTrainFn(torch.autograd.Function):
 
 
 class _BlockFn(torch.autograd.Function):
-    """A whole BasicBlock as ONE autograd node on the bf16 channels-last fast path:
-         raw1 = conv1(x) [+moments] -> a1 = relu(bn1) -> raw2 = conv2(a1) [+moments] -> out = relu(bn2(raw2) + shortcut(x))
-    The hand-ordered backward fuses what autograd's per-op graph cannot: the reduction pass of bn1's backward rides in
-    conv2's dgrad epilogue, the sum of the two gradient branches arriving at the block input rides in conv1's dgrad
-    epilogue (no separate add launches), parameter gradients are accumulated by the kernels into the arena views.
+    """A whole residual block as ONE autograd node on the bf16 channels-last fast path.  The main branch is a chain of
+    conv -> BN stages (2 for a BasicBlock, 3 for a Bottleneck), ReLU after each, the last one after adding the shortcut:
+         raw_i = conv_i(a_{i-1}) [+moments]   a_i = relu(bn_i(raw_i))   out = relu(bn_n(raw_n) + shortcut(x))
+    The hand-ordered backward fuses what autograd's per-op graph cannot: the reduction pass of bn_{i-1}'s backward rides
+    in conv_i's dgrad epilogue, the sum of the two gradient branches arriving at the block input rides in conv_1's dgrad
+    epilogue (no separate add launches), parameter gradients are accumulated by the kernels into the arena views, and
+    the dgrad producing the gradient for the PREVIOUS block's output also takes that block's last-BN backward sums.
     `params` only tell autograd which leaves the node depends on; values are read from the modules."""
 
     @staticmethod
     def forward(ctx, x, blk, want_pgrad, *params):
-        c1, b1, c2, b2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
-        s = c1.stride[0]
+        chain = blk._chain()
+        n = len(chain)
         mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
-        raw1, st = ops.conv_fwd(x, c1.lp_weight(), s, stats_shift=b1.running_mean, want_stats=True, stats_buf=c1._stats_buf)
-        c1._stats_buf = st.partials
-        a1, s1 = ops.bn_train_forward(raw1, b1.weight, b1.bias, None, True, b1.eps, mom(b1), b1.running_mean,
-                                      b1.running_var, b1.num_batches_tracked, st)
-        raw2, st = ops.conv_fwd(a1, c2.lp_weight(), 1, stats_shift=b2.running_mean, want_stats=True, stats_buf=c2._stats_buf)
-        c2._stats_buf = st.partials
         rawsc = ssc = None
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
@@ -239,40 +235,52 @@ class _BlockFn(torch.autograd.Function):
                                             bsc.running_var, bsc.num_batches_tracked, stc)
         else:
             res = x
-        out, s2 = ops.bn_train_forward(raw2, b2.weight, b2.bias, res, True, b2.eps, mom(b2), b2.running_mean,
-                                       b2.running_var, b2.num_batches_tracked, st)
-        ctx.blk, ctx.want_pgrad = blk, want_pgrad
+        a, saved = x, []
+        for i, (c, b) in enumerate(chain):
+            raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
+                                   stats_buf=c._stats_buf)
+            c._stats_buf = st.partials
+            a, s_i = ops.bn_train_forward(raw, b.weight, b.bias, res if i == n - 1 else None, True, b.eps, mom(b),
+                                          b.running_mean, b.running_var, b.num_batches_tracked, st)
+            saved += [raw, a, s_i]
+        ctx.blk, ctx.want_pgrad, ctx.n = blk, want_pgrad, n
         # cross-block fusion: when x is the output of another _BlockFn, this block's input-gradient dgrad also takes the
-        # reduction sums of THAT block's bn2 backward (its ReLU mask is x > 0) — see backward
-        ctx.prev_bn2 = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
-        ctx.save_for_backward(x, raw1, a1, raw2, out, s1, s2, rawsc, ssc)
-        out._afan_bn2 = (raw2, s2)
-        return out
+        # reduction sums of THAT block's last BN backward (its ReLU mask is x > 0) — see backward
+        ctx.prev_bn = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
+        ctx.save_for_backward(x, rawsc, ssc, *saved)
+        a._afan_bn2 = (saved[-3], saved[-1])
+        return a
 
     @staticmethod
     def backward(ctx, gout):
-        x, raw1, a1, raw2, out, s1, s2, rawsc, ssc = ctx.saved_tensors
-        blk, pg = ctx.blk, ctx.want_pgrad
-        c1, b1, c2, b2 = blk.conv1, blk.bn1, blk.conv2, blk.bn2
+        x, rawsc, ssc, *saved = ctx.saved_tensors
+        blk, pg, n = ctx.blk, ctx.want_pgrad, ctx.n
+        chain = blk._chain()
+        raws, acts, stats = saved[0::3], saved[1::3], saved[2::3]
         need_dx = ctx.needs_input_grad[0]
         g = lambda p: p.grad if pg else None
+        out = acts[-1]
         pre = getattr(gout, "_afan_bn_sums", None)     # taken by the consumer block's dgrad epilogue (same tensor object)
         gout = _like_layout(gout, out)
-        # bn2 (+residual, ReLU mask from `out`): gradient to raw2 and to the shortcut branch
-        d_raw2, dres = ops.bn_backward(gout, raw2, out, s2, b2.weight, b2.bias, True, True, g(b2.weight), g(b2.bias), pg,
-                                       partials=pre)
-        # conv2: dgrad carries bn1's backward reduction in its epilogue; wgrad straight into the arena
-        d_a1, part = ops.conv_dgrad(d_raw2, c2.lp_weight_t(), a1.shape[2:], 1, bn_bwd=(raw1, s1, True),
-                                    partials_buf=c2._bwd_buf)
-        c2._bwd_buf = part.partials
+        # last BN (+residual, ReLU mask from `out`): gradient to its conv output and to the shortcut branch
+        bl = chain[-1][1]
+        d_raw, dres = ops.bn_backward(gout, raws[-1], out, stats[-1], bl.weight, bl.bias, True, True, g(bl.weight),
+                                      g(bl.bias), pg, partials=pre)
+        for i in range(n - 1, 0, -1):
+            c, bp = chain[i][0], chain[i - 1][1]
+            # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
+            d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
+                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf)
+            c._bwd_buf = part.partials
+            if pg:
+                ops.conv_wgrad(acts[i - 1], d_raw, c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True)
+            d_raw, _ = ops.bn_backward(d_a, raws[i - 1], None, stats[i - 1], bp.weight, bp.bias, True, False, g(bp.weight),
+                                       g(bp.bias), pg, partials=part)
+        c1 = chain[0][0]
         if pg:
-            ops.conv_wgrad(a1, d_raw2, c2.kernel_size[0], 1, c2.weight.grad, accumulate=True)
-        d_raw1, _ = ops.bn_backward(d_a1, raw1, None, s1, b1.weight, b1.bias, True, False, g(b1.weight), g(b1.bias), pg,
-                                    partials=part)
-        if pg:
-            ops.conv_wgrad(x, d_raw1, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
+            ops.conv_wgrad(x, d_raw, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
         dx = None
-        prev = ctx.prev_bn2
+        prev = ctx.prev_bn
         fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x) if (prev is not None and need_dx) else {}
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
@@ -283,13 +291,49 @@ class _BlockFn(torch.autograd.Function):
                     ops.conv_wgrad(x, d_rawsc, csc.kernel_size[0], csc.stride[0], csc.weight.grad, accumulate=True)
                 if need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
-                    dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
+                    dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
-            dx = ops.conv_dgrad(d_raw1, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
+            dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
         if fuse and dx is not None:
             dx, sums = dx
             dx._afan_bn_sums = sums
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def _block_fast_path_ok(blk, x):
+    """bf16 channels-last training step with every convolution of the block on the library's MFMA kernels and every
+    parameter's gradient buffer owned by the arena (or parameter gradients switched off, as inside PGD)."""
+    chain = blk._chain()
+    c1 = chain[0][0]
+    if c1.compute_dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != 4:
+        return False
+    if not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda:
+        return False
+    convs, mods = [c for c, _ in chain], [b for _, b in chain]
+    if blk._sc_kind == "conv":
+        convs.append(blk.shortcut[0])
+        mods.append(blk.shortcut[1])
+    elif blk._sc_kind != "identity":
+        return False
+    if not all(m.training and m.track_running_stats for m in mods):
+        return False
+    for c in convs:
+        if not _own_conv_ok_shape(c.lp_weight(), c.stride, c.padding):
+            return False
+    if _Flags.param_grads and torch.is_grad_enabled():
+        ps = [c.weight for c in convs] + [m.weight for m in mods] + [m.bias for m in mods]
+        if not all(_accumulates_in_place(p) for p in ps):
+            return False
+    return True
+
+
+def _block_params(blk):
+    ps = []
+    for c, b in blk._chain():
+        ps += [c.weight, b.weight, b.bias]
+    if blk._sc_kind == "conv":
+        ps += [blk.shortcut[0].weight, blk.shortcut[1].weight, blk.shortcut[1].bias]
+    return ps
 
 
 # ---------------------------------------------------------------------------------------------- layers
@@ -422,43 +466,13 @@ class BasicBlock(nn.Module):
                     BatchNorm2d(self.expansion * planes))
                 self._sc_kind = "conv"
 
-    def _fast_path_ok(self, x):
-        """bf16 channels-last training step with every convolution on the library's MFMA kernels and every parameter's
-        gradient buffer owned by the arena (or parameter gradients switched off, as inside PGD)."""
-        c1, c2 = self.conv1, self.conv2
-        if c1.compute_dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or x.dim() != 4:
-            return False
-        if not x.is_contiguous(memory_format=torch.channels_last) or not x.is_cuda:
-            return False
-        mods = [self.bn1, self.bn2]
-        convs = [c1, c2]
-        if self._sc_kind == "conv":
-            convs.append(self.shortcut[0])
-            mods.append(self.shortcut[1])
-        elif self._sc_kind != "identity":
-            return False
-        if not all(m.training and m.track_running_stats for m in mods):
-            return False
-        for c in convs:
-            w = c.lp_weight()
-            if not _own_conv_ok_shape(w, c.stride, c.padding):
-                return False
-        if _Flags.param_grads and torch.is_grad_enabled():
-            ps = [c.weight for c in convs] + [m.weight for m in mods] + [m.bias for m in mods]
-            if not all(_accumulates_in_place(p) for p in ps):
-                return False
-        return True
-
-    def _params(self):
-        ps = [self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight, self.bn2.bias]
-        if self._sc_kind == "conv":
-            ps += [self.shortcut[0].weight, self.shortcut[1].weight, self.shortcut[1].bias]
-        return ps
+    def _chain(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
 
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
-        if _Flags.block_fusion and self._fast_path_ok(x):
-            return _BlockFn.apply(x, self, _Flags.param_grads, *self._params())
+        if _Flags.block_fusion and _block_fast_path_ok(self, x):
+            return _BlockFn.apply(x, self, _Flags.param_grads, *_block_params(self))
         out, st = self.conv1.forward_with_stats(x, self.bn1)
         out = self.bn1.fused(out, None, True, st)
         out, st = self.conv2.forward_with_stats(out, self.bn2)
@@ -487,12 +501,19 @@ class Bottleneck(nn.Module):
         self.conv3 = Conv2d(planes, out_planes, kernel_size=1, stride=1, padding=0, bias=False)
         self.bn3 = BatchNorm2d(out_planes)
         self.shortcut = nn.Sequential()
+        self._sc_kind = "identity"
         if stride != 1 or in_planes != out_planes:
             self.shortcut = nn.Sequential(Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False),
                                           BatchNorm2d(out_planes))
+            self._sc_kind = "conv"
+
+    def _chain(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
 
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
+        if _Flags.block_fusion and _block_fast_path_ok(self, x):
+            return _BlockFn.apply(x, self, _Flags.param_grads, *_block_params(self))
         out, st = self.conv1.forward_with_stats(x, self.bn1)
         out = self.bn1.fused(out, None, True, st)
         out, st = self.conv2.forward_with_stats(out, self.bn2)

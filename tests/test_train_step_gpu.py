@@ -254,6 +254,38 @@ def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode):
             assert int(a[3][k]) == int(b[3][k]), k     # same BN side effects (K+2 / 2 updates)
 
 
+def test_bottleneck_block_fusion_matches_per_op_path(pkg, orc, gpu):
+    """Same comparison for the Bottleneck chain (conv-BN x 3) of the ResNet-50: one-node block vs per-op autograd on the
+    same bf16 kernels, K = 0 so that no sign() step amplifies rounding differences."""
+    res = {}
+    for fused in (False, True):
+        pkg.resnet_s._Flags.block_fusion = fused
+        try:
+            torch.manual_seed(3)
+            ref = orc.resnet50(num_classes=16)
+            m = pkg.resnet_s.resnet50(num_classes=16)
+            m.load_state_dict(ref.state_dict())
+            m.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+            tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=0, gamma=0.5, eps=2.0, perturb_idx=8, lr=0.1,
+                                            use_graph=False)
+            torch.manual_seed(0)
+            x, y = torch.rand(16, 3, 64, 64, device=gpu), torch.randint(0, 16, (16,), device=gpu)
+            r = tr.step(x, y)
+            res[fused] = (float(r["loss"]), tr.arena.grad.clone().cpu().numpy(),
+                          {k: v.clone().cpu() for k, v in m.state_dict().items()})
+        finally:
+            pkg.resnet_s._Flags.block_fusion = True
+    a, b = res[False], res[True]
+    assert abs(a[0] - b[0]) < 2e-3 * max(1.0, abs(a[0])), (a[0], b[0])
+    rel = np.linalg.norm(b[1] - a[1]) / np.linalg.norm(a[1])
+    assert rel < 3e-2, rel
+    for k in a[2]:
+        if "num_batches" in k:
+            assert int(a[2][k]) == int(b[2][k]), k
+        elif "running_mean" in k:
+            np.testing.assert_allclose(b[2][k].numpy(), a[2][k].numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
+
+
 def test_resnet50_imagenet_shape_step(pkg, orc, gpu):
     """BASELINE config 3 (build-defined ResNet-50, perturbation after layer1) at a size the CPU oracle finishes in
     seconds: fp32 product vs oracle on identical weights/inputs (K = 1: one sign() step, so the adversarial loss is not
