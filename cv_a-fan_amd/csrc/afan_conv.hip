@@ -21,7 +21,10 @@
 
 using namespace afan;
 
-namespace afan_nhwc { int acc_slot_count(int64_t C); }   // afan_bn_nhwc.hip: accumulator copies per channel
+namespace afan_nhwc {   // afan_bn_nhwc.hip: accumulator copies per channel / doubles per accumulator block
+int acc_slot_count(int64_t C);
+int64_t acc_doubles(int64_t C);
+}
 
 namespace {
 
@@ -65,6 +68,8 @@ struct ConvP {
                                  //     instead of the recomputed bnx*alpha+beta > 0 (a BN whose ReLU follows a residual add)
     double* acc;                 // alternative to `stats`: the same column sums added into f64 accumulators [NS][2][Co]
     int acc_ns;                  //   with native atomics, copy = row tile % NS (+ [Co] floats after them: the shift used)
+    int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
+    int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
     ConvClass cls[4];
 };
@@ -352,14 +357,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     //  * addend: y += addend (the other branch of a residual gradient), rounded to bf16 like a separate add would;
     //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
     //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
+    // image group of this row tile (tiles never straddle the two halves: checked on the host)
+    int grp = 0;
+    uint32_t grp_m0 = 0;
+    if (pp.groups == 2) {
+        const uint32_t half = (uint32_t)(pp.N / 2) * Hg * Wg;
+        if (m0 >= half) { grp = 1; grp_m0 = half; }
+    }
+    const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
+    double* acc_blk = pp.acc ? pp.acc + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
         const int c = n0 + pc * 8 + j;
-        sh[j] = bn_bwd ? pp.bn_stats[c] : ((want_stats && pp.shift) ? pp.shift[c] : 0.f);   // mean or shift
-        al[j] = bn_bwd ? pp.bn_stats[2 * pp.Co + c] : 0.f;
-        be[j] = bn_bwd ? pp.bn_stats[3 * pp.Co + c] : 0.f;
+        sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && pp.shift) ? pp.shift[c] : 0.f);   // mean or shift
+        al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : 0.f;
+        be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < EPI_ROWS; ++q) {
@@ -423,11 +437,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
                 b += red[w][1][tid];
             }
             if (pp.acc) {
-                double* dst = pp.acc + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
+                double* dst = acc_blk + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
                 unsafeAtomicAdd(dst + n0 + tid, (double)a);
                 unsafeAtomicAdd(dst + pp.Co + n0 + tid, (double)b);
-                if (!bn_bwd && blockIdx.y == 0 && blockIdx.z == 0)   // snapshot of the shift for the BN that consumes the sums
-                    reinterpret_cast<float*>(pp.acc + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = pp.shift ? pp.shift[n0 + tid] : 0.f;
+                if (!bn_bwd && m0 == grp_m0 && blockIdx.z == 0)   // snapshot of the shift for the BN that consumes the sums
+                    reinterpret_cast<float*>(acc_blk + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = pp.shift ? pp.shift[n0 + tid] : 0.f;
             } else {
                 const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
                 pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
@@ -519,6 +533,19 @@ int dispatch(const ConvP& p, hipStream_t st) {
 #undef AFAN_CONV_GO
 }
 
+// groups = 2: rows of the two half-batches must fall into different row tiles (largest tile: 128 rows), and the sums go
+// to per-group f64 accumulator blocks (the slab form has no group dimension)
+int set_groups(ConvP& p, int groups, int64_t n, int64_t positions_per_image, int64_t channels, bool have_acc) {
+    p.groups = 1;
+    p.acc_stride = 0;
+    if (groups <= 1) return AFAN_OK;
+    if (groups != 2 || (n & 1) || !have_acc) return AFAN_ESHAPE;
+    if (((n / 2) * positions_per_image) % 128 != 0) return AFAN_ESHAPE;
+    p.groups = 2;
+    p.acc_stride = (int)((afan_nhwc::acc_doubles(channels) + 1) & ~(int64_t)1);
+    return AFAN_OK;
+}
+
 int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
     if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // caller falls back for the 3-channel stem
@@ -547,7 +574,7 @@ int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64
 // y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding k/2, stride 1 or 2; all bf16, channels-last.
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                             int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
-                            double* stats_acc, afan_stream_t stream) {
+                            double* stats_acc, int groups, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, ci, co, k, stride);
     if (e) return e;
     if (!x || !w || !y) return AFAN_ENULL;
@@ -561,6 +588,7 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     if (stats_partials && stats_acc) return AFAN_ESHAPE;   // one destination for the moments, not both
     if (stats_acc && !aligned(stats_acc, 16)) return AFAN_EALIGN;
     p.stats = stats_partials; p.shift = stats_shift; p.acc = stats_acc; p.acc_ns = afan_nhwc::acc_slot_count(co);
+    if ((e = set_groups(p, groups, n, (int64_t)p.Ho * p.Wo, co, stats_acc != nullptr))) return e;
     ConvClass& c0 = p.cls[0];
     c0.Hg = p.Ho; c0.Wg = p.Wo; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
     for (int r = 0; r < k; ++r)
@@ -572,7 +600,7 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     const double M = (double)n * p.Ho * p.Wo;
     AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
                     2.0 * M * co * k * k * ci, st);
-    if (!stats_partials && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
+    if (!stats_partials && groups <= 1 && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.flip = 0;
         q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
@@ -609,7 +637,7 @@ int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                               int64_t co, int k, int stride, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
-                              double* bn_acc, afan_stream_t stream) {
+                              double* bn_acc, int groups, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
     if (e) return e;
     if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
@@ -628,13 +656,17 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     if (bn_partials || bn_acc) {
         if (!bn_x || !bn_stats) return AFAN_ENULL;
         if (bn_acc && !aligned(bn_acc, 16)) return AFAN_EALIGN;
+        // image groups: every parity class of a stride-2 launch has at least (hi/2)*(wi/2) positions per image, a
+        // multiple of that class's own count is what matters; the smallest class decides
+        if ((e = set_groups(p, groups, n, stride == 1 ? hi * wi : (hi / 2) * (wi / 2), ci, bn_acc != nullptr))) return e;
+        if (groups == 2 && stride == 2 && ((hi | wi) & 1)) return AFAN_ESHAPE;
         p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
         p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
     p.in_s = 1;
-    if (!bn_partials && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
+    if (!bn_partials && groups <= 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
         q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu; q.bny = p.bny;

@@ -93,12 +93,13 @@ def acc_reset(device):
     a.off = 0
 
 
-def acc_take(device, c):
-    """A zeroed accumulator block for one BatchNorm pass over c channels (see afan_bn_acc_doubles).  Blocks are cut
+def acc_take(device, c, groups=1):
+    """A zeroed accumulator block for one BatchNorm pass over c channels (see afan_bn_acc_doubles); groups = 2: two
+    consecutive blocks, one per half-batch (stride = acc_block_doubles(c)).  Blocks are cut
     from a per-stream arena; when it runs out the arena is zeroed in stream order and reused — every block is consumed
     by the launch right after its producer, so nothing live is lost."""
     a = _acc_arena(device)
-    n = (int(_lib.load().afan_bn_acc_doubles(int(c))) + 1) & ~1
+    n = acc_block_doubles(c) * int(groups)
     if n > _ACC_DOUBLES:
         raise ValueError("too many channels for the accumulator arena")
     if a.off + n > _ACC_DOUBLES:
@@ -107,6 +108,10 @@ def acc_take(device, c):
     blk = a.buf[a.off:a.off + n]
     a.off += n
     return blk
+
+
+def acc_block_doubles(c):
+    return (int(_lib.load().afan_bn_acc_doubles(int(c))) + 1) & ~1
 
 
 def bn_acc_ok(x):
@@ -311,9 +316,10 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num
 
 
 def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches,
-                     conv_stats=None):
+                     conv_stats=None, out=None, stats_out=None):
     """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward).
-    conv_stats: ConvStats from the producing convolution -> the moments pass over x is skipped."""
+    conv_stats: ConvStats from the producing convolution -> the moments pass over x is skipped.
+    out / stats_out: write into these tensors (views of a batched buffer) instead of allocating."""
     lib = _lib.load()
     _need(x, "x")
     if x.dtype not in _DT:
@@ -322,8 +328,11 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
         _need(residual, "residual", x.dtype)
         _same_layout(x, residual)
     n, c, hw = _nchw(x)
-    y = torch.empty_like(x)
-    stats = torch.empty(4, c, dtype=torch.float32, device=x.device)
+    if out is not None:
+        _need(out, "out", x.dtype)
+        _same_layout(x, out)
+    y = out if out is not None else torch.empty_like(x)
+    stats = stats_out if stats_out is not None else torch.empty(4, c, dtype=torch.float32, device=x.device)
     acc = conv_stats.acc if conv_stats is not None else None
     ready = acc is not None
     if acc is None and conv_stats is None and bn_acc_ok(x):
@@ -369,7 +378,7 @@ def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
 
 
 def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False,
-                partials=None):
+                partials=None, dx_out=None, dres_out=None):
     """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given.
     partials: ConvStats written by the dgrad that produced dy (conv_dgrad(..., bn_bwd=...)): skips the reduction pass."""
     lib = _lib.load()
@@ -379,8 +388,9 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
         _need(y, "y", x.dtype)
     _same_layout(x, dy, y)
     n, c, hw = _nchw(x)
-    dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
+    dx = dx_out if dx_out is not None else torch.empty_like(x)
+    dres = (dres_out if dres_out is not None else torch.empty_like(x)) if want_dres else None
+    _same_layout(x, dx, dres)
     # stand-alone reductions keep the slab + finalize kernels: their blocks all finish together, so the accumulator
     # atomics would arrive as one burst and serialise per address (measured 2x slower); a dgrad epilogue spreads them
     acc = partials.acc if partials is not None else None
@@ -418,12 +428,17 @@ class ConvStats:
     def __init__(self, partials, g, shift, acc=None):
         self.partials, self.g, self.shift, self.acc = partials, g, shift, acc
 
+    def group(self, i, c):
+        """The accumulator block of half-batch i of a grouped launch (conv_fwd / conv_dgrad with groups = 2)."""
+        n = acc_block_doubles(c)
+        return ConvStats(None, 0, self.shift, self.acc[i * n:(i + 1) * n])
+
 
 def _conv_acc_ok(c):
     return BN_ACC and bool(_lib.load().afan_bn_acc_supported(AFAN_BF16, int(c)))
 
 
-def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
+def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, groups=1):
     """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last.
     want_stats=True also returns a ConvStats (moments of y around stats_shift[c], e.g. the BN running mean)."""
     lib = _lib.load()
@@ -436,8 +451,10 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     y = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     st = None
+    if groups != 1 and not (want_stats and _conv_acc_ok(co)):
+        raise ValueError("grouped statistics need the accumulator path")
     if want_stats and _conv_acc_ok(co):
-        st = ConvStats(None, 0, stats_shift, acc_take(x.device, co))
+        st = ConvStats(None, 0, stats_shift, acc_take(x.device, co, groups))
     elif want_stats:
         g = lib.afan_conv_fwd_tiles(n, hi, wi, ci, co, k, stride)
         if stats_buf is None or stats_buf.numel() < 2 * co * g:
@@ -445,11 +462,11 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None):
         st = ConvStats(stats_buf, g, stats_shift)
     check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride,
                                       _ptr(st.partials) if st else None, _ptr(stats_shift) if st else None,
-                                      _ptr(st.acc) if st else None, _stream(x)), "afan_conv_fwd_nhwc_bf16")
+                                      _ptr(st.acc) if st else None, int(groups), _stream(x)), "afan_conv_fwd_nhwc_bf16")
     return (y, st) if want_stats else y
 
 
-def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None):
+def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient
     entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward).
@@ -472,14 +489,16 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
         bnx, bstats, relu = bn_bwd
         _cl4(bnx, "bn_x")
         _need(bstats, "bn_stats", torch.float32)
-        if bnx.shape != dx.shape or bstats.numel() != 4 * ci:
+        if bnx.shape != dx.shape or bstats.numel() != 4 * ci * groups:
             raise ValueError("bn_x / bn_stats do not match dx")
         if bn_y is not None:
             _cl4(bn_y, "bn_y")
             if bn_y.shape != dx.shape:
                 raise ValueError("bn_y must have dx's shape")
+        if groups != 1 and not _conv_acc_ok(ci):
+            raise ValueError("grouped statistics need the accumulator path")
         if _conv_acc_ok(ci):
-            st = ConvStats(None, 0, None, acc_take(dy.device, ci))
+            st = ConvStats(None, 0, None, acc_take(dy.device, ci, groups))
         else:
             g = lib.afan_conv_dgrad_tiles(n, hi, wi, ci, co, k, stride)
             if partials_buf is None or partials_buf.numel() < 2 * ci * g:
@@ -487,7 +506,8 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
             st = ConvStats(partials_buf, g, None)
     check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _ptr(addend),
                                         _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(bn_y) if st else None,
-                                        _ptr(st.partials) if st else None, _ptr(st.acc) if st else None, _stream(dy)),
+                                        _ptr(st.partials) if st else None, _ptr(st.acc) if st else None,
+                                        int(groups) if st else 1, _stream(dy)),
           "afan_conv_dgrad_nhwc_bf16")
     return (dx, st) if bn_bwd is not None else dx
 

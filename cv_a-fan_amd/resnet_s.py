@@ -28,6 +28,7 @@ class _Flags:
     weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
     wgrad_stream = None  # side stream for weight-gradient kernels (set by AfanTrainer; None = same stream)
     block_fusion = True  # BasicBlock as one autograd node on the bf16 channels-last fast path (_BlockFn)
+    bn_groups = 1        # 2: the batch is [adv half | clean half]; BatchNorm statistics / running updates per half, in order
 
 
 def join_wgrad_stream():
@@ -45,6 +46,51 @@ def dgrad_only():
         yield
     finally:
         _Flags.param_grads = old
+
+
+@contextlib.contextmanager
+def bn_groups(g):
+    """Inside this context a batch is g concatenated half-batches that BatchNorm treats as separate forward passes
+    (statistics, running-stat updates in order, backward sums) while convolutions run once over the whole batch:
+    main_perturb.py:195-196's adversarial and clean passes as one pass over the tail.  Only the one-node residual
+    blocks implement it; any other BatchNorm raises."""
+    old = _Flags.bn_groups
+    _Flags.bn_groups = int(g)
+    try:
+        yield
+    finally:
+        _Flags.bn_groups = old
+
+
+def _bn_fwd_g(raw, b, res, relu, st, G, mom):
+    """BatchNorm forward of one layer over G half-batches (G = 1: the plain call)."""
+    if G == 1:
+        return ops.bn_train_forward(raw, b.weight, b.bias, res, relu, b.eps, mom, b.running_mean, b.running_var,
+                                    b.num_batches_tracked, st)
+    c, n = raw.shape[1], raw.shape[0] // G
+    y = torch.empty_like(raw)
+    stats = torch.empty(G, 4, c, dtype=torch.float32, device=raw.device)
+    for g in range(G):                         # in order: the adversarial half updates the running statistics first
+        sl = slice(g * n, (g + 1) * n)
+        ops.bn_train_forward(raw[sl], b.weight, b.bias, None if res is None else res[sl], relu, b.eps, mom,
+                             b.running_mean, b.running_var, b.num_batches_tracked, st.group(g, c), out=y[sl],
+                             stats_out=stats[g])
+    return y, stats
+
+
+def _bn_bwd_g(dy, raw, y, stats, b, relu, want_dres, pg, part, G):
+    gw, gb = (b.weight.grad, b.bias.grad) if pg else (None, None)
+    if G == 1:
+        return ops.bn_backward(dy, raw, y, stats, b.weight, b.bias, relu, want_dres, gw, gb, pg, partials=part)
+    c, n = raw.shape[1], raw.shape[0] // G
+    dx = torch.empty_like(raw)
+    dres = torch.empty_like(raw) if want_dres else None
+    for g in range(G):
+        sl = slice(g * n, (g + 1) * n)
+        ops.bn_backward(dy[sl], raw[sl], None if y is None else y[sl], stats[g], b.weight, b.bias, relu, want_dres, gw, gb,
+                        pg, partials=None if part is None else part.group(g, c), dx_out=dx[sl],
+                        dres_out=dres[sl] if want_dres else None)
+    return dx, dres
 
 
 # ------------------------------------------------------------------------------------------------ ops
@@ -224,37 +270,37 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, blk, want_pgrad, *params):
         chain = blk._chain()
         n = len(chain)
+        G = _Flags.bn_groups
         mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
         rawsc = ssc = None
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
-                                      stats_buf=csc._stats_buf)
+                                      stats_buf=csc._stats_buf, groups=G)
             csc._stats_buf = stc.partials
-            res, ssc = ops.bn_train_forward(rawsc, bsc.weight, bsc.bias, None, False, bsc.eps, mom(bsc), bsc.running_mean,
-                                            bsc.running_var, bsc.num_batches_tracked, stc)
+            res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
         else:
             res = x
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
             raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
-                                   stats_buf=c._stats_buf)
+                                   stats_buf=c._stats_buf, groups=G)
             c._stats_buf = st.partials
-            a, s_i = ops.bn_train_forward(raw, b.weight, b.bias, res if i == n - 1 else None, True, b.eps, mom(b),
-                                          b.running_mean, b.running_var, b.num_batches_tracked, st)
+            a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
             saved += [raw, a, s_i]
-        ctx.blk, ctx.want_pgrad, ctx.n = blk, want_pgrad, n
+        ctx.blk, ctx.want_pgrad, ctx.n, ctx.G = blk, want_pgrad, n, G
         # cross-block fusion: when x is the output of another _BlockFn, this block's input-gradient dgrad also takes the
         # reduction sums of THAT block's last BN backward (its ReLU mask is x > 0) — see backward
-        ctx.prev_bn = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
+        prev = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
+        ctx.prev_bn = prev if (prev is not None and prev[2] == G) else None
         ctx.save_for_backward(x, rawsc, ssc, *saved)
-        a._afan_bn2 = (saved[-3], saved[-1])
+        a._afan_bn2 = (saved[-3], saved[-1], G)
         return a
 
     @staticmethod
     def backward(ctx, gout):
         x, rawsc, ssc, *saved = ctx.saved_tensors
-        blk, pg, n = ctx.blk, ctx.want_pgrad, ctx.n
+        blk, pg, n, G = ctx.blk, ctx.want_pgrad, ctx.n, ctx.G
         chain = blk._chain()
         raws, acts, stats = saved[0::3], saved[1::3], saved[2::3]
         need_dx = ctx.needs_input_grad[0]
@@ -264,29 +310,26 @@ class _BlockFn(torch.autograd.Function):
         gout = _like_layout(gout, out)
         # last BN (+residual, ReLU mask from `out`): gradient to its conv output and to the shortcut branch
         bl = chain[-1][1]
-        d_raw, dres = ops.bn_backward(gout, raws[-1], out, stats[-1], bl.weight, bl.bias, True, True, g(bl.weight),
-                                      g(bl.bias), pg, partials=pre)
+        d_raw, dres = _bn_bwd_g(gout, raws[-1], out, stats[-1], bl, True, True, pg, pre, G)
         for i in range(n - 1, 0, -1):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
             d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
-                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf)
+                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G)
             c._bwd_buf = part.partials
             if pg:
                 ops.conv_wgrad(acts[i - 1], d_raw, c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True)
-            d_raw, _ = ops.bn_backward(d_a, raws[i - 1], None, stats[i - 1], bp.weight, bp.bias, True, False, g(bp.weight),
-                                       g(bp.bias), pg, partials=part)
+            d_raw, _ = _bn_bwd_g(d_a, raws[i - 1], None, stats[i - 1], bp, True, False, pg, part, G)
         c1 = chain[0][0]
         if pg:
             ops.conv_wgrad(x, d_raw, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
         dx = None
         prev = ctx.prev_bn
-        fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x) if (prev is not None and need_dx) else {}
+        fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x, groups=G) if (prev is not None and need_dx) else {}
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             if pg or need_dx:
-                d_rawsc, _ = ops.bn_backward(dres, rawsc, None, ssc, bsc.weight, bsc.bias, False, False, g(bsc.weight),
-                                             g(bsc.bias), pg)
+                d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G)
                 if pg:
                     ops.conv_wgrad(x, d_rawsc, csc.kernel_size[0], csc.stride[0], csc.weight.grad, accumulate=True)
                 if need_dx:
@@ -415,6 +458,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameters/buffers; fused HIP execution."""
 
     def fused(self, x, residual=None, relu=False, conv_stats=None):
+        if _Flags.bn_groups != 1 and self.training:
+            raise NotImplementedError("grouped BatchNorm statistics are implemented by the one-node residual blocks only")
         if self.training:
             mom = self.momentum if self.momentum is not None else 0.1
             return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, mom, self.running_mean,

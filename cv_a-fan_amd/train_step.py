@@ -119,7 +119,7 @@ class AfanTrainer:
 
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
-                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False):
+                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -133,6 +133,8 @@ class AfanTrainer:
         if self.world > 1:
             self.optimizer.grad_scale = 1.0 / self.world
         self.async_wgrad = bool(async_wgrad)
+        self.batch_final = bool(batch_final)      # adv + clean final passes as one grouped pass over the tail
+        self._groupable_key, self._groupable = None, False
         self._wgrad_stream = None
         self.use_graph = bool(use_graph) and not randinit
         self.graph_warmup = graph_warmup
@@ -162,8 +164,21 @@ class AfanTrainer:
         adv_in = getattr(feature_map_adv, "_afan_shadow", None)
         if adv_in is None:
             adv_in = feature_map_adv.detach()
-        output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
-        output_clean = m(inp, end_point=ln, start_point=0)                   # main_perturb.py:196
+        if self.batch_final and self._tail_groupable(adv_in):
+            # main_perturb.py:195-196 as ONE pass over the tail: [adv | clean] concatenated, convolutions and weight
+            # gradients run once over both halves (each layer's weights are fetched once instead of twice, twice the
+            # row tiles per launch), BatchNorm treats the halves as the two separate passes they are — statistics,
+            # running-stat updates (adv first, then clean) and backward sums per half (resnet_s.bn_groups).
+            from . import resnet_s
+            fm_clean = m(inp, end_point=idx, start_point=0)
+            both = torch.cat([adv_in, fm_clean.to(adv_in.dtype)], dim=0)
+            with resnet_s.bn_groups(2):
+                out_both = m(both, end_point=ln, start_point=idx)
+            nb = adv_in.shape[0]
+            output_adv, output_clean = out_both[:nb], out_both[nb:]
+        else:
+            output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
+            output_clean = m(inp, end_point=ln, start_point=0)                   # main_perturb.py:196
         loss_adv = self.criterion(output_adv, target)
         loss_clean = self.criterion(output_clean, target)
         loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
@@ -186,6 +201,41 @@ class AfanTrainer:
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
                 "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
                 "feature_map": feature_map, "out_clean": output_clean.detach()}
+
+    def _tail_groupable(self, fea):
+        """Can the tail run the adversarial and the clean pass as one grouped pass?  bf16 channels-last feature map, every
+        BatchNorm of the tail inside a one-node residual block on the library's kernels, and at every resolution the
+        half-batch's pixel count a multiple of the largest row tile (so no tile straddles the halves)."""
+        from . import ops as _ops
+        key = (tuple(fea.shape), fea.dtype, fea.is_contiguous(memory_format=torch.channels_last), _ops.BN_ACC)
+        if self._groupable_key == key:
+            return self._groupable
+        from . import resnet_s
+        from . import ops
+        ok = (fea.is_cuda and fea.dim() == 4 and fea.dtype == torch.bfloat16 and key[2] and resnet_s._Flags.block_fusion
+              and ops.BN_ACC)                                  # per-half sums live in the f64 accumulator blocks
+        n, _, h, w = fea.shape if fea.dim() == 4 else (0, 0, 0, 0)
+        if ok:
+            for mod in self.model.sequential_model[self.perturb_idx:self.layer_number]:
+                if isinstance(mod, (resnet_s.BasicBlock, resnet_s.Bottleneck)):
+                    probe = torch.empty((2, mod._chain()[0][0].in_channels, 2, 2), dtype=torch.bfloat16,
+                                        device=fea.device).contiguous(memory_format=torch.channels_last)
+                    if not (mod.training and resnet_s._block_fast_path_ok(mod, probe)):
+                        ok = False
+                        break
+                    for c, _ in mod._chain():
+                        if (n * h * w) % 128 or (c.stride[0] == 2 and ((h | w) & 1)):
+                            ok = False
+                        h, w = (h + c.stride[0] - 1) // c.stride[0], (w + c.stride[0] - 1) // c.stride[0]
+                        if (n * h * w) % 128:
+                            ok = False
+                    if not ok:
+                        break
+                elif any(isinstance(q, torch.nn.modules.batchnorm._BatchNorm) for q in mod.modules()):
+                    ok = False
+                    break
+        self._groupable_key, self._groupable = key, bool(ok)
+        return self._groupable
 
     def _step_eager(self, inp, target):
         self.optimizer._sync_lr()

@@ -202,18 +202,21 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride);
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                             int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
-                            double* stats_acc, afan_stream_t stream);
+                            double* stats_acc, int groups, afan_stream_t stream);
 /* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
  * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
  * sum((y - shift[c])^2) at [(1*Co + c)*G + g], G = afan_conv_fwd_tiles(...), over the bf16 values it stores
  * (shift = the BN layer's running mean, NULL = 0).  afan_bn_train_forward_partials() consumes them.
  * stats_acc != NULL (instead of stats_partials): the same sums are added into the zeroed accumulator block
- * stats_acc[afan_bn_acc_doubles(Co)] and the shift is copied behind them; afan_bn_train_forward_acc() consumes it. */
+ * stats_acc[afan_bn_acc_doubles(Co)] and the shift is copied behind them; afan_bn_train_forward_acc() consumes it.
+ * groups = 2 (with stats_acc): the batch is two concatenated half-batches normalised SEPARATELY (the adversarial and
+ * the clean pass of main_perturb.py:195-196 run as one launch): images n >= N/2 add into a second accumulator block at
+ * stats_acc + afan_bn_acc_doubles(Co) rounded up to even.  (N/2)*Ho*Wo must be a multiple of 128.  groups = 1 otherwise. */
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
-                              double* bn_acc, afan_stream_t stream);
+                              double* bn_acc, int groups, afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
  *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
  *               both the main branch and the shortcut;
@@ -224,6 +227,8 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
  *   bn_y        optional [N,Hi,Wi,Ci] bf16: the OUTPUT of that BatchNorm after its residual add and ReLU (the next
  *               block's input): the ReLU mask is (bn_y > 0) instead of the recomputed bn_x*alpha+beta > 0 — the form a
  *               BasicBlock's second BatchNorm needs (resnet_s.py:54-55: relu(bn2(conv2(.)) + shortcut(x)));
+ *   groups      2 (with bn_acc): two concatenated half-batches with separate statistics — bn_stats is [2][4*Ci] and
+ *               bn_acc two accumulator blocks, as for the forward; 1 otherwise;
  *   bn_acc      (instead of bn_partials) the same sums added into the zeroed accumulator block bn_acc[afan_bn_acc_doubles(Ci)], consumed by
  *               afan_bn_backward_acc(..., acc_ready = 1). */
 int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);

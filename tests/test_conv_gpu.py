@@ -155,3 +155,52 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-4, atol=2e-4 * scale)
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(outs[0][0]).max())))
     np.testing.assert_array_equal(outs[1][2], outs[0][2])
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", [(8, 64, 128, 16, 3, 2), (16, 128, 128, 8, 3, 1), (64, 256, 512, 4, 1, 2),
+                                                 (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1)])
+def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, stride):
+    """groups = 2 (two concatenated half-batches, BatchNorm statistics per half): one launch over [a | b] must equal the
+    two launches over a and over b — outputs bit for bit (row tiles are independent), sums to accumulation-order noise."""
+    torch.manual_seed(n + ci + co + h)
+    ops = pkg.ops
+    x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, device=gpu) / (ci * k * k) ** 0.5).bfloat16())
+    shift = torch.randn(co, device=gpu) * 0.1
+    gamma, beta = torch.rand(co, device=gpu) + 0.5, torch.randn(co, device=gpu) * 0.2
+    hb = n // 2
+    y, st = ops.conv_fwd(x, w, stride, stats_shift=shift, want_stats=True, groups=2)
+    outs, stats = [], []
+    for g in range(2):
+        xs = x[g * hb:(g + 1) * hb]
+        ys, sts = ops.conv_fwd(xs, w, stride, stats_shift=shift, want_stats=True)
+        assert torch.equal(ys, y[g * hb:(g + 1) * hb])
+        o_ref, s_ref = ops.bn_train_forward(ys, gamma, beta, None, True, 1e-5, 0.1, None, None, None, sts)
+        o_grp, s_grp = ops.bn_train_forward(y[g * hb:(g + 1) * hb], gamma, beta, None, True, 1e-5, 0.1, None, None, None,
+                                            st.group(g, co))
+        np.testing.assert_allclose(s_grp.cpu().numpy(), s_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert_close = np.testing.assert_allclose
+        assert_close(o_grp.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
+        outs.append(o_ref)
+        stats.append(s_ref)
+    # dgrad with the BN-backward sums of a BatchNorm over dx's tensor (ci channels), per group
+    ho = y.shape[2]
+    dy = _cl(torch.randn(n, co, ho, ho, device=gpu).bfloat16())
+    wt = _cl(w.permute(1, 0, 2, 3))
+    bn_x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
+    g2, b2 = torch.rand(ci, device=gpu) + 0.5, torch.randn(ci, device=gpu) * 0.2
+    st2 = torch.stack([ops.bn_train_forward(bn_x[g * hb:(g + 1) * hb], g2, b2, None, True, 1e-5, 0.1, None, None, None)[1]
+                       for g in range(2)])
+    dx, part = ops.conv_dgrad(dy, wt, (h, h), stride, bn_bwd=(bn_x, st2, True), groups=2)
+    for g in range(2):
+        sl = slice(g * hb, (g + 1) * hb)
+        dxs, parts = ops.conv_dgrad(dy[sl], wt, (h, h), stride, bn_bwd=(bn_x[sl], st2[g], True))
+        assert torch.equal(dxs, dx[sl])
+        res = []
+        for p_ in (parts, part.group(g, ci)):
+            dwb = torch.zeros(2, ci, device=gpu)
+            d_, _ = ops.bn_backward(dxs, bn_x[sl], None, st2[g], g2, b2, True, False, dwb[0], dwb[1], partials=p_)
+            res.append((d_.float().cpu().numpy(), dwb.cpu().numpy()))
+        scale = max(1.0, float(np.abs(res[0][1]).max()))
+        np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-2, atol=1e-3 * max(1.0, float(np.abs(res[0][0]).max())))
