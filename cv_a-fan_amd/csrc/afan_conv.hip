@@ -11,10 +11,14 @@
 // mirrored tap offsets), dgrad at stride 2 as four output-parity classes with 1/2/2/4 taps each (no multiplications
 // by the zeros a "dilated" formulation would insert).
 //
-// Tile: BM x BN outputs per 256-thread workgroup (2x2 waves, each (BM/2)x(BN/2) = 32x32 MFMA tiles), BK = 64 channels of
-// one tap per step.  Operands are staged global -> VGPR -> LDS (rows padded to 144 B: conflict-free ds_read_b128
-// fragments), double buffered, one barrier per step, next step's global loads in flight under the MFMAs.  The epilogue
-// rounds to bf16 through LDS so that every store is a 16-byte piece of a channels-last row.
+// Tile: BM x BN outputs per workgroup of 8 waves (2x4 or 4x2; 2x2 with 4 waves as a tuning variant), BK = 64 channels
+// of one tap per step, 32x32 MFMA tiles.  Default staging is LDS-DMA (global_load_lds: no VGPR round trip; unpadded
+// 128-byte rows XOR-swizzled for conflict-free ds_read_b128; a zero page feeds the padding rows), with 2 LDS stages and
+// __syncthreads() where two workgroups share a CU, and 4 stages with counted s_waitcnt vmcnt(N) + bare s_barrier where
+// the launch is about one workgroup per CU (see dispatch()).  Register-staged variants (PF 1 / 2: 144-byte padded rows)
+// remain as A/B references (AFAN_CONV_MODE).  The epilogue rounds to bf16 through LDS so that every store is a 16-byte
+// piece of a channels-last row, and carries the optional fusions (addend, BatchNorm sums per image group).
+// Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64.
 #include "afan_common.h"
 #include "afan_conv_c64.h"
 #include <stdlib.h>
