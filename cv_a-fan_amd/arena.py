@@ -70,10 +70,10 @@ class ParamArena:
                 if isinstance(m, Conv2d) and n.endswith(".weight"):
                     m._arena_shadow = self._view(self.shadow, o, p)
                     k_, c_, r_, s_ = p.shape
-                    if self.channels_last and k_ % 64 == 0 and c_ % 64 == 0:   # the shapes the MFMA dgrad kernel takes
+                    if self.channels_last and k_ % 16 == 0 and c_ % 16 == 0:   # the shapes the MFMA dgrad kernels take
                         desc.append((o, t_off, k_, r_ * s_, c_, tiles, m, p))
                         t_off += p.numel()
-                        tiles += (k_ // 64) * r_ * s_ * (c_ // 64)
+                        tiles += ((k_ + 63) // 64) * r_ * s_ * ((c_ + 63) // 64)
             if desc:
                 # CRSK copies of the conv weights (dgrad operands), rebuilt by ONE launch after every SGD step
                 self.shadow_t = torch.zeros(t_off, dtype=torch.bfloat16, device=dev)

@@ -21,9 +21,11 @@
 // Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64.
 #include "afan_common.h"
 #include "afan_conv_c64.h"
+#include "afan_conv_params.h"
 #include <stdlib.h>
 
 using namespace afan;
+using namespace afan_conv;
 
 namespace afan_nhwc {   // afan_bn_nhwc.hip: accumulator copies per channel / doubles per accumulator block
 int acc_slot_count(int64_t C);
@@ -39,44 +41,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int TRANSPOSE_THREADS = 256;
 constexpr int BK = 64;           // reduction channels per step
 constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes (register-staged variants)
-constexpr int MAX_TAPS = 9;
 
 // landing zone for the padding rows of the LDS-DMA variant (a DMA lane has to read SOMETHING: zeros)
 __device__ const uint4 conv_zero_page[4] = {};
-
-// One "class" = one set of output positions with its tap list.  A forward conv or a stride-1 dgrad has one class;
-// a stride-2 dgrad has four (output-pixel parity), run as blockIdx.z of ONE launch.
-struct ConvClass {
-    int Hg, Wg;                  // grid of output positions of this class
-    int out_h0, out_w0;          // output coordinate = g * out_s + out_0
-    int T;                       // number of taps
-    int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
-};
-
-struct ConvP {
-    const uint16_t* x;
-    const uint16_t* w;
-    uint16_t* y;
-    int N, Hi, Wi, Ci;           // input tensor [N, Hi, Wi, Ci]
-    int Ho, Wo, Co;              // output tensor [N, Ho, Wo, Co]
-    int in_s;                    // input coordinate = g * in_s + d
-    int out_s;
-    int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
-    int n_classes;
-    float* stats;                // optional [2][Co][G] per-tile column sums, G = gridDim.y * gridDim.z; meaning by `bnx`:
-    const float* shift;          //   bnx == NULL: sum (y - shift), sum (y - shift)^2      (moments for a following BN forward)
-    const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):
-    const float* bn_stats;       //     g = relu-masked y, sums g and g*(bnx - mean) from bn_stats[4][Co] = mean|invstd|alpha|beta
-    int bn_relu;                 //     (the reduction pass of that BN's backward, fused here)
-    const uint16_t* bny;         //     optional: that BN layer's OUTPUT after residual add + ReLU — the mask is (bny > 0)
-                                 //     instead of the recomputed bnx*alpha+beta > 0 (a BN whose ReLU follows a residual add)
-    double* acc;                 // alternative to `stats`: the same column sums added into f64 accumulators [NS][2][Co]
-    int acc_ns;                  //   with native atomics, copy = row tile % NS (+ [Co] floats after them: the shift used)
-    int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
-    int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
-    const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
-    ConvClass cls[4];
-};
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
 constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
@@ -550,9 +517,16 @@ int set_groups(ConvP& p, int groups, int64_t n, int64_t positions_per_image, int
     return AFAN_OK;
 }
 
+// reduction channels `ci` / output channels `co` of the GEMM: multiples of 64 (the tiled kernels), or the small-channel
+// kernel's set (afan_conv_small.hip): ci in {16, 32, 64}, co a multiple of 16 up to 64
+bool channels_ok(int64_t ci, int64_t co) {
+    if (ci % BK == 0 && co % 64 == 0) return true;
+    return (ci == 16 || ci == 32 || ci == 64) && co % 16 == 0 && co <= 64;
+}
+
 int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
-    if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // caller falls back for the 3-channel stem
+    if (!channels_ok(ci, co)) return AFAN_ESHAPE;                // caller falls back for the 3-channel stem
     if (!(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
     if (n * hi * wi * (ci > co ? ci : co) * 2 > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit byte offsets / buffer descriptors
     return AFAN_OK;
@@ -563,7 +537,8 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
 extern "C" {
 
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
-    return (ci % BK == 0 && co % 64 == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
+    // forward needs channels_ok(ci, co), the input gradient channels_ok(co, ci): both must hold for a layer to be taken
+    return (channels_ok(ci, co) && channels_ok(co, ci) && (k == 1 || k == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
 }
 
 // number of row tiles (= BN-statistics partials per channel) the forward launch of this problem uses
@@ -604,6 +579,8 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     const double M = (double)n * p.Ho * p.Wo;
     AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
                     2.0 * M * co * k * k * ci, st);
+    if (small_eligible(p)) return small_launch(p, st);
+    if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // (small shape asked for the partial-slab statistics)
     if (!stats_partials && groups <= 1 && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.flip = 0;
@@ -644,7 +621,6 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                               double* bn_acc, int groups, afan_stream_t stream) {
     int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
     if (e) return e;
-    if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
     if (!dy || !wt || !dx) return AFAN_ENULL;
     if (!aligned(dy, 16) || !aligned(wt, 16) || !aligned(dx, 16)) return AFAN_EALIGN;
     const int pad = k / 2;
@@ -687,6 +663,8 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                 const int t = r * k + s;
                 c0.dh[t] = pad - r; c0.dw[t] = pad - s; c0.wofs[t] = (int)(t * co);
             }
+        if (small_eligible(p)) return small_launch(p, st);
+        if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
         return dispatch(p, st);
     }
     // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
@@ -716,11 +694,14 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
             ++nc;
         }
     p.n_classes = nc;
+    if (small_eligible(p)) return small_launch(p, st);
+    if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
     return dispatch(p, st);
 }
 
 // ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------
-// desc[i] = {src_off, dst_off, K, RS, C, first_tile}; tiles of 64(k) x 64(c) at fixed rs; K % 64 == 0, C % 64 == 0.
+// desc[i] = {src_off, dst_off, K, RS, C, first_tile}; tiles of 64(k) x 64(c) at fixed rs, ceil(K/64)*RS*ceil(C/64) of them
+// per tensor (partial tiles are masked); K % 8 == 0, C % 8 == 0.
 __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(const uint16_t* __restrict__ src,
                                                                 uint16_t* __restrict__ dst,
                                                                 const int64_t* __restrict__ desc, int n_desc) {
@@ -730,7 +711,8 @@ __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(co
     const int64_t* D = desc + d * 6;
     const int64_t K = D[2], RS = D[3], Cc = D[4];
     int64_t t = blockIdx.x - D[5];
-    const int64_t ct = t % (Cc / 64); t /= (Cc / 64);
+    const int64_t ctiles = (Cc + 63) / 64;
+    const int64_t ct = t % ctiles; t /= ctiles;
     const int64_t rs = t % RS;
     const int64_t kt = t / RS;
     const uint16_t* s = src + D[0];
@@ -739,8 +721,9 @@ __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(co
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int k = r0 + 32 * i;
-        *reinterpret_cast<u32x4*>(&tile[k][piece * 8]) =
-            *reinterpret_cast<const u32x4*>(s + ((kt * 64 + k) * RS + rs) * Cc + ct * 64 + piece * 8);
+        if (kt * 64 + k < K && ct * 64 + piece * 8 < Cc)
+            *reinterpret_cast<u32x4*>(&tile[k][piece * 8]) =
+                *reinterpret_cast<const u32x4*>(s + ((kt * 64 + k) * RS + rs) * Cc + ct * 64 + piece * 8);
     }
     __syncthreads();
 #pragma unroll
@@ -749,7 +732,8 @@ __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(co
         u16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tile[piece * 8 + j][c];
-        *reinterpret_cast<u16x8*>(o + ((ct * 64 + c) * RS + rs) * K + kt * 64 + piece * 8) = v;
+        if (ct * 64 + c < Cc && kt * 64 + piece * 8 < K)
+            *reinterpret_cast<u16x8*>(o + ((ct * 64 + c) * RS + rs) * K + kt * 64 + piece * 8) = v;
     }
 }
 

@@ -1,0 +1,49 @@
+// Problem description shared by the implicit-GEMM convolution kernels (afan_conv.hip, afan_conv_small.hip).
+#pragma once
+#include "afan_common.h"
+
+namespace afan_conv {
+
+constexpr int MAX_TAPS = 9;
+
+// One "class" = one set of output positions with its tap list.  A forward conv or a stride-1 dgrad has one class;
+// a stride-2 dgrad has four (output-pixel parity), run as blockIdx.z of ONE launch.
+struct ConvClass {
+    int Hg, Wg;                  // grid of output positions of this class
+    int out_h0, out_w0;          // output coordinate = g * out_s + out_0
+    int T;                       // number of taps
+    int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
+};
+
+struct ConvP {
+    const uint16_t* x;
+    const uint16_t* w;
+    uint16_t* y;
+    int N, Hi, Wi, Ci;           // input tensor [N, Hi, Wi, Ci]
+    int Ho, Wo, Co;              // output tensor [N, Ho, Wo, Co]
+    int in_s;                    // input coordinate = g * in_s + d
+    int out_s;
+    int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
+    int n_classes;
+    float* stats;                // optional [2][Co][G] per-tile column sums, G = gridDim.y * gridDim.z; meaning by `bnx`:
+    const float* shift;          //   bnx == NULL: sum (y - shift), sum (y - shift)^2      (moments for a following BN forward)
+    const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):
+    const float* bn_stats;       //     g = relu-masked y, sums g and g*(bnx - mean) from bn_stats[4][Co] = mean|invstd|alpha|beta
+    int bn_relu;                 //     (the reduction pass of that BN's backward, fused here)
+    const uint16_t* bny;         //     optional: that BN layer's OUTPUT after residual add + ReLU — the mask is (bny > 0)
+                                 //     instead of the recomputed bnx*alpha+beta > 0 (a BN whose ReLU follows a residual add)
+    double* acc;                 // alternative to `stats`: the same column sums added into f64 accumulators [NS][2][Co]
+    int acc_ns;                  //   with native atomics, copy = row tile % NS (+ [Co] floats after them: the shift used)
+    int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
+    int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
+    const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
+    ConvClass cls[4];
+};
+
+
+// small-channel kernel (afan_conv_small.hip): reduction channels in {16, 32, 64}, output channels a multiple of 16, at
+// least one of the two below 64
+bool small_eligible(const ConvP& p);
+int small_launch(const ConvP& p, hipStream_t st);
+
+}  // namespace afan_conv

@@ -410,7 +410,16 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
 
 # ----------------------------------------------------------------------------------- convolutions
 def conv_supported(ci, co, k, stride):
-    return bool(_lib.load().afan_conv_supported(int(ci), int(co), int(k), int(stride)))
+    """Forward + input gradient of this layer run on the library's kernels.  Layers with a 16/32-channel side take the
+    small-channel kernel, whose BatchNorm fusions exist in the accumulator form only."""
+    if not _lib.load().afan_conv_supported(int(ci), int(co), int(k), int(stride)):
+        return False
+    return BN_ACC or (ci % 64 == 0 and co % 64 == 0)
+
+
+def conv_wgrad_supported(ci, co, k, stride):
+    """The weight-gradient kernel tiles 64 x 64 (co x ci); smaller layers leave wgrad to the vendor library."""
+    return ci % 64 == 0 and co % 64 == 0 and k in (1, 3) and stride in (1, 2)
 
 
 def _cl4(t, name):

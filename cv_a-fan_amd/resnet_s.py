@@ -162,7 +162,7 @@ class _ConvFn(torch.autograd.Function):
         if need_gx and own:
             gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0])
             need_gx = False
-        if need_gw and own:
+        if need_gw and own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], w_lp.shape[2], ctx.stride[0]):
             w_master = ctx.w_master
             k = w_lp.shape[2]
             if _accumulates_in_place(w_master) and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
@@ -195,6 +195,18 @@ class _ConvFn(torch.autograd.Function):
                 elif gw.dtype != torch.float32:
                     gw = gw.float()
         return gx, gw, None, None, None, None, None, None
+
+
+def _wgrad_accumulate(x, dy, c):
+    """Weight gradient of conv module c added into its arena gradient view: the library's kernel where it tiles, else
+    (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
+    k, st = c.kernel_size[0], c.stride[0]
+    if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st):
+        ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True)
+        return
+    gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
+                                             [False, True, False])[1]
+    c.weight.grad.add_(gw)
 
 
 def _accumulates_in_place(p):
@@ -318,11 +330,11 @@ class _BlockFn(torch.autograd.Function):
                                        bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G)
             c._bwd_buf = part.partials
             if pg:
-                ops.conv_wgrad(acts[i - 1], d_raw, c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True)
+                _wgrad_accumulate(acts[i - 1], d_raw, c)
             d_raw, _ = _bn_bwd_g(d_a, raws[i - 1], None, stats[i - 1], bp, True, False, pg, part, G)
         c1 = chain[0][0]
         if pg:
-            ops.conv_wgrad(x, d_raw, c1.kernel_size[0], c1.stride[0], c1.weight.grad, accumulate=True)
+            _wgrad_accumulate(x, d_raw, c1)
         dx = None
         prev = ctx.prev_bn
         fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x, groups=G) if (prev is not None and need_dx) else {}
@@ -331,7 +343,7 @@ class _BlockFn(torch.autograd.Function):
             if pg or need_dx:
                 d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G)
                 if pg:
-                    ops.conv_wgrad(x, d_rawsc, csc.kernel_size[0], csc.stride[0], csc.weight.grad, accumulate=True)
+                    _wgrad_accumulate(x, d_rawsc, csc)
                 if need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
                     dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)

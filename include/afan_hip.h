@@ -195,7 +195,9 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
  * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside
  * `model(x_adv, end_point, start_point)` (attack_algo.py:50; resnet_s.py:52-54,66,72-73) and its input-gradient
  * (attack_algo.py:52), implicit-GEMM kernels of this library.  k in {1,3}, padding k/2, stride in {1,2},
- * Ci % 64 == 0 and Co % 64 == 0 (afan_conv_supported() tells; the 3-channel stem stays with the vendor library).
+ * Ci % 64 == 0 and Co % 64 == 0, or — the reference's own 16-32-64-channel CIFAR ResNets — Ci, Co in {16, 32, 64}
+ * (afan_conv_supported() tells; the 3-channel stem stays with the vendor library).  Layers with a 16/32-channel side
+ * take the small-channel kernel, whose statistics fusions exist in the accumulator form (stats_acc / bn_acc) only.
  *   fwd  : y[N,Ho,Wo,Co]  = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci])
  *   dgrad: dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w)  given  wt[Ci,k,k,Co] = w transposed
  */
@@ -244,7 +246,7 @@ int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_
 
 /* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
  * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
- * offsets into src_arena / dst_arena, K % 64 == 0, C % 64 == 0, first_tile = running sum of (K/64)*RS*(C/64)). */
+ * offsets into src_arena / dst_arena, K % 8 == 0, C % 8 == 0, first_tile = running sum of ceil(K/64)*RS*ceil(C/64)). */
 int afan_transpose_weights(const void* src_arena, void* dst_arena, const int64_t* desc_dev, int n_desc,
                            int64_t total_tiles, afan_stream_t stream);
 
