@@ -291,6 +291,9 @@ class _BlockFn(torch.autograd.Function):
                                       stats_buf=csc._stats_buf, groups=G)
             csc._stats_buf = stc.partials
             res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
+        elif blk._sc_kind == "pad":
+            # option-A shortcut (resnet_s.py:64-65): every second pixel, zero channels either side — data movement only
+            res = blk.shortcut(x).contiguous(memory_format=torch.channels_last)
         else:
             res = x
         a, saved = x, []
@@ -347,6 +350,13 @@ class _BlockFn(torch.autograd.Function):
                 if need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
                     dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
+        elif blk._sc_kind == "pad":
+            if need_dx:
+                # gradient of the subsample + channel padding: the middle channels of dres land on the even pixels
+                pad = blk.shortcut.pad
+                dx_sc = torch.zeros_like(x)
+                dx_sc[:, :, ::2, ::2] = dres[:, pad:pad + x.shape[1]]
+                dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
             dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
         if fuse and dx is not None:
@@ -368,6 +378,9 @@ def _block_fast_path_ok(blk, x):
     if blk._sc_kind == "conv":
         convs.append(blk.shortcut[0])
         mods.append(blk.shortcut[1])
+    elif blk._sc_kind == "pad":
+        if x.shape[2] % 2 or x.shape[3] % 2:
+            return False
     elif blk._sc_kind != "identity":
         return False
     if not all(m.training and m.track_running_stats for m in mods):

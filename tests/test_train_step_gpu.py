@@ -223,7 +223,8 @@ def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode,
             np.testing.assert_allclose(sd1[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=wtol, err_msg=k)
 
 
-def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode):
+@pytest.mark.parametrize("arch,idx", [("resnet18", 6), ("resnet56s", 13)])
+def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode, arch, idx):
     """The one-node BasicBlock (_BlockFn: fused dgrad epilogues, in-kernel gradient accumulation) against the per-op
     autograd path on the same bf16 kernels.  K = 0 isolates the joint forward/backward (no sign() amplification):
     gradients agree at bf16 level; K = 3 compares the losses and the BN side effects of a full step."""
@@ -232,9 +233,9 @@ def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode):
         for fused in (False, True):
             pkg.resnet_s._Flags.block_fusion = fused
             try:
-                model = _build(pkg, orc, "resnet18", gpu, dtype=torch.bfloat16)
+                model = _build(pkg, orc, arch, gpu, dtype=torch.bfloat16)
                 model.set_channels_last(True)
-                tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=6,
+                tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=idx,
                                                 lr=0.1, use_graph=False)
                 torch.manual_seed(0)
                 x, y = torch.rand(32, 3, 32, 32, device=gpu), torch.randint(0, 10, (32,), device=gpu)
