@@ -12,6 +12,8 @@ CASES = [  # n, ci, co, h, k, stride
     (2, 256, 512, 8, 1, 2), (1, 64, 64, 7, 3, 1), (2, 64, 64, 9, 3, 2), (1, 128, 64, 5, 1, 1), (64, 128, 128, 16, 3, 1),
     # the weights-in-registers kernel (afan_conv_c64.hip): W in {32, 16, 8, 4}, one and several tiles per workgroup
     (1, 64, 64, 32, 3, 1), (3, 64, 64, 16, 3, 1), (5, 64, 64, 8, 3, 1), (32, 64, 64, 4, 3, 1), (160, 64, 64, 32, 3, 1),
+    # the halo kernel (afan_conv_halo.hip): 256-, 128- and 64-row tiles, one and several images per tile
+    (256, 128, 128, 16, 3, 1), (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1), (8, 128, 256, 16, 3, 1), (6, 256, 128, 8, 3, 1),
     # the small-channel kernel (afan_conv_small.hip): the reference's 16-32-64-channel CIFAR ResNets
     (4, 16, 16, 32, 3, 1), (3, 16, 32, 32, 3, 2), (5, 32, 32, 16, 3, 1), (2, 32, 64, 16, 3, 2), (1, 16, 16, 7, 3, 1),
     (2, 32, 64, 9, 3, 2), (130, 16, 16, 32, 3, 1), (2, 64, 32, 8, 3, 1), (2, 16, 32, 8, 1, 2),
@@ -69,7 +71,8 @@ def test_conv_rejects_unsupported(pkg, gpu):
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 256, 512, 8, 1, 2),
                                                  (64, 128, 128, 16, 3, 1), (1, 64, 64, 7, 3, 1),
-                                                 (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1)])   # tall / deep tiles
+                                                 (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1),    # halo kernel
+                                                 (256, 128, 128, 16, 3, 1)])
 def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     """conv (+ epilogue moment partials) -> BN(train) must equal conv -> stand-alone BN on the stored bf16 tensor."""
     torch.manual_seed(ci + co + h)
@@ -121,7 +124,8 @@ def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 128, 256, 16, 1, 2),
-                                                 (64, 128, 128, 16, 3, 1), (3, 256, 512, 9, 3, 2)])
+                                                 (64, 128, 128, 16, 3, 1), (3, 256, 512, 9, 3, 2),
+                                                 (256, 128, 128, 16, 3, 1), (128, 256, 256, 8, 3, 1)])     # halo kernel
 def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     """dgrad + addend == dgrad then add; dgrad's fused BN-backward partials == the stand-alone reduction pass."""
     torch.manual_seed(ci + co + h + k)
