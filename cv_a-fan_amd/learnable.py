@@ -44,7 +44,8 @@ class LearnableTrainer:
     """Owns the backbone arena + SGD (sequential_model parameters only, :82-84) and the optimizer of `w` (:86-90)."""
 
     def __init__(self, model, criterion, *, steps=3, gamma=1.0, eps=2.0, idx_list=LEARNABLE_IDX, layer_number=None,
-                 randinit=False, clip=False, lr=0.1, w_lr=0.01, l1_coef=1.0, momentum=0.9, weight_decay=5e-4):
+                 randinit=False, clip=False, lr=0.1, w_lr=0.01, l1_coef=1.0, momentum=0.9, weight_decay=5e-4,
+                 use_graph=True, graph_warmup=3):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.idx_list = tuple(idx_list)
@@ -56,8 +57,53 @@ class LearnableTrainer:
         self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay)
         self.optimizer_w = torch.optim.SGD([{"params": model.w, "lr": w_lr, "weight_decay": 0}], w_lr,
                                            momentum=momentum, weight_decay=0)
+        # hipGraph replay of the whole iteration (~2 500 launches on ResNet-56s), as AfanTrainer does; randinit draws on
+        # the host generator every step and therefore stays eager
+        self.use_graph = bool(use_graph) and not randinit
+        self.graph_warmup = graph_warmup
+        self._graph = self._graph_failed = self._static = self._out = self._key = None
+        self._eager_steps = 0
 
     def step(self, inp, target):
+        """One iteration; returns device tensors (loss, loss_clean, loss_adv, l1, l2[9,N], linf[9,N], prec1, w)."""
+        key = (tuple(inp.shape), inp.dtype, tuple(target.shape))
+        if self._graph is not None and self._key == key:
+            return self._replay(inp, target)
+        if (self.use_graph and self._graph is None and self._graph_failed is None and inp.is_cuda
+                and self._eager_steps >= self.graph_warmup and self.model.training):
+            try:
+                self._capture(inp, target, key)
+                return self._replay(inp, target)
+            except Exception as e:  # noqa: BLE001 — stay correct: fall back to eager launches, loudly
+                import warnings
+                self._graph, self._graph_failed = None, e
+                warnings.warn(f"hipGraph capture of the learnable A-FAN step failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize()
+        self._eager_steps += 1
+        self.optimizer._sync_lr()
+        return self._body(inp, target)
+
+    def _capture(self, inp, target, key):
+        dev = inp.device
+        self._static = (torch.empty_like(inp), torch.empty_like(target))
+        self._static[0].copy_(inp)
+        self._static[1].copy_(target)
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            out = self._body(self._static[0], self._static[1])
+        self._graph, self._out, self._key = g, out, key
+
+    def _replay(self, inp, target):
+        self._static[0].copy_(inp, non_blocking=True)
+        self._static[1].copy_(target, non_blocking=True)
+        self.optimizer._sync_lr()          # lr lives in device memory: the graph reads it, the host only writes it here
+        self._graph.replay()
+        return {k: v.clone() for k, v in self._out.items() if k != "out_clean"} | {"out_clean": self._out["out_clean"]}
+
+    def _body(self, inp, target):
         m, ln = self.model, self.layer_number
         if inp.is_cuda:
             ops.acc_reset(inp.device)
@@ -91,7 +137,7 @@ class LearnableTrainer:
         self.optimizer.step()
         self.optimizer_w.step()
         with torch.no_grad():
-            m.w.data = sum_project(m.w.data, K=len(self.idx_list))
+            m.w.data.copy_(sum_project(m.w.data, K=len(self.idx_list)))   # in place (same values): graph-capturable
         prec1 = (out_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
         return {"loss": loss.detach(), "loss_clean": loss_clean.detach(), "loss_adv": loss_adv.detach(),
                 "l1": l1.detach(), "l2": torch.stack(l2s), "linf": torch.stack(linfs), "prec1": prec1,

@@ -83,3 +83,30 @@ def test_learnable_step_bf16_runs_and_tracks_fp32(pkg, orc, gpu):
     assert abs(float(r["loss"]) - float(g["loss"])) < 0.15                      # bf16 backbone on a batch of 4
     np.testing.assert_allclose(model.w.detach().cpu().numpy(), g["w1"], atol=2e-4)
     assert torch.isfinite(r["l2"]).all() and abs(float(model.w.detach().sum()) - 1.0) < 1e-6
+
+
+def test_learnable_step_graph_replay_tracks_eager(pkg, orc, gpu):
+    """After the warm-up iterations the whole learnable step is replayed from a hipGraph: same trajectory as eager
+    launches (bf16, loose), `w` still on the simplex, BatchNorm side effects counted."""
+    g = golden("learn_r56s_k1")
+    runs = {}
+    for use_graph in (False, True):
+        torch.manual_seed(3)
+        ref = orc.resnet56s(init_weight_eta=1 / 9)
+        model = pkg.resnet_s.resnet56(init_weight_eta=1 / 9)
+        model.load_state_dict(ref.state_dict())
+        model.set_compute_dtype(torch.bfloat16).to(gpu)
+        model.set_channels_last(True)
+        model.train()
+        tr = pkg.learnable.LearnableTrainer(model, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, layer_number=34,
+                                            lr=0.01, use_graph=use_graph, graph_warmup=2)
+        torch.manual_seed(0)
+        x, y = torch.rand(32, 3, 32, 32, device=gpu), torch.randint(0, 10, (32,), device=gpu)
+        losses = [float(tr.step(x, y)["loss"]) for _ in range(5)]
+        assert (tr._graph is not None) == use_graph and tr._graph_failed is None
+        runs[use_graph] = (losses, model.w.detach().cpu().numpy().copy(),
+                           int(model.state_dict()["sequential_model.2.num_batches_tracked"]))
+    a, b = runs[False], runs[True]
+    np.testing.assert_allclose(b[0], a[0], rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(b[1], a[1], atol=2e-3)
+    assert abs(float(b[1].sum()) - 1.0) < 1e-5 and a[2] == b[2] == 50
