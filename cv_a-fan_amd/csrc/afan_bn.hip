@@ -28,10 +28,10 @@ int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void*
 int64_t workspace_floats(int64_t c);
 int fwd_acc(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom,
             const float* w, const float* b, int relu, double* acc, int acc_ready, float* stats, float* rm, float* rv,
-            int64_t* nbt, hipStream_t st);
+            int64_t* nbt, hipStream_t st, int groups);
 int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
             const float* stats_in, int relu, double* acc, int acc_ready, float* dw, float* db, int accumulate,
-            hipStream_t st);
+            hipStream_t st, int groups);
 int acc_supported(int dtype, int64_t C);
 int64_t acc_doubles(int64_t C);
 }
@@ -597,7 +597,7 @@ int afan_bn_acc_supported(int dtype, int64_t c) {
 int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias, int relu,
                               double* acc, int acc_ready, float* save_stats, float* running_mean, float* running_var,
-                              int64_t* num_batches, afan_stream_t stream) {
+                              int64_t* num_batches, int groups, afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
     if (!x || !y || !acc || !save_stats) return AFAN_ENULL;
@@ -605,13 +605,15 @@ int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int 
     if (!afan_nhwc::acc_supported(dtype, c)) return AFAN_ESHAPE;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(x, a) || !aligned(y, a) || (residual && !aligned(residual, a)) || !aligned(acc, 16)) return AFAN_EALIGN;
-    return afan_nhwc::fwd_acc(dtype, x, residual, y, n * hw, c, eps, momentum, weight, bias, relu, acc, acc_ready,
-                              save_stats, running_mean, running_var, num_batches, (hipStream_t)stream);
+    if (groups < 1 || n % groups != 0) return AFAN_ESHAPE;
+    return afan_nhwc::fwd_acc(dtype, x, residual, y, (n / groups) * hw, c, eps, momentum, weight, bias, relu, acc, acc_ready,
+                              save_stats, running_mean, running_var, num_batches, (hipStream_t)stream, groups);
 }
 
 int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
                          int64_t n, int64_t c, int64_t hw, const float* save_stats, int relu, double* acc,
-                         int acc_ready, float* dweight, float* dbias, int accumulate, afan_stream_t stream) {
+                         int acc_ready, float* dweight, float* dbias, int accumulate, int groups,
+                         afan_stream_t stream) {
     int e = check_common(dtype, n, c, hw);
     if (e) return e;
     if (!dy || !x || !dx || !save_stats || !acc) return AFAN_ENULL;
@@ -620,8 +622,9 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
     if (!aligned(dy, a) || !aligned(x, a) || !aligned(dx, a) || (y && !aligned(y, a)) ||
         (d_residual && !aligned(d_residual, a)) || !aligned(acc, 16))
         return AFAN_EALIGN;
-    return afan_nhwc::bwd_acc(dtype, dy, x, y, dx, d_residual, n * hw, c, save_stats, relu, acc, acc_ready, dweight, dbias,
-                              accumulate, (hipStream_t)stream);
+    if (groups < 1 || n % groups != 0) return AFAN_ESHAPE;
+    return afan_nhwc::bwd_acc(dtype, dy, x, y, dx, d_residual, (n / groups) * hw, c, save_stats, relu, acc, acc_ready, dweight,
+                              dbias, accumulate, (hipStream_t)stream, groups);
 }
 
 int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, int64_t n, int64_t c, int64_t hw,

@@ -99,6 +99,8 @@ __host__ __device__ inline int acc_slots(int64_t C) {   // NS * C <= 1024, 1 <= 
     return ns;
 }
 
+int64_t acc_doubles(int64_t C);   // doubles per accumulator block (defined with the entry points below)
+
 template <int VEC, int NQ>
 __device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV, int C, int NS,
                                                   double* __restrict__ out) {
@@ -412,38 +414,67 @@ __device__ __forceinline__ void fold_slots(const double* __restrict__ acc, int C
 // coalesced f64 loads), parks them in LDS, and its threads pick up their own VEC channels from there; block 0 also
 // publishes stats[4][C] for the backward and updates the running statistics.  `shift` is never the live running_mean
 // buffer (the producing convolution snapshots it behind the accumulators), so that in-place update races with nothing.
-template <typename T, int VEC, bool RES, bool RELU>
+template <typename T, int VEC, bool RES, bool RELU, bool GROUPED>
 __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                           T* __restrict__ y, int64_t nvec, int CV, int C, int NS,
                                                           const double* __restrict__ acc,
                                                           const float* __restrict__ shift, double inv_m, float unbias,
                                                           float eps, float momentum, const float* __restrict__ weight,
                                                           const float* __restrict__ bias, float* __restrict__ stats,
-                                                          float* rmean, float* rvar, int64_t* nbt) {
+                                                          float* rmean, float* rvar, int64_t* nbt, int shift_in_acc,
+                                                          int64_t acc_stride) {
+    // gridDim.y = image groups (half-batches with separate statistics): group g owns rows [g*nvec, (g+1)*nvec) vectors,
+    // accumulator block acc + g*acc_stride and stats + g*4*C.  The running statistics see the groups as consecutive
+    // forward passes: block (0, 0) alone applies all the updates, in group order.
     extern __shared__ __attribute__((aligned(16))) float coef[];   // [2][C]: alpha | beta
+    // (GROUPED is a template flag so that the ordinary launch carries none of the multi-group code)
+    const int grp = GROUPED ? blockIdx.y : 0, G = GROUPED ? gridDim.y : 1;
+    x += (int64_t)grp * nvec * VEC;
+    y += (int64_t)grp * nvec * VEC;
+    if (RES) res += (int64_t)grp * nvec * VEC;
+    const double* acc_g = acc + (int64_t)grp * acc_stride;
+    float* stats_g = stats + (int64_t)grp * 4 * C;
     for (int c = threadIdx.x; c < C; c += BLOCK) {
+        const float wv = weight ? weight[c] : 1.f, bv = bias ? bias[c] : 0.f;
         double a, b;
-        fold_slots(acc, C, NS, c, a, b);
-        const float sh = shift ? shift[c] : Elt<T>::ld(x + c);
+        fold_slots(acc_g, C, NS, c, a, b);
+        const float sh = shift_in_acc ? reinterpret_cast<const float*>(acc_g + (int64_t)2 * NS * C)[c]
+                                      : (shift ? shift[c] : Elt<T>::ld(x + c));
         const double dm = a * inv_m;
         const double m2 = fmax(b - a * dm, 0.0);
         const float mean = sh + (float)dm;
         const float varb = (float)(m2 * inv_m);
         const float is = 1.0f / sqrtf(varb + eps);
         float alpha, beta;
-        affine_coeffs(mean, is, weight ? weight[c] : 1.f, bias ? bias[c] : 0.f, alpha, beta);
+        affine_coeffs(mean, is, wv, bv, alpha, beta);
         coef[c] = alpha;
         coef[C + c] = beta;
         if (blockIdx.x == 0) {
-            stats[c] = mean;
-            stats[C + c] = is;
-            stats[2 * C + c] = alpha;
-            stats[3 * C + c] = beta;
-            if (rmean) {
-                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
-                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
+            stats_g[c] = mean;
+            stats_g[C + c] = is;
+            stats_g[2 * C + c] = alpha;
+            stats_g[3 * C + c] = beta;
+            if (grp == 0) {
+                if (rmean) {
+                    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
+                }
+                if (c == 0 && nbt) *nbt += G;
+                // the later groups' running-stat updates, in order
+                if constexpr (GROUPED) for (int gg = 1; gg < G; ++gg) {
+                    const double* ag = acc + (int64_t)gg * acc_stride;
+                    double a2, b2;
+                    fold_slots(ag, C, NS, c, a2, b2);
+                    const float sh2 = reinterpret_cast<const float*>(ag + (int64_t)2 * NS * C)[c];
+                    const double dm2 = a2 * inv_m;
+                    const float mean2 = sh2 + (float)dm2;
+                    const float var2 = (float)(fmax(b2 - a2 * dm2, 0.0) * inv_m);
+                    if (rmean) {
+                        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean2;
+                        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (var2 * unbias);
+                    }
+                }
             }
-            if (c == 0 && nbt) *nbt += 1;
         }
     }
     __syncthreads();
@@ -470,28 +501,45 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
 
 // backward: acc[slot][0][c] = sum g, acc[slot][1][c] = sum g*(x - mean) (f64) -> B, D per channel, same block-level
 // prologue; block 0 writes dweight / dbias.
-template <typename T, int VEC, bool RELU, bool HAVE_Y, bool DRES>
+template <typename T, int VEC, bool RELU, bool HAVE_Y, bool DRES, bool GROUPED>
 __global__ __launch_bounds__(BLOCK) void bwd_apply_acc_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                               const T* __restrict__ y, T* __restrict__ dx,
                                                               T* __restrict__ dres, int64_t nvec, int CV, int C, int NS,
                                                               const float* __restrict__ stats,
                                                               const double* __restrict__ acc, double inv_m,
-                                                              float* dweight, float* dbias, int accumulate) {
+                                                              float* dweight, float* dbias, int accumulate,
+                                                              int64_t acc_stride) {
+    // gridDim.y = image groups, as in apply_acc_kernel; block (0, 0) alone adds every group's sums to dweight / dbias
     extern __shared__ __attribute__((aligned(16))) float coef[];   // [2][C]: B | D
+    const int grp = GROUPED ? blockIdx.y : 0, G = GROUPED ? gridDim.y : 1;
+    dy += (int64_t)grp * nvec * VEC;
+    x += (int64_t)grp * nvec * VEC;
+    dx += (int64_t)grp * nvec * VEC;
+    if (RELU && HAVE_Y) y += (int64_t)grp * nvec * VEC;
+    if (DRES) dres += (int64_t)grp * nvec * VEC;
+    const double* acc_g = acc + (int64_t)grp * acc_stride;
+    const float* stats_g = stats + (int64_t)grp * 4 * C;
     for (int c = threadIdx.x; c < C; c += BLOCK) {
         double a, b;
-        fold_slots(acc, C, NS, c, a, b);
-        const float is = stats[C + c], alpha = stats[2 * C + c];
-        const float sum_g = (float)a;
-        const float sum_gx = (float)b * is;
+        fold_slots(acc_g, C, NS, c, a, b);
+        const float is = stats_g[C + c], alpha = stats_g[2 * C + c];
+        float sum_g = (float)a;
+        float sum_gx = (float)b * is;
         coef[c] = -alpha * is * (float)((double)sum_gx * inv_m);
         coef[C + c] = -alpha * (float)((double)sum_g * inv_m);
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && grp == 0) {
+            if constexpr (GROUPED) for (int gg = 1; gg < G; ++gg) {        // the other groups' sums for dweight / dbias
+                double a2, b2;
+                fold_slots(acc + (int64_t)gg * acc_stride, C, NS, c, a2, b2);
+                sum_g += (float)a2;
+                sum_gx += (float)b2 * stats[(int64_t)gg * 4 * C + C + c];
+            }
             if (dbias) dbias[c] = accumulate ? dbias[c] + sum_g : sum_g;
             if (dweight) dweight[c] = accumulate ? dweight[c] + sum_gx : sum_gx;
         }
     }
     __syncthreads();
+    stats += (int64_t)grp * 4 * C;
     const int c0 = (threadIdx.x % CV) * VEC;
     float mu[VEC], alpha[VEC], beta[VEC], B[VEC], D[VEC];
     ld_coef<VEC>(stats, c0, mu);
@@ -675,7 +723,9 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
 template <typename T>
 int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float momentum,
                 const float* weight, const float* bias, int relu, double* acc, int acc_ready, float* stats,
-                float* rmean, float* rvar, int64_t* nbt, hipStream_t st) {
+                float* rmean, float* rvar, int64_t* nbt, hipStream_t st, int groups = 1) {
+    // M: rows per group; groups > 1 needs accumulators that a convolution epilogue already filled
+    if (groups < 1 || (groups > 1 && !acc_ready)) return AFAN_ESHAPE;
     Plan p;
     if (!make_plan<T>(M, C, {x, res, y}, p)) return AFAN_ESHAPE;
     if (!p.vec || !aligned(stats, 16) || !aligned(acc, 16)) return AFAN_ESHAPE;
@@ -691,15 +741,18 @@ int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, f
     const size_t lds = (size_t)2 * C * sizeof(float);
     const double inv_m = 1.0 / (double)M;
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
-    AFAN_PROF("bn_nhwc_apply_kernel", p.tensor_bytes * (res ? 3 : 2), st);
-    const int grid = apply_grid(p, M * C);
-#define AFAN_GO(RES, RELU)                                                                                        \
-    apply_acc_kernel<T, NV, RES, RELU><<<grid, BLOCK, lds, st>>>(x_, r_, y_, p.nvec, p.CV, (int)C, NS, acc, shift, inv_m, \
-                                                               unbias, eps, momentum, weight, bias, stats, rmean,  \
-                                                               rvar, nbt)
+    AFAN_PROF("bn_nhwc_apply_kernel", p.tensor_bytes * (res ? 3 : 2) * groups, st);
+    const dim3 grid((unsigned)apply_grid(p, M * C), (unsigned)groups);
+    const int64_t acc_stride = (acc_doubles(C) + 1) & ~(int64_t)1;
+#define AFAN_GO1(RES, RELU, GR)                                                                                   \
+    apply_acc_kernel<T, NV, RES, RELU, GR><<<grid, BLOCK, lds, st>>>(x_, r_, y_, p.nvec, p.CV, (int)C, NS, acc, shift,   \
+                                                                   inv_m, unbias, eps, momentum, weight, bias, stats,  \
+                                                                   rmean, rvar, nbt, acc_ready, acc_stride)
+#define AFAN_GO(RES, RELU) do { if (groups > 1) AFAN_GO1(RES, RELU, true); else AFAN_GO1(RES, RELU, false); } while (0)
     if (res) { if (relu) AFAN_GO(true, true); else AFAN_GO(true, false); }
     else { if (relu) AFAN_GO(false, true); else AFAN_GO(false, false); }
 #undef AFAN_GO
+#undef AFAN_GO1
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -707,7 +760,8 @@ int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, f
 template <typename T>
 int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
                  const float* stats, int relu, double* acc, int acc_ready, float* dweight, float* dbias,
-                 int accumulate, hipStream_t st) {
+                 int accumulate, hipStream_t st, int groups = 1) {
+    if (groups < 1 || (groups > 1 && !acc_ready)) return AFAN_ESHAPE;
     Plan p;
     if (!make_plan<T>(M, C, {dy, x, y, dx, dres}, p)) return AFAN_ESHAPE;
     if (!p.vec || !aligned(stats, 16) || !aligned(acc, 16)) return AFAN_ESHAPE;
@@ -723,18 +777,21 @@ int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d
 #undef AFAN_RED
         AFAN_LAUNCH_CHECK();
     }
-    const int grid = apply_grid(p, M * C);
+    const dim3 grid((unsigned)apply_grid(p, M * C), (unsigned)groups);
+    const int64_t acc_stride = (acc_doubles(C) + 1) & ~(int64_t)1;
     const double inv_m = 1.0 / (double)M;
     const int NS = acc_slots(C);
     const size_t lds = (size_t)2 * C * sizeof(float);
-    AFAN_PROF("bn_nhwc_bwd_apply_kernel", p.tensor_bytes * (3 + ((relu && y) ? 1 : 0) + (dres ? 1 : 0)), st);
-#define AFAN_APP(RELU, HY, DR)                                                                                    \
-    bwd_apply_acc_kernel<T, NV, RELU, HY, DR><<<grid, BLOCK, lds, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, p.nvec, p.CV, \
-                                                                        (int)C, NS, stats, acc, inv_m, dweight,     \
-                                                                        dbias, accumulate)
+    AFAN_PROF("bn_nhwc_bwd_apply_kernel", p.tensor_bytes * (3 + ((relu && y) ? 1 : 0) + (dres ? 1 : 0)) * groups, st);
+#define AFAN_APP1(RELU, HY, DR, GR)                                                                               \
+    bwd_apply_acc_kernel<T, NV, RELU, HY, DR, GR><<<grid, BLOCK, lds, st>>>(dy_, x_, y_, (T*)dx, (T*)dres, p.nvec, p.CV, \
+                                                                            (int)C, NS, stats, acc, inv_m, dweight, \
+                                                                            dbias, accumulate, acc_stride)
+#define AFAN_APP(RELU, HY, DR) do { if (groups > 1) AFAN_APP1(RELU, HY, DR, true); else AFAN_APP1(RELU, HY, DR, false); } while (0)
     if (!relu) { if (dres) AFAN_APP(false, false, true); else AFAN_APP(false, false, false); }
     else if (y) { if (dres) AFAN_APP(true, true, true); else AFAN_APP(true, true, false); }
     else { if (dres) AFAN_APP(true, false, true); else AFAN_APP(true, false, false); }
+#undef AFAN_APP1
 #undef AFAN_APP
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
@@ -742,15 +799,15 @@ int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d
 
 int fwd_acc(int dtype, const void* x, const void* res, void* y, int64_t M, int64_t C, float eps, float mom,
             const float* w, const float* b, int relu, double* acc, int acc_ready, float* stats, float* rm, float* rv,
-            int64_t* nbt, hipStream_t st) {
-    return dtype == AFAN_F32 ? forward_acc<float>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st)
-                             : forward_acc<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st);
+            int64_t* nbt, hipStream_t st, int groups) {
+    return dtype == AFAN_F32 ? forward_acc<float>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st, groups)
+                             : forward_acc<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st, groups);
 }
 int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
             const float* stats_in, int relu, double* acc, int acc_ready, float* dw, float* db, int accumulate,
-            hipStream_t st) {
-    return dtype == AFAN_F32 ? backward_acc<float>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st)
-                             : backward_acc<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st);
+            hipStream_t st, int groups) {
+    return dtype == AFAN_F32 ? backward_acc<float>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st, groups)
+                             : backward_acc<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, acc, acc_ready, dw, db, accumulate, st, groups);
 }
 int64_t acc_doubles(int64_t C) { return C > 0 ? (int64_t)2 * acc_slots(C) * C + (C + 1) / 2 : 0; }
 int acc_slot_count(int64_t C) { return acc_slots(C); }

@@ -316,10 +316,12 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num
 
 
 def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches,
-                     conv_stats=None, out=None, stats_out=None):
+                     conv_stats=None, out=None, stats_out=None, groups=1):
     """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward).
     conv_stats: ConvStats from the producing convolution -> the moments pass over x is skipped.
-    out / stats_out: write into these tensors (views of a batched buffer) instead of allocating."""
+    out / stats_out: write into these tensors (views of a batched buffer) instead of allocating.
+    groups = 2: x is two concatenated half-batches normalised separately in one launch (conv_stats from a grouped
+    convolution); stats is then [2, 4, C]."""
     lib = _lib.load()
     _need(x, "x")
     if x.dtype not in _DT:
@@ -332,7 +334,10 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
         _need(out, "out", x.dtype)
         _same_layout(x, out)
     y = out if out is not None else torch.empty_like(x)
-    stats = stats_out if stats_out is not None else torch.empty(4, c, dtype=torch.float32, device=x.device)
+    if groups != 1 and (conv_stats is None or conv_stats.acc is None):
+        raise ValueError("grouped BatchNorm needs the accumulators of a grouped convolution")
+    stats = stats_out if stats_out is not None else torch.empty((4, c) if groups == 1 else (groups, 4, c),
+                                                                dtype=torch.float32, device=x.device)
     acc = conv_stats.acc if conv_stats is not None else None
     ready = acc is not None
     if acc is None and conv_stats is None and bn_acc_ok(x):
@@ -343,7 +348,7 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
         check(lib.afan_bn_train_forward_acc(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, float(eps),
                                             float(momentum), _ptr(weight), _ptr(bias), int(bool(relu)), _ptr(acc),
                                             int(ready), _ptr(stats), _ptr(running_mean), _ptr(running_var),
-                                            _ptr(num_batches), _stream(x)), "afan_bn_train_forward_acc")
+                                            _ptr(num_batches), int(groups), _stream(x)), "afan_bn_train_forward_acc")
         return y, stats
     if conv_stats is not None:
         if layout_of(x) != AFAN_NHWC and not (x.shape[2] == 1 and x.shape[3] == 1):
@@ -378,7 +383,7 @@ def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
 
 
 def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False,
-                partials=None, dx_out=None, dres_out=None):
+                partials=None, dx_out=None, dres_out=None, groups=1):
     """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given.
     partials: ConvStats written by the dgrad that produced dy (conv_dgrad(..., bn_bwd=...)): skips the reduction pass."""
     lib = _lib.load()
@@ -395,10 +400,12 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     # atomics would arrive as one burst and serialise per address (measured 2x slower); a dgrad epilogue spreads them
     acc = partials.acc if partials is not None else None
     ready = acc is not None
+    if groups != 1 and acc is None:
+        raise ValueError("grouped BatchNorm backward needs the accumulators of a grouped dgrad")
     if acc is not None:
         check(lib.afan_bn_backward_acc(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
                                        _ptr(stats), int(bool(relu)), _ptr(acc), int(ready), _ptr(dweight), _ptr(dbias),
-                                       int(bool(accumulate)), _stream(x)), "afan_bn_backward_acc")
+                                       int(bool(accumulate)), int(groups), _stream(x)), "afan_bn_backward_acc")
         return dx, dres
     ws = _workspace(x, lib.afan_bn_workspace_floats(c), "bn")
     check(lib.afan_bn_backward(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], layout_of(x), n, c, hw,

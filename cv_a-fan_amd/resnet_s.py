@@ -64,9 +64,9 @@ def bn_groups(g):
 
 def _bn_fwd_g(raw, b, res, relu, st, G, mom):
     """BatchNorm forward of one layer over G half-batches (G = 1: the plain call)."""
-    if G == 1:
+    if G == 1 or st.acc is not None:     # one launch: the kernel walks the groups (statistics per half, updates in order)
         return ops.bn_train_forward(raw, b.weight, b.bias, res, relu, b.eps, mom, b.running_mean, b.running_var,
-                                    b.num_batches_tracked, st)
+                                    b.num_batches_tracked, st, groups=G)
     c, n = raw.shape[1], raw.shape[0] // G
     y = torch.empty_like(raw)
     stats = torch.empty(G, 4, c, dtype=torch.float32, device=raw.device)
@@ -80,8 +80,8 @@ def _bn_fwd_g(raw, b, res, relu, st, G, mom):
 
 def _bn_bwd_g(dy, raw, y, stats, b, relu, want_dres, pg, part, G):
     gw, gb = (b.weight.grad, b.bias.grad) if pg else (None, None)
-    if G == 1:
-        return ops.bn_backward(dy, raw, y, stats, b.weight, b.bias, relu, want_dres, gw, gb, pg, partials=part)
+    if G == 1 or (part is not None and part.acc is not None):
+        return ops.bn_backward(dy, raw, y, stats, b.weight, b.bias, relu, want_dres, gw, gb, pg, partials=part, groups=G)
     c, n = raw.shape[1], raw.shape[0] // G
     dx = torch.empty_like(raw)
     dres = torch.empty_like(raw) if want_dres else None

@@ -186,10 +186,14 @@ int afan_bn_acc_supported(int dtype, int64_t c);
 int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias,
                               int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,
-                              float* running_var, int64_t* num_batches, afan_stream_t stream);
+                              float* running_var, int64_t* num_batches, int groups, afan_stream_t stream);
 int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
                          int64_t n, int64_t c, int64_t hw, const float* save_stats, int relu, double* acc,
-                         int acc_ready, float* dweight, float* dbias, int accumulate, afan_stream_t stream);
+                         int acc_ready, float* dweight, float* dbias, int accumulate, int groups,
+                         afan_stream_t stream);
+/* groups = 2 (acc_ready only): x is two concatenated half-batches (n/2 images each) normalised separately in ONE launch:
+ * acc holds one accumulator block per half (stride afan_bn_acc_doubles(c) rounded up to even), save_stats is [2][4*c],
+ * the running statistics receive the two updates in order (first half, then second), dweight/dbias the sum. */
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside

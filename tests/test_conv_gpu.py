@@ -194,6 +194,18 @@ def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, s
         assert_close(o_grp.float().cpu().numpy(), o_ref.float().cpu().numpy(), rtol=1e-2, atol=1e-2)
         outs.append(o_ref)
         stats.append(s_ref)
+    # ONE BatchNorm launch over both halves (gridDim.y = groups): per-half statistics, running stats updated half by half
+    rm1, rv1, nb1 = shift.clone(), torch.ones(co, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu)
+    o_all, s_all = ops.bn_train_forward(y, gamma, beta, None, True, 1e-5, 0.1, rm1, rv1, nb1, st, groups=2)
+    rm2, rv2, nb2 = shift.clone(), torch.ones(co, device=gpu), torch.zeros((), dtype=torch.int64, device=gpu)
+    for g in range(2):
+        o_h, s_h = ops.bn_train_forward(y[g * hb:(g + 1) * hb], gamma, beta, None, True, 1e-5, 0.1, rm2, rv2, nb2,
+                                        st.group(g, co))
+        np.testing.assert_array_equal(s_all[g].cpu().numpy(), s_h.cpu().numpy())
+        assert torch.equal(o_all[g * hb:(g + 1) * hb], o_h)
+    np.testing.assert_allclose(rm1.cpu().numpy(), rm2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv1.cpu().numpy(), rv2.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert int(nb1) == int(nb2) == 2
     # dgrad with the BN-backward sums of a BatchNorm over dx's tensor (ci channels), per group
     ho = y.shape[2]
     dy = _cl(torch.randn(n, co, ho, ho, device=gpu).bfloat16())
@@ -215,6 +227,15 @@ def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, s
         scale = max(1.0, float(np.abs(res[0][1]).max()))
         np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5 * scale)
         np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-2, atol=1e-3 * max(1.0, float(np.abs(res[0][0]).max())))
+    # one grouped BatchNorm-backward launch against the two per-half launches
+    dwb_a, dwb_b = torch.zeros(2, ci, device=gpu), torch.zeros(2, ci, device=gpu)
+    d_all, _ = ops.bn_backward(dx, bn_x, None, st2, g2, b2, True, False, dwb_a[0], dwb_a[1], True, partials=part, groups=2)
+    for g in range(2):
+        sl = slice(g * hb, (g + 1) * hb)
+        d_h, _ = ops.bn_backward(dx[sl], bn_x[sl], None, st2[g], g2, b2, True, False, dwb_b[0], dwb_b[1], True,
+                                 partials=part.group(g, ci))
+        assert torch.equal(d_all[sl], d_h)
+    np.testing.assert_allclose(dwb_a.cpu().numpy(), dwb_b.cpu().numpy(), rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(8, 16, 16, 32, 3, 1), (6, 16, 32, 32, 3, 2), (8, 32, 32, 16, 3, 1),

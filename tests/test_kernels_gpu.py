@@ -381,7 +381,7 @@ def test_bn_backward_acc_self_reducing_matches_slab_path(pkg, gpu, shape):
     dx1, dwb1 = torch.empty_like(x), torch.ones(2, c, device=gpu)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     rc = lib.afan_bn_backward_acc(P(dy), P(x), None, P(dx1), None, pkg._lib.AFAN_BF16, shape[0], c, shape[2] * shape[3],
-                                  P(stats), 1, P(acc), 0, P(dwb1[0]), P(dwb1[1]), 1,
+                                  P(stats), 1, P(acc), 0, P(dwb1[0]), P(dwb1[1]), 1, 1,
                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     scale = max(1.0, float(dwb0.abs().max()))
