@@ -49,3 +49,31 @@ def test_run_perturb_entry_point(tmp_path, orc):
     assert abs(float(norms["linf"][1]) - 2 * 0.5 / 255) < 1e-4        # K=2 unclipped steps of gamma = 0.5/255
     out2 = _run(common + ["--epochs", "3", "--resume"], cwd)
     assert "resume from checkpoint" in out2 and "Epoch: [2][" in out2 and "Epoch: [1][" not in out2
+
+
+def test_main_learnable_entry_point(tmp_path, orc):
+    """main_learnable.py end to end (synthetic data): the reference's stdout lines (weightK = ..., two learning rates,
+    Epoch/Loss/Accuracy, l2/linf means), checkpoint keys incl. `optimizer_w`, `w` on the simplex, --resume."""
+    cwd = os.path.join(ROOT, "cv_a-fan_amd")
+    save = str(tmp_path / "learn")
+    env = dict(os.environ, PYTHONUNBUFFERED="1")
+    common = ["--seed", "3", "--save_dir", save, "--synthetic", "256", "--batch_size", "64", "--print_freq", "1",
+              "--steps", "1", "--gamma", "0.5"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, "-u", "main_learnable.py"] + common + extra, cwd=cwd, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        return r.stdout
+
+    out = run(["--epochs", "1"])
+    assert "weight1 = " in out and "weight9 = " in out and "Epoch: [0][0/4]\tLoss" in out
+    assert "l2 mean = " in out and "linf mean = " in out and "valid_accuracy" in out
+    ck = torch.load(os.path.join(save, "checkpoint.pt"), map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "state_dict", "best_prec1", "optimizer", "optimizer_w", "scheduler"} and ck["epoch"] == 1
+    w = ck["state_dict"]["w"]
+    assert w.shape == (9,) and abs(float(w.sum()) - 1.0) < 1e-5
+    ref = orc.resnet56s(init_weight_eta=1 / 9)
+    ref.load_state_dict(ck["state_dict"])                      # reference layout (335 tensors incl. w, mean, std)
+    out = run(["--epochs", "2", "--resume"])
+    assert "resume from checkpoint" in out and "Epoch: [1][0/4]" in out and "Epoch: [0][" not in out
