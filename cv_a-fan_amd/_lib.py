@@ -27,6 +27,7 @@ SIGNATURES = {
     "afan_perturb_norms": (_i, [_p, _p, _l, _l, _p, _p, _p, _p]),
     "afan_axpy_noise": (_i, [_p, _p, _l, _f, _p, _p]),
     "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
+    "afan_mix_feature_nhwc": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
     "afan_mix_w_workspace_floats": (_l, []),
     "afan_mix_w": (_i, [_p, _p, _p, _p, _i, _l, _p]),

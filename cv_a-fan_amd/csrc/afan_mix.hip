@@ -84,6 +84,71 @@ __global__ __launch_bounds__(BLOCK) void mix_feature_kernel(const T* __restrict_
     }
 }
 
+// Channels-last variant: a pixel's C channels are contiguous, so ONE WAVE owns one pixel: lanes stride over the
+// channels (coalesced 2/4-byte accesses; 16-byte vectors when C % (64 * VEC) == 0), the clean values of the lane stay in
+// registers between the two passes (C <= 64 * KEEP) or are re-read, moments merge across lanes by butterfly (Chan).
+template <typename T, int KEEP>
+__global__ __launch_bounds__(BLOCK) void mix_feature_nhwc_kernel(const T* __restrict__ clean, const T* __restrict__ adv,
+                                                                 T* __restrict__ out, int C, int64_t pixels, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (BLOCK / AFAN_WAVE);
+    for (int64_t p = wave0; p < pixels; p += nwaves) {
+        const T* pc = clean + p * C;
+        const T* pa = adv + p * C;
+        float keep[KEEP];
+        float sh_c = 0.f, s_c = 0.f, q_c = 0.f, sh_a = 0.f, s_a = 0.f, q_a = 0.f, cnt = 0.f;
+        bool first = true;
+        int k = 0;
+        for (int c = lane; c < C; c += AFAN_WAVE, ++k) {
+            const float vc = Elt<T>::ld(pc + c), va = Elt<T>::ld(pa + c);
+            if (k < KEEP) keep[k] = vc;
+            if (first) { sh_c = vc; sh_a = va; first = false; }
+            const float dc = vc - sh_c, da = va - sh_a;
+            s_c += dc; q_c += dc * dc;
+            s_a += da; q_a += da * da;
+            cnt += 1.f;
+        }
+        Moments mc{cnt, 0.f, 0.f}, ma{cnt, 0.f, 0.f};
+        if (cnt > 0.f) {
+            const float dmc = s_c / cnt, dma = s_a / cnt;
+            mc.mean = sh_c + dmc; mc.m2 = fmaxf(q_c - s_c * dmc, 0.f);
+            ma.mean = sh_a + dma; ma.m2 = fmaxf(q_a - s_a * dma, 0.f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            Moments oc{__shfl_xor(mc.n, o, 64), __shfl_xor(mc.mean, o, 64), __shfl_xor(mc.m2, o, 64)};
+            Moments oa{__shfl_xor(ma.n, o, 64), __shfl_xor(ma.mean, o, 64), __shfl_xor(ma.m2, o, 64)};
+            // merge in a lane-symmetric order so that every lane ends with the same bits
+            const bool lo = (lane & o) == 0;
+            mc = lo ? merge(mc, oc) : merge(oc, mc);
+            ma = lo ? merge(ma, oa) : merge(oa, ma);
+        }
+        const float denom = (float)C - 1.0f;
+        const float mean_c = mc.mean, std_c = sqrtf(mc.m2 / denom + eps);
+        const float mean_a = ma.mean, std_a = sqrtf(ma.m2 / denom + eps);
+        T* po = out + p * C;
+        k = 0;
+        for (int c = lane; c < C; c += AFAN_WAVE, ++k) {
+            const float vc = k < KEEP ? keep[k] : Elt<T>::ld(pc + c);
+            float t = (vc - mean_c) / std_c;
+            t = t * std_a;
+            t = t + mean_a;
+            Elt<T>::st(po + c, t);
+        }
+    }
+}
+
+template <typename T>
+int mix_nhwc_impl(const void* clean, const void* adv, void* out, int64_t pixels, int64_t c, float eps, hipStream_t st) {
+    const int grid = grid_for(pixels * AFAN_WAVE, BLOCK, 8192);
+    AFAN_PROF("mix_feature_kernel", 3.0 * sizeof(T) * pixels * c, st);
+    if (c <= 64 * 8) mix_feature_nhwc_kernel<T, 8><<<grid, BLOCK, 0, st>>>((const T*)clean, (const T*)adv, (T*)out, (int)c, pixels, eps);
+    else mix_feature_nhwc_kernel<T, 20><<<grid, BLOCK, 0, st>>>((const T*)clean, (const T*)adv, (T*)out, (int)c, pixels, eps);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
 struct LerpW {
     float w[8];
 };
@@ -207,6 +272,18 @@ __global__ __launch_bounds__(AFAN_WAVE) void mix_w_dot_finalize_kernel(const flo
 constexpr int MIXW_MAX_BLOCKS = 1024;
 
 extern "C" {
+
+int afan_mix_feature_nhwc(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw, float eps,
+                          int dtype, afan_stream_t stream) {
+    if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n < 0 || c <= 0 || hw < 0 || c > 0x7fffffffLL) return AFAN_ESHAPE;
+    if (n == 0 || hw == 0) return AFAN_OK;
+    if (!clean || !adv || !out) return AFAN_ENULL;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(clean, a) || !aligned(adv, a) || !aligned(out, a)) return AFAN_EALIGN;
+    if (dtype == AFAN_F32) return mix_nhwc_impl<float>(clean, adv, out, n * hw, c, eps, (hipStream_t)stream);
+    return mix_nhwc_impl<uint16_t>(clean, adv, out, n * hw, c, eps, (hipStream_t)stream);
+}
 
 int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw,
                      float eps, int dtype, afan_stream_t stream) {

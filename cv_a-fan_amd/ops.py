@@ -242,12 +242,13 @@ def mix_feature(clean, adv, eps=1e-5):
     _need(adv, "adv", clean.dtype)
     if clean.dtype not in _DT or clean.shape != adv.shape:
         raise TypeError("clean/adv must be fp32 or bf16 tensors of the same shape")
-    if layout_of(clean) != AFAN_NCHW or layout_of(adv) != AFAN_NCHW:
-        clean, adv = clean.contiguous(), adv.contiguous()   # TODO(N1): channels-last mix_feature kernel
+    if layout_of(clean) != layout_of(adv):
+        adv = adv.contiguous(memory_format=torch.channels_last if layout_of(clean) == AFAN_NHWC else torch.contiguous_format)
     n, c, hw = _nchw(clean)
     out = torch.empty_like(clean)
-    check(lib.afan_mix_feature(_ptr(clean), _ptr(adv), _ptr(out), n, c, hw, float(eps), _DT[clean.dtype],
-                               _stream(clean)), "afan_mix_feature")
+    fn = lib.afan_mix_feature_nhwc if layout_of(clean) == AFAN_NHWC else lib.afan_mix_feature
+    check(fn(_ptr(clean), _ptr(adv), _ptr(out), n, c, hw, float(eps), _DT[clean.dtype], _stream(clean)),
+          "afan_mix_feature")
     return out
 
 

@@ -94,6 +94,10 @@ int afan_axpy_noise(float* x_adv, const float* u, int64_t n, float eps, uint16_t
  */
 int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw,
                      float eps, int dtype, afan_stream_t stream);
+/* The same transform for channels-last tensors ([N,H,W,C] memory: a pixel's channels contiguous — the layout of the bf16
+ * backbone): one wave per pixel, moments merged across lanes. */
+int afan_mix_feature_nhwc(const void* clean, const void* adv, void* out, int64_t n, int64_t c, int64_t hw, float eps,
+                          int dtype, afan_stream_t stream);
 
 /* SAT sample points.  Replaces Segmentation/attack_algo.py:108-118 (torch.lerp semantics:
  * w<0.5: x + w*(y-x); else y - (y-x)*(1-w)).  Writes the n_points-2 interior points, point k (1-based)

@@ -144,6 +144,36 @@ def test_mix_feature_vs_c_oracle(pkg, gpu, c_oracle, shape):
     np.testing.assert_allclose(same.cpu().numpy(), clean, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 64, 16, 16)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_mix_feature_channels_last(pkg, gpu, c_oracle, shape, dt):
+    """The channels-last kernel (one wave per pixel) against the C oracle / the NCHW kernel on the same values, and on
+    the golden vectors of the reference's mix_feature."""
+    rng = np.random.default_rng(sum(shape))
+    clean = (rng.standard_normal(shape) * 1.3 + 4.0).astype(np.float32)
+    adv = (clean + rng.standard_normal(shape) * 0.1).astype(np.float32)
+    tc = torch.from_numpy(clean).to(gpu, dt).contiguous(memory_format=torch.channels_last)
+    ta = torch.from_numpy(adv).to(gpu, dt).contiguous(memory_format=torch.channels_last)
+    out = pkg.ops.mix_feature(tc, ta)
+    assert out.stride() == tc.stride() and out.dtype == dt
+    n, c = shape[:2]
+    cin, ain = tc.float().cpu().contiguous().numpy(), ta.float().cpu().contiguous().numpy()   # the values the kernel saw
+    ref = np.zeros_like(cin)
+    c_oracle.oracle_mix_feature(ptr(cin), ptr(ain), ptr(ref), n, c, cin.size // (n * c), np.float32(1e-5))
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == torch.float32 else dict(rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, **tol)
+    np.testing.assert_allclose(out.float().cpu().numpy(), pkg.ops.mix_feature(tc.contiguous(), ta.contiguous()).float().cpu().numpy(),
+                               **tol)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_mix_feature_channels_last_golden(pkg, gpu, tag):
+    g = golden("seg_ops")
+    cl = lambda a: _dev(a, gpu).contiguous(memory_format=torch.channels_last)
+    out = pkg.attack_algo.mix_feature(cl(g[f"mix_{tag}_clean"]), cl(g[f"mix_{tag}_adv"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"mix_{tag}_out"], rtol=1e-5, atol=1e-5)
+
+
 def test_mix_feature_c1_is_nan(pkg, gpu):
     x = torch.randn(1, 1, 4, 4, device=gpu)
     assert torch.isnan(pkg.ops.mix_feature(x, x + 1)).all()   # unbiased variance over one channel: 0/0, as the reference
