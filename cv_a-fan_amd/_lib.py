@@ -29,6 +29,9 @@ SIGNATURES = {
     "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_mix_feature_nhwc": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
+    "afan_head_max_classes": (_i, []),
+    "afan_head_forward": (_i, [_p, _i, _l, _l, _l, _p, _p, _l, _p, _p, _p]),
+    "afan_head_backward": (_i, [_p, _p, _p, _l, _l, _l, _l, _p, _i, _p, _p, _i, _p]),
     "afan_mix_w_workspace_floats": (_l, []),
     "afan_mix_w": (_i, [_p, _p, _p, _p, _i, _l, _p]),
     "afan_mix_w_backward": (_i, [_p, _i, _p, _p, _l, _p, _p, _i, _p]),

@@ -1,0 +1,132 @@
+// Classifier head of the slice protocol: global average pool -> flatten -> linear (resnet_s.py:108-110, run at the end of
+// every tail pass: K times inside PGD and for both final passes).  In eager PyTorch this is a mean, a cast, an addmm and,
+// backward, two GEMMs, a column sum, an expand/divide and a cast — ten launches of a few microseconds on tensors of a
+// few hundred KB.  Here: one forward launch, two backward launches, fp32 arithmetic throughout.
+//   forward : pooled[b][c] = mean_hw x[b][hw][c]   (channels-last: lanes along c, coalesced)
+//             logits[b][k] = sum_c pooled[b][c] * W[k][c] + bias[k]
+//   backward: dx[b][hw][c] = (sum_k dlogits[b][k] * W[k][c]) / HW
+//             dW[k][c] (+)= sum_b dlogits[b][k] * pooled[b][c] ;  db[k] (+)= sum_b dlogits[b][k]
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int MAXK = 16;      // classes handled with register accumulators; larger heads take the vendor GEMM (caller)
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ pooled,
+                                                         float* __restrict__ logits, int C, int HW, int K) {
+    const int b = blockIdx.x;
+    const T* xb = x + (int64_t)b * HW * C;
+    float part[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) part[k] = 0.f;
+    const float inv = 1.0f / (float)HW;
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += Elt<T>::ld(xb + (int64_t)p * C + c);
+        const float m = s * inv;
+        pooled[(int64_t)b * C + c] = m;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) part[k] = fmaf(m, W[(int64_t)k * C + c], part[k]);
+    }
+    __shared__ float red[BLOCK / AFAN_WAVE][MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        const float v = wave_sum(part[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float s = bias ? bias[threadIdx.x] : 0.f;
+        for (int w = 0; w < BLOCK / AFAN_WAVE; ++w) s += red[w][threadIdx.x];
+        logits[(int64_t)b * K + threadIdx.x] = s;
+    }
+}
+
+// dx: block per image, thread per channel
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void head_bwd_dx_kernel(const float* __restrict__ dlogits, const float* __restrict__ W,
+                                                            T* __restrict__ dx, int C, int HW, int K) {
+    const int b = blockIdx.x;
+    __shared__ float dl[MAXK];
+    if (threadIdx.x < K) dl[threadIdx.x] = dlogits[(int64_t)b * K + threadIdx.x];
+    __syncthreads();
+    const float inv = 1.0f / (float)HW;
+    T* xb = dx + (int64_t)b * HW * C;
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+        float g = 0.f;
+        for (int k = 0; k < K; ++k) g = fmaf(dl[k], W[(int64_t)k * C + c], g);
+        g *= inv;
+        for (int p = 0; p < HW; ++p) Elt<T>::st(xb + (int64_t)p * C + c, g);
+    }
+}
+
+// dW / db: thread per (k, c) column walking the batch in order (deterministic); block 0 also sums db
+__global__ __launch_bounds__(BLOCK) void head_bwd_dw_kernel(const float* __restrict__ dlogits,
+                                                            const float* __restrict__ pooled, float* __restrict__ dW,
+                                                            float* __restrict__ db, int B, int C, int K, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < (int64_t)K * C) {
+        const int k = (int)(i / C), c = (int)(i % C);
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(dlogits[(int64_t)b * K + k], pooled[(int64_t)b * C + c], s);
+        dW[i] = accumulate ? dW[i] + s : s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < K && db) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dlogits[(int64_t)b * K + threadIdx.x];
+        db[threadIdx.x] = accumulate ? db[threadIdx.x] + s : s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int afan_head_max_classes(void) { return MAXK; }
+
+int afan_head_forward(const void* x, int dtype, int64_t n, int64_t c, int64_t hw, const float* weight, const float* bias,
+                      int64_t k, float* pooled, float* logits, afan_stream_t stream) {
+    if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n <= 0 || c <= 0 || hw <= 0 || k <= 0 || k > MAXK) return AFAN_ESHAPE;
+    if (!x || !weight || !pooled || !logits) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("head_fwd_kernel", (double)n * hw * c * (dtype == AFAN_F32 ? 4 : 2), st);
+    if (dtype == AFAN_F32)
+        head_fwd_kernel<float><<<(unsigned)n, BLOCK, 0, st>>>((const float*)x, weight, bias, pooled, logits, (int)c, (int)hw, (int)k);
+    else
+        head_fwd_kernel<uint16_t><<<(unsigned)n, BLOCK, 0, st>>>((const uint16_t*)x, weight, bias, pooled, logits, (int)c, (int)hw, (int)k);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_head_backward(const float* dlogits, const float* weight, const float* pooled, int64_t n, int64_t c, int64_t hw,
+                       int64_t k, void* dx, int dx_dtype, float* dweight, float* dbias, int accumulate,
+                       afan_stream_t stream) {
+    if (dx && dx_dtype != AFAN_F32 && dx_dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n <= 0 || c <= 0 || hw <= 0 || k <= 0 || k > MAXK) return AFAN_ESHAPE;
+    if (!dlogits || !weight || !pooled) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        AFAN_PROF("head_bwd_dx_kernel", (double)n * hw * c * (dx_dtype == AFAN_F32 ? 4 : 2), st);
+        if (dx_dtype == AFAN_F32)
+            head_bwd_dx_kernel<float><<<(unsigned)n, BLOCK, 0, st>>>(dlogits, weight, (float*)dx, (int)c, (int)hw, (int)k);
+        else
+            head_bwd_dx_kernel<uint16_t><<<(unsigned)n, BLOCK, 0, st>>>(dlogits, weight, (uint16_t*)dx, (int)c, (int)hw, (int)k);
+        AFAN_LAUNCH_CHECK();
+    }
+    if (dweight) {
+        AFAN_PROF("head_bwd_dw_kernel", 4.0 * n * (c + k), st);
+        const unsigned grid = (unsigned)((k * c + BLOCK - 1) / BLOCK);
+        head_bwd_dw_kernel<<<grid, BLOCK, 0, st>>>(dlogits, pooled, dweight, dbias, (int)n, (int)c, (int)k, accumulate);
+        AFAN_LAUNCH_CHECK();
+    }
+    return AFAN_OK;
+}
+
+}  // extern "C"

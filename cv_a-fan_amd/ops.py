@@ -302,6 +302,33 @@ def mix_w_backward(grad_out, clean, adv, dw_elem, accumulate=False):
     return dw_elem
 
 
+def head_forward(x, weight, bias):
+    """Global average pool + flatten + linear on a channels-last [N,C,H,W] tensor: (logits fp32 [N,K], pooled fp32 [N,C])."""
+    lib = _lib.load()
+    _need(x, "x"), _need(weight, "weight", torch.float32)
+    if x.dim() != 4 or not (layout_of(x) == AFAN_NHWC or x.shape[2] * x.shape[3] == 1) or x.dtype not in _DT:
+        raise ValueError("head_forward: x must be a channels-last fp32/bf16 feature map")
+    n, c, hw = _nchw(x)
+    k = weight.shape[0]
+    pooled = torch.empty(n, c, dtype=torch.float32, device=x.device)
+    logits = torch.empty(n, k, dtype=torch.float32, device=x.device)
+    check(lib.afan_head_forward(_ptr(x), _DT[x.dtype], n, c, hw, _ptr(weight), _ptr(bias), k, _ptr(pooled), _ptr(logits),
+                                _stream(x)), "afan_head_forward")
+    return logits, pooled
+
+
+def head_backward(dlogits, weight, pooled, x_like, want_dx, dweight=None, dbias=None, accumulate=False):
+    """Backward of head_forward: dx (x_like's shape / dtype / layout) or None; dweight / dbias written or added into."""
+    lib = _lib.load()
+    _need(dlogits, "dlogits", torch.float32), _need(pooled, "pooled", torch.float32)
+    n, c, hw = _nchw(x_like)
+    dx = torch.empty_like(x_like) if want_dx else None
+    check(lib.afan_head_backward(_ptr(dlogits.contiguous()), _ptr(weight), _ptr(pooled), n, c, hw, weight.shape[0], _ptr(dx),
+                                 _DT[x_like.dtype], _ptr(dweight), _ptr(dbias), int(bool(accumulate)), _stream(x_like)),
+          "afan_head_backward")
+    return dx
+
+
 # ------------------------------------------------------------------------------------- BatchNorm
 def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num_batches=None):
     """Per-channel batch mean and 1/sqrt(var_biased + eps) (optionally updating running statistics)."""

@@ -597,6 +597,43 @@ class Bottleneck(nn.Module):
         return self.bn3.fused(out, res, True, st)
 
 
+class _HeadFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110) as one forward and two backward launches
+    (afan_head_*): the classifier head runs at the end of every tail pass, K + 2 times per iteration."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_pgrad):
+        logits, pooled = ops.head_forward(x, weight, bias)
+        ctx.save_for_backward(x, weight, pooled)
+        ctx.bias, ctx.pg = bias, want_pgrad
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, pooled = ctx.saved_tensors
+        bias = ctx.bias
+        want_p = ctx.pg and ctx.needs_input_grad[1]
+        dw = db = None
+        direct = False
+        if want_p:
+            direct = _accumulates_in_place(weight) and (bias is None or _accumulates_in_place(bias))
+            if direct:
+                dw, db = weight.grad, (bias.grad if bias is not None else None)
+            else:
+                dw = torch.empty_like(weight)
+                db = torch.empty_like(bias) if bias is not None else None
+        dx = ops.head_backward(g.float(), weight, pooled, x, ctx.needs_input_grad[0], dw, db, accumulate=direct)
+        if direct:
+            dw = db = None
+        return dx, dw, db, None
+
+
+def _head_ok(x, lin):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and lin.weight.dtype == torch.float32
+            and (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() or x.shape[2] * x.shape[3] == 1)
+            and lin.out_features <= 16)
+
+
 class _HeadPool(nn.AdaptiveAvgPool2d):
     """Global average pool; accumulates and returns fp32 (the classifier head runs in fp32)."""
 
@@ -668,6 +705,12 @@ class ResNet(nn.Module):
                     i += 2
                     continue
                 x = L.fused(x)
+            elif (isinstance(L, _HeadPool) and i + 2 < n and isinstance(layers[i + 1], nn.Flatten)
+                  and isinstance(layers[i + 2], nn.Linear) and _head_ok(x, layers[i + 2])):
+                lin = layers[i + 2]
+                x = _HeadFn.apply(x, lin.weight, lin.bias, _Flags.param_grads)
+                i += 3
+                continue
             elif isinstance(L, nn.Linear):
                 x = L(x.float())
             else:

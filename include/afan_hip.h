@@ -252,6 +252,19 @@ int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_
                               int64_t ci, int64_t co, int k, int stride, float* workspace, int accumulate,
                               afan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Classifier head of the slice protocol: AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110), run at the
+ * end of every tail pass.  x: channels-last [N,HW,C] (`dtype`); weight fp32 [K,C], bias fp32 [K] (nullable), K <=
+ * afan_head_max_classes(); pooled fp32 [N,C] is kept for the backward; logits fp32 [N,K].
+ * Backward: dx (nullable, `dx_dtype`, [N,HW,C]) = (dlogits @ weight) / HW broadcast over HW; dweight (nullable) and dbias
+ * written (accumulate = 0) or added into (1): the batch is summed in index order (deterministic). */
+int afan_head_max_classes(void);
+int afan_head_forward(const void* x, int dtype, int64_t n, int64_t c, int64_t hw, const float* weight, const float* bias,
+                      int64_t k, float* pooled, float* logits, afan_stream_t stream);
+int afan_head_backward(const float* dlogits, const float* weight, const float* pooled, int64_t n, int64_t c, int64_t hw,
+                       int64_t k, void* dx, int dx_dtype, float* dweight, float* dbias, int accumulate,
+                       afan_stream_t stream);
+
 /* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
  * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
  * offsets into src_arena / dst_arena, K % 8 == 0, C % 8 == 0, first_tile = running sum of ceil(K/64)*RS*ceil(C/64)). */

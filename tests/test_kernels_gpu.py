@@ -3,6 +3,7 @@ Bit-exact for the PGD update / projection / noise / clamp / lerp; stated toleran
 import numpy as np
 import pytest
 import torch
+import torch.nn as nn
 
 from conftest import assert_close_frac, golden, ptr
 
@@ -469,3 +470,25 @@ def test_elementwise_kernels_accept_channels_last(pkg, gpu, c_oracle):
     assert b.is_contiguous(memory_format=torch.channels_last)
     np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
     np.testing.assert_array_equal(a.cpu().numpy(), ((img - m[None, :, None, None]) / s[None, :, None, None]).cpu().numpy())
+
+
+@pytest.mark.parametrize("shape,k", [((32, 512, 4, 4), 10), ((6, 64, 8, 8), 10), ((3, 2048, 7, 7), 16), ((4, 64, 1, 1), 7)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_fused_classifier_head_matches_torch(pkg, gpu, shape, k, dt):
+    """afan_head_forward / _backward against pool -> flatten -> linear in torch fp32 on the same values."""
+    torch.manual_seed(sum(shape) + k)
+    x = torch.randn(shape, device=gpu).to(dt).contiguous(memory_format=torch.channels_last)
+    lin = nn.Linear(shape[1], k).to(gpu)
+    xr = x.float().detach().requires_grad_(True)
+    ref = lin(xr.mean(dim=(2, 3)))
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    logits, pooled = pkg.ops.head_forward(x, lin.weight.detach(), lin.bias.detach())
+    np.testing.assert_allclose(logits.cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dw, db = torch.ones_like(lin.weight), torch.ones_like(lin.bias)
+    dx = pkg.ops.head_backward(g, lin.weight.detach(), pooled, x, True, dw, db, accumulate=True)
+    assert dx.dtype == dt and dx.stride() == x.stride()
+    tol = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-4)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.cpu().numpy(), **tol)
+    np.testing.assert_allclose(dw.cpu().numpy() - 1, lin.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy() - 1, lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
