@@ -12,6 +12,7 @@ and the slice executor fuses BN->ReLU pairs that sit at adjacent indices of the 
 ResNet-18 (CIFAR stem) is build-defined: the reference ships only resnet56 (SURVEY.md warning 3).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -628,8 +629,11 @@ class _HeadFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+_FUSED_HEAD = os.environ.get("AFAN_FUSED_HEAD", "1") != "0"   # 0: pool / flatten / linear as separate torch ops (A/B)
+
+
 def _head_ok(x, lin):
-    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and lin.weight.dtype == torch.float32
+    return (_FUSED_HEAD and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and lin.weight.dtype == torch.float32
             and (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() or x.shape[2] * x.shape[3] == 1)
             and lin.out_features <= 16)
 
