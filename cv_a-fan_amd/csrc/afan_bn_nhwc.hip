@@ -15,6 +15,7 @@
 // Channel counts that do not fit the mapping (C/VEC not a divisor of 256, e.g. C = 304) take the generic
 // kernels: one thread per channel walking rows, lanes across channels (still coalesced, narrower accesses).
 #include "afan_common.h"
+#include <stdlib.h>
 
 using namespace afan;
 
@@ -599,7 +600,8 @@ bool make_plan(int64_t M, int64_t C, std::initializer_list<const void*> ptrs, Pl
 
 static inline int apply_grid(const Plan& p, int64_t total) {
     // ~4 vectors per thread: amortises the per-thread coefficient loads, still >= 2 blocks per CU on the big tensors
-    return grid_for(p.vec ? (p.nvec + 3) / 4 : total, BLOCK, 2048);
+    static const int vpt = [] { const char* v = getenv("AFAN_BN_VPT"); return v ? atoi(v) : 4; }();
+    return grid_for(p.vec ? (p.nvec + vpt - 1) / vpt : total, BLOCK, 2048);
 }
 
 template <typename T>

@@ -15,6 +15,7 @@
 // into the fp32 gradient arena (KRSC), so autograd's AccumulateGrad, the bf16->fp32 cast and the split-K workspace
 // zero/cast passes of the vendor path all disappear.
 #include "afan_common.h"
+#include <stdlib.h>
 
 using namespace afan;
 
@@ -198,7 +199,8 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
     pl.bn = (ci % 128 == 0) ? 128 : 64;
     const int64_t tiles = (int64_t)(co / pl.bm) * (ci / pl.bn) * taps;
     const int64_t total_steps = (P + BKP - 1) / BKP;
-    int64_t S = 320 / tiles;                       // ~1.25 workgroups per CU
+    static const int target = [] { const char* v = getenv("AFAN_WGRAD_WGS"); return v ? atoi(v) : 512; }();
+    int64_t S = target / tiles;                    // ~2 workgroups per CU (measured: 512 beats 320 by 2 % of the step)
     const int64_t max_s = total_steps / 16 > 0 ? total_steps / 16 : 1;   // >= 16 steps per workgroup
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
