@@ -601,7 +601,8 @@ bool make_plan(int64_t M, int64_t C, std::initializer_list<const void*> ptrs, Pl
 static inline int apply_grid(const Plan& p, int64_t total) {
     // ~4 vectors per thread: amortises the per-thread coefficient loads, still >= 2 blocks per CU on the big tensors
     static const int vpt = [] { const char* v = getenv("AFAN_BN_VPT"); return v ? atoi(v) : 4; }();
-    return grid_for(p.vec ? (p.nvec + vpt - 1) / vpt : total, BLOCK, 2048);
+    static const int cap = [] { const char* v = getenv("AFAN_BN_MAXBLOCKS"); return v ? atoi(v) : 512; }();     // (512 vs 2048 blocks: +0.6 % of the step)
+    return grid_for(p.vec ? (p.nvec + vpt - 1) / vpt : total, BLOCK, cap);
 }
 
 template <typename T>

@@ -460,7 +460,8 @@ static int env_int(const char* name, int dflt) {
 int choose_bm(int64_t M, int co, int n_classes) {
     const bool n128 = (co % 128 == 0);
     const int64_t wg_128 = ((M + 127) / 128) * (co / (n128 ? 128 : 64)) * n_classes;
-    if (wg_128 >= 384) return 128;
+    static const int thr = env_int("AFAN_CONV_THR128", 256);   // (256 vs 384: +0.3 % of the step)
+    if (wg_128 >= thr) return 128;
     // 385..768 workgroups of 64 rows (the 8x8 stage) would be two per CU on the two-stage pipeline; 128-row tiles bring
     // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
     static const int tall = env_int("AFAN_CONV_TALL", 1);
@@ -486,7 +487,8 @@ int dispatch(const ConvP& p, hipStream_t st) {
     static const int deep = env_int("AFAN_CONV_DEEP", 1);     // 0: two LDS stages everywhere
     if (mode == 3 && nw >= 8 && n128 && deep >= 1) {
         const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
-        if (wgs <= 384) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
+        static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
+        if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
     }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
     if (mode == 3 && nw >= 8) {
