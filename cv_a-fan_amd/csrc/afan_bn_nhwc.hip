@@ -94,9 +94,10 @@ __device__ __forceinline__ void block_fold_store(float (&acc)[NQ][VEC], int CV, 
 // (apply_acc / bwd_apply_acc kernels) derive their coefficients from the accumulators themselves, so neither a partial
 // slab nor a finalize launch exists on this path.  fp32 block sums widened to f64 add exactly unless they differ by
 // > 2^29 in magnitude, so the result is order-independent to ~1e-16 relative — far below the fp32 statistics.
-__host__ __device__ inline int acc_slots(int64_t C) {   // NS * C <= 1024, 1 <= NS <= 16, power of two
+inline int acc_slots(int64_t C) {   // NS * C <= 1024, 1 <= NS <= 16, power of two (host side; kernels get NS as a parameter)
+    static const int64_t budget = [] { const char* v = getenv("AFAN_BN_SLOTS"); return v ? (int64_t)atoi(v) : (int64_t)1024; }();
     int ns = 16;
-    while (ns > 1 && (int64_t)ns * C > 1024) ns >>= 1;
+    while (ns > 1 && (int64_t)ns * C > budget) ns >>= 1;
     return ns;
 }
 
@@ -126,7 +127,8 @@ __device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV,
 // ---- forward 1: shifted column sums -----------------------------------------------------------------
 template <typename T, int VEC, bool ATOMIC = false>
 __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, int64_t nvec, int CV, int C,
-                                                      float* __restrict__ ws, double* __restrict__ accd = nullptr) {
+                                                      float* __restrict__ ws, double* __restrict__ accd = nullptr,
+                                                      int NS = 1) {
     const int cv = threadIdx.x % CV;
     float shift[VEC];
     LdV<T, VEC>::ld(x + (int64_t)cv * VEC, shift);  // first row of the tensor: same shift in every block
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, i
             acc[1][k] += d * d;
         }
     }
-    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, acc_slots(C), accd);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, NS, accd);
     else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
 }
 
@@ -279,7 +281,7 @@ template <typename T, int VEC, bool RELU, bool HAVE_Y, bool ATOMIC = false>
 __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, int64_t nvec, int CV, int C,
                                                            const float* __restrict__ stats, float* __restrict__ ws,
-                                                           double* __restrict__ accd = nullptr) {
+                                                           double* __restrict__ accd = nullptr, int NS = 1) {
     const int c0 = (threadIdx.x % CV) * VEC;
     float mu[VEC], alpha[VEC], beta[VEC];
     ld_coef<VEC>(stats, c0, mu);
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__
             acc[1][k] += g * (e[k] - mu[k]);   // invstd is applied once per channel in the finalize
         }
     }
-    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, acc_slots(C), accd);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, NS, accd);
     else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
 }
 
@@ -736,7 +738,7 @@ int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, f
     const T* x_ = (const T*)x; const T* r_ = (const T*)res; T* y_ = (T*)y;
     if (!acc_ready) {
         AFAN_PROF("bn_nhwc_stats_kernel", p.tensor_bytes, st);
-        stats_kernel<T, NV, true><<<p.G, BLOCK, 0, st>>>(x_, p.nvec, p.CV, (int)C, nullptr, acc);
+        stats_kernel<T, NV, true><<<p.G, BLOCK, 0, st>>>(x_, p.nvec, p.CV, (int)C, nullptr, acc, acc_slots(C));
         AFAN_LAUNCH_CHECK();
     }
     const int NS = acc_slots(C);
@@ -773,7 +775,7 @@ int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d
     if (!acc_ready) {
         AFAN_PROF("bn_nhwc_bwd_reduce_kernel", p.tensor_bytes * ((relu && y) ? 3 : 2), st);
 #define AFAN_RED(RELU, HY)                                                                                        \
-    bwd_reduce_kernel<T, NV, RELU, HY, true><<<p.G, BLOCK, 0, st>>>(dy_, x_, y_, p.nvec, p.CV, (int)C, stats, nullptr, acc)
+    bwd_reduce_kernel<T, NV, RELU, HY, true><<<p.G, BLOCK, 0, st>>>(dy_, x_, y_, p.nvec, p.CV, (int)C, stats, nullptr, acc, acc_slots(C))
         if (!relu) AFAN_RED(false, false);
         else if (y) AFAN_RED(true, true);
         else AFAN_RED(true, false);
