@@ -8,7 +8,7 @@ wrappers over the C-ABI in include/afan_hip.h), main_perturb (entry point for cm
 """
 from . import _lib, ops  # noqa: F401
 from ._lib import AfanLibraryError, LIB_PATH  # noqa: F401
-from . import resnet_s, attack_algo, arena, train_step, learnable  # noqa: F401
+from . import resnet_s, attack_algo, arena, train_step, learnable, seg_attack_algo  # noqa: F401
 from .attack_algo import PGD, get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,113 @@
+"""Segmentation feature-space operators (first slice) — names, signatures and error behaviour of the
+reference's `Segmentation/attack_algo.py`:
+
+    PGD(x, image_batch, low_level_feat, criterion, y, model, steps, eps, gamma, idx, randinit, clip)        :40-59
+    decoder_PGD(input_dict, image_batch, criterion, y, model, steps, eps, gamma, idx, randinit, clip)       :61-84
+    adv_input(x, criterion, y, model, steps, eps, gamma, randinit, clip)                                    :86-105
+    get_sample_points / mix_feature / tensor_clamp / linfball_proj                  (shared with attack_algo.py)
+
+`model` is anything that follows the reference's dict-dispatch protocol (`Segmentation/network/utils.py:14-47`):
+`model({'x', 'adv', 'out_idx', 'flag', 'low_level_feat'}) -> logits | feature dict`.  The sign-step / projection / noise /
+mix / lerp arithmetic runs in libafan_hip.so; the model's own layers are whatever the caller built (the DeepLabv3+
+network with the library's kernels is the next slice)."""
+import torch
+
+from . import ops
+from .attack_algo import get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401 (same functions)
+
+
+def _start(x, eps, randinit):
+    if x.device.type != "cuda":
+        raise ops.AfanLibraryError("x must live on the MI355X (no CPU path in this build)")
+    x = x.detach().float().contiguous()
+    x_adv = x.clone()
+    if randinit:   # noise from the CPU default generator, like the reference (:44)
+        ops.axpy_noise_(x_adv, torch.rand(x_adv.shape).to(x.device, non_blocking=True), eps)
+    return x, x_adv
+
+
+def _ascend(x_adv, logits_of, criterion, y, gamma, x, eps, clip):
+    xin = x_adv.detach().requires_grad_(True)
+    loss = criterion(logits_of(xin), y)
+    grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
+    ops.pgd_step_(x_adv, grad.contiguous(), gamma, x, eps, clip)          # one launch: sign step (+ projection)
+
+
+def PGD(x, image_batch, low_level_feat, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
+        randinit=False, clip=False):
+    """SE-branch feature PGD (:40-59).  Returns a new fp32 leaf with requires_grad=True; `x` is not modified."""
+    x, x_adv = _start(x, eps, randinit)
+    for _ in range(steps):
+        _ascend(x_adv, lambda t: model({"x": image_batch, "adv": t, "out_idx": idx, "flag": "tail",
+                                        "low_level_feat": low_level_feat}), criterion, y, gamma, x, eps, clip)
+    return x_adv.requires_grad_(True)
+
+
+def decoder_PGD(input_dict, image_batch, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
+                randinit=False, clip=False):
+    """SD-branch (decoder feature) PGD (:61-84): perturbs input_dict['adv'] in the dict and returns the dict.  The
+    reference cannot clip here — its projection names an undefined `x` and raises NameError after the first step — and
+    neither does this: same exception."""
+    _, x_adv = _start(input_dict["adv"], eps, randinit)
+    input_dict["adv"] = x_adv
+    for _ in range(steps):
+        def logits_of(t):
+            d = dict(input_dict)
+            d["adv"] = t
+            return model({"x": image_batch, "adv": d, "out_idx": idx + "_tail", "flag": "clean"})
+        _ascend(x_adv, logits_of, criterion, y, gamma, None, 0.0, False)
+        if clip:
+            raise NameError("name 'x' is not defined")
+    input_dict["adv"] = x_adv.requires_grad_(True)
+    return input_dict
+
+
+def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False):
+    """Image-space PGD (:86-105), clamped to [0, 1] at the end."""
+    x, x_adv = _start(x, eps, randinit)
+    for _ in range(steps):
+        _ascend(x_adv, lambda t: model({"x": t, "adv": None, "out_idx": 0, "flag": "clean", "low_level_feat": None}),
+                criterion, y, gamma, x, eps, clip)
+    lo, hi = torch.zeros_like(x_adv), torch.ones_like(x_adv)
+    ops.tensor_clamp_(x_adv, lo, hi)
+    return x_adv.requires_grad_(True)
+
+
+def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
+                   pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
+                   clip=False):
+    """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
+    (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
+    0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
+    f0, f1 = int(mix_layer[0]), int(mix_layer[1])
+    optimizer.zero_grad()
+    out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
+    dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
+    fm_sd = dec["adv"].detach()
+    low = out_se["low_level"]
+    fm_se = out_se["out"].detach()
+    adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
+                 eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip)
+    adv_sd_dict = decoder_PGD(input_dict=dec, image_batch=images, criterion=criterion, y=labels, model=model, steps=steps,
+                              eps=(eps / 255), gamma=(gamma_sd / 255), idx=pertub_idx_sd, randinit=randinit, clip=clip)
+    adv_sd = adv_sd_dict["adv"].detach()
+    if mix_sd:
+        adv_sd = mix_feature(fm_sd, adv_sd)
+    if noise_sd != 0:
+        ops.axpy_noise_(adv_sd, torch.rand(adv_sd.shape).to(adv_sd.device, non_blocking=True), gamma_sd * noise_sd)
+    adv_sd_dict["adv"] = adv_sd
+    pts = get_sample_points(fm_se.float().contiguous(), adv_se.detach(), 3)
+    if f0:
+        pts[1] = mix_feature(fm_se, pts[1])
+    if f1:
+        pts[2] = mix_feature(fm_se, pts[2])
+    o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
+    o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+    o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+    o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
+    l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
+    loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
+    loss.backward()
+    optimizer.step()
+    return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
+            "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}

@@ -350,6 +350,171 @@ def learnable_train_step(model, optimizer, optimizer_w, criterion, inp, target, 
             "out_clean": out_clean.detach()}
 
 
+# ----------------------------------------------------------------------- Segmentation operators and step (N1, first slice)
+class _ConvBNReLU(nn.Sequential):
+    def __init__(self, ci, co, k=3, stride=1):
+        super().__init__(nn.Conv2d(ci, co, k, stride, k // 2, bias=False), nn.BatchNorm2d(co), nn.ReLU())
+
+
+class TinySegNet(nn.Module):
+    """A small network that follows the reference's dict-dispatch protocol exactly — `Segmentation/network/utils.py:14-47`
+    (flag head / tail / clean, integer or "aspp|concat"_"head|tail" out_idx), `backbone/resnet.py:198-304` (head up to
+    layer out_idx, tail from there, low_level = layer1 output) and `_deeplab.py:48-80` (project + aspp + classifier with
+    the aspp/concat split) — on a 4-stage toy backbone.  Test infrastructure: it lets the reference's own
+    `Segmentation/attack_algo.py` functions and the build's operators run on the same model; DeepLabv3+ itself is the
+    next slice."""
+
+    def __init__(self, classes=5, w=8):
+        super().__init__()
+        self.stem = _ConvBNReLU(3, w, 3, 2)
+        self.layer1 = _ConvBNReLU(w, w)
+        self.layer2 = _ConvBNReLU(w, 2 * w, 3, 2)
+        self.layer3 = _ConvBNReLU(2 * w, 2 * w)
+        self.layer4 = _ConvBNReLU(2 * w, 4 * w)
+        self.project = _ConvBNReLU(w, w // 2, 1)
+        self.aspp = _ConvBNReLU(4 * w, 2 * w, 1)
+        self.classifier = nn.Sequential(_ConvBNReLU(2 * w + w // 2, 2 * w), nn.Conv2d(2 * w, classes, 1))
+
+    def backbone(self, d):
+        layers = [self.layer1, self.layer2, self.layer3, self.layer4]
+        out = {}
+        if d["flag"] == "head":
+            x = self.layer1(self.stem(d["x"]))
+            out["low_level"] = x
+            for L in layers[1:d["out_idx"]]:
+                x = L(x)
+            out["out"] = x
+            return out
+        if d["flag"] == "tail":
+            x = d["adv"]
+            for L in layers[d["out_idx"]:]:
+                x = L(x)
+            return {"out": x, "low_level": d["low_level_feat"]}
+        assert d["flag"] == "clean"
+        x = self.layer1(self.stem(d["x"]))
+        out["low_level"] = x
+        for L in layers[1:]:
+            x = L(x)
+        out["out"] = x
+        return out
+
+    def head(self, f, return_type=None):
+        import torch.nn.functional as F
+        if return_type == "aspp_head":
+            return self.aspp(f["out"])
+        if return_type == "concat_tail":
+            return self.classifier(f["adv"])
+        low = self.project(f["low_level"])
+        o = f["adv"] if return_type == "aspp_tail" else self.aspp(f["out"])
+        o = F.interpolate(o, size=low.shape[2:], mode="bilinear", align_corners=False)
+        cat = torch.cat([low, o], dim=1)
+        if return_type == "concat_head":
+            return cat
+        assert return_type in (None, "aspp_tail")
+        return self.classifier(cat)
+
+    def forward(self, d):
+        import torch.nn.functional as F
+        if d["flag"] == "head":
+            return self.backbone(d)
+        assert d["flag"] in ("tail", "clean")
+        if isinstance(d["out_idx"], int):
+            x = self.head(self.backbone(d))
+            return F.interpolate(x, size=d["x"].shape[-2:], mode="bilinear", align_corners=False)
+        if d["out_idx"] in ("aspp_head", "concat_head"):
+            f = self.backbone(d)
+            f["adv"] = self.head(f, d["out_idx"])
+            return f
+        assert d["out_idx"] in ("aspp_tail", "concat_tail")
+        x = self.head(d["adv"], d["out_idx"])
+        return F.interpolate(x, size=d["x"].shape[-2:], mode="bilinear", align_corners=False)
+
+
+def seg_PGD(x, image_batch, low_level_feat, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
+            randinit=False, clip=False):
+    """Segmentation/attack_algo.py:40-59."""
+    x_adv = x.clone()
+    if randinit:
+        x_adv = randinit_(x_adv, eps)
+    x_adv.requires_grad_(True)
+    for _ in range(steps):
+        logits = model({"x": image_batch, "adv": x_adv, "out_idx": idx, "flag": "tail", "low_level_feat": low_level_feat})
+        grad0 = torch.autograd.grad(criterion(logits, y), x_adv, only_inputs=True)[0]
+        with torch.no_grad():
+            pgd_step_(x_adv.data, grad0.data, gamma, x, eps, clip)
+    return x_adv
+
+
+def seg_decoder_PGD(input_dict, image_batch, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
+                    randinit=False, clip=False):
+    """Segmentation/attack_algo.py:61-84.  (With clip=True the reference raises NameError: its projection refers to an
+    undefined `x`; restated as such.)"""
+    x_adv = input_dict["adv"].detach().clone()
+    if randinit:
+        x_adv = randinit_(x_adv, eps)
+    x_adv.requires_grad_(True)
+    input_dict["adv"] = x_adv
+    for _ in range(steps):
+        logits = model({"x": image_batch, "adv": input_dict, "out_idx": idx + "_tail", "flag": "clean"})
+        grad = torch.autograd.grad(criterion(logits, y), x_adv, only_inputs=True)[0]
+        with torch.no_grad():
+            pgd_step_(x_adv.data, grad.data, gamma, None, eps, False)
+        if clip:
+            raise NameError("name 'x' is not defined")
+    input_dict["adv"] = x_adv
+    return input_dict
+
+
+def seg_adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False):
+    """Segmentation/attack_algo.py:86-105: image-space PGD, clamped to [0, 1] at the end."""
+    x_adv = x.clone()
+    if randinit:
+        x_adv = randinit_(x_adv, eps)
+    x_adv.requires_grad_(True)
+    for _ in range(steps):
+        logits = model({"x": x_adv, "adv": None, "out_idx": 0, "flag": "clean", "low_level_feat": None})
+        grad0 = torch.autograd.grad(criterion(logits, y), x_adv, only_inputs=True)[0]
+        with torch.no_grad():
+            pgd_step_(x_adv.data, grad0.data, gamma, x, eps, clip)
+    return torch.clamp(x_adv, 0, 1.0)
+
+
+def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
+                   pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, randinit=False, clip=False):
+    """One iteration of Segmentation/main_aug_final.py:158-232 (noise_sd = 0): SE feature PGD + SD decoder PGD, 3 SAT
+    sample points, mix_feature, four forwards, loss = 0.7*clean + 0.1*(se1 + se2 + sd)."""
+    f0, f1 = int(mix_layer[0]), int(mix_layer[1])
+    optimizer.zero_grad()
+    out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
+    dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
+    fm_sd = dec["adv"].detach()
+    low = out_se["low_level"]
+    fm_se = out_se["out"].detach()
+    adv_se = seg_PGD(fm_se, images, low, criterion, y=labels, model=model, steps=steps, eps=eps / 255,
+                     gamma=gamma_se / 255, idx=pertub_idx_se, randinit=randinit, clip=clip)
+    adv_sd_dict = seg_decoder_PGD(dec, images, criterion, y=labels, model=model, steps=steps, eps=eps / 255,
+                                  gamma=gamma_sd / 255, idx=pertub_idx_sd, randinit=randinit, clip=clip)
+    adv_sd = adv_sd_dict["adv"].detach()
+    if mix_sd:
+        adv_sd = mix_feature(fm_sd, adv_sd)
+    adv_sd_dict["adv"] = adv_sd
+    pts = get_sample_points(fm_se, adv_se, 3)
+    if f0:
+        pts[1] = mix_feature(fm_se, pts[1])
+    if f1:
+        pts[2] = mix_feature(fm_se, pts[2])
+    o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
+    o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+    o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+    o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
+    l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
+    loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
+    loss.backward()
+    optimizer.step()
+    return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
+            "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}
+
+
 def sharded_train_step(model, optimizer, criterion, inp, target, world, **kw):
     """N-GPU data-parallel emulation: each rank runs the step on its shard with per-shard BN
     statistics from the SAME starting weights, parameter gradients are averaged, one SGD update is applied.

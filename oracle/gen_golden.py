@@ -261,6 +261,66 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
         print(name, "loss", loss, "w", sd["w"].tolist())
 
+    # ---- Segmentation operators + iteration (N1, first slice): the reference's own PGD / decoder_PGD / adv_input /
+    # get_sample_points / mix_feature (Segmentation/attack_algo.py) and the loop body of main_aug_final.py:158-232 driven line
+    # by line around them, on the protocol-faithful stand-in network oracle.TinySegNet (the reference's DeepLab needs
+    # torchvision; its restatement is the next slice) --------------------------------------------------------------------
+    for name, steps, gamma_se, gamma_sd, sd_idx, clip in (("seg_step_aspp_k1", 1, 0.5, 0.5, "aspp", False),
+                                                          ("seg_step_concat_k2", 2, 1.0, 0.5, "concat", False)):
+        torch.manual_seed(5)
+        net = orc.TinySegNet()
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), 0.01, momentum=0.9, weight_decay=1e-4)
+        seg_crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+        images = torch.rand(2, 3, 33, 33)
+        labels = torch.randint(0, 5, (2, 33, 33))
+        labels[torch.rand(2, 33, 33) < 0.05] = 255
+        k0, c0 = _checksums(net)
+        se_idx, eps = 3, 2.0
+        inputs_all_se = {"x": images, "adv": None, "out_idx": se_idx, "flag": "head"}
+        inputs_all_sd = {"x": images, "adv": None, "out_idx": sd_idx + "_head", "flag": "clean"}
+        opt.zero_grad()
+        output_dict_se = net(inputs_all_se)
+        decoder_feature_map_dict = net(inputs_all_sd)
+        feature_map_sd = decoder_feature_map_dict["adv"].detach()
+        low_level_feat = output_dict_se["low_level"]
+        feature_map_se = output_dict_se["out"].detach()
+        feature_adv_se = ref_seg.PGD(x=feature_map_se, image_batch=images, low_level_feat=low_level_feat, criterion=seg_crit,
+                                     y=labels, model=net, steps=steps, eps=(eps / 255), gamma=(gamma_se / 255), idx=se_idx,
+                                     randinit=False, clip=clip)
+        feature_adv_sd_dict = ref_seg.decoder_PGD(input_dict=decoder_feature_map_dict, image_batch=images, criterion=seg_crit,
+                                                  y=labels, model=net, steps=steps, eps=(eps / 255), gamma=(gamma_sd / 255),
+                                                  idx=sd_idx, randinit=False, clip=False)
+        adv_feature_map_sd = feature_adv_sd_dict["adv"].detach()
+        adv_feature_map_sd = ref_seg.mix_feature(feature_map_sd, adv_feature_map_sd)          # opts.mix_sd
+        feature_adv_sd_dict["adv"] = adv_feature_map_sd
+        adv_list_se = ref_seg.get_sample_points(feature_map_se, feature_adv_se, 3)
+        adv_list_se[1] = ref_seg.mix_feature(feature_map_se, adv_list_se[1])                  # mix_layer "11"
+        adv_list_se[2] = ref_seg.mix_feature(feature_map_se, adv_list_se[2])
+        clean_input_dict = {"x": images, "adv": None, "out_idx": 0, "flag": "clean"}
+        adv_input_se_dict1 = {"x": images, "adv": adv_list_se[1], "out_idx": se_idx, "flag": "tail", "low_level_feat": low_level_feat}
+        adv_input_se_dict2 = {"x": images, "adv": adv_list_se[2], "out_idx": se_idx, "flag": "tail", "low_level_feat": low_level_feat}
+        adv_input_sd_dict = {"x": images, "adv": feature_adv_sd_dict, "out_idx": sd_idx + "_tail", "flag": "clean"}
+        output0, output1 = net(clean_input_dict), net(adv_input_se_dict1)
+        output2, output3 = net(adv_input_se_dict2), net(adv_input_sd_dict)
+        loss0, loss1 = seg_crit(output0, labels), seg_crit(output1, labels)
+        loss2, loss3 = seg_crit(output2, labels), seg_crit(output3, labels)
+        loss = 0.7 * loss0 + 0.1 * loss1 + 0.1 * loss2 + 0.1 * loss3
+        loss.backward()
+        opt.step()
+        k1, c1 = _checksums(net)
+        # image-space PGD of the same file (adv_input), on the updated network in eval mode (no BN side effects)
+        net.eval()
+        x_img = ref_seg.adv_input(x=images, criterion=seg_crit, y=labels, model=net, steps=2, eps=(2.0 / 255),
+                                  gamma=(1.0 / 255), randinit=False, clip=True)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), images=_np(images), labels=_np(labels),
+                            meta=np.array([steps, se_idx, int(clip)]), gammas=np.array([gamma_se, gamma_sd, eps]),
+                            sd_idx=np.array(sd_idx), ck0=c0, ck1=c1, keys=np.array(k1), loss=_np(loss),
+                            losses=np.array([float(loss0), float(loss1), float(loss2), float(loss3)], dtype=np.float32),
+                            adv_se=_np(feature_adv_se), adv_sd=_np(adv_feature_map_sd), fm_se=_np(feature_map_se),
+                            out_clean=_np(output0), x_img=_np(x_img))
+        print(name, "loss", float(loss))
+
     # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
     torch.manual_seed(7)
     rec = {}
