@@ -13,6 +13,7 @@ import torch
 from . import ops
 from .arena import ArenaSGD, ParamArena
 from .attack_algo import PGD
+from . import resnet_s
 from .resnet_s import _like_layout
 
 LEARNABLE_IDX = (4, 8, 11, 14, 18, 21, 24, 28, 31)   # main_learnable.py:59
@@ -70,7 +71,7 @@ class LearnableTrainer:
         if self._graph is not None and self._key == key:
             return self._replay(inp, target)
         if (self.use_graph and self._graph is None and self._graph_failed is None and inp.is_cuda
-                and self._eager_steps >= self.graph_warmup and self.model.training):
+                and self._eager_steps >= self.graph_warmup and self.model.training and self._graph_safe()):
             try:
                 self._capture(inp, target, key)
                 return self._replay(inp, target)
@@ -82,6 +83,12 @@ class LearnableTrainer:
         self._eager_steps += 1
         self.optimizer._sync_lr()
         return self._body(inp, target)
+
+    def _graph_safe(self):
+        """As AfanTrainer._graph_safe: no hipGraph around vendor convolutions (fp32 parity mode, NCHW weights)."""
+        if resnet_s.vendor_convs(self.model):
+            self.use_graph = False
+        return self.use_graph
 
     def _capture(self, inp, target, key):
         dev = inp.device

@@ -45,6 +45,8 @@ parser.add_argument("--init_weight", default=(1 / 9), type=float, help="initial 
 parser.add_argument("--l1_coef", default=1, type=float, help="coefficient of the L1 penalty on the mixing weights")
 # ---- additions
 parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="backbone compute dtype")
+parser.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
+                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: vendor convolutions)")
 parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of CIFAR-10")
 parser.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
 
@@ -90,12 +92,16 @@ def main(argv=None):
     if args.seed:
         mp.setup_seed(args.seed)
     model = resnet_s.resnet56(init_weight_eta=args.init_weight)       # :73
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.set_channels_last(args.layout == "nhwc").to(dev)
     criterion = nn.CrossEntropyLoss()
     trainer = learnable.LearnableTrainer(model, criterion, steps=args.steps, gamma=args.gamma, eps=args.eps,
                                          randinit=args.randinit, clip=args.clip, lr=args.lr, w_lr=args.w_lr,
                                          l1_coef=args.l1_coef, momentum=args.momentum, weight_decay=args.weight_decay)
     optimizer, optimizer_w = trainer.optimizer, trainer.optimizer_w
+    vendor = resnet_s.vendor_convs(model)
+    log("convolutions outside the library's kernels: {}{}".format(
+        len(vendor), " (vendor library, eager launches; --dtype bf16 --layout nhwc is the MFMA path)" if vendor else ""))
     decreasing_lr = list(map(int, args.decreasing_lr.split(",")))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=decreasing_lr, gamma=0.1)
     if args.synthetic:

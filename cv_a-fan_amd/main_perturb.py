@@ -51,6 +51,8 @@ parser.add_argument("--clip", action="store_true", help="whether using clip")
 # ---- additions
 parser.add_argument("--arch", default="resnet56s", choices=sorted(resnet_s.ARCHS))
 parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="backbone compute dtype")
+parser.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
+                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: vendor convolutions)")
 parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of CIFAR-10")
 parser.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
 
@@ -231,13 +233,17 @@ def main(argv=None):
     ctor, _ = resnet_s.ARCHS[args.arch]
     model = ctor()                      # constructed after seeding, on the host generator, like main_perturb.py:64
     layer_number = model.layer_number
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.set_channels_last(args.layout == "nhwc").to(dev)
     criterion = nn.CrossEntropyLoss()
     trainer = train_step.AfanTrainer(model, criterion, steps=args.steps, gamma=args.gamma, eps=args.eps,
                                      perturb_idx=args.perturb_idx, layer_number=layer_number, randinit=args.randinit,
                                      clip=args.clip, lr=args.lr, momentum=args.momentum,
                                      weight_decay=args.weight_decay)
     optimizer = trainer.optimizer
+    vendor = resnet_s.vendor_convs(model)
+    log("convolutions outside the library's kernels: {}{}".format(
+        len(vendor), " (vendor library, eager launches; --dtype bf16 --layout nhwc is the MFMA path)" if vendor else ""))
     decreasing_lr = list(map(int, args.decreasing_lr.split(",")))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=decreasing_lr, gamma=0.1)
 

@@ -12,6 +12,9 @@ from ._lib import AFAN_BF16, AFAN_F32, AFAN_NCHW, AFAN_NHWC, AfanLibraryError, c
 
 _DT = {torch.float32: AFAN_F32, torch.bfloat16: AFAN_BF16}
 _ws_cache = {}
+# how many convolution passes ran on the library's kernels / went to the vendor library since import (tests and the
+# entry points' logs use it to show which path a configuration really takes)
+CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "vendor_conv": 0}
 
 
 def _need(t, name, dtype=None):
@@ -486,6 +489,7 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
     """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last.
     want_stats=True also returns a ConvStats (moments of y around stats_shift[c], e.g. the BN running mean)."""
     lib = _lib.load()
+    CALLS["conv_fwd"] += 1
     _cl4(x, "x"), _cl4(w, "w")
     n, ci, hi, wi = x.shape
     co, ci2, k, k2 = w.shape
@@ -516,6 +520,7 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
     entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward).
     bn_y: that BatchNorm's output after residual add + ReLU (dx's shape): the ReLU mask is bn_y > 0 instead of recomputed."""
     lib = _lib.load()
+    CALLS["conv_dgrad"] += 1
     _cl4(dy, "dy"), _cl4(wt, "wt")
     n, co, ho, wo = dy.shape
     ci, co2, k, _ = wt.shape
@@ -560,6 +565,7 @@ def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False):
     """Weight gradient of y = conv2d(x, w, padding=k//2, stride): returns / adds into an fp32 [Co,Ci,k,k] tensor with
     channels_last strides (KRSC memory, the parameter arena's layout)."""
     lib = _lib.load()
+    CALLS["conv_wgrad"] += 1
     _cl4(x, "x"), _cl4(dy, "dy")
     n, ci, hi, wi = x.shape
     co = dy.shape[1]

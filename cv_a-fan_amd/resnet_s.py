@@ -150,6 +150,7 @@ class _ConvFn(torch.autograd.Function):
                 stats_req.append(st)
                 return y
             return ops.conv_fwd(x, w_lp, stride[0])
+        ops.CALLS["vendor_conv"] += 1
         return torch.ops.aten.convolution(x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1)
 
     @staticmethod
@@ -183,6 +184,7 @@ class _ConvFn(torch.autograd.Function):
                 gw = ops.conv_wgrad(x, gy, k, ctx.stride[0])
             need_gw = False
         if need_gx or need_gw:
+            ops.CALLS["vendor_conv"] += 1
             g2, g3, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, (1, 1), False,
                                                             (0, 0), 1, [need_gx, need_gw, False])
             if need_gx:
@@ -205,6 +207,7 @@ def _wgrad_accumulate(x, dy, c):
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st):
         ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True)
         return
+    ops.CALLS["vendor_conv"] += 1
     gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
                                              [False, True, False])[1]
     c.weight.grad.add_(gw)
@@ -225,6 +228,19 @@ def _own_conv_ok_shape(w, stride, padding):
     if stride[0] != stride[1] or padding[0] != k // 2 or padding[1] != k // 2:
         return False
     return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0])
+
+
+def vendor_convs(model):
+    """Names of the convolutions of `model` whose forward / input gradient would go to the vendor library in its present
+    configuration (fp32 parity mode, NCHW weights, unsupported shapes); the image stem (3 input channels) is not listed.
+    A hipGraph of the training step is only captured when this is empty: a captured vendor input-gradient pass was
+    measured reading memory the graph does not own (tools/diag_graph_piece.py; NaNs after the first validation pass)."""
+    bad = []
+    for name, m in model.named_modules():
+        if isinstance(m, Conv2d) and m.in_channels > 4:
+            if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding):
+                bad.append(name)
+    return bad
 
 
 def _own_conv_ok(x, w, stride, padding):

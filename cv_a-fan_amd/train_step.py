@@ -140,6 +140,7 @@ class AfanTrainer:
         self.graph_warmup = graph_warmup
         self._graph = None
         self._graph_failed = None
+        self._graph_unsafe = None
         self._eager_steps = 0
         self._static_in = None
         self._static_out = None
@@ -237,6 +238,16 @@ class AfanTrainer:
         self._groupable_key, self._groupable = key, bool(ok)
         return self._groupable
 
+    def _graph_safe(self):
+        """Capture only the configuration whose convolutions all run on the library's kernels (bf16, channels-last);
+        anything else (fp32 parity mode, NCHW) keeps eager launches — see resnet_s.vendor_convs."""
+        if self._graph_unsafe is None:
+            from . import resnet_s
+            self._graph_unsafe = resnet_s.vendor_convs(self.model) if hasattr(self.model, "sequential_model") else []
+            if self._graph_unsafe:
+                self.use_graph = False
+        return not self._graph_unsafe
+
     def _step_eager(self, inp, target):
         self.optimizer._sync_lr()
         out = self._forward_backward(inp, target, overlap_allreduce=self.reducer is not None)
@@ -277,7 +288,8 @@ class AfanTrainer:
         if self._graph is not None and self._shape_key == (tuple(inp.shape), inp.dtype, tuple(target.shape)):
             return self._step_graph(inp, target)
         if (self.use_graph and self._graph is None and self._graph_failed is None
-                and self._eager_steps >= self.graph_warmup and inp.is_cuda and self.model.training):
+                and self._eager_steps >= self.graph_warmup and inp.is_cuda and self.model.training
+                and self._graph_safe()):
             try:
                 self._capture(inp, target)
                 return self._step_graph(inp, target)

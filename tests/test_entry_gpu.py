@@ -22,6 +22,11 @@ def _run(args, cwd):
     return r.stdout
 
 
+def _losses(out):
+    import re
+    return [float(v) for v in re.findall(r"Loss (\S+) \(", out)]
+
+
 def test_run_perturb_entry_point(tmp_path, orc):
     cwd = os.path.join(ROOT, "cv_a-fan_amd")          # the reference runs from Classification/, we from the package dir
     line = open(os.path.join(cwd, "cmd", "run_perturb.sh")).read().strip().splitlines()[-1]
@@ -31,6 +36,13 @@ def test_run_perturb_entry_point(tmp_path, orc):
               "--synthetic", "512", "--batch_size", "64", "--print_freq", "2", "--steps", "2"]
     out = _run(common + ["--epochs", "2"], cwd)
     assert "Epoch: [0][0/8]\tLoss" in out and "Epoch: [1][" in out
+    # the entry point runs the product path: every 16+-channel convolution on the library's kernels, one hipGraph
+    assert "convolutions outside the library's kernels: 0" in out
+    # ... and the captured step survives the eager validation passes between epochs (regression: a graph holding vendor
+    # convolutions read freed memory -> NaN from the first iteration of epoch 1)
+    import math
+    ls = _losses(out)
+    assert len(ls) >= 8 and all(math.isfinite(v) for v in ls), ls
     assert "l2 mean = " in out and "linf mean = " in out and "train_accuracy" in out and "valid_accuracy" in out
     for f in ("checkpoint.pt", "best_model.pt", "result.pkl", "result_norm.pkl"):
         assert os.path.exists(os.path.join(save, f)), f
@@ -68,6 +80,9 @@ def test_main_learnable_entry_point(tmp_path, orc):
 
     out = run(["--epochs", "1"])
     assert "weight1 = " in out and "weight9 = " in out and "Epoch: [0][0/4]\tLoss" in out
+    assert "convolutions outside the library's kernels: 0" in out
+    import math
+    assert all(math.isfinite(v) for v in _losses(out))
     assert "l2 mean = " in out and "linf mean = " in out and "valid_accuracy" in out
     ck = torch.load(os.path.join(save, "checkpoint.pt"), map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "state_dict", "best_prec1", "optimizer", "optimizer_w", "scheduler"} and ck["epoch"] == 1
