@@ -21,6 +21,7 @@
 // Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64.
 #include "afan_common.h"
 #include "afan_conv_c64.h"
+#include "afan_conv_stem.h"
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
@@ -539,6 +540,7 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
 extern "C" {
 
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
+    if (ci == 3) return afan_stem::eligible(1, 1, 32, ci, co, k, stride) ? 1 : 0;   // image stem (forward only; width % 32 == 0)
     // forward needs channels_ok(ci, co), the input gradient channels_ok(co, ci): both must hold for a layer to be taken
     return (channels_ok(ci, co) && channels_ok(co, ci) && (k == 1 || k == 3) && (stride == 1 || stride == 2)) ? 1 : 0;
 }
@@ -556,6 +558,15 @@ int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                             int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
                             double* stats_acc, int groups, afan_stream_t stream) {
+    if (ci == 3) {                                              // the image stem has its own kernel
+        if (!afan_stem::eligible(n, hi, wi, ci, co, k, stride) || stats_partials || groups > 1) return AFAN_ESHAPE;
+        if (!x || !w || !y) return AFAN_ENULL;
+        if (!aligned(x, 2) || !aligned(w, 2) || !aligned(y, 16) || (stats_acc && !aligned(stats_acc, 16))) return AFAN_EALIGN;
+        hipStream_t st = (hipStream_t)stream;
+        const double M = (double)n * hi * wi;
+        AFAN_PROF_FLOPS("conv_stem_fwd_kernel", 2.0 * (M * co + M * 3 + 27.0 * co), 2.0 * M * co * 27, st);
+        return afan_stem::fwd_launch(x, w, y, n, hi, wi, co, stats_acc, afan_nhwc::acc_slot_count(co), stats_shift, st);
+    }
     int e = check_dims(n, hi, wi, ci, co, k, stride);
     if (e) return e;
     if (!x || !w || !y) return AFAN_ENULL;

@@ -452,11 +452,14 @@ def conv_supported(ci, co, k, stride):
     small-channel kernel, whose BatchNorm fusions exist in the accumulator form only."""
     if not _lib.load().afan_conv_supported(int(ci), int(co), int(k), int(stride)):
         return False
-    return BN_ACC or (ci % 64 == 0 and co % 64 == 0)
+    return BN_ACC or ci == 3 or (ci % 64 == 0 and co % 64 == 0)
 
 
 def conv_wgrad_supported(ci, co, k, stride):
-    """The weight-gradient kernel tiles 64 x 64 (co x ci); smaller layers leave wgrad to the vendor library."""
+    """The weight-gradient kernel tiles 64 x 64 (co x ci); smaller layers leave wgrad to the vendor library.  The
+    3-channel image stem has its own kernel."""
+    if ci == 3:     # image stem (afan_conv_stem.hip); the caller also needs the image width to be a multiple of 32
+        return bool(_lib.load().afan_conv_supported(3, int(co), int(k), int(stride)))
     return ci % 64 == 0 and co % 64 == 0 and k in (1, 3) and stride in (1, 2)
 
 
@@ -503,6 +506,8 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
         raise ValueError("grouped statistics need the accumulator path")
     if want_stats and _conv_acc_ok(co):
         st = ConvStats(None, 0, stats_shift, acc_take(x.device, co, groups))
+    elif want_stats and ci == 3:
+        pass            # the stem kernel sums moments into accumulator blocks only: without them BatchNorm reduces itself
     elif want_stats:
         g = lib.afan_conv_fwd_tiles(n, hi, wi, ci, co, k, stride)
         if stats_buf is None or stats_buf.numel() < 2 * co * g:

@@ -237,7 +237,7 @@ def vendor_convs(model):
     measured reading memory the graph does not own (tools/diag_graph_piece.py; NaNs after the first validation pass)."""
     bad = []
     for name, m in model.named_modules():
-        if isinstance(m, Conv2d) and m.in_channels > 4:
+        if isinstance(m, Conv2d) and m.in_channels > 4:       # (the stem decides by image width at run time)
             if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding):
                 bad.append(name)
     return bad
@@ -245,6 +245,8 @@ def vendor_convs(model):
 
 def _own_conv_ok(x, w, stride, padding):
     if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    if x.shape[1] == 3 and x.shape[3] % 32:      # the stem kernel walks 32-pixel row segments
         return False
     return _own_conv_ok_shape(w, stride, padding)
 

@@ -204,8 +204,10 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
  * `model(x_adv, end_point, start_point)` (attack_algo.py:50; resnet_s.py:52-54,66,72-73) and its input-gradient
  * (attack_algo.py:52), implicit-GEMM kernels of this library.  k in {1,3}, padding k/2, stride in {1,2},
  * Ci % 64 == 0 and Co % 64 == 0, or — the reference's own 16-32-64-channel CIFAR ResNets — Ci, Co in {16, 32, 64}
- * (afan_conv_supported() tells; the 3-channel stem stays with the vendor library).  Layers with a 16/32-channel side
- * take the small-channel kernel, whose statistics fusions exist in the accumulator form (stats_acc / bn_acc) only.
+ * (afan_conv_supported() tells).  Layers with a 16/32-channel side take the small-channel kernel, whose statistics
+ * fusions exist in the accumulator form (stats_acc / bn_acc) only.  The image stem (resnet_s.py:88: Ci == 3, k == 3,
+ * stride 1, Co in {16, 32, 64}, image width % 32 == 0) has its own forward kernel (moments: accumulator form only, no
+ * image groups) and weight-gradient kernel; it has no input gradient (the images carry none).
  *   fwd  : y[N,Ho,Wo,Co]  = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci])
  *   dgrad: dx[N,Hi,Wi,Ci] = conv_transpose(dy[N,Ho,Wo,Co], w)  given  wt[Ci,k,k,Co] = w transposed
  */

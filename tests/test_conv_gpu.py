@@ -62,11 +62,78 @@ def test_conv_identity_kernel_is_exact(pkg, gpu):
 
 
 def test_conv_rejects_unsupported(pkg, gpu):
-    assert not pkg.ops.conv_supported(3, 64, 3, 1)
-    x = _cl(torch.randn(1, 3, 8, 8, device=gpu).bfloat16())
+    assert not pkg.ops.conv_supported(3, 48, 3, 1) and not pkg.ops.conv_supported(3, 64, 3, 2)
+    assert not pkg.ops.conv_supported(24, 64, 3, 1)
+    x = _cl(torch.randn(1, 3, 8, 8, device=gpu).bfloat16())        # stem kernel: image width must be a multiple of 32
     w = _cl(torch.randn(64, 3, 3, 3, device=gpu).bfloat16())
     with pytest.raises(pkg.AfanLibraryError):
         pkg.ops.conv_fwd(x, w, 1)
+    x = _cl(torch.randn(1, 24, 8, 8, device=gpu).bfloat16())
+    w = _cl(torch.randn(64, 24, 3, 3, device=gpu).bfloat16())
+    with pytest.raises(pkg.AfanLibraryError):
+        pkg.ops.conv_fwd(x, w, 1)
+
+
+STEM = [  # n, co, h, w   (afan_conv_stem.hip: 3 image channels, 3x3, stride 1)
+    (4, 64, 32, 32), (3, 16, 32, 32), (5, 32, 8, 64), (1, 64, 1, 32), (2, 64, 5, 96), (256, 64, 32, 32), (130, 16, 32, 32),
+]
+
+
+@pytest.mark.parametrize("n,co,h,w", STEM)
+def test_stem_forward_moments_and_wgrad(pkg, gpu, bn_mode, n, co, h, w):
+    torch.manual_seed(n + co + h + w)
+    assert pkg.ops.conv_supported(3, co, 3, 1) and pkg.ops.conv_wgrad_supported(3, co, 3, 1)
+    x = _cl(torch.randn(n, 3, h, w, device=gpu).bfloat16())
+    wt = _cl((torch.randn(co, 3, 3, 3, device=gpu) / 27 ** 0.5).bfloat16())
+    y = pkg.ops.conv_fwd(x, wt, 1)
+    ref = F.conv2d(x.float(), wt.float(), None, 1, 1)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    # 27 products of bf16 values summed in fp32, one bf16 rounding (an ulp where the fp32 sums straddle a tie)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-3)
+    # moments for the following train-mode BatchNorm (accumulator form; the slab mode lets BatchNorm reduce itself)
+    shift = torch.randn(co, device=gpu) * 0.1
+    y2, st = pkg.ops.conv_fwd(x, wt, 1, stats_shift=shift, want_stats=True)
+    assert torch.equal(y2, y)
+    if bn_mode == "acc":
+        assert st is not None and st.acc is not None
+        gamma, beta = torch.rand(co, device=gpu) + 0.5, torch.randn(co, device=gpu)
+        outs = []
+        for cs in (None, st):
+            rm, rv = shift.clone(), torch.ones(co, device=gpu)
+            nbt = torch.zeros((), dtype=torch.int64, device=gpu)
+            o, stats = pkg.ops.bn_train_forward(y, gamma, beta, None, True, 1e-5, 0.1, rm, rv, nbt, cs)
+            outs.append((o.float().cpu().numpy(), stats.cpu().numpy(), rm.cpu().numpy(), rv.cpu().numpy()))
+        a, b = outs
+        np.testing.assert_allclose(b[1][:2], a[1][:2], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(b[2], a[2], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(b[3], a[3], rtol=2e-5)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-2, atol=1e-2)
+    else:
+        assert st is None
+    # weight gradient
+    dy = _cl((torch.randn(n, co, h, w, device=gpu) / (n * h * w) ** 0.5).bfloat16())
+    gref = torch.ops.aten.convolution_backward(dy.float(), x.float(), torch.zeros(co, 3, 3, 3, device=gpu), None, (1, 1),
+                                               (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])[1]
+    g = pkg.ops.conv_wgrad(x, dy, 3, 1)
+    assert g.shape == gref.shape and g.dtype == torch.float32
+    scale = float(gref.abs().max())
+    np.testing.assert_allclose(g.cpu().numpy(), gref.cpu().numpy(), rtol=2e-3, atol=2e-3 * scale)
+    acc = torch.ones((co, 3, 3, 3), device=gpu).contiguous(memory_format=torch.channels_last)
+    pkg.ops.conv_wgrad(x, dy, 3, 1, acc, accumulate=True)
+    pkg.ops.conv_wgrad(x, dy, 3, 1, acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), 1 + 2 * gref.cpu().numpy(), rtol=2e-3, atol=4e-3 * scale)
+    assert torch.equal(pkg.ops.conv_wgrad(x, dy, 3, 1), g)          # fixed summation order
+
+
+def test_stem_shift_kernel_is_exact(pkg, gpu):
+    """Tap / channel order: a kernel that copies input channel c of the pixel at (h-1, w+1) into output channel c."""
+    x = _cl(torch.randn(2, 3, 4, 32, device=gpu).bfloat16())
+    w = torch.zeros(16, 3, 3, 3, device=gpu)
+    w[torch.arange(3), torch.arange(3), 0, 2] = 1.0
+    y = pkg.ops.conv_fwd(x, _cl(w.bfloat16()), 1)
+    ref = torch.zeros(2, 16, 4, 32, device=gpu, dtype=torch.bfloat16)
+    ref[:, :3, 1:, :-1] = x[:, :, :-1, 1:]
+    assert torch.equal(y, _cl(ref))
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 256, 512, 8, 1, 2),

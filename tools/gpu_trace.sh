@@ -2,7 +2,7 @@
 # per-dispatch durations of the default bench, aggregated by (kernel, grid): gpurun_out/trace_by_grid.txt
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no_cpu_baseline --no_roofline > /tmp/bench_trace.log 2>&1
+rm -rf /tmp/trace_out; cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no_cpu_baseline --no_roofline > /tmp/bench_trace.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections
@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f)))
 print(rows[0].keys())
 for r in rows:
     name = r['Kernel_Name']
-    if 'conv' not in name and 'wgrad' not in name: continue
+    if 'conv' not in name and 'wgrad' not in name and 'stem' not in name: continue
     short = name.split('(')[0][-60:]
     key = (short, r.get('Grid_Size_X', r.get('Grid_Size')), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'), r.get('Workgroup_Size_X', r.get('Workgroup_Size')))
     agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
