@@ -26,8 +26,9 @@ def _poison(dev):
     return keep
 
 
-@pytest.mark.parametrize("arch,idx,batch", [("resnet18", 6, 64), ("resnet20s", 7, 64)])
-def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch):
+@pytest.mark.parametrize("arch,idx,batch,side,classes", [("resnet18", 6, 64, 32, 10), ("resnet20s", 7, 64, 32, 10),
+                                                         ("resnet56s", 13, 32, 32, 10), ("resnet50", 8, 8, 224, 1000)])
+def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch, side, classes):
     torch.manual_seed(0)
     ctor, _ = pkg.resnet_s.ARCHS[arch]
     model = ctor()
@@ -35,8 +36,8 @@ def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch):
     tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.01)
     assert not pkg.resnet_s.vendor_convs(model)
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(batch, 3, 32, 32, generator=g).to(gpu)
-    y = torch.randint(0, 10, (batch,), generator=g).to(gpu)
+    x = torch.rand(batch, 3, side, side, generator=g).to(gpu)
+    y = torch.randint(0, classes, (batch,), generator=g).to(gpu)
     for _ in range(5):
         r = tr.step(x, y)
     assert tr._graph is not None, tr._graph_failed
