@@ -16,6 +16,7 @@
 // zero/cast passes of the vendor path all disappear.
 #include "afan_common.h"
 #include "afan_conv_stem.h"
+#include "afan_wgrad_small.h"
 #include <stdlib.h>
 
 using namespace afan;
@@ -225,6 +226,7 @@ extern "C" {
 // floats of workspace the call below needs for its partial slabs
 int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (ci == 3) return afan_stem::eligible(n, hi, wi, ci, co, k, stride) ? afan_stem::wgrad_workspace_floats(n, hi, wi, co) : 0;
+    if (afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) return afan_wgrad_small::workspace_floats(n, hi, wi, ci, co, stride);
     if (n <= 0 || hi <= 0 || wi <= 0 || ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2))
         return 0;
     const int pad = k / 2;
@@ -245,6 +247,14 @@ int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_
         const double M = (double)n * hi * wi;
         AFAN_PROF_FLOPS("conv_stem_wgrad_kernel", 2.0 * (M * co + M * 3), 2.0 * M * co * 27, st);
         return afan_stem::wgrad_launch(x, dy, grad, n, hi, wi, co, workspace, accumulate, st);
+    }
+    if (afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) {     // 16/32-channel layers
+        if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
+        if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 4) || !aligned(workspace, 16)) return AFAN_EALIGN;
+        hipStream_t st = (hipStream_t)stream;
+        const double P = (double)n * ((hi - 1) / stride + 1) * ((wi - 1) / stride + 1);
+        AFAN_PROF_FLOPS("conv_wgrad_small_kernel", 2.0 * (P * co + (double)n * hi * wi * ci), 2.0 * P * co * ci * 9, st);
+        return afan_wgrad_small::launch(x, dy, grad, n, hi, wi, ci, co, stride, workspace, accumulate, st);
     }
     if (ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
     if (!x || !dy || !grad || !workspace) return AFAN_ENULL;

@@ -455,12 +455,16 @@ def conv_supported(ci, co, k, stride):
     return BN_ACC or ci == 3 or (ci % 64 == 0 and co % 64 == 0)
 
 
-def conv_wgrad_supported(ci, co, k, stride):
-    """The weight-gradient kernel tiles 64 x 64 (co x ci); smaller layers leave wgrad to the vendor library.  The
-    3-channel image stem has its own kernel."""
-    if ci == 3:     # image stem (afan_conv_stem.hip); the caller also needs the image width to be a multiple of 32
-        return bool(_lib.load().afan_conv_supported(3, int(co), int(k), int(stride)))
-    return ci % 64 == 0 and co % 64 == 0 and k in (1, 3) and stride in (1, 2)
+def conv_wgrad_supported(ci, co, k, stride, in_shape=None):
+    """The tiled weight-gradient kernel takes co, ci multiples of 64.  With in_shape = (n, hi, wi) also: the image stem
+    (ci == 3, afan_conv_stem.hip) and the 3x3 layers with a 16/32-channel side (afan_wgrad_small.hip), which walk whole
+    image rows and so depend on the spatial size.  Anything else leaves wgrad to the vendor library."""
+    if ci % 64 == 0 and co % 64 == 0:
+        return k in (1, 3) and stride in (1, 2)
+    if in_shape is None:
+        return False
+    n, hi, wi = (int(v) for v in in_shape)
+    return _lib.load().afan_conv_wgrad_workspace_floats(n, hi, wi, int(ci), int(co), int(k), int(stride)) > 0
 
 
 def _cl4(t, name):

@@ -164,7 +164,8 @@ class _ConvFn(torch.autograd.Function):
         if need_gx and own:
             gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0])
             need_gx = False
-        if need_gw and own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], w_lp.shape[2], ctx.stride[0]):
+        if need_gw and own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], w_lp.shape[2], ctx.stride[0],
+                                                        (x.shape[0], x.shape[2], x.shape[3])):
             w_master = ctx.w_master
             k = w_lp.shape[2]
             if _accumulates_in_place(w_master) and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
@@ -204,7 +205,7 @@ def _wgrad_accumulate(x, dy, c):
     """Weight gradient of conv module c added into its arena gradient view: the library's kernel where it tiles, else
     (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
     k, st = c.kernel_size[0], c.stride[0]
-    if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st):
+    if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
         ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True)
         return
     ops.CALLS["vendor_conv"] += 1

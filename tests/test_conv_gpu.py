@@ -82,7 +82,7 @@ STEM = [  # n, co, h, w   (afan_conv_stem.hip: 3 image channels, 3x3, stride 1)
 @pytest.mark.parametrize("n,co,h,w", STEM)
 def test_stem_forward_moments_and_wgrad(pkg, gpu, bn_mode, n, co, h, w):
     torch.manual_seed(n + co + h + w)
-    assert pkg.ops.conv_supported(3, co, 3, 1) and pkg.ops.conv_wgrad_supported(3, co, 3, 1)
+    assert pkg.ops.conv_supported(3, co, 3, 1) and pkg.ops.conv_wgrad_supported(3, co, 3, 1, (n, h, w))
     x = _cl(torch.randn(n, 3, h, w, device=gpu).bfloat16())
     wt = _cl((torch.randn(co, 3, 3, 3, device=gpu) / 27 ** 0.5).bfloat16())
     y = pkg.ops.conv_fwd(x, wt, 1)
@@ -164,7 +164,20 @@ def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, bn_mode, n, ci, co, h, k
     assert a[4] == b[4] == 1
 
 
-@pytest.mark.parametrize("n,ci,co,h,k,stride", CASES + [(256, 128, 128, 16, 3, 1), (7, 64, 64, 5, 3, 1)])
+SMALL_WGRAD = [  # afan_wgrad_small.hip: every 16/32-channel 3x3 layer of ResNet-20s / 56s, and more tile geometries
+    (128, 16, 16, 32, 3, 1), (128, 16, 32, 32, 3, 2), (128, 32, 32, 16, 3, 1), (128, 32, 64, 16, 3, 2), (3, 32, 32, 8, 3, 1),
+    (2, 16, 16, 64, 3, 1), (1, 32, 16, 16, 3, 1), (5, 16, 64, 32, 3, 2), (300, 16, 16, 32, 3, 1),
+]
+
+
+def test_small_wgrad_cases_are_taken_by_the_library(pkg, gpu):
+    for n, ci, co, h, k, stride in SMALL_WGRAD:
+        assert pkg.ops.conv_wgrad_supported(ci, co, k, stride, (n, h, h)), (n, ci, co, h, k, stride)
+    assert not pkg.ops.conv_wgrad_supported(16, 16, 3, 1, (2, 7, 7)) and not pkg.ops.conv_wgrad_supported(16, 32, 1, 2, (2, 8, 8))
+    assert not pkg.ops.conv_wgrad_supported(16, 16, 3, 1)          # no spatial size given: only the 64-multiple rule
+
+
+@pytest.mark.parametrize("n,ci,co,h,k,stride", CASES + [(256, 128, 128, 16, 3, 1), (7, 64, 64, 5, 3, 1)] + SMALL_WGRAD)
 def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
     torch.manual_seed(n + ci + co + h + k + stride)
     x = _cl(torch.randn(n, ci, h, h, device=gpu).bfloat16())
@@ -173,7 +186,7 @@ def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
     w = torch.zeros(co, ci, k, k, device=gpu)
     ref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w, None, (stride, stride), (k // 2, k // 2), (1, 1),
                                               False, (0, 0), 1, [False, True, False])[1]
-    if not pkg.ops.conv_wgrad_supported(ci, co, k, stride):      # 16/32-channel layers: left to the vendor library
+    if not pkg.ops.conv_wgrad_supported(ci, co, k, stride, (n, h, h)):   # odd sizes / 1x1 of the small-channel layers: vendor library
         with pytest.raises(pkg.AfanLibraryError):
             pkg.ops.conv_wgrad(x, dy, k, stride)
         return

@@ -70,3 +70,25 @@ def test_vendor_configurations_are_not_captured(pkg, gpu):
     assert tr._graph is None and tr.use_graph is False
     assert pkg.ops.CALLS["vendor_conv"] > before["vendor_conv"]
     assert math.isfinite(float(r["loss"]))
+
+
+def test_learnable_captured_step_owns_its_memory(pkg, gpu):
+    """The learnable multi-layer step (main_learnable.py) is replayed from a hipGraph too: same requirement."""
+    torch.manual_seed(0)
+    model = pkg.resnet_s.resnet56(init_weight_eta=1 / 9)
+    model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+    tr = pkg.learnable.LearnableTrainer(model, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, lr=0.01, w_lr=0.01,
+                                        l1_coef=0.1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(32, 3, 32, 32, generator=g).to(gpu)
+    y = torch.randint(0, 10, (32,), generator=g).to(gpu)
+    for _ in range(5):
+        r = tr.step(x, y)
+    assert tr._graph is not None, tr._graph_failed
+    keep = _poison(gpu)
+    del keep
+    for _ in range(3):
+        r = tr.step(x, y)
+        junk = torch.full((1 << 22,), float("nan"), device=gpu)       # eager allocations between replays
+        del junk
+    assert math.isfinite(float(r["loss"])) and torch.isfinite(r["w"]).all() and torch.isfinite(r["l2"]).all()

@@ -85,3 +85,13 @@ def test_main_perturb_flags(pkg):
     assert (a.print_freq, a.seed, a.gpu, a.resume, a.save_dir) == (50, None, 0, False, "res56s_adv_aug")
     b = mp.parser.parse_args("--seed 3 --save_dir x --gamma 0.5".split())      # cmd/run_perturb.sh
     assert (b.seed, b.save_dir, b.gamma) == (3, "x", 0.5)
+
+
+def test_vendor_convs_lists_what_leaves_the_library(pkg):
+    """resnet_s.vendor_convs decides whether the step may be captured as a hipGraph: fp32 parity mode runs every
+    convolution in the vendor library (all 16+-channel convolutions are listed); the image stem is never listed."""
+    m = pkg.resnet_s.resnet20()
+    names = pkg.resnet_s.vendor_convs(m)
+    convs = [n for n, mod in m.named_modules() if isinstance(mod, pkg.resnet_s.Conv2d) and mod.in_channels > 4]
+    assert names == convs and len(names) == 18 + 0 * len(convs)
+    assert set(pkg.ops.CALLS) == {"conv_fwd", "conv_dgrad", "conv_wgrad", "vendor_conv"}
