@@ -92,3 +92,33 @@ def test_learnable_captured_step_owns_its_memory(pkg, gpu):
         junk = torch.full((1 << 22,), float("nan"), device=gpu)       # eager allocations between replays
         del junk
     assert math.isfinite(float(r["loss"])) and torch.isfinite(r["w"]).all() and torch.isfinite(r["l2"]).all()
+
+
+def test_ragged_last_batch_runs_eagerly_beside_the_graph(pkg, gpu, orc):
+    """The reference's loaders keep the last, smaller batch (drop_last=False): a captured step serves its own shape only;
+    another batch size takes eager launches on the same weights, and the graph keeps working afterwards.  The smaller
+    batch is not a multiple of any tile (odd image count): it also checks the kernels' row masks end to end against
+    the oracle."""
+    torch.manual_seed(0)
+    model = pkg.resnet_s.resnet20()
+    ref = orc.resnet20s()
+    ref.load_state_dict({k: v.clone() for k, v in model.state_dict().items()})
+    model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=7, lr=0.0)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(64, 3, 32, 32, generator=g)
+    y = torch.randint(0, 10, (64,), generator=g)
+    for _ in range(5):
+        tr.step(x.to(gpu), y.to(gpu))
+    assert tr._graph is not None
+    xs, ys = x[:37], y[:37]
+    r = tr.step(xs.to(gpu), ys.to(gpu))                     # eager: different shape
+    assert r["l2"].shape == (37,) and math.isfinite(float(r["loss"]))
+    # lr = 0: weights unchanged (running statistics move, training-mode passes do not read them) -> comparable to the oracle
+    ref.train()
+    r_ref = orc.afan_train_step(ref, orc.make_optimizer(ref, lr=0.0), nn.CrossEntropyLoss(), xs, ys, steps=2, gamma=0.5,
+                                eps=2.0, perturb_idx=7, layer_number=16)
+    assert abs(float(r["loss_clean"]) - float(r_ref["loss_clean"])) < 5e-2       # bf16 backbone vs fp32 oracle
+    assert abs(float(r["loss"]) - float(r_ref["loss"])) < 8e-2
+    r2 = tr.step(x.to(gpu), y.to(gpu))                      # the captured shape again: replay
+    assert tr._graph is not None and math.isfinite(float(r2["loss"])) and r2["l2"].shape == (64,)
