@@ -472,7 +472,8 @@ def test_elementwise_kernels_accept_channels_last(pkg, gpu, c_oracle):
     np.testing.assert_array_equal(a.cpu().numpy(), ((img - m[None, :, None, None]) / s[None, :, None, None]).cpu().numpy())
 
 
-@pytest.mark.parametrize("shape,k", [((32, 512, 4, 4), 10), ((6, 64, 8, 8), 10), ((3, 2048, 7, 7), 16), ((4, 64, 1, 1), 7)])
+@pytest.mark.parametrize("shape,k", [((32, 512, 4, 4), 10), ((6, 64, 8, 8), 10), ((3, 2048, 7, 7), 16), ((4, 64, 1, 1), 7),
+                                     ((512, 512, 4, 4), 10), ((5, 24, 3, 3), 3)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_fused_classifier_head_matches_torch(pkg, gpu, shape, k, dt):
     """afan_head_forward / _backward against pool -> flatten -> linear in torch fp32 on the same values."""
