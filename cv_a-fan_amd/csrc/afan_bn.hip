@@ -34,6 +34,7 @@ int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, v
             hipStream_t st, int groups);
 int acc_supported(int dtype, int64_t C);
 int64_t acc_doubles(int64_t C);
+int set_running_updates(int n);
 }
 
 namespace {
@@ -518,6 +519,11 @@ int afan_bn_train_forward(const void* x, const void* residual, void* y, int dtyp
     if (layout == AFAN_NHWC)
         return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, eps, momentum, weight, bias, relu, workspace, save_stats,
                               nullptr, nullptr, running_mean, running_var, num_batches, true, st, nullptr, 0, nullptr);
+    {   // the NCHW kernels apply one running-statistics update per pass: refuse a pending repeat count loudly
+        const int pending = afan_nhwc::set_running_updates(1);
+        afan_nhwc::set_running_updates(pending);
+        if (pending != 1) return AFAN_ESHAPE;
+    }
     if (dtype == AFAN_F32)
         return bn_forward_impl<float>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
     return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, eps, momentum, weight, bias, relu, workspace, save_stats, save_stats + c, running_mean, running_var, num_batches, true, st);
@@ -588,6 +594,8 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
 }
 
 int64_t afan_bn_acc_doubles(int64_t c) { return afan_nhwc::acc_doubles(c); }
+
+int afan_bn_set_running_updates(int n) { return afan_nhwc::set_running_updates(n); }
 
 int afan_bn_acc_supported(int dtype, int64_t c) {
     if (dtype != AFAN_F32 && dtype != AFAN_BF16) return 0;

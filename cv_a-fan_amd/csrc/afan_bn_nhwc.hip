@@ -103,6 +103,12 @@ inline int acc_slots(int64_t C) {   // NS * C <= 1024, 1 <= NS <= 16, power of t
 
 int64_t acc_doubles(int64_t C);   // doubles per accumulator block (defined with the entry points below)
 
+// How many identical train-mode forward passes the next BatchNorm forward launches of this host thread stand for (1 by
+// default): the running statistics are updated that many times, in sequence, from the same batch moments —
+// main_perturb.py:173 and :196 run the head twice on the same images with the same weights (afan_bn_set_running_updates).
+static thread_local int g_running_updates = 1;
+static inline int running_updates() { return g_running_updates; }
+
 template <int VEC, int NQ>
 __device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV, int C, int NS,
                                                   double* __restrict__ out) {
@@ -181,7 +187,8 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
                                                          const float* __restrict__ weight,
                                                          const float* __restrict__ bias, float* stats, float* coef,
                                                          float* rmean, float* rvar, int64_t* nbt, float* dweight,
-                                                         float* dbias, int accumulate, const float* shift_ptr) {
+                                                         float* dbias, int accumulate, const float* shift_ptr,
+                                                         int updates) {
     const int c = blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -206,11 +213,12 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
         stats[C + c] = is;
         stats[2 * C + c] = alpha;
         stats[3 * C + c] = beta;
-        if (rmean) {
-            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
-            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (m2 / (m_count - 1.0f));
-        }
-        if (c == 0 && nbt) *nbt += 1;
+        if (rmean)
+            for (int u = 0; u < updates; ++u) {    // updates > 1: this pass stands for that many identical train-mode passes
+                rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (m2 / (m_count - 1.0f));
+            }
+        if (c == 0 && nbt) *nbt += updates;
     } else {
         const float is = stats[C + c], alpha = stats[2 * C + c];
         const float sum_g = a, sum_gx = b * is;
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
                                                           float eps, float momentum, const float* __restrict__ weight,
                                                           const float* __restrict__ bias, float* __restrict__ stats,
                                                           float* rmean, float* rvar, int64_t* nbt, int shift_in_acc,
-                                                          int64_t acc_stride) {
+                                                          int64_t acc_stride, int updates) {
     // gridDim.y = image groups (half-batches with separate statistics): group g owns rows [g*nvec, (g+1)*nvec) vectors,
     // accumulator block acc + g*acc_stride and stats + g*4*C.  The running statistics see the groups as consecutive
     // forward passes: block (0, 0) alone applies all the updates, in group order.
@@ -458,11 +466,12 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
             stats_g[2 * C + c] = alpha;
             stats_g[3 * C + c] = beta;
             if (grp == 0) {
-                if (rmean) {
-                    rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
-                    rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
-                }
-                if (c == 0 && nbt) *nbt += G;
+                if (rmean)
+                    for (int u = 0; u < updates; ++u) {   // updates > 1: stands for that many identical passes (ungrouped)
+                        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
+                        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
+                    }
+                if (c == 0 && nbt) *nbt += G * updates;
                 // the later groups' running-stat updates, in order
                 if constexpr (GROUPED) for (int gg = 1; gg < G; ++gg) {
                     const double* ag = acc + (int64_t)gg * acc_stride;
@@ -619,7 +628,7 @@ int run_stats(const Plan& p, const T* x_, int64_t M, int64_t C, float eps, float
     AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * p.G, st);
     finalize_kernel<T, 0><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(ws, p.G, (int)C, x_, 1.0f / (float)M, (float)M, eps,
                                                                       momentum, weight, bias, stats, nullptr, rmean,
-                                                                      rvar, nbt, nullptr, nullptr, 0, nullptr);
+                                                                      rvar, nbt, nullptr, nullptr, 0, nullptr, running_updates());
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -640,7 +649,7 @@ int forward(const void* x, const void* res, void* y, int64_t M, int64_t C, float
         AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * partials_g, st);
         finalize_kernel<T, 0><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
             partials, (int)partials_g, (int)C, nullptr, 1.0f / (float)M, (float)M, eps, momentum, weight, bias, stats,
-            nullptr, rmean, rvar, nbt, nullptr, nullptr, 0, partials_shift);
+            nullptr, rmean, rvar, nbt, nullptr, nullptr, 0, partials_shift, running_updates());
         AFAN_LAUNCH_CHECK();
     } else if (train) {
         int e = run_stats<T>(p, x_, M, C, eps, momentum, weight, bias, ws, stats, rmean, rvar, nbt, st);
@@ -704,7 +713,7 @@ int backward(const void* dy, const void* x, const void* y, void* dx, void* dres,
         AFAN_PROF("bn_nhwc_finalize_kernel", 8.0 * C * red_g, st);
         finalize_kernel<T, 1><<<(unsigned)((C + 3) / 4), BLOCK, 0, st>>>(
             red, red_g, (int)C, nullptr, 1.0f / (float)M, (float)M, 0.f, 0.f, nullptr, nullptr, const_cast<float*>(stats),
-            coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate, nullptr);
+            coef, nullptr, nullptr, nullptr, dweight, dbias, accumulate, nullptr, 1);
     }
     AFAN_LAUNCH_CHECK();
     const int grid = apply_grid(p, M * C);
@@ -752,7 +761,8 @@ int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, f
 #define AFAN_GO1(RES, RELU, GR)                                                                                   \
     apply_acc_kernel<T, NV, RES, RELU, GR><<<grid, BLOCK, lds, st>>>(x_, r_, y_, p.nvec, p.CV, (int)C, NS, acc, shift,   \
                                                                    inv_m, unbias, eps, momentum, weight, bias, stats,  \
-                                                                   rmean, rvar, nbt, acc_ready, acc_stride)
+                                                                   rmean, rvar, nbt, acc_ready, acc_stride,        \
+                                                                   groups > 1 ? 1 : running_updates())
 #define AFAN_GO(RES, RELU) do { if (groups > 1) AFAN_GO1(RES, RELU, true); else AFAN_GO1(RES, RELU, false); } while (0)
     if (res) { if (relu) AFAN_GO(true, true); else AFAN_GO(true, false); }
     else { if (relu) AFAN_GO(false, true); else AFAN_GO(false, false); }
@@ -842,6 +852,11 @@ int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void*
     return dtype == AFAN_F32
                ? backward<float>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g)
                : backward<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g);
+}
+int set_running_updates(int n) {
+    const int old = g_running_updates;
+    g_running_updates = n < 1 ? 1 : n;
+    return old;
 }
 // partials [2][C][MAX_G] + coef [2][C] + eval-mode stats [4][C]
 int64_t workspace_floats(int64_t c) { return c > 0 ? 2 * c * MAX_G + 2 * c + 4 * c : 0; }

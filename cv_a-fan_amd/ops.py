@@ -137,6 +137,23 @@ def _nchw(t):
     return n, c, hw
 
 
+class bn_running_updates:
+    """Context: the channels-last train-mode BatchNorm forwards issued inside stand for `n` identical passes — their
+    running statistics are updated n times in sequence (afan_bn_set_running_updates; main_perturb.py:173 + :196 run the
+    head twice on the same images with the same weights)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old = _lib.load().afan_bn_set_running_updates(self.n)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().afan_bn_set_running_updates(self.old)
+        return False
+
+
 # ---------------------------------------------------------------------------------------------- PGD
 def pgd_step_(x_adv, grad, gamma, x_clean=None, eps=0.0, clip=False, shadow=None):
     """In place: x_adv += gamma*sign(grad) [then project onto the eps-ball around x_clean]."""

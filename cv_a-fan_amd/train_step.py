@@ -119,7 +119,8 @@ class AfanTrainer:
 
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
-                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True):
+                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True,
+                 share_head=True):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -136,6 +137,7 @@ class AfanTrainer:
         self.batch_final = bool(batch_final)      # adv + clean final passes as one grouped pass over the tail
         self._groupable_key, self._groupable = None, False
         self._wgrad_stream = None
+        self.share_head = bool(share_head)
         self.use_graph = bool(use_graph) and not randinit
         self.graph_warmup = graph_warmup
         self._graph = None
@@ -153,8 +155,19 @@ class AfanTrainer:
         if inp.is_cuda:
             from . import ops
             ops.acc_reset(inp.device)   # BatchNorm accumulator arena: one memset per step, blocks are bump-allocated
-        with torch.no_grad():  # main_perturb.py:173 (.detach()): values and BN side effects are identical
-            feature_map = m(inp, end_point=idx, start_point=0)
+        # main_perturb.py:173 runs the head detached for PGD and :196 runs it again inside the clean forward: same images,
+        # same weights, same values; each head BatchNorm updates its running statistics twice from the same moments.
+        # On the channels-last kernels ONE head pass (with its autograd graph) stands for both: the BatchNorm launches apply
+        # their running-statistics update twice (ops.bn_running_updates).  Otherwise: a no_grad pass here, a second below.
+        fm_clean = None
+        if self._share_head(inp):
+            from . import ops
+            with ops.bn_running_updates(2):
+                fm_clean = m(inp, end_point=idx, start_point=0)
+            feature_map = fm_clean.detach()
+        else:
+            with torch.no_grad():  # (.detach()): values and BN side effects are identical
+                feature_map = m(inp, end_point=idx, start_point=0)
         feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
         feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
                               gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
@@ -171,7 +184,8 @@ class AfanTrainer:
             # row tiles per launch), BatchNorm treats the halves as the two separate passes they are — statistics,
             # running-stat updates (adv first, then clean) and backward sums per half (resnet_s.bn_groups).
             from . import resnet_s
-            fm_clean = m(inp, end_point=idx, start_point=0)
+            if fm_clean is None:
+                fm_clean = m(inp, end_point=idx, start_point=0)
             both = torch.cat([adv_in, fm_clean.to(adv_in.dtype)], dim=0)
             with resnet_s.bn_groups(2):
                 out_both = m(both, end_point=ln, start_point=idx)
@@ -179,7 +193,8 @@ class AfanTrainer:
             output_adv, output_clean = out_both[:nb], out_both[nb:]
         else:
             output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
-            output_clean = m(inp, end_point=ln, start_point=0)                   # main_perturb.py:196
+            output_clean = (m(fm_clean, end_point=ln, start_point=idx) if fm_clean is not None
+                            else m(inp, end_point=ln, start_point=0))            # main_perturb.py:196
         loss_adv = self.criterion(output_adv, target)
         loss_clean = self.criterion(output_clean, target)
         loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
@@ -202,6 +217,11 @@ class AfanTrainer:
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
                 "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
                 "feature_map": feature_map, "out_clean": output_clean.detach()}
+
+    def _share_head(self, inp):
+        m = self.model
+        return bool(self.share_head and inp.is_cuda and self.perturb_idx > 0 and getattr(m, "channels_last", False)
+                    and hasattr(m, "sequential_model") and m.training)
 
     def _tail_groupable(self, fea):
         """Can the tail run the adversarial and the clean pass as one grouped pass?  bf16 channels-last feature map, every

@@ -187,6 +187,14 @@ int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, voi
  * launches).  No partial slabs, no finalize launch.  afan_bn_acc_supported(): c / (8 bf16 | 4 fp32) must divide 256. */
 int64_t afan_bn_acc_doubles(int64_t c);
 int afan_bn_acc_supported(int dtype, int64_t c);
+
+/* main_perturb.py:173 and :196 run the head of the network twice per iteration on the same images with the same weights
+ * (once detached for PGD, once inside the clean forward): same values, and each train-mode BatchNorm updates its running
+ * statistics twice from the same batch moments.  afan_bn_set_running_updates(n) makes the channels-last
+ * afan_bn_train_forward* launches issued by THIS host thread from now on stand for n such identical passes: the
+ * running-statistics update is applied n times in sequence (bit-identical to n passes) and num_batches_tracked advances by
+ * n.  Returns the previous value; 1 restores the default.  Ungrouped launches only; the NCHW kernels refuse n != 1. */
+int afan_bn_set_running_updates(int n);
 int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias,
                               int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,

@@ -421,3 +421,39 @@ def test_two_rank_sharded_step_matches_sharded_oracle(pkg, orc, gpu):
             assert int(sd[k]) == int(sd_ref[k]), k
         else:
             np.testing.assert_allclose(sd[k].cpu().numpy(), sd_ref[k].numpy(), rtol=2e-3, atol=3e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("arch,idx", [("resnet20s", 7), ("resnet18", 6)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shared_head_pass_equals_two_head_passes(pkg, orc, gpu, arch, idx, dtype):
+    """main_perturb.py:173 + :196 run the head twice on the same images and weights.  One head pass whose BatchNorm
+    launches apply their running-statistics update twice (AfanTrainer(share_head=True), the default on the channels-last
+    kernels) against two real passes: same losses and gradients, running statistics equal, num_batches_tracked equal."""
+    res = {}
+    for share in (False, True):
+        m = _build(pkg, orc, arch, gpu, dtype=dtype)
+        m.set_channels_last(True)
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.1,
+                                        use_graph=False, share_head=share)
+        torch.manual_seed(0)
+        x, y = torch.rand(8, 3, 32, 32, device=gpu), torch.randint(0, 10, (8,), device=gpu)
+        before = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}
+        r = tr.step(x, y)
+        assert tr._share_head(x) == share
+        res[share] = (float(r["loss"]), float(r["loss_adv"]), float(r["loss_clean"]), tr.arena.grad.clone().cpu().numpy(),
+                      {k: v.clone().cpu() for k, v in m.state_dict().items()}, before)
+    a, b = res[False], res[True]
+    fp32 = dtype == torch.float32
+    for i in range(3):
+        assert abs(a[i] - b[i]) <= (1e-5 if fp32 else 2e-2) * max(1.0, abs(a[i])), (i, a[i], b[i])
+    if fp32:
+        np.testing.assert_allclose(b[3], a[3], rtol=1e-3, atol=1e-5 * float(np.abs(a[3]).max()))
+    moved = 0
+    for k in a[4]:
+        if "num_batches" in k:
+            assert int(a[4][k]) == int(b[4][k]) and int(a[4][k]) in (2, 4), k      # head: 2 passes, tail: K + 2 = 4
+        elif "running_" in k:
+            # identical batch moments, the update applied twice either way: fp32 rounding of the moments only
+            np.testing.assert_allclose(b[4][k].numpy(), a[4][k].numpy(), rtol=(2e-6 if fp32 else 2e-2), atol=(1e-7 if fp32 else 3e-3), err_msg=k)
+            moved += int(not torch.equal(b[4][k], b[5][k].cpu()))
+    assert moved > 0
