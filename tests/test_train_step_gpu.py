@@ -457,3 +457,44 @@ def test_shared_head_pass_equals_two_head_passes(pkg, orc, gpu, arch, idx, dtype
             np.testing.assert_allclose(b[4][k].numpy(), a[4][k].numpy(), rtol=(2e-6 if fp32 else 2e-2), atol=(1e-7 if fp32 else 3e-3), err_msg=k)
             moved += int(not torch.equal(b[4][k], b[5][k].cpu()))
     assert moved > 0
+
+
+def test_product_step_full_size_properties(pkg, orc, gpu):
+    """BASELINE cfg2 at full size on the product path (bf16 channels-last, library convolutions, grouped final pass, one
+    head pass, hipGraph replay): size-independent properties of an A-FAN iteration."""
+    K, gamma = 5, 0.5
+    m = _build(pkg, orc, "resnet18", gpu, dtype=torch.bfloat16)
+    m.set_channels_last(True)
+    tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=gamma, eps=2.0, perturb_idx=6, lr=0.01)
+    assert not pkg.resnet_s.vendor_convs(m)
+    torch.manual_seed(0)
+    x, y = torch.rand(256, 3, 32, 32, device=gpu), torch.randint(0, 10, (256,), device=gpu)
+    calls = dict(pkg.ops.CALLS)
+    n_steps = 6
+    for _ in range(n_steps):
+        r = tr.step(x, y)
+    assert tr._graph is not None and tr._groupable and tr._share_head(x)
+    assert pkg.ops.CALLS["vendor_conv"] == calls["vendor_conv"]              # no vendor convolution anywhere in the step
+    fm, xa = r["feature_map"].float(), r["x_adv"].float()
+    assert fm.shape == (256, 64, 32, 32)
+    # perturbation on the sign grid: delta / gamma integer, |.| <= K, odd unless a gradient was exactly zero at a step
+    q = (xa - fm) / np.float32(gamma / 255)
+    k = q.round()
+    assert float((q - k).abs().max()) < 1e-2 and float(k.abs().max()) <= K
+    assert float((k % 2 == 0).float().mean()) < 5e-3
+    # fused per-sample norms = norms of the returned perturbation
+    d = (xa - fm).reshape(256, -1)
+    np.testing.assert_allclose(r["l2"].cpu().numpy(), d.double().norm(dim=1).float().cpu().numpy(), rtol=1e-5)
+    assert torch.equal(r["linf"], d.abs().amax(dim=1))
+    # joint loss, accuracy in range
+    assert abs(float(r["loss"]) - 0.5 * (float(r["loss_adv"]) + float(r["loss_clean"]))) < 1e-5 * max(1.0, float(r["loss"]))
+    assert 0.0 <= float(r["prec1"]) <= 100.0
+    # BatchNorm side effects: head layers see 2 train-mode passes per iteration, tail layers K + 2 (main_perturb.py:173-196)
+    seq = m.sequential_model
+    assert int(seq[2].num_batches_tracked) == 2 * n_steps                     # stem BN
+    assert int(seq[5].bn2.num_batches_tracked) == 2 * n_steps                 # last head block
+    assert int(seq[6].bn1.num_batches_tracked) == (K + 2) * n_steps           # first tail block
+    assert int(seq[11].bn2.num_batches_tracked) == (K + 2) * n_steps
+    for name, buf in m.named_buffers():
+        assert torch.isfinite(buf.float()).all(), name
+    assert torch.isfinite(tr.arena.param).all() and float(tr.arena.momentum_buf.abs().max()) > 0
