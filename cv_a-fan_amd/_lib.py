@@ -32,6 +32,7 @@ SIGNATURES = {
     "afan_head_max_classes": (_i, []),
     "afan_head_forward": (_i, [_p, _i, _l, _l, _l, _p, _p, _l, _p, _p, _p]),
     "afan_head_backward": (_i, [_p, _p, _p, _l, _l, _l, _l, _p, _i, _p, _p, _i, _p]),
+    "afan_cross_entropy": (_i, [_p, _p, _l, _l, _p, _p, _p]),
     "afan_mix_w_workspace_floats": (_l, []),
     "afan_mix_w": (_i, [_p, _p, _p, _p, _i, _l, _p]),
     "afan_mix_w_backward": (_i, [_p, _i, _p, _p, _l, _p, _p, _i, _p]),

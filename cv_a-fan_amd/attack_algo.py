@@ -12,7 +12,7 @@ switched off (the reference asks autograd for the feature gradient only, attack_
 import torch
 
 from . import ops
-from .resnet_s import _dense, _like_layout, dgrad_only
+from .resnet_s import _dense, _like_layout, dgrad_only, fused_criterion
 
 __all__ = ["PGD", "tensor_clamp", "linfball_proj", "mix_feature", "get_sample_points", "last_norms"]
 
@@ -63,6 +63,7 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
     elif lp:
         ops.cast_bf16(x_adv, shadow)
     l2 = linf = None
+    loss_fn = fused_criterion(loss_fn, model)
     for t in range(steps):
         # the tail consumes the bf16 shadow written by the previous step's kernel (no separate cast)
         xin = (shadow if lp else x_adv).detach().requires_grad_(True)

@@ -144,6 +144,39 @@ __global__ __launch_bounds__(64 * DW_SLICES) void head_bwd_dw_kernel(const float
     }
 }
 
+// Mean cross-entropy of the classifier's logits (nn.CrossEntropyLoss defaults: main_perturb.py:71, attack_algo.py:51) and
+// its gradient in ONE launch: per row  lse = max + log sum exp(l - max),  loss_r = lse - l[target],
+// dlogits[r][k] = (exp(l[k] - lse) - [k == target]) / N;  loss = (sum_r loss_r) / N, rows summed in fixed order.
+// One block (N * K is a few thousand values here); in torch the same is log_softmax, nll_loss, a ones_like fill, two
+// backward kernels and a zero fill — at the end of every tail pass, K + 2 times per iteration.
+constexpr int CE_BLOCK = 256;
+__global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                          float* __restrict__ loss, float* __restrict__ dlogits, int N, int K) {
+    __shared__ float red[CE_BLOCK / AFAN_WAVE];
+    const float invn = 1.0f / (float)N;
+    float local = 0.f;
+    for (int r = threadIdx.x; r < N; r += CE_BLOCK) {
+        const float* l = logits + (int64_t)r * K;
+        float m = l[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, l[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(l[k] - m);
+        const float lse = m + logf(s);
+        const int t = (int)target[r];
+        local += lse - l[t];
+        float* d = dlogits + (int64_t)r * K;
+        for (int k = 0; k < K; ++k) d[k] = (expf(l[k] - lse) - (k == t ? 1.f : 0.f)) * invn;
+    }
+    const float w = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < CE_BLOCK / AFAN_WAVE; ++i) s += red[i];
+        loss[0] = s * invn;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +221,17 @@ int afan_head_backward(const float* dlogits, const float* weight, const float* p
         head_bwd_dw_kernel<<<grid, 64 * DW_SLICES, 0, st>>>(dlogits, pooled, dweight, dbias, (int)n, (int)c, (int)k, accumulate);
         AFAN_LAUNCH_CHECK();
     }
+    return AFAN_OK;
+}
+
+int afan_cross_entropy(const float* logits, const int64_t* target, int64_t n, int64_t k, float* loss, float* dlogits,
+                       afan_stream_t stream) {
+    if (n <= 0 || k <= 0 || n * k > (1 << 16)) return AFAN_ESHAPE;        // one block; larger heads stay with the caller
+    if (!logits || !target || !loss || !dlogits) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("ce_fwd_kernel", 8.0 * n * k, st);
+    ce_fwd_kernel<<<1, CE_BLOCK, 0, st>>>(logits, target, loss, dlogits, (int)n, (int)k);
+    AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
 

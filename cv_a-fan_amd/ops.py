@@ -137,6 +137,23 @@ def _nchw(t):
     return n, c, hw
 
 
+def cross_entropy(logits, target):
+    """Mean cross-entropy (nn.CrossEntropyLoss defaults) and d(loss)/d(logits) in one launch: returns (loss [1], dlogits)."""
+    lib = _lib.load()
+    _need(logits, "logits", torch.float32)
+    if logits.dim() != 2 or not logits.is_contiguous() or target.dtype != torch.int64 or target.dim() != 1 \
+            or target.shape[0] != logits.shape[0] or not target.is_cuda:
+        raise TypeError("cross_entropy: logits [N,K] fp32 contiguous and target [N] int64 on the GPU")
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    check(lib.afan_cross_entropy(_ptr(logits), _ptr(target.contiguous()), logits.shape[0], logits.shape[1], _ptr(loss),
+                                 _ptr(dlogits), _stream(logits)), "afan_cross_entropy")
+    return loss, dlogits
+
+
+CE_MAX_ELEMS = 1 << 16
+
+
 class bn_running_updates:
     """Context: the channels-last train-mode BatchNorm forwards issued inside stand for `n` identical passes — their
     running statistics are updated n times in sequence (afan_bn_set_running_updates; main_perturb.py:173 + :196 run the

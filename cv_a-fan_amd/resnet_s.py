@@ -648,6 +648,42 @@ class _HeadFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _CEFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(logits, target) with its defaults as one forward launch that also leaves d(loss)/d(logits)
+    (afan_cross_entropy); backward = that gradient times the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, dlogits = ops.cross_entropy(logits, target)
+        ctx.save_for_backward(dlogits)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
+_FUSED_CE = os.environ.get("AFAN_FUSED_CE", "1") != "0"
+
+
+def fused_criterion(criterion, model):
+    """`criterion` as the step applies it to the classifier's logits.  A plain nn.CrossEntropyLoss() on the bf16 product
+    path becomes the one-launch fused form when its arguments allow; anything else (a caller's own loss_fn, class weights,
+    label smoothing, fp32 parity mode — which stays on torch's own loss kernels) is returned unchanged."""
+    if not (_FUSED_CE and type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.ignore_index == -100
+            and criterion.reduction == "mean" and getattr(criterion, "label_smoothing", 0.0) == 0.0
+            and getattr(model, "compute_dtype", torch.float32) == torch.bfloat16):
+        return criterion
+
+    def ce(out, y):
+        if (out.is_cuda and out.dtype == torch.float32 and out.dim() == 2 and out.is_contiguous() and y.dtype == torch.int64
+                and y.dim() == 1 and 0 < out.numel() <= ops.CE_MAX_ELEMS):
+            return _CEFn.apply(out, y)
+        return criterion(out, y)
+    return ce
+
+
 _FUSED_HEAD = os.environ.get("AFAN_FUSED_HEAD", "1") != "0"   # 0: pool / flatten / linear as separate torch ops (A/B)
 
 

@@ -195,8 +195,10 @@ class AfanTrainer:
             output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
             output_clean = (m(fm_clean, end_point=ln, start_point=idx) if fm_clean is not None
                             else m(inp, end_point=ln, start_point=0))            # main_perturb.py:196
-        loss_adv = self.criterion(output_adv, target)
-        loss_clean = self.criterion(output_clean, target)
+        from . import resnet_s as _rs
+        crit = _rs.fused_criterion(self.criterion, m)
+        loss_adv = crit(output_adv.contiguous() if output_adv.dim() == 2 else output_adv, target)
+        loss_clean = crit(output_clean.contiguous() if output_clean.dim() == 2 else output_clean, target)
         loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
         self.optimizer.zero_grad()
         if overlap_allreduce:

@@ -275,6 +275,13 @@ int afan_head_backward(const float* dlogits, const float* weight, const float* p
                        int64_t k, void* dx, int dx_dtype, float* dweight, float* dbias, int accumulate,
                        afan_stream_t stream);
 
+/* The loss at the end of every tail pass: mean cross-entropy of logits[n][k] (fp32) against target[n] (int64 class ids;
+ * nn.CrossEntropyLoss with its defaults, main_perturb.py:71 / attack_algo.py:51) AND its gradient in one launch:
+ * loss[0] = mean_r (logsumexp(logits[r]) - logits[r][target[r]]),  dlogits[r][j] = (softmax(logits[r])[j] - [j == target[r]]) / n.
+ * n * k <= 65536 (one workgroup; rows summed in fixed order). */
+int afan_cross_entropy(const float* logits, const int64_t* target, int64_t n, int64_t k, float* loss, float* dlogits,
+                       afan_stream_t stream);
+
 /* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
  * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
  * offsets into src_arena / dst_arena, K % 8 == 0, C % 8 == 0, first_tile = running sum of ceil(K/64)*RS*ceil(C/64)). */

@@ -493,3 +493,27 @@ def test_fused_classifier_head_matches_torch(pkg, gpu, shape, k, dt):
     np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.cpu().numpy(), **tol)
     np.testing.assert_allclose(dw.cpu().numpy() - 1, lin.weight.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(db.cpu().numpy() - 1, lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,k", [(256, 10), (512, 10), (7, 3), (1, 10), (64, 1000)])
+def test_fused_cross_entropy_matches_torch(pkg, gpu, n, k):
+    """afan_cross_entropy (loss and d(loss)/d(logits) in one launch) against nn.CrossEntropyLoss on the same logits."""
+    torch.manual_seed(n + k)
+    logits = (torch.randn(n, k, device=gpu) * 4).requires_grad_(True)
+    y = torch.randint(0, k, (n,), device=gpu)
+    ref = nn.CrossEntropyLoss()(logits, y)
+    (gref,) = torch.autograd.grad(ref * 0.5, logits)
+    loss, dl = pkg.ops.cross_entropy(logits.detach(), y)
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-6)
+    # softmax - onehot cancels where the target's probability is near 1: absolute tolerance of a few ulps of 1/n
+    np.testing.assert_allclose(dl.cpu().numpy() * 0.5, gref.cpu().numpy(), rtol=1e-5, atol=1e-6 / n)
+    # through autograd, as the step uses it (criterion pattern-matched on the bf16 path only)
+    class _M:
+        compute_dtype = torch.bfloat16
+    crit = pkg.resnet_s.fused_criterion(nn.CrossEntropyLoss(), _M())
+    l2 = crit(logits, y)
+    (g2,) = torch.autograd.grad(l2 * 0.5, logits)
+    np.testing.assert_allclose(g2.cpu().numpy(), gref.cpu().numpy(), rtol=1e-5, atol=1e-6 / n)
+    _M.compute_dtype = torch.float32
+    assert isinstance(pkg.resnet_s.fused_criterion(nn.CrossEntropyLoss(), _M()), nn.CrossEntropyLoss)
+    assert isinstance(pkg.resnet_s.fused_criterion(nn.CrossEntropyLoss(label_smoothing=0.1), _M()), nn.CrossEntropyLoss)
