@@ -70,7 +70,8 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
         with dgrad_only():
             out = model(xin, end_point=layer_number, start_point=start_idx)
             loss = loss_fn(out, y)
-            grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
+            root = ops.one(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32) else None
+            grad = torch.autograd.grad(loss, xin, grad_outputs=root, only_inputs=True)[0]
         grad = _like_layout(grad, x_adv)
         if with_norms and t == steps - 1:
             l2, linf = ops.pgd_step_norms_(x_adv, grad, gamma, x, eps, clip, shadow)

@@ -152,6 +152,16 @@ def cross_entropy(logits, target):
 
 
 CE_MAX_ELEMS = 1 << 16
+_ones = {}
+
+
+def one(device):
+    """A cached fp32 scalar 1.0 on `device`: the explicit root gradient of the step's backward passes (autograd would
+    otherwise allocate and fill a ones_like(loss) per pass); never written."""
+    t = _ones.get(device.index)
+    if t is None:
+        t = _ones[device.index] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 class bn_running_updates:

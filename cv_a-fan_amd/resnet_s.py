@@ -661,6 +661,8 @@ class _CEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
+        if g.data_ptr() == ops.one(g.device).data_ptr():      # the root gradient ops.one(): d(loss)/d(logits) as it is
+            return dlogits, None
         return dlogits * g, None
 
 

@@ -210,7 +210,11 @@ class AfanTrainer:
             resnet_s._Flags.wgrad_stream = self._wgrad_stream
             self._wgrad_stream.wait_stream(torch.cuda.current_stream())   # zero_grad before any accumulation
         try:
-            loss.backward()
+            if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+                from . import ops as _ops
+                loss.backward(gradient=_ops.one(loss.device))
+            else:
+                loss.backward()
         finally:
             resnet_s.join_wgrad_stream()
             resnet_s._Flags.wgrad_stream = None
