@@ -41,12 +41,13 @@ def linfball_proj(center, radius, t, in_place=True):
 
 
 def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_number=16, eps=(2 / 255),
-        randinit=False, clip=False, with_norms=False):
+        randinit=False, clip=False, with_norms=False, grad0=None):
     """K-step sign-gradient ascent on the feature map `x` (attack_algo.py:38-58).
 
     Returns a NEW fp32 leaf tensor with requires_grad=True; `x` is not modified.  `with_norms=True`
     (an addition) fuses the per-sample L2/Linf perturbation norms into the last step; read them with
-    `last_norms()`.
+    `last_norms()`.  `grad0` (an addition; not with randinit): a positive multiple of d(loss)/d(x) at x itself, already
+    computed by the caller — the first ascent step uses it instead of running the tail on x (sign() ignores the scale).
     """
     if x.device.type != "cuda":
         raise ops.AfanLibraryError("PGD: x must live on the MI355X (no CPU path in this build)")
@@ -56,22 +57,27 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
     x_adv = x.clone()
     lp = getattr(model, "compute_dtype", torch.float32) == torch.bfloat16
     shadow = torch.empty_like(x, dtype=torch.bfloat16) if lp else None
+    if grad0 is not None and (randinit or steps < 1):
+        raise ValueError("grad0 is the gradient at x: not with randinit, and only when there is a first step")
     if randinit:
         # the reference draws the noise on the CPU default generator (attack_algo.py:44); same stream here
         u = _like_layout(torch.rand(x_adv.shape).to(x.device, non_blocking=True), x_adv)
         ops.axpy_noise_(x_adv, u, eps, shadow)
-    elif lp:
-        ops.cast_bf16(x_adv, shadow)
+    elif lp and grad0 is None:
+        ops.cast_bf16(x_adv, shadow)        # (with grad0 the first step's kernel writes the shadow)
     l2 = linf = None
     loss_fn = fused_criterion(loss_fn, model)
     for t in range(steps):
-        # the tail consumes the bf16 shadow written by the previous step's kernel (no separate cast)
-        xin = (shadow if lp else x_adv).detach().requires_grad_(True)
-        with dgrad_only():
-            out = model(xin, end_point=layer_number, start_point=start_idx)
-            loss = loss_fn(out, y)
-            root = ops.one(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32) else None
-            grad = torch.autograd.grad(loss, xin, grad_outputs=root, only_inputs=True)[0]
+        if t == 0 and grad0 is not None:
+            grad = grad0.detach()
+        else:
+            # the tail consumes the bf16 shadow written by the previous step's kernel (no separate cast)
+            xin = (shadow if lp else x_adv).detach().requires_grad_(True)
+            with dgrad_only():
+                out = model(xin, end_point=layer_number, start_point=start_idx)
+                loss = loss_fn(out, y)
+                root = ops.one(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32) else None
+                grad = torch.autograd.grad(loss, xin, grad_outputs=root, only_inputs=True)[0]
         grad = _like_layout(grad, x_adv)
         if with_norms and t == steps - 1:
             l2, linf = ops.pgd_step_norms_(x_adv, grad, gamma, x, eps, clip, shadow)

@@ -4,6 +4,7 @@ tensor, a non-contiguous tensor or a missing library raises.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -12,6 +13,7 @@ from ._lib import AFAN_BF16, AFAN_F32, AFAN_NCHW, AFAN_NHWC, AfanLibraryError, c
 
 _DT = {torch.float32: AFAN_F32, torch.bfloat16: AFAN_BF16}
 _ws_cache = {}
+_tls = threading.local()
 # how many convolution passes ran on the library's kernels / went to the vendor library since import (tests and the
 # entry points' logs use it to show which path a configuration really takes)
 CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "vendor_conv": 0}
@@ -153,6 +155,14 @@ def cross_entropy(logits, target):
 
 CE_MAX_ELEMS = 1 << 16
 _ones = {}
+
+
+def half(device):
+    """A cached fp32 scalar 0.5: root gradient of each half of the joint loss (CE_adv + CE_clean) / 2."""
+    t = _ones.get(("half", device.index))
+    if t is None:
+        t = _ones[("half", device.index)] = torch.full((), 0.5, dtype=torch.float32, device=device)
+    return t
 
 
 def one(device):
@@ -390,6 +400,35 @@ def bn_stats(x, eps=1e-5, momentum=0.1, running_mean=None, running_var=None, num
     return stats[0], stats[1]
 
 
+class record_bn_updates:
+    """Context: remember (running buffers, saved statistics, count, eps, momentum) of every train-mode BatchNorm forward
+    issued inside by this thread, so that `replay()` can apply each one's running-statistics update once more later —
+    see afan_bn_running_update (the clean tail pass that stands for two of the reference's)."""
+
+    def __enter__(self):
+        self.old = getattr(_tls, "bn_rec", None)
+        self.items = _tls.bn_rec = []
+        return self
+
+    def __exit__(self, *exc):
+        _tls.bn_rec = self.old
+        return False
+
+    def replay(self):
+        lib = _lib.load()
+        for rm, rv, nbt, stats, m, eps, mom in self.items:
+            check(lib.afan_bn_running_update(_ptr(stats), rm.numel(), float(m), float(eps), float(mom), _ptr(rm), _ptr(rv),
+                                             _ptr(nbt), _stream(rm)), "afan_bn_running_update")
+
+
+def _bn_record(running_mean, running_var, num_batches, stats, m, eps, momentum, groups):
+    rec = getattr(_tls, "bn_rec", None)
+    if rec is not None and running_mean is not None:
+        if groups != 1:
+            raise ValueError("record_bn_updates: grouped BatchNorm launches cannot be replayed")
+        rec.append((running_mean, running_var, num_batches, stats, m, eps, momentum))
+
+
 def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mean, running_var, num_batches,
                      conv_stats=None, out=None, stats_out=None, groups=1):
     """Returns (y, stats) with stats = [4, C] fp32: mean, invstd, alpha, beta (kept for bn_backward).
@@ -413,6 +452,7 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
         raise ValueError("grouped BatchNorm needs the accumulators of a grouped convolution")
     stats = stats_out if stats_out is not None else torch.empty((4, c) if groups == 1 else (groups, 4, c),
                                                                 dtype=torch.float32, device=x.device)
+    _bn_record(running_mean, running_var, num_batches, stats, n * hw, eps, momentum, groups)
     acc = conv_stats.acc if conv_stats is not None else None
     ready = acc is not None
     if acc is None and conv_stats is None and bn_acc_ok(x):

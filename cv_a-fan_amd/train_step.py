@@ -120,7 +120,7 @@ class AfanTrainer:
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
                  group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True,
-                 share_head=True):
+                 share_head=True, fold_clean=True):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -138,6 +138,7 @@ class AfanTrainer:
         self._groupable_key, self._groupable = None, False
         self._wgrad_stream = None
         self.share_head = bool(share_head)
+        self.fold_clean = bool(fold_clean)
         self.use_graph = bool(use_graph) and not randinit
         self.graph_warmup = graph_warmup
         self._graph = None
@@ -150,7 +151,63 @@ class AfanTrainer:
         self._stream = None
 
     # ------------------------------------------------------------------------------------------------ body
+    def _fold_ok(self, inp):
+        return bool(self.fold_clean and self._share_head(inp) and self.steps >= 1 and not self.randinit
+                    and not self.async_wgrad)
+
+    def _forward_backward_folded(self, inp, target, overlap_allreduce):
+        """The iteration with ONE clean tail pass.  Without randinit PGD starts AT the clean feature map
+        (attack_algo.py:40-41), so its first pass (attack_algo.py:50-52: tail forward, CE, gradient w.r.t. the feature map)
+        and the clean forward/backward of the joint loss (main_perturb.py:196-200) evaluate the same function of the same
+        weights at the same point: same logits, same CE, same BatchNorm batch moments, and d(CE)/d(activations) differing
+        by the joint loss's factor 1/2 only — which sign() ignores.  So the clean tail pass runs ONCE, with parameter
+        gradients and root gradient 1/2: it yields loss_clean, the clean half of every tail parameter gradient, and
+        g0 = (1/2) dCE/dfeature, which is both PGD's first ascent direction (PGD(grad0=g0)) and the gradient the clean
+        branch sends into the head.  Then PGD steps 1..K-1, the adversarial pass (root 1/2), and the head backward from
+        g0.  BatchNorm running statistics: the clean pass updates them first (as PGD's first pass does) and its moments
+        are applied once more after the adversarial pass (ops.record_bn_updates: the reference's final clean forward
+        comes last) — K + 2 updates per tail layer, in the reference's order.  Two tail forwards, one input-gradient
+        pass and — against the grouped form — nothing but launch geometry are saved: 16 -> 14 tail pass-units."""
+        from . import ops, resnet_s
+        m, idx, ln = self.model, self.perturb_idx, self.layer_number
+        ops.acc_reset(inp.device)
+        self.optimizer.zero_grad()                      # before the first backward of the iteration
+        crit = resnet_s.fused_criterion(self.criterion, m)
+        half = ops.half(inp.device)
+        with ops.bn_running_updates(2):                 # main_perturb.py:173 + :196: the head, once for both
+            fm_clean = m(inp, end_point=idx, start_point=0)
+        xin = fm_clean.detach().requires_grad_(True)
+        with ops.record_bn_updates() as clean_bn:
+            output_clean = m(xin, end_point=ln, start_point=idx)
+        loss_clean = crit(output_clean, target)
+        torch.autograd.backward(loss_clean, grad_tensors=half)
+        g0 = xin.grad
+        feature_map = fm_clean.detach()
+        feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
+        feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
+                              gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
+                              randinit=False, clip=self.clip, with_norms=True, grad0=g0)
+        l2, linf = last_norms()
+        adv_in = getattr(feature_map_adv, "_afan_shadow", None)
+        if adv_in is None:
+            adv_in = feature_map_adv.detach()
+        output_adv = m(adv_in, end_point=ln, start_point=idx)                    # main_perturb.py:195
+        loss_adv = crit(output_adv, target)
+        torch.autograd.backward(loss_adv, grad_tensors=half)
+        clean_bn.replay()                               # main_perturb.py:196's BatchNorm side effect, last in order
+        if overlap_allreduce:
+            self.reducer.begin()
+        fm_clean.backward(g0)                           # the clean branch's gradient through the head
+        with torch.no_grad():
+            loss = (loss_adv + loss_clean) / 2                                   # main_perturb.py:197
+            prec1 = (output_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
+        return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
+                "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
+                "feature_map": feature_map, "out_clean": output_clean.detach()}
+
     def _forward_backward(self, inp, target, overlap_allreduce):
+        if self._fold_ok(inp):
+            return self._forward_backward_folded(inp, target, overlap_allreduce)
         m, idx, ln = self.model, self.perturb_idx, self.layer_number
         if inp.is_cuda:
             from . import ops

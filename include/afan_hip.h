@@ -195,6 +195,12 @@ int afan_bn_acc_supported(int dtype, int64_t c);
  * running-statistics update is applied n times in sequence (bit-identical to n passes) and num_batches_tracked advances by
  * n.  Returns the previous value; 1 restores the default.  Ungrouped launches only; the NCHW kernels refuse n != 1. */
 int afan_bn_set_running_updates(int n);
+
+/* One more running-statistics update from the saved statistics (mean | invstd rows of save_stats) of an earlier train-mode
+ * forward over m_count values per channel — the update the reference's value-identical second clean tail pass
+ * (attack_algo.py:50 at step 0, then main_perturb.py:196) would apply last.  running_var uses 1/invstd^2 - eps. */
+int afan_bn_running_update(const float* stats, int64_t c, double m_count, float eps, float momentum, float* running_mean,
+                           float* running_var, int64_t* num_batches, afan_stream_t stream);
 int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias,
                               int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,

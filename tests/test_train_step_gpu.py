@@ -275,7 +275,7 @@ def test_batched_final_passes_match_separate_passes(pkg, orc, gpu, arch, idx, sh
             m.set_channels_last(True)
             m.train()
             tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.1,
-                                            use_graph=False, batch_final=batched)
+                                            use_graph=False, batch_final=batched, fold_clean=False)
             torch.manual_seed(0)
             x, y = torch.rand(*shape, device=gpu), torch.randint(0, 10, (shape[0],), device=gpu)
             r = tr.step(x, y)
@@ -434,7 +434,7 @@ def test_shared_head_pass_equals_two_head_passes(pkg, orc, gpu, arch, idx, dtype
         m = _build(pkg, orc, arch, gpu, dtype=dtype)
         m.set_channels_last(True)
         tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.1,
-                                        use_graph=False, share_head=share)
+                                        use_graph=False, share_head=share, fold_clean=False)
         torch.manual_seed(0)
         x, y = torch.rand(8, 3, 32, 32, device=gpu), torch.randint(0, 10, (8,), device=gpu)
         before = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k}
@@ -473,7 +473,7 @@ def test_product_step_full_size_properties(pkg, orc, gpu):
     n_steps = 6
     for _ in range(n_steps):
         r = tr.step(x, y)
-    assert tr._graph is not None and tr._groupable and tr._share_head(x)
+    assert tr._graph is not None and tr._fold_ok(x) and tr._share_head(x)
     assert pkg.ops.CALLS["vendor_conv"] == calls["vendor_conv"]              # no vendor convolution anywhere in the step
     fm, xa = r["feature_map"].float(), r["x_adv"].float()
     assert fm.shape == (256, 64, 32, 32)
@@ -498,3 +498,45 @@ def test_product_step_full_size_properties(pkg, orc, gpu):
     for name, buf in m.named_buffers():
         assert torch.isfinite(buf.float()).all(), name
     assert torch.isfinite(tr.arena.param).all() and float(tr.arena.momentum_buf.abs().max()) > 0
+
+
+@pytest.mark.parametrize("arch,idx", [("resnet20s", 7), ("resnet18", 6)])
+@pytest.mark.parametrize("dtype,clip", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_folded_clean_pass_equals_reference_schedule(pkg, orc, gpu, arch, idx, dtype, clip):
+    """PGD's first pass and the final clean pass evaluate the same function at the same point (no randinit): the step runs
+    that tail pass once (AfanTrainer(fold_clean=True), default) — against the reference's schedule on the same kernels
+    (fold_clean=False): same losses, same perturbation, same parameter gradients, same BatchNorm buffers."""
+    K = 3
+    res = {}
+    for fold in (False, True):
+        m = _build(pkg, orc, arch, gpu, dtype=dtype)
+        m.set_channels_last(True)
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=1.0, perturb_idx=idx, lr=0.1,
+                                        clip=clip, use_graph=False, fold_clean=fold)
+        torch.manual_seed(0)
+        x, y = torch.rand(8, 3, 32, 32, device=gpu), torch.randint(0, 10, (8,), device=gpu)
+        assert tr._fold_ok(x) == fold
+        r = tr.step(x, y)
+        res[fold] = (float(r["loss"]), float(r["loss_adv"]), float(r["loss_clean"]), tr.arena.grad.clone().cpu().numpy(),
+                     {k: v.clone().cpu() for k, v in m.state_dict().items()}, r["x_adv"].float().cpu(), r["feature_map"].float().cpu(),
+                     r["l2"].cpu().numpy())
+    a, b = res[False], res[True]
+    fp32 = dtype == torch.float32
+    for i in range(3):
+        assert abs(a[i] - b[i]) <= (2e-5 if fp32 else 3e-2) * max(1.0, abs(a[i])), (i, a[i], b[i])
+    # the perturbation: same sign pattern (a positive scale of the gradient does not move sign(); fp32: every element)
+    qa, qb = ((a[5] - a[6]) / (0.5 / 255)).round(), ((b[5] - b[6]) / (0.5 / 255)).round()
+    flips = float((qa != qb).float().mean())
+    assert flips <= (1e-4 if fp32 else 0.2), flips
+    if fp32:
+        np.testing.assert_allclose(b[7], a[7], rtol=1e-4)
+        gs = float(np.abs(a[3]).max())
+        np.testing.assert_allclose(b[3], a[3], rtol=2e-3, atol=2e-5 * gs)
+    else:
+        assert abs(np.linalg.norm(b[3]) / np.linalg.norm(a[3]) - 1.0) < 0.1
+    for k in a[4]:
+        if "num_batches" in k:
+            assert int(a[4][k]) == int(b[4][k]), k                       # head 2, tail K + 2
+        elif "running_" in k:
+            np.testing.assert_allclose(b[4][k].numpy(), a[4][k].numpy(), rtol=(1e-4 if fp32 else 3e-2),
+                                       atol=(1e-6 if fp32 else 5e-3), err_msg=k)
