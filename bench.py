@@ -110,7 +110,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
     trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
-                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph, batch_final=not args.no_batch_final, share_head=not args.no_share_head, fold_clean=not args.no_fold_clean,
+                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph, batch_final=not args.no_batch_final, share_head=not args.no_share_head, fold_clean=(False if args.no_fold_clean else None),
                                          async_wgrad=args.async_wgrad)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4
@@ -179,11 +179,11 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command supplies it (per launch)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01n_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01o_pmc_hbm_traffic.json")))
             key = next((k for k in pmc if k in name or name.replace("_fwd", "").replace("_dgrad", "") .startswith(k.split("_kernel")[0])), None)
             if key:
                 roof["traffic"] = round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024)
-                roof["traffic_source"] = "profiles/r01n_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch)"
+                roof["traffic_source"] = "profiles/r01o_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch)"
         except (OSError, KeyError, ValueError):
             pass
     if world > 1:

@@ -416,9 +416,15 @@ class record_bn_updates:
 
     def replay(self):
         lib = _lib.load()
-        for rm, rv, nbt, stats, m, eps, mom in self.items:
-            check(lib.afan_bn_running_update(_ptr(stats), rm.numel(), float(m), float(eps), float(mom), _ptr(rm), _ptr(rv),
-                                             _ptr(nbt), _stream(rm)), "afan_bn_running_update")
+        it = self.items
+        n = len(it)
+        if n == 0:
+            return
+        ptrs = lambda k: (C.c_void_p * n)(*[(t[k].data_ptr() if t[k] is not None else None) for t in it])
+        check(lib.afan_bn_running_update_batched(
+            ptrs(3), ptrs(0), ptrs(1), ptrs(2), (C.c_int64 * n)(*[t[0].numel() for t in it]),
+            (C.c_double * n)(*[float(t[4]) for t in it]), (C.c_float * n)(*[float(t[5]) for t in it]),
+            (C.c_float * n)(*[float(t[6]) for t in it]), n, _stream(it[0][0])), "afan_bn_running_update_batched")
 
 
 def _bn_record(running_mean, running_var, num_batches, stats, m, eps, momentum, groups):

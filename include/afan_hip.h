@@ -201,6 +201,10 @@ int afan_bn_set_running_updates(int n);
  * (attack_algo.py:50 at step 0, then main_perturb.py:196) would apply last.  running_var uses 1/invstd^2 - eps. */
 int afan_bn_running_update(const float* stats, int64_t c, double m_count, float eps, float momentum, float* running_mean,
                            float* running_var, int64_t* num_batches, afan_stream_t stream);
+/* The same for n layers (host arrays of n device pointers / sizes) in ceil(n / 64) launches. */
+int afan_bn_running_update_batched(const float* const* stats, float* const* running_mean, float* const* running_var,
+                                   int64_t* const* num_batches, const int64_t* c, const double* m_count, const float* eps,
+                                   const float* momentum, int n, afan_stream_t stream);
 int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c,
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias,
                               int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,

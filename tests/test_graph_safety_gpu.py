@@ -28,12 +28,14 @@ def _poison(dev):
 
 @pytest.mark.parametrize("arch,idx,batch,side,classes", [("resnet18", 6, 64, 32, 10), ("resnet20s", 7, 64, 32, 10),
                                                          ("resnet56s", 13, 32, 32, 10), ("resnet50", 8, 8, 224, 1000)])
-def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch, side, classes):
+@pytest.mark.parametrize("fold", [False, True])
+def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch, side, classes, fold):
     torch.manual_seed(0)
     ctor, _ = pkg.resnet_s.ARCHS[arch]
     model = ctor()
     model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
-    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.01)
+    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.01,
+                                    fold_clean=fold)      # both schedules: the reference's, and the one clean tail pass
     assert not pkg.resnet_s.vendor_convs(model)
     g = torch.Generator().manual_seed(1)
     x = torch.rand(batch, 3, side, side, generator=g).to(gpu)
