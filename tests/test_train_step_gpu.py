@@ -190,9 +190,14 @@ def test_state_dict_roundtrip_with_reference_layout(pkg, orc, gpu):
     np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("case", ["step_r20s_k5", "step_r20s_k3_clip_rand", "step_r18_k5"])
-def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode, case):
-    """Same parity bar with the backbone in its channels-last execution layout (what bench.py runs)."""
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("case", ["step_r20s_k5", "step_r20s_k3_clip_rand", "step_r18_k5", "step_r56s_k5", "step_r20s_k1"])
+def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode, case, fold):
+    """Same parity bar with the backbone in its channels-last execution layout (what bench.py runs), in both schedules:
+    the reference's (fold=False: K PGD passes, adversarial and clean final passes — grouped) and the one with a single
+    clean tail pass standing for PGD's first pass and the final clean pass (fold=True; with randinit it does not apply
+    and the trainer keeps the reference's schedule).  Against the goldens of the reference's own code: losses, the
+    perturbation, and every parameter and BatchNorm buffer after the SGD step."""
     g = golden(case)
     K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]
     gamma, eps = [float(v) for v in g["gamma_eps"]]
@@ -200,8 +205,9 @@ def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode,
     model = _build(pkg, orc, arch, gpu, sd=_sd0(golden("step_r20s_k1")) if arch == "resnet20s" else None)
     model.set_channels_last(True)
     tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=K, gamma=gamma, eps=eps, perturb_idx=idx,
-                                    layer_number=ln, randinit=bool(randinit), clip=bool(clip), lr=0.1)
+                                    layer_number=ln, randinit=bool(randinit), clip=bool(clip), lr=0.1, fold_clean=fold)
     assert tr.arena.channels_last and model.sequential_model[1].weight.is_contiguous(memory_format=torch.channels_last)
+    assert tr._fold_ok(torch.from_numpy(g["x"]).to(gpu)) == (fold and not randinit)
     if randinit:
         torch.manual_seed(3)
         _ = orc.ARCHS[arch][0]()
