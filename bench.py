@@ -209,7 +209,14 @@ def main():
                                    f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
                                    f"(BASELINE configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
-                       "hipgraph": graphed},
+                       "hipgraph": graphed,
+                       # which passes one iteration runs: the reference's text is 2 head passes + K PGD
+                       # passes + adversarial and clean final passes; value-identical passes are run once
+                       "schedule": ("1 head pass (stands for the reference's 2), " if trainer._share_head(xs[0]) else "2 head passes, ")
+                                   + (f"1 clean tail pass (= PGD step 0 and the final clean pass) + {args.pgd_steps - 1} PGD passes + "
+                                      "adversarial pass" if trainer._fold_ok(xs[0]) else
+                                      f"{args.pgd_steps} PGD passes + adversarial and clean final passes"
+                                      + (" (one grouped pass)" if getattr(trainer, "_groupable", False) else ""))},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if gf is not None:
