@@ -56,6 +56,7 @@ SIGNATURES = {
     "afan_conv_dgrad_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _i, _p]),
+    "afan_conv_wgrad2_nhwc_bf16": (_i, [_p, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _i, _p]),
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),

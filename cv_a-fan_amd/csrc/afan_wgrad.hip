@@ -52,8 +52,15 @@ struct WgradP {
     int k, stride, pad;
     int S;               // pixel slices
     int steps_per_slice; // BKP-pixel steps per slice (last slice may be ragged; rows beyond P read as zero)
-    uint32_t P;          // N*Ho*Wo
+    uint32_t P;          // output pixels in total (both segments)
     FastDiv dWo, dHo;
+    // optional second segment: pixels [P1, P) come from (x2, dy2) — the same layer's operands of another pass (the clean
+    // and the adversarial tail pass of one iteration: ONE launch and one slab reduction for both).  P1 % BKP == 0, so
+    // a K-step never straddles the segments; without a second segment P1 == P.
+    const uint16_t* x2;
+    const uint16_t* dy2;
+    uint32_t P1;
+    int N2;
 };
 
 template <int BM, int BN>   // BM = co tile, BN = ci tile
@@ -76,7 +83,11 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.Ci * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(p.dy), 0, (int)((int64_t)p.P * p.Co * 2), 0x00020000);
+        const_cast<uint16_t*>(p.dy), 0, (int)((int64_t)p.P1 * p.Co * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.x2), 0, p.x2 ? (int)((int64_t)p.N2 * p.Hi * p.Wi * p.Ci * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.dy2), 0, p.dy2 ? (int)((int64_t)(p.P - p.P1) * p.Co * 2) : 0, 0x00020000);
     constexpr uint32_t OOB = 0x80000000u;
 
     const int pa = tid % PA, ra0 = tid / PA;   // dy tile: piece / first row
@@ -94,21 +105,25 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
     u32x4 va[NA], vb[NB];
     auto gload = [&](int ks) {
         const uint32_t pbase = p_begin + ks * BKP;
+        const bool seg2 = pbase >= p.P1;                       // wave-uniform: the whole K-step lies in one segment
+        const uint32_t shift = seg2 ? p.P1 : 0u, plim = seg2 ? p.P : p.P1;
+        const __amdgpu_buffer_rsrc_t dsel = seg2 ? dr2 : dr, xsel = seg2 ? xr2 : xr;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const uint32_t pix = pbase + ra0 + i * RA;
-            const uint32_t off = pix < p.P ? (pix * p.Co + co0 + pa * 8) * 2u : OOB;
-            va[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)off, 0, 0));
+            const uint32_t off = pix < plim ? ((pix - shift) * p.Co + co0 + pa * 8) * 2u : OOB;
+            va[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dsel, (int)off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const uint32_t pix = pbase + rb0 + i * RB;
-            const uint32_t t1 = fdiv(pix, p.dWo), wo = pix - t1 * p.Wo;
+            const uint32_t pl = pix - shift;
+            const uint32_t t1 = fdiv(pl, p.dWo), wo = pl - t1 * p.Wo;
             const uint32_t n = fdiv(t1, p.dHo), ho = t1 - n * p.Ho;
             const int hi = (int)ho * p.stride + dh, wi = (int)wo * p.stride + dw;
-            const bool ok = pix < p.P && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
+            const bool ok = pix < plim && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
             const uint32_t off = ok ? (((n * p.Hi + hi) * p.Wi + wi) * p.Ci + ci0 + pb * 8) * 2u : OOB;
-            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
         }
     };
     auto lstore = [&]() {
@@ -238,7 +253,18 @@ int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int6
 // grad[Co,k,k,Ci] (fp32, KRSC) (+)= wgrad(x[N,Hi,Wi,Ci], dy[N,Ho,Wo,Co]); bf16 channels-last operands.
 int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi, int64_t ci,
                               int64_t co, int k, int stride, float* workspace, int accumulate, afan_stream_t stream) {
-    if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
+    return afan_conv_wgrad2_nhwc_bf16(x, dy, n, nullptr, nullptr, 0, grad, hi, wi, ci, co, k, stride, workspace, accumulate,
+                                      stream);
+}
+
+// The same over TWO operand pairs of one layer in one launch: grad (+)= wgrad(x, dy) + wgrad(x2, dy2) (n2 = 0: one pair).
+// Workspace: afan_conv_wgrad_workspace_floats(n + n2, ...).  The first pair's output pixel count must be a multiple of 64.
+int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2,
+                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
+                               float* workspace, int accumulate, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0 || n2 < 0) return AFAN_ESHAPE;
+    if (n2 > 0 && (ci == 3 || afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride))) return AFAN_ESHAPE;  // tiled kernel only
+    if (n2 > 0 && (!x2 || !dy2)) return AFAN_ENULL;
     if (ci == 3) {                                              // the image stem has its own kernel
         if (!afan_stem::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
         if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
@@ -261,14 +287,16 @@ int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_
     if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 16) || !aligned(workspace, 16)) return AFAN_EALIGN;
     const int pad = k / 2;
     const int64_t ho = (hi + 2 * pad - k) / stride + 1, wo = (wi + 2 * pad - k) / stride + 1;
-    const int64_t P = n * ho * wo;
-    if (P * co * 2 > 0x7fffffffLL || n * hi * wi * ci * 2 > 0x7fffffffLL) return AFAN_ESHAPE;
+    const int64_t P1 = n * ho * wo, P = (n + n2) * ho * wo;
+    if (P * co * 2 > 0x7fffffffLL || (n + n2) * hi * wi * ci * 2 > 0x7fffffffLL) return AFAN_ESHAPE;
+    if (n2 > 0 && (P1 % BKP != 0 || !aligned(x2, 16) || !aligned(dy2, 16))) return n2 > 0 && P1 % BKP != 0 ? AFAN_ESHAPE : AFAN_EALIGN;
     const int taps = k * k;
     const Plan pl = make_plan(P, (int)co, (int)ci, taps);
     WgradP p{};
     p.x = (const uint16_t*)x; p.dy = (const uint16_t*)dy; p.slab = workspace;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
     p.k = k; p.stride = stride; p.pad = pad; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
+    p.x2 = (const uint16_t*)x2; p.dy2 = (const uint16_t*)dy2; p.P1 = (uint32_t)P1; p.N2 = (int)n2;
     p.dWo = make_fastdiv((uint32_t)wo); p.dHo = make_fastdiv((uint32_t)ho);
     hipStream_t st = (hipStream_t)stream;
     int rc;

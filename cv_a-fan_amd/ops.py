@@ -660,9 +660,10 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
     return (dx, st) if bn_bwd is not None else dx
 
 
-def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False):
+def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False, second=None):
     """Weight gradient of y = conv2d(x, w, padding=k//2, stride): returns / adds into an fp32 [Co,Ci,k,k] tensor with
-    channels_last strides (KRSC memory, the parameter arena's layout)."""
+    channels_last strides (KRSC memory, the parameter arena's layout).  second = (x2, dy2): the same layer's operands
+    of another pass, summed in the same launch (wgrad_pairable tells when)."""
     lib = _lib.load()
     CALLS["conv_wgrad"] += 1
     _cl4(x, "x"), _cl4(dy, "dy")
@@ -674,10 +675,26 @@ def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False):
     _need(grad, "grad", torch.float32)
     if tuple(grad.shape) != (co, ci, k, k) or not (grad.is_contiguous(memory_format=torch.channels_last) or k == 1 or ci == 1):
         raise ValueError("grad must be an fp32 [Co,Ci,k,k] tensor in KRSC (channels_last) memory order")
-    ws = _workspace(x, lib.afan_conv_wgrad_workspace_floats(n, hi, wi, ci, co, k, stride), "wgrad")
-    check(lib.afan_conv_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, ci, co, k, stride, _ptr(ws),
-                                        int(bool(accumulate)), _stream(x)), "afan_conv_wgrad_nhwc_bf16")
+    n2 = 0
+    if second is not None:
+        x2, dy2 = second
+        _cl4(x2, "x2"), _cl4(dy2, "dy2")
+        if x2.shape[1:] != x.shape[1:] or dy2.shape[1:] != dy.shape[1:] or x2.shape[0] != dy2.shape[0]:
+            raise ValueError("second operand pair must have the first pair's layer shape")
+        n2 = x2.shape[0]
+    ws = _workspace(x, lib.afan_conv_wgrad_workspace_floats(n + n2, hi, wi, ci, co, k, stride), "wgrad")
+    if second is None:
+        check(lib.afan_conv_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, ci, co, k, stride, _ptr(ws),
+                                            int(bool(accumulate)), _stream(x)), "afan_conv_wgrad_nhwc_bf16")
+    else:
+        check(lib.afan_conv_wgrad2_nhwc_bf16(_ptr(x), _ptr(dy), n, _ptr(x2), _ptr(dy2), n2, _ptr(grad), hi, wi, ci, co, k,
+                                             stride, _ptr(ws), int(bool(accumulate)), _stream(x)), "afan_conv_wgrad2_nhwc_bf16")
     return grad
+
+
+def wgrad_pairable(x, dy):
+    """conv_wgrad(..., second=) takes this layer: tiled kernel (channels multiples of 64), first pair's pixels % 64 == 0."""
+    return x.shape[1] % 64 == 0 and dy.shape[1] % 64 == 0 and (dy.shape[0] * dy.shape[2] * dy.shape[3]) % 64 == 0
 
 
 def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):

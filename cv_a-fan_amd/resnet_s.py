@@ -29,6 +29,7 @@ class _Flags:
     weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
     wgrad_stream = None  # side stream for weight-gradient kernels (set by AfanTrainer; None = same stream)
     block_fusion = True  # BasicBlock as one autograd node on the bf16 channels-last fast path (_BlockFn)
+    wgrad_stash = False  # True: block weight gradients are not launched but their operands kept on the conv module (stash_wgrad)
     bn_groups = 1        # 2: the batch is [adv half | clean half]; BatchNorm statistics / running updates per half, in order
 
 
@@ -206,12 +207,49 @@ def _wgrad_accumulate(x, dy, c):
     (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
     k, st = c.kernel_size[0], c.stride[0]
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
+        pairable = ops.wgrad_pairable(x, dy)
+        if _Flags.wgrad_stash and pairable:
+            c._pending_wgrad = (x, dy)          # summed into the launch of the next pass over this layer (stash_wgrad)
+            return
+        pend = getattr(c, "_pending_wgrad", None)
+        if pend is not None:
+            c._pending_wgrad = None
+            if pairable and pend[0].shape[1:] == x.shape[1:] and pend[1].shape[1:] == dy.shape[1:]:
+                ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True, second=(x, dy))
+                return
+            ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True)
         ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True)
         return
     ops.CALLS["vendor_conv"] += 1
     gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
                                              [False, True, False])[1]
     c.weight.grad.add_(gw)
+
+
+class stash_wgrad:
+    """Context for the backward of the FIRST of two passes over the same layers within one iteration (the clean and the
+    adversarial tail pass): the residual blocks' weight-gradient launches are held back — each conv module keeps its
+    (input, output-gradient) pair — and the next backward over the layer sums both pairs in ONE launch and one slab
+    reduction (afan_conv_wgrad2_nhwc_bf16).  flush_wgrad() afterwards launches whatever was not picked up."""
+
+    ON = os.environ.get("AFAN_WGRAD_STASH", "1") != "0"     # 0: every pass launches its own weight gradients (A/B)
+
+    def __enter__(self):
+        self.old = _Flags.wgrad_stash
+        _Flags.wgrad_stash = self.ON
+        return self
+
+    def __exit__(self, *exc):
+        _Flags.wgrad_stash = self.old
+        return False
+
+
+def flush_wgrad(model):
+    for c in model.modules():
+        pend = getattr(c, "_pending_wgrad", None)
+        if pend is not None:
+            c._pending_wgrad = None
+            ops.conv_wgrad(pend[0], pend[1], c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True)
 
 
 def _accumulates_in_place(p):

@@ -220,7 +220,8 @@ class AfanTrainer:
         with ops.record_bn_updates() as clean_bn:
             output_clean = m(xin, end_point=ln, start_point=idx)
         loss_clean = crit(output_clean, target)
-        torch.autograd.backward(loss_clean, grad_tensors=half)
+        with resnet_s.stash_wgrad():                    # the tail's weight gradients wait for the adversarial pass's operands
+            torch.autograd.backward(loss_clean, grad_tensors=half)
         g0 = xin.grad
         feature_map = fm_clean.detach()
         feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
@@ -233,7 +234,8 @@ class AfanTrainer:
             adv_in = feature_map_adv.detach()
         output_adv = m(adv_in, end_point=ln, start_point=idx)                    # main_perturb.py:195
         loss_adv = crit(output_adv, target)
-        torch.autograd.backward(loss_adv, grad_tensors=half)
+        torch.autograd.backward(loss_adv, grad_tensors=half)    # weight gradients: clean + adversarial operands, one launch
+        resnet_s.flush_wgrad(m)
         clean_bn.replay()                               # main_perturb.py:196's BatchNorm side effect, last in order
         if overlap_allreduce:
             self.reducer.begin()

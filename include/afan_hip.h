@@ -271,6 +271,13 @@ int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int6
 int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
                               int64_t ci, int64_t co, int k, int stride, float* workspace, int accumulate,
                               afan_stream_t stream);
+/* The same over TWO operand pairs of one layer in one launch and one slab reduction:
+ * grad (+)= wgrad(x[n], dy[n]) + wgrad(x2[n2], dy2[n2]) — a tail layer's operands of the clean and of the adversarial pass of
+ * one iteration (main_perturb.py:195-200: both contribute to the same .grad).  Tiled kernel only (ci, co multiples of 64);
+ * n * Ho * Wo must be a multiple of 64; workspace = afan_conv_wgrad_workspace_floats(n + n2, ...); n2 = 0: one pair. */
+int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2,
+                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
+                               float* workspace, int accumulate, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Classifier head of the slice protocol: AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110), run at the

@@ -368,3 +368,28 @@ def test_small_channel_epilogue_fusions(pkg, gpu, n, ci, co, h, k, stride):
             a = ops.bn_train_forward(ys, gamma, beta, None, True, 1e-5, 0.1, None, None, None, sts)[1]
             b = ops.bn_train_forward(ys, gamma, beta, None, True, 1e-5, 0.1, None, None, None, stg.group(g, co))[1]
             np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,n2,ci,co,h,k,stride", [(4, 4, 64, 64, 32, 3, 1), (8, 3, 128, 128, 16, 3, 1), (4, 4, 128, 256, 16, 3, 2),
+                                                   (16, 16, 256, 512, 8, 1, 2), (16, 5, 512, 512, 4, 3, 1)])
+def test_wgrad_two_operand_pairs_in_one_launch(pkg, gpu, n, n2, ci, co, h, k, stride):
+    """afan_conv_wgrad2: grad += wgrad(x, dy) + wgrad(x2, dy2) in one launch (a tail layer's clean and adversarial pass)
+    equals the two separate launches; pairs of different batch sizes; first pair's pixel count % 64 == 0."""
+    torch.manual_seed(n + n2 + ci + co + h + k)
+    ho = (h + 2 * (k // 2) - k) // stride + 1
+    mk = lambda b: (_cl(torch.randn(b, ci, h, h, device=gpu).bfloat16()),
+                    _cl((torch.randn(b, co, ho, ho, device=gpu) / (b * ho * ho) ** 0.5).bfloat16()))
+    (x, dy), (x2, dy2) = mk(n), mk(n2)
+    assert pkg.ops.wgrad_pairable(x, dy)
+    ref = pkg.ops.conv_wgrad(x, dy, k, stride)
+    pkg.ops.conv_wgrad(x2, dy2, k, stride, ref, accumulate=True)
+    got = pkg.ops.conv_wgrad(x, dy, k, stride, second=(x2, dy2))
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    acc = torch.ones_like(ref)
+    pkg.ops.conv_wgrad(x, dy, k, stride, acc, accumulate=True, second=(x2, dy2))
+    np.testing.assert_allclose(acc.cpu().numpy(), 1 + ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    assert torch.equal(pkg.ops.conv_wgrad(x, dy, k, stride, second=(x2, dy2)), got)      # fixed summation order
+    with pytest.raises(pkg.AfanLibraryError):                                            # 3 * 5 * 5 pixels: not a multiple of 64
+        xs, dys = _cl(torch.randn(3, 64, 5, 5, device=gpu).bfloat16()), _cl(torch.randn(3, 64, 5, 5, device=gpu).bfloat16())
+        pkg.ops.conv_wgrad(xs, dys, 3, 1, second=(xs, dys))
