@@ -61,9 +61,12 @@ struct WgradP {
     const uint16_t* dy2;
     uint32_t P1;
     int N2;
+    // incremental pixel decomposition (INC kernels): Wo divides 64, so a staged row keeps its output column over the K
+    // loop and advances by 64 pixels = dn images + dho rows per step; N1 = images of the first segment
+    int dn, dho, N1;
 };
 
-template <int BM, int BN>   // BM = co tile, BN = ci tile
+template <int BM, int BN, bool INC>   // BM = co tile, BN = ci tile; INC: see WgradP::dn
 __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
     constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 32, NI = TN / 32;
     constexpr int LDA = BM + 32, LDB = BN + 32;            // elements per LDS row
@@ -103,6 +106,24 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     u32x4 va[NA], vb[NB];
+    // INC: per staged x row — image and output row of its pixel at the slice's first step (over the concatenated batch of
+    // both segments: P1 is a whole number of images), validity and byte offset of its (constant) input column
+    int rn[NB], rho[NB];
+    bool wi_ok[NB];
+    uint32_t col_off[NB];
+    if constexpr (INC) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const uint32_t pix = p_begin + rb0 + i * RB;
+            const uint32_t t1 = fdiv(pix, p.dWo), wo = pix - t1 * p.Wo;
+            const uint32_t n = fdiv(t1, p.dHo);
+            rn[i] = (int)n;
+            rho[i] = (int)(t1 - n * p.Ho);
+            const int wi = (int)wo * p.stride + dw;
+            wi_ok[i] = wi >= 0 && wi < p.Wi;
+            col_off[i] = (uint32_t)((wi * p.Ci + ci0 + pb * 8) * 2);
+        }
+    }
     auto gload = [&](int ks) {
         const uint32_t pbase = p_begin + ks * BKP;
         const bool seg2 = pbase >= p.P1;                       // wave-uniform: the whole K-step lies in one segment
@@ -117,13 +138,26 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const uint32_t pix = pbase + rb0 + i * RB;
-            const uint32_t pl = pix - shift;
-            const uint32_t t1 = fdiv(pl, p.dWo), wo = pl - t1 * p.Wo;
-            const uint32_t n = fdiv(t1, p.dHo), ho = t1 - n * p.Ho;
-            const int hi = (int)ho * p.stride + dh, wi = (int)wo * p.stride + dw;
-            const bool ok = pix < plim && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
-            const uint32_t off = ok ? (((n * p.Hi + hi) * p.Wi + wi) * p.Ci + ci0 + pb * 8) * 2u : OOB;
-            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
+            if constexpr (INC) {
+                // (n, ho) of this row are carried from step to step (two fast divisions and their multiplies per row and
+                // step otherwise: ~120 VALU instructions per K-step against 16 MFMA); the column part is constant
+                const int hi = rho[i] * p.stride + dh;
+                const int nl = rn[i] - (seg2 ? p.N1 : 0);
+                const bool ok = pix < plim && wi_ok[i] && hi >= 0 && hi < p.Hi;
+                const uint32_t off = ok ? ((uint32_t)((nl * p.Hi + hi) * p.Wi) * (uint32_t)p.Ci) * 2u + col_off[i] : OOB;
+                vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
+                rn[i] += p.dn;
+                rho[i] += p.dho;
+                if (rho[i] >= p.Ho) { rho[i] -= p.Ho; rn[i] += 1; }
+            } else {
+                const uint32_t pl = pix - shift;
+                const uint32_t t1 = fdiv(pl, p.dWo), wo = pl - t1 * p.Wo;
+                const uint32_t n = fdiv(t1, p.dHo), ho = t1 - n * p.Ho;
+                const int hi = (int)ho * p.stride + dh, wi = (int)wo * p.stride + dw;
+                const bool ok = pix < plim && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
+                const uint32_t off = ok ? (((n * p.Hi + hi) * p.Wi + wi) * p.Ci + ci0 + pb * 8) * 2u : OOB;
+                vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
+            }
         }
     };
     auto lstore = [&]() {
@@ -229,7 +263,8 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
 template <int BM, int BN>
 int launch(const WgradP& p, int taps, hipStream_t st) {
     dim3 grid((unsigned)((p.Co / BM) * (p.Ci / BN)), (unsigned)taps, (unsigned)p.S);
-    wgrad_kernel<BM, BN><<<grid, THREADS, 0, st>>>(p);
+    if (p.dn >= 0) wgrad_kernel<BM, BN, true><<<grid, THREADS, 0, st>>>(p);
+    else wgrad_kernel<BM, BN, false><<<grid, THREADS, 0, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -297,6 +332,16 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
     p.k = k; p.stride = stride; p.pad = pad; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
     p.x2 = (const uint16_t*)x2; p.dy2 = (const uint16_t*)dy2; p.P1 = (uint32_t)P1; p.N2 = (int)n2;
+    p.N1 = (int)n;
+    p.dn = -1; p.dho = 0;
+    {   // 64 pixels = dn images + dho output rows exactly (the column does not move): Wo | 64 and dho <= Ho
+        static const bool inc_on = [] { const char* v = getenv("AFAN_WGRAD_INC"); return !v || atoi(v) != 0; }();
+        if (inc_on && BKP % wo == 0) {
+            const int64_t hw = ho * wo;
+            p.dn = (int)(BKP / hw);
+            p.dho = (int)((BKP % hw) / wo);
+        }
+    }
     p.dWo = make_fastdiv((uint32_t)wo); p.dHo = make_fastdiv((uint32_t)ho);
     hipStream_t st = (hipStream_t)stream;
     int rc;
