@@ -64,6 +64,7 @@ struct WgradP {
     // incremental pixel decomposition (INC kernels): Wo divides 64, so a staged row keeps its output column over the K
     // loop and advances by 64 pixels = dn images + dho rows per step; N1 = images of the first segment
     int dn, dho, N1;
+    int xcd_remap;       // 1: XCD-aware workgroup order (see the kernel)
 };
 
 template <int BM, int BN, bool INC>   // BM = co tile, BN = ci tile; INC: see WgradP::dn
@@ -79,8 +80,26 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = p.Ci / BN;
-    const int co0 = (blockIdx.x / tiles_n) * BM, ci0 = (blockIdx.x % tiles_n) * BN;
-    const int tap = blockIdx.y, slice = blockIdx.z;
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  The taps
+    // of one (tile, pixel slice) read the same dy tile and the same x pixels (shifted by a column or a row): with the tap
+    // as the grid's y dimension they ran far apart in time and on different XCDs, and every tap fetched its operands from
+    // HBM again (PMC: 267 MB per launch against 33 MB of operands).  Here dispatch slot `lin` is mapped to a logical
+    // index that is contiguous per XCD, with the tap fastest: the nine taps of a group run back to back on ONE XCD.
+    int tap, slice, tile;
+    {
+        const uint32_t taps_ = gridDim.y, tiles_ = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
+        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        uint32_t logical = lin;
+        if (p.xcd_remap) {
+            const uint32_t per = total >> 3, main_ = per << 3;           // the last total % 8 slots keep their index
+            if (lin < main_) logical = (lin & 7u) * per + (lin >> 3);
+        }
+        tap = (int)(logical % taps_);
+        const uint32_t rest = logical / taps_;
+        tile = (int)(rest % tiles_);
+        slice = (int)(rest / tiles_);
+    }
+    const int co0 = (tile / tiles_n) * BM, ci0 = (tile % tiles_n) * BN;
     const int dh = tap / p.k - p.pad, dw = tap % p.k - p.pad;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
@@ -333,6 +352,10 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
     p.k = k; p.stride = stride; p.pad = pad; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
     p.x2 = (const uint16_t*)x2; p.dy2 = (const uint16_t*)dy2; p.P1 = (uint32_t)P1; p.N2 = (int)n2;
     p.N1 = (int)n;
+    {
+        static const bool remap_on = [] { const char* v = getenv("AFAN_WGRAD_XCD"); return !v || atoi(v) != 0; }();
+        p.xcd_remap = remap_on ? 1 : 0;
+    }
     p.dn = -1; p.dho = 0;
     {   // 64 pixels = dn images + dho output rows exactly (the column does not move): Wo | 64 and dho <= Ho
         static const bool inc_on = [] { const char* v = getenv("AFAN_WGRAD_INC"); return !v || atoi(v) != 0; }();
