@@ -53,7 +53,7 @@ constexpr size_t LDS_BYTES = (size_t)NBUF * HALO_ALLOC * CH * 2 + (size_t)TP * L
 #endif
 
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps) {
+void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps, int xcd_pair) {
 #ifdef AFAN_C64_STAMPS
     uint64_t stamp_acc[6] = {0, 0, 0, 0, 0, 0};
     uint64_t stamp_last = __builtin_amdgcn_s_memtime();
@@ -65,7 +65,14 @@ void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps) {
     __shared__ __attribute__((aligned(16))) uint16_t w8[COH][(9 - RTAPS) * CH + 8];   // weights of the LDS-resident taps (padded rows)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int coh = blockIdx.x & 1;                      // which 32 output channels
+    // XCD-aware pairing: the two workgroups of a tile (channel halves) read the same halo; dispatch slots go to the XCDs
+    // round-robin, so slots are mapped to logical ids that are contiguous per XCD — a pair shares one XCD's L2
+    uint32_t bid = blockIdx.x;
+    if (xcd_pair) {
+        const uint32_t per = gridDim.x >> 3;
+        if (bid < (per << 3)) bid = (bid & 7u) * per + (bid >> 3);
+    }
+    const int coh = bid & 1;                             // which 32 output channels
     const int W = p.W, H = p.H, W2 = W + 2, TR = TP >> logW;
     const int HP = (TR + 2) * W2;                       // halo pixels actually used
     const int tiles_per_img = H / TR;
@@ -109,7 +116,7 @@ void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps) {
 
     // Two workgroups per CU (one per channel half) run out of step, so one's stores, barriers and halo fetches sit
     // under the other's MFMAs; inside a workgroup the schedule is the plain one: fetch next, multiply, stage, store.
-    int tile = blockIdx.x >> 1;
+    int tile = bid >> 1;
     const int G = gridDim.x >> 1;
     if (tile < tiles) fetch(tile, 0);
 
@@ -277,10 +284,10 @@ void conv3x3_c64_kernel(const Params p, int tiles, int logW, uint64_t* stamps) {
                 b += red[w][1][tid];
             }
             const int c = coh * COH + tid;
-            double* dst = p.acc + (int64_t)((blockIdx.x >> 1) & (p.acc_ns - 1)) * 2 * CH;
+            double* dst = p.acc + (int64_t)((bid >> 1) & (p.acc_ns - 1)) * 2 * CH;
             unsafeAtomicAdd(dst + c, (double)a);
             unsafeAtomicAdd(dst + CH + c, (double)b);
-            if (!bn_bwd && (blockIdx.x >> 1) == 0)
+            if (!bn_bwd && (bid >> 1) == 0)
                 reinterpret_cast<float*>(p.acc + (int64_t)2 * p.acc_ns * CH)[c] = p.shift ? p.shift[c] : 0.f;
         }
     }
@@ -319,7 +326,7 @@ int launch(const Params& p, hipStream_t st) {
 #ifdef AFAN_C64_STAMPS
     static uint64_t* stamps = nullptr;
     if (!stamps && hipMalloc(&stamps, 6 * 1024 * sizeof(uint64_t)) != hipSuccess) return AFAN_ESHAPE;
-    conv3x3_c64_kernel<<<grid, THREADS, LDS_BYTES, st>>>(p, tiles, logW, stamps);
+    conv3x3_c64_kernel<<<grid, THREADS, LDS_BYTES, st>>>(p, tiles, logW, stamps, 1);
     {
         static int calls = 0;
         if (++calls % 50 == 0) {
@@ -334,7 +341,8 @@ int launch(const Params& p, hipStream_t st) {
         }
     }
 #else
-    conv3x3_c64_kernel<<<grid, THREADS, LDS_BYTES, st>>>(p, tiles, logW, nullptr);
+    static const int xcd_pair = [] { const char* v = getenv("AFAN_C64_XCD"); return v ? atoi(v) : 1; }();
+    conv3x3_c64_kernel<<<grid, THREADS, LDS_BYTES, st>>>(p, tiles, logW, nullptr, xcd_pair);
 #endif
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
