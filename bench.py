@@ -179,11 +179,11 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary
         # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command supplies it (per launch)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01p_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01q_pmc_hbm_traffic.json")))
             key = next((k for k in pmc if k in name or name.replace("_fwd", "").replace("_dgrad", "") .startswith(k.split("_kernel")[0])), None)
             if key:
                 roof["traffic"] = round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024)
-                roof["traffic_source"] = "profiles/r01p_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch)"
+                roof["traffic_source"] = "profiles/r01q_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch)"
         except (OSError, KeyError, ValueError):
             pass
     if world > 1:
