@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--async_wgrad", action="store_true", help="weight gradients on a side stream (measured: no gain)")
     ap.add_argument("--no_batch_final", action="store_true", help="run the adv and clean final passes separately (A/B)")
     ap.add_argument("--no_fold_clean", action="store_true", help="separate first PGD pass and final clean pass (A/B)")
+    ap.add_argument("--force_fold_clean", action="store_true", help="one clean tail pass regardless of the size heuristic (A/B)")
     ap.add_argument("--no_share_head", action="store_true", help="run the head twice per step like the reference's text (A/B)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
@@ -110,7 +111,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
     trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
-                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph, batch_final=not args.no_batch_final, share_head=not args.no_share_head, fold_clean=(False if args.no_fold_clean else None),
+                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph, batch_final=not args.no_batch_final, share_head=not args.no_share_head, fold_clean=(False if args.no_fold_clean else (True if args.force_fold_clean else None)),
                                          async_wgrad=args.async_wgrad)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4

@@ -317,7 +317,7 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
                                float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
                                float* workspace, int accumulate, afan_stream_t stream) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0 || n2 < 0) return AFAN_ESHAPE;
-    if (n2 > 0 && (ci == 3 || afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride))) return AFAN_ESHAPE;  // tiled kernel only
+    if (n2 > 0 && ci == 3) return AFAN_ESHAPE;                  // (the stem runs in one pass per iteration)
     if (n2 > 0 && (!x2 || !dy2)) return AFAN_ENULL;
     if (ci == 3) {                                              // the image stem has its own kernel
         if (!afan_stem::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
@@ -334,7 +334,8 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         hipStream_t st = (hipStream_t)stream;
         const double P = (double)n * ((hi - 1) / stride + 1) * ((wi - 1) / stride + 1);
         AFAN_PROF_FLOPS("conv_wgrad_small_kernel", 2.0 * (P * co + (double)n * hi * wi * ci), 2.0 * P * co * ci * 9, st);
-        return afan_wgrad_small::launch(x, dy, grad, n, hi, wi, ci, co, stride, workspace, accumulate, st);
+        if (n2 > 0 && (!aligned(x2, 16) || !aligned(dy2, 16))) return AFAN_EALIGN;
+        return afan_wgrad_small::launch(x, dy, grad, n, hi, wi, ci, co, stride, workspace, accumulate, st, x2, dy2, n2);
     }
     if (ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
     if (!x || !dy || !grad || !workspace) return AFAN_ENULL;

@@ -32,6 +32,8 @@ constexpr int MAX_DY = 32 * (32 + 8);            // dy tile of one 32-channel gr
 
 struct P {
     const uint16_t* x; const uint16_t* dy; float* slab;
+    const uint16_t* x2; const uint16_t* dy2;   // optional second operand pair (another pass over the same layer), N2 images
+    int N2;
     int N, Hi, Wi, Ci, Ho, Wo, Co, s;
     int R;                 // output rows per tile (32 / Wo, or 1 when Wo >= 32)
     int wr, wc;            // window rows / columns
@@ -47,8 +49,10 @@ __global__ __launch_bounds__(THREADS) void wgrad_small_kernel(const P p) {
     const int cg = blockIdx.y;                             // output channels cg*32 .. +32
     const int cow = Co - cg * 32 < 32 ? Co - cg * 32 : 32; // channels of this group (16 or 32)
     const int LDW = Ci + 8, LDD = 32 + 8;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+    const __amdgpu_buffer_rsrc_t xr1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(p.x), 0, (int)((int64_t)p.N * Hi * Wi * Ci * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(p.x2), 0, p.x2 ? (int)((int64_t)p.N2 * Hi * Wi * Ci * 2) : 0, 0x00020000);
     uint16_t* win = win_s[wave];
     uint16_t* dyt = dy_s[wave];
 
@@ -62,8 +66,12 @@ __global__ __launch_bounds__(THREADS) void wgrad_small_kernel(const P p) {
     const int win_pieces = p.wr * p.wc * cpp;
     const int dpp = cow >> 3;                              // pieces per dy pixel (this group's channels)
     const int tiles_per_img = (p.Ho * Wo) >> 5;
-    const int tiles = p.N * tiles_per_img;
-    for (int t = blockIdx.x * WAVES + wave; t < tiles; t += gridDim.x * WAVES) {
+    const int tiles1 = p.N * tiles_per_img, tiles = tiles1 + p.N2 * tiles_per_img;
+    for (int tg = blockIdx.x * WAVES + wave; tg < tiles; tg += gridDim.x * WAVES) {
+        const bool seg2 = tg >= tiles1;                                // wave-uniform: a tile lies in one operand pair
+        const int t = seg2 ? tg - tiles1 : tg;
+        const __amdgpu_buffer_rsrc_t xr = seg2 ? xr2 : xr1;
+        const uint16_t* dyb = seg2 ? p.dy2 : p.dy;
         const int n = t / tiles_per_img, ti = t - n * tiles_per_img;
         const int ho0 = Wo >= 32 ? ti / (Wo >> 5) : ti * p.R;          // first output row of the tile
         const int wo0 = Wo >= 32 ? (ti - ho0 * (Wo >> 5)) << 5 : 0;    // first output column
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_small_kernel(const P p) {
             *reinterpret_cast<u32x4*>(win + px * LDW + c8 * 8) =
                 __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
         }
-        const uint16_t* dsrc = p.dy + ((int64_t)t * 32) * Co + cg * 32;
+        const uint16_t* dsrc = dyb + ((int64_t)t * 32) * Co + cg * 32;
         for (int q = lane; q < 32 * dpp; q += 64) {
             const int px = q / dpp, c8 = q - px * dpp;
             *reinterpret_cast<u16x8*>(dyt + px * LDD + c8 * 8) = *reinterpret_cast<const u16x8*>(dsrc + (int64_t)px * Co + c8 * 8);
@@ -188,15 +196,16 @@ int64_t workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t 
 }
 
 int launch(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int stride,
-           float* ws, int accumulate, hipStream_t st) {
+           float* ws, int accumulate, hipStream_t st, const void* x2, const void* dy2, int64_t n2) {
     P p{};
     p.x = (const uint16_t*)x; p.dy = (const uint16_t*)dy; p.slab = ws;
+    p.x2 = (const uint16_t*)x2; p.dy2 = (const uint16_t*)dy2; p.N2 = (int)n2;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Co = (int)co; p.s = stride;
     p.Ho = (int)((hi - 1) / stride + 1); p.Wo = (int)((wi - 1) / stride + 1);
     p.R = p.Wo >= 32 ? 1 : 32 / p.Wo;
     p.wr = (p.R - 1) * stride + 3;
     p.wc = ((p.Wo >= 32 ? 32 : p.Wo) - 1) * stride + 3;
-    const int S = slabs((int64_t)n * p.Ho * p.Wo / 32, co);
+    const int S = slabs((int64_t)(n + n2) * p.Ho * p.Wo / 32, co);
     dim3 grid((unsigned)S, (unsigned)((co + 31) / 32));
     wgrad_small_kernel<<<grid, THREADS, 0, st>>>(p);
     AFAN_LAUNCH_CHECK();

@@ -692,9 +692,12 @@ def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False, second=None):
     return grad
 
 
-def wgrad_pairable(x, dy):
-    """conv_wgrad(..., second=) takes this layer: tiled kernel (channels multiples of 64), first pair's pixels % 64 == 0."""
-    return x.shape[1] % 64 == 0 and dy.shape[1] % 64 == 0 and (dy.shape[0] * dy.shape[2] * dy.shape[3]) % 64 == 0
+def wgrad_pairable(x, dy, k=3, stride=1):
+    """conv_wgrad(..., second=) takes this layer: the tiled kernel (channels multiples of 64, first pair's pixels % 64 == 0)
+    or the small-channel kernel (any layer it takes); not the image stem."""
+    if x.shape[1] % 64 == 0 and dy.shape[1] % 64 == 0:
+        return (dy.shape[0] * dy.shape[2] * dy.shape[3]) % 64 == 0
+    return x.shape[1] != 3 and conv_wgrad_supported(x.shape[1], dy.shape[1], k, stride, (x.shape[0], x.shape[2], x.shape[3]))
 
 
 def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):

@@ -207,7 +207,7 @@ def _wgrad_accumulate(x, dy, c):
     (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
     k, st = c.kernel_size[0], c.stride[0]
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
-        pairable = ops.wgrad_pairable(x, dy)
+        pairable = ops.wgrad_pairable(x, dy, k, st)
         if _Flags.wgrad_stash and pairable:
             c._pending_wgrad = (x, dy)          # summed into the launch of the next pass over this layer (stash_wgrad)
             return

@@ -170,13 +170,14 @@ class AfanTrainer:
         self._stream = None
 
     # ------------------------------------------------------------------------------------------------ body
-    FOLD_MIN_ELEMS = 1 << 23      # feature-map elements (batch x C x H x W) from which fold_clean=None folds
+    FOLD_MIN_ELEMS = 0            # feature-map elements (batch x C x H x W) from which fold_clean=None folds (0: always)
 
     def _fold_ok(self, inp):
-        """fold_clean: True / False force it; None (default) folds where it pays — the folded schedule saves two tail
-        pass-units of arithmetic but issues the weight-gradient launches twice (clean and adversarial pass separately
-        instead of one grouped pass): launch-bound networks lose (ResNet-56s, batch 128: 11.19 -> 11.40 ms), the
-        compute-bound configurations win (ResNet-18 batch 256: 11.10 -> 10.47 ms; ResNet-50/224 batch 64: 31.7 -> 27.9)."""
+        """fold_clean: True / False force it; None (default) folds whenever the schedule applies (FOLD_MIN_ELEMS can
+        restrict it to large feature maps).  Before the clean and the adversarial pass shared their weight-gradient
+        launches the launch-bound networks lost with it (ResNet-56s, batch 128: 11.19 -> 11.40 ms); with the shared
+        launches everything measured wins: ResNet-56s 10.99 -> 10.76 ms, ResNet-20s 3.87 -> 3.71, ResNet-18 batch 256
+        11.10 -> 10.03, ResNet-50/224 batch 64 31.7 -> 26.9."""
         if self.fold_clean is False or not (self._share_head(inp) and self.steps >= 1 and not self.randinit
                                             and not self.async_wgrad):
             return False

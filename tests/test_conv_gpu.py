@@ -371,7 +371,10 @@ def test_small_channel_epilogue_fusions(pkg, gpu, n, ci, co, h, k, stride):
 
 
 @pytest.mark.parametrize("n,n2,ci,co,h,k,stride", [(4, 4, 64, 64, 32, 3, 1), (8, 3, 128, 128, 16, 3, 1), (4, 4, 128, 256, 16, 3, 2),
-                                                   (16, 16, 256, 512, 8, 1, 2), (16, 5, 512, 512, 4, 3, 1)])
+                                                   (16, 16, 256, 512, 8, 1, 2), (16, 5, 512, 512, 4, 3, 1),
+                                                   # the small-channel kernel (ResNet-20s / 56s layers)
+                                                   (8, 8, 16, 16, 32, 3, 1), (8, 3, 16, 32, 32, 3, 2), (6, 6, 32, 32, 16, 3, 1),
+                                                   (4, 7, 32, 64, 16, 3, 2)])
 def test_wgrad_two_operand_pairs_in_one_launch(pkg, gpu, n, n2, ci, co, h, k, stride):
     """afan_conv_wgrad2: grad += wgrad(x, dy) + wgrad(x2, dy2) in one launch (a tail layer's clean and adversarial pass)
     equals the two separate launches; pairs of different batch sizes; first pair's pixel count % 64 == 0."""
@@ -380,7 +383,7 @@ def test_wgrad_two_operand_pairs_in_one_launch(pkg, gpu, n, n2, ci, co, h, k, st
     mk = lambda b: (_cl(torch.randn(b, ci, h, h, device=gpu).bfloat16()),
                     _cl((torch.randn(b, co, ho, ho, device=gpu) / (b * ho * ho) ** 0.5).bfloat16()))
     (x, dy), (x2, dy2) = mk(n), mk(n2)
-    assert pkg.ops.wgrad_pairable(x, dy)
+    assert pkg.ops.wgrad_pairable(x, dy, k, stride)
     ref = pkg.ops.conv_wgrad(x, dy, k, stride)
     pkg.ops.conv_wgrad(x2, dy2, k, stride, ref, accumulate=True)
     got = pkg.ops.conv_wgrad(x, dy, k, stride, second=(x2, dy2))
