@@ -49,14 +49,32 @@ SIGNATURES = {
     "afan_bn_apply": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _p, _p, _p, _p, _i, _p, _p]),
     "afan_bn_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _l, _l, _p, _p, _p, _i, _p, _p, _p, _i, _p, _l, _p]),
     "afan_conv_supported": (_i, [_l, _l, _i, _i]),
-    "afan_conv_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _i, _p]),
+    "afan_conv_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _p, _p, _i, _p]),
     "afan_conv_fwd_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_bn_train_forward_partials": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _l, _p, _p, _p, _p, _p, _p]),
-    "afan_conv_dgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "afan_conv_dgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "afan_conv_dgrad_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),
-    "afan_conv_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _i, _p]),
-    "afan_conv_wgrad2_nhwc_bf16": (_i, [_p, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _p, _i, _p]),
+    "afan_conv_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
+    "afan_conv_wgrad2_nhwc_bf16": (_i, [_p, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
+    "afan_conv_stem7_supported": (_i, [_l, _l, _i, _i]),
+    "afan_conv_stem7_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p]),
+    "afan_conv_stem7_wgrad_workspace_floats": (_l, [_l, _l, _l]),
+    "afan_conv_stem7_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p, _i, _p]),
+    "afan_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),
+    "afan_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),
+    "afan_ce2d_workspace_floats": (_l, [_l]),
+    "afan_ce2d": (_i, [_p, _p, _i, _l, _l, _l, _l, _f, _p, _p, _p, _p]),
+    "afan_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _p]),
+    "afan_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _p]),
+    "afan_avgpool_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _p]),
+    "afan_avgpool_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _p]),
+    "afan_pointwise_max_co": (_i, []),
+    "afan_pointwise_fwd": (_i, [_p, _i, _p, _p, _p, _l, _l, _l, _p]),
+    "afan_pointwise_bwd_dx": (_i, [_p, _p, _p, _i, _l, _l, _l, _p]),
+    "afan_pointwise_workspace_floats": (_l, [_l, _l, _l]),
+    "afan_pointwise_bwd_dw": (_i, [_p, _p, _i, _p, _p, _l, _l, _l, _p, _i, _p]),
+    "afan_dropout": (_i, [_p, _p, _i, _l, _f, _p, _p, _p, _i, _p]),
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),

@@ -21,7 +21,10 @@ _ALIGN = 64  # floats: every tensor starts on a 256-byte boundary of the arena
 
 
 class ParamArena:
-    def __init__(self, model, skip=("w",), bf16_shadow=None, allow_cpu=False, channels_last=None):
+    def __init__(self, model, skip=("w",), bf16_shadow=None, allow_cpu=False, channels_last=None, index_root=None):
+        """index_root: the module whose .parameters() the REFERENCE hands to torch.optim.SGD (default: the model itself,
+        main_perturb.py:72; main_learnable.py:82 passes model.sequential_model) — optimizer state is keyed by a
+        parameter's position in that list (ArenaSGD.state_dict)."""
         all_named = list(model.named_parameters())
         named = [(n, p) for n, p in all_named if n not in skip and p.requires_grad]
         if not named:
@@ -33,9 +36,12 @@ class ParamArena:
         self.names = [n for n, _ in named]
         # index of every managed parameter in model.parameters() order (what torch.optim.SGD(model.parameters())
         # uses as state keys, main_perturb.py:72 — the skipped `w` is index 0 there)
-        all_names = [n for n, _ in all_named]
-        self.model_index = [all_names.index(n) for n in self.names]
-        self.n_model_params = len(all_names)
+        if index_root is None:
+            root_ids = [id(p) for _, p in all_named]
+        else:
+            root_ids = [id(p) for p in index_root.parameters()]
+        self.model_index = [root_ids.index(id(p)) for _, p in named]     # ValueError: a managed parameter outside the root
+        self.n_model_params = len(root_ids)
         self.offsets, off = [], 0
         for _, p in named:
             self.offsets.append(off)
@@ -114,46 +120,82 @@ class ParamArena:
 
 class ArenaSGD(torch.optim.Optimizer):
     """torch.optim.SGD's surface (param_groups, step, zero_grad, state_dict in the SAME layout, so lr schedulers
-    and the reference's checkpoints work) executed as ONE afan_sgd_step launch over the arena."""
+    and the reference's checkpoints work) executed as ONE afan_sgd_step launch per parameter group over the arena.
 
-    def __init__(self, arena, lr, momentum=0.9, weight_decay=5e-4):
+    groups: None = one group over everything (main_perturb.py:72-74), or [(name_prefix, lr), ...] — consecutive runs of
+    the arena's parameters by name prefix, each with its own learning rate (Segmentation/main_aug_final.py:79-82:
+    backbone 0.1*lr, classifier lr).  Every group's lr lives in device memory (arena.lr[g])."""
+
+    def __init__(self, arena, lr, momentum=0.9, weight_decay=5e-4, groups=None):
         self.arena = arena
-        super().__init__(arena.params, dict(lr=float(lr), momentum=float(momentum), dampening=0,
-                                            weight_decay=float(weight_decay), nesterov=False))
-        self._lr_on_device = None
+        base = dict(lr=float(lr), momentum=float(momentum), dampening=0, weight_decay=float(weight_decay), nesterov=False)
+        if groups is None:
+            spec = [dict(params=arena.params)]
+            self._ranges = [(0, arena.numel)]
+            self._members = [list(range(len(arena.params)))]
+        else:
+            spec, self._ranges, self._members = [], [], []
+            bounds = arena.offsets + [arena.numel]
+            i = 0
+            for prefix, glr in groups:
+                j = i
+                while j < len(arena.names) and arena.names[j].startswith(prefix):
+                    j += 1
+                if j == i:
+                    raise ValueError(f"no parameters (left) with prefix {prefix!r}: groups must follow the arena's order")
+                spec.append(dict(params=arena.params[i:j], lr=float(glr)))
+                self._ranges.append((bounds[i], bounds[j]))
+                self._members.append(list(range(i, j)))
+                i = j
+            if i != len(arena.names):
+                raise ValueError("parameter groups do not cover the arena")
+        super().__init__(spec, base)
+        if arena.lr.numel() < len(self.param_groups):
+            arena.lr = torch.zeros(len(self.param_groups), dtype=torch.float32, device=arena.param.device)
+        self._lr_on_device = [None] * len(self.param_groups)
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
     def _sync_lr(self):
-        lr = float(self.param_groups[0]["lr"])
-        if lr != self._lr_on_device:
-            self.arena.lr.fill_(lr)
-            self._lr_on_device = lr
+        for gi, g in enumerate(self.param_groups):
+            lr = float(g["lr"])
+            if lr != self._lr_on_device[gi]:
+                self.arena.lr[gi:gi + 1].fill_(lr)
+                self._lr_on_device[gi] = lr
 
     @torch.no_grad()
     def step(self, closure=None):
-        g = self.param_groups[0]
         if not torch.cuda.is_current_stream_capturing():
             self._sync_lr()     # (inside a capture the fill would be frozen into the graph: callers sync before replay)
         a = self.arena
-        ops.sgd_step_(a.param, a.grad, a.momentum_buf, a.lr, g["momentum"], g["weight_decay"], self.grad_scale,
-                      a.shadow)
+        for gi, (g, (lo, hi)) in enumerate(zip(self.param_groups, self._ranges)):
+            ops.sgd_step_(a.param[lo:hi], a.grad[lo:hi], a.momentum_buf[lo:hi], a.lr[gi:gi + 1], g["momentum"],
+                          g["weight_decay"], self.grad_scale, a.shadow[lo:hi] if a.shadow is not None else None)
         a.refresh_transposed()
         _Flags.weight_epoch += 1   # module-level caches of transposed weights (no arena) are stale now
 
     def state_dict(self):
-        """Layout of torch.optim.SGD(model.parameters()).state_dict() (main_perturb.py:124,132 store it): state keyed
-        by the parameter's index in model.parameters(); parameters outside the arena (`w`) have no state."""
+        """Layout of torch.optim.SGD(<root>.parameters()).state_dict() (main_perturb.py:124,132 store it): state keyed
+        by the parameter's index in the root's parameter list (ParamArena index_root); parameters outside the arena
+        (`w`) have no state.  With several groups: each group lists its own indices, as torch does."""
         a = self.arena
         state = {mi: {"momentum_buffer": a.view(a.momentum_buf, i).clone()} for i, mi in enumerate(a.model_index)}
-        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        group["params"] = list(range(a.n_model_params))
-        return {"state": state, "param_groups": [group]}
+        out_groups = []
+        for gi, g in enumerate(self.param_groups):
+            group = {k: v for k, v in g.items() if k != "params"}
+            if len(self.param_groups) == 1:
+                group["params"] = list(range(a.n_model_params))
+            else:
+                group["params"] = [a.model_index[i] for i in self._members[gi]]
+            out_groups.append(group)
+        return {"state": state, "param_groups": out_groups}
 
     def load_state_dict(self, sd):
         a = self.arena
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
         for i, mi in enumerate(a.model_index):
             st = sd["state"].get(mi)
             buf = a.view(a.momentum_buf, i)
@@ -161,8 +203,9 @@ class ArenaSGD(torch.optim.Optimizer):
                 buf.copy_(st["momentum_buffer"])
             else:
                 buf.zero_()
-        for k in ("lr", "momentum", "weight_decay"):
-            self.param_groups[0][k] = sd["param_groups"][0][k]
-        if "initial_lr" in sd["param_groups"][0]:
-            self.param_groups[0]["initial_lr"] = sd["param_groups"][0]["initial_lr"]
-        self._lr_on_device = None
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "momentum", "weight_decay"):
+                g[k] = src[k]
+            if "initial_lr" in src:
+                g["initial_lr"] = src["initial_lr"]
+        self._lr_on_device = [None] * len(self.param_groups)

@@ -44,7 +44,7 @@ constexpr int BK = 64;           // reduction channels per step
 constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes (register-staged variants)
 
 // landing zone for the padding rows of the LDS-DMA variant (a DMA lane has to read SOMETHING: zeros)
-constexpr int MAX_PAD = 1;   // |tap displacement| <= 1 pixel in both directions (3x3 / 1x1, stride 1 or 2, forward and dgrad)
+// (|tap displacement| <= ConvP::max_pad pixels in both directions: 1 for 3x3 / 1x1, the dilation for atrous 3x3)
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
 constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     const uint32_t M = (uint32_t)pp.N * Hg * Wg;
     const uint32_t m0 = blockIdx.y * BM;
     if (m0 >= M) {         // smaller class than the grid's tallest: nothing to compute, but its partial slots must read 0
-        if (pp.stats && threadIdx.x < BN) {
+        if (pp.stats && threadIdx.x < BN && (int)(blockIdx.x * BN + threadIdx.x) < pp.Co) {
             const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
             const int c = blockIdx.x * BN + threadIdx.x;
             pp.stats[((int64_t)0 * pp.Co + c) * G + slot] = 0.f;
@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         out_off[r] = off;
     }
     const uint32_t b_off = ((uint32_t)(n0 + row0) * pp.w_row_stride + piece * 8) * 2u;
+    const int b_rows_ok = pp.Co - n0 - row0;                      // weight row (row0 + RPP * i) exists iff RPP * i < b_rows_ok
     const uint32_t b_row32 = (uint32_t)RPP * pp.w_row_stride * 2u;
 
     // accumulators: acc[j][i] = channels tile j x pixels tile i (weights are the MFMA A operand, so a lane ends up
@@ -146,22 +147,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    const int chunks = Ci / BK;
+    // Ragged channel counts (multiples of 8, e.g. DeepLab's 304-channel decoder input and 48-channel projection): the last
+    // 64-channel chunk of a tap is partly beyond Ci — those 16-byte pieces are requested at an out-of-range offset (zeros
+    // from the hardware range check) for BOTH operands, and weight rows / output channels >= Co are masked the same way.
+    const int chunks = (Ci + BK - 1) / BK;
     const int KS = T * chunks;
+    const bool last_ok = (chunks - 1) * BK + piece * 8 < Ci;      // this thread's piece exists in the last chunk
     u32x4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
 
     auto gload = [&](int ks, u32x4 (&ra)[A_ROWS], u32x4 (&rb)[B_ROWS]) {
         const int t = ks / chunks, q = ks - t * chunks;
         const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK) * 2);   // may be "negative": wraps
         const uint32_t b_tap = (uint32_t)((cc.wofs[t] + q * BK) * 2);
+        const bool pk = q + 1 < chunks || last_ok;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const uint32_t off = ((a_valid[i] >> t) & 1u) ? a_off[i] + a_tap : OOB;
+            const uint32_t off = (((a_valid[i] >> t) & 1u) && pk) ? a_off[i] + a_tap : OOB;
             ra[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(b_off + i * b_row32), (int)b_tap, 0));
+            rb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (pk && RPP * i < b_rows_ok) ? (int)(b_off + i * b_row32) : (int)OOB, (int)b_tap, 0));
     };
     auto lstore = [&](int buf, const u32x4 (&ra)[A_ROWS], const u32x4 (&rb)[B_ROWS]) {
         uint16_t* A = lds + buf * STAGE;
@@ -204,12 +210,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     // activation descriptor is based A_BIAS bytes below the tensor to keep the scalar offset non-negative; gfx950 range-checks
     // VGPR + scalar offset against num_records (measured: with num_records = tensor bytes the last rows of the tensor read
     // as zero), so num_records = tensor bytes + A_BIAS; an invalid row is VGPR offset 2^31 (LDS gets zeros).
-    const uint32_t A_BIAS = (uint32_t)(((MAX_PAD * Wi + MAX_PAD) * Ci) * 2);
+    const uint32_t A_BIAS = (uint32_t)(((pp.max_pad * Wi + pp.max_pad) * Ci) * 2);
     const __amdgpu_buffer_rsrc_t xdma = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(const_cast<uint16_t*>(pp.x)) - A_BIAS, 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2 + A_BIAS), 0x00020000);
     uint32_t b_voff[B_ROWS];
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) b_voff[i] = b_off + i * b_row32;
+    for (int i = 0; i < B_ROWS; ++i) b_voff[i] = RPP * i < b_rows_ok ? b_off + i * b_row32 : OOB;
     // K-steps are issued strictly in order 0, 1, 2, ...: the (tap, chunk) position and the two scalar offsets are carried
     // from call to call instead of being recomputed from ks (an integer division and three scalar loads of the tap table
     // per step, with the s_waitcnt lgkmcnt(0) they drag along: 63 SALU instructions per K-step before).
@@ -219,17 +225,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     auto gdma = [&](int /*ks*/, int buf) {
         const int t = dma_t;
         const int a_tap = dma_a, b_tap = dma_b;
+        const bool pk = dma_q + 1 < chunks || last_ok;
         uint16_t* A = lds + buf * STAGE + wave * 512;          // wave-uniform: M0 base; hardware adds lane * 16 B
         uint16_t* B = A + BM * LDR;
         typedef __attribute__((address_space(3))) void* lptr;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
-            const uint32_t voff = ((a_valid[i] >> t) & 1u) ? a_off[i] : OOB;
+            const uint32_t voff = (((a_valid[i] >> t) & 1u) && pk) ? a_off[i] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xdma, (lptr)(A + i * (RPP * 64)), 16, (int)voff, a_tap, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr)(B + i * (RPP * 64)), 16, (int)b_voff[i], b_tap, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr)(B + i * (RPP * 64)), 16, pk ? (int)b_voff[i] : (int)OOB, b_tap, 0, 0);
         // advance to the next K-step
         if (++dma_q == chunks) {
             dma_q = 0;
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     constexpr int ROWS_PER_PASS = THREADS / PIECES;
     constexpr int EPI_ROWS = BM / ROWS_PER_PASS;
     const int pc = tid % PIECES, pr = tid / PIECES;
+    const bool ch_ok = n0 + pc * 8 < pp.Co;      // this thread's 8 output channels exist (Co % 8 == 0)
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
     u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
 #pragma unroll
         for (int q = 0; q < EPI_ROWS; ++q) {
             const int off = out_off[pr + q * ROWS_PER_PASS];
-            const uint32_t bo = off >= 0 ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
+            const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
             if (pp.addend) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
             if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
             if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
-        const int c = n0 + pc * 8 + j;
+        const int c = ch_ok ? n0 + pc * 8 + j : 0;
         sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && pp.shift) ? pp.shift[c] : 0.f);   // mean or shift
         al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : 0.f;
         be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : 0.f;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     for (int q = 0; q < EPI_ROWS; ++q) {
         const int r = pr + q * ROWS_PER_PASS;
         const int off = out_off[r];
-        if (off >= 0) {
+        if (off >= 0 && ch_ok) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
             if (pp.addend) {
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
             }
         }
         __syncthreads();
-        if (tid < BN) {
+        if (tid < BN && n0 + tid < pp.Co) {
             float a = 0.f, b = 0.f;
 #pragma unroll
             for (int w = 0; w < THREADS / 64; ++w) {
@@ -460,7 +468,7 @@ template <int BM, int BN, int PF, int WM, int WN>
 int launch(const ConvP& p, hipStream_t st) {
     constexpr int THREADS = 64 * WM * WN;
     const int64_t M = max_rows(p);
-    dim3 grid((unsigned)(p.Co / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
+    dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
     constexpr size_t stage_bytes = (size_t)(PF <= 3 ? 2 : PF - 1) * (BM + BN) * (PF >= 3 ? BK : LDK) * 2;
     constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
@@ -484,13 +492,13 @@ static int env_int(const char* name, int dflt) {
 // tile choice: fill >= ~256 workgroups when the problem allows it
 int choose_bm(int64_t M, int co, int n_classes) {
     const bool n128 = (co % 128 == 0);
-    const int64_t wg_128 = ((M + 127) / 128) * (co / (n128 ? 128 : 64)) * n_classes;
+    const int64_t wg_128 = ((M + 127) / 128) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
     static const int thr = env_int("AFAN_CONV_THR128", 256);   // (256 vs 384: +0.3 % of the step)
     if (wg_128 >= thr) return 128;
     // 385..768 workgroups of 64 rows (the 8x8 stage) would be two per CU on the two-stage pipeline; 128-row tiles bring
     // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
     static const int tall = env_int("AFAN_CONV_TALL", 1);
-    const int64_t wg_64 = ((M + 63) / 64) * (co / (n128 ? 128 : 64)) * n_classes;
+    const int64_t wg_64 = ((M + 63) / 64) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
     if (tall && n128 && n_classes == 1 && wg_64 > 384 && wg_64 <= 768) return 128;
     return 64;
 }
@@ -547,15 +555,16 @@ int set_groups(ConvP& p, int groups, int64_t n, int64_t positions_per_image, int
 // reduction channels `ci` / output channels `co` of the GEMM: multiples of 64 (the tiled kernels), or the small-channel
 // kernel's set (afan_conv_small.hip): ci in {16, 32, 64}, co a multiple of 16 up to 64
 bool channels_ok(int64_t ci, int64_t co) {
-    if (ci % BK == 0 && co % 64 == 0) return true;
+    if (ci % 8 == 0 && co % 8 == 0 && ci >= 40 && co >= 40) return true;     // tiled kernel (ragged last chunk / tile masked)
     return (ci == 16 || ci == 32 || ci == 64) && co % 16 == 0 && co <= 64;
 }
 
-int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation = 1) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0) return AFAN_ESHAPE;
     if (!channels_ok(ci, co)) return AFAN_ESHAPE;                // caller falls back for the 3-channel stem
     if (!(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
-    if (n * hi * wi * (ci > co ? ci : co) * 2 + 2 * (wi + 1) * (ci > co ? ci : co) > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit byte offsets / buffer descriptors (+ the DMA descriptor's bias)
+    if (dilation < 1 || dilation > 64 || (dilation > 1 && (stride != 1 || k != 3))) return AFAN_ESHAPE;   // atrous: 3x3, stride 1
+    if (n * hi * wi * (ci > co ? ci : co) * 2 + 2 * dilation * (wi + 1) * (ci > co ? ci : co) > 0x7fffffffLL) return AFAN_ESHAPE;  // 32-bit byte offsets / buffer descriptors (+ the DMA descriptor's bias)
     return AFAN_OK;
 }
 
@@ -572,18 +581,20 @@ int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
 // number of row tiles (= BN-statistics partials per channel) the forward launch of this problem uses
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (check_dims(n, hi, wi, ci, co, k, stride)) return 0;
-    const int pad = k / 2;
+    const int pad = k / 2;     // (a dilated 3x3 at stride 1 keeps the spatial size, like the plain one)
     const int64_t M = n * ((hi + 2 * pad - k) / stride + 1) * ((wi + 2 * pad - k) / stride + 1);
     const int bm = choose_bm(M, (int)co, 1);
     return (M + bm - 1) / bm;
 }
 
-// y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding k/2, stride 1 or 2; all bf16, channels-last.
+// y[N,Ho,Wo,Co] = conv(x[N,Hi,Wi,Ci], w[Co,k,k,Ci]) with padding dilation*(k/2), stride 1 or 2 (dilation > 1: 3x3 at
+// stride 1, the atrous convolutions of Segmentation/network/backbone/resnet.py:29-32 and _deeplab.py:146-153); all bf16,
+// channels-last.
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                            int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
+                            int64_t co, int k, int stride, int dilation, float* stats_partials, const float* stats_shift,
                             double* stats_acc, int groups, afan_stream_t stream) {
     if (ci == 3) {                                              // the image stem has its own kernel
-        if (!afan_stem::eligible(n, hi, wi, ci, co, k, stride) || stats_partials || groups > 1) return AFAN_ESHAPE;
+        if (!afan_stem::eligible(n, hi, wi, ci, co, k, stride) || stats_partials || groups > 1 || dilation != 1) return AFAN_ESHAPE;
         if (!x || !w || !y) return AFAN_ENULL;
         if (!aligned(x, 2) || !aligned(w, 2) || !aligned(y, 16) || (stats_acc && !aligned(stats_acc, 16))) return AFAN_EALIGN;
         hipStream_t st = (hipStream_t)stream;
@@ -591,12 +602,13 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
         AFAN_PROF_FLOPS("conv_stem_fwd_kernel", 2.0 * (M * co + M * 3 + 27.0 * co), 2.0 * M * co * 27, st);
         return afan_stem::fwd_launch(x, w, y, n, hi, wi, co, stats_acc, afan_nhwc::acc_slot_count(co), stats_shift, st);
     }
-    int e = check_dims(n, hi, wi, ci, co, k, stride);
+    int e = check_dims(n, hi, wi, ci, co, k, stride, dilation);
     if (e) return e;
     if (!x || !w || !y) return AFAN_ENULL;
     if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 16)) return AFAN_EALIGN;
     const int pad = k / 2;
     ConvP p{};
+    p.max_pad = dilation;
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
     p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
@@ -610,15 +622,15 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     for (int r = 0; r < k; ++r)
         for (int s = 0; s < k; ++s) {
             const int t = r * k + s;
-            c0.dh[t] = r - pad; c0.dw[t] = s - pad; c0.wofs[t] = (int)(t * ci);
+            c0.dh[t] = (r - pad) * dilation; c0.dw[t] = (s - pad) * dilation; c0.wofs[t] = (int)(t * ci);
         }
     hipStream_t st = (hipStream_t)stream;
     const double M = (double)n * p.Ho * p.Wo;
     AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
                     2.0 * M * co * k * k * ci, st);
     if (small_eligible(p)) return small_launch(p, st);
-    if (ci % BK != 0 || co % 64 != 0) return AFAN_ESHAPE;       // (small shape asked for the partial-slab statistics)
-    if (!stats_partials && groups <= 1 && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
+    if (ci % 8 != 0 || co % 8 != 0 || ci < 40 || co < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab statistics)
+    if (!stats_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.flip = 0;
         q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
@@ -653,10 +665,10 @@ int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int
 // the backward of the BatchNorm whose input was bn_x — its reduction sums are written to bn_partials[2][Ci][G], or
 // added into the f64 accumulators bn_acc[2][Ci] (zeroed by the caller; see afan_bn_backward_acc).
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                              int64_t co, int k, int stride, const void* addend, const void* bn_x,
+                              int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
                               double* bn_acc, int groups, afan_stream_t stream) {
-    int e = check_dims(n, hi, wi, co, ci, k, stride);   // reduction runs over co here
+    int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
     if (e) return e;
     if (!dy || !wt || !dx) return AFAN_ENULL;
     if (!aligned(dy, 16) || !aligned(wt, 16) || !aligned(dx, 16)) return AFAN_EALIGN;
@@ -668,6 +680,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.N = (int)n; p.Hi = ho; p.Wi = wo; p.Ci = (int)co;      // GEMM input = dy
     p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
     p.w_row_stride = (int)(k * k * co);
+    p.max_pad = dilation;
     p.addend = (const uint16_t*)addend;
     if (bn_partials && bn_acc) return AFAN_ESHAPE;
     if (bn_partials || bn_acc) {
@@ -683,7 +696,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
     p.in_s = 1;
-    if (!bn_partials && groups <= 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
+    if (!bn_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
         afan_c64::Params q{};
         q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
         q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu; q.bny = p.bny;
@@ -698,10 +711,10 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
         for (int r = 0; r < k; ++r)
             for (int s = 0; s < k; ++s) {
                 const int t = r * k + s;
-                c0.dh[t] = pad - r; c0.dw[t] = pad - s; c0.wofs[t] = (int)(t * co);
+                c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
             }
         if (small_eligible(p)) return small_launch(p, st);
-        if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
+        if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
         return dispatch(p, st);
     }
     // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
@@ -732,7 +745,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
         }
     p.n_classes = nc;
     if (small_eligible(p)) return small_launch(p, st);
-    if (co % BK != 0 || ci % 64 != 0) return AFAN_ESHAPE;
+    if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
     return dispatch(p, st);
 }
 

@@ -25,6 +25,7 @@ struct ConvP {
     int out_s;
     int w_row_stride;            // elements between consecutive weight rows (output channels of this GEMM)
     int n_classes;
+    int max_pad;                 // largest |tap displacement| in pixels (1; the dilation for an atrous 3x3): sizes the DMA descriptor's bias
     float* stats;                // optional [2][Co][G] per-tile column sums, G = gridDim.y * gridDim.z; meaning by `bnx`:
     const float* shift;          //   bnx == NULL: sum (y - shift), sum (y - shift)^2      (moments for a following BN forward)
     const uint16_t* bnx;         //   bnx != NULL: y is d(loss)/d(BN output); bnx = that BN's INPUT (same shape as y):

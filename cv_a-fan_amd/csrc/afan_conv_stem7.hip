@@ -1,0 +1,175 @@
+// ImageNet-style image stem: 7x7 / stride 2 / pad 3 convolution, 3 -> 64 channels, bf16 channels-last — the first layer
+// of the DeepLabv3+ / ResNet-50/101 backbones (Segmentation/network/backbone/resnet.py:143-144 `conv1`) and of the
+// build-defined ImageNet-shape ResNet-50.  Forward and weight gradient; no input gradient (images carry none on the
+// A-FAN feature path).  ~0.6 % of the 513x513 step's FLOPs and K = 147 with 6-byte pixels (nothing wider than 2 bytes is
+// aligned when the image width is odd), so this is a plain fp32 FMA kernel out of LDS, not an MFMA one: a workgroup
+// stages the 7 input rows of a 64-pixel output segment once (133 pixels each) and all 147 x 64 weights, then every lane
+// owns one output channel (weights: conflict-free LDS reads; pixels: broadcasts).
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int CO = 64, KK = 7, K = KK * KK * 3;   // 147
+constexpr int SEG = 64;                           // output pixels per tile (one row segment)
+constexpr int PATCH = (2 * SEG + 5) * 3;          // 399 staged elements per input row
+constexpr int ROWP = 400;
+constexpr int PPT = SEG / 4;                      // forward: pixels per thread (4 pixel groups x 64 channels)
+constexpr int KPT = (K + 3) / 4;                  // wgrad: reduction columns per thread (4 groups): 37
+
+__device__ __forceinline__ void stage_patch(const uint16_t* __restrict__ x, float* xl, int n, int oy, int ox0, int Hi, int Wi) {
+    const int ix0 = 2 * ox0 - 3;
+    for (int i = threadIdx.x; i < KK * PATCH; i += BLOCK) {
+        const int r = i / PATCH, e = i - r * PATCH;
+        const int iy = 2 * oy - 3 + r, col = ix0 + e / 3;
+        float v = 0.f;
+        if (iy >= 0 && iy < Hi && col >= 0 && col < Wi) v = bf2f(x[(((int64_t)n * Hi + iy) * Wi + ix0) * 3 + e]);
+        xl[r * ROWP + e] = v;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void stem7_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                          uint16_t* __restrict__ y, int Hi, int Wi, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;               // [K][CO]
+    float* xl = lds + K * CO;      // [7][ROWP]
+    const int n = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * SEG;
+    for (int i = threadIdx.x; i < K * CO; i += BLOCK) {
+        const int ch = i / K, k = i - ch * K;
+        wl[k * CO + ch] = bf2f(w[i]);
+    }
+    stage_patch(x, xl, n, oy, ox0, Hi, Wi);
+    __syncthreads();
+    const int ch = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    float acc[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) acc[p] = 0.f;
+    for (int r = 0; r < KK; ++r) {
+#pragma unroll 3
+        for (int j = 0; j < 21; ++j) {
+            const float wv = wl[(r * 21 + j) * CO + ch];
+            const float* xp = xl + r * ROWP + pg * PPT * 6 + j;
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) acc[p] = fmaf(wv, xp[p * 6], acc[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const int ox = ox0 + pg * PPT + p;
+        if (ox < Wo) y[(((int64_t)n * Ho + oy) * Wo + ox) * CO + ch] = f2bf(acc[p]);
+    }
+}
+
+// persistent workgroups; slab[blk][k][ch]
+__global__ __launch_bounds__(BLOCK) void stem7_wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                            float* __restrict__ slab, int N, int Hi, int Wi, int Ho, int Wo,
+                                                            int segs, int64_t tiles) {
+    __shared__ float dyl[SEG * CO];
+    __shared__ float xl[KK * ROWP];
+    const int ch = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    float acc[KPT];
+    int koff[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        acc[j] = 0.f;
+        const int k = kg * KPT + j;
+        koff[j] = k < K ? (k / 21) * ROWP + (k % 21) : -1;
+    }
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int seg = (int)(t % segs);
+        const int64_t t2 = t / segs;
+        const int oy = (int)(t2 % Ho), n = (int)(t2 / Ho);
+        const int ox0 = seg * SEG;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SEG * CO; i += BLOCK) {
+            const int p = i >> 6, c = i & 63;
+            dyl[i] = (ox0 + p < Wo) ? bf2f(dy[(((int64_t)n * Ho + oy) * Wo + ox0 + p) * CO + c]) : 0.f;
+        }
+        stage_patch(x, xl, n, oy, ox0, Hi, Wi);
+        __syncthreads();
+        for (int p = 0; p < SEG; ++p) {
+            const float d = dyl[p * CO + ch];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (koff[j] >= 0) acc[j] = fmaf(d, xl[koff[j] + p * 6], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = kg * KPT + j;
+        if (k < K) slab[((int64_t)blockIdx.x * K + k) * CO + ch] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void stem7_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad,
+                                                                   int G, int accumulate) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;      // index into [k][ch]
+    if (i >= K * CO) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += slab[(int64_t)g * K * CO + i];
+    const int k = i >> 6, ch = i & 63;
+    float* dst = grad + ch * K + k;                      // KRSC: [ch][r][s][c]
+    *dst = accumulate ? *dst + s : s;
+}
+
+int wgrad_blocks(int64_t tiles) { return (int)(tiles < 512 ? tiles : 512); }
+
+}  // namespace
+
+extern "C" {
+
+int afan_conv_stem7_supported(int64_t ci, int64_t co, int k, int stride) { return (ci == 3 && co == CO && k == KK && stride == 2) ? 1 : 0; }
+
+// y[N,Ho,Wo,64] = conv7x7/2 pad 3 (x[N,Hi,Wi,3], w[64,7,7,3]); all bf16 channels-last.  Ho = (Hi - 1) / 2 + 1.
+int afan_conv_stem7_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || n > 65535) return AFAN_ESHAPE;
+    if (!x || !w || !y) return AFAN_ENULL;
+    if (!aligned(x, 2) || !aligned(w, 2) || !aligned(y, 2)) return AFAN_EALIGN;
+    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    if (ho > 65535) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(K * CO + KK * ROWP) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)stem7_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const double M = (double)n * ho * wo;
+    AFAN_PROF_FLOPS("conv_stem7_fwd_kernel", 2.0 * (M * CO + (double)n * hi * wi * 3), 2.0 * M * CO * K, st);
+    dim3 grid((unsigned)((wo + SEG - 1) / SEG), (unsigned)ho, (unsigned)n);
+    stem7_fwd_kernel<<<grid, BLOCK, lds, st>>>((const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (int)hi, (int)wi, (int)ho, (int)wo);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int64_t afan_conv_stem7_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi) {
+    if (n <= 0 || hi <= 0 || wi <= 0) return 0;
+    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    return (int64_t)wgrad_blocks(n * ho * ((wo + SEG - 1) / SEG)) * K * CO;
+}
+
+// grad[64,7,7,3] (fp32, KRSC) (+)= sum over output pixels of dy[N,Ho,Wo,64] * window(x[N,Hi,Wi,3])
+int afan_conv_stem7_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
+                                    float* workspace, int accumulate, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0) return AFAN_ESHAPE;
+    if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
+    if (!aligned(x, 2) || !aligned(dy, 2) || !aligned(grad, 4) || !aligned(workspace, 4)) return AFAN_EALIGN;
+    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    const int segs = (int)((wo + SEG - 1) / SEG);
+    const int64_t tiles = n * ho * segs;
+    const int G = wgrad_blocks(tiles);
+    hipStream_t st = (hipStream_t)stream;
+    const double M = (double)n * ho * wo;
+    AFAN_PROF_FLOPS("conv_stem7_wgrad_kernel", 2.0 * (M * CO + (double)n * hi * wi * 3) + 4.0 * G * K * CO, 2.0 * M * CO * K, st);
+    stem7_wgrad_kernel<<<G, BLOCK, 0, st>>>((const uint16_t*)x, (const uint16_t*)dy, workspace, (int)n, (int)hi, (int)wi, (int)ho,
+                                            (int)wo, segs, tiles);
+    AFAN_LAUNCH_CHECK();
+    stem7_wgrad_reduce_kernel<<<(K * CO + BLOCK - 1) / BLOCK, BLOCK, 0, st>>>(workspace, grad, G, accumulate);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // extern "C"

@@ -49,7 +49,7 @@ struct WgradP {
     const uint16_t* dy;  // [N, Ho, Wo, Co]
     float* slab;         // [S][taps][Co][Ci]
     int N, Hi, Wi, Ci, Ho, Wo, Co;
-    int k, stride, pad;
+    int k, stride, pad, dil;     // pad = dil * (k / 2)
     int S;               // pixel slices
     int steps_per_slice; // BKP-pixel steps per slice (last slice may be ragged; rows beyond P read as zero)
     uint32_t P;          // output pixels in total (both segments)
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = p.Ci / BN;
+    const int tiles_n = (p.Ci + BN - 1) / BN;      // ragged channel counts (multiples of 8): pieces beyond Co / Ci read as zero
     // XCD-aware order: workgroups go to the 8 XCDs round-robin in dispatch order, and each XCD has its own L2.  The taps
     // of one (tile, pixel slice) read the same dy tile and the same x pixels (shifted by a column or a row): with the tap
     // as the grid's y dimension they ran far apart in time and on different XCDs, and every tap fetched its operands from
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
         slice = (int)(rest / tiles_);
     }
     const int co0 = (tile / tiles_n) * BM, ci0 = (tile % tiles_n) * BN;
-    const int dh = tap / p.k - p.pad, dw = tap % p.k - p.pad;
+    const int dh = (tap / p.k) * p.dil - p.pad, dw = (tap % p.k) * p.dil - p.pad;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(p.x), 0, (int)((int64_t)p.N * p.Hi * p.Wi * p.Ci * 2), 0x00020000);
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
 
     const int pa = tid % PA, ra0 = tid / PA;   // dy tile: piece / first row
     const int pb = tid % PB, rb0 = tid / PB;   // x tile
+    const bool a_ok = co0 + pa * 8 < p.Co, b_ok = ci0 + pb * 8 < p.Ci;
     const uint32_t p_begin = (uint32_t)slice * p.steps_per_slice * BKP;
 
     f32x16 acc[MI][NI];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const uint32_t pix = pbase + ra0 + i * RA;
-            const uint32_t off = pix < plim ? ((pix - shift) * p.Co + co0 + pa * 8) * 2u : OOB;
+            const uint32_t off = (pix < plim && a_ok) ? ((pix - shift) * p.Co + co0 + pa * 8) * 2u : OOB;
             va[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dsel, (int)off, 0, 0));
         }
 #pragma unroll
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
                 // step otherwise: ~120 VALU instructions per K-step against 16 MFMA); the column part is constant
                 const int hi = rho[i] * p.stride + dh;
                 const int nl = rn[i] - (seg2 ? p.N1 : 0);
-                const bool ok = pix < plim && wi_ok[i] && hi >= 0 && hi < p.Hi;
+                const bool ok = pix < plim && wi_ok[i] && hi >= 0 && hi < p.Hi && b_ok;
                 const uint32_t off = ok ? ((uint32_t)((nl * p.Hi + hi) * p.Wi) * (uint32_t)p.Ci) * 2u + col_off[i] : OOB;
                 vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
                 rn[i] += p.dn;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
                 const uint32_t t1 = fdiv(pl, p.dWo), wo = pl - t1 * p.Wo;
                 const uint32_t n = fdiv(t1, p.dHo), ho = t1 - n * p.Ho;
                 const int hi = (int)ho * p.stride + dh, wi = (int)wo * p.stride + dw;
-                const bool ok = pix < plim && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi;
+                const bool ok = pix < plim && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi && b_ok;
                 const uint32_t off = ok ? (((n * p.Hi + hi) * p.Wi + wi) * p.Ci + ci0 + pb * 8) * 2u : OOB;
                 vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xsel, (int)off, 0, 0));
             }
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int ci = ci0 + wc * TN + j * 32 + (lane & 31);
-                out[(int64_t)co * p.Ci + ci] = acc[i][j][r];
+                if (co < p.Co && ci < p.Ci) out[(int64_t)co * p.Ci + ci] = acc[i][j][r];
             }
 }
 
@@ -267,7 +268,7 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
     Plan pl;
     pl.bm = (co % 128 == 0) ? 128 : 64;
     pl.bn = (ci % 128 == 0) ? 128 : 64;
-    const int64_t tiles = (int64_t)(co / pl.bm) * (ci / pl.bn) * taps;
+    const int64_t tiles = (int64_t)((co + pl.bm - 1) / pl.bm) * ((ci + pl.bn - 1) / pl.bn) * taps;
     const int64_t total_steps = (P + BKP - 1) / BKP;
     static const int target = [] { const char* v = getenv("AFAN_WGRAD_WGS"); return v ? atoi(v) : 512; }();
     int64_t S = target / tiles;                    // ~2 workgroups per CU (measured: 512 beats 320 by 2 % of the step)
@@ -281,7 +282,7 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
 
 template <int BM, int BN>
 int launch(const WgradP& p, int taps, hipStream_t st) {
-    dim3 grid((unsigned)((p.Co / BM) * (p.Ci / BN)), (unsigned)taps, (unsigned)p.S);
+    dim3 grid((unsigned)(((p.Co + BM - 1) / BM) * ((p.Ci + BN - 1) / BN)), (unsigned)taps, (unsigned)p.S);
     if (p.dn >= 0) wgrad_kernel<BM, BN, true><<<grid, THREADS, 0, st>>>(p);
     else wgrad_kernel<BM, BN, false><<<grid, THREADS, 0, st>>>(p);
     AFAN_LAUNCH_CHECK();
@@ -296,7 +297,7 @@ extern "C" {
 int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
     if (ci == 3) return afan_stem::eligible(n, hi, wi, ci, co, k, stride) ? afan_stem::wgrad_workspace_floats(n, hi, wi, co) : 0;
     if (afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) return afan_wgrad_small::workspace_floats(n, hi, wi, ci, co, stride);
-    if (n <= 0 || hi <= 0 || wi <= 0 || ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2))
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci % 8 || co % 8 || ci < 40 || co < 40 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2))
         return 0;
     const int pad = k / 2;
     const int64_t P = n * ((hi + 2 * pad - k) / stride + 1) * ((wi + 2 * pad - k) / stride + 1);
@@ -306,17 +307,19 @@ int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int6
 
 // grad[Co,k,k,Ci] (fp32, KRSC) (+)= wgrad(x[N,Hi,Wi,Ci], dy[N,Ho,Wo,Co]); bf16 channels-last operands.
 int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                              int64_t co, int k, int stride, float* workspace, int accumulate, afan_stream_t stream) {
-    return afan_conv_wgrad2_nhwc_bf16(x, dy, n, nullptr, nullptr, 0, grad, hi, wi, ci, co, k, stride, workspace, accumulate,
-                                      stream);
+                              int64_t co, int k, int stride, int dilation, float* workspace, int accumulate,
+                              afan_stream_t stream) {
+    return afan_conv_wgrad2_nhwc_bf16(x, dy, n, nullptr, nullptr, 0, grad, hi, wi, ci, co, k, stride, dilation, workspace,
+                                      accumulate, stream);
 }
 
 // The same over TWO operand pairs of one layer in one launch: grad (+)= wgrad(x, dy) + wgrad(x2, dy2) (n2 = 0: one pair).
 // Workspace: afan_conv_wgrad_workspace_floats(n + n2, ...).  The first pair's output pixel count must be a multiple of 64.
 int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2,
-                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
+                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation,
                                float* workspace, int accumulate, afan_stream_t stream) {
     if (n <= 0 || hi <= 0 || wi <= 0 || ci <= 0 || co <= 0 || n2 < 0) return AFAN_ESHAPE;
+    if (dilation < 1 || (dilation > 1 && (k != 3 || stride != 1 || ci % 8 || co % 8 || ci < 40 || co < 40))) return AFAN_ESHAPE;
     if (n2 > 0 && ci == 3) return AFAN_ESHAPE;                  // (the stem runs in one pass per iteration)
     if (n2 > 0 && (!x2 || !dy2)) return AFAN_ENULL;
     if (ci == 3) {                                              // the image stem has its own kernel
@@ -328,7 +331,7 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         AFAN_PROF_FLOPS("conv_stem_wgrad_kernel", 2.0 * (M * co + M * 3), 2.0 * M * co * 27, st);
         return afan_stem::wgrad_launch(x, dy, grad, n, hi, wi, co, workspace, accumulate, st);
     }
-    if (afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) {     // 16/32-channel layers
+    if (dilation == 1 && afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) {     // 16/32-channel layers
         if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
         if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 4) || !aligned(workspace, 16)) return AFAN_EALIGN;
         hipStream_t st = (hipStream_t)stream;
@@ -337,11 +340,11 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         if (n2 > 0 && (!aligned(x2, 16) || !aligned(dy2, 16))) return AFAN_EALIGN;
         return afan_wgrad_small::launch(x, dy, grad, n, hi, wi, ci, co, stride, workspace, accumulate, st, x2, dy2, n2);
     }
-    if (ci % 64 || co % 64 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
+    if (ci % 8 || co % 8 || ci < 40 || co < 40 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
     if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
     if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 16) || !aligned(workspace, 16)) return AFAN_EALIGN;
-    const int pad = k / 2;
-    const int64_t ho = (hi + 2 * pad - k) / stride + 1, wo = (wi + 2 * pad - k) / stride + 1;
+    const int pad = dilation * (k / 2);
+    const int64_t ho = (hi + 2 * (k / 2) - k) / stride + 1, wo = (wi + 2 * (k / 2) - k) / stride + 1;
     const int64_t P1 = n * ho * wo, P = (n + n2) * ho * wo;
     if (P * co * 2 > 0x7fffffffLL || (n + n2) * hi * wi * ci * 2 > 0x7fffffffLL) return AFAN_ESHAPE;
     if (n2 > 0 && (P1 % BKP != 0 || !aligned(x2, 16) || !aligned(dy2, 16))) return n2 > 0 && P1 % BKP != 0 ? AFAN_ESHAPE : AFAN_EALIGN;
@@ -350,7 +353,7 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
     WgradP p{};
     p.x = (const uint16_t*)x; p.dy = (const uint16_t*)dy; p.slab = workspace;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
-    p.k = k; p.stride = stride; p.pad = pad; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
+    p.k = k; p.stride = stride; p.pad = pad; p.dil = dilation; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
     p.x2 = (const uint16_t*)x2; p.dy2 = (const uint16_t*)dy2; p.P1 = (uint32_t)P1; p.N2 = (int)n2;
     p.N1 = (int)n;
     {

@@ -1,0 +1,588 @@
+"""DeepLabv3+ (atrous ResNet-50/101 backbone) with the reference's split-forward protocol, on the library's kernels
+(second slice; BASELINE config 4).
+
+Host-side mirror of `Segmentation/network/`:
+  * `_SimpleSegmentationModel.forward(input_dict)` — the dict dispatch of network/utils.py:14-47 (flag head / tail / clean,
+    integer or "aspp|concat"_"head|tail" out_idx) that `Segmentation/attack_algo.py:40-105` calls back into;
+  * `ResNet` backbone with `replace_stride_with_dilation` (backbone/resnet.py:109-304) and `DeepLabHeadV3Plus` with the
+    aspp / concat split (_deeplab.py:28-80), `ASPP` (_deeplab.py:143-193);
+  * state_dict keys identical to the reference's (`backbone.conv1.weight`, `backbone.layer3.0.downsample.1.running_mean`,
+    `classifier.aspp.convs.4.1.weight`, `classifier.classifier.3.bias`, ...), so checkpoints interchange.
+What differs is execution: bf16 channels-last activations, every 1x1 / 3x3 / atrous convolution on the implicit-GEMM MFMA
+kernels (a Bottleneck is one autograd node, `resnet_s._BlockFn`), BatchNorm (+ReLU, +residual) fused, and the resize / max
+pool / average pool / classifier / dropout / per-pixel cross-entropy layers as hand-written HIP kernels (`afan_seg.hip`).
+fp32 (parity mode) keeps the vendor's fp32 convolutions, like the classification path; everything else is the same code.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .resnet_s import (BatchNorm2d, Conv2d, NormalizeByChannelMeanStd, _BlockFn, _Flags, _accumulates_in_place,
+                       _block_fast_path_ok, _block_params, _dense, _like_layout, _to_compute)
+
+__all__ = ["deeplabv3plus_resnet50", "deeplabv3plus_resnet101", "deeplabv3_resnet50", "deeplabv3_resnet101", "DeepLabV3",
+           "seg_criterion", "set_bn_momentum", "PolyLR", "MODELS"]
+
+
+# ------------------------------------------------------------------------------------------- autograd nodes
+class _UpsampleFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) (afan_upsample_bilinear_*)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        x = _dense(x)
+        ctx.in_hw, ctx.like = x.shape[2:], x
+        return ops.upsample_bilinear(x, size)
+
+    @staticmethod
+    def backward(ctx, g):
+        y_like = ctx.like
+        cl = ops.layout_of(y_like) == ops.AFAN_NHWC
+        g = g.contiguous(memory_format=torch.channels_last) if cl else g.contiguous()
+        return ops.upsample_bilinear_backward(g, ctx.in_hw), None
+
+
+def interpolate(x, size):
+    size = (int(size[0]), int(size[1]))
+    if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        if tuple(x.shape[2:]) == size:
+            return x
+        return _UpsampleFn.apply(x, size)
+    return nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class _BroadcastFn(torch.autograd.Function):
+    """Bilinear resize of a 1x1 map = broadcast over the pixels (the ASPP pooling branch, _deeplab.py:139-141); the
+    backward sums the pixels of every (image, channel) — through the average-pool kernel (sum = mean * HW)."""
+
+    @staticmethod
+    def forward(ctx, x, size, channels_last):
+        n, c = x.shape[:2]
+        ctx.hw = size
+        y = x.reshape(n, c, 1, 1).expand(n, c, size[0], size[1])
+        return y.contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dense(g)
+        s = ops.avgpool(g)
+        return s * float(ctx.hw[0] * ctx.hw[1]), None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x)
+        ctx.save_for_backward(x)
+        return ops.maxpool3x3s2(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_backward(_match(g, x), x)
+
+
+def _match(g, ref):
+    """g in ref's memory format (channels-last or contiguous)."""
+    if ref.dim() == 4 and ops.layout_of(ref) == ops.AFAN_NHWC:
+        return g.contiguous(memory_format=torch.channels_last)
+    return g.contiguous()
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x)
+        ctx.like = x
+        return ops.avgpool(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.avgpool_backward(g.contiguous(), ctx.like)
+
+
+class _PointwiseFn(torch.autograd.Function):
+    """nn.Conv2d(ci, num_classes, 1) with bias on a channels-last map, fp32 logits (afan_pointwise_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_pgrad):
+        x = _dense(x)
+        ctx.save_for_backward(x, weight)
+        ctx.bias, ctx.pg = bias, want_pgrad
+        return ops.pointwise_forward(x, weight.detach(), None if bias is None else bias.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        bias = ctx.bias
+        want_p = ctx.pg and ctx.needs_input_grad[1]
+        dw = db = None
+        direct = False
+        if want_p:
+            direct = _accumulates_in_place(weight) and (bias is None or _accumulates_in_place(bias))
+            if direct:
+                dw, db = weight.grad, (bias.grad if bias is not None else None)
+            else:
+                dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                db = torch.empty_like(bias) if bias is not None else None
+        g = g.contiguous(memory_format=torch.channels_last)
+        dx = ops.pointwise_backward(g, x, weight.detach(), ctx.needs_input_grad[0], dw, db, accumulate=direct)
+        if direct:
+            dw = db = None
+        return dx, dw, db, None
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, mask):
+        x = _dense(x)
+        y, used = ops.dropout(x, p, mask)
+        ctx.p, ctx.mask, ctx.used = p, mask, used
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _dense(g)
+        if ctx.mask is not None:
+            g = _match(g, ctx.mask)
+        return ops.dropout(g, ctx.p, ctx.mask, ctx.used)[0], None, None
+
+
+class _CE2dFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(ignore_index=I)(logits [N,C,H,W], target [N,H,W]) and grad_scale * its gradient in one pass
+    (afan_ce2d).  backward with the library's cached scalar 1 (ops.one) hands the stored gradient over as it is."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, grad_scale):
+        logits = _dense(logits)
+        loss, dl = ops.ce2d(logits, target, ignore_index, grad_scale)
+        ctx.save_for_backward(dl)
+        ctx.scale = grad_scale
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        if g.data_ptr() == ops.one(g.device).data_ptr():
+            return dl, None, None, None
+        return dl * (g / ctx.scale), None, None, None
+
+
+def seg_criterion(criterion):
+    """`criterion` as the step applies it to the upsampled logits: a plain nn.CrossEntropyLoss(ignore_index=I,
+    reduction='mean') becomes the one-pass HIP form on GPU fp32 logits of up to 32 classes; anything else is unchanged.
+    The returned callable also takes grad_scale= (the weight of this term in the joint loss, main_aug_final.py:216):
+    the gradient it stores is pre-scaled, for `torch.autograd.backward(loss, ops.one(dev))`."""
+    if not (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == "mean"
+            and getattr(criterion, "label_smoothing", 0.0) == 0.0):
+        return criterion
+    ign = criterion.ignore_index
+
+    def ce(out, y, grad_scale=1.0):
+        if (out.is_cuda and out.dtype == torch.float32 and out.dim() == 4 and out.shape[1] <= ops.CE2D_MAX_CLASSES
+                and y.dtype == torch.int64 and y.dim() == 3):
+            return _CE2dFn.apply(out, y, ign, float(grad_scale))
+        return criterion(out, y)
+    ce.fused = True
+    return ce
+
+
+class _Stem7Fn(torch.autograd.Function):
+    """conv1 (7x7 / 2, 3 -> 64) on the image: forward + weight gradient (afan_conv_stem7_*); images carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, w_lp, want_wgrad):
+        ctx.save_for_backward(x)
+        ctx.w_master, ctx.want = w_master, want_wgrad
+        return ops.conv_stem7_fwd(x, w_lp)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gw = None
+        if ctx.want and ctx.needs_input_grad[1]:
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            wm = ctx.w_master
+            if _accumulates_in_place(wm) and wm.grad.is_contiguous(memory_format=torch.channels_last):
+                ops.conv_stem7_wgrad(x, gy, wm.grad, accumulate=True)
+            else:
+                gw = ops.conv_stem7_wgrad(x, gy)
+        return None, gw, None, None
+
+
+# ---------------------------------------------------------------------------------------------------- layers
+class StemConv(Conv2d):
+    """backbone/resnet.py:143: nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)."""
+
+    def forward(self, x):
+        x = _to_compute(x, self.compute_dtype)
+        w = self.lp_weight()
+        if not x.requires_grad and ops.conv_stem7_ok(x, w, self.stride, self.padding) and w.is_contiguous(memory_format=torch.channels_last):
+            return _Stem7Fn.apply(x, self.weight, w.detach(), _Flags.param_grads)
+        return super().forward(x)
+
+    def forward_with_stats(self, x, bn):
+        return self.forward(x), None
+
+
+class ClassifierConv(Conv2d):
+    """_deeplab.py:45: nn.Conv2d(256, num_classes, 1) — with bias, fp32 logits."""
+
+    def forward(self, x):
+        x = _to_compute(x, self.compute_dtype)
+        if ops.pointwise_supported(x, self.out_channels) and self.weight.dtype == torch.float32:
+            return _PointwiseFn.apply(x, self.weight, self.bias, _Flags.param_grads)
+        ops.CALLS["vendor_conv"] += 1
+        return nn.functional.conv2d(x.float(), self.weight, self.bias)
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and (self.kernel_size, self.stride, self.padding) == (3, 2, 1):
+            return _MaxPoolFn.apply(x)
+        return super().forward(x)
+
+
+class Dropout(nn.Dropout):
+    """nn.Dropout(p) with the mask drawn in-kernel (device generator) — or supplied by the caller through `.mask`
+    (uint8 tensor, consumed by the next forward; parity tests)."""
+    mask = None
+
+    def forward(self, x):
+        if not self.training or (self.p == 0 and self.mask is None):
+            return x
+        if not x.is_cuda:
+            return super().forward(x)
+        mask = self.mask
+        if mask is not None:
+            mask = _match(mask.to(x.device, torch.uint8), _dense(x))
+        return _DropoutFn.apply(x, float(self.p), mask)
+
+
+def _enter(x, dtype, channels_last):
+    """A caller's tensor (e.g. the fp32 x_adv of a PGD step) in the network's compute dtype and activation layout."""
+    if channels_last and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    return _to_compute(x, dtype)
+
+
+def _cbr(conv, bn, x, relu=True):
+    """conv -> BatchNorm (moments from the convolution's epilogue where the kernels take the shape) -> ReLU."""
+    out, st = conv.forward_with_stats(x, bn)
+    return bn.fused(out, None, relu, st)
+
+
+class Bottleneck(nn.Module):
+    """backbone/resnet.py:76-119: 1x1 -> 3x3 (stride, dilation) -> 1x1 x4, `downsample` = 1x1 conv + BN when the shape
+    changes.  One autograd node on the bf16 channels-last path (resnet_s._BlockFn)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1, stride=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self._sc_kind = "conv" if downsample is not None else "identity"
+
+    @property
+    def shortcut(self):          # the name resnet_s._BlockFn uses for the projection branch
+        return self.downsample
+
+    def _chain(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+    def forward(self, x):
+        x = _to_compute(x, self.conv1.compute_dtype)
+        if _Flags.block_fusion and _block_fast_path_ok(self, x):
+            return _BlockFn.apply(x, self, _Flags.param_grads, *_block_params(self))
+        out = _cbr(self.conv1, self.bn1, x)
+        out = _cbr(self.conv2, self.bn2, out)
+        out, st = self.conv3.forward_with_stats(out, self.bn3)
+        res = x if self.downsample is None else _cbr(self.downsample[0], self.downsample[1], x, relu=False)
+        return self.bn3.fused(out, res, True, st)
+
+
+class ResNet(nn.Module):
+    """backbone/resnet.py:109-304 (Bottleneck variants): atrous ResNet with the head / tail / clean dispatch."""
+
+    def __init__(self, layers, replace_stride_with_dilation=(False, False, False)):
+        super().__init__()
+        self.normal = NormalizeByChannelMeanStd(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+        self.inplanes, self.dilation = 64, 1
+        self.conv1 = StemConv(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2, dilate=replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(256, layers[2], stride=2, dilate=replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(512, layers[3], stride=2, dilate=replace_stride_with_dilation[2])
+        for m in self.modules():                               # backbone/resnet.py:160-165
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        downsample, previous_dilation = None, self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                       BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, previous_dilation)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, dilation=self.dilation))
+        return nn.Sequential(*layers)
+
+    def _stem(self, x):
+        x = self.normal(x)
+        x = self.bn1.fused(self.conv1(x), None, True)
+        return self.maxpool(x)
+
+    def forward(self, input_dict):
+        stages = [self.layer1, self.layer2, self.layer3, self.layer4]
+        flag, out = input_dict["flag"], {}
+        if flag in ("head", "clean"):
+            last = 4 if flag == "clean" else input_dict["out_idx"]
+            assert last in (1, 2, 3, 4)
+            x = self.layer1(self._stem(input_dict["x"]))
+            out["low_level"] = x
+            for st in stages[1:last]:
+                x = st(x)
+            out["out"] = x
+            return out
+        assert flag == "tail" and input_dict["out_idx"] in (1, 2, 3, 4)
+        x = _enter(input_dict["adv"], self.conv1.compute_dtype, self.normal.channels_last)
+        for st in stages[input_dict["out_idx"]:]:
+            x = st(x)
+        out["out"] = x
+        out["low_level"] = input_dict["low_level_feat"]
+        return out
+
+
+class ASPPConv(nn.Sequential):
+    """_deeplab.py:143-150."""
+
+    def __init__(self, in_channels, out_channels, dilation):
+        super().__init__(Conv2d(in_channels, out_channels, 3, padding=dilation, dilation=dilation, bias=False),
+                         BatchNorm2d(out_channels), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return _cbr(self[0], self[1], x)
+
+
+class ASPPPooling(nn.Sequential):
+    """_deeplab.py:152-163: global average pool -> 1x1 conv -> BN -> ReLU -> resize back (a broadcast)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.AdaptiveAvgPool2d(1), Conv2d(in_channels, out_channels, 1, bias=False), BatchNorm2d(out_channels),
+                         nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        size = tuple(x.shape[-2:])
+        if not x.is_cuda:
+            y = nn.functional.relu(self[2](self[1](self[0](x))))
+            return nn.functional.interpolate(y, size=size, mode="bilinear", align_corners=False)
+        cl = ops.layout_of(x) == ops.AFAN_NHWC
+        y = _cbr(self[1], self[2], _AvgPoolFn.apply(x))
+        return _BroadcastFn.apply(y, size, cl)
+
+
+class ASPP(nn.Module):
+    """_deeplab.py:165-193."""
+
+    def __init__(self, in_channels, atrous_rates):
+        super().__init__()
+        oc = 256
+        mods = [nn.Sequential(Conv2d(in_channels, oc, 1, bias=False), BatchNorm2d(oc), nn.ReLU(inplace=True))]
+        mods += [ASPPConv(in_channels, oc, r) for r in atrous_rates]
+        mods.append(ASPPPooling(in_channels, oc))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(Conv2d(5 * oc, oc, 1, bias=False), BatchNorm2d(oc), nn.ReLU(inplace=True), Dropout(0.1))
+
+    def forward(self, x):
+        x = _to_compute(x, self.convs[0][0].compute_dtype)
+        res = [_cbr(self.convs[0][0], self.convs[0][1], x)] + [c(x) for c in list(self.convs)[1:]]
+        res = torch.cat(res, dim=1)
+        return self.project[3](_cbr(self.project[0], self.project[1], res))
+
+
+class DeepLabHeadV3Plus(nn.Module):
+    """_deeplab.py:28-90, with the aspp / concat split-forward return types."""
+
+    def __init__(self, in_channels, low_level_channels, num_classes, aspp_dilate=(12, 24, 36)):
+        super().__init__()
+        self.project = nn.Sequential(Conv2d(low_level_channels, 48, 1, bias=False), BatchNorm2d(48), nn.ReLU(inplace=True))
+        self.aspp = ASPP(in_channels, aspp_dilate)
+        self.classifier = nn.Sequential(Conv2d(304, 256, 3, padding=1, bias=False), BatchNorm2d(256), nn.ReLU(inplace=True),
+                                        ClassifierConv(256, num_classes, 1))
+        _init_head(self)
+
+    def _classify(self, cat):
+        return self.classifier[3](_cbr(self.classifier[0], self.classifier[1], cat))
+
+    channels_last = False     # set by DeepLabV3.set_channels_last
+
+    def _concat(self, low, hi):
+        hi = interpolate(_enter(hi, self.project[0].compute_dtype, self.channels_last), low.shape[2:])
+        return torch.cat([low, hi], dim=1)
+
+    def forward(self, feature, return_type=None):
+        dt, cl = self.project[0].compute_dtype, self.channels_last
+        if return_type == "aspp_head":
+            return self.aspp(_enter(feature["out"], dt, cl))
+        if return_type == "concat_tail":
+            return self._classify(_enter(feature["adv"], dt, cl))
+        low = _cbr(self.project[0], self.project[1], _enter(feature["low_level"], dt, cl))
+        if return_type == "aspp_tail":
+            return self._classify(self._concat(low, feature["adv"]))
+        cat = self._concat(low, self.aspp(_enter(feature["out"], dt, cl)))
+        if return_type == "concat_head":
+            return cat
+        assert return_type is None
+        return self._classify(cat)
+
+
+class DeepLabHead(nn.Module):
+    """_deeplab.py:92-115 (DeepLabv3: no decoder)."""
+
+    def __init__(self, in_channels, num_classes, aspp_dilate=(12, 24, 36)):
+        super().__init__()
+        self.classifier = nn.Sequential(ASPP(in_channels, aspp_dilate), Conv2d(256, 256, 3, padding=1, bias=False),
+                                        BatchNorm2d(256), nn.ReLU(inplace=True), ClassifierConv(256, num_classes, 1))
+        _init_head(self)
+
+    channels_last = False
+
+    def forward(self, feature):
+        c = self.classifier
+        return c[4](_cbr(c[1], c[2], c[0](_enter(feature["out"], c[1].compute_dtype, self.channels_last))))
+
+
+def _init_head(head):          # _deeplab.py:82-89
+    for m in head.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class DeepLabV3(nn.Module):
+    """network/utils.py:8-47 `_SimpleSegmentationModel`: the dict dispatch the A-FAN operators call back into."""
+
+    def __init__(self, backbone, classifier):
+        super().__init__()
+        self.backbone = backbone
+        self.classifier = classifier
+        self.compute_dtype = torch.float32
+        self.channels_last = False
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.compute_dtype = dtype
+            elif isinstance(m, NormalizeByChannelMeanStd):
+                m.out_dtype = dtype
+        return self
+
+    def set_channels_last(self, on=True):
+        self.channels_last = bool(on)
+        for m in self.modules():
+            if isinstance(m, NormalizeByChannelMeanStd):
+                m.channels_last = self.channels_last
+        self.classifier.channels_last = self.channels_last
+        return self
+
+    def _up(self, x, input_shape):
+        return interpolate(x, input_shape)
+
+    def forward(self, input_dict):
+        flag = input_dict["flag"]
+        if flag == "head":
+            return self.backbone(input_dict)
+        assert flag in ("tail", "clean")
+        idx = input_dict["out_idx"]
+        if type(idx) == int:
+            features = self.backbone(input_dict)
+            return self._up(self.classifier(features), input_dict["x"].shape[-2:])
+        if idx in ("aspp_head", "concat_head"):
+            features = self.backbone(input_dict)
+            features["adv"] = self.classifier(features, return_type=idx)
+            return features
+        assert idx in ("aspp_tail", "concat_tail")
+        return self._up(self.classifier(input_dict["adv"], return_type=idx), input_dict["x"].shape[-2:])
+
+
+def set_bn_momentum(model, momentum=0.1):
+    """utils/utils.py:26-29 (main_aug_final.py:77 sets the backbone's BatchNorm momentum to 0.01)."""
+    for m in model.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.momentum = momentum
+
+
+class PolyLR(torch.optim.lr_scheduler._LRScheduler):
+    """utils/scheduler.py:3-12."""
+
+    def __init__(self, optimizer, max_iters, power=0.9, last_epoch=-1, min_lr=1e-6):
+        self.power, self.max_iters, self.min_lr = power, max_iters, min_lr
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        return [max(base_lr * (1 - self.last_epoch / self.max_iters) ** self.power, self.min_lr) for base_lr in self.base_lrs]
+
+
+def _segm_resnet(name, layers, num_classes, output_stride):
+    """network/modeling.py:6-29."""
+    if output_stride == 8:
+        rswd, aspp_dilate = (False, True, True), (12, 24, 36)
+    else:
+        rswd, aspp_dilate = (False, False, True), (6, 12, 18)
+    backbone = ResNet(layers, replace_stride_with_dilation=rswd)
+    if name == "deeplabv3plus":
+        classifier = DeepLabHeadV3Plus(2048, 256, num_classes, aspp_dilate)
+    else:
+        classifier = DeepLabHead(2048, num_classes, aspp_dilate)
+    return DeepLabV3(backbone, classifier)
+
+
+def deeplabv3plus_resnet101(num_classes=21, output_stride=8, pretrained_backbone=False):
+    """network/modeling.py:124-132.  pretrained_backbone: there is no network here — load a state_dict instead."""
+    if pretrained_backbone:
+        raise NotImplementedError("no download in this build: load the ImageNet weights with load_state_dict")
+    return _segm_resnet("deeplabv3plus", (3, 4, 23, 3), num_classes, output_stride)
+
+
+def deeplabv3plus_resnet50(num_classes=21, output_stride=8, pretrained_backbone=False):
+    if pretrained_backbone:
+        raise NotImplementedError("no download in this build: load the ImageNet weights with load_state_dict")
+    return _segm_resnet("deeplabv3plus", (3, 4, 6, 3), num_classes, output_stride)
+
+
+def deeplabv3_resnet101(num_classes=21, output_stride=8, pretrained_backbone=False):
+    if pretrained_backbone:
+        raise NotImplementedError("no download in this build: load the ImageNet weights with load_state_dict")
+    return _segm_resnet("deeplabv3", (3, 4, 23, 3), num_classes, output_stride)
+
+
+def deeplabv3_resnet50(num_classes=21, output_stride=8, pretrained_backbone=False):
+    if pretrained_backbone:
+        raise NotImplementedError("no download in this build: load the ImageNet weights with load_state_dict")
+    return _segm_resnet("deeplabv3", (3, 4, 6, 3), num_classes, output_stride)
+
+
+MODELS = {"deeplabv3plus_resnet101": deeplabv3plus_resnet101, "deeplabv3plus_resnet50": deeplabv3plus_resnet50,
+          "deeplabv3_resnet101": deeplabv3_resnet101, "deeplabv3_resnet50": deeplabv3_resnet50}

@@ -54,7 +54,8 @@ class LearnableTrainer:
         if len(self.idx_list) != model.w.numel():
             raise ValueError("one mixing weight per perturbed depth")
         self.randinit, self.clip, self.l1_coef = randinit, clip, l1_coef
-        self.arena = ParamArena(model)                       # every parameter except `w`
+        # every parameter except `w`; optimizer state keyed like SGD(model.sequential_model.parameters()) (:82-84)
+        self.arena = ParamArena(model, index_root=getattr(model, "sequential_model", None))
         self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay)
         self.optimizer_w = torch.optim.SGD([{"params": model.w, "lr": w_lr, "weight_decay": 0}], w_lr,
                                            momentum=momentum, weight_decay=0)

@@ -537,19 +537,21 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
 
 
 # ----------------------------------------------------------------------------------- convolutions
-def conv_supported(ci, co, k, stride):
+def conv_supported(ci, co, k, stride, dilation=1):
     """Forward + input gradient of this layer run on the library's kernels.  Layers with a 16/32-channel side take the
-    small-channel kernel, whose BatchNorm fusions exist in the accumulator form only."""
+    small-channel kernel, whose BatchNorm fusions exist in the accumulator form only.  dilation > 1: 3x3 at stride 1."""
     if not _lib.load().afan_conv_supported(int(ci), int(co), int(k), int(stride)):
+        return False
+    if dilation != 1 and not (k == 3 and stride == 1 and ci >= 40 and co >= 40):
         return False
     return BN_ACC or ci == 3 or (ci % 64 == 0 and co % 64 == 0)
 
 
 def conv_wgrad_supported(ci, co, k, stride, in_shape=None):
-    """The tiled weight-gradient kernel takes co, ci multiples of 64.  With in_shape = (n, hi, wi) also: the image stem
+    """The tiled weight-gradient kernel takes co, ci multiples of 8 from 40 up.  With in_shape = (n, hi, wi) also: the image stem
     (ci == 3, afan_conv_stem.hip) and the 3x3 layers with a 16/32-channel side (afan_wgrad_small.hip), which walk whole
     image rows and so depend on the spatial size.  Anything else leaves wgrad to the vendor library."""
-    if ci % 64 == 0 and co % 64 == 0:
+    if ci % 8 == 0 and co % 8 == 0 and ci >= 40 and co >= 40:
         return k in (1, 3) and stride in (1, 2)
     if in_shape is None:
         return False
@@ -582,9 +584,10 @@ def _conv_acc_ok(c):
     return BN_ACC and bool(_lib.load().afan_bn_acc_supported(AFAN_BF16, int(c)))
 
 
-def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, groups=1):
-    """y = conv2d(x, w, padding=k//2, stride): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last.
-    want_stats=True also returns a ConvStats (moments of y around stats_shift[c], e.g. the BN running mean)."""
+def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, groups=1, dilation=1):
+    """y = conv2d(x, w, padding=dilation*(k//2), stride, dilation): x [N,Ci,H,W], w [Co,Ci,k,k], both bf16 channels_last.
+    want_stats=True also returns a ConvStats (moments of y around stats_shift[c], e.g. the BN running mean); None for a
+    channel count the statistics fusions do not take (not a multiple of 64 on the tiled kernel)."""
     lib = _lib.load()
     CALLS["conv_fwd"] += 1
     _cl4(x, "x"), _cl4(w, "w")
@@ -600,20 +603,20 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
         raise ValueError("grouped statistics need the accumulator path")
     if want_stats and _conv_acc_ok(co):
         st = ConvStats(None, 0, stats_shift, acc_take(x.device, co, groups))
-    elif want_stats and ci == 3:
+    elif want_stats and (ci == 3 or co % 64 or ci % 8):
         pass            # the stem kernel sums moments into accumulator blocks only: without them BatchNorm reduces itself
     elif want_stats:
         g = lib.afan_conv_fwd_tiles(n, hi, wi, ci, co, k, stride)
         if stats_buf is None or stats_buf.numel() < 2 * co * g:
             stats_buf = torch.empty(2 * co * g, dtype=torch.float32, device=x.device)
         st = ConvStats(stats_buf, g, stats_shift)
-    check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride,
+    check(lib.afan_conv_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, stride, int(dilation),
                                       _ptr(st.partials) if st else None, _ptr(stats_shift) if st else None,
                                       _ptr(st.acc) if st else None, int(groups), _stream(x)), "afan_conv_fwd_nhwc_bf16")
     return (y, st) if want_stats else y
 
 
-def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1):
+def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1, dilation=1):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient
     entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward).
@@ -652,7 +655,7 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
             if partials_buf is None or partials_buf.numel() < 2 * ci * g:
                 partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
             st = ConvStats(partials_buf, g, None)
-    check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, _ptr(addend),
+    check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, int(dilation), _ptr(addend),
                                         _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(bn_y) if st else None,
                                         _ptr(st.partials) if st else None, _ptr(st.acc) if st else None,
                                         int(groups) if st else 1, _stream(dy)),
@@ -660,7 +663,7 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
     return (dx, st) if bn_bwd is not None else dx
 
 
-def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False, second=None):
+def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False, second=None, dilation=1):
     """Weight gradient of y = conv2d(x, w, padding=k//2, stride): returns / adds into an fp32 [Co,Ci,k,k] tensor with
     channels_last strides (KRSC memory, the parameter arena's layout).  second = (x2, dy2): the same layer's operands
     of another pass, summed in the same launch (wgrad_pairable tells when)."""
@@ -684,11 +687,12 @@ def conv_wgrad(x, dy, k, stride, grad=None, accumulate=False, second=None):
         n2 = x2.shape[0]
     ws = _workspace(x, lib.afan_conv_wgrad_workspace_floats(n + n2, hi, wi, ci, co, k, stride), "wgrad")
     if second is None:
-        check(lib.afan_conv_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, ci, co, k, stride, _ptr(ws),
-                                            int(bool(accumulate)), _stream(x)), "afan_conv_wgrad_nhwc_bf16")
+        check(lib.afan_conv_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, ci, co, k, stride, int(dilation),
+                                            _ptr(ws), int(bool(accumulate)), _stream(x)), "afan_conv_wgrad_nhwc_bf16")
     else:
         check(lib.afan_conv_wgrad2_nhwc_bf16(_ptr(x), _ptr(dy), n, _ptr(x2), _ptr(dy2), n2, _ptr(grad), hi, wi, ci, co, k,
-                                             stride, _ptr(ws), int(bool(accumulate)), _stream(x)), "afan_conv_wgrad2_nhwc_bf16")
+                                             stride, int(dilation), _ptr(ws), int(bool(accumulate)), _stream(x)),
+              "afan_conv_wgrad2_nhwc_bf16")
     return grad
 
 
@@ -708,6 +712,204 @@ def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):
     _need(desc_dev, "desc_dev", torch.int64)
     check(lib.afan_transpose_weights(_ptr(src_arena), _ptr(dst_arena), _ptr(desc_dev), int(n_desc), int(total_tiles),
                                      _stream(src_arena)), "afan_transpose_weights")
+
+
+# ------------------------------------------------------------------ DeepLabv3+ layers (afan_seg.hip, afan_conv_stem7.hip)
+def _mf(t):
+    return torch.channels_last if layout_of(t) == AFAN_NHWC else torch.contiguous_format
+
+
+def upsample_bilinear(x, size):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False) for a dense fp32 / bf16 [N,C,H,W] tensor."""
+    lib = _lib.load()
+    _need(x, "x")
+    if x.dim() != 4 or x.dtype not in _DT:
+        raise TypeError("upsample_bilinear: 4-D fp32 / bf16 tensor expected")
+    n, c, hi, wi = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=_mf(x))
+    check(lib.afan_upsample_bilinear_fwd(_ptr(x), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hi, wi, ho, wo, _stream(x)),
+          "afan_upsample_bilinear_fwd")
+    return y
+
+
+def upsample_bilinear_backward(dy, in_hw):
+    lib = _lib.load()
+    _need(dy, "dy")
+    n, c, ho, wo = dy.shape
+    hi, wi = int(in_hw[0]), int(in_hw[1])
+    dx = torch.empty((n, c, hi, wi), dtype=dy.dtype, device=dy.device, memory_format=_mf(dy))
+    check(lib.afan_upsample_bilinear_bwd(_ptr(dy), _ptr(dx), _DT[dy.dtype], layout_of(dy), n, c, hi, wi, ho, wo, _stream(dy)),
+          "afan_upsample_bilinear_bwd")
+    return dx
+
+
+CE2D_MAX_CLASSES = 32
+
+
+def ce2d(logits, target, ignore_index=255, grad_scale=1.0, want_grad=True):
+    """nn.CrossEntropyLoss(ignore_index, reduction='mean') on [N,C,H,W] fp32 logits and [N,H,W] int64 labels:
+    (loss [1], grad_scale * d(loss)/d(logits) in the logits' layout | None)."""
+    lib = _lib.load()
+    _need(logits, "logits", torch.float32)
+    if logits.dim() != 4 or target.dim() != 3 or target.dtype != torch.int64 or not target.is_cuda \
+            or tuple(target.shape) != (logits.shape[0], logits.shape[2], logits.shape[3]):
+        raise TypeError("ce2d: logits [N,C,H,W] fp32 and target [N,H,W] int64 on the GPU")
+    n, c, h, w = logits.shape
+    target = target.contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = _workspace(logits, lib.afan_ce2d_workspace_floats(n * h * w), "ce2d")
+    check(lib.afan_ce2d(_ptr(logits), _ptr(target), layout_of(logits), n, c, h * w, int(ignore_index), float(grad_scale),
+                        _ptr(ws), _ptr(loss), _ptr(dl), _stream(logits)), "afan_ce2d")
+    return loss, dl
+
+
+def maxpool3x3s2(x):
+    lib = _lib.load()
+    _need(x, "x")
+    n, c, hi, wi = x.shape
+    y = torch.empty((n, c, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=_mf(x))
+    check(lib.afan_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hi, wi, _stream(x)),
+          "afan_maxpool3x3s2_fwd")
+    return y
+
+
+def maxpool3x3s2_backward(dy, x):
+    lib = _lib.load()
+    _need(dy, "dy", x.dtype), _need(x, "x")
+    if layout_of(dy) != layout_of(x) and dy.numel() > 0:
+        raise ValueError("dy must have x's memory layout")
+    n, c, hi, wi = x.shape
+    dx = torch.empty_like(x)
+    check(lib.afan_maxpool3x3s2_bwd(_ptr(dy), _ptr(x), _ptr(dx), _DT[x.dtype], layout_of(x), n, c, hi, wi, _stream(x)),
+          "afan_maxpool3x3s2_bwd")
+    return dx
+
+
+def avgpool(x):
+    """nn.AdaptiveAvgPool2d(1): [N,C,H,W] -> [N,C,1,1] (same dtype, fp32 accumulate)."""
+    lib = _lib.load()
+    _need(x, "x")
+    n, c, hw = _nchw(x)
+    y = torch.empty((n, c, 1, 1), dtype=x.dtype, device=x.device)
+    check(lib.afan_avgpool_fwd(_ptr(x), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, _stream(x)), "afan_avgpool_fwd")
+    return y.contiguous(memory_format=torch.channels_last) if layout_of(x) == AFAN_NHWC else y
+
+
+def avgpool_backward(dy, like):
+    lib = _lib.load()
+    _need(dy, "dy", like.dtype)
+    n, c, hw = _nchw(like)
+    dx = torch.empty_like(like)
+    check(lib.afan_avgpool_bwd(_ptr(dy.reshape(n, c).contiguous()), _ptr(dx), _DT[like.dtype], layout_of(like), n, c, hw,
+                               _stream(like)), "afan_avgpool_bwd")
+    return dx
+
+
+def pointwise_supported(x, co):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in _DT and (layout_of(x) == AFAN_NHWC or x.shape[2] * x.shape[3] == 1)
+            and x.shape[1] % 8 == 0 and co <= _lib.load().afan_pointwise_max_co() and x.shape[1] * co * 4 <= 64 * 1024)
+
+
+def pointwise_forward(x, weight, bias):
+    """1x1 convolution with bias on a channels-last map: fp32 logits [N,Co,H,W] (channels-last memory)."""
+    lib = _lib.load()
+    _need(x, "x"), _need(weight, "weight", torch.float32)
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    y = torch.empty((n, co, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    check(lib.afan_pointwise_fwd(_ptr(x), _DT[x.dtype], _ptr(weight.reshape(co, ci)), _ptr(bias), _ptr(y), n * h * w, ci, co,
+                                 _stream(x)), "afan_pointwise_fwd")
+    return y
+
+
+def pointwise_backward(dy, x, weight, want_dx, dweight=None, dbias=None, accumulate=False):
+    lib = _lib.load()
+    _need(dy, "dy", torch.float32), _need(x, "x")
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    m = n * h * w
+    if layout_of(dy) != AFAN_NHWC and h * w != 1 and co != 1:
+        dy = dy.contiguous(memory_format=torch.channels_last)
+    dx = None
+    if want_dx:
+        dx = torch.empty_like(x)
+        check(lib.afan_pointwise_bwd_dx(_ptr(dy), _ptr(weight.reshape(co, ci)), _ptr(dx), _DT[x.dtype], m, ci, co, _stream(x)),
+              "afan_pointwise_bwd_dx")
+    if dweight is not None:
+        ws = _workspace(x, lib.afan_pointwise_workspace_floats(m, ci, co), "pointwise")
+        check(lib.afan_pointwise_bwd_dw(_ptr(dy), _ptr(x), _DT[x.dtype], _ptr(dweight), _ptr(dbias), m, ci, co, _ptr(ws),
+                                        int(bool(accumulate)), _stream(x)), "afan_pointwise_bwd_dw")
+    return dx
+
+
+_dropout_state = {}
+
+
+def dropout_state(device):
+    """The device-resident generator of afan_dropout for this device (one uint64, seeded from torch's CPU generator)."""
+    st = _dropout_state.get(device.index)
+    if st is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        st = _dropout_state[device.index] = torch.tensor([seed], dtype=torch.int64, device=device)
+    return st
+
+
+def dropout(x, p, mask=None, used=None):
+    """Forward (used=None): returns (y, used) — `used` [1] int64 holds the seed of this call.  Backward: pass the forward's
+    `used` (the mask is re-derived).  mask: uint8 tensor of x's shape / layout (host-supplied, for parity tests)."""
+    lib = _lib.load()
+    _need(x, "x")
+    y = torch.empty_like(x)
+    fwd = used is None
+    if fwd:
+        used = torch.empty(1, dtype=torch.int64, device=x.device)
+    if mask is not None:
+        _need(mask, "mask", torch.uint8)
+        _same_layout(x, mask)
+    state = dropout_state(x.device) if (fwd and mask is None) else None
+    check(lib.afan_dropout(_ptr(x), _ptr(y), _DT[x.dtype], x.numel(), float(p), _ptr(mask), _ptr(state), _ptr(used), 1,
+                           _stream(x)), "afan_dropout")
+    return y, used
+
+
+def conv_stem7_ok(x, w, stride, padding):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and layout_of(x) == AFAN_NHWC
+            and w.dtype == torch.bfloat16 and tuple(w.shape) == (64, 3, 7, 7) and tuple(stride) == (2, 2)
+            and tuple(padding) == (3, 3))
+
+
+def conv_stem7_fwd(x, w):
+    """The 7x7 / stride 2 image stem: x [N,3,H,W] bf16 channels-last, w [64,3,7,7] bf16 in KRSC memory."""
+    lib = _lib.load()
+    CALLS["conv_fwd"] += 1
+    _cl4(x, "x")
+    _need(w, "w", torch.bfloat16)
+    if not (w.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("stem weight must be in KRSC (channels_last) memory order")
+    n, _, hi, wi = x.shape
+    y = torch.empty((n, 64, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    check(lib.afan_conv_stem7_fwd_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, _stream(x)), "afan_conv_stem7_fwd_nhwc_bf16")
+    return y
+
+
+def conv_stem7_wgrad(x, dy, grad=None, accumulate=False):
+    lib = _lib.load()
+    CALLS["conv_wgrad"] += 1
+    _cl4(x, "x"), _cl4(dy, "dy")
+    n, _, hi, wi = x.shape
+    if grad is None:
+        grad = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        accumulate = False
+    _need(grad, "grad", torch.float32)
+    if not grad.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("grad must be in KRSC (channels_last) memory order")
+    ws = _workspace(x, lib.afan_conv_stem7_wgrad_workspace_floats(n, hi, wi), "stem7")
+    check(lib.afan_conv_stem7_wgrad_nhwc_bf16(_ptr(x), _ptr(dy), _ptr(grad), n, hi, wi, _ptr(ws), int(bool(accumulate)),
+                                              _stream(x)), "afan_conv_stem7_wgrad_nhwc_bf16")
+    return grad
 
 
 # ------------------------------------------------------------------------------------------- SGD

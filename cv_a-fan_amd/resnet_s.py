@@ -139,20 +139,21 @@ class _ConvFn(torch.autograd.Function):
     to MIOpen through aten.  wgrad is returned for the fp32 master weight."""
 
     @staticmethod
-    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad, stats_req=None):
+    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad, stats_req=None, dilation=(1, 1)):
         ctx.stride, ctx.padding, ctx.want_wgrad, ctx.wt_fn = stride, padding, want_wgrad, wt_fn
+        ctx.dilation = dilation = tuple(dilation)
         ctx.w_master = w_master
-        ctx.own = _own_conv_ok(x, w_lp, stride, padding)
+        ctx.own = _own_conv_ok(x, w_lp, stride, padding, dilation)
         ctx.save_for_backward(x, w_lp)
         if ctx.own:
             if stats_req is not None:   # [shift tensor | None, reusable partials buffer | None] -> filled with ConvStats
                 y, st = ops.conv_fwd(x, w_lp, stride[0], stats_shift=stats_req[0], want_stats=True,
-                                     stats_buf=stats_req[1])
+                                     stats_buf=stats_req[1], dilation=dilation[0])
                 stats_req.append(st)
                 return y
-            return ops.conv_fwd(x, w_lp, stride[0])
+            return ops.conv_fwd(x, w_lp, stride[0], dilation=dilation[0])
         ops.CALLS["vendor_conv"] += 1
-        return torch.ops.aten.convolution(x, w_lp, None, stride, padding, (1, 1), False, (0, 0), 1)
+        return torch.ops.aten.convolution(x, w_lp, None, stride, padding, dilation, False, (0, 0), 1)
 
     @staticmethod
     def backward(ctx, gy):
@@ -163,7 +164,7 @@ class _ConvFn(torch.autograd.Function):
         gx = gw = None
         own = ctx.own and gy.is_contiguous(memory_format=torch.channels_last)
         if need_gx and own:
-            gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0])
+            gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0], dilation=ctx.dilation[0])
             need_gx = False
         if need_gw and own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], w_lp.shape[2], ctx.stride[0],
                                                         (x.shape[0], x.shape[2], x.shape[3])):
@@ -177,17 +178,17 @@ class _ConvFn(torch.autograd.Function):
                 if side is not None:
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
-                        ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
+                        ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True, dilation=ctx.dilation[0])
                     x.record_stream(side)
                     gy.record_stream(side)
                 else:
-                    ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True)
+                    ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True, dilation=ctx.dilation[0])
             else:
-                gw = ops.conv_wgrad(x, gy, k, ctx.stride[0])
+                gw = ops.conv_wgrad(x, gy, k, ctx.stride[0], dilation=ctx.dilation[0])
             need_gw = False
         if need_gx or need_gw:
             ops.CALLS["vendor_conv"] += 1
-            g2, g3, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, (1, 1), False,
+            g2, g3, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, ctx.dilation, False,
                                                             (0, 0), 1, [need_gx, need_gw, False])
             if need_gx:
                 gx = g2
@@ -199,13 +200,13 @@ class _ConvFn(torch.autograd.Function):
                     gw = None
                 elif gw.dtype != torch.float32:
                     gw = gw.float()
-        return gx, gw, None, None, None, None, None, None
+        return gx, gw, None, None, None, None, None, None, None
 
 
 def _wgrad_accumulate(x, dy, c):
     """Weight gradient of conv module c added into its arena gradient view: the library's kernel where it tiles, else
     (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
-    k, st = c.kernel_size[0], c.stride[0]
+    k, st, dil = c.kernel_size[0], c.stride[0], c.dilation[0]
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
         pairable = ops.wgrad_pairable(x, dy, k, st)
         if _Flags.wgrad_stash and pairable:
@@ -215,13 +216,13 @@ def _wgrad_accumulate(x, dy, c):
         if pend is not None:
             c._pending_wgrad = None
             if pairable and pend[0].shape[1:] == x.shape[1:] and pend[1].shape[1:] == dy.shape[1:]:
-                ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True, second=(x, dy))
+                ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True, second=(x, dy), dilation=dil)
                 return
-            ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True)
-        ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True)
+            ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True, dilation=dil)
+        ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True, dilation=dil)
         return
     ops.CALLS["vendor_conv"] += 1
-    gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), (k // 2, k // 2), (1, 1), False, (0, 0), 1,
+    gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), c.padding, c.dilation, False, (0, 0), 1,
                                              [False, True, False])[1]
     c.weight.grad.add_(gw)
 
@@ -249,7 +250,8 @@ def flush_wgrad(model):
         pend = getattr(c, "_pending_wgrad", None)
         if pend is not None:
             c._pending_wgrad = None
-            ops.conv_wgrad(pend[0], pend[1], c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True)
+            ops.conv_wgrad(pend[0], pend[1], c.kernel_size[0], c.stride[0], c.weight.grad, accumulate=True,
+                           dilation=c.dilation[0])
 
 
 def _accumulates_in_place(p):
@@ -258,15 +260,16 @@ def _accumulates_in_place(p):
     return isinstance(p, torch.nn.Parameter) and p.grad is not None and getattr(p, "_afan_arena_grad", False)
 
 
-def _own_conv_ok_shape(w, stride, padding):
+def _own_conv_ok_shape(w, stride, padding, dilation=(1, 1)):
     if w.dtype != torch.bfloat16 or w.shape[2] != w.shape[3]:
         return False
     k = w.shape[2]
     if not (w.is_contiguous(memory_format=torch.channels_last) or k == 1):
         return False
-    if stride[0] != stride[1] or padding[0] != k // 2 or padding[1] != k // 2:
+    d = dilation[0]
+    if stride[0] != stride[1] or dilation[0] != dilation[1] or padding[0] != d * (k // 2) or padding[1] != d * (k // 2):
         return False
-    return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0])
+    return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0], d if k > 1 else 1)
 
 
 def vendor_convs(model):
@@ -277,17 +280,17 @@ def vendor_convs(model):
     bad = []
     for name, m in model.named_modules():
         if isinstance(m, Conv2d) and m.in_channels > 4:       # (the stem decides by image width at run time)
-            if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding):
+            if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding, m.dilation):
                 bad.append(name)
     return bad
 
 
-def _own_conv_ok(x, w, stride, padding):
+def _own_conv_ok(x, w, stride, padding, dilation=(1, 1)):
     if x.dtype != torch.bfloat16 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
         return False
     if x.shape[1] == 3 and x.shape[3] % 32:      # the stem kernel walks 32-pixel row segments
         return False
-    return _own_conv_ok_shape(w, stride, padding)
+    return _own_conv_ok_shape(w, stride, padding, dilation)
 
 
 class _BNTrainFn(torch.autograd.Function):
@@ -346,7 +349,7 @@ class _BlockFn(torch.autograd.Function):
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
-                                      stats_buf=csc._stats_buf, groups=G)
+                                      stats_buf=csc._stats_buf, groups=G)      # (1x1: no dilation)
             csc._stats_buf = stc.partials
             res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
         elif blk._sc_kind == "pad":
@@ -357,7 +360,7 @@ class _BlockFn(torch.autograd.Function):
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
             raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
-                                   stats_buf=c._stats_buf, groups=G)
+                                   stats_buf=c._stats_buf, groups=G, dilation=c.dilation[0])
             c._stats_buf = st.partials
             a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
             saved += [raw, a, s_i]
@@ -388,7 +391,8 @@ class _BlockFn(torch.autograd.Function):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
             d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
-                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G)
+                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G,
+                                       dilation=c.dilation[0])
             c._bwd_buf = part.partials
             if pg:
                 _wgrad_accumulate(acts[i - 1], d_raw, c)
@@ -399,6 +403,7 @@ class _BlockFn(torch.autograd.Function):
         dx = None
         prev = ctx.prev_bn
         fuse = dict(bn_bwd=(prev[0], prev[1], True), bn_y=x, groups=G) if (prev is not None and need_dx) else {}
+        fuse["dilation"] = c1.dilation[0]
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             if pg or need_dx:
@@ -417,7 +422,7 @@ class _BlockFn(torch.autograd.Function):
                 dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
             dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
-        if fuse and dx is not None:
+        if "bn_bwd" in fuse and dx is not None:
             dx, sums = dx
             dx._afan_bn_sums = sums
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -517,7 +522,7 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         x = _to_compute(x, self.compute_dtype)
         return _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.lp_weight_t, self.stride, self.padding,
-                             _Flags.param_grads)
+                             _Flags.param_grads, None, self.dilation)
 
     _stats_buf = None
     _bwd_buf = None
@@ -530,7 +535,7 @@ class Conv2d(nn.Conv2d):
         x = _to_compute(x, self.compute_dtype)
         req = [bn.running_mean if bn.track_running_stats else None, self._stats_buf]
         y = _ConvFn.apply(x, self.weight, self.lp_weight().detach(), self.lp_weight_t, self.stride, self.padding,
-                          _Flags.param_grads, req)
+                          _Flags.param_grads, req, self.dilation)
         st = req[2] if len(req) > 2 else None
         if st is not None:
             self._stats_buf = st.partials

@@ -14,23 +14,32 @@ import torch
 
 from . import ops
 from .attack_algo import get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401 (same functions)
+from .resnet_s import dgrad_only
 
 
 def _start(x, eps, randinit):
     if x.device.type != "cuda":
         raise ops.AfanLibraryError("x must live on the MI355X (no CPU path in this build)")
-    x = x.detach().float().contiguous()
-    x_adv = x.clone()
+    x = x.detach().float()
+    x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))) else x.contiguous()
+    x_adv = x.clone()     # keeps the feature map's own dense layout (channels-last on the bf16 path: no transposes per step)
     if randinit:   # noise from the CPU default generator, like the reference (:44)
-        ops.axpy_noise_(x_adv, torch.rand(x_adv.shape).to(x.device, non_blocking=True), eps)
+        u = torch.rand(x_adv.shape).to(x.device, non_blocking=True)
+        if u.stride() != x_adv.stride():
+            u = u.contiguous(memory_format=torch.channels_last)
+        ops.axpy_noise_(x_adv, u, eps)
     return x, x_adv
 
 
 def _ascend(x_adv, logits_of, criterion, y, gamma, x, eps, clip):
     xin = x_adv.detach().requires_grad_(True)
-    loss = criterion(logits_of(xin), y)
-    grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
-    ops.pgd_step_(x_adv, grad.contiguous(), gamma, x, eps, clip)          # one launch: sign step (+ projection)
+    with dgrad_only():          # only_inputs=True (:52): the library's layers must not add into the parameters' .grad here
+        loss = criterion(logits_of(xin), y)
+        root = ops.one(loss.device) if (getattr(criterion, "fused", False) and loss.dim() == 0) else None
+        grad = torch.autograd.grad(loss, xin, grad_outputs=root, only_inputs=True)[0]
+    if grad.stride() != x_adv.stride():
+        grad = grad.contiguous(memory_format=torch.channels_last) if x_adv.is_contiguous(memory_format=torch.channels_last) and not x_adv.is_contiguous() else grad.contiguous()
+    ops.pgd_step_(x_adv, grad, gamma, x, eps, clip)          # one launch: sign step (+ projection)
 
 
 def PGD(x, image_batch, low_level_feat, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
@@ -79,7 +88,11 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
     0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
+    from .deeplab import seg_criterion
     f0, f1 = int(mix_layer[0]), int(mix_layer[1])
+    criterion = seg_criterion(criterion)        # one-pass HIP cross-entropy for a plain nn.CrossEntropyLoss(ignore_index=...)
+    if images.is_cuda:
+        ops.acc_reset(images.device)            # BatchNorm accumulator arena: one memset per iteration
     optimizer.zero_grad()
     out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
     dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
@@ -105,9 +118,18 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
     o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
     o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
-    l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
-    loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
-    loss.backward()
+    wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
+    if getattr(criterion, "fused", False) and all(o.is_cuda and o.dtype == torch.float32 for o in (o0, o1, o2, o3)):
+        # every term's stored gradient already carries its weight: four roots, no scaling passes over the logits
+        l0, l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o0, o1, o2, o3), wts))
+        with torch.no_grad():
+            loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
+        one = ops.one(images.device)
+        torch.autograd.backward([l0, l1, l2, l3], [one, one, one, one])
+    else:
+        l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
+        loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
+        loss.backward()
     optimizer.step()
     return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}

@@ -1,0 +1,84 @@
+"""The Segmentation A-FAN iteration (Segmentation/main_aug_final.py:149-232) on one MI355X: owner of the parameter arena,
+the two-group SGD and the PolyLR schedule around `seg_attack_algo.seg_train_step`.
+
+    head pass (SE, out_idx) + clean decoder-head pass (SD) -> K-step SE feature PGD + K-step SD decoder PGD
+    -> 3 SAT sample points + mix_feature -> clean / SE1 / SE2 / SD forwards -> 0.7/0.1/0.1/0.1 loss -> backward -> SGD
+
+Reference details kept: BatchNorm momentum 0.01 in the backbone (main_aug_final.py:77), SGD(momentum 0.9) with the
+backbone at 0.1 x lr (:79-82), PolyLR(power 0.9) stepped once per iteration (:261), CrossEntropyLoss(ignore_index=255).
+After `graph_warmup` eager iterations the whole iteration body is captured into a hipGraph and replayed (bf16
+channels-last configuration only: no vendor convolution inside a capture, see resnet_s.vendor_convs)."""
+import torch
+import torch.nn as nn
+
+from . import ops, resnet_s
+from .arena import ArenaSGD, ParamArena
+from .deeplab import PolyLR, set_bn_momentum
+from .seg_attack_algo import seg_train_step
+
+
+class SegTrainer:
+    def __init__(self, model, criterion=None, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3,
+                 pertub_idx_sd="aspp", mix_layer="11", mix_sd=False, noise_sd=0.0, randinit=False, clip=False, lr=0.01,
+                 momentum=0.9, weight_decay=1e-4, total_itrs=30000, lr_policy="poly", step_size=10000,
+                 backbone_bn_momentum=0.01, use_graph=True, graph_warmup=2):
+        self.model = model
+        self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+        self.kw = dict(steps=steps, eps=eps, gamma_se=gamma_se, gamma_sd=gamma_sd, pertub_idx_se=pertub_idx_se,
+                       pertub_idx_sd=pertub_idx_sd, mix_layer=mix_layer, mix_sd=mix_sd, noise_sd=noise_sd, randinit=randinit,
+                       clip=clip)
+        if backbone_bn_momentum is not None:
+            set_bn_momentum(model.backbone, backbone_bn_momentum)
+        self.arena = ParamArena(model, skip=())
+        self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay,
+                                  groups=[("backbone.", 0.1 * lr), ("classifier.", lr)])
+        if lr_policy == "poly":
+            self.scheduler = PolyLR(self.optimizer, total_itrs, power=0.9)
+        else:
+            self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=step_size, gamma=0.1)
+        self.use_graph = bool(use_graph) and not randinit and noise_sd == 0
+        self.graph_warmup = graph_warmup
+        self._graph = self._graph_failed = self._static = self._out = self._key = None
+        self._eager_steps = 0
+
+    def _body(self, images, labels):
+        return seg_train_step(self.model, self.optimizer, self.criterion, images, labels, **self.kw)
+
+    def _graph_safe(self):
+        if resnet_s.vendor_convs(self.model):
+            self.use_graph = False
+        return self.use_graph
+
+    def step(self, images, labels):
+        """One iteration (device tensors only; the scheduler is NOT stepped here — call `trainer.scheduler.step()` once
+        per iteration like main_aug_final.py:261)."""
+        key = (tuple(images.shape), images.dtype, tuple(labels.shape))
+        if self._graph is not None and self._key == key:
+            self._static[0].copy_(images, non_blocking=True)
+            self._static[1].copy_(labels, non_blocking=True)
+            self.optimizer._sync_lr()
+            self._graph.replay()
+            small = ("loss", "losses")
+            return {k: (v.clone() if k in small else v) for k, v in self._out.items()}
+        if (self.use_graph and self._graph is None and self._graph_failed is None and images.is_cuda
+                and self._eager_steps >= self.graph_warmup and self.model.training and self._graph_safe()):
+            try:
+                dev = images.device
+                self._static = (images.clone(), labels.clone())
+                stream = torch.cuda.Stream(device=dev)
+                stream.wait_stream(torch.cuda.current_stream(dev))
+                torch.cuda.synchronize(dev)
+                self.optimizer._sync_lr()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    out = self._body(self._static[0], self._static[1])
+                self._graph, self._out, self._key = g, out, key
+                return self.step(images, labels)
+            except Exception as e:  # noqa: BLE001 — stay correct: fall back to eager launches, loudly
+                import warnings
+                self._graph, self._graph_failed = None, e
+                warnings.warn(f"hipGraph capture of the segmentation A-FAN step failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize()
+        self._eager_steps += 1
+        self.optimizer._sync_lr()
+        return self._body(images, labels)

@@ -220,9 +220,11 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
 /* ------------------------------------------------------------------------------------------------
  * Backbone convolutions (bf16, channels-last, fp32 accumulate on MFMA) — what torch.nn.Conv2d runs inside
  * `model(x_adv, end_point, start_point)` (attack_algo.py:50; resnet_s.py:52-54,66,72-73) and its input-gradient
- * (attack_algo.py:52), implicit-GEMM kernels of this library.  k in {1,3}, padding k/2, stride in {1,2},
- * Ci % 64 == 0 and Co % 64 == 0, or — the reference's own 16-32-64-channel CIFAR ResNets — Ci, Co in {16, 32, 64}
- * (afan_conv_supported() tells).  Layers with a 16/32-channel side take the small-channel kernel, whose statistics
+ * (attack_algo.py:52), implicit-GEMM kernels of this library.  k in {1,3}, padding dilation*(k/2), stride in {1,2},
+ * dilation >= 1 (> 1: the atrous 3x3 stride-1 convolutions of Segmentation/network/backbone/resnet.py:29-32 and
+ * _deeplab.py:146-153).  Channels: Ci and Co multiples of 8, both >= 40 (the tiled kernel; counts that are not multiples of
+ * its 64-channel tiles — DeepLab's 48 and 304, _deeplab.py:33,41 — are masked in the last tile), or — the reference's own
+ * 16-32-64-channel CIFAR ResNets — Ci, Co in {16, 32, 64} (afan_conv_supported() tells).  Layers with a 16/32-channel side take the small-channel kernel, whose statistics
  * fusions exist in the accumulator form (stats_acc / bn_acc) only.  The image stem (resnet_s.py:88: Ci == 3, k == 3,
  * stride 1, Co in {16, 32, 64}, image width % 32 == 0) has its own forward kernel (moments: accumulator form only, no
  * image groups) and weight-gradient kernel; it has no input gradient (the images carry none).
@@ -231,7 +233,7 @@ int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx,
  */
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride);
 int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                            int64_t co, int k, int stride, float* stats_partials, const float* stats_shift,
+                            int64_t co, int k, int stride, int dilation, float* stats_partials, const float* stats_shift,
                             double* stats_acc, int groups, afan_stream_t stream);
 /* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
  * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
@@ -244,7 +246,7 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
  * stats_acc + afan_bn_acc_doubles(Co) rounded up to even.  (N/2)*Ho*Wo must be a multiple of 128.  groups = 1 otherwise. */
 int64_t afan_conv_fwd_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
-                              int64_t ci, int64_t co, int k, int stride, const void* addend, const void* bn_x,
+                              int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
                               double* bn_acc, int groups, afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
@@ -269,15 +271,72 @@ int64_t afan_conv_dgrad_tiles(int64_t n, int64_t hi, int64_t wi, int64_t ci, int
  * accumulate != 0 adds into grad (the two branches of the joint loss both contribute to tail weights). */
 int64_t afan_conv_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
 int afan_conv_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
-                              int64_t ci, int64_t co, int k, int stride, float* workspace, int accumulate,
+                              int64_t ci, int64_t co, int k, int stride, int dilation, float* workspace, int accumulate,
                               afan_stream_t stream);
 /* The same over TWO operand pairs of one layer in one launch and one slab reduction:
  * grad (+)= wgrad(x[n], dy[n]) + wgrad(x2[n2], dy2[n2]) — a tail layer's operands of the clean and of the adversarial pass of
- * one iteration (main_perturb.py:195-200: both contribute to the same .grad).  Tiled kernel only (ci, co multiples of 64);
+ * one iteration (main_perturb.py:195-200: both contribute to the same .grad).  Tiled kernel (ci, co multiples of 8, >= 40) or the small-channel one;
  * n * Ho * Wo must be a multiple of 64; workspace = afan_conv_wgrad_workspace_floats(n + n2, ...); n2 = 0: one pair. */
 int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2,
-                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
+                               float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation,
                                float* workspace, int accumulate, afan_stream_t stream);
+
+/* The ImageNet-style image stem of the DeepLabv3+ / ResNet-50/101 backbones (Segmentation/network/backbone/resnet.py:143-144
+ * `conv1`: 7x7, stride 2, padding 3, 3 -> 64 channels): forward and weight gradient, bf16 channels-last.
+ * x[N,Hi,Wi,3], w[64,7,7,3] (KRSC), y / dy[N,Ho,Wo,64], Ho = (Hi-1)/2+1; grad fp32 [64,7,7,3] written or added into.
+ * No input gradient: the images carry none on the feature-perturbation path. */
+int afan_conv_stem7_supported(int64_t ci, int64_t co, int k, int stride);
+int afan_conv_stem7_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi,
+                                  afan_stream_t stream);
+int64_t afan_conv_stem7_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi);
+int afan_conv_stem7_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
+                                    float* workspace, int accumulate, afan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The non-convolution layers of the DeepLabv3+ split-forward network.  `dtype` AFAN_F32 / AFAN_BF16,
+ * `layout` AFAN_NCHW / AFAN_NHWC; tensors dense.  Backward passes are gathers (no float atomics: reproducible).
+ *
+ * Bilinear resize with align_corners=False — F.interpolate(..., mode='bilinear', align_corners=False) at
+ * Segmentation/network/utils.py:30,45 and _deeplab.py:54,66,75,141 (ATen's source-index rule in fp32:
+ * src = max(0, (in/out)*(dst+0.5)-0.5)).  fwd: y[n,c,ho,wo] from x[n,c,hi,wi]; bwd: dx[n,c,hi,wi] from dy[n,c,ho,wo]. */
+int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                               int64_t ho, int64_t wo, afan_stream_t stream);
+int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                               int64_t ho, int64_t wo, afan_stream_t stream);
+/* Per-pixel cross-entropy, nn.CrossEntropyLoss(ignore_index=I, reduction='mean') of Segmentation/main_aug_final.py:95:
+ * logits fp32 [n,c,hw] (NCHW) or [n,hw,c] (NHWC), c <= 32; target int64 [n,hw].  loss[0] = sum over pixels with
+ * target != I of (logsumexp - logit[target]) / count; dlogits (nullable, same layout) = grad_scale * d(loss)/d(logits)
+ * (0 at ignored pixels).  A target outside [0,c) that is not I makes the loss NaN.  workspace: afan_ce2d_workspace_floats(n*hw). */
+int64_t afan_ce2d_workspace_floats(int64_t pixels);
+int afan_ce2d(const float* logits, const int64_t* target, int layout, int64_t n, int64_t c, int64_t hw, int64_t ignore_index,
+              float grad_scale, float* workspace, float* loss, float* dlogits, afan_stream_t stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (backbone/resnet.py:146): ho = (hi-1)/2+1.  The backward routes each
+ * output gradient to the FIRST maximum of its window in (h, w) scan order, NaN winning — ATen's CPU rule. */
+int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                          afan_stream_t stream);
+int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi,
+                          int64_t wi, afan_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast. */
+int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream);
+int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream);
+/* 1x1 convolution WITH bias to a few output channels and fp32 logits — the classifier nn.Conv2d(256, num_classes, 1) of
+ * _deeplab.py:45 on channels-last pixels: y[m,co] = b[co] + sum_ci x[m,ci]*w[co,ci]; x `x_dtype` [m,ci] (ci % 8 == 0),
+ * w fp32 [co,ci], co <= afan_pointwise_max_co().  dx[m,ci] = dy[m,:] @ w; dw[co,ci] (+)= sum_m dy[m,co]*x[m,ci],
+ * db[co] (+)= sum_m dy[m,co] (two launches, slices of 128 pixels summed in order). */
+int afan_pointwise_max_co(void);
+int afan_pointwise_fwd(const void* x, int x_dtype, const float* w, const float* b, float* y, int64_t m, int64_t ci,
+                       int64_t co, afan_stream_t stream);
+int afan_pointwise_bwd_dx(const float* dy, const float* w, void* dx, int dx_dtype, int64_t m, int64_t ci, int64_t co,
+                          afan_stream_t stream);
+int64_t afan_pointwise_workspace_floats(int64_t m, int64_t ci, int64_t co);
+int afan_pointwise_bwd_dw(const float* dy, const void* x, int x_dtype, float* dw, float* db, int64_t m, int64_t ci,
+                          int64_t co, float* workspace, int accumulate, afan_stream_t stream);
+/* nn.Dropout(p) (_deeplab.py:185): y = keep ? x / (1 - p) : 0.  mask != NULL: keep = mask[i] != 0 (host-supplied, parity
+ * tests).  Otherwise keep(i) is a counter-based hash of (seed, i): forward passes `state` (device uint64, the generator:
+ * seed = state[0]; copied to used[0]; advanced afterwards when `advance`), backward passes state = NULL and the `used`
+ * the forward filled — the mask is re-derived, never stored, and a replayed hipGraph draws fresh masks. */
+int afan_dropout(const void* x, void* y, int dtype, int64_t n, float p, const uint8_t* mask, uint64_t* state, uint64_t* used,
+                 int advance, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Classifier head of the slice protocol: AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110), run at the

@@ -515,6 +515,188 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}
 
 
+# ------------------------------------------------------------- DeepLabv3+ (N1, second slice): the reference's network restated
+class SegBottleneck(nn.Module):
+    """Segmentation/network/backbone/resnet.py:76-119 (groups=1, base_width=64)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class SegResNet(nn.Module):
+    """Segmentation/network/backbone/resnet.py:109-304: atrous ResNet with the head / tail / clean dispatch."""
+
+    def __init__(self, layers, replace_stride_with_dilation=(False, False, False)):
+        super().__init__()
+        self.normal = ChannelNormalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+        self.inplanes, self.dilation = 64, 1
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], 2, replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(256, layers[2], 2, replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(512, layers[3], 2, replace_stride_with_dilation[2])
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        downsample, prev = None, self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+        layers = [SegBottleneck(self.inplanes, planes, stride, downsample, prev)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(SegBottleneck(self.inplanes, planes, dilation=self.dilation))
+        return nn.Sequential(*layers)
+
+    def forward(self, d):
+        stages = [self.layer1, self.layer2, self.layer3, self.layer4]
+        out = {}
+        if d["flag"] in ("head", "clean"):
+            last = 4 if d["flag"] == "clean" else d["out_idx"]
+            x = self.maxpool(self.relu(self.bn1(self.conv1(self.normal(d["x"])))))
+            x = self.layer1(x)
+            out["low_level"] = x
+            for st in stages[1:last]:
+                x = st(x)
+            out["out"] = x
+            return out
+        assert d["flag"] == "tail"
+        x = d["adv"]
+        for st in stages[d["out_idx"]:]:
+            x = st(x)
+        return {"out": x, "low_level": d["low_level_feat"]}
+
+
+class SegASPP(nn.Module):
+    """Segmentation/network/_deeplab.py:143-193 (ASPPConv, ASPPPooling, ASPP)."""
+
+    def __init__(self, cin, rates):
+        super().__init__()
+        mods = [nn.Sequential(nn.Conv2d(cin, 256, 1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True))]
+        for r in rates:
+            mods.append(nn.Sequential(nn.Conv2d(cin, 256, 3, padding=r, dilation=r, bias=False), nn.BatchNorm2d(256),
+                                      nn.ReLU(inplace=True)))
+        mods.append(nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, 256, 1, bias=False), nn.BatchNorm2d(256),
+                                  nn.ReLU(inplace=True)))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(5 * 256, 256, 1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+                                     nn.Dropout(0.1))
+
+    def forward(self, x):
+        res = [c(x) for c in list(self.convs)[:4]]
+        res.append(F.interpolate(self.convs[4](x), size=x.shape[-2:], mode="bilinear", align_corners=False))
+        return self.project(torch.cat(res, dim=1))
+
+
+class SegHeadV3Plus(nn.Module):
+    """Segmentation/network/_deeplab.py:28-90."""
+
+    def __init__(self, cin, low_level_channels, num_classes, rates):
+        super().__init__()
+        self.project = nn.Sequential(nn.Conv2d(low_level_channels, 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU(inplace=True))
+        self.aspp = SegASPP(cin, rates)
+        self.classifier = nn.Sequential(nn.Conv2d(304, 256, 3, padding=1, bias=False), nn.BatchNorm2d(256), nn.ReLU(inplace=True),
+                                        nn.Conv2d(256, num_classes, 1))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, f, return_type=None):
+        if return_type == "aspp_head":
+            return self.aspp(f["out"])
+        if return_type == "concat_tail":
+            return self.classifier(f["adv"])
+        low = self.project(f["low_level"])
+        hi = f["adv"] if return_type == "aspp_tail" else self.aspp(f["out"])
+        cat = torch.cat([low, F.interpolate(hi, size=low.shape[2:], mode="bilinear", align_corners=False)], dim=1)
+        if return_type == "concat_head":
+            return cat
+        assert return_type in (None, "aspp_tail")
+        return self.classifier(cat)
+
+
+class SegDeepLabV3Plus(nn.Module):
+    """Segmentation/network/utils.py:8-47 (`_SimpleSegmentationModel`) around the two modules above; built as
+    network/modeling.py:6-29 does (output_stride 16: dilate layer4, ASPP rates 6/12/18; 8: layers 3-4, rates 12/24/36)."""
+
+    def __init__(self, layers=(3, 4, 23, 3), num_classes=21, output_stride=16):
+        super().__init__()
+        rswd, rates = ((False, True, True), (12, 24, 36)) if output_stride == 8 else ((False, False, True), (6, 12, 18))
+        self.backbone = SegResNet(layers, rswd)
+        self.classifier = SegHeadV3Plus(2048, 256, num_classes, rates)
+
+    def forward(self, d):
+        if d["flag"] == "head":
+            return self.backbone(d)
+        assert d["flag"] in ("tail", "clean")
+        if isinstance(d["out_idx"], int):
+            x = self.classifier(self.backbone(d))
+            return F.interpolate(x, size=d["x"].shape[-2:], mode="bilinear", align_corners=False)
+        if d["out_idx"] in ("aspp_head", "concat_head"):
+            f = self.backbone(d)
+            f["adv"] = self.classifier(f, return_type=d["out_idx"])
+            return f
+        assert d["out_idx"] in ("aspp_tail", "concat_tail")
+        x = self.classifier(d["adv"], return_type=d["out_idx"])
+        return F.interpolate(x, size=d["x"].shape[-2:], mode="bilinear", align_corners=False)
+
+
+def deeplabv3plus_resnet101(num_classes=21, output_stride=16):
+    return SegDeepLabV3Plus((3, 4, 23, 3), num_classes, output_stride)
+
+
+def deeplabv3plus_resnet50(num_classes=21, output_stride=16):
+    return SegDeepLabV3Plus((3, 4, 6, 3), num_classes, output_stride)
+
+
+def seg_make_optimizer(model, lr=0.01, weight_decay=1e-4):
+    """Segmentation/main_aug_final.py:77-82: backbone BN momentum 0.01; SGD with two groups (backbone 0.1*lr, head lr)."""
+    for m in model.backbone.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.momentum = 0.01
+    return torch.optim.SGD(params=[{"params": model.backbone.parameters(), "lr": 0.1 * lr},
+                                   {"params": model.classifier.parameters(), "lr": lr}], lr=lr, momentum=0.9,
+                           weight_decay=weight_decay)
+
+
+def poly_lr(base_lr, it, max_iters, power=0.9, min_lr=1e-6):
+    """Segmentation/utils/scheduler.py:3-12 after `it` scheduler steps."""
+    return max(base_lr * (1 - it / max_iters) ** power, min_lr)
+
+
 def sharded_train_step(model, optimizer, criterion, inp, target, world, **kw):
     """N-GPU data-parallel emulation: each rank runs the step on its shard with per-shard BN
     statistics from the SAME starting weights, parameter gradients are averaged, one SGD update is applied.

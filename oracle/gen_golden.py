@@ -1,9 +1,12 @@
 """Golden-vector generator — runs ONLY in the build container, where /root/reference exists.
 
 It imports the reference's own Python (Classification/attack_algo.py, Classification/resnet_s.py,
-Classification/main_learnable.py, Segmentation/attack_algo.py) with arithmetic-neutral shims:
+Classification/main_learnable.py, Segmentation/attack_algo.py, Segmentation/network/) with arithmetic-neutral shims
+(SURVEY.md §8c):
   1. a stand-in for `advertorch.utils.NormalizeByChannelMeanStd` (absent from the image; 3-line formula),
   2. `.cuda()` -> identity, because Classification/attack_algo.py:44-46 hard-codes it,
+  3. an empty `torchvision.models.utils.load_state_dict_from_url` (Segmentation/network/backbone/resnet.py:3; never called
+     with pretrained_backbone=False),
 runs fixed-seed cases through the REFERENCE functions and writes inputs + outputs to tests/golden/*.npz.
 Only those arrays travel to the GPU box; no reference source does.  `main_perturb.py` itself cannot be
 imported (top-level torchvision/matplotlib imports, main_perturb.py:15-23), so its loop body (lines
@@ -320,6 +323,98 @@ def main():
                             adv_se=_np(feature_adv_se), adv_sd=_np(adv_feature_map_sd), fm_se=_np(feature_map_se),
                             out_clean=_np(output0), x_img=_np(x_img))
         print(name, "loss", float(loss))
+
+    # ---- DeepLabv3+ (ResNet-101, output stride 16): the reference's OWN network (Segmentation/network/, imported with one
+    # more shim: torchvision.models.utils.load_state_dict_from_url, unused with pretrained_backbone=False) driven through
+    # the loop body of main_aug_final.py:158-232 with the reference's own attack_algo functions.  Dropout(0.1) of the ASPP
+    # projection (_deeplab.py:185) is switched off (p = 0: a device-RNG mask cannot be matched); nothing
+    # else is touched.  Initial weights are a function of the seed (construction order), so only checksums travel. -----
+    tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    tvm = sys.modules.setdefault("torchvision.models", types.ModuleType("torchvision.models"))
+    tvu = types.ModuleType("torchvision.models.utils")
+    tvu.load_state_dict_from_url = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no network"))
+    sys.modules["torchvision.models.utils"] = tvu
+    tv.models, tvm.utils = tvm, tvu
+    sys.path.insert(0, os.path.join(REF, "Segmentation"))
+    for clash in ("network", "utils"):
+        sys.modules.pop(clash, None)
+    import network as ref_network            # noqa: E402  (Segmentation/network)
+    sys.path.pop(0)
+    for name, steps, gamma_se, gamma_sd, sd_idx, mix_layer, mix_sd, side in (
+            ("seg_dl101_aspp_k1", 1, 0.5, 0.5, "aspp", "11", False, 129),
+            ("seg_dl101_concat_k3", 3, 0.5, 1.5, "concat", "01", True, 129)):
+        torch.manual_seed(3)
+        net = ref_network.deeplabv3plus_resnet101(num_classes=21, output_stride=16, pretrained_backbone=False)
+        net.classifier.aspp.project[3].p = 0.0
+        for m in net.backbone.modules():                       # utils.set_bn_momentum(model.backbone, 0.01), main_aug_final.py:77
+            if isinstance(m, nn.BatchNorm2d):
+                m.momentum = 0.01
+        net.train()
+        lr = 0.01
+        opt = torch.optim.SGD(params=[{"params": net.backbone.parameters(), "lr": 0.1 * lr},
+                                      {"params": net.classifier.parameters(), "lr": lr}], lr=lr, momentum=0.9, weight_decay=1e-4)
+        seg_crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+        images = torch.rand(2, 3, side, side)
+        labels = torch.randint(0, 21, (2, side, side))
+        labels[torch.rand(2, side, side) < 0.05] = 255
+        k0, c0 = _checksums(net)
+        se_idx, eps = 3, 2.0
+        f0, f1 = int(mix_layer[0]), int(mix_layer[1])
+        inputs_all_se = {"x": images, "adv": None, "out_idx": se_idx, "flag": "head"}
+        inputs_all_sd = {"x": images, "adv": None, "out_idx": sd_idx + "_head", "flag": "clean"}
+        opt.zero_grad()
+        output_dict_se = net(inputs_all_se)
+        decoder_feature_map_dict = net(inputs_all_sd)
+        feature_map_sd = decoder_feature_map_dict["adv"].detach()
+        low_level_feat = output_dict_se["low_level"]
+        feature_map_se = output_dict_se["out"].detach()
+        feature_adv_se = ref_seg.PGD(x=feature_map_se, image_batch=images, low_level_feat=low_level_feat, criterion=seg_crit,
+                                     y=labels, model=net, steps=steps, eps=(eps / 255), gamma=(gamma_se / 255), idx=se_idx,
+                                     randinit=False, clip=False)
+        feature_adv_sd_dict = ref_seg.decoder_PGD(input_dict=decoder_feature_map_dict, image_batch=images, criterion=seg_crit,
+                                                  y=labels, model=net, steps=steps, eps=(eps / 255), gamma=(gamma_sd / 255),
+                                                  idx=sd_idx, randinit=False, clip=False)
+        adv_feature_map_sd = feature_adv_sd_dict["adv"].detach()
+        if mix_sd:
+            adv_feature_map_sd = ref_seg.mix_feature(feature_map_sd, adv_feature_map_sd)
+        feature_adv_sd_dict["adv"] = adv_feature_map_sd
+        adv_list_se = ref_seg.get_sample_points(feature_map_se, feature_adv_se, 3)
+        if f0:
+            adv_list_se[1] = ref_seg.mix_feature(feature_map_se, adv_list_se[1])
+        if f1:
+            adv_list_se[2] = ref_seg.mix_feature(feature_map_se, adv_list_se[2])
+        clean_input_dict = {"x": images, "adv": None, "out_idx": 0, "flag": "clean"}
+        adv_input_se_dict1 = {"x": images, "adv": adv_list_se[1], "out_idx": se_idx, "flag": "tail", "low_level_feat": low_level_feat}
+        adv_input_se_dict2 = {"x": images, "adv": adv_list_se[2], "out_idx": se_idx, "flag": "tail", "low_level_feat": low_level_feat}
+        adv_input_sd_dict = {"x": images, "adv": feature_adv_sd_dict, "out_idx": sd_idx + "_tail", "flag": "clean"}
+        output0, output1 = net(clean_input_dict), net(adv_input_se_dict1)
+        output2, output3 = net(adv_input_se_dict2), net(adv_input_sd_dict)
+        loss0, loss1 = seg_crit(output0, labels), seg_crit(output1, labels)
+        loss2, loss3 = seg_crit(output2, labels), seg_crit(output3, labels)
+        loss = 0.7 * loss0 + 0.1 * loss1 + 0.1 * loss2 + 0.1 * loss3
+        loss.backward()
+        opt.step()
+        k1, c1 = _checksums(net)
+        sd = net.state_dict()
+        rec = dict(images=_np(images), labels=_np(labels), meta=np.array([steps, se_idx, int(mix_sd)]),
+                   gammas=np.array([gamma_se, gamma_sd, eps]), sd_idx=np.array(sd_idx), mix_layer=np.array(mix_layer),
+                   seed=np.array(3), lr=np.array(lr), ck0=c0, ck1=c1, keys=np.array(k1), loss=_np(loss),
+                   losses=np.array([float(loss0), float(loss1), float(loss2), float(loss3)], dtype=np.float32),
+                   adv_se=_np(feature_adv_se), fm_se=_np(feature_map_se), fm_sd_sub=_np(feature_map_sd[:, ::4]),
+                   adv_sd_sub=_np(adv_feature_map_sd[:, ::4]),
+                   adv_sd_sum=np.array([float(adv_feature_map_sd.double().sum()), float(adv_feature_map_sd.double().abs().sum())]),
+                   out_clean_sub=_np(output0[:, :, ::4, ::4]),
+                   out_clean_sum=np.array([float(output0.double().sum()), float(output0.double().abs().sum())]))
+        for k in ("classifier.classifier.3.weight", "classifier.classifier.3.bias", "backbone.bn1.running_mean",
+                  "backbone.bn1.running_var", "backbone.bn1.num_batches_tracked", "backbone.layer4.0.bn1.running_mean",
+                  "backbone.layer4.0.bn1.num_batches_tracked", "classifier.aspp.convs.4.2.running_var",
+                  "classifier.classifier.1.num_batches_tracked", "classifier.project.1.running_mean",
+                  "classifier.project.1.num_batches_tracked", "backbone.conv1.weight"):
+            rec["sd1/" + k] = _np(sd[k])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+        print(name, "loss", float(loss), [float(loss0), float(loss1), float(loss2), float(loss3)])
+    for clash in ("network", "utils"):
+        sys.modules.pop(clash, None)
 
     # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
     torch.manual_seed(7)

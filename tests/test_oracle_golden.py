@@ -111,6 +111,53 @@ def test_segmentation_step_matches_reference_functions(orc, case):
         orc.seg_decoder_PGD(d, images, crit, y=labels, model=net, steps=1, eps=2 / 255, gamma=0.5 / 255, idx="aspp", clip=True)
 
 
+@pytest.mark.parametrize("case", ["seg_dl101_aspp_k1", "seg_dl101_concat_k3"])
+def test_deeplab_step_matches_reference_network(orc, case):
+    """oracle.SegDeepLabV3Plus (ResNet-101, output stride 16) + oracle.seg_train_step against the reference's OWN network
+    (Segmentation/network/, imported by oracle/gen_golden.py) driven through main_aug_final.py:158-232 — bit for bit:
+    seeded construction, feature maps, perturbations, the four losses, every tensor of the state_dict after the step."""
+    g = golden(case)
+    steps, se_idx, mix_sd = [int(v) for v in g["meta"]]
+    gamma_se, gamma_sd, eps = [float(v) for v in g["gammas"]]
+    torch.manual_seed(int(g["seed"]))
+    net = orc.deeplabv3plus_resnet101(num_classes=21, output_stride=16)
+    net.classifier.aspp.project[3].p = 0.0                      # as in the golden run (dropout masks cannot be matched)
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    np.testing.assert_array_equal(_checks(net), g["ck0"])
+    opt = orc.seg_make_optimizer(net, lr=float(g["lr"]), weight_decay=1e-4)
+    net.train()
+    crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+    images, labels = torch.from_numpy(g["images"]), torch.from_numpy(g["labels"])
+    r = orc.seg_train_step(net, opt, crit, images, labels, steps=steps, eps=eps, gamma_se=gamma_se, gamma_sd=gamma_sd,
+                           pertub_idx_se=se_idx, pertub_idx_sd=str(g["sd_idx"]), mix_layer=str(g["mix_layer"]),
+                           mix_sd=bool(mix_sd))
+    np.testing.assert_array_equal(r["loss"].numpy(), g["loss"])
+    np.testing.assert_array_equal(r["losses"].numpy(), g["losses"])
+    np.testing.assert_array_equal(r["adv_se"].numpy(), g["adv_se"])
+    np.testing.assert_array_equal(r["fm_se"].numpy(), g["fm_se"])
+    np.testing.assert_array_equal(r["adv_sd"][:, ::4].numpy(), g["adv_sd_sub"])
+    np.testing.assert_array_equal(r["out_clean"][:, :, ::4, ::4].numpy(), g["out_clean_sub"])
+    np.testing.assert_array_equal(_checks(net), g["ck1"])
+    sd = net.state_dict()
+    for k in g.files:
+        if k.startswith("sd1/"):
+            np.testing.assert_array_equal(sd[k[4:]].numpy(), g[k], err_msg=k)
+
+
+def test_poly_lr_schedule(orc):
+    """utils/scheduler.py:3-12 restated (oracle.poly_lr) against torch's scheduler machinery driving the same formula."""
+    import importlib
+    dl = importlib.import_module("cv_a-fan_amd.deeplab")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [p], "lr": 0.001}, {"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 0.01}], lr=0.01)
+    sch = dl.PolyLR(opt, 30, power=0.9)
+    for it in range(1, 6):
+        opt.step()
+        sch.step()
+        assert opt.param_groups[0]["lr"] == orc.poly_lr(0.001, it, 30)
+        assert opt.param_groups[1]["lr"] == orc.poly_lr(0.01, it, 30)
+
+
 def test_stored_initial_weights_equal_seeded_construction(orc):
     g = golden("step_r20s_k1")
     torch.manual_seed(3)
