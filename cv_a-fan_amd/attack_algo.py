@@ -95,10 +95,13 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
 
 def mix_feature(clean_feature, adv_feature):
     """Segmentation/attack_algo.py:121-130: re-normalise clean features to the adversarial channel statistics."""
-    return ops.mix_feature(clean_feature.contiguous(), adv_feature.contiguous(), 1e-5)
+    return ops.mix_feature(_dense(clean_feature), _dense(adv_feature), 1e-5)      # (either dense layout; adv follows clean's)
 
 
 def get_sample_points(pointx, pointy, number):
     """Segmentation/attack_algo.py:108-118: [x, lerp(x,y,1/(n-1)), ..., y]; interior points in one launch."""
-    inner = ops.lerp_points(pointx.contiguous(), pointy.contiguous(), number)
+    px, py = _dense(pointx), _dense(pointy)
+    if py.stride() != px.stride():
+        py = _like_layout(py, px)
+    inner = ops.lerp_points(px, py, number)
     return [pointx] + inner + [pointy]

@@ -738,7 +738,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
             if (T == 0) {
                 // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  One all-invalid tap makes
                 // the kernel write zeros through its normal path.
-                T = 1; c.dh[0] = -(1 << 20); c.dw[0] = 0; c.wofs[0] = 0;
+                T = 1; c.dh[0] = -(ho + 2); c.dw[0] = 0; c.wofs[0] = 0;   // (small enough for the 32-bit tap offset)
             }
             c.T = T;
             ++nc;

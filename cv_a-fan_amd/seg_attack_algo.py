@@ -96,9 +96,9 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     optimizer.zero_grad()
     out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
     dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
-    fm_sd = dec["adv"].detach()
+    fm_sd = dec["adv"].detach().float()       # (bf16 activations on the product path: the A-FAN operators work in fp32)
     low = out_se["low_level"]
-    fm_se = out_se["out"].detach()
+    fm_se = out_se["out"].detach().float()
     adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
                  eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip)
     adv_sd_dict = decoder_PGD(input_dict=dec, image_batch=images, criterion=criterion, y=labels, model=model, steps=steps,
@@ -109,7 +109,7 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     if noise_sd != 0:
         ops.axpy_noise_(adv_sd, torch.rand(adv_sd.shape).to(adv_sd.device, non_blocking=True), gamma_sd * noise_sd)
     adv_sd_dict["adv"] = adv_sd
-    pts = get_sample_points(fm_se.float().contiguous(), adv_se.detach(), 3)
+    pts = get_sample_points(fm_se, adv_se.detach(), 3)
     if f0:
         pts[1] = mix_feature(fm_se, pts[1])
     if f1:

@@ -59,6 +59,26 @@ def test_argument_errors_without_gpu(pkg):
     assert lib.afan_norms_workspace_floats(256, 65536) == 2 * 256 * 16
     assert lib.afan_bn_workspace_floats(64) >= 64 * 64 * 4
     assert lib.afan_lerp_points(p, p, p, 4, buf, 9, None) == -3
+    # DeepLab layers
+    assert lib.afan_upsample_bilinear_fwd(p, p, 0, 0, 1, 0, 4, 4, 8, 8, None) == -3
+    assert lib.afan_upsample_bilinear_fwd(p, p, 0, 7, 1, 1, 4, 4, 8, 8, None) == -5
+    assert lib.afan_upsample_bilinear_fwd(p, p, 0, 0, 0, 1, 4, 4, 8, 8, None) == 0          # empty batch: no launch
+    assert lib.afan_ce2d(p, p, 0, 1, 33, 4, 255, 1.0, p, p, None, None) == -3               # more than 32 classes
+    assert lib.afan_ce2d(p, None, 0, 1, 4, 4, 255, 1.0, p, p, None, None) == -4
+    assert lib.afan_ce2d_workspace_floats(513 * 513) == 1 + 2 * 1029
+    assert lib.afan_maxpool3x3s2_fwd(p, p, 3, 0, 1, 1, 4, 4, None) == -1
+    assert lib.afan_pointwise_fwd(p, 1, p, None, p, 4, 12, 4, None) == -3                   # ci % 8
+    assert lib.afan_pointwise_fwd(p, 1, p, None, p, 4, 16, 33, None) == -3                  # co > afan_pointwise_max_co()
+    assert lib.afan_pointwise_max_co() == 32
+    assert lib.afan_dropout(p, p, 0, 4, 1.0, None, None, None, 1, None) == -3               # p must be < 1
+    assert lib.afan_dropout(p, p, 0, 4, 0.1, None, None, None, 1, None) == -4               # needs a mask or a generator
+    assert lib.afan_conv_stem7_supported(3, 64, 7, 2) == 1 and lib.afan_conv_stem7_supported(3, 64, 3, 1) == 0
+    assert lib.afan_conv_stem7_wgrad_workspace_floats(2, 513, 513) == 512 * 147 * 64
+    # atrous / ragged-channel convolutions: shapes the tiled kernels take or decline
+    assert lib.afan_conv_supported(304, 256, 3, 1) == 1 and lib.afan_conv_supported(256, 48, 1, 1) == 1
+    assert lib.afan_conv_supported(20, 256, 3, 1) == 0 and lib.afan_conv_supported(100, 256, 3, 1) == 0
+    assert lib.afan_conv_fwd_nhwc_bf16(p, p, p, 1, 8, 8, 256, 256, 3, 2, 2, None, None, None, 1, None) == -3   # dilation needs stride 1
+    assert lib.afan_conv_fwd_nhwc_bf16(p, p, p, 1, 8, 8, 256, 256, 1, 1, 2, None, None, None, 1, None) == -3   # ... and a 3x3
 
 
 def test_missing_library_fails_loudly(pkg, monkeypatch):

@@ -1,0 +1,229 @@
+"""The DeepLabv3+ layer kernels (afan_seg.hip, afan_conv_stem7.hip) and the atrous / ragged-channel convolution paths,
+each through the C-ABI against torch's CPU ops on the same values (the arithmetic the reference's network runs:
+F.interpolate(bilinear, align_corners=False), nn.CrossEntropyLoss(ignore_index), nn.MaxPool2d(3,2,1),
+nn.AdaptiveAvgPool2d(1), nn.Conv2d with dilation, nn.Dropout)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _fmt(t, nhwc):
+    return t.contiguous(memory_format=torch.channels_last) if nhwc else t.contiguous()
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("shape,size", [((2, 21, 33, 33), (129, 129)), ((1, 256, 9, 9), (33, 33)), ((2, 8, 1, 1), (33, 33)),
+                                        ((1, 5, 17, 23), (40, 31)), ((2, 16, 40, 31), (17, 23)), ((1, 3, 129, 129), (513, 513))])
+def test_upsample_bilinear_fp32(pkg, gpu, shape, size, nhwc):
+    torch.manual_seed(1)
+    x = torch.randn(shape)
+    ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    got = pkg.ops.upsample_bilinear(_fmt(x.to(gpu), nhwc), size)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # backward: the adjoint of the same linear map
+    g = torch.randn(ref.shape)
+    xr = x.clone().requires_grad_(True)
+    F.interpolate(xr, size=size, mode="bilinear", align_corners=False).backward(g)
+    dx = pkg.ops.upsample_bilinear_backward(_fmt(g.to(gpu), nhwc), shape[2:])
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_upsample_bilinear_bf16_nhwc(pkg, gpu):
+    torch.manual_seed(2)
+    x = torch.randn(2, 256, 33, 33).bfloat16()
+    ref = F.interpolate(x.float(), size=(129, 129), mode="bilinear", align_corners=False)
+    got = pkg.ops.upsample_bilinear(_fmt(x.to(gpu), True), (129, 129))
+    assert got.dtype == torch.bfloat16 and got.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)
+    g = torch.randn(2, 256, 129, 129).bfloat16()
+    xr = x.float().requires_grad_(True)
+    F.interpolate(xr, size=(129, 129), mode="bilinear", align_corners=False).backward(g.float())
+    dx = pkg.ops.upsample_bilinear_backward(_fmt(g.to(gpu), True), (33, 33))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=6e-2)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("n,c,h,w", [(2, 21, 65, 65), (1, 19, 33, 47), (2, 5, 33, 33), (1, 32, 8, 8)])
+def test_ce2d_vs_torch(pkg, gpu, n, c, h, w, nhwc):
+    torch.manual_seed(3)
+    logits = torch.randn(n, c, h, w) * 3
+    target = torch.randint(0, c, (n, h, w))
+    target[torch.rand(n, h, w) < 0.07] = 255
+    lr = logits.clone().requires_grad_(True)
+    ref = nn.CrossEntropyLoss(ignore_index=255)(lr, target)
+    ref.backward()
+    loss, dl = pkg.ops.ce2d(_fmt(logits.to(gpu), nhwc), target.to(gpu), 255, 1.0)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    np.testing.assert_allclose(dl.cpu().numpy(), lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # pre-scaled gradient (the weight of a term in the joint loss)
+    _, dl7 = pkg.ops.ce2d(_fmt(logits.to(gpu), nhwc), target.to(gpu), 255, 0.7)
+    np.testing.assert_allclose(dl7.cpu().numpy(), 0.7 * lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_ce2d_edge_cases(pkg, gpu):
+    logits = torch.randn(1, 4, 3, 3, device=gpu)
+    all_ign = torch.full((1, 3, 3), 255, dtype=torch.int64, device=gpu)
+    loss, dl = pkg.ops.ce2d(logits, all_ign, 255)
+    assert torch.isnan(loss).all() and float(dl.abs().sum()) == 0.0           # torch: 0 / 0 = nan, zero gradient
+    bad = torch.zeros((1, 3, 3), dtype=torch.int64, device=gpu)
+    bad[0, 1, 1] = 7                                                           # outside [0, C) and not the ignore index
+    assert torch.isnan(pkg.ops.ce2d(logits, bad, 255)[0]).all()
+    with pytest.raises(TypeError):
+        pkg.ops.ce2d(logits, bad.int(), 255)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 65, 65), (1, 16, 9, 12), (2, 3, 5, 5), (1, 8, 1, 1)])
+def test_maxpool_vs_torch_with_ties(pkg, gpu, shape, dtype, nhwc):
+    torch.manual_seed(4)
+    x = torch.relu(torch.randn(shape)).to(dtype)          # post-ReLU: windows tie at 0 — the gradient must go where ATen's goes
+    xr = x.float().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    g = torch.randn(ref.shape).to(dtype)
+    ref.backward(g.float())
+    y = pkg.ops.maxpool3x3s2(_fmt(x.to(gpu), nhwc))
+    np.testing.assert_array_equal(y.float().cpu().numpy(), ref.detach().numpy())
+    dx = pkg.ops.maxpool3x3s2_backward(_fmt(g.to(gpu), nhwc), _fmt(x.to(gpu), nhwc))
+    tol = dict(rtol=0, atol=0) if dtype == torch.float32 else dict(rtol=8e-3, atol=2e-2)   # bf16: up to 4 addends rounded once
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), **tol)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_avgpool(pkg, gpu, dtype, nhwc):
+    torch.manual_seed(5)
+    x = torch.randn(2, 2048, 9, 9).to(dtype)
+    y = pkg.ops.avgpool(_fmt(x.to(gpu), nhwc))
+    ref = x.float().mean(dim=(2, 3), keepdim=True)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=1e-5 if dtype == torch.float32 else 8e-3, atol=1e-6 if dtype == torch.float32 else 4e-3)
+    g = torch.randn(2, 2048, 1, 1).to(dtype)
+    dx = pkg.ops.avgpool_backward(g.to(gpu), _fmt(x.to(gpu), nhwc))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), (g.float() / 81).expand(2, 2048, 9, 9).numpy(),
+                               rtol=1e-6 if dtype == torch.float32 else 8e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 256, 21, 33, 33), (1, 256, 19, 17, 9), (1, 64, 32, 5, 5)])
+def test_pointwise_classifier(pkg, gpu, n, ci, co, h, w, dtype):
+    torch.manual_seed(6)
+    x = torch.randn(n, ci, h, w).to(dtype)
+    wt = torch.randn(co, ci, 1, 1) * 0.1
+    b = torch.randn(co)
+    xr = x.float().requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    g = torch.randn(ref.shape)
+    ref.backward(g)
+    xg = _fmt(x.to(gpu), True)
+    y = pkg.ops.pointwise_forward(xg, wt.to(gpu), b.to(gpu))
+    assert y.dtype == torch.float32
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    dw, db = torch.zeros(co, ci, 1, 1, device=gpu), torch.zeros(co, device=gpu)
+    dx = pkg.ops.pointwise_backward(_fmt(g.to(gpu), True), xg, wt.to(gpu), True, dw, db, accumulate=False)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-3)
+    # accumulate = 1 adds into the buffers
+    pkg.ops.pointwise_backward(_fmt(g.to(gpu), True), xg, wt.to(gpu), False, dw, db, accumulate=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), 2 * wr.grad.numpy(), rtol=1e-3, atol=4e-3)
+
+
+def test_dropout_mask_and_generator(pkg, gpu):
+    torch.manual_seed(7)
+    x = torch.randn(2, 256, 9, 9, device=gpu)
+    mask = (torch.rand(2, 256, 9, 9) > 0.1).to(torch.uint8).to(gpu)
+    y, _ = pkg.ops.dropout(x, 0.1, mask)
+    np.testing.assert_array_equal(y.cpu().numpy(), (x * mask.float() * (1.0 / (1.0 - 0.1))).cpu().numpy())
+    # device generator: ~p dropped, scale 1/(1-p), fresh mask per call, backward re-derives the forward's mask
+    big = torch.ones(1 << 20, device=gpu)
+    y1, used1 = pkg.ops.dropout(big, 0.1)
+    y2, used2 = pkg.ops.dropout(big, 0.1)
+    k1, k2 = (y1 != 0), (y2 != 0)
+    assert abs(float(k1.float().mean()) - 0.9) < 3e-3 and abs(float(k2.float().mean()) - 0.9) < 3e-3
+    assert int(used1) != int(used2) and float((k1 != k2).float().mean()) > 0.1
+    np.testing.assert_allclose(y1[k1].cpu().numpy(), 1.0 / 0.9, rtol=1e-6)
+    g = torch.full_like(big, 2.0)
+    dx, _ = pkg.ops.dropout(g, 0.1, None, used1)
+    np.testing.assert_array_equal((dx != 0).cpu().numpy(), k1.cpu().numpy())
+    # bf16 tensors take the same path
+    yb, _ = pkg.ops.dropout(big.bfloat16(), 0.5)
+    assert abs(float((yb != 0).float().mean()) - 0.5) < 3e-3
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 129, 129), (1, 64, 64), (1, 33, 47), (2, 7, 5)])
+def test_stem7_fwd_wgrad(pkg, gpu, n, h, w):
+    torch.manual_seed(8)
+    x = _bf(torch.randn(n, 3, h, w))
+    wt = _bf(torch.randn(64, 3, 7, 7) * 0.1)
+    xr, wr = x.clone(), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, 2, 3)
+    g = _bf(torch.randn(ref.shape))
+    ref.backward(g)
+    xg = _fmt(x.to(gpu).bfloat16(), True)
+    wg = _fmt(wt.to(gpu).bfloat16(), True)
+    y = pkg.ops.conv_stem7_fwd(xg, wg)
+    assert tuple(y.shape) == tuple(ref.shape)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=2e-2)
+    gw = pkg.ops.conv_stem7_wgrad(xg, _fmt(g.to(gpu).bfloat16(), True))
+    np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+    gw2 = pkg.ops.conv_stem7_wgrad(xg, _fmt(g.to(gpu).bfloat16(), True), gw.clone(), accumulate=True)
+    np.testing.assert_allclose(gw2.cpu().numpy(), 2 * wr.grad.numpy(), rtol=2e-3, atol=4e-3 * float(wr.grad.abs().max()))
+
+
+CONV_CASES = [
+    # n, ci, co, h, w, k, stride, dilation
+    (2, 256, 256, 33, 33, 3, 1, 2),          # layer4-style atrous
+    (2, 512, 256, 17, 17, 3, 1, 6),          # ASPP rate 6
+    (1, 2048, 256, 9, 9, 3, 1, 12),          # ASPP rate 12 on a 9x9 map: most taps fall outside
+    (1, 512, 256, 33, 33, 3, 1, 18),
+    (2, 304, 256, 33, 33, 3, 1, 1),          # decoder: ragged reduction (304 = 4.75 x 64)
+    (2, 256, 48, 33, 33, 1, 1, 1),           # low-level projection: ragged output tile
+    (2, 64, 256, 33, 33, 1, 1, 1),
+    (1, 128, 128, 65, 65, 3, 2, 1),          # odd size, stride 2 (129 -> 65 style)
+    (2, 2048, 256, 1, 1, 1, 1, 1),           # ASPP pooling branch: two rows
+    (1, 1280, 256, 9, 9, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,k,stride,dil", CONV_CASES)
+def test_conv_atrous_ragged_vs_torch(pkg, gpu, n, ci, co, h, w, k, stride, dil):
+    """forward, input gradient and weight gradient of the tiled kernels on the DeepLab shapes against torch's fp32
+    convolution of the same bf16 values."""
+    torch.manual_seed(9)
+    pad = dil * (k // 2)
+    x = _bf(torch.randn(n, ci, h, w))
+    wt = _bf(torch.randn(co, ci, k, k) * (1.0 / (ci * k * k) ** 0.5))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride, pad, dil)
+    g = _bf(torch.randn(ref.shape))
+    ref.backward(g)
+    xg, wg = _fmt(x.to(gpu).bfloat16(), True), _fmt(wt.to(gpu).bfloat16(), True)
+    y = pkg.ops.conv_fwd(xg, wg, stride, dilation=dil)
+    assert tuple(y.shape) == tuple(ref.shape)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.detach().numpy(), rtol=1e-2, atol=2e-2)
+    gg = _fmt(g.to(gpu).bfloat16(), True)
+    wtt = _fmt(wt.permute(1, 0, 2, 3).contiguous().to(gpu).bfloat16(), True)
+    dx = pkg.ops.conv_dgrad(gg, wtt, (h, w), stride, dilation=dil)
+    scale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=1e-2 * scale)
+    gw = pkg.ops.conv_wgrad(xg, gg, k, stride, dilation=dil)
+    np.testing.assert_allclose(gw.cpu().numpy(), wr.grad.numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+
+
+def test_conv_stats_fusion_on_ragged_channels_is_declined(pkg, gpu):
+    """48 output channels: the moments fusion does not apply — conv_fwd returns no ConvStats and BatchNorm reduces itself."""
+    x = torch.randn(1, 256, 9, 9, device=gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(48, 256, 1, 1, device=gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+    y, st = pkg.ops.conv_fwd(x, w, 1, stats_shift=torch.zeros(48, device=gpu), want_stats=True)
+    assert st is None and tuple(y.shape) == (1, 48, 9, 9)
