@@ -21,7 +21,7 @@ struct Src {
     float l0, l1;
 };
 __device__ __forceinline__ Src src_index(float scale, int dst, int in_size) {
-    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    float s = fmaf(scale, (float)dst + 0.5f, -0.5f);    // (ATen's CPU kernels are built with FMA contraction: same rounding)
     if (s < 0.f) s = 0.f;
     Src r;
     r.i0 = (int)s;
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(BLOCK) void maxpool_bwd_kernel(const T* __restrict_
 
 // ---- global average pool ----------------------------------------------------------------------------------------------
 // NHWC: block = (sample, 64 channels); 4 waves walk the pixels 4 apart, lanes along the channels (coalesced 128 B rows)
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void avgpool_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int C, int64_t HW) {
+template <typename T, typename TP>
+__global__ __launch_bounds__(BLOCK) void avgpool_nhwc_kernel(const T* __restrict__ x, TP* __restrict__ y, int C, int64_t HW) {
     const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
     float s = 0.f;
     if (c < C)
@@ -320,26 +320,26 @@ __global__ __launch_bounds__(BLOCK) void avgpool_nhwc_kernel(const T* __restrict
     __shared__ float red[4][64];
     red[r][threadIdx.x & 63] = s;
     __syncthreads();
-    if (r == 0 && c < C) Elt<T>::st(y + (int64_t)n * C + c, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW);
+    if (r == 0 && c < C) Elt<TP>::st(y + (int64_t)n * C + c, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW);
 }
 // NCHW: one wave per (n, c) plane
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void avgpool_nchw_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t planes, int64_t HW) {
+template <typename T, typename TP>
+__global__ __launch_bounds__(BLOCK) void avgpool_nchw_kernel(const T* __restrict__ x, TP* __restrict__ y, int64_t planes, int64_t HW) {
     const int64_t pl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pl >= planes) return;
     float s = 0.f;
     for (int64_t p = threadIdx.x & 63; p < HW; p += 64) s += Elt<T>::ld(x + pl * HW + p);
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) Elt<T>::st(y + pl, s / (float)HW);
+    if ((threadIdx.x & 63) == 0) Elt<TP>::st(y + pl, s / (float)HW);
 }
-template <typename T, bool NHWC>
-__global__ __launch_bounds__(BLOCK) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int C, int64_t HW, int64_t total) {
+template <typename T, typename TP, bool NHWC>
+__global__ __launch_bounds__(BLOCK) void avgpool_bwd_kernel(const TP* __restrict__ dy, T* __restrict__ dx, int C, int64_t HW, int64_t total) {
     const float inv = 1.f / (float)HW;
     for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
         int64_t plane;
         if constexpr (NHWC) { const int c = (int)(v % C); plane = (v / C / HW) * C + c; }
         else plane = v / HW;
-        Elt<T>::st(dx + v, Elt<T>::ld(dy + plane) * inv);
+        Elt<T>::st(dx + v, Elt<TP>::ld(dy + plane) * inv);
     }
 }
 
@@ -455,6 +455,65 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dw_reduce_kernel(const float*
         for (int g = 0; g < G; ++g) s += bslab[(int64_t)g * Co + i];
         db[i] = accumulate ? db[i] + s : s;
     }
+}
+
+// ---- fp32 linear layer on a handful of rows -------------------------------------------------------------------------------
+// The ASPP pooling branch (_deeplab.py:152-163) works on ONE vector per image: with 2 images per GPU its BatchNorm sees two
+// samples per channel and normalises their DIFFERENCE, which bf16 storage of the pooled vector would round away (measured:
+// backbone gradients off by 30-60 %).  The branch therefore stays in fp32 from the pooled vector to the broadcast:
+//   y[n][co] = sum_ci x[n][ci] * w[co][ci]      (n <= LIN_MAX_N rows, fp32 master weights)
+constexpr int LIN_MAX_N = 16;
+__global__ __launch_bounds__(BLOCK) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 float* __restrict__ y, int N, int Ci, int Co) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= Co) return;
+    float acc[LIN_MAX_N];
+#pragma unroll
+    for (int n = 0; n < LIN_MAX_N; ++n) acc[n] = 0.f;
+    for (int c = lane; c < Ci; c += 64) {
+        const float wv = w[(int64_t)co * Ci + c];
+#pragma unroll
+        for (int n = 0; n < LIN_MAX_N; ++n)
+            if (n < N) acc[n] = fmaf(x[(int64_t)n * Ci + c], wv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < LIN_MAX_N; ++n) {
+        if (n < N) {
+            const float s = wave_sum(acc[n]);
+            if (lane == 0) y[(int64_t)n * Co + co] = s;
+        }
+    }
+}
+// dx[n][ci] = sum_co dy[n][co] * w[co][ci]
+__global__ __launch_bounds__(BLOCK) void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                float* __restrict__ dx, int N, int Ci, int Co) {
+    extern __shared__ float g[];      // [N][Co]
+    for (int i = threadIdx.x; i < N * Co; i += BLOCK) g[i] = dy[i];
+    __syncthreads();
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= Ci) return;
+    float acc[LIN_MAX_N];
+#pragma unroll
+    for (int n = 0; n < LIN_MAX_N; ++n) acc[n] = 0.f;
+    for (int co = 0; co < Co; ++co) {
+        const float wv = w[(int64_t)co * Ci + c];
+#pragma unroll
+        for (int n = 0; n < LIN_MAX_N; ++n)
+            if (n < N) acc[n] = fmaf(g[n * Co + co], wv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < LIN_MAX_N; ++n)
+        if (n < N) dx[(int64_t)n * Ci + c] = acc[n];
+}
+// dw[co][ci] (+)= sum_n dy[n][co] * x[n][ci]
+__global__ __launch_bounds__(BLOCK) void linear_small_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ dw, int N, int Ci, int Co, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (int64_t)Co * Ci) return;
+    const int co = (int)(i / Ci), c = (int)(i - (int64_t)co * Ci);
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dy[(int64_t)n * Co + co], x[(int64_t)n * Ci + c], s);
+    dw[i] = accumulate ? dw[i] + s : s;
 }
 
 // ---- dropout -----------------------------------------------------------------------------------------------------------
@@ -622,7 +681,8 @@ int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, in
     return AFAN_OK;
 }
 
-int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream) {
+int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,
+                     afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
     if (n < 0 || c <= 0 || hw <= 0 || n > 65535) return AFAN_ESHAPE;
@@ -631,20 +691,25 @@ int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, i
     hipStream_t st = (hipStream_t)stream;
     const int es = dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("avgpool_fwd_kernel", (double)es * n * c * (hw + 1), st);
+    const bool pf = pooled_f32 || dtype == AFAN_F32;
     if (layout == AFAN_NHWC) {
         dim3 grid((unsigned)((c + 63) / 64), (unsigned)n);
-        if (dtype == AFAN_F32) avgpool_nhwc_kernel<float><<<grid, BLOCK, 0, st>>>((const float*)x, (float*)y, (int)c, hw);
-        else avgpool_nhwc_kernel<uint16_t><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)y, (int)c, hw);
+        if (dtype == AFAN_F32) avgpool_nhwc_kernel<float, float><<<grid, BLOCK, 0, st>>>((const float*)x, (float*)y, (int)c, hw);
+        else if (pf) avgpool_nhwc_kernel<uint16_t, float><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (float*)y, (int)c, hw);
+        else avgpool_nhwc_kernel<uint16_t, uint16_t><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)y, (int)c, hw);
     } else {
         const int64_t planes = n * c;
-        if (dtype == AFAN_F32) avgpool_nchw_kernel<float><<<(unsigned)((planes + 3) / 4), BLOCK, 0, st>>>((const float*)x, (float*)y, planes, hw);
-        else avgpool_nchw_kernel<uint16_t><<<(unsigned)((planes + 3) / 4), BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)y, planes, hw);
+        const unsigned g = (unsigned)((planes + 3) / 4);
+        if (dtype == AFAN_F32) avgpool_nchw_kernel<float, float><<<g, BLOCK, 0, st>>>((const float*)x, (float*)y, planes, hw);
+        else if (pf) avgpool_nchw_kernel<uint16_t, float><<<g, BLOCK, 0, st>>>((const uint16_t*)x, (float*)y, planes, hw);
+        else avgpool_nchw_kernel<uint16_t, uint16_t><<<g, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)y, planes, hw);
     }
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
 
-int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream) {
+int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,
+                     afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
     if (n < 0 || c <= 0 || hw <= 0) return AFAN_ESHAPE;
@@ -655,13 +720,13 @@ int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n,
     const int es = dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("avgpool_bwd_kernel", (double)es * n * c * (hw + 1), st);
     const int g = grid_for(total, BLOCK, 4096);
-    if (dtype == AFAN_F32) {
-        if (layout == AFAN_NHWC) avgpool_bwd_kernel<float, true><<<g, BLOCK, 0, st>>>((const float*)dy, (float*)dx, (int)c, hw, total);
-        else avgpool_bwd_kernel<float, false><<<g, BLOCK, 0, st>>>((const float*)dy, (float*)dx, (int)c, hw, total);
-    } else {
-        if (layout == AFAN_NHWC) avgpool_bwd_kernel<uint16_t, true><<<g, BLOCK, 0, st>>>((const uint16_t*)dy, (uint16_t*)dx, (int)c, hw, total);
-        else avgpool_bwd_kernel<uint16_t, false><<<g, BLOCK, 0, st>>>((const uint16_t*)dy, (uint16_t*)dx, (int)c, hw, total);
-    }
+    const bool pf = pooled_f32 || dtype == AFAN_F32;
+#define AP_(T, TP) do { if (layout == AFAN_NHWC) avgpool_bwd_kernel<T, TP, true><<<g, BLOCK, 0, st>>>((const TP*)dy, (T*)dx, (int)c, hw, total); \
+                        else avgpool_bwd_kernel<T, TP, false><<<g, BLOCK, 0, st>>>((const TP*)dy, (T*)dx, (int)c, hw, total); } while (0)
+    if (dtype == AFAN_F32) AP_(float, float);
+    else if (pf) AP_(uint16_t, float);
+    else AP_(uint16_t, uint16_t);
+#undef AP_
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -729,6 +794,35 @@ int afan_pointwise_bwd_dw(const float* dy, const void* x, int x_dtype, float* dw
     AFAN_LAUNCH_CHECK();
     pointwise_dw_reduce_kernel<<<(unsigned)((co * ci + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(workspace, bslab, dw, db, G, (int)ci, (int)co, accumulate);
     AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_linear_small_max_rows(void) { return LIN_MAX_N; }
+
+int afan_linear_small_fwd(const float* x, const float* w, float* y, int64_t n, int64_t ci, int64_t co, afan_stream_t stream) {
+    if (n <= 0 || n > LIN_MAX_N || ci <= 0 || co <= 0) return AFAN_ESHAPE;
+    if (!x || !w || !y) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("linear_small_fwd_kernel", 4.0 * (ci * co + n * (ci + co)), st);
+    linear_small_fwd_kernel<<<(unsigned)((co + 3) / 4), BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int64_t n, int64_t ci,
+                          int64_t co, int accumulate, afan_stream_t stream) {
+    if (n <= 0 || n > LIN_MAX_N || ci <= 0 || co <= 0 || n * co * 4 > 64 * 1024) return AFAN_ESHAPE;
+    if (!dy || !w || !x) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("linear_small_bwd_kernel", 4.0 * (2 * ci * co + 2 * n * (ci + co)), st);
+    if (dx) {
+        linear_small_dx_kernel<<<(unsigned)((ci + BLOCK - 1) / BLOCK), BLOCK, (size_t)n * co * 4, st>>>(dy, w, dx, (int)n, (int)ci, (int)co);
+        AFAN_LAUNCH_CHECK();
+    }
+    if (dw) {
+        linear_small_dw_kernel<<<(unsigned)((ci * co + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(dy, x, dw, (int)n, (int)ci, (int)co, accumulate);
+        AFAN_LAUNCH_CHECK();
+    }
     return AFAN_OK;
 }
 

@@ -52,21 +52,43 @@ def interpolate(x, size):
 
 
 class _BroadcastFn(torch.autograd.Function):
-    """Bilinear resize of a 1x1 map = broadcast over the pixels (the ASPP pooling branch, _deeplab.py:139-141); the
-    backward sums the pixels of every (image, channel) — through the average-pool kernel (sum = mean * HW)."""
+    """Bilinear resize of a 1x1 map = broadcast over the pixels (the ASPP pooling branch, _deeplab.py:139-141), cast from
+    the branch's fp32 to the network's compute dtype on the way; the backward sums the pixels of every (image, channel)
+    in fp32 — through the average-pool kernel (sum = mean * HW)."""
 
     @staticmethod
-    def forward(ctx, x, size, channels_last):
+    def forward(ctx, x, size, channels_last, dtype):
         n, c = x.shape[:2]
         ctx.hw = size
-        y = x.reshape(n, c, 1, 1).expand(n, c, size[0], size[1])
+        y = x.reshape(n, c, 1, 1).to(dtype).expand(n, c, size[0], size[1])
         return y.contiguous(memory_format=torch.channels_last if channels_last else torch.contiguous_format)
 
     @staticmethod
     def backward(ctx, g):
-        g = _dense(g)
-        s = ops.avgpool(g)
-        return s * float(ctx.hw[0] * ctx.hw[1]), None, None
+        s = ops.avgpool(_dense(g), out_fp32=True)
+        return s * float(ctx.hw[0] * ctx.hw[1]), None, None, None
+
+
+class _LinearSmallFn(torch.autograd.Function):
+    """The pooling branch's 1x1 convolution on one vector per image, fp32 with the master weights (afan_linear_small_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, want_pgrad):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.pg = want_pgrad
+        return ops.linear_small(x, weight.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        want_p = ctx.pg and ctx.needs_input_grad[1]
+        dw, direct = None, False
+        if want_p:
+            direct = _accumulates_in_place(weight)
+            dw = weight.grad if direct else torch.empty_like(weight, memory_format=torch.contiguous_format)
+        dx = ops.linear_small_backward(g, x, weight.detach(), ctx.needs_input_grad[0], dw, accumulate=direct)
+        return dx, (None if direct else dw), None
 
 
 class _MaxPoolFn(torch.autograd.Function):
@@ -90,15 +112,17 @@ def _match(g, ref):
 
 
 class _AvgPoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) with an fp32 result (see afan_linear_small_fwd for why the pooled side is fp32)."""
+
     @staticmethod
     def forward(ctx, x):
         x = _dense(x)
         ctx.like = x
-        return ops.avgpool(x)
+        return ops.avgpool(x, out_fp32=True)
 
     @staticmethod
     def backward(ctx, g):
-        return ops.avgpool_backward(g.contiguous(), ctx.like)
+        return ops.avgpool_backward(g.float().contiguous(), ctx.like)
 
 
 class _PointwiseFn(torch.autograd.Function):
@@ -227,6 +251,10 @@ class StemConv(Conv2d):
 
 class ClassifierConv(Conv2d):
     """_deeplab.py:45: nn.Conv2d(256, num_classes, 1) — with bias, fp32 logits."""
+
+    @property
+    def own_kernel(self):       # resnet_s.vendor_convs: the pointwise kernel takes it on channels-last maps
+        return self.in_channels % 8 == 0 and self.out_channels <= 32 and self.in_channels * self.out_channels * 4 <= 64 * 1024
 
     def forward(self, x):
         x = _to_compute(x, self.compute_dtype)
@@ -394,8 +422,14 @@ class ASPPPooling(nn.Sequential):
             y = nn.functional.relu(self[2](self[1](self[0](x))))
             return nn.functional.interpolate(y, size=size, mode="bilinear", align_corners=False)
         cl = ops.layout_of(x) == ops.AFAN_NHWC
-        y = _cbr(self[1], self[2], _AvgPoolFn.apply(x))
-        return _BroadcastFn.apply(y, size, cl)
+        p = _AvgPoolFn.apply(x)                                      # fp32 [N, C, 1, 1]
+        n, conv, bn = p.shape[0], self[1], self[2]
+        if ops.linear_small_ok(p, conv.weight):
+            y = _LinearSmallFn.apply(p.reshape(n, -1), conv.weight, _Flags.param_grads).reshape(n, conv.out_channels, 1, 1)
+            y = bn.fused(y, None, True)                              # BatchNorm over the N images, in fp32
+        else:
+            y = _cbr(conv, bn, p.to(x.dtype))
+        return _BroadcastFn.apply(y, size, cl, x.dtype)
 
 
 class ASPP(nn.Module):

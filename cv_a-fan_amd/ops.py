@@ -43,9 +43,14 @@ def layout_of(t):
     return AFAN_NCHW
 
 
+def _strides_eq(a, b):
+    """Same memory order: strides of size-1 dimensions carry no information (a [N,C,1,1] tensor is both layouts)."""
+    return all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 def _same_layout(ref, *others):
     for o in others:
-        if o is not None and ref.numel() > 0 and (o.shape != ref.shape or o.stride() != ref.stride()):
+        if o is not None and ref.numel() > 0 and (o.shape != ref.shape or not _strides_eq(o, ref)):
             raise ValueError("operands must share shape and memory layout (strides): "
                              f"{tuple(ref.shape)}/{ref.stride()} vs {tuple(o.shape)}/{o.stride()}")
 
@@ -787,23 +792,53 @@ def maxpool3x3s2_backward(dy, x):
     return dx
 
 
-def avgpool(x):
-    """nn.AdaptiveAvgPool2d(1): [N,C,H,W] -> [N,C,1,1] (same dtype, fp32 accumulate)."""
+def avgpool(x, out_fp32=False):
+    """nn.AdaptiveAvgPool2d(1): [N,C,H,W] -> [N,C,1,1] (x's dtype, or fp32 with out_fp32; fp32 accumulate)."""
     lib = _lib.load()
     _need(x, "x")
     n, c, hw = _nchw(x)
-    y = torch.empty((n, c, 1, 1), dtype=x.dtype, device=x.device)
-    check(lib.afan_avgpool_fwd(_ptr(x), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, _stream(x)), "afan_avgpool_fwd")
-    return y.contiguous(memory_format=torch.channels_last) if layout_of(x) == AFAN_NHWC else y
+    y = torch.empty((n, c, 1, 1), dtype=torch.float32 if out_fp32 else x.dtype, device=x.device)
+    check(lib.afan_avgpool_fwd(_ptr(x), _ptr(y), _DT[x.dtype], layout_of(x), n, c, hw, int(bool(out_fp32)), _stream(x)),
+          "afan_avgpool_fwd")
+    return y
 
 
 def avgpool_backward(dy, like):
+    """dx (like's shape / dtype / layout) = dy / HW broadcast; dy [N,C,1,1] in like's dtype or fp32."""
     lib = _lib.load()
-    _need(dy, "dy", like.dtype)
+    f32 = dy.dtype == torch.float32
+    _need(dy, "dy", None if f32 else like.dtype)
     n, c, hw = _nchw(like)
     dx = torch.empty_like(like)
     check(lib.afan_avgpool_bwd(_ptr(dy.reshape(n, c).contiguous()), _ptr(dx), _DT[like.dtype], layout_of(like), n, c, hw,
-                               _stream(like)), "afan_avgpool_bwd")
+                               int(f32), _stream(like)), "afan_avgpool_bwd")
+    return dx
+
+
+def linear_small_ok(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.shape[0] <= _lib.load().afan_linear_small_max_rows() and x.shape[0] * weight.shape[0] * 4 <= 64 * 1024)
+
+
+def linear_small(x, weight):
+    """y[n,co] = sum_ci x[n,ci] * w[co,ci] in fp32 for a handful of rows (the ASPP pooling branch's 1x1 convolution)."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32), _need(weight, "weight", torch.float32)
+    n, ci = x.shape[0], x.numel() // x.shape[0]
+    co = weight.shape[0]
+    y = torch.empty((n, co), dtype=torch.float32, device=x.device)
+    check(lib.afan_linear_small_fwd(_ptr(x), _ptr(weight), _ptr(y), n, ci, co, _stream(x)), "afan_linear_small_fwd")
+    return y
+
+
+def linear_small_backward(dy, x, weight, want_dx, dweight=None, accumulate=False):
+    lib = _lib.load()
+    _need(dy, "dy", torch.float32)
+    n, ci = x.shape[0], x.numel() // x.shape[0]
+    co = weight.shape[0]
+    dx = torch.empty((n, ci), dtype=torch.float32, device=x.device) if want_dx else None
+    check(lib.afan_linear_small_bwd(_ptr(dy.contiguous()), _ptr(x), _ptr(weight), _ptr(dx), _ptr(dweight), n, ci, co,
+                                    int(bool(accumulate)), _stream(x)), "afan_linear_small_bwd")
     return dx
 
 

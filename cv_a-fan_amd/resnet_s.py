@@ -279,7 +279,7 @@ def vendor_convs(model):
     measured reading memory the graph does not own (tools/diag_graph_piece.py; NaNs after the first validation pass)."""
     bad = []
     for name, m in model.named_modules():
-        if isinstance(m, Conv2d) and m.in_channels > 4:       # (the stem decides by image width at run time)
+        if isinstance(m, Conv2d) and m.in_channels > 4 and not getattr(m, "own_kernel", False):   # (the stem decides by image width at run time)
             if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding, m.dilation):
                 bad.append(name)
     return bad

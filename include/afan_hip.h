@@ -316,9 +316,20 @@ int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t
                           afan_stream_t stream);
 int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi,
                           int64_t wi, afan_stream_t stream);
-/* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast. */
-int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream);
-int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hw, afan_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast.
+ * pooled_f32 != 0: the pooled side (y / dy) is fp32 whatever `dtype` the map has. */
+int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,
+                     afan_stream_t stream);
+int afan_avgpool_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,
+                     afan_stream_t stream);
+/* The 1x1 convolution of the ASPP pooling branch (_deeplab.py:155: one 2048-vector per image) as an fp32 linear layer on
+ * n <= afan_linear_small_max_rows() rows with the fp32 master weights: y[n,co] = sum_ci x[n,ci]*w[co,ci].  That branch's
+ * BatchNorm normalises over the n images only; bf16 storage of the pooled vectors rounds their differences away.
+ * bwd: dx (nullable) [n,ci], dw (nullable) [co,ci] written or added into. */
+int afan_linear_small_max_rows(void);
+int afan_linear_small_fwd(const float* x, const float* w, float* y, int64_t n, int64_t ci, int64_t co, afan_stream_t stream);
+int afan_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int64_t n, int64_t ci,
+                          int64_t co, int accumulate, afan_stream_t stream);
 /* 1x1 convolution WITH bias to a few output channels and fp32 logits — the classifier nn.Conv2d(256, num_classes, 1) of
  * _deeplab.py:45 on channels-last pixels: y[m,co] = b[co] + sum_ci x[m,ci]*w[co,ci]; x `x_dtype` [m,ci] (ci % 8 == 0),
  * w fp32 [co,ci], co <= afan_pointwise_max_co().  dx[m,ci] = dy[m,:] @ w; dw[co,ci] (+)= sum_m dy[m,co]*x[m,ci],

@@ -111,7 +111,7 @@ def test_segmentation_step_matches_reference_functions(orc, case):
         orc.seg_decoder_PGD(d, images, crit, y=labels, model=net, steps=1, eps=2 / 255, gamma=0.5 / 255, idx="aspp", clip=True)
 
 
-@pytest.mark.parametrize("case", ["seg_dl101_aspp_k1", "seg_dl101_concat_k3"])
+@pytest.mark.parametrize("case", ["seg_dl101_aspp_k1", "seg_dl101_concat_k3", "seg_dl101_aspp_k3_damped"])
 def test_deeplab_step_matches_reference_network(orc, case):
     """oracle.SegDeepLabV3Plus (ResNet-101, output stride 16) + oracle.seg_train_step against the reference's OWN network
     (Segmentation/network/, imported by oracle/gen_golden.py) driven through main_aug_final.py:158-232 — bit for bit:
@@ -122,6 +122,11 @@ def test_deeplab_step_matches_reference_network(orc, case):
     torch.manual_seed(int(g["seed"]))
     net = orc.deeplabv3plus_resnet101(num_classes=21, output_stride=16)
     net.classifier.aspp.project[3].p = 0.0                      # as in the golden run (dropout masks cannot be matched)
+    if float(g["damp"]) != 1.0:                                 # weights are data: the damped (contractive) variant
+        for m in net.backbone.modules():
+            if isinstance(m, orc.SegBottleneck):
+                m.bn3.weight.data.mul_(float(g["damp"]))
+    assert [n for n, _ in net.named_parameters()] == [str(k) for k in g["param_names"]]
     assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
     np.testing.assert_array_equal(_checks(net), g["ck0"])
     opt = orc.seg_make_optimizer(net, lr=float(g["lr"]), weight_decay=1e-4)
@@ -142,6 +147,10 @@ def test_deeplab_step_matches_reference_network(orc, case):
     for k in g.files:
         if k.startswith("sd1/"):
             np.testing.assert_array_equal(sd[k[4:]].numpy(), g[k], err_msg=k)
+    params = dict(net.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            np.testing.assert_array_equal(params[k[5:]].grad.numpy(), g[k], err_msg=k)
 
 
 def test_poly_lr_schedule(orc):

@@ -24,7 +24,8 @@ def test_upsample_bilinear_fp32(pkg, gpu, shape, size, nhwc):
     ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
     got = pkg.ops.upsample_bilinear(_fmt(x.to(gpu), nhwc), size)
     assert got.shape == ref.shape
-    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    # (the interpolation weight is src - floor(src) with src up to ~hi: one ulp of src is ~1e-5 of a weight at 129 -> 513)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6 + 4e-7 * max(shape[2], shape[3]))
     # backward: the adjoint of the same linear map
     g = torch.randn(ref.shape)
     xr = x.clone().requires_grad_(True)
@@ -102,10 +103,35 @@ def test_avgpool(pkg, gpu, dtype, nhwc):
     y = pkg.ops.avgpool(_fmt(x.to(gpu), nhwc))
     ref = x.float().mean(dim=(2, 3), keepdim=True)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), rtol=1e-5 if dtype == torch.float32 else 8e-3, atol=1e-6 if dtype == torch.float32 else 4e-3)
+    y32 = pkg.ops.avgpool(_fmt(x.to(gpu), nhwc), out_fp32=True)          # fp32 pooled side whatever the map's dtype
+    assert y32.dtype == torch.float32
+    np.testing.assert_allclose(y32.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     g = torch.randn(2, 2048, 1, 1).to(dtype)
     dx = pkg.ops.avgpool_backward(g.to(gpu), _fmt(x.to(gpu), nhwc))
     np.testing.assert_allclose(dx.float().cpu().numpy(), (g.float() / 81).expand(2, 2048, 9, 9).numpy(),
                                rtol=1e-6 if dtype == torch.float32 else 8e-3, atol=1e-7)
+    dx32 = pkg.ops.avgpool_backward(g.float().to(gpu), _fmt(x.to(gpu), nhwc))
+    assert dx32.dtype == dtype
+    np.testing.assert_allclose(dx32.float().cpu().numpy(), (g.float() / 81).expand(2, 2048, 9, 9).numpy(),
+                               rtol=1e-6 if dtype == torch.float32 else 8e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,ci,co", [(2, 2048, 256), (1, 64, 8), (16, 320, 256)])
+def test_linear_small(pkg, gpu, n, ci, co):
+    torch.manual_seed(12)
+    x, w = torch.randn(n, ci), torch.randn(co, ci, 1, 1) * 0.05
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.linear(xr, wr.reshape(co, ci))
+    g = torch.randn(n, co)
+    ref.backward(g)
+    y = pkg.ops.linear_small(x.to(gpu), w.to(gpu))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+    dw = torch.zeros(co, ci, 1, 1, device=gpu)
+    dx = pkg.ops.linear_small_backward(g.to(gpu), x.to(gpu), w.to(gpu), True, dw)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=1e-5)
+    pkg.ops.linear_small_backward(g.to(gpu), x.to(gpu), w.to(gpu), False, dw, accumulate=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), 2 * wr.grad.numpy(), rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
