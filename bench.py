@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — images/sec of the A-FAN train step (BASELINE.json metric) on N MI355X of one node.
 
-Workload (configs[1]): ResNet-18 (CIFAR stem), A-FAN K=5 at the end of stage 1 (perturb_idx 6: 64x32x32
+Default workload (configs[1]): ResNet-18 (CIFAR stem), A-FAN K=5 at the end of stage 1 (perturb_idx 6: 64x32x32
 feature map), bf16 backbone, batch 256 PER GPU (weak scaling), synthetic 3x32x32 inputs in [0,1),
 gamma 0.5/255, eps 2/255, no clip / no randinit (= cmd/run_perturb.sh flags), SGD(0.1, 0.9, 5e-4).
 A "step" is one full iteration of main_perturb.py:165-201: head fwd -> 5 x (tail fwd, CE, dgrad, sign
@@ -11,13 +11,25 @@ step) -> norms -> adv tail fwd + clean full fwd -> joint loss -> backward -> [al
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant hand-written kernel, achieved algorithmic GB/s vs the 8 TB/s HBM peak, timed
-                 per launch with HIP events on the launch stream in a separate instrumented pass (not in `value`);
-  cpu_baseline — the CPU oracle (oracle/afan_oracle.py, bit-identical to the reference's Python on CPU) timed on
-                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+Second workload (configs[3], the Segmentation A-FAN iteration of main_aug_final.py:149-232 on DeepLabv3+ / ResNet-101,
+output stride 16, 3x513x513 inputs, 21 classes with ~5 % ignore labels, K=3 SE + SD feature PGD, mix_feature, four
+forwards, two-group SGD + PolyLR):
+
+  python bench.py --arch deeplabv3plus_resnet101 --batch 2 --pgd_steps 3 --steps 10 --warmup 4
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     — the dominant hand-written kernel by time: achieved algorithmic FLOP/s (MFMA-bound) or GB/s (HBM-bound),
+                 timed per launch with HIP events on the launch stream in a separate instrumented pass (not in `value`);
+                 `traffic` = HBM bytes per launch from the newest committed rocprofv3 --pmc summary that names the kernel,
+                 flagged `traffic_stale` when the kernel sources changed since that summary was taken;
+  conv_mfma    — EXECUTED convolution FLOPs per step (summed over the launches of the instrumented pass) / step time;
+  hbm_kernels  — the A-FAN element-wise kernels (PGD step, mix_feature, lerp, ...) as fractions of the 8 TB/s HBM peak;
+  cpu_baseline — the CPU oracle (oracle/afan_oracle.py, bit-identical to the reference's Python on CPU) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -30,9 +42,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 BF16_DENSE_PEAK_TFLOPS = 2500.0
-GFLOP_PER_IMAGE = {"resnet18": 14.1, "resnet20s": None, "resnet56s": 2.99}   # 4H + (2K+6)T at K=5
-GFLOP_PER_IMAGE_K3 = {"resnet50": 85.5}                                       # K=3, 224^2, perturb after layer1
+# reference-schedule convolution / linear FLOPs per image (4H + (2K+6)T), for the secondary figure only
+REF_GFLOP_PER_IMAGE = {("resnet18", 5): 14.1, ("resnet56s", 5): 2.99, ("resnet50", 3): 85.5}
 ARCH_INPUT = {"resnet50": (224, 1000)}                                        # (image side, classes); default (32, 10)
+SEG_ARCHS = ("deeplabv3plus_resnet101", "deeplabv3plus_resnet50")
+HBM_KERNELS = ("pgd_step_kernel", "pgd_step_norms_kernel", "mix_feature_nhwc_kernel", "mix_feature_kernel", "lerp_points_kernel",
+               "sgd_kernel", "cast_bf16_kernel", "upsample_bilinear_fwd_kernel", "upsample_bilinear_bwd_kernel", "ce2d_kernel",
+               "maxpool_fwd_kernel", "maxpool_bwd_kernel", "bn_nhwc_apply_kernel", "bn_nhwc_bwd_apply_kernel")
 
 
 def parse():
@@ -41,8 +57,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--arch", default="resnet18")
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--pgd_steps", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256; 2 for the DeepLab workload)")
+    ap.add_argument("--pgd_steps", type=int, default=None, help="K (default 5; 3 for the DeepLab workload)")
+    ap.add_argument("--side", type=int, default=None, help="image side of the DeepLab workload (default 513)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"], help="internal activation layout")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
@@ -53,8 +70,18 @@ def parse():
     ap.add_argument("--no_share_head", action="store_true", help="run the head twice per step like the reference's text (A/B)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
-    ap.add_argument("--cpu_steps", type=int, default=2)
+    ap.add_argument("--cpu_steps", type=int, default=None, help="timed CPU-oracle steps (default 3; 1 for the DeepLab workload)")
     return ap.parse_args()
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(arch, batch, pgd_steps, idx, timed_steps):
@@ -72,14 +99,75 @@ def cpu_baseline(arch, batch, pgd_steps, idx, timed_steps):
     x, y = torch.rand(batch, 3, side, side), torch.randint(0, ncls, (batch,))
     kw = dict(steps=pgd_steps, gamma=0.5, eps=2.0, perturb_idx=idx, layer_number=ln)
     orc.afan_train_step(model, opt, crit, x[:16], y[:16], **kw)      # thread-pool / allocator warm-up (small)
-    t0 = time.perf_counter()
+    per = []
     for _ in range(timed_steps):
+        t0 = time.perf_counter()
         orc.afan_train_step(model, opt, crit, x, y, **kw)
-    dt = time.perf_counter() - t0
+        per.append(time.perf_counter() - t0)
+    dt = sum(per)
     return {"value": round(batch * timed_steps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "cpu": cpu_model(),
             "sample": f"{timed_steps} full steps of the same workload (batch {batch}, K={pgd_steps}, fp32) after one "
-                      f"batch-16 warm-up step; {dt / timed_steps * 1e3:.0f} ms/step; host {os.cpu_count()} logical CPUs"}
+                      f"batch-16 warm-up step; per step {[round(p, 2) for p in per]} s; host {os.cpu_count()} logical CPUs"}
+
+
+def cpu_baseline_seg(arch, batch, pgd_steps, side, timed_steps):
+    """The oracle's Segmentation iteration (oracle.seg_train_step on oracle.SegDeepLabV3Plus) on the host cores."""
+    import torch
+    import torch.nn as nn
+    from oracle import afan_oracle as orc
+    torch.manual_seed(3)
+    model = orc.deeplabv3plus_resnet101(21, 16) if arch.endswith("101") else orc.deeplabv3plus_resnet50(21, 16)
+    opt = orc.seg_make_optimizer(model, lr=0.01)
+    model.train()
+    crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+    x, y = synth_seg(batch, side, torch.Generator().manual_seed(3))
+    kw = dict(steps=pgd_steps, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True)
+    orc.seg_train_step(model, opt, crit, x[:1, :, :129, :129].contiguous(), y[:1, :129, :129].contiguous(), **kw)   # warm-up (small)
+    per = []
+    for _ in range(timed_steps):
+        t0 = time.perf_counter()
+        orc.seg_train_step(model, opt, crit, x, y, **kw)
+        per.append(time.perf_counter() - t0)
+    dt = sum(per)
+    return {"value": round(batch * timed_steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "cpu": cpu_model(),
+            "sample": f"{timed_steps} full iteration(s) of the same workload (batch {batch}, {side}x{side}, K={pgd_steps}, fp32) "
+                      f"after one 1x129x129 warm-up; per step {[round(p, 1) for p in per]} s; host {os.cpu_count()} logical CPUs"}
+
+
+def synth_seg(batch, side, g):
+    """rand(N,3,S,S) images, labels randint(0,21) with ~5 % set to 255 (ignore)."""
+    import torch
+    x = torch.rand(batch, 3, side, side, generator=g)
+    y = torch.randint(0, 21, (batch, side, side), generator=g)
+    y[torch.rand(batch, side, side, generator=g) < 0.05] = 255
+    return x, y
+
+
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes: the guide's gfx950 correction) of `kernel_name` from the
+    newest profiles/*_pmc_hbm_traffic*.json that has it; (bytes, source file, stale?) or None."""
+    base = kernel_name.replace("_fwd_kernel", "_kernel").replace("_dgrad_kernel", "_kernel")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        key = next((k for k in pmc if not k.startswith("_") and (k == kernel_name or k == base or k in kernel_name)), None)
+        if key and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
+            meta = pmc.get("_meta", {})
+            stale = meta.get("kernel_sources_sha") != kernel_sources_sha()
+            return (round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024),
+                    os.path.relpath(f, ROOT), stale, meta.get("command"))
+    return None
 
 
 def main():
@@ -88,6 +176,15 @@ def main():
     import torch.distributed as dist
     import torch.nn as nn
     pkg = importlib.import_module("cv_a-fan_amd")
+    seg = args.arch in SEG_ARCHS
+    if args.batch is None:
+        args.batch = 2 if seg else 256
+    if args.pgd_steps is None:
+        args.pgd_steps = 3 if seg else 5
+    if args.side is None:
+        args.side = 513
+    if args.cpu_steps is None:
+        args.cpu_steps = 1 if seg else 3
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,20 +201,50 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if seg and world > 1:
+        raise SystemExit("the DeepLab workload is benched per GPU (replicas only in this build; see DESIGN.md §7)")
 
-    ctor, idx = pkg.resnet_s.ARCHS[args.arch]
-    torch.manual_seed(3)                      # same initial weights on every rank (reference --seed 3)
-    model = ctor()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
-    trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
-                                         perturb_idx=idx, lr=0.1, use_graph=not args.no_graph, batch_final=not args.no_batch_final, share_head=not args.no_share_head, fold_clean=(False if args.no_fold_clean else (True if args.force_fold_clean else None)),
-                                         async_wgrad=args.async_wgrad)
+    torch.manual_seed(3)                      # same initial weights on every rank (reference --seed 3)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4
-    side, ncls = ARCH_INPUT.get(args.arch, (32, 10))
-    xs = [torch.rand(args.batch, 3, side, side, generator=g).to(dev) for _ in range(nbuf)]
-    ys = [torch.randint(0, ncls, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]
+    idx = None
+    if seg:
+        model = pkg.deeplab.MODELS[args.arch](num_classes=21, output_stride=16)
+        model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
+        trainer = pkg.seg_trainer.SegTrainer(model, nn.CrossEntropyLoss(ignore_index=255, reduction="mean"), steps=args.pgd_steps,
+                                             eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp",
+                                             mix_layer="11", mix_sd=True, lr=0.01, use_graph=not args.no_graph)
+        side, ncls = args.side, 21
+        data = [synth_seg(args.batch, side, g) for _ in range(nbuf)]
+        xs, ys = [d[0].to(dev) for d in data], [d[1].to(dev) for d in data]
+
+        def one(i):
+            r = trainer.step(xs[i % nbuf], ys[i % nbuf])
+            trainer.scheduler.step()               # main_aug_final.py:261: PolyLR once per iteration
+            return r
+
+        def one_eager(i):
+            trainer.optimizer._sync_lr()
+            return trainer._body(xs[i % nbuf], ys[i % nbuf])
+    else:
+        ctor, idx = pkg.resnet_s.ARCHS[args.arch]
+        model = ctor()
+        model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
+        trainer = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0,
+                                             perturb_idx=idx, lr=0.1, use_graph=not args.no_graph,
+                                             batch_final=not args.no_batch_final, share_head=not args.no_share_head,
+                                             fold_clean=(False if args.no_fold_clean else (True if args.force_fold_clean else None)),
+                                             async_wgrad=args.async_wgrad)
+        side, ncls = ARCH_INPUT.get(args.arch, (32, 10))
+        xs = [torch.rand(args.batch, 3, side, side, generator=g).to(dev) for _ in range(nbuf)]
+        ys = [torch.randint(0, ncls, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]
+
+        def one(i):
+            return trainer.step(xs[i % nbuf], ys[i % nbuf])
+
+        def one_eager(i):
+            return trainer._step_eager(xs[i % nbuf], ys[i % nbuf])
 
     def sync():
         if world > 1:
@@ -125,11 +252,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        r = trainer.step(xs[i % nbuf], ys[i % nbuf])
+        r = one(i)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        r = trainer.step(xs[i % nbuf], ys[i % nbuf])
+        r = one(i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -138,24 +265,27 @@ def main():
         dt = float(t.item())
     loss = float(r["loss"])
     assert loss == loss, "loss is NaN"
+    step_ms = dt / args.steps * 1e3
 
     # ---- instrumented pass (not part of `value`): per-launch HIP-event timing of the hand-written kernels ----
-    roof, kernels = None, None
+    roof, kernels, conv_exec, hbm = None, None, None, None
     graphed = trainer._graph is not None
+    NP = 2
     if not args.no_roofline:
         # per-launch event timing needs eager launches: the same step body, un-captured.  EVERY rank runs it (the step
         # contains the gradient all-reduce); only rank 0 records.
         if rank == 0:
             pkg.ops.profile_enable(True)
-        for i in range(2):
-            trainer._step_eager(xs[i % nbuf], ys[i % nbuf])
+        for i in range(NP):
+            one_eager(i)
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         prof = pkg.ops.profile_collect()
         pkg.ops.profile_enable(False)
+
         def _k(v):
-            d = {"launches_per_step": v["launches"] // 2, "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                 "ms_per_step": round(v["ms"] / 2, 3)}
+            d = {"launches_per_step": v["launches"] // NP, "avg_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                 "ms_per_step": round(v["ms"] / NP, 3)}
             if v["flops"] > 0:
                 d["algo_TFLOPs"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)
             else:
@@ -163,7 +293,7 @@ def main():
             return d
         kernels = {k: _k(v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        hand_ms = round(sum(q["ms"] for q in prof.values()) / 2, 3)
+        hand_ms = round(sum(q["ms"] for q in prof.values()) / NP, 3)
         if v["flops"] > 0:      # MFMA-bound kernel: algorithmic FLOPs / measured launch time vs the dense bf16 peak
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
@@ -177,54 +307,78 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                     "algo_bytes_per_launch": round(v["bytes"] / v["launches"]), "handwritten_ms_per_step": hand_ms}
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the committed summary
-        # of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command supplies it (per launch)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01q_pmc_hbm_traffic.json")))
-            key = next((k for k in pmc if k in name or name.replace("_fwd", "").replace("_dgrad", "") .startswith(k.split("_kernel")[0])), None)
-            if key:
-                roof["traffic"] = round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024)
-                roof["traffic_source"] = "profiles/r01q_pmc_hbm_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch)"
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the newest committed
+        # summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes supplies it (per launch)
+        tr = pmc_traffic(name)
+        if tr is not None:
+            roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = tr[0], tr[1], tr[2]
+            roof["traffic_note"] = ("rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch; stale = the kernel sources changed "
+                                    "since that summary was taken" + (f"; measured on: {tr[3]}" if tr[3] else ""))
+        # executed convolution FLOPs of one step: every conv launch records its own 2*M*N*K
+        cf = sum(q["flops"] for k, q in prof.items() if k.startswith("conv_")) / NP
+        conv_ms = sum(q["ms"] for k, q in prof.items() if k.startswith("conv_")) / NP
+        if cf > 0:
+            tf = cf / (step_ms * 1e-3) / 1e12
+            conv_exec = {"executed_GFLOP_per_step": round(cf / 1e9, 1), "achieved_TFLOPs": round(tf, 1),
+                         "peak_TFLOPs": BF16_DENSE_PEAK_TFLOPS, "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
+                         "conv_kernel_ms_per_step_eager": round(conv_ms, 3),
+                         "in_kernel_TFLOPs": round(cf / (conv_ms * 1e-3) / 1e12, 1) if conv_ms > 0 else None,
+                         "note": "FLOPs of the convolution launches the step EXECUTES (summed over the instrumented pass), "
+                                 "divided by the timed step; in_kernel = the same FLOPs over the summed conv kernel time"}
+        hbm = {}
+        for k in HBM_KERNELS:
+            if k in prof and prof[k]["ms"] > 0 and prof[k]["bytes"] > 0:
+                gbs = prof[k]["bytes"] / (prof[k]["ms"] * 1e-3) / 1e9
+                hbm[k] = {"achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+                          "algo_bytes_per_launch": round(prof[k]["bytes"] / prof[k]["launches"]),
+                          "avg_us": round(prof[k]["ms"] * 1e3 / prof[k]["launches"], 2)}
     if world > 1:
         dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.arch, args.batch, args.pgd_steps, idx, args.cpu_steps)
+        cpu = (cpu_baseline_seg(args.arch, args.batch, args.pgd_steps, side, args.cpu_steps) if seg
+               else cpu_baseline(args.arch, args.batch, args.pgd_steps, idx, args.cpu_steps))
 
     if rank == 0:
         ips = args.batch * world * args.steps / dt
-        gf = GFLOP_PER_IMAGE.get(args.arch) if args.pgd_steps == 5 else None
-        if gf is None and args.pgd_steps == 3:
-            gf = GFLOP_PER_IMAGE_K3.get(args.arch)
         default_cfg = args.arch == "resnet18" and args.pgd_steps == 5
+        if seg:
+            metric = f"images/sec (whole node) Segmentation A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}"
+            workload = (f"{args.arch} output-stride 16, VOC-shape {side}x{side} synthetic, SE (layer3) + SD (aspp) feature PGD K="
+                        f"{args.pgd_steps}, mix_feature 11 + mix_sd, {args.dtype}, batch {args.batch}/GPU, internal layout "
+                        f"{args.layout} (BASELINE configs[3], per-GPU share)")
+            sched = ("main_aug_final.py:158-232 as written: head pass + clean decoder-head pass, K SE + K SD PGD passes, "
+                     "clean / SE1 / SE2 / SD forwards, one joint backward")
+        else:
+            metric = ("images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10" if default_cfg else
+                      f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}")
+            workload = (f"{args.arch} {'CIFAR-10' if side == 32 else 'ImageNet'}-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
+                        f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
+                        f"(BASELINE configs[1])")
+            # which passes one iteration runs: the reference's text is 2 head passes + K PGD
+            # passes + adversarial and clean final passes; value-identical passes are run once
+            sched = (("1 head pass (stands for the reference's 2), " if trainer._share_head(xs[0]) else "2 head passes, ")
+                     + (f"1 clean tail pass (= PGD step 0 and the final clean pass) + {args.pgd_steps - 1} PGD passes + "
+                        "adversarial pass" if trainer._fold_ok(xs[0]) else
+                        f"{args.pgd_steps} PGD passes + adversarial and clean final passes"
+                        + (" (one grouped pass)" if getattr(trainer, "_groupable", False) else "")))
         line = {
-            "metric": "images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10" if default_cfg else
-                      f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}",
-            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "metric": metric, "value": round(ips, 2 if seg else 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.arch} {'CIFAR-10' if side == 32 else 'ImageNet'}-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
-                                   f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
-                                   f"(BASELINE configs[1])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(loss, 4),
-                       "hipgraph": graphed,
-                       # which passes one iteration runs: the reference's text is 2 head passes + K PGD
-                       # passes + adversarial and clean final passes; value-identical passes are run once
-                       "schedule": ("1 head pass (stands for the reference's 2), " if trainer._share_head(xs[0]) else "2 head passes, ")
-                                   + (f"1 clean tail pass (= PGD step 0 and the final clean pass) + {args.pgd_steps - 1} PGD passes + "
-                                      "adversarial pass" if trainer._fold_ok(xs[0]) else
-                                      f"{args.pgd_steps} PGD passes + adversarial and clean final passes"
-                                      + (" (one grouped pass)" if getattr(trainer, "_groupable", False) else ""))},
+            "config": {"workload": workload, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "final_loss": round(loss, 4), "hipgraph": graphed, "schedule": sched},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if gf is not None:
-            tf = gf * 1e9 * ips / 1e12
-            line["conv_mfma"] = {"achieved_TFLOPs": round(tf, 1), "peak_TFLOPs": BF16_DENSE_PEAK_TFLOPS,
-                                 "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
-                                 "note": "algorithmic conv/linear FLOPs (4H+(2K+6)T, BASELINE.md §4) / step time"}
+        if conv_exec is not None:
+            gf = REF_GFLOP_PER_IMAGE.get((args.arch, args.pgd_steps))
+            if gf is not None:      # secondary: what the same img/s would mean at the reference schedule's FLOP count
+                conv_exec["reference_schedule_GFLOP_per_image"] = gf
+                conv_exec["reference_schedule_equiv_TFLOPs"] = round(gf * 1e9 * ips / 1e12, 1)
+            line["conv_mfma"] = conv_exec
+        if hbm:
+            line["hbm_kernels"] = hbm
         if cpu is not None:
             line["speedup_vs_cpu"] = round(ips / cpu["value"], 1)
         if kernels is not None:

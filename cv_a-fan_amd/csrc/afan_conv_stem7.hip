@@ -114,6 +114,38 @@ __global__ __launch_bounds__(BLOCK) void stem7_wgrad_reduce_kernel(const float* 
     *dst = accumulate ? *dst + s : s;
 }
 
+// ---- im2col of the stem: cols[m][k], m = (n, oy, ox), k = (r, s, c) in the weights' KRSC order, K = 147 padded to KP = 152 ----
+// With it the stem's forward and weight gradient are plain 1x1 problems for the MFMA kernels (reduction 152 channels,
+// ragged last chunk masked): 0.04 GB written once per pass and read twice against ~0.7 ms of LDS-bound FMAs before.
+constexpr int KP = 152;
+__global__ __launch_bounds__(BLOCK) void stem7_im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ cols,
+                                                             int Hi, int Wi, int Ho, int Wo) {
+    __shared__ uint16_t xl[KK * ROWP];
+    const int n = blockIdx.z, oy = blockIdx.y, ox0 = blockIdx.x * SEG;
+    const int ix0 = 2 * ox0 - 3;
+    for (int i = threadIdx.x; i < KK * PATCH; i += BLOCK) {
+        const int r = i / PATCH, e = i - r * PATCH;
+        const int iy = 2 * oy - 3 + r, col = ix0 + e / 3;
+        uint16_t v = 0;
+        if (iy >= 0 && iy < Hi && col >= 0 && col < Wi) v = x[(((int64_t)n * Hi + iy) * Wi + ix0) * 3 + e];
+        xl[r * ROWP + e] = v;
+    }
+    __syncthreads();
+    constexpr int PIECES = KP / 8;     // 19 16-byte pieces per output row
+    for (int i = threadIdx.x; i < SEG * PIECES; i += BLOCK) {
+        const int px = i / PIECES, pc = i - px * PIECES;
+        if (ox0 + px >= Wo) continue;
+        u16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = pc * 8 + e;
+            const int r = k / 21, j = k - r * 21;
+            v[e] = k < K ? xl[r * ROWP + px * 6 + j] : (uint16_t)0;
+        }
+        *reinterpret_cast<u16x8*>(cols + ((((int64_t)n * Ho + oy) * Wo + ox0 + px) * KP + pc * 8)) = v;
+    }
+}
+
 int wgrad_blocks(int64_t tiles) { return (int)(tiles < 512 ? tiles : 512); }
 
 }  // namespace
@@ -141,6 +173,25 @@ int afan_conv_stem7_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t
     AFAN_PROF_FLOPS("conv_stem7_fwd_kernel", 2.0 * (M * CO + (double)n * hi * wi * 3), 2.0 * M * CO * K, st);
     dim3 grid((unsigned)((wo + SEG - 1) / SEG), (unsigned)ho, (unsigned)n);
     stem7_fwd_kernel<<<grid, BLOCK, lds, st>>>((const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (int)hi, (int)wi, (int)ho, (int)wo);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// cols[N*Ho*Wo][152] (bf16) = im2col of x[N,Hi,Wi,3] for the 7x7 / 2 / pad 3 stem: column k = (r*7 + s)*3 + c for k < 147
+// (the weights' KRSC order), zero for k >= 147.  The stem's forward and weight gradient then run as 1x1 problems on
+// afan_conv_fwd_nhwc_bf16 / afan_conv_wgrad_nhwc_bf16 with ci = 152.
+int afan_conv_stem7_im2col_k(void) { return KP; }
+
+int afan_conv_stem7_im2col(const void* x, void* cols, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || n > 65535) return AFAN_ESHAPE;
+    if (!x || !cols) return AFAN_ENULL;
+    if (!aligned(x, 2) || !aligned(cols, 16)) return AFAN_EALIGN;
+    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    if (ho > 65535) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("stem7_im2col_kernel", 2.0 * ((double)n * hi * wi * 3 + (double)n * ho * wo * KP), st);
+    dim3 grid((unsigned)((wo + SEG - 1) / SEG), (unsigned)ho, (unsigned)n);
+    stem7_im2col_kernel<<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)cols, (int)hi, (int)wi, (int)ho, (int)wo);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void mix_feature_nhwc_kernel(const T* __rest
 template <typename T>
 int mix_nhwc_impl(const void* clean, const void* adv, void* out, int64_t pixels, int64_t c, float eps, hipStream_t st) {
     const int grid = grid_for(pixels * AFAN_WAVE, BLOCK, 8192);
-    AFAN_PROF("mix_feature_kernel", 3.0 * sizeof(T) * pixels * c, st);
+    AFAN_PROF("mix_feature_nhwc_kernel", 3.0 * sizeof(T) * pixels * c, st);
     if (c <= 64 * 8) mix_feature_nhwc_kernel<T, 8><<<grid, BLOCK, 0, st>>>((const T*)clean, (const T*)adv, (T*)out, (int)c, pixels, eps);
     else mix_feature_nhwc_kernel<T, 20><<<grid, BLOCK, 0, st>>>((const T*)clean, (const T*)adv, (T*)out, (int)c, pixels, eps);
     AFAN_LAUNCH_CHECK();

@@ -32,45 +32,42 @@ __device__ __forceinline__ Src src_index(float scale, int dst, int in_size) {
     return r;
 }
 
-// One thread = one output pixel x VEC consecutive channels (NHWC) or one output element (NCHW, VEC = 1).
+// Grid: blockIdx.x = (image, output row) [NHWC] or (image, channel, output row) [NCHW]; a thread = one (column, channel
+// vector) of that row — one 32-bit division per thread, the row's source rows and weights are wave-uniform.
 template <typename T, int VEC, bool NHWC>
 __global__ __launch_bounds__(BLOCK) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int C, int Hi,
-                                                             int Wi, int Ho, int Wo, float sh, float sw, int64_t total) {
-    const int CV = C / VEC;
-    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
-        int64_t t = v;
-        int cv, ox, oy;
-        int64_t n;
-        if constexpr (NHWC) { cv = (int)(t % CV); t /= CV; ox = (int)(t % Wo); t /= Wo; oy = (int)(t % Ho); n = t / Ho; }
-        else { ox = (int)(t % Wo); t /= Wo; oy = (int)(t % Ho); t /= Ho; cv = (int)(t % CV); n = t / CV; }
-        const Src a = src_index(sh, oy, Hi), b = src_index(sw, ox, Wi);
-        float o[VEC];
-        if constexpr (NHWC) {
-            const T* base = x + (n * Hi * (int64_t)Wi) * C + cv * VEC;
-            float p00[VEC], p01[VEC], p10[VEC], p11[VEC];
-            if constexpr (VEC == 1) {
-                p00[0] = Elt<T>::ld(base + ((int64_t)a.i0 * Wi + b.i0) * C);
-                p01[0] = Elt<T>::ld(base + ((int64_t)a.i0 * Wi + b.i1) * C);
-                p10[0] = Elt<T>::ld(base + ((int64_t)a.i1 * Wi + b.i0) * C);
-                p11[0] = Elt<T>::ld(base + ((int64_t)a.i1 * Wi + b.i1) * C);
-            } else {
-                Elt<T>::ldv(base + ((int64_t)a.i0 * Wi + b.i0) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p00));
-                Elt<T>::ldv(base + ((int64_t)a.i0 * Wi + b.i1) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p01));
-                Elt<T>::ldv(base + ((int64_t)a.i1 * Wi + b.i0) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p10));
-                Elt<T>::ldv(base + ((int64_t)a.i1 * Wi + b.i1) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p11));
-            }
-#pragma unroll
-            for (int k = 0; k < VEC; ++k)     // ATen's association: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
-                o[k] = a.l0 * (b.l0 * p00[k] + b.l1 * p01[k]) + a.l1 * (b.l0 * p10[k] + b.l1 * p11[k]);
-            T* dst = y + ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC;
-            if constexpr (VEC == 1) Elt<T>::st(dst, o[0]);
-            else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(o));
+                                                             int Wi, int Ho, int Wo, float sh, float sw) {
+    const uint32_t CV = NHWC ? C / VEC : 1;
+    const uint32_t row = blockIdx.x, oy = row % Ho, plane = row / Ho;      // plane = n (NHWC) or n * C + c (NCHW)
+    const uint32_t t = blockIdx.y * BLOCK + threadIdx.x;
+    if (t >= (uint32_t)Wo * CV) return;
+    const uint32_t ox = t / CV, cv = t - ox * CV;
+    const Src a = src_index(sh, (int)oy, Hi), b = src_index(sw, (int)ox, Wi);
+    if constexpr (NHWC) {
+        const T* base = x + (int64_t)plane * Hi * Wi * C + cv * VEC;
+        float p00[VEC], p01[VEC], p10[VEC], p11[VEC], o[VEC];
+        if constexpr (VEC == 1) {
+            p00[0] = Elt<T>::ld(base + ((int64_t)a.i0 * Wi + b.i0) * C);
+            p01[0] = Elt<T>::ld(base + ((int64_t)a.i0 * Wi + b.i1) * C);
+            p10[0] = Elt<T>::ld(base + ((int64_t)a.i1 * Wi + b.i0) * C);
+            p11[0] = Elt<T>::ld(base + ((int64_t)a.i1 * Wi + b.i1) * C);
         } else {
-            const T* base = x + (n * C + cv) * (int64_t)Hi * Wi;
-            const float p00 = Elt<T>::ld(base + (int64_t)a.i0 * Wi + b.i0), p01 = Elt<T>::ld(base + (int64_t)a.i0 * Wi + b.i1);
-            const float p10 = Elt<T>::ld(base + (int64_t)a.i1 * Wi + b.i0), p11 = Elt<T>::ld(base + (int64_t)a.i1 * Wi + b.i1);
-            Elt<T>::st(y + v, a.l0 * (b.l0 * p00 + b.l1 * p01) + a.l1 * (b.l0 * p10 + b.l1 * p11));
+            Elt<T>::ldv(base + ((int64_t)a.i0 * Wi + b.i0) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p00));
+            Elt<T>::ldv(base + ((int64_t)a.i0 * Wi + b.i1) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p01));
+            Elt<T>::ldv(base + ((int64_t)a.i1 * Wi + b.i0) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p10));
+            Elt<T>::ldv(base + ((int64_t)a.i1 * Wi + b.i1) * C, reinterpret_cast<float(&)[Elt<T>::VEC]>(p11));
         }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)     // ATen's association: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
+            o[k] = a.l0 * (b.l0 * p00[k] + b.l1 * p01[k]) + a.l1 * (b.l0 * p10[k] + b.l1 * p11[k]);
+        T* dst = y + (((int64_t)plane * Ho + oy) * Wo + ox) * C + cv * VEC;
+        if constexpr (VEC == 1) Elt<T>::st(dst, o[0]);
+        else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(o));
+    } else {
+        const T* base = x + (int64_t)plane * Hi * Wi;
+        const float p00 = Elt<T>::ld(base + (int64_t)a.i0 * Wi + b.i0), p01 = Elt<T>::ld(base + (int64_t)a.i0 * Wi + b.i1);
+        const float p10 = Elt<T>::ld(base + (int64_t)a.i1 * Wi + b.i0), p11 = Elt<T>::ld(base + (int64_t)a.i1 * Wi + b.i1);
+        Elt<T>::st(y + ((int64_t)plane * Ho + oy) * Wo + ox, a.l0 * (b.l0 * p00 + b.l1 * p01) + a.l1 * (b.l0 * p10 + b.l1 * p11));
     }
 }
 
@@ -87,53 +84,49 @@ __device__ __forceinline__ float axis_weight(float scale, int o, int i, int in_s
     return (s.i0 == i ? s.l0 : 0.f) + (s.i1 == i ? s.l1 : 0.f);
 }
 
-// Backward as a gather: one thread = one INPUT pixel x VEC channels, summing the output gradients it fed, rows then
-// columns in increasing order (deterministic).
+// Backward as a gather over the same row-wise grid (blockIdx.x = input row): a thread = one INPUT (column, channel vector),
+// summing the output gradients it fed, rows then columns in increasing order (deterministic).
 template <typename T, int VEC, bool NHWC>
 __global__ __launch_bounds__(BLOCK) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int C, int Hi,
-                                                             int Wi, int Ho, int Wo, float sh, float sw, float ish,
-                                                             float isw, int64_t total) {
-    const int CV = C / VEC;
-    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
-        int64_t t = v;
-        int cv, ix, iy;
-        int64_t n;
-        if constexpr (NHWC) { cv = (int)(t % CV); t /= CV; ix = (int)(t % Wi); t /= Wi; iy = (int)(t % Hi); n = t / Hi; }
-        else { ix = (int)(t % Wi); t /= Wi; iy = (int)(t % Hi); t /= Hi; cv = (int)(t % CV); n = t / CV; }
-        int ylo, yhi, xlo, xhi;
-        out_range(ish, iy, Ho, ylo, yhi);
-        out_range(isw, ix, Wo, xlo, xhi);
-        float acc[VEC];
+                                                             int Wi, int Ho, int Wo, float sh, float sw, float ish, float isw) {
+    const uint32_t CV = NHWC ? C / VEC : 1;
+    const uint32_t row = blockIdx.x, iy = row % Hi, plane = row / Hi;
+    const uint32_t t = blockIdx.y * BLOCK + threadIdx.x;
+    if (t >= (uint32_t)Wi * CV) return;
+    const uint32_t ix = t / CV, cv = t - ix * CV;
+    int ylo, yhi, xlo, xhi;
+    out_range(ish, (int)iy, Ho, ylo, yhi);
+    out_range(isw, (int)ix, Wo, xlo, xhi);
+    float acc[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        for (int oy = ylo; oy <= yhi; ++oy) {
-            const float wy = axis_weight(sh, oy, iy, Hi);
-            if (wy == 0.f) continue;
-            for (int ox = xlo; ox <= xhi; ++ox) {
-                const float wx = axis_weight(sw, ox, ix, Wi);
-                if (wx == 0.f) continue;
-                const float w = wy * wx;
-                if constexpr (NHWC) {
-                    const T* src = dy + ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC;
-                    if constexpr (VEC == 1) acc[0] += w * Elt<T>::ld(src);
-                    else {
-                        float g[VEC];
-                        Elt<T>::ldv(src, reinterpret_cast<float(&)[Elt<T>::VEC]>(g));
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = axis_weight(sh, oy, (int)iy, Hi);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const float wx = axis_weight(sw, ox, (int)ix, Wi);
+            if (wx == 0.f) continue;
+            const float w = wy * wx;
+            if constexpr (NHWC) {
+                const T* src = dy + (((int64_t)plane * Ho + oy) * Wo + ox) * C + cv * VEC;
+                if constexpr (VEC == 1) acc[0] += w * Elt<T>::ld(src);
+                else {
+                    float g[VEC];
+                    Elt<T>::ldv(src, reinterpret_cast<float(&)[Elt<T>::VEC]>(g));
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] += w * g[k];
-                    }
-                } else {
-                    acc[0] += w * Elt<T>::ld(dy + ((n * C + cv) * (int64_t)Ho + oy) * Wo + ox);
+                    for (int k = 0; k < VEC; ++k) acc[k] += w * g[k];
                 }
+            } else {
+                acc[0] += w * Elt<T>::ld(dy + ((int64_t)plane * Ho + oy) * Wo + ox);
             }
         }
-        if constexpr (NHWC) {
-            T* dst = dx + ((n * Hi + iy) * (int64_t)Wi + ix) * C + cv * VEC;
-            if constexpr (VEC == 1) Elt<T>::st(dst, acc[0]);
-            else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(acc));
-        } else {
-            Elt<T>::st(dx + v, acc[0]);
-        }
+    }
+    if constexpr (NHWC) {
+        T* dst = dx + (((int64_t)plane * Hi + iy) * Wi + ix) * C + cv * VEC;
+        if constexpr (VEC == 1) Elt<T>::st(dst, acc[0]);
+        else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(acc));
+    } else {
+        Elt<T>::st(dx + ((int64_t)plane * Hi + iy) * Wi + ix, acc[0]);
     }
 }
 
@@ -153,49 +146,77 @@ __global__ __launch_bounds__(BLOCK) void ce2d_count_kernel(const int64_t* __rest
 }
 
 // ws: [0] = count (written by ce2d_fold_count_kernel), [1..1+G) count partials, [1+G..1+2G) loss partials
-__global__ void ce2d_fold_count_kernel(float* ws, int G) {
+__device__ __forceinline__ float block_sum256(float v) {      // fixed order: wave butterflies, then the 4 waves in index order
+    v = wave_sum(v);
+    __shared__ float red[BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(BLOCK) void ce2d_fold_count_kernel(float* ws, int G) {
     float c = 0.f;
-    for (int i = 0; i < G; ++i) c += ws[1 + i];
-    ws[0] = c;
+    for (int i = threadIdx.x; i < G; i += BLOCK) c += ws[1 + i];
+    c = block_sum256(c);
+    if (threadIdx.x == 0) ws[0] = c;
 }
 
+// One thread = one pixel.  NHWC: the block's 256 pixels x C logits are one contiguous run — copied through LDS (row stride C
+// words: conflict-free for odd C, 2-way for C = 2 mod 4) so that global loads and stores are fully coalesced; NCHW: class
+// planes are already coalesced along the pixels.
 template <bool NHWC>
 __global__ __launch_bounds__(BLOCK) void ce2d_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                      float* __restrict__ dlogits, int C, int64_t HW, int64_t P,
                                                      int64_t ignore, float grad_scale, float* __restrict__ ws, int G) {
+    extern __shared__ float tile[];          // NHWC: [BLOCK][C]
     const float count = ws[0];
     const float gs = grad_scale / count;
     float loss = 0.f;
-    for (int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x; p < P; p += (int64_t)gridDim.x * BLOCK) {
-        const int64_t t = target[p];
-        const int64_t n = p / HW, q = p - n * HW;
-        const int64_t base = NHWC ? p * C : n * C * HW + q;
-        const int64_t cs = NHWC ? 1 : HW;
-        float l[CE_MAX_C];               // fully unrolled with a guard: stays in registers
-        float m = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < CE_MAX_C; ++c) {
-            l[c] = c < C ? logits[base + c * cs] : -INFINITY;
-            m = fmaxf(m, l[c]);
+    for (int64_t p0 = (int64_t)blockIdx.x * BLOCK; p0 < P; p0 += (int64_t)gridDim.x * BLOCK) {
+        const int npx = (int)((P - p0) < BLOCK ? (P - p0) : BLOCK);
+        if (NHWC) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < npx * C; i += BLOCK) tile[i] = logits[p0 * C + i];
+            __syncthreads();
         }
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < CE_MAX_C; ++c) {
-            l[c] = c < C ? expf(l[c] - m) : 0.f;
-            s += l[c];
-        }
-        const bool live = t != ignore;
-        const bool bad = live && (t < 0 || t >= C);          // torch asserts here; poison the loss instead of reading out of range
-        const float inv = 1.f / s;
-        if (live && !bad) loss += logf(s) + m - logits[base + t * cs];
-        if (bad) loss = NAN;
-        if (dlogits) {
+        const int64_t p = p0 + threadIdx.x;
+        if ((int)threadIdx.x < npx) {
+            const int64_t t = target[p];
+            const int64_t n = p / HW, q = p - n * HW;
+            const int64_t base = n * C * HW + q;          // NCHW
+            float l[CE_MAX_C];               // fully unrolled with a guard: stays in registers
+            float m = -INFINITY;
 #pragma unroll
             for (int c = 0; c < CE_MAX_C; ++c) {
-                float g = 0.f;
-                if (live && !bad) g = (l[c] * inv - (c == (int)t ? 1.f : 0.f)) * gs;
-                if (c < C) dlogits[base + c * cs] = g;
+                l[c] = c < C ? (NHWC ? tile[threadIdx.x * C + c] : logits[base + c * HW]) : -INFINITY;
+                m = fmaxf(m, l[c]);
             }
+            const bool live = t != ignore;
+            const bool bad = live && (t < 0 || t >= C);      // torch asserts here; poison the loss instead of reading out of range
+            float lt = 0.f, s = 0.f;
+#pragma unroll
+            for (int c = 0; c < CE_MAX_C; ++c) {
+                if (c == (int)t) lt = l[c];
+                l[c] = c < C ? expf(l[c] - m) : 0.f;
+                s += l[c];
+            }
+            const float inv = 1.f / s;
+            if (live && !bad) loss += logf(s) + m - lt;
+            if (bad) loss = NAN;
+            if (dlogits) {
+#pragma unroll
+                for (int c = 0; c < CE_MAX_C; ++c) {
+                    float g = 0.f;
+                    if (live && !bad) g = (l[c] * inv - (c == (int)t ? 1.f : 0.f)) * gs;
+                    if (c < C) {
+                        if (NHWC) tile[threadIdx.x * C + c] = g;
+                        else dlogits[base + c * HW] = g;
+                    }
+                }
+            }
+        }
+        if (NHWC && dlogits) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < npx * C; i += BLOCK) dlogits[p0 * C + i] = tile[i];
         }
     }
     loss = wave_sum(loss);
@@ -205,10 +226,11 @@ __global__ __launch_bounds__(BLOCK) void ce2d_kernel(const float* __restrict__ l
     if (threadIdx.x == 0) ws[1 + G + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void ce2d_finalize_kernel(const float* ws, int G, float* loss) {
+__global__ __launch_bounds__(BLOCK) void ce2d_finalize_kernel(const float* ws, int G, float* loss) {
     float s = 0.f;
-    for (int i = 0; i < G; ++i) s += ws[1 + G + i];
-    loss[0] = s / ws[0];
+    for (int i = threadIdx.x; i < G; i += BLOCK) s += ws[1 + G + i];
+    s = block_sum256(s);
+    if (threadIdx.x == 0) loss[0] = s / ws[0];
 }
 
 // ---- 3x3 / stride 2 / pad 1 max pooling --------------------------------------------------------------------------------
@@ -311,16 +333,28 @@ __global__ __launch_bounds__(BLOCK) void maxpool_bwd_kernel(const T* __restrict_
 
 // ---- global average pool ----------------------------------------------------------------------------------------------
 // NHWC: block = (sample, 64 channels); 4 waves walk the pixels 4 apart, lanes along the channels (coalesced 128 B rows)
+constexpr int AP_WAVES = 16;     // 1024 threads: 16 pixel rows of a 64-channel column block in flight
 template <typename T, typename TP>
-__global__ __launch_bounds__(BLOCK) void avgpool_nhwc_kernel(const T* __restrict__ x, TP* __restrict__ y, int C, int64_t HW) {
+__global__ __launch_bounds__(64 * AP_WAVES) void avgpool_nhwc_kernel(const T* __restrict__ x, TP* __restrict__ y, int C, int64_t HW) {
     const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < C)
-        for (int64_t p = r; p < HW; p += 4) s += Elt<T>::ld(x + ((int64_t)n * HW + p) * C + c);
-    __shared__ float red[4][64];
-    red[r][threadIdx.x & 63] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        int64_t p = r;
+        for (; p + AP_WAVES < HW; p += 2 * AP_WAVES) {       // two independent loads per iteration
+            s0 += Elt<T>::ld(x + ((int64_t)n * HW + p) * C + c);
+            s1 += Elt<T>::ld(x + ((int64_t)n * HW + p + AP_WAVES) * C + c);
+        }
+        if (p < HW) s0 += Elt<T>::ld(x + ((int64_t)n * HW + p) * C + c);
+    }
+    __shared__ float red[AP_WAVES][64];
+    red[r][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
-    if (r == 0 && c < C) Elt<TP>::st(y + (int64_t)n * C + c, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)HW);
+    if (r == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < AP_WAVES; ++i) t += red[i][threadIdx.x];
+        Elt<TP>::st(y + (int64_t)n * C + c, t / (float)HW);
+    }
 }
 // NCHW: one wave per (n, c) plane
 template <typename T, typename TP>
@@ -346,7 +380,8 @@ __global__ __launch_bounds__(BLOCK) void avgpool_bwd_kernel(const TP* __restrict
 // ---- 1x1 convolution with bias to a few output channels, fp32 out ------------------------------------------------
 constexpr int PW_MAX_CO = 32;
 
-// y[m][co] = b[co] + sum_ci x[m][ci] * w[co][ci]; weights in LDS (read as broadcasts), one thread per pixel
+// y[m][co] = b[co] + sum_ci x[m][ci] * w[co][ci]; weights in LDS.  FOUR lanes per pixel: lane q takes the 16-byte pieces
+// q, q + 4, ... of the pixel's row (the quad reads 64 contiguous bytes per step), partial sums meet by two shuffles.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pointwise_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, float* __restrict__ y,
@@ -355,13 +390,15 @@ __global__ __launch_bounds__(BLOCK) void pointwise_fwd_kernel(const T* __restric
     for (int i = threadIdx.x; i < Co * Ci; i += BLOCK) wl[i] = w[i];
     __syncthreads();
     constexpr int V = Elt<T>::VEC;
-    const int64_t m = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (m >= M) return;
+    const int64_t m = (int64_t)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const int q = threadIdx.x & 3;
+    const bool live = m < M;
     float acc[PW_MAX_CO];
 #pragma unroll
-    for (int o = 0; o < PW_MAX_CO; ++o) acc[o] = (o < Co && b) ? b[o] : 0.f;
-    const T* row = x + m * Ci;
-    for (int c = 0; c < Ci; c += V) {
+    for (int o = 0; o < PW_MAX_CO; ++o) acc[o] = (o < Co && b && q == 0) ? b[o] : 0.f;
+    const T* row = x + (live ? m : 0) * Ci;
+#pragma unroll 2
+    for (int c = q * V; c < Ci; c += 4 * V) {
         float xv[V];
         Elt<T>::ldv(row + c, xv);
 #pragma unroll
@@ -373,11 +410,17 @@ __global__ __launch_bounds__(BLOCK) void pointwise_fwd_kernel(const T* __restric
         }
     }
 #pragma unroll
-    for (int o = 0; o < PW_MAX_CO; ++o)
-        if (o < Co) y[m * Co + o] = acc[o];
+    for (int o = 0; o < PW_MAX_CO; ++o) {
+        if (o < Co) {
+            float v = acc[o];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (live && (o & 3) == q) y[m * Co + o] = v;
+        }
+    }
 }
 
-// dx[m][ci] = sum_co dy[m][co] * w[co][ci]
+// dx[m][ci] = sum_co dy[m][co] * w[co][ci]; same quad mapping (no reduction: every lane owns its output pieces)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pointwise_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              T* __restrict__ dx, int64_t M, int Ci, int Co) {
@@ -385,13 +428,14 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dx_kernel(const float* __rest
     for (int i = threadIdx.x; i < Co * Ci; i += BLOCK) wl[i] = w[i];
     __syncthreads();
     constexpr int V = Elt<T>::VEC;
-    const int64_t m = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t m = (int64_t)blockIdx.x * (BLOCK / 4) + (threadIdx.x >> 2);
+    const int q = threadIdx.x & 3;
     if (m >= M) return;
     float g[PW_MAX_CO];
 #pragma unroll
     for (int o = 0; o < PW_MAX_CO; ++o) g[o] = o < Co ? dy[m * Co + o] : 0.f;
     T* row = dx + m * Ci;
-    for (int c = 0; c < Ci; c += V) {
+    for (int c = q * V; c < Ci; c += 4 * V) {
         float o8[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) o8[k] = 0.f;
@@ -406,55 +450,73 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dx_kernel(const float* __rest
     }
 }
 
-// dw partials: block = PW_SLICE pixels; thread = input channel (strided if Ci > BLOCK); slab[blk][Co + 1][Ci]: row Co is unused
-// padding so that db (summed by thread 0.. over dy only) lives in its own array
-constexpr int PW_SLICE = 128;
+// dw partials: persistent workgroups walk 64-pixel slices; thread = input channel, the slice's dy tile in LDS (read as
+// broadcasts), 8 independent x loads in flight; slab[blk][Co][Ci] + bslab[blk][Co], folded in two stages (PW_FOLD groups)
+constexpr int PW_SLICE = 64;
+constexpr int PW_FOLD = 16;
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pointwise_dw_kernel(const float* __restrict__ dy, const T* __restrict__ x,
                                                              float* __restrict__ slab, float* __restrict__ bslab,
                                                              int64_t M, int Ci, int Co) {
     __shared__ float g[PW_SLICE][PW_MAX_CO];
-    const int64_t m0 = (int64_t)blockIdx.x * PW_SLICE;
-    const int rows = (int)((M - m0) < PW_SLICE ? (M - m0) : PW_SLICE);
-    for (int i = threadIdx.x; i < PW_SLICE * Co; i += BLOCK) {
-        const int r = i / Co, o = i - r * Co;
-        g[r][o] = r < rows ? dy[(m0 + r) * Co + o] : 0.f;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < Ci; c += BLOCK) {
+    const int64_t slices = (M + PW_SLICE - 1) / PW_SLICE;
+    float bsum = 0.f;
+    for (int c0 = 0; c0 < Ci; c0 += BLOCK) {
+        const int c = c0 + threadIdx.x;
         float acc[PW_MAX_CO];
 #pragma unroll
         for (int o = 0; o < PW_MAX_CO; ++o) acc[o] = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            const float xv = Elt<T>::ld(x + (m0 + r) * Ci + c);
+        for (int64_t sl = blockIdx.x; sl < slices; sl += gridDim.x) {
+            const int64_t m0 = sl * PW_SLICE;
+            const int rows = (int)((M - m0) < PW_SLICE ? (M - m0) : PW_SLICE);
+            __syncthreads();
+            for (int i = threadIdx.x; i < PW_SLICE * Co; i += BLOCK) {
+                const int r = i / Co, o = i - r * Co;
+                g[r][o] = r < rows ? dy[(m0 + r) * Co + o] : 0.f;
+            }
+            __syncthreads();
+            if (c0 == 0 && (int)threadIdx.x < Co)
+                for (int r = 0; r < rows; ++r) bsum += g[r][threadIdx.x];
+            if (c < Ci) {
+                for (int r0 = 0; r0 < PW_SLICE; r0 += 8) {
+                    float xv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = (r0 + j < rows) ? Elt<T>::ld(x + (m0 + r0 + j) * Ci + c) : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+#pragma unroll
+                        for (int o = 0; o < PW_MAX_CO; ++o)
+                            if (o < Co) acc[o] = fmaf(g[r0 + j][o], xv[j], acc[o]);
+                }
+            }
+        }
+        if (c < Ci) {
 #pragma unroll
             for (int o = 0; o < PW_MAX_CO; ++o)
-                if (o < Co) acc[o] = fmaf(g[r][o], xv, acc[o]);
+                if (o < Co) slab[((int64_t)blockIdx.x * Co + o) * Ci + c] = acc[o];
         }
-#pragma unroll
-        for (int o = 0; o < PW_MAX_CO; ++o)
-            if (o < Co) slab[((int64_t)blockIdx.x * Co + o) * Ci + c] = acc[o];
     }
-    if (threadIdx.x < Co) {
-        float s = 0.f;
-        for (int r = 0; r < rows; ++r) s += g[r][threadIdx.x];
-        bslab[(int64_t)blockIdx.x * Co + threadIdx.x] = s;
-    }
+    if ((int)threadIdx.x < Co) bslab[(int64_t)blockIdx.x * Co + threadIdx.x] = bsum;
 }
-__global__ __launch_bounds__(BLOCK) void pointwise_dw_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
-                                                                    float* __restrict__ dw, float* __restrict__ db, int G,
-                                                                    int Ci, int Co, int accumulate) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < Co * Ci) {
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += slab[(int64_t)g * Co * Ci + i];
-        dw[i] = accumulate ? dw[i] + s : s;
-    }
-    if (db && i < Co) {
-        float s = 0.f;
-        for (int g = 0; g < G; ++g) s += bslab[(int64_t)g * Co + i];
-        db[i] = accumulate ? db[i] + s : s;
-    }
+// stage A: partial[f][i] = sum over slabs g = f, f + PW_FOLD, ... ; i runs over the Co*Ci weights, then the Co biases
+__global__ __launch_bounds__(BLOCK) void pointwise_dw_fold_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                                  float* __restrict__ part, int G, int Ci, int Co) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x, f = blockIdx.y, nw = Co * Ci;
+    if (i >= nw + Co) return;
+    float s = 0.f;
+    if (i < nw) for (int g = f; g < G; g += PW_FOLD) s += slab[(int64_t)g * nw + i];
+    else for (int g = f; g < G; g += PW_FOLD) s += bslab[(int64_t)g * Co + (i - nw)];
+    part[(int64_t)f * (nw + Co) + i] = s;
+}
+__global__ __launch_bounds__(BLOCK) void pointwise_dw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                    float* __restrict__ db, int Ci, int Co, int accumulate) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x, nw = Co * Ci;
+    if (i >= nw + Co) return;
+    float s = 0.f;
+#pragma unroll
+    for (int f = 0; f < PW_FOLD; ++f) s += part[(int64_t)f * (nw + Co) + i];
+    if (i < nw) dw[i] = accumulate ? dw[i] + s : s;
+    else if (db) db[i - nw] = accumulate ? db[i - nw] + s : s;
 }
 
 // ---- fp32 linear layer on a handful of rows -------------------------------------------------------------------------------
@@ -485,25 +547,39 @@ __global__ __launch_bounds__(BLOCK) void linear_small_fwd_kernel(const float* __
     }
 }
 // dx[n][ci] = sum_co dy[n][co] * w[co][ci]
-__global__ __launch_bounds__(BLOCK) void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                float* __restrict__ dx, int N, int Ci, int Co) {
-    extern __shared__ float g[];      // [N][Co]
-    for (int i = threadIdx.x; i < N * Co; i += BLOCK) g[i] = dy[i];
+// block = 64 input channels x 16 waves; wave w sums output channels w, w + 16, ... (4 loads in flight), then the waves fold
+constexpr int LDX_WAVES = 16;
+__global__ __launch_bounds__(64 * LDX_WAVES) void linear_small_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                         float* __restrict__ dx, int N, int Ci, int Co) {
+    extern __shared__ float g[];      // [N][Co] then [LDX_WAVES][N][64] partials
+    float* part = g + N * Co;
+    for (int i = threadIdx.x; i < N * Co; i += 64 * LDX_WAVES) g[i] = dy[i];
     __syncthreads();
-    const int c = blockIdx.x * BLOCK + threadIdx.x;
-    if (c >= Ci) return;
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float acc[LIN_MAX_N];
 #pragma unroll
     for (int n = 0; n < LIN_MAX_N; ++n) acc[n] = 0.f;
-    for (int co = 0; co < Co; ++co) {
-        const float wv = w[(int64_t)co * Ci + c];
+    if (c < Ci) {
+#pragma unroll 4
+        for (int co = wv_; co < Co; co += LDX_WAVES) {
+            const float wv = w[(int64_t)co * Ci + c];
 #pragma unroll
-        for (int n = 0; n < LIN_MAX_N; ++n)
-            if (n < N) acc[n] = fmaf(g[n * Co + co], wv, acc[n]);
+            for (int n = 0; n < LIN_MAX_N; ++n)
+                if (n < N) acc[n] = fmaf(g[n * Co + co], wv, acc[n]);
+        }
     }
 #pragma unroll
     for (int n = 0; n < LIN_MAX_N; ++n)
-        if (n < N) dx[(int64_t)n * Ci + c] = acc[n];
+        if (n < N) part[(wv_ * N + n) * 64 + lane] = acc[n];
+    __syncthreads();
+    for (int i = threadIdx.x; i < N * 64; i += 64 * LDX_WAVES) {
+        const int n = i >> 6, l = i & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < LDX_WAVES; ++q) s += part[(q * N + n) * 64 + l];
+        if (blockIdx.x * 64 + l < Ci) dx[(int64_t)n * Ci + blockIdx.x * 64 + l] = s;
+    }
 }
 // dw[co][ci] (+)= sum_n dy[n][co] * x[n][ci]
 __global__ __launch_bounds__(BLOCK) void linear_small_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -586,7 +662,11 @@ int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, in
     const int64_t total = n * ho * wo * c / vec;
     const float sh = (float)hi / (float)ho, sw = (float)wi / (float)wo;
     AFAN_PROF("upsample_bilinear_fwd_kernel", (double)es * n * c * (ho * wo + hi * wi), st);
-#define K_(T, V, L, ...) upsample_fwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)x, (T*)y, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, total)
+    const int64_t rows = layout == AFAN_NHWC ? n * ho : n * c * ho, per_row = layout == AFAN_NHWC ? wo * (c / vec) : wo;
+    if (rows > 0x7fffffffLL || (per_row + BLOCK - 1) / BLOCK > 65535) return AFAN_ESHAPE;
+    (void)total;
+    const dim3 ugrid((unsigned)rows, (unsigned)((per_row + BLOCK - 1) / BLOCK));
+#define K_(T, V, L, ...) upsample_fwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)x, (T*)y, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw)
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();
@@ -608,7 +688,11 @@ int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, 
     const float sh = (float)hi / (float)ho, sw = (float)wi / (float)wo;
     const float ish = (float)ho / (float)hi, isw = (float)wo / (float)wi;
     AFAN_PROF("upsample_bilinear_bwd_kernel", (double)es * n * c * (ho * wo + hi * wi), st);
-#define K_(T, V, L, ...) upsample_bwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)dy, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, ish, isw, total)
+    const int64_t rows = layout == AFAN_NHWC ? n * hi : n * c * hi, per_row = layout == AFAN_NHWC ? wi * (c / vec) : wi;
+    if (rows > 0x7fffffffLL || (per_row + BLOCK - 1) / BLOCK > 65535) return AFAN_ESHAPE;
+    (void)total;
+    const dim3 ugrid((unsigned)rows, (unsigned)((per_row + BLOCK - 1) / BLOCK));
+#define K_(T, V, L, ...) upsample_bwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)dy, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, ish, isw)
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();
@@ -631,12 +715,12 @@ int afan_ce2d(const float* logits, const int64_t* target, int layout, int64_t n,
     AFAN_PROF("ce2d_kernel", (double)P * (8.0 + 8.0 + 4.0 * c * (dlogits ? 2 : 1)), st);
     ce2d_count_kernel<<<G, BLOCK, 0, st>>>(target, P, ignore_index, workspace + 1);
     AFAN_LAUNCH_CHECK();
-    ce2d_fold_count_kernel<<<1, 1, 0, st>>>(workspace, G);
+    ce2d_fold_count_kernel<<<1, BLOCK, 0, st>>>(workspace, G);
     AFAN_LAUNCH_CHECK();
-    if (layout == AFAN_NHWC) ce2d_kernel<true><<<G, BLOCK, 0, st>>>(logits, target, dlogits, (int)c, hw, P, ignore_index, grad_scale, workspace, G);
+    if (layout == AFAN_NHWC) ce2d_kernel<true><<<G, BLOCK, (size_t)BLOCK * c * 4, st>>>(logits, target, dlogits, (int)c, hw, P, ignore_index, grad_scale, workspace, G);
     else ce2d_kernel<false><<<G, BLOCK, 0, st>>>(logits, target, dlogits, (int)c, hw, P, ignore_index, grad_scale, workspace, G);
     AFAN_LAUNCH_CHECK();
-    ce2d_finalize_kernel<<<1, 1, 0, st>>>(workspace, G, loss);
+    ce2d_finalize_kernel<<<1, BLOCK, 0, st>>>(workspace, G, loss);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -694,9 +778,9 @@ int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, i
     const bool pf = pooled_f32 || dtype == AFAN_F32;
     if (layout == AFAN_NHWC) {
         dim3 grid((unsigned)((c + 63) / 64), (unsigned)n);
-        if (dtype == AFAN_F32) avgpool_nhwc_kernel<float, float><<<grid, BLOCK, 0, st>>>((const float*)x, (float*)y, (int)c, hw);
-        else if (pf) avgpool_nhwc_kernel<uint16_t, float><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (float*)y, (int)c, hw);
-        else avgpool_nhwc_kernel<uint16_t, uint16_t><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)y, (int)c, hw);
+        if (dtype == AFAN_F32) avgpool_nhwc_kernel<float, float><<<grid, 64 * AP_WAVES, 0, st>>>((const float*)x, (float*)y, (int)c, hw);
+        else if (pf) avgpool_nhwc_kernel<uint16_t, float><<<grid, 64 * AP_WAVES, 0, st>>>((const uint16_t*)x, (float*)y, (int)c, hw);
+        else avgpool_nhwc_kernel<uint16_t, uint16_t><<<grid, 64 * AP_WAVES, 0, st>>>((const uint16_t*)x, (uint16_t*)y, (int)c, hw);
     } else {
         const int64_t planes = n * c;
         const unsigned g = (unsigned)((planes + 3) / 4);
@@ -748,7 +832,7 @@ int afan_pointwise_fwd(const void* x, int x_dtype, const float* w, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int es = x_dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("pointwise_fwd_kernel", (double)m * (es * ci + 4.0 * co), st);
-    const unsigned g = (unsigned)((m + BLOCK - 1) / BLOCK);
+    const unsigned g = (unsigned)((m + BLOCK / 4 - 1) / (BLOCK / 4));
     const size_t lds = (size_t)ci * co * 4;
     if (x_dtype == AFAN_F32) pointwise_fwd_kernel<float><<<g, BLOCK, lds, st>>>((const float*)x, w, b, y, m, (int)ci, (int)co);
     else pointwise_fwd_kernel<uint16_t><<<g, BLOCK, lds, st>>>((const uint16_t*)x, w, b, y, m, (int)ci, (int)co);
@@ -765,7 +849,7 @@ int afan_pointwise_bwd_dx(const float* dy, const float* w, void* dx, int dx_dtyp
     hipStream_t st = (hipStream_t)stream;
     const int es = dx_dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("pointwise_dx_kernel", (double)m * (es * ci + 4.0 * co), st);
-    const unsigned g = (unsigned)((m + BLOCK - 1) / BLOCK);
+    const unsigned g = (unsigned)((m + BLOCK / 4 - 1) / (BLOCK / 4));
     const size_t lds = (size_t)ci * co * 4;
     if (dx_dtype == AFAN_F32) pointwise_dx_kernel<float><<<g, BLOCK, lds, st>>>(dy, w, (float*)dx, m, (int)ci, (int)co);
     else pointwise_dx_kernel<uint16_t><<<g, BLOCK, lds, st>>>(dy, w, (uint16_t*)dx, m, (int)ci, (int)co);
@@ -773,10 +857,14 @@ int afan_pointwise_bwd_dx(const float* dy, const float* w, void* dx, int dx_dtyp
     return AFAN_OK;
 }
 
+static int pw_blocks(int64_t m) {
+    const int64_t slices = (m + PW_SLICE - 1) / PW_SLICE;
+    return (int)(slices < 512 ? slices : 512);
+}
+
 int64_t afan_pointwise_workspace_floats(int64_t m, int64_t ci, int64_t co) {
     if (m <= 0 || ci <= 0 || co <= 0) return 0;
-    const int64_t g = (m + PW_SLICE - 1) / PW_SLICE;
-    return g * co * (ci + 1);
+    return (int64_t)(pw_blocks(m) + PW_FOLD) * co * (ci + 1);
 }
 
 int afan_pointwise_bwd_dw(const float* dy, const void* x, int x_dtype, float* dw, float* db, int64_t m, int64_t ci,
@@ -785,14 +873,18 @@ int afan_pointwise_bwd_dw(const float* dy, const void* x, int x_dtype, float* dw
     if (e) return e;
     if (!dy || !x || !dw || !workspace) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    const int G = (int)((m + PW_SLICE - 1) / PW_SLICE);
+    const int G = pw_blocks(m);
     float* bslab = workspace + (int64_t)G * co * ci;
+    float* part = bslab + (int64_t)G * co;
     const int es = x_dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("pointwise_dw_kernel", (double)m * (es * ci + 4.0 * co) + 8.0 * G * co * ci, st);
     if (x_dtype == AFAN_F32) pointwise_dw_kernel<float><<<G, BLOCK, 0, st>>>(dy, (const float*)x, workspace, bslab, m, (int)ci, (int)co);
     else pointwise_dw_kernel<uint16_t><<<G, BLOCK, 0, st>>>(dy, (const uint16_t*)x, workspace, bslab, m, (int)ci, (int)co);
     AFAN_LAUNCH_CHECK();
-    pointwise_dw_reduce_kernel<<<(unsigned)((co * ci + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>(workspace, bslab, dw, db, G, (int)ci, (int)co, accumulate);
+    const unsigned gx = (unsigned)((co * ci + co + BLOCK - 1) / BLOCK);
+    pointwise_dw_fold_kernel<<<dim3(gx, PW_FOLD), BLOCK, 0, st>>>(workspace, bslab, part, G, (int)ci, (int)co);
+    AFAN_LAUNCH_CHECK();
+    pointwise_dw_reduce_kernel<<<gx, BLOCK, 0, st>>>(part, dw, db, (int)ci, (int)co, accumulate);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -811,12 +903,12 @@ int afan_linear_small_fwd(const float* x, const float* w, float* y, int64_t n, i
 
 int afan_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int64_t n, int64_t ci,
                           int64_t co, int accumulate, afan_stream_t stream) {
-    if (n <= 0 || n > LIN_MAX_N || ci <= 0 || co <= 0 || n * co * 4 > 64 * 1024) return AFAN_ESHAPE;
+    if (n <= 0 || n > LIN_MAX_N || ci <= 0 || co <= 0 || (n * co + LDX_WAVES * n * 64) * 4 > 64 * 1024) return AFAN_ESHAPE;
     if (!dy || !w || !x) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
     AFAN_PROF("linear_small_bwd_kernel", 4.0 * (2 * ci * co + 2 * n * (ci + co)), st);
     if (dx) {
-        linear_small_dx_kernel<<<(unsigned)((ci + BLOCK - 1) / BLOCK), BLOCK, (size_t)n * co * 4, st>>>(dy, w, dx, (int)n, (int)ci, (int)co);
+        linear_small_dx_kernel<<<(unsigned)((ci + 63) / 64), 64 * LDX_WAVES, (size_t)(n * co + LDX_WAVES * n * 64) * 4, st>>>(dy, w, dx, (int)n, (int)ci, (int)co);
         AFAN_LAUNCH_CHECK();
     }
     if (dw) {

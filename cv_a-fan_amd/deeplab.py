@@ -13,6 +13,8 @@ kernels (a Bottleneck is one autograd node, `resnet_s._BlockFn`), BatchNorm (+Re
 pool / average pool / classifier / dropout / per-pixel cross-entropy layers as hand-written HIP kernels (`afan_seg.hip`).
 fp32 (parity mode) keeps the vendor's fp32 convolutions, like the classification path; everything else is the same code.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -212,25 +214,43 @@ def seg_criterion(criterion):
 
 
 class _Stem7Fn(torch.autograd.Function):
-    """conv1 (7x7 / 2, 3 -> 64) on the image: forward + weight gradient (afan_conv_stem7_*); images carry no gradient."""
+    """conv1 (7x7 / 2, 3 -> 64) on the image; images carry no gradient.  im2col (afan_conv_stem7_im2col: 152 columns, the
+    147 taps in the weights' KRSC order + 5 zeros) turns forward and weight gradient into 1x1 problems for the MFMA
+    kernels; the column tensor is kept for the backward.  AFAN_STEM7_DIRECT=1 selects the direct FMA kernels (A/B)."""
+    DIRECT = os.environ.get("AFAN_STEM7_DIRECT", "0") == "1"
 
     @staticmethod
     def forward(ctx, x, w_master, w_lp, want_wgrad):
-        ctx.save_for_backward(x)
         ctx.w_master, ctx.want = w_master, want_wgrad
-        return ops.conv_stem7_fwd(x, w_lp)
+        if _Stem7Fn.DIRECT:
+            ctx.save_for_backward(x)
+            return ops.conv_stem7_fwd(x, w_lp)
+        cols = ops.conv_stem7_im2col(x)
+        k = cols.shape[1]
+        wp = torch.zeros((64, k, 1, 1), dtype=torch.bfloat16, device=x.device)
+        wp.view(64, k)[:, :147] = w_lp.permute(0, 2, 3, 1).reshape(64, 147)        # KRSC memory: a plain row copy
+        ctx.save_for_backward(cols)
+        return ops.conv_fwd(cols, wp.contiguous(memory_format=torch.channels_last), 1)
 
     @staticmethod
     def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
+        (saved,) = ctx.saved_tensors
         gw = None
         if ctx.want and ctx.needs_input_grad[1]:
             gy = gy.contiguous(memory_format=torch.channels_last)
             wm = ctx.w_master
-            if _accumulates_in_place(wm) and wm.grad.is_contiguous(memory_format=torch.channels_last):
-                ops.conv_stem7_wgrad(x, gy, wm.grad, accumulate=True)
+            direct = _accumulates_in_place(wm) and wm.grad.is_contiguous(memory_format=torch.channels_last)
+            if _Stem7Fn.DIRECT:
+                if direct:
+                    ops.conv_stem7_wgrad(saved, gy, wm.grad, accumulate=True)
+                else:
+                    gw = ops.conv_stem7_wgrad(saved, gy)
             else:
-                gw = ops.conv_stem7_wgrad(x, gy)
+                g = ops.conv_wgrad(saved, gy, 1, 1).view(64, -1)[:, :147]               # fp32 [64, 152] -> the 147 taps
+                if direct:
+                    wm.grad.permute(0, 2, 3, 1).reshape(64, 147).add_(g)                 # (a view of the KRSC arena slice)
+                else:
+                    gw = g.reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
         return None, gw, None, None
 
 

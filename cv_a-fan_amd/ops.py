@@ -817,7 +817,8 @@ def avgpool_backward(dy, like):
 
 def linear_small_ok(x, weight):
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and x.shape[0] <= _lib.load().afan_linear_small_max_rows() and x.shape[0] * weight.shape[0] * 4 <= 64 * 1024)
+            and x.shape[0] <= _lib.load().afan_linear_small_max_rows()
+            and (x.shape[0] * weight.shape[0] + 16 * x.shape[0] * 64) * 4 <= 64 * 1024)
 
 
 def linear_small(x, weight):
@@ -915,6 +916,18 @@ def conv_stem7_ok(x, w, stride, padding):
             and tuple(padding) == (3, 3))
 
 
+def conv_stem7_im2col(x):
+    """[N*Ho*Wo, K] -> as a [N, K, Ho, Wo] channels-last bf16 tensor (K = 152: the 147 taps + 5 zero columns)."""
+    lib = _lib.load()
+    _cl4(x, "x")
+    n, _, hi, wi = x.shape
+    k = lib.afan_conv_stem7_im2col_k()
+    ho, wo = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    cols = torch.empty((n, k, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(lib.afan_conv_stem7_im2col(_ptr(x), _ptr(cols), n, hi, wi, _stream(x)), "afan_conv_stem7_im2col")
+    return cols
+
+
 def conv_stem7_fwd(x, w):
     """The 7x7 / stride 2 image stem: x [N,3,H,W] bf16 channels-last, w [64,3,7,7] bf16 in KRSC memory."""
     lib = _lib.load()
@@ -980,7 +993,7 @@ def profile_enable(on=True):
     check(_lib.load().afan_profile_enable(int(bool(on))), "afan_profile_enable")
 
 
-def profile_collect(max_kernels=32):
+def profile_collect(max_kernels=96):
     """{kernel: {"launches", "ms", "bytes"}} for the launches recorded since profile_enable(True)."""
     lib = _lib.load()
     names = C.create_string_buffer(64 * max_kernels)

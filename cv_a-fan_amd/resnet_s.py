@@ -830,10 +830,11 @@ class ResNet50(ResNet):
 
     def __init__(self, num_classes=1000, blocks=(3, 4, 6, 3), init_weight=1):
         nn.Module.__init__(self)
+        from .deeplab import MaxPool2d, StemConv      # the 7x7 / 2 stem (im2col + MFMA 1x1) and the 3x3 / 2 max-pool kernels
         self.all_layers = 9
         layers = [NormalizeByChannelMeanStd(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
-                  Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), BatchNorm2d(64), nn.ReLU(),
-                  nn.MaxPool2d(3, 2, 1)]
+                  StemConv(3, 64, kernel_size=7, stride=2, padding=3, bias=False), BatchNorm2d(64), nn.ReLU(),
+                  MaxPool2d(3, 2, 1)]
         in_planes = 64
         for stage, (planes, nb) in enumerate(zip((64, 128, 256, 512), blocks)):
             for b in range(nb):

@@ -288,6 +288,11 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
 int afan_conv_stem7_supported(int64_t ci, int64_t co, int k, int stride);
 int afan_conv_stem7_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi,
                                   afan_stream_t stream);
+/* im2col form (the product path): cols[N*Ho*Wo][K] bf16 with K = afan_conv_stem7_im2col_k() = 152 (147 taps in the
+ * weights' KRSC order + 5 zeros); forward and weight gradient are then 1x1 problems for afan_conv_fwd_nhwc_bf16 /
+ * afan_conv_wgrad_nhwc_bf16 (ci = 152) on the MFMA kernels. */
+int afan_conv_stem7_im2col_k(void);
+int afan_conv_stem7_im2col(const void* x, void* cols, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream);
 int64_t afan_conv_stem7_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi);
 int afan_conv_stem7_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
                                     float* workspace, int accumulate, afan_stream_t stream);

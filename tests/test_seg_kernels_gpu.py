@@ -116,7 +116,7 @@ def test_avgpool(pkg, gpu, dtype, nhwc):
                                rtol=1e-6 if dtype == torch.float32 else 8e-3, atol=1e-7)
 
 
-@pytest.mark.parametrize("n,ci,co", [(2, 2048, 256), (1, 64, 8), (16, 320, 256)])
+@pytest.mark.parametrize("n,ci,co", [(2, 2048, 256), (1, 64, 8), (8, 320, 256)])
 def test_linear_small(pkg, gpu, n, ci, co):
     torch.manual_seed(12)
     x, w = torch.randn(n, ci), torch.randn(co, ci, 1, 1) * 0.05
