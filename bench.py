@@ -123,7 +123,7 @@ def cpu_baseline_seg(arch, batch, pgd_steps, side, timed_steps):
     crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
     x, y = synth_seg(batch, side, torch.Generator().manual_seed(3))
     kw = dict(steps=pgd_steps, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True)
-    orc.seg_train_step(model, opt, crit, x[:1, :, :129, :129].contiguous(), y[:1, :129, :129].contiguous(), **kw)   # warm-up (small)
+    orc.seg_train_step(model, opt, crit, x[:2, :, :129, :129].contiguous(), y[:2, :129, :129].contiguous(), **kw)   # warm-up (small)
     per = []
     for _ in range(timed_steps):
         t0 = time.perf_counter()
@@ -133,7 +133,7 @@ def cpu_baseline_seg(arch, batch, pgd_steps, side, timed_steps):
     return {"value": round(batch * timed_steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
             "kind": "port", "cpu": cpu_model(),
             "sample": f"{timed_steps} full iteration(s) of the same workload (batch {batch}, {side}x{side}, K={pgd_steps}, fp32) "
-                      f"after one 1x129x129 warm-up; per step {[round(p, 1) for p in per]} s; host {os.cpu_count()} logical CPUs"}
+                      f"after one 2x129x129 warm-up; per step {[round(p, 1) for p in per]} s; host {os.cpu_count()} logical CPUs"}
 
 
 def synth_seg(batch, side, g):

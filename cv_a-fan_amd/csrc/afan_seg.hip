@@ -450,27 +450,31 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dx_kernel(const float* __rest
     }
 }
 
-// dw partials: persistent workgroups walk 64-pixel slices; thread = input channel, the slice's dy tile in LDS (read as
-// broadcasts), 8 independent x loads in flight; slab[blk][Co][Ci] + bslab[blk][Co], folded in two stages (PW_FOLD groups)
+// dw partials: persistent single-wave workgroups walk 64-pixel slices; a lane owns FOUR consecutive input channels (one
+// 8- or 16-byte load per row, each broadcast LDS read of a dy value feeds four FMAs), the slice's dy tile sits in LDS;
+// slab[blk][Co][Ci] + bslab[blk][Co], folded in two stages (PW_FOLD groups).
 constexpr int PW_SLICE = 64;
 constexpr int PW_FOLD = 16;
+constexpr int PW_DW_THREADS = 64;
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void pointwise_dw_kernel(const float* __restrict__ dy, const T* __restrict__ x,
-                                                             float* __restrict__ slab, float* __restrict__ bslab,
-                                                             int64_t M, int Ci, int Co) {
+__global__ __launch_bounds__(PW_DW_THREADS) void pointwise_dw_kernel(const float* __restrict__ dy, const T* __restrict__ x,
+                                                                     float* __restrict__ slab, float* __restrict__ bslab,
+                                                                     int64_t M, int Ci, int Co) {
     __shared__ float g[PW_SLICE][PW_MAX_CO];
     const int64_t slices = (M + PW_SLICE - 1) / PW_SLICE;
     float bsum = 0.f;
-    for (int c0 = 0; c0 < Ci; c0 += BLOCK) {
-        const int c = c0 + threadIdx.x;
-        float acc[PW_MAX_CO];
+    for (int c0 = 0; c0 < Ci; c0 += 4 * PW_DW_THREADS) {
+        const int c = c0 + 4 * threadIdx.x;
+        float acc[PW_MAX_CO][4];
 #pragma unroll
-        for (int o = 0; o < PW_MAX_CO; ++o) acc[o] = 0.f;
+        for (int o = 0; o < PW_MAX_CO; ++o)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[o][k] = 0.f;
         for (int64_t sl = blockIdx.x; sl < slices; sl += gridDim.x) {
             const int64_t m0 = sl * PW_SLICE;
             const int rows = (int)((M - m0) < PW_SLICE ? (M - m0) : PW_SLICE);
             __syncthreads();
-            for (int i = threadIdx.x; i < PW_SLICE * Co; i += BLOCK) {
+            for (int i = threadIdx.x; i < PW_SLICE * Co; i += PW_DW_THREADS) {
                 const int r = i / Co, o = i - r * Co;
                 g[r][o] = r < rows ? dy[(m0 + r) * Co + o] : 0.f;
             }
@@ -478,22 +482,41 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dw_kernel(const float* __rest
             if (c0 == 0 && (int)threadIdx.x < Co)
                 for (int r = 0; r < rows; ++r) bsum += g[r][threadIdx.x];
             if (c < Ci) {
-                for (int r0 = 0; r0 < PW_SLICE; r0 += 8) {
-                    float xv[8];
+                for (int r0 = 0; r0 < PW_SLICE; r0 += 4) {
+                    float xv[4][4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[j] = (r0 + j < rows) ? Elt<T>::ld(x + (m0 + r0 + j) * Ci + c) : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        if (r0 + j < rows) {
+                            if constexpr (sizeof(T) == 2) {
+                                const u16x4 t = *reinterpret_cast<const u16x4*>(x + (m0 + r0 + j) * Ci + c);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                                for (int k = 0; k < 4; ++k) xv[j][k] = bf2f(t[k]);
+                            } else {
+                                const f32x4 t = *reinterpret_cast<const f32x4*>(x + (m0 + r0 + j) * Ci + c);
+                                xv[j][0] = t.x; xv[j][1] = t.y; xv[j][2] = t.z; xv[j][3] = t.w;
+                            }
+                        } else {
 #pragma unroll
-                        for (int o = 0; o < PW_MAX_CO; ++o)
-                            if (o < Co) acc[o] = fmaf(g[r0 + j][o], xv[j], acc[o]);
+                            for (int k = 0; k < 4; ++k) xv[j][k] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int o = 0; o < PW_MAX_CO; ++o) {
+                            if (o < Co) {
+                                const float gv = g[r0 + j][o];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[o][k] = fmaf(gv, xv[j][k], acc[o][k]);
+                            }
+                        }
                 }
             }
         }
         if (c < Ci) {
 #pragma unroll
             for (int o = 0; o < PW_MAX_CO; ++o)
-                if (o < Co) slab[((int64_t)blockIdx.x * Co + o) * Ci + c] = acc[o];
+                if (o < Co) *reinterpret_cast<f32x4*>(slab + ((int64_t)blockIdx.x * Co + o) * Ci + c) = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
         }
     }
     if ((int)threadIdx.x < Co) bslab[(int64_t)blockIdx.x * Co + threadIdx.x] = bsum;
@@ -859,7 +882,7 @@ int afan_pointwise_bwd_dx(const float* dy, const float* w, void* dx, int dx_dtyp
 
 static int pw_blocks(int64_t m) {
     const int64_t slices = (m + PW_SLICE - 1) / PW_SLICE;
-    return (int)(slices < 512 ? slices : 512);
+    return (int)(slices < 1024 ? slices : 1024);
 }
 
 int64_t afan_pointwise_workspace_floats(int64_t m, int64_t ci, int64_t co) {
@@ -878,8 +901,8 @@ int afan_pointwise_bwd_dw(const float* dy, const void* x, int x_dtype, float* dw
     float* part = bslab + (int64_t)G * co;
     const int es = x_dtype == AFAN_F32 ? 4 : 2;
     AFAN_PROF("pointwise_dw_kernel", (double)m * (es * ci + 4.0 * co) + 8.0 * G * co * ci, st);
-    if (x_dtype == AFAN_F32) pointwise_dw_kernel<float><<<G, BLOCK, 0, st>>>(dy, (const float*)x, workspace, bslab, m, (int)ci, (int)co);
-    else pointwise_dw_kernel<uint16_t><<<G, BLOCK, 0, st>>>(dy, (const uint16_t*)x, workspace, bslab, m, (int)ci, (int)co);
+    if (x_dtype == AFAN_F32) pointwise_dw_kernel<float><<<G, PW_DW_THREADS, 0, st>>>(dy, (const float*)x, workspace, bslab, m, (int)ci, (int)co);
+    else pointwise_dw_kernel<uint16_t><<<G, PW_DW_THREADS, 0, st>>>(dy, (const uint16_t*)x, workspace, bslab, m, (int)ci, (int)co);
     AFAN_LAUNCH_CHECK();
     const unsigned gx = (unsigned)((co * ci + co + BLOCK - 1) / BLOCK);
     pointwise_dw_fold_kernel<<<dim3(gx, PW_FOLD), BLOCK, 0, st>>>(workspace, bslab, part, G, (int)ci, (int)co);

@@ -133,7 +133,7 @@ def test_deeplab_step_bf16_runs_on_the_library_kernels(pkg, gpu, case):
         fm = r["fm_se"].float().cpu().numpy()
         assert np.linalg.norm((fm - g["fm_se"]).ravel()) <= 0.04 * np.linalg.norm(g["fm_se"].ravel())
         assert abs(float(r["loss"]) - loss) <= 5e-3, (float(r["loss"]), loss)
-        _grad_check(pkg, tr, g, 0.12, 0.12, 0.5)
+        _grad_check(pkg, tr, g, 0.12, 0.2, 0.5)
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("sd1/") and k.endswith("num_batches_tracked"):

@@ -1,11 +1,13 @@
 #!/bin/bash
-# per-dispatch durations of the default bench, aggregated by (kernel, grid): gpurun_out/trace_by_grid.txt
+# per-dispatch durations of a bench run, aggregated by (kernel, grid): gpurun_out/${TAG}_trace_by_grid.txt
+#   bash tools/gpu_trace.sh TAG [bench.py args...]
+TAG=${1:-x}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -rf /tmp/trace_out; cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no_cpu_baseline --no_roofline > /tmp/bench_trace.log 2>&1
+rm -rf /tmp/trace_out; cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_out -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps 6 --warmup 3 --no_cpu_baseline --no_roofline > /tmp/bench_trace.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 - <<'PY'
-import csv, glob, collections
+TAG=$TAG python3 - <<'PY'
+import csv, glob, collections, os
 f = glob.glob('/tmp/trace_out/**/*kernel_trace.csv', recursive=True)[0]
 agg = collections.defaultdict(list)
 rows = list(csv.DictReader(open(f)))
@@ -21,7 +23,7 @@ for k, v in agg.items():
     v = sorted(v)
     out.append((sum(v), k, len(v), v[len(v)//2], v[0], v[-1]))
 out.sort(reverse=True)
-with open('gpurun_out/trace_by_grid.txt', 'w') as fo:
+with open('gpurun_out/%s_trace_by_grid.txt' % os.environ.get('TAG', 'x'), 'w') as fo:
     for tot, k, n, med, lo, hi in out[:60]:
         line = f"{tot/1e6:9.3f} ms  n={n:5d} med={med/1e3:7.1f}us min={lo/1e3:7.1f} max={hi/1e3:7.1f}  {k}"
         print(line); fo.write(line + "\n")
