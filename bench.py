@@ -152,14 +152,19 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, arch):
     """HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes: the guide's gfx950 correction) of `kernel_name` from the
-    newest profiles/*_pmc_hbm_traffic*.json that has it; (bytes, source file, stale?) or None."""
+    newest profiles/*_pmc_hbm_traffic*.json collected on THIS workload (its `_meta.command` names the same --arch; summaries
+    without `_meta` predate round 2 and count as the default workload) that has it; (bytes, source file, stale?, command) or None."""
     base = kernel_name.replace("_fwd_kernel", "_kernel").replace("_dgrad_kernel", "_kernel")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
         try:
             pmc = json.load(open(f))
         except (OSError, ValueError):
+            continue
+        cmd = (pmc.get("_meta", {}).get("command") or "")
+        f_arch = cmd.split("--arch", 1)[1].split()[0] if "--arch" in cmd else "resnet18"
+        if f_arch != arch:
             continue
         key = next((k for k in pmc if not k.startswith("_") and (k == kernel_name or k == base or k in kernel_name)), None)
         if key and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
@@ -309,7 +314,7 @@ def main():
                     "algo_bytes_per_launch": round(v["bytes"] / v["launches"]), "handwritten_ms_per_step": hand_ms}
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process; the newest committed
         # summary of the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes supplies it (per launch)
-        tr = pmc_traffic(name)
+        tr = pmc_traffic(name, args.arch)
         if tr is not None:
             roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = tr[0], tr[1], tr[2]
             roof["traffic_note"] = ("rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch; stale = the kernel sources changed "

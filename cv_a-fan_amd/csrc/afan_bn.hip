@@ -489,7 +489,9 @@ __global__ __launch_bounds__(256) void running_update_batched_kernel(const RUBat
     const RUEntry& e = b.e[blockIdx.x];
     for (int c = threadIdx.x; c < e.c; c += blockDim.x) {
         const float mean = e.stats[c], is = e.stats[e.c + c];
-        const float varb = fmaxf(1.0f / (is * is) - e.eps, 0.f);
+        // biased variance back from the saved 1/sqrt(var + eps), in f64 (no second rounding on top of invstd's own: what is
+        // left is invstd's fp32 ulp, ~1.2e-7 * (var + eps) absolute — relevant only for channels with var << eps)
+        const float varb = (float)fmax(1.0 / ((double)is * (double)is) - (double)e.eps, 0.0);
         e.rm[c] = (1.0f - e.momentum) * e.rm[c] + e.momentum * mean;
         e.rv[c] = (1.0f - e.momentum) * e.rv[c] + e.momentum * (varb * e.unbias);
     }
@@ -501,7 +503,7 @@ __global__ void running_update_kernel(const float* __restrict__ stats, int C, fl
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
         const float mean = stats[c], is = stats[C + c];
-        const float varb = fmaxf(1.0f / (is * is) - eps, 0.f);
+        const float varb = (float)fmax(1.0 / ((double)is * (double)is) - (double)eps, 0.0);
         rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean;
         rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (varb * unbias);
     }

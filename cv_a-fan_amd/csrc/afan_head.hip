@@ -162,10 +162,12 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const float* __restric
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += expf(l[k] - m);
         const float lse = m + logf(s);
-        const int t = (int)target[r];
-        local += lse - l[t];
+        const int64_t t64 = target[r];
+        const bool bad = t64 < 0 || t64 >= K;       // torch asserts here: poison the loss instead of reading out of range
+        const int t = bad ? 0 : (int)t64;
+        local += bad ? NAN : lse - l[t];
         float* d = dlogits + (int64_t)r * K;
-        for (int k = 0; k < K; ++k) d[k] = (expf(l[k] - lse) - (k == t ? 1.f : 0.f)) * invn;
+        for (int k = 0; k < K; ++k) d[k] = bad ? NAN : (expf(l[k] - lse) - (k == t ? 1.f : 0.f)) * invn;
     }
     const float w = wave_sum(local);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;

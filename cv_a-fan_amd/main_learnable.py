@@ -57,6 +57,7 @@ def train(train_loader, trainer, epoch, args, log):
     trainer.model.train()
     wp_steps = len(train_loader)
     norm_l2, norm_linf = [], []
+    pend = []            # (loss, prec1, n) device scalars of EVERY iteration, flushed into the meters at print time
     for i, (inp, target) in enumerate(train_loader):
         if args.max_iters and i >= args.max_iters:
             break
@@ -67,12 +68,18 @@ def train(train_loader, trainer, epoch, args, log):
         r = trainer.step(inp, target)
         norm_l2.append(r["l2"])
         norm_linf.append(r["linf"])
+        pend.append((r["loss"].float(), r["prec1"], inp.size(0)))    # (graph replays hand out copies of the small outputs)
         if i % args.print_freq == 0:
-            losses.update(r["loss"].float().item(), inp.size(0))
-            top1.update(r["prec1"].item(), inp.size(0))
+            for lo, pr, n in pend:       # one host sync per print, every iteration counted (:263-268 update per iteration)
+                losses.update(lo.item(), n)
+                top1.update(pr.item(), n)
+            pend = []
             log("Epoch: [{0}][{1}/{2}]\t"
                 "Loss {loss.val:.4f} ({loss.avg:.4f})\t"
                 "Accuracy {top1.val:.3f} ({top1.avg:.3f})\t".format(epoch, i, len(train_loader), loss=losses, top1=top1))
+    for lo, pr, n in pend:
+        losses.update(lo.item(), n)
+        top1.update(pr.item(), n)
     l2m = torch.cat(norm_l2, dim=1).mean(dim=1).cpu()
     linfm = torch.cat(norm_linf, dim=1).mean(dim=1).cpu()
     log("l2 mean = {}".format(l2m))

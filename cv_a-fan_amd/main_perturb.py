@@ -100,10 +100,13 @@ class DeviceLoader:
     """Whole split resident in HBM as uint8 (CIFAR-10 train = 138 MB of 288 GB); per batch: shuffle index, random
     crop (pad 4) + horizontal flip (dataset.py:36-39) and the /255 ToTensor scaling run on the device."""
 
-    def __init__(self, x_u8, y, batch, device, train, rank=0, world=1, drop_last=True):
+    def __init__(self, x_u8, y, batch, device, train, rank=0, world=1, drop_last=True, seed=None):
         self.x = torch.as_tensor(x_u8).to(device)
         self.y = torch.as_tensor(y).to(device)
         self.batch, self.train, self.rank, self.world, self.device = batch, train, rank, world, device
+        # data parallel: every rank must slice the SAME permutation (its own CPU generator would give overlapping shards):
+        # a generator seeded with (seed + epoch), `seed` agreed on by all ranks (main() broadcasts rank 0's draw)
+        self.seed, self.epoch = seed, 0
         n = self.x.shape[0]
         self.n_batches = n // batch if drop_last else (n + batch - 1) // batch
 
@@ -112,7 +115,15 @@ class DeviceLoader:
 
     def __iter__(self):
         n = self.x.shape[0]
-        perm = torch.randperm(n) if self.train else torch.arange(n)   # CPU generator, like DataLoader's sampler
+        if not self.train:
+            perm = torch.arange(n)
+        elif self.world > 1:
+            if self.seed is None:
+                raise RuntimeError("a data-parallel DeviceLoader needs a seed shared by all ranks")
+            perm = torch.randperm(n, generator=torch.Generator().manual_seed(int(self.seed) + self.epoch))
+            self.epoch += 1
+        else:
+            perm = torch.randperm(n)                                  # CPU generator, like DataLoader's sampler
         per = self.batch // self.world
         for b in range(self.n_batches):
             idx = perm[b * self.batch:(b + 1) * self.batch]
@@ -254,7 +265,11 @@ def main(argv=None):
                                                    side=side, classes=classes)
     else:
         tr, va, te = _load_cifar10(args.data)
-        train_loader = DeviceLoader(tr[0], tr[1], args.batch_size, dev, True, rank, world)
+        shared = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)     # rank 0's draw (seeded or not) for everyone
+        if world > 1:
+            shared = shared.to(dev)
+            dist.broadcast(shared, src=0)
+        train_loader = DeviceLoader(tr[0], tr[1], args.batch_size, dev, True, rank, world, seed=int(shared.item()))
         val_loader = DeviceLoader(va[0], va[1], args.batch_size, dev, False, drop_last=False)
         test_loader = DeviceLoader(te[0], te[1], args.batch_size, dev, False, drop_last=False)
 

@@ -67,9 +67,23 @@ class GradAllReducer:
                 self._launch(start, end)
         return hook
 
-    def begin(self):
-        self.enabled = True
+    def begin(self, explicit=False):
+        """explicit=True: the caller announces finished ranges with launch_params(); the autograd hooks stay off."""
+        self.enabled = not explicit
         self._done = [0] * len(self.chunks)
+        self._covered = []
+
+    def launch_params(self, p_lo, p_hi):
+        """Start the exchange of the gradients of parameters [p_lo, p_hi) (arena order) NOW, on the side stream: the
+        caller guarantees that every kernel writing them has been issued on the current stream.  The library's layers
+        add their parameter gradients straight into the arena (no AccumulateGrad node runs, so no autograd hook can
+        tell when a gradient is final): the step announces finished ranges itself, segment by segment of its backward."""
+        if p_hi <= p_lo:
+            return
+        bounds = self.arena.offsets + [self.arena.numel]
+        start, end = bounds[p_lo], bounds[p_hi]
+        self._covered.append((start, end))
+        self._launch(start, end)
 
     def _launch(self, start, end):
         buf = self.arena.grad[start:end]
@@ -83,11 +97,23 @@ class GradAllReducer:
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(w)
 
+    _covered = ()
+
     def finish(self):
         self.enabled = False
-        for ci, (start, end, _) in enumerate(self.chunks):  # parameters that got no gradient this step
-            if self._done[ci] < self._need[ci]:
-                self._launch(start, end)
+        if self._covered:                                    # explicit ranges: reduce whatever they left out, then wait
+            pos = 0
+            for start, end in sorted(self._covered):
+                if start > pos:
+                    self._launch(pos, start)
+                pos = max(pos, end)
+            if pos < self.arena.numel:
+                self._launch(pos, self.arena.numel)
+            self._covered = []
+        else:
+            for ci, (start, end, _) in enumerate(self.chunks):  # parameters that got no gradient this step
+                if self._done[ci] < self._need[ci]:
+                    self._launch(start, end)
         for w in self._pending:
             w.wait()
         self._pending.clear()
@@ -138,7 +164,7 @@ class AfanTrainer:
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
                  group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True,
-                 share_head=True, fold_clean=None):
+                 share_head=True, fold_clean=None, segmented=None):
         self.model, self.criterion = model, criterion
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
@@ -151,6 +177,13 @@ class AfanTrainer:
         self.reducer = GradAllReducer(self.arena, allreduce_chunks, group) if self.world > 1 else None
         if self.world > 1:
             self.optimizer.grad_scale = 1.0 / self.world
+            self.sync_replicas()
+        import os
+        # exchange the tail's gradients stage by stage while the rest of the backward runs (folded schedule); 0: one
+        # blocking all-reduce after the backward (A/B, and the fallback if a piece-wise capture fails)
+        self.ddp_overlap = self.world > 1 and os.environ.get("AFAN_DDP_OVERLAP", "1") != "0"
+        self.segmented = bool(segmented)          # True: run the segmented (piece-wise) step on one GPU too (tests)
+        self._pieces = None
         self.async_wgrad = bool(async_wgrad)
         self.batch_final = bool(batch_final)      # adv + clean final passes as one grouped pass over the tail
         self._groupable_key, self._groupable = None, False
@@ -168,6 +201,19 @@ class AfanTrainer:
         self._static_out = None
         self._shape_key = None
         self._stream = None
+
+    def sync_replicas(self, src=0):
+        """Every rank starts from rank `src`'s parameters, momentum and BatchNorm buffers (the reference's nn.DataParallel
+        replicates module 0 every iteration; here replicas only ever see identical updates, so once is enough).  Without
+        it an unseeded launch (`--seed` unset, or 0: main_perturb.py:61) would average gradients of DIFFERENT weights."""
+        if not dist.is_initialized() or self.world <= 1:
+            return
+        a = self.arena
+        for t in (a.param, a.momentum_buf):
+            dist.broadcast(t, src=src, group=self.group)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=src, group=self.group)
+        a.refresh_shadow()
 
     # ------------------------------------------------------------------------------------------------ body
     FOLD_MIN_ELEMS = 0            # feature-map elements (batch x C x H x W) from which fold_clean=None folds (0: always)
@@ -247,6 +293,95 @@ class AfanTrainer:
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
                 "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
                 "feature_map": feature_map, "out_clean": output_clean.detach()}
+
+    def _tail_segments(self):
+        """[(a, b), ...] cutting the tail at its stage transitions (blocks that change the shape): the backward finishes
+        the LAST segment's parameter gradients first — 75 % of ResNet-18's parameters sit in the last stage."""
+        m, idx, ln = self.model, self.perturb_idx, self.layer_number
+        cuts = [idx]
+        for i in range(idx + 1, ln):
+            mod = m.sequential_model[i]
+            if getattr(mod, "_sc_kind", "identity") != "identity":
+                cuts.append(i)
+        cuts.append(ln)
+        return [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1)]
+
+    def _param_range(self, a, b):
+        """Arena parameter indices [lo, hi) of sequential_model[a:b] (named_parameters order is the Sequential's order)."""
+        pre = tuple(f"sequential_model.{i}." for i in range(a, b))
+        idxs = [i for i, n in enumerate(self.arena.names) if n.startswith(pre)]
+        return (idxs[0], idxs[-1] + 1) if idxs else (0, 0)
+
+    def _phases_folded(self, inp, target, out):
+        """The folded iteration (see _forward_backward_folded) as a generator for data-parallel runs: it yields the arena
+        parameter range whose gradients have just become final — the tail stage by stage from the last one (the tail is
+        run in segments, detached at the stage transitions, so that its backward can be issued piece by piece), then the
+        head — and the caller starts that range's all-reduce while the next piece runs.  Same arithmetic as the unsegmented
+        step; only the BatchNorm-backward sums across a cut are reduced stand-alone instead of in the next dgrad's epilogue.
+        `out`: dict filled with the step's observables at the end."""
+        from . import ops, resnet_s
+        m, idx, ln = self.model, self.perturb_idx, self.layer_number
+        segs = self._tail_segments()
+        ops.acc_reset(inp.device)
+        self.optimizer.zero_grad()
+        crit = resnet_s.fused_criterion(self.criterion, m)
+        half = ops.half(inp.device)
+
+        def run_segments(x0):
+            ins, outs, h = [x0], [], x0
+            for k, (a, b) in enumerate(segs):
+                o = m(h, end_point=b, start_point=a)
+                outs.append(o)
+                if k + 1 < len(segs):
+                    h = o.detach().requires_grad_(True)
+                    ins.append(h)
+            return ins, outs
+
+        with ops.bn_running_updates(2):
+            fm_clean = m(inp, end_point=idx, start_point=0)
+        xin = fm_clean.detach().requires_grad_(True)
+        with ops.record_bn_updates() as clean_bn:
+            c_ins, c_outs = run_segments(xin)
+        loss_clean = crit(c_outs[-1], target)
+        with resnet_s.stash_wgrad():
+            torch.autograd.backward(loss_clean, grad_tensors=half)
+            for k in range(len(segs) - 2, -1, -1):
+                c_outs[k].backward(c_ins[k + 1].grad)
+        g0 = xin.grad
+        feature_map = fm_clean.detach()
+        feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
+        feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
+                              gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
+                              randinit=False, clip=self.clip, with_norms=True, grad0=g0)
+        l2, linf = last_norms()
+        adv_in = getattr(feature_map_adv, "_afan_shadow", None)
+        if adv_in is None:
+            adv_in = feature_map_adv.detach()
+        a_ins, a_outs = run_segments(adv_in)
+        loss_adv = crit(a_outs[-1], target)
+        torch.autograd.backward(loss_adv, grad_tensors=half)                 # last segment (+ classifier head)
+        resnet_s.flush_wgrad(m.sequential_model[segs[-1][0]:segs[-1][1]])
+        yield self._param_range(*segs[-1])
+        for k in range(len(segs) - 2, -1, -1):
+            a_outs[k].backward(a_ins[k + 1].grad)
+            resnet_s.flush_wgrad(m.sequential_model[segs[k][0]:segs[k][1]])
+            if k == 0:
+                clean_bn.replay()                       # main_perturb.py:196's BatchNorm side effect, last in order
+            yield self._param_range(*segs[k])
+        if len(segs) == 1:
+            clean_bn.replay()
+        fm_clean.backward(g0)                           # the clean branch's gradient through the head
+        with torch.no_grad():
+            loss = (loss_adv + loss_clean) / 2
+            prec1 = (c_outs[-1].argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
+        out.update({"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),
+                    "prec1": prec1, "l2": l2, "linf": linf, "x_adv": feature_map_adv.detach(),
+                    "feature_map": feature_map, "out_clean": c_outs[-1].detach()})
+        yield self._param_range(0, idx)
+
+    def _ddp_phases_ok(self, inp):
+        want = self.segmented or (self.ddp_overlap and self.reducer is not None)
+        return bool(want and self._fold_ok(inp) and hasattr(self.model, "sequential_model"))
 
     def _forward_backward(self, inp, target, overlap_allreduce):
         if self._fold_ok(inp):
@@ -376,6 +511,17 @@ class AfanTrainer:
 
     def _step_eager(self, inp, target):
         self.optimizer._sync_lr()
+        if self._ddp_phases_ok(inp):
+            out = {}
+            if self.reducer is not None:
+                self.reducer.begin(explicit=True)
+            for rng in self._phases_folded(inp, target, out):
+                if self.reducer is not None:
+                    self.reducer.launch_params(*rng)
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.optimizer.step()
+            return out
         out = self._forward_backward(inp, target, overlap_allreduce=self.reducer is not None)
         if self.reducer is not None:
             self.reducer.finish()
@@ -383,7 +529,31 @@ class AfanTrainer:
         return out
 
     # ----------------------------------------------------------------------------------------------- graph
+    def _capture_pieces(self, inp, target):
+        """Data-parallel capture: one hipGraph per phase of _phases_folded; between two replays the host starts the
+        all-reduce of the range the finished piece completed (RCCL on the side stream), so the exchange of the last
+        stage's gradients — most of the bytes — runs under the rest of the backward.  The pieces share one memory pool."""
+        dev = inp.device
+        self._stream = torch.cuda.Stream(device=dev)
+        self._static_in = (inp.clone(), target.clone())
+        self._stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        out, pieces, pool = {}, [], None
+        gen = self._phases_folded(self._static_in[0], self._static_in[1], out)
+        for _ in range(len(self._tail_segments()) + 1):      # one piece per tail segment + the head (nothing follows the last)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
+                rng = next(gen)
+            pieces.append((g, rng))
+            pool = pieces[0][0].pool()
+        gen.close()
+        self._pieces, self._static_out = pieces, out
+        self._graph = pieces[0][0]
+        self._shape_key = (tuple(inp.shape), inp.dtype, tuple(target.shape))
+
     def _capture(self, inp, target):
+        if self._ddp_phases_ok(inp):
+            return self._capture_pieces(inp, target)
         dev = inp.device
         self._stream = torch.cuda.Stream(device=dev)
         self._static_in = (inp.clone(), target.clone())
@@ -400,10 +570,21 @@ class AfanTrainer:
         self._static_in[0].copy_(inp, non_blocking=True)
         self._static_in[1].copy_(target, non_blocking=True)
         self.optimizer._sync_lr()          # lr lives in device memory: the graph reads it, the host only writes it here
-        self._graph.replay()
-        if self.world > 1:
-            dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self._pieces is not None:
+            if self.reducer is not None:
+                self.reducer.begin(explicit=True)
+            for g, rng in self._pieces:
+                g.replay()
+                if self.reducer is not None:
+                    self.reducer.launch_params(*rng)
+            if self.reducer is not None:
+                self.reducer.finish()
             self.optimizer.step()
+        else:
+            self._graph.replay()
+            if self.world > 1:
+                dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+                self.optimizer.step()
         small = ("loss", "loss_adv", "loss_clean", "prec1", "l2", "linf")
         # graph-owned outputs are overwritten by the next replay: hand out copies of the small ones
         return {k: (v.clone() if k in small else v) for k, v in self._static_out.items()}

@@ -546,3 +546,33 @@ def test_folded_clean_pass_equals_reference_schedule(pkg, orc, gpu, arch, idx, d
         elif "running_" in k:
             np.testing.assert_allclose(b[4][k].numpy(), a[4][k].numpy(), rtol=(1e-4 if fp32 else 3e-2),
                                        atol=(1e-6 if fp32 else 5e-3), err_msg=k)
+
+
+@pytest.mark.parametrize("arch,idx,graph", [("resnet18", 6, False), ("resnet18", 6, True), ("resnet20s", 7, False)])
+def test_segmented_step_equals_unsegmented(pkg, orc, gpu, arch, idx, graph):
+    """The data-parallel form of the folded step (tail run in segments cut at the stage transitions, backward issued piece
+    by piece so that each stage's gradients can be all-reduced while the rest runs; one hipGraph per piece) against the
+    one-piece step on one GPU: same losses, gradients, weights and BatchNorm buffers after three iterations."""
+    res = {}
+    for seg in (False, True):
+        m = _build(pkg, orc, arch, gpu, dtype=torch.bfloat16)
+        m.set_channels_last(True)
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.05,
+                                        use_graph=graph, graph_warmup=1, segmented=seg)
+        torch.manual_seed(0)
+        x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
+        losses = [float(tr.step(x, y)["loss"]) for _ in range(3)]
+        if graph:
+            assert tr._graph is not None, tr._graph_failed
+            assert (tr._pieces is not None) == seg
+        if seg:
+            assert len(tr._tail_segments()) >= 2
+        res[seg] = (losses, tr.arena.grad.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=2e-3)
+    g0, g1 = res[False][1], res[True][1]
+    assert float((g1 - g0).norm() / g0.norm()) <= 2e-2
+    for k, v in res[False][2].items():
+        if "num_batches" in k:
+            assert int(res[True][2][k]) == int(v), k
+        elif "running" in k:
+            np.testing.assert_allclose(res[True][2][k].float().cpu().numpy(), v.float().cpu().numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
