@@ -64,6 +64,20 @@ def _worker(rank, world, port, ret):
         gathered = [torch.zeros_like(arena.grad) for _ in range(world)]
         dist.all_gather(gathered, arena.grad)
         assert all(torch.equal(gathered[0], t) for t in gathered)
+        # explicit ranges (what the segmented A-FAN step uses: the library's layers add parameter gradients straight into
+        # the arena, so no autograd hook can announce them): launched before finish(), in backward order, no hook fires;
+        # whatever the ranges leave out is reduced by finish(); nothing is reduced twice
+        npar = len(arena.params)
+        for covered in ([(npar - 2, npar), (2, npar - 2), (0, 2)], [(npar - 2, npar)], []):
+            arena.zero_grad()
+            reducer.begin(explicit=True)
+            crit(model(x), y).backward()
+            assert not reducer._pending                                   # hooks are off in explicit mode
+            for lo, hi in covered:
+                reducer.launch_params(lo, hi)
+                assert len(reducer._pending) >= 1                         # started before finish()
+            reducer.finish()
+            torch.testing.assert_close(arena.grad, ref, rtol=1e-5, atol=1e-6)
         # a chunk whose parameters got no gradient this step is still reduced by finish()
         arena.zero_grad()
         reducer.begin()

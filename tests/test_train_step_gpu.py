@@ -561,16 +561,19 @@ def test_segmented_step_equals_unsegmented(pkg, orc, gpu, arch, idx, graph):
                                         use_graph=graph, graph_warmup=1, segmented=seg)
         torch.manual_seed(0)
         x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
-        losses = [float(tr.step(x, y)["loss"]) for _ in range(3)]
+        losses = [float(tr.step(x, y)["loss"])]
+        grad1 = tr.arena.grad.clone()               # after the FIRST step: identical weights in both runs
+        losses += [float(tr.step(x, y)["loss"]) for _ in range(2)]
         if graph:
             assert tr._graph is not None, tr._graph_failed
             assert (tr._pieces is not None) == seg
         if seg:
             assert len(tr._tail_segments()) >= 2
-        res[seg] = (losses, tr.arena.grad.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+        res[seg] = (losses, grad1, {k: v.clone() for k, v in m.state_dict().items()})
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=2e-3)
     g0, g1 = res[False][1], res[True][1]
-    assert float((g1 - g0).norm() / g0.norm()) <= 2e-2
+    # same weights, same arithmetic except where a BatchNorm-backward reduction moved out of a dgrad epilogue at a cut
+    assert float((g1 - g0).norm() / g0.norm()) <= 1e-2, float((g1 - g0).norm() / g0.norm())
     for k, v in res[False][2].items():
         if "num_batches" in k:
             assert int(res[True][2][k]) == int(v), k
