@@ -23,6 +23,84 @@ import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------------------------------
+# bf16 emulation (for checking the product's bf16 channels-last path tighter than against the fp32 reference):
+# inside `with emulate_bf16():` the ResNets below round to bf16 at the points where the product stores bf16 —
+# the low-precision weight copy, every convolution output, every BatchNorm(+residual)(+ReLU) output, the normalised
+# image, the feature map PGD hands to the tail — and the gradients flowing back through those same points; sums,
+# statistics, the loss, parameter gradients and the SGD update stay fp32, as in the product.  Everything else in this
+# file is unchanged, so with emulation off the functions remain the bit-exact restatement of the reference.
+# --------------------------------------------------------------------------------------------------
+_EMU = [False]
+
+
+class emulate_bf16:
+    def __enter__(self):
+        self.old = _EMU[0]
+        _EMU[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _EMU[0] = self.old
+        return False
+
+
+class _RoundBoth(torch.autograd.Function):
+    """bf16 round-to-nearest-even of the value (forward) and of the gradient (backward): a tensor stored in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 copy of an fp32 master weight: rounded value forward, fp32 gradient backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _r(t):
+    return _RoundBoth.apply(t) if _EMU[0] else t
+
+
+def _conv(c, t):
+    """c(t) for a bias-free nn.Conv2d; under emulation: bf16 weights, bf16-rounded output (fp32 accumulate)."""
+    if not _EMU[0]:
+        return c(t)
+    return _RoundBoth.apply(F.conv2d(t, _RoundFwd.apply(c.weight), None, c.stride, c.padding, c.dilation))
+
+
+def _emu_sequential(layers, x):
+    """sequential_model[s:e](x) with the product's rounding points (only called under emulation)."""
+    i, n = 0, len(layers)
+    while i < n:
+        L = layers[i]
+        if isinstance(L, nn.Conv2d):
+            x = _conv(L, x)
+        elif isinstance(L, nn.BatchNorm2d):
+            if i + 1 < n and isinstance(layers[i + 1], nn.ReLU):
+                x = _r(F.relu(L(x)))
+                i += 1
+            else:
+                x = _r(L(x))
+        elif isinstance(L, ChannelNormalize):
+            x = _r(L(x))
+        else:
+            x = L(x)          # blocks round inside; pooling / flatten / the fp32 classifier do not round
+        i += 1
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
 # model protocol: model(x, end_point, start_point) == sequential_model[start_point:end_point](x)
 # --------------------------------------------------------------------------------------------------
 class ChannelNormalize(nn.Module):
@@ -66,6 +144,12 @@ class Block(nn.Module):
                 self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, t):
+        if _EMU[0]:
+            o = _r(F.relu(self.bn1(_conv(self.conv1, t))))
+            o = self.bn2(_conv(self.conv2, o))
+            sc = self.shortcut
+            res = _r(sc[1](_conv(sc[0], t))) if (isinstance(sc, nn.Sequential) and len(sc) == 2) else sc(t)
+            return _r(F.relu(o + res))
         o = F.relu(self.bn1(self.conv1(t)))
         o = self.bn2(self.conv2(o))
         o += self.shortcut(t)  # resnet_s.py:75 (in-place add, then relu)
@@ -92,6 +176,13 @@ class Bottleneck(nn.Module):
             self.shortcut = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, t):
+        if _EMU[0]:
+            o = _r(F.relu(self.bn1(_conv(self.conv1, t))))
+            o = _r(F.relu(self.bn2(_conv(self.conv2, o))))
+            o = self.bn3(_conv(self.conv3, o))
+            sc = self.shortcut
+            res = _r(sc[1](_conv(sc[0], t))) if len(sc) == 2 else t
+            return _r(F.relu(o + res))
         o = F.relu(self.bn1(self.conv1(t)))
         o = F.relu(self.bn2(self.conv2(o)))
         o = self.bn3(self.conv3(o))
@@ -123,6 +214,8 @@ class SlicedResNet50(nn.Module):
     def forward(self, x, end_point=None, start_point=0):
         if end_point is None:
             end_point = len(self.sequential_model)
+        if _EMU[0]:
+            return _emu_sequential(list(self.sequential_model[start_point:end_point]), x)
         return self.sequential_model[start_point:end_point](x)
 
 
@@ -152,6 +245,8 @@ class SlicedResNet(nn.Module):
     def forward(self, x, end_point=None, start_point=0):
         if end_point is None:
             end_point = len(self.sequential_model)
+        if _EMU[0]:
+            return _emu_sequential(list(self.sequential_model[start_point:end_point]), x)
         return self.sequential_model[start_point:end_point](x)
 
 
@@ -214,7 +309,7 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
         randinit_(x_adv, eps)
     x_adv.requires_grad_(True)
     for _ in range(steps):
-        out = model(x_adv, end_point=layer_number, start_point=start_idx)
+        out = model(_r(x_adv), end_point=layer_number, start_point=start_idx)    # (_r: identity unless emulate_bf16())
         loss = loss_fn(out, y)
         g = torch.autograd.grad(loss, x_adv, only_inputs=True)[0]
         with torch.no_grad():
@@ -281,7 +376,7 @@ def afan_train_step(model, optimizer, criterion, inp, target, *, steps, gamma, e
                           start_idx=perturb_idx, layer_number=layer_number, eps=eps / 255, randinit=randinit,
                           clip=clip)
     l2, linf = perturb_norms(feature_map_adv, feature_map)
-    out_adv = model(feature_map_adv, end_point=layer_number, start_point=perturb_idx)
+    out_adv = model(_r(feature_map_adv), end_point=layer_number, start_point=perturb_idx)
     out_clean = model(inp, end_point=layer_number, start_point=0)
     loss_adv = criterion(out_adv, target)
     loss_clean = criterion(out_clean, target)
