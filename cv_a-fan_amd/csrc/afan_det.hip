@@ -1,0 +1,320 @@
+// Detection operators of the A-FAN Detection step: the only native code the reference ships —
+//   NMS        Detection/support/src/cuda/nms.cu:23-67 (mask kernel) + :70-130 (host-side greedy scan)
+//   ROIAlign   Detection/support/src/cuda/ROIAlign_cuda.cu:65-122 (forward), :178-254 (backward)
+// re-done for gfx950.
+//
+// NMS: boxes are visited in descending-score order (`order`, computed by the caller's sort).  The 64 x 64 overlap tiles map
+// one to one onto wave64: one wave per tile, lane = row box, bit = column box, a 64-bit word per (row, column block).  Only
+// tiles on or above the diagonal are computed (the scan never reads the others).  The reference then copies the whole mask
+// to the HOST and scans it there (12 MB and a device sync per call at 9 770 boxes); here the greedy scan stays on the
+// device: one wave walks the column blocks in order, resolves a diagonal tile with 64 scalar steps on its 64 words, and ORs
+// the kept rows' words into the running `removed` bit set (LDS) for the blocks to the right.  Kept boxes are flagged at
+// their ORIGINAL index and compacted by a prefix sum — ascending original indices, what nms_cuda returns after its sort.
+// Suppression test: IoU > threshold like nms.cu:49 (inclusive = 0) or IoU >= threshold like nms_cpu.cpp:62 (inclusive = 1);
+// areas and intersections with the reference's +1 (pixel-inclusive corners).
+#include "afan_common.h"
+
+using namespace afan;
+
+namespace {
+
+constexpr int W64 = 64;
+
+__device__ __forceinline__ float iou_incl(const float* a, const float* b) {
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float w = fmaxf(right - left + 1.f, 0.f), h = fmaxf(bottom - top + 1.f, 0.f);
+    const float inter = w * h;
+    const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+    const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+    return inter / (sa + sb - inter);
+}
+
+// grid (col_blocks, col_blocks), one wave per tile
+__global__ __launch_bounds__(W64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ order, int n,
+                                                       float thresh, int inclusive, unsigned long long* __restrict__ mask,
+                                                       int col_blocks) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;
+    const int row_size = min(n - rb * W64, W64), col_size = min(n - cb * W64, W64);
+    __shared__ float cbox[W64 * 4];
+    if ((int)threadIdx.x < col_size) {
+        const float* src = boxes + order[cb * W64 + threadIdx.x] * 4;
+        cbox[threadIdx.x * 4 + 0] = src[0]; cbox[threadIdx.x * 4 + 1] = src[1];
+        cbox[threadIdx.x * 4 + 2] = src[2]; cbox[threadIdx.x * 4 + 3] = src[3];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < row_size) {
+        const int i = rb * W64 + threadIdx.x;
+        const float* p = boxes + order[i] * 4;
+        const float cur[4] = {p[0], p[1], p[2], p[3]};
+        unsigned long long t = 0;
+        const int start = (rb == cb) ? threadIdx.x + 1 : 0;
+        for (int j = start; j < col_size; ++j) {
+            const float v = iou_incl(cur, cbox + j * 4);
+            if (inclusive ? (v >= thresh) : (v > thresh)) t |= 1ULL << j;
+        }
+        mask[(int64_t)i * col_blocks + cb] = t;
+    }
+}
+
+// one wave; removed[] (col_blocks words) in LDS
+__global__ __launch_bounds__(W64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int64_t* __restrict__ order,
+                                                       int n, int col_blocks, uint8_t* __restrict__ kept_flag) {
+    extern __shared__ unsigned long long removed[];
+    const int lane = threadIdx.x;
+    for (int j = lane; j < col_blocks; j += W64) removed[j] = 0;
+    __syncthreads();
+    for (int b = 0; b < col_blocks; ++b) {
+        const int size = min(n - b * W64, W64);
+        // lane r holds the diagonal word of row b*64 + r
+        const unsigned long long diag = lane < size ? mask[(int64_t)(b * W64 + lane) * col_blocks + b] : 0ULL;
+        unsigned long long rem = removed[b];
+        unsigned long long keep = 0;
+        for (int r = 0; r < size; ++r) {                       // wave-uniform: every lane runs the same scalar recurrence
+            const unsigned long long dr = __shfl(diag, r, W64);
+            if (!((rem >> r) & 1ULL)) {
+                keep |= 1ULL << r;
+                rem |= dr;
+            }
+        }
+        if (lane < size && ((keep >> lane) & 1ULL)) kept_flag[order[b * W64 + lane]] = 1;
+        // OR the kept rows' words into the blocks to the right: lanes stride over the column blocks
+        for (int j = b + 1 + lane; j < col_blocks; j += W64) {
+            unsigned long long acc = removed[j];
+            unsigned long long k = keep;
+            while (k) {
+                const int r = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= mask[(int64_t)(b * W64 + r) * col_blocks + j];
+            }
+            removed[j] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// ascending original indices of the flagged boxes; one workgroup (prefix sum over chunks)
+constexpr int CP_THREADS = 1024;
+__global__ __launch_bounds__(CP_THREADS) void nms_compact_kernel(const uint8_t* __restrict__ kept_flag, int n, int64_t* __restrict__ keep_out,
+                                                                 int64_t* __restrict__ count_out) {
+    __shared__ int sums[CP_THREADS];
+    const int per = (n + CP_THREADS - 1) / CP_THREADS;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n);
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += kept_flag[i] ? 1 : 0;
+    sums[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < CP_THREADS; o <<= 1) {             // Hillis-Steele inclusive scan
+        const int v = (int)threadIdx.x >= o ? sums[threadIdx.x - o] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = sums[threadIdx.x] - c;
+    for (int i = lo; i < hi; ++i)
+        if (kept_flag[i]) keep_out[pos++] = i;
+    if (threadIdx.x == CP_THREADS - 1) count_out[0] = sums[threadIdx.x];
+}
+
+// ---- ROIAlign ---------------------------------------------------------------------------------------------------------------
+struct Bilin {
+    int y_low, x_low, y_high, x_high;
+    float w1, w2, w3, w4;
+    bool empty;
+};
+// ROIAlign_cuda.cu:16-62 / :125-170: sample points outside [-1, size] contribute nothing; clamped to the border otherwise
+__device__ __forceinline__ Bilin bilin_prep(int height, int width, float y, float x) {
+    Bilin b;
+    b.empty = (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width);
+    if (b.empty) { b.y_low = b.x_low = b.y_high = b.x_high = -1; b.w1 = b.w2 = b.w3 = b.w4 = 0.f; return b; }
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    b.y_low = (int)y;
+    b.x_low = (int)x;
+    if (b.y_low >= height - 1) { b.y_high = b.y_low = height - 1; y = (float)b.y_low; } else b.y_high = b.y_low + 1;
+    if (b.x_low >= width - 1) { b.x_high = b.x_low = width - 1; x = (float)b.x_low; } else b.x_high = b.x_low + 1;
+    const float ly = y - (float)b.y_low, lx = x - (float)b.x_low;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+    return b;
+}
+
+struct RoiGeom {
+    int batch;
+    float start_w, start_h, bin_h, bin_w;
+    int grid_h, grid_w;
+    float count;
+};
+__device__ __forceinline__ RoiGeom roi_geom(const float* roi, float scale, int ph_n, int pw_n, int sampling_ratio) {
+    RoiGeom g;
+    g.batch = (int)roi[0];
+    g.start_w = roi[1] * scale; g.start_h = roi[2] * scale;          // "Do not using rounding; this implementation detail is critical"
+    const float end_w = roi[3] * scale, end_h = roi[4] * scale;
+    const float rw = fmaxf(end_w - g.start_w, 1.f), rh = fmaxf(end_h - g.start_h, 1.f);   // malformed ROIs forced to 1x1
+    g.bin_h = rh / (float)ph_n; g.bin_w = rw / (float)pw_n;
+    g.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph_n);
+    g.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw_n);
+    g.count = (float)(g.grid_h * g.grid_w);
+    return g;
+}
+
+// index over the pooled output.  NCHW: (n, c, ph, pw) with pw fastest (the reference's layout); NHWC: (n, ph, pw, c) with c
+// fastest — lanes run along channels, so the four corner reads of a sample point are coalesced 256-byte rows.
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const T* __restrict__ x, const float* __restrict__ rois, T* __restrict__ y,
+                                                            int64_t total, float scale, int C, int H, int Wd, int PH, int PW,
+                                                            int sampling_ratio) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int pw, ph, c;
+        int64_t n;
+        if (NHWC) { c = (int)(idx % C); pw = (int)((idx / C) % PW); ph = (int)((idx / C / PW) % PH); n = idx / C / PW / PH; }
+        else { pw = (int)(idx % PW); ph = (int)((idx / PW) % PH); c = (int)((idx / PW / PH) % C); n = idx / PW / PH / C; }
+        const RoiGeom g = roi_geom(rois + n * 5, scale, PH, PW, sampling_ratio);
+        float out = 0.f;
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Bilin b = bilin_prep(H, Wd, yy, xx);
+                if (b.empty) continue;
+                float v1, v2, v3, v4;
+                if (NHWC) {
+                    const T* base = x + (int64_t)g.batch * H * Wd * C + c;
+                    v1 = Elt<T>::ld(base + ((int64_t)b.y_low * Wd + b.x_low) * C); v2 = Elt<T>::ld(base + ((int64_t)b.y_low * Wd + b.x_high) * C);
+                    v3 = Elt<T>::ld(base + ((int64_t)b.y_high * Wd + b.x_low) * C); v4 = Elt<T>::ld(base + ((int64_t)b.y_high * Wd + b.x_high) * C);
+                } else {
+                    const T* base = x + ((int64_t)g.batch * C + c) * H * Wd;
+                    v1 = Elt<T>::ld(base + b.y_low * Wd + b.x_low); v2 = Elt<T>::ld(base + b.y_low * Wd + b.x_high);
+                    v3 = Elt<T>::ld(base + b.y_high * Wd + b.x_low); v4 = Elt<T>::ld(base + b.y_high * Wd + b.x_high);
+                }
+                out += b.w1 * v1 + b.w2 * v2 + b.w3 * v3 + b.w4 * v4;
+            }
+        }
+        Elt<T>::st(y + idx, out / g.count);
+    }
+}
+
+// scatter with hardware fp32 atomics into a zeroed fp32 gradient map (the reference's atomicAdd, ROIAlign_cuda.cu:238-241:
+// the summation order — and so the last bits — varies from run to run there too)
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ rois, float* __restrict__ dx,
+                                                            int64_t total, float scale, int C, int H, int Wd, int PH, int PW,
+                                                            int sampling_ratio) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int pw, ph, c;
+        int64_t n;
+        if (NHWC) { c = (int)(idx % C); pw = (int)((idx / C) % PW); ph = (int)((idx / C / PW) % PH); n = idx / C / PW / PH; }
+        else { pw = (int)(idx % PW); ph = (int)((idx / PW) % PH); c = (int)((idx / PW / PH) % C); n = idx / PW / PH / C; }
+        const RoiGeom g = roi_geom(rois + n * 5, scale, PH, PW, sampling_ratio);
+        const float gtop = Elt<T>::ld(dy + idx);
+        for (int iy = 0; iy < g.grid_h; ++iy) {
+            const float yy = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+            for (int ix = 0; ix < g.grid_w; ++ix) {
+                const float xx = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+                const Bilin b = bilin_prep(H, Wd, yy, xx);
+                if (b.empty) continue;
+                const float g1 = gtop * b.w1 / g.count, g2 = gtop * b.w2 / g.count, g3 = gtop * b.w3 / g.count, g4 = gtop * b.w4 / g.count;
+                if (NHWC) {
+                    float* base = dx + (int64_t)g.batch * H * Wd * C + c;
+                    unsafeAtomicAdd(base + ((int64_t)b.y_low * Wd + b.x_low) * C, g1); unsafeAtomicAdd(base + ((int64_t)b.y_low * Wd + b.x_high) * C, g2);
+                    unsafeAtomicAdd(base + ((int64_t)b.y_high * Wd + b.x_low) * C, g3); unsafeAtomicAdd(base + ((int64_t)b.y_high * Wd + b.x_high) * C, g4);
+                } else {
+                    float* base = dx + ((int64_t)g.batch * C + c) * H * Wd;
+                    unsafeAtomicAdd(base + b.y_low * Wd + b.x_low, g1); unsafeAtomicAdd(base + b.y_low * Wd + b.x_high, g2);
+                    unsafeAtomicAdd(base + b.y_high * Wd + b.x_low, g3); unsafeAtomicAdd(base + b.y_high * Wd + b.x_high, g4);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of scratch afan_nms needs for n boxes: the overlap mask (n x ceil(n/64) 64-bit words) + one flag per box
+int64_t afan_nms_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    const int64_t cb = (n + W64 - 1) / W64;
+    return n * cb * 8 + ((n + 7) & ~(int64_t)7);
+}
+
+// boxes [n,4] fp32 (left, top, right, bottom; corners inclusive), order [n] int64 = indices by DESCENDING score;
+// keep_out [n] int64: the kept boxes' original indices, ascending, count_out[0] of them valid.
+int afan_nms(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
+             int64_t* keep_out, int64_t* count_out, afan_stream_t stream) {
+    if (n < 0 || n > (1 << 24)) return AFAN_ESHAPE;
+    if (!count_out) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return (int)hipMemsetAsync(count_out, 0, 8, st);
+    if (!boxes || !order || !workspace || !keep_out) return AFAN_ENULL;
+    if (!aligned(workspace, 8)) return AFAN_EALIGN;
+    const int cb = (int)((n + W64 - 1) / W64);
+    if ((size_t)cb * 8 > 64 * 1024) return AFAN_ESHAPE;          // the scan keeps one word per column block in LDS
+    unsigned long long* mask = (unsigned long long*)workspace;
+    uint8_t* flag = (uint8_t*)workspace + n * (int64_t)cb * 8;
+    hipError_t e = hipMemsetAsync(flag, 0, (size_t)n, st);
+    if (e != hipSuccess) return (int)e;
+    AFAN_PROF("nms_kernel", 16.0 * n + 8.0 * n * cb, st);
+    nms_mask_kernel<<<dim3(cb, cb), W64, 0, st>>>(boxes, order, (int)n, threshold, inclusive, mask, cb);
+    AFAN_LAUNCH_CHECK();
+    nms_scan_kernel<<<1, W64, (size_t)cb * 8, st>>>(mask, order, (int)n, cb, flag);
+    AFAN_LAUNCH_CHECK();
+    nms_compact_kernel<<<1, CP_THREADS, 0, st>>>(flag, (int)n, keep_out, count_out);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+static int roi_check(int dtype, int layout, int64_t num_rois, int64_t c, int64_t h, int64_t w, int ph, int pw) {
+    if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (layout != AFAN_NCHW && layout != AFAN_NHWC) return AFAN_ELAYOUT;
+    if (num_rois < 0 || c <= 0 || h <= 0 || w <= 0 || ph <= 0 || pw <= 0) return AFAN_ESHAPE;
+    return AFAN_OK;
+}
+
+// y[num_rois, C, PH, PW] (in `layout`: NCHW, or [num_rois, PH, PW, C]) from x[N, C, H, W]; rois [num_rois, 5] fp32 =
+// (batch index, x1, y1, x2, y2) in image coordinates; sampling_ratio <= 0: ceil(roi extent / pooled extent) samples per bin.
+int afan_roi_align_fwd(const void* x, const float* rois, void* y, int dtype, int layout, int64_t num_rois, int64_t c, int64_t h,
+                       int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, afan_stream_t stream) {
+    int e = roi_check(dtype, layout, num_rois, c, h, w, pooled_h, pooled_w);
+    if (e) return e;
+    if (num_rois == 0) return AFAN_OK;
+    if (!x || !rois || !y) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = num_rois * c * pooled_h * pooled_w;
+    const int grid = grid_for(total, 256, 8192);
+    AFAN_PROF("roi_align_fwd_kernel", (double)total * (dtype == AFAN_F32 ? 4 : 2) * 5, st);
+#define RA_(T, L) roi_align_fwd_kernel<T, L><<<grid, 256, 0, st>>>((const T*)x, rois, (T*)y, total, spatial_scale, (int)c, (int)h, (int)w, pooled_h, pooled_w, sampling_ratio)
+    if (dtype == AFAN_F32) { if (layout == AFAN_NHWC) RA_(float, true); else RA_(float, false); }
+    else { if (layout == AFAN_NHWC) RA_(uint16_t, true); else RA_(uint16_t, false); }
+#undef RA_
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// dx[N, C, H, W] fp32 (zeroed here, in `layout`) += scatter of dy[num_rois, C, PH, PW] (`dtype`, same layout convention)
+int afan_roi_align_bwd(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
+                       int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                       afan_stream_t stream) {
+    int e = roi_check(dtype, layout, num_rois, c, h, w, pooled_h, pooled_w);
+    if (e) return e;
+    if (n <= 0) return AFAN_ESHAPE;
+    if (!dx) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t he = hipMemsetAsync(dx, 0, (size_t)(n * c * h * w) * 4, st);
+    if (he != hipSuccess) return (int)he;
+    if (num_rois == 0) return AFAN_OK;
+    if (!dy || !rois) return AFAN_ENULL;
+    const int64_t total = num_rois * c * pooled_h * pooled_w;
+    const int grid = grid_for(total, 256, 8192);
+    AFAN_PROF("roi_align_bwd_kernel", (double)total * ((dtype == AFAN_F32 ? 4 : 2) + 16.0) + 4.0 * n * c * h * w, st);
+#define RB_(T, L) roi_align_bwd_kernel<T, L><<<grid, 256, 0, st>>>((const T*)dy, rois, dx, total, spatial_scale, (int)c, (int)h, (int)w, pooled_h, pooled_w, sampling_ratio)
+    if (dtype == AFAN_F32) { if (layout == AFAN_NHWC) RB_(float, true); else RB_(float, false); }
+    else { if (layout == AFAN_NHWC) RB_(uint16_t, true); else RB_(uint16_t, false); }
+#undef RB_
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // extern "C"

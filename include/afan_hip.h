@@ -355,6 +355,31 @@ int afan_dropout(const void* x, void* y, int dtype, int64_t n, float p, const ui
                  int advance, afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Detection operators: the reference's only native code, Detection/support/src/cuda/{nms,ROIAlign_cuda}.cu.
+ *
+ * afan_nms — `support._C.nms(dets, scores, threshold)` (nms.h:10-28 -> nms.cu:70-130).  boxes [n,4] fp32 (left, top, right,
+ * bottom, corners inclusive: areas and intersections use +1), order [n] int64 = box indices by DESCENDING score (the caller's
+ * sort, as nms.cu:73-75 sorts with ATen).  A box is dropped when its IoU with a kept box of higher score is > threshold
+ * (inclusive = 0: nms.cu:49) or >= threshold (inclusive = 1: the CPU path, nms_cpu.cpp:62).  keep_out [n] int64 receives the
+ * kept boxes' ORIGINAL indices in ascending order (what nms_cuda returns after its final sort), count_out[0] how many.  The
+ * greedy scan runs on the device (the reference copies the n x n/64 mask to the host and syncs).  workspace:
+ * afan_nms_workspace_bytes(n) bytes, 8-byte aligned. */
+int64_t afan_nms_workspace_bytes(int64_t n);
+int afan_nms(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
+             int64_t* keep_out, int64_t* count_out, afan_stream_t stream);
+/* afan_roi_align_{fwd,bwd} — `support._C.roi_align_forward / roi_align_backward` (ROIAlign.h:12-47 -> ROIAlign_cuda.cu:256-346).
+ * x [N,C,H,W], rois [num_rois,5] fp32 = (batch index, x1, y1, x2, y2) in image coordinates (scaled by spatial_scale, NOT
+ * rounded), y [num_rois,C,PH,PW]; sampling_ratio <= 0: ceil(roi extent / pooled extent) sample points per bin and axis.
+ * layout AFAN_NCHW (the reference's) or AFAN_NHWC (x [N,H,W,C], y [num_rois,PH,PW,C]: lanes along channels).
+ * bwd: dx fp32 [N,C,H,W] in `layout` is zeroed and receives the scatter of dy through hardware fp32 atomics, like the
+ * reference's atomicAdd (ROIAlign_cuda.cu:238-241): bitwise run-to-run reproducibility is not promised by either. */
+int afan_roi_align_fwd(const void* x, const float* rois, void* y, int dtype, int layout, int64_t num_rois, int64_t c, int64_t h,
+                       int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, afan_stream_t stream);
+int afan_roi_align_bwd(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
+                       int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                       afan_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Classifier head of the slice protocol: AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110), run at the
  * end of every tail pass.  x: channels-last [N,HW,C] (`dtype`); weight fp32 [K,C], bias fp32 [K] (nullable), K <=
  * afan_head_max_classes(); pooled fp32 [N,C] is kept for the backward; logits fp32 [N,K].

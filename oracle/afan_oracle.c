@@ -170,3 +170,98 @@ void oracle_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, fl
         p[i] = p[i] - lr * m[i];
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Detection operators.  NMS is pinned to the reference's own golden (Detection/test/nms/
+ * nms-large-{input,output}.npy, copied as data into tests/golden/) and to the three small cases of
+ * Detection/test/nms/test_nms.py:21-37.  ROIAlign: the reference holds no vector and its CPU source does not compile
+ * against this image's torch — PARITY UNPINNED for ROIAlign: the restatement below follows
+ * Detection/support/src/cuda/ROIAlign_cuda.cu line by line and is itself checked against closed-form cases.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Greedy NMS over boxes visited in `order` (descending score).  inclusive = 1: suppress at IoU >= thresh
+ * (Detection/support/src/cpu/nms_cpu.cpp:36-66); inclusive = 0: IoU > thresh (Detection/support/src/cuda/nms.cu:49).  Areas and
+ * intersections with +1 (nms_cpu.cpp:22,56-57; nms.cu:14-21).  keep_out: kept ORIGINAL indices, ascending; returns the count. */
+int64_t oracle_nms(const float* boxes, const int64_t* order, int64_t n, float thresh, int inclusive, int64_t* keep_out,
+                   unsigned char* suppressed /* scratch, n bytes */) {
+    for (int64_t i = 0; i < n; ++i) suppressed[i] = 0;
+    for (int64_t _i = 0; _i < n; ++_i) {
+        const int64_t i = order[_i];
+        if (suppressed[i]) continue;
+        const float ix1 = boxes[4 * i], iy1 = boxes[4 * i + 1], ix2 = boxes[4 * i + 2], iy2 = boxes[4 * i + 3];
+        const float iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
+        for (int64_t _j = _i + 1; _j < n; ++_j) {
+            const int64_t j = order[_j];
+            if (suppressed[j]) continue;
+            const float xx1 = fmaxf(ix1, boxes[4 * j]), yy1 = fmaxf(iy1, boxes[4 * j + 1]);
+            const float xx2 = fminf(ix2, boxes[4 * j + 2]), yy2 = fminf(iy2, boxes[4 * j + 3]);
+            const float w = fmaxf(0.f, xx2 - xx1 + 1), h = fmaxf(0.f, yy2 - yy1 + 1);
+            const float inter = w * h;
+            const float jarea = (boxes[4 * j + 2] - boxes[4 * j] + 1) * (boxes[4 * j + 3] - boxes[4 * j + 1] + 1);
+            const float ovr = inter / (iarea + jarea - inter);
+            if (inclusive ? (ovr >= thresh) : (ovr > thresh)) suppressed[j] = 1;
+        }
+    }
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (!suppressed[i]) keep_out[k++] = i;
+    return k;
+}
+
+typedef struct { int yl, xl, yh, xh; float w1, w2, w3, w4; int empty; } oracle_bilin;
+/* ROIAlign_cuda.cu:16-62 / :125-170 */
+static oracle_bilin oracle_bilin_prep(int height, int width, float y, float x) {
+    oracle_bilin b;
+    b.empty = (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width);
+    b.yl = b.xl = b.yh = b.xh = -1; b.w1 = b.w2 = b.w3 = b.w4 = 0.f;
+    if (b.empty) return b;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    b.yl = (int)y; b.xl = (int)x;
+    if (b.yl >= height - 1) { b.yh = b.yl = height - 1; y = (float)b.yl; } else b.yh = b.yl + 1;
+    if (b.xl >= width - 1) { b.xh = b.xl = width - 1; x = (float)b.xl; } else b.xh = b.xl + 1;
+    const float ly = y - b.yl, lx = x - b.xl, hy = 1.f - ly, hx = 1.f - lx;
+    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+    return b;
+}
+
+/* mode 0: forward (ROIAlign_cuda.cu:65-122): y[num_rois,C,PH,PW] from x[N,C,H,W] (NCHW fp32);
+ * mode 1: backward (:178-254): x is the zero-initialised gradient map that dy = y scatters into, in index order. */
+void oracle_roi_align(float* x, const float* rois, float* y, int64_t num_rois, int64_t C, int64_t H, int64_t W, int PH, int PW,
+                      float scale, int sampling_ratio, int mode) {
+    for (int64_t n = 0; n < num_rois; ++n) {
+        const float* r = rois + n * 5;
+        const int b = (int)r[0];
+        const float sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
+        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
+        const float bh = rh / (float)PH, bw = rw / (float)PW;
+        const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+        const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+        const float count = (float)(gh * gw);
+        for (int64_t c = 0; c < C; ++c) {
+            float* plane = x + ((int64_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    float* out = y + ((n * C + c) * PH + ph) * PW + pw;
+                    float acc = 0.f;
+                    for (int iy = 0; iy < gh; ++iy) {
+                        const float yy = sh + ph * bh + ((float)iy + .5f) * bh / (float)gh;
+                        for (int ix = 0; ix < gw; ++ix) {
+                            const float xx = sw + pw * bw + ((float)ix + .5f) * bw / (float)gw;
+                            const oracle_bilin q = oracle_bilin_prep((int)H, (int)W, yy, xx);
+                            if (q.empty) continue;
+                            if (mode == 0) {
+                                acc += q.w1 * plane[q.yl * W + q.xl] + q.w2 * plane[q.yl * W + q.xh] + q.w3 * plane[q.yh * W + q.xl] +
+                                       q.w4 * plane[q.yh * W + q.xh];
+                            } else {
+                                const float g = *out;
+                                plane[q.yl * W + q.xl] += g * q.w1 / count; plane[q.yl * W + q.xh] += g * q.w2 / count;
+                                plane[q.yh * W + q.xl] += g * q.w3 / count; plane[q.yh * W + q.xh] += g * q.w4 / count;
+                            }
+                        }
+                    }
+                    if (mode == 0) *out = acc / count;
+                }
+        }
+    }
+}

@@ -46,6 +46,10 @@ def _c_oracle():
     lib.oracle_bn_train_forward.argtypes = [_p, _p, _p, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p]
     lib.oracle_bn_backward.argtypes = [_p, _p, _p, _p, _p, _l, _l, _l, _p, _p, _p, _i, _p, _p]
     lib.oracle_sgd_step.argtypes = [_p, _p, _p, _l, _f, _f, _f, _f]
+    lib.oracle_nms.argtypes = [_p, _p, _l, _f, _i, _p, _p]
+    lib.oracle_nms.restype = _l
+    lib.oracle_roi_align.argtypes = [_p, _p, _p, _l, _l, _l, _l, _i, _i, _f, _i, _i]
+    lib.oracle_roi_align.restype = None
     for n in ("oracle_pgd_step", "oracle_axpy_noise", "oracle_perturb_norms", "oracle_mix_feature",
               "oracle_lerp_points", "oracle_bn_train_forward", "oracle_bn_backward", "oracle_sgd_step"):
         getattr(lib, n).restype = None
