@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libafan_hip.so")
+# AFAN_HIP_LIB: another build of the SAME library (diagnostic builds of tools/build_ablate.sh); never a different backend
+LIB_PATH = os.environ.get("AFAN_HIP_LIB") or os.path.join(_HERE, "libafan_hip.so")
 
 AFAN_F32, AFAN_BF16 = 0, 1
 AFAN_NCHW, AFAN_NHWC = 0, 1
@@ -57,6 +58,9 @@ SIGNATURES = {
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
     "afan_conv_wgrad2_nhwc_bf16": (_i, [_p, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
+    "afan_pack_weights_elems": (_l, [_l, _l, _l]),
+    "afan_pack_weights": (_i, [_p, _p, _l, _l, _l, _p]),
+    "afan_conv_fwd_breg_exp": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p]),
     "afan_conv_stem7_supported": (_i, [_l, _l, _i, _i]),
     "afan_conv_stem7_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "afan_conv_stem7_im2col_k": (_i, []),

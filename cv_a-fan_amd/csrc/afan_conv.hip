@@ -25,6 +25,10 @@
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
+#ifndef AFAN_CONV_FRAG_BATCH
+#define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
+#endif
+
 using namespace afan;
 using namespace afan_conv;
 
@@ -51,11 +55,19 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 
 // PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
 // the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
-template <int BM, int BN, int PF, int WM, int WN>   // WM x WN waves: pixels x channels
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp) {
+// PW > 0: PW extra PRODUCER waves issue every operand DMA and the WM x WN waves only read LDS and issue MFMAs.  An LDS-DMA
+// instruction holds its wave's issue slot for 60-185 cycles (tools/conv_ablate_bench.py: MFMAs on constant fragments
+// 12.0 us, the same plus the DMA 19.8 us, DMA alone 13.8 us on the 256-channel 8x8 layer — the two serialise inside a
+// wave); in a producer wave that stall costs no MFMA slot.
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0>   // WM x WN waves: pixels x channels
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const ConvP pp) {
     constexpr int NW = WM * WN;
-    constexpr int THREADS = 64 * NW;
-    constexpr int RPP = THREADS / 8;                  // rows staged per pass of the workgroup
+    constexpr int THREADS = 64 * (NW + PW);
+    constexpr int STG = PW ? 64 * PW : THREADS;       // threads that stage operands
+    constexpr int RPP = STG / 8;                      // rows staged per pass of the workgroup
+#if AFAN_CONV_ABLATE == 7
+    return;
+#endif
     const ConvClass& cc = pp.cls[blockIdx.z];
     const uint32_t Wg = (uint32_t)cc.Wg, Hg = (uint32_t)cc.Hg;
     const uint32_t M = (uint32_t)pp.N * Hg * Wg;
@@ -81,8 +93,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     __shared__ int out_off[BM];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = PW ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wr = wave / WN, wc = wave % WN;
+    const bool producer = PW && wave >= NW;           // wave-uniform
+    const int stid = PW ? tid - 64 * NW : tid, swave = PW ? wave - NW : wave;   // index among the staging threads / waves
     const int n0 = blockIdx.x * BN;
     const int T = cc.T, Ci = pp.Ci, Hi = pp.Hi, Wi = pp.Wi;
 
@@ -99,8 +114,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     // fix is a swizzle instead of padding: row r keeps its 16-byte piece q at position q ^ ((r >> 1) & 7).  Seen from
     // the source side, thread t (linear LDS position: row t/8 + 32 i, slot t & 7) fetches logical piece
     // (t & 7) ^ ((t >> 4) & 7) — the same for all its rows.
-    const int piece = GLDS ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
-    const int row0 = tid >> 3;
+    const int piece = GLDS ? ((stid & 7) ^ ((stid >> 4) & 7)) : (stid & 7);
+    const int row0 = stid >> 3;
     uint32_t a_off[A_ROWS];   // byte offset of (n, hi0, wi0, piece*8)
     uint32_t a_valid[A_ROWS];
 #pragma unroll
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         const uint32_t m = m0 + row0 + RPP * i;
         a_off[i] = 0;
         a_valid[i] = 0;
-        if (m < M) {
+        if (m < M && (!PW || producer)) {
             const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
             const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
             const int hi0 = (int)hg * pp.in_s, wi0 = (int)wg * pp.in_s;
@@ -151,7 +166,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     // 64-channel chunk of a tap is partly beyond Ci — those 16-byte pieces are requested at an out-of-range offset (zeros
     // from the hardware range check) for BOTH operands, and weight rows / output channels >= Co are masked the same way.
     const int chunks = (Ci + BK - 1) / BK;
+#if AFAN_CONV_ABLATE == 5
+    const int KS = 0;
+#else
     const int KS = T * chunks;
+#endif
     const bool last_ok = (chunks - 1) * BK + piece * 8 < Ci;      // this thread's piece exists in the last chunk
     u32x4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
 
@@ -180,25 +199,47 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
             *reinterpret_cast<u32x4*>(B + (row0 + RPP * i) * LDK + piece * 8) = rb[i];
     };
     auto compute = [&](int buf) {
+#if AFAN_CONV_ABLATE == 2
+        return;
+#endif
         const uint16_t* A = lds + buf * STAGE;
         const uint16_t* B = A + BM * LDR;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
         const int sw = (frow >> 1) & 7;     // GLDS swizzle of this lane's row (tile bases are multiples of 32 rows)
+        // Fragments of FB k16-slices are requested before the first MFMA that uses them (the compiler's own order reuses
+        // four fragment registers and waits for every read: one exposed LDS latency per MFMA pair — measured 1 150 cycles
+        // per K-step with NO operand traffic at all, against 512 of MFMA).
+        constexpr int FB = AFAN_CONV_FRAG_BATCH;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 fx[MI], fw[NI];
-            const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ sw) * 8) : (kk * 16 + fk);
+        for (int k0 = 0; k0 < BK / 16; k0 += FB) {
+            bf16x8 fx[FB][MI], fw[FB][NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                fx[i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
+            for (int b = 0; b < FB; ++b) {
+                const int kk = k0 + b;
+                const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ sw) * 8) : (kk * 16 + fk);
+#if AFAN_CONV_ABLATE == 3 || AFAN_CONV_ABLATE == 8
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                fw[j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
+                for (int i = 0; i < MI; ++i) fx[b][i] = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)lane, (uint32_t)buf, 0u, 0u});
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NI; ++j) fw[b][j] = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)lane, (uint32_t)kk, 0u, 0u});
+#else
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+                    fx[b][i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
+#endif
+            }
+            if (FB > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
+            if (FB > 1) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -226,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         const int t = dma_t;
         const int a_tap = dma_a, b_tap = dma_b;
         const bool pk = dma_q + 1 < chunks || last_ok;
-        uint16_t* A = lds + buf * STAGE + wave * 512;          // wave-uniform: M0 base; hardware adds lane * 16 B
+        uint16_t* A = lds + buf * STAGE + swave * 512;          // wave-uniform: M0 base; hardware adds lane * 16 B
         uint16_t* B = A + BM * LDR;
         typedef __attribute__((address_space(3))) void* lptr;
 #pragma unroll
@@ -251,7 +292,41 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         }
     };
 
-    if constexpr (GLDS && NS > 2) {
+    if constexpr (PW > 0) {
+        static_assert(GLDS && NS > 2, "producer waves: LDS-DMA with a counted multi-stage pipeline only");
+        constexpr int LPT = A_ROWS + B_ROWS;
+        // Two separate loops with the same barrier count (one loop with a role branch inside made the compiler copy all
+        // 64 accumulator registers around the branch on every K-step).
+        if (producer) {
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < KS) gdma(s, s);
+            int buf = 0;
+            for (int ks = 0; ks < KS; ++ks) {
+                const int rem = KS - 1 - ks;             // this wave's pieces of tile ks have landed:
+                if (rem >= NS - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * (NS - 2)));
+                else if (NS == 4 && rem == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
+                else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
+                __builtin_amdgcn_s_barrier();            // tile ks is in LDS for everyone; buffer of tile ks-1 is free
+#endif
+#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
+                if (ks + NS - 1 < KS) gdma(ks + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+#endif
+                buf = buf + 1 == NS ? 0 : buf + 1;
+            }
+        } else {
+            int buf = 0;
+            for (int ks = 0; ks < KS; ++ks) {
+#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
+                __builtin_amdgcn_s_barrier();
+#endif
+                compute(buf);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+            }
+        }
+        __syncthreads();
+    } else if constexpr (GLDS && NS > 2) {
         // Deep pipeline for launches of about one workgroup per CU (the 8x8 and 4x4 stages: few, long K loops): with two
         // buffers and __syncthreads() every DMA has to land within ONE step's MFMAs (a few hundred cycles against
         // 1-2 k of memory latency).  Here NS - 1 tiles are in flight; the wait is counted (vmcnt(N) leaves the younger
@@ -266,8 +341,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
             if (rem >= NS - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * (NS - 2)));
             else if (NS == 4 && rem == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             __builtin_amdgcn_s_barrier();                // tile ks is in LDS for everyone; buffer of tile ks-1 is free
+#endif
+#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             if (ks + NS - 1 < KS) gdma(ks + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+#endif
             compute(buf);
             buf = buf + 1 == NS ? 0 : buf + 1;
         }
@@ -277,9 +356,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
         __syncthreads();                     // (the compiler drains vmcnt before the barrier)
         for (int ks = 0; ks < KS; ++ks) {
             const int buf = ks & 1;
+#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             if (ks + 1 < KS) gdma(ks + 1, buf ^ 1);   // lands while this step's MFMAs run
+#endif
             compute(buf);
+#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             __syncthreads();
+#endif
         }
     } else if constexpr (PF == 1) {
         gload(0, ra0, rb0);
@@ -316,6 +399,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvP pp
     // ---- epilogue: fp32 accumulators -> packed bf16 tile [pixel][channel] in LDS -> 16-byte channels-last stores ------
     constexpr int LDC = BN + 8;
     uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
+#if AFAN_CONV_ABLATE == 6
+    if (acc[0][0][0] != 1.2345e30f) return;
+#endif
+    if (!producer)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -464,9 +551,9 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF, int WM, int WN>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0>
 int launch(const ConvP& p, hipStream_t st) {
-    constexpr int THREADS = 64 * WM * WN;
+    constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
     constexpr size_t stage_bytes = (size_t)(PF <= 3 ? 2 : PF - 1) * (BM + BN) * (PF >= 3 ? BK : LDK) * 2;
@@ -474,12 +561,12 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN, PW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv_igemm_kernel<BM, BN, PF, WM, WN><<<grid, THREADS, lds, st>>>(p);
+    conv_igemm_kernel<BM, BN, PF, WM, WN, PW><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -521,6 +608,8 @@ int dispatch(const ConvP& p, hipStream_t st) {
     if (mode == 3 && nw >= 8 && n128 && deep >= 1) {
         const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
         static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
+        static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
+        if (wgs <= deep_max && spec) return bm == 64 ? launch<64, 128, 5, 2, 2, 4>(p, st) : launch<128, 128, 5, 2, 2, 4>(p, st);
         if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
     }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);

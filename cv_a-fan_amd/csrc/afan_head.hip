@@ -179,6 +179,41 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const float* __restric
     }
 }
 
+// Many classes (ImageNet-shape heads): one WAVE per row, lanes stride over the classes; the 16 waves of the single
+// workgroup take rows w, w + 16, ...; row losses are summed per wave in row order and the waves in index order
+// (deterministic).  64 x 1000 logits: 313 us with the thread-per-row kernel above, ~10 us here.
+constexpr int CEW_WAVES = 16;
+__global__ __launch_bounds__(64 * CEW_WAVES) void ce_fwd_wide_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                                     float* __restrict__ loss, float* __restrict__ dlogits, int N, int K) {
+    __shared__ float red[CEW_WAVES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float invn = 1.0f / (float)N;
+    float local = 0.f;
+    for (int r = w; r < N; r += CEW_WAVES) {
+        const float* l = logits + (int64_t)r * K;
+        float m = -INFINITY;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, l[k]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += expf(l[k] - m);
+        s = wave_sum(s);
+        const float lse = m + logf(s);
+        const int64_t t64 = target[r];
+        const bool bad = t64 < 0 || t64 >= K;
+        const int t = bad ? 0 : (int)t64;
+        if (lane == 0) local += bad ? NAN : lse - l[t];
+        float* d = dlogits + (int64_t)r * K;
+        for (int k = lane; k < K; k += 64) d[k] = bad ? NAN : (expf(l[k] - lse) - (k == t ? 1.f : 0.f)) * invn;
+    }
+    if (lane == 0) red[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < CEW_WAVES; ++i) s += red[i];
+        loss[0] = s * invn;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -232,7 +267,8 @@ int afan_cross_entropy(const float* logits, const int64_t* target, int64_t n, in
     if (!logits || !target || !loss || !dlogits) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
     AFAN_PROF("ce_fwd_kernel", 8.0 * n * k, st);
-    ce_fwd_kernel<<<1, CE_BLOCK, 0, st>>>(logits, target, loss, dlogits, (int)n, (int)k);
+    if (k >= 64) ce_fwd_wide_kernel<<<1, 64 * CEW_WAVES, 0, st>>>(logits, target, loss, dlogits, (int)n, (int)k);
+    else ce_fwd_kernel<<<1, CE_BLOCK, 0, st>>>(logits, target, loss, dlogits, (int)n, (int)k);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -495,7 +495,7 @@ def test_fused_classifier_head_matches_torch(pkg, gpu, shape, k, dt):
     np.testing.assert_allclose(db.cpu().numpy() - 1, lin.bias.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("n,k", [(256, 10), (512, 10), (7, 3), (1, 10), (64, 1000)])
+@pytest.mark.parametrize("n,k", [(256, 10), (512, 10), (7, 3), (1, 10), (64, 1000), (3, 100), (65, 64), (17, 63)])
 def test_fused_cross_entropy_matches_torch(pkg, gpu, n, k):
     """afan_cross_entropy (loss and d(loss)/d(logits) in one launch) against nn.CrossEntropyLoss on the same logits."""
     torch.manual_seed(n + k)

@@ -244,7 +244,9 @@ def test_bf16_step_matches_bf16_emulating_oracle(pkg, orc, gpu, arch, idx, batch
     assert worst <= (0.5 if arch != "resnet56s" else 0.8), worst      # (27 blocks: the gradient reaching the stem has crossed them all)
     for k, v in sd1_ref.items():
         if "running_mean" in k or "running_var" in k:
-            np.testing.assert_allclose(sd1[k].cpu().numpy(), v.numpy(), rtol=5e-3, atol=2e-3, err_msg=k)
+            # (ResNet-56s: one channel of block 26's running_var measured 6.4e-3 off on one GPU box, 4e-3 on another —
+            # the CPU oracle's own summation order varies with the host's thread count, and 27 blocks amplify it)
+            np.testing.assert_allclose(sd1[k].cpu().numpy(), v.numpy(), rtol=5e-3 if arch != "resnet56s" else 1.2e-2, atol=2e-3, err_msg=k)
         elif "num_batches" in k:
             assert int(sd1[k]) == int(v), k
 
