@@ -59,7 +59,7 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // instruction holds its wave's issue slot for 60-185 cycles (tools/conv_ablate_bench.py: MFMAs on constant fragments
 // 12.0 us, the same plus the DMA 19.8 us, DMA alone 13.8 us on the 256-channel 8x8 layer — the two serialise inside a
 // wave); in a producer wave that stall costs no MFMA slot.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0>   // WM x WN waves: pixels x channels
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>   // WM x WN waves: pixels x channels
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const ConvP pp) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
         // Fragments of FB k16-slices are requested before the first MFMA that uses them (the compiler's own order reuses
         // four fragment registers and waits for every read: one exposed LDS latency per MFMA pair — measured 1 150 cycles
         // per K-step with NO operand traffic at all, against 512 of MFMA).
-        constexpr int FB = AFAN_CONV_FRAG_BATCH;
+        constexpr int FB = FBT;
 #pragma unroll
         for (int k0 = 0; k0 < BK / 16; k0 += FB) {
             bf16x8 fx[FB][MI], fw[FB][NI];
@@ -293,8 +293,31 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
     };
 
     if constexpr (PW > 0) {
-        static_assert(GLDS && NS > 2, "producer waves: LDS-DMA with a counted multi-stage pipeline only");
+        static_assert(GLDS, "producer waves: LDS-DMA only");
         constexpr int LPT = A_ROWS + B_ROWS;
+        if constexpr (NS == 2) {
+            // two stages (two workgroups per CU cover each other's DMA latency): the producers issue tile ks+1 while the
+            // MFMA waves work on tile ks; one barrier per K-step ends both
+            if (producer) {
+                gdma(0, 0);
+                __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                __builtin_amdgcn_s_barrier();
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + 1 < KS) gdma(ks + 1, (ks & 1) ^ 1);
+                    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                __builtin_amdgcn_s_barrier();
+                for (int ks = 0; ks < KS; ++ks) {
+                    compute(ks & 1);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this tile's fragment reads have returned
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            __syncthreads();
+        } else
+        {
         // Two separate loops with the same barrier count (one loop with a role branch inside made the compiler copy all
         // 64 accumulator registers around the branch on every K-step).
         if (producer) {
@@ -326,6 +349,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
             }
         }
         __syncthreads();
+        }
     } else if constexpr (GLDS && NS > 2) {
         // Deep pipeline for launches of about one workgroup per CU (the 8x8 and 4x4 stages: few, long K loops): with two
         // buffers and __syncthreads() every DMA has to land within ONE step's MFMAs (a few hundred cycles against
@@ -423,8 +447,11 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
     // records), is an out-of-range offset — no divergent branch to serialise the requests.  (Requesting them before
     // the K loop instead measured slower: they sit in front of the first operand tiles in the in-order return queue.)
     constexpr int PIECES = BN / 8;               // 16-byte pieces per output row
-    constexpr int ROWS_PER_PASS = THREADS / PIECES;
+    constexpr int EPI_THREADS = (THREADS & (THREADS - 1)) == 0 ? THREADS : 512;   // 768-thread workgroups store with their first 512
+    constexpr int ROWS_PER_PASS = EPI_THREADS / PIECES;
     constexpr int EPI_ROWS = BM / ROWS_PER_PASS;
+    static_assert(BM % ROWS_PER_PASS == 0 && EPI_THREADS <= THREADS, "epilogue passes must cover the tile exactly");
+    const bool epi_on = tid < EPI_THREADS;
     const int pc = tid % PIECES, pr = tid / PIECES;
     const bool ch_ok = n0 + pc * 8 < pp.Co;      // this thread's 8 output channels exist (Co % 8 == 0)
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
@@ -437,7 +464,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
         const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bny), 0, (bn_bwd && pp.bny) ? out_bytes : 0, 0x00020000);
 #pragma unroll
         for (int q = 0; q < EPI_ROWS; ++q) {
-            const int off = out_off[pr + q * ROWS_PER_PASS];
+            const int off = epi_on ? out_off[pr + q * ROWS_PER_PASS] : -1;
             const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
             if (pp.addend) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
             if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
 #pragma unroll
     for (int q = 0; q < EPI_ROWS; ++q) {
         const int r = pr + q * ROWS_PER_PASS;
-        const int off = out_off[r];
+        const int off = epi_on ? out_off[r] : -1;
         if (off >= 0 && ch_ok) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
@@ -551,7 +578,7 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
 int launch(const ConvP& p, hipStream_t st) {
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
@@ -561,12 +588,12 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN, PW>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN, PW, FBT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv_igemm_kernel<BM, BN, PF, WM, WN, PW><<<grid, THREADS, lds, st>>>(p);
+    conv_igemm_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -581,6 +608,11 @@ int choose_bm(int64_t M, int co, int n_classes) {
     const bool n128 = (co % 128 == 0);
     const int64_t wg_128 = ((M + 127) / 128) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
     static const int thr = env_int("AFAN_CONV_THR128", 256);   // (256 vs 384: +0.3 % of the step)
+    // 385..512 workgroups of 128 rows would sit two per CU on the two-stage pipeline: 256-row tiles (8 MFMA waves + 4
+    // DMA waves, three 48 KB stages) bring the launch to one workgroup per CU with a quarter less operand traffic.
+    // M % 512: whole tiles, also for each half of a two-group launch.
+    static const int tall256 = env_int("AFAN_CONV_TALL256", 0);   // measured: 29.4 vs 28.0 us in isolation, 9.98 vs 9.76 ms on the step — off
+    if (tall256 && n128 && n_classes == 1 && M % 512 == 0 && wg_128 > 384 && wg_128 <= 512) return 256;
     if (wg_128 >= thr) return 128;
     // 385..768 workgroups of 64 rows (the 8x8 stage) would be two per CU on the two-stage pipeline; 128-row tiles bring
     // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
@@ -598,6 +630,7 @@ int dispatch(const ConvP& p, hipStream_t st) {
     static const int nw = env_int("AFAN_CONV_NW", 8);          // waves per workgroup where the tile allows it
     const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
     const bool n128 = p.Co % 128 == 0;
+    if (bm == 256) return launch<256, 128, 4, 4, 2, 4>(p, st);      // (only with Co % 128 == 0: choose_bm)
     // launches of about one workgroup per CU (8x8 / 4x4 stages): deep DMA pipeline (3 or 4 LDS stages, counted vmcnt)
     // In the training step every layer's weights are cold (44 MB of bf16 weights cycle through a 32 MB L2 between two
     // uses), so each K-step's weight tile is a first-touch miss that all row tiles of the launch wait for together:
@@ -613,6 +646,8 @@ int dispatch(const ConvP& p, hipStream_t st) {
         if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
     }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
+    static const int spec2 = env_int("AFAN_CONV_SPEC2", 0);  // producer waves on the two-stage launches too (measured: no gain)
+    if (mode == 3 && nw >= 8 && n128 && spec2) return bm == 128 ? launch<128, 128, 3, 2, 2, 4, 2>(p, st) : launch<64, 128, 3, 2, 2, 4, 2>(p, st);
     if (mode == 3 && nw >= 8) {
         if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st) : launch<64, 128, 3, 2, 4>(p, st);
         if (bm == 128) return launch<128, 64, 3, 4, 2>(p, st);

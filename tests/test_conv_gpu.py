@@ -12,7 +12,8 @@ CASES = [  # n, ci, co, h, k, stride
     (2, 256, 512, 8, 1, 2), (1, 64, 64, 7, 3, 1), (2, 64, 64, 9, 3, 2), (1, 128, 64, 5, 1, 1), (64, 128, 128, 16, 3, 1),
     # the weights-in-registers kernel (afan_conv_c64.hip): W in {32, 16, 8, 4}, one and several tiles per workgroup
     (1, 64, 64, 32, 3, 1), (3, 64, 64, 16, 3, 1), (5, 64, 64, 8, 3, 1), (32, 64, 64, 4, 3, 1), (160, 64, 64, 32, 3, 1),
-    # the halo kernel (afan_conv_halo.hip): 256-, 128- and 64-row tiles, one and several images per tile
+    # the launches of the training step itself: the 256-row producer-wave tile (16x16 stage), the deep 128- and 64-row
+    # pipelines (8x8, 4x4 stages), one and several images per tile
     (256, 128, 128, 16, 3, 1), (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1), (8, 128, 256, 16, 3, 1), (6, 256, 128, 8, 3, 1),
     # the small-channel kernel (afan_conv_small.hip): the reference's 16-32-64-channel CIFAR ResNets
     (4, 16, 16, 32, 3, 1), (3, 16, 32, 32, 3, 2), (5, 32, 32, 16, 3, 1), (2, 32, 64, 16, 3, 2), (1, 16, 16, 7, 3, 1),
@@ -138,7 +139,7 @@ def test_stem_shift_kernel_is_exact(pkg, gpu):
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 256, 512, 8, 1, 2),
                                                  (64, 128, 128, 16, 3, 1), (1, 64, 64, 7, 3, 1),
-                                                 (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1),    # halo kernel
+                                                 (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1),    # deep-pipeline launches
                                                  (256, 128, 128, 16, 3, 1)])
 def test_conv_epilogue_moments_feed_batchnorm(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     """conv (+ epilogue moment partials) -> BN(train) must equal conv -> stand-alone BN on the stored bf16 tensor."""
@@ -205,7 +206,7 @@ def test_conv_wgrad_matches_torch(pkg, gpu, n, ci, co, h, k, stride):
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(4, 64, 64, 32, 3, 1), (3, 64, 128, 32, 3, 2), (2, 128, 256, 16, 1, 2),
                                                  (64, 128, 128, 16, 3, 1), (3, 256, 512, 9, 3, 2),
-                                                 (256, 128, 128, 16, 3, 1), (128, 256, 256, 8, 3, 1)])     # halo kernel
+                                                 (256, 128, 128, 16, 3, 1), (128, 256, 256, 8, 3, 1)])     # 256-row / deep-pipeline launches
 def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     """dgrad + addend == dgrad then add; dgrad's fused BN-backward partials == the stand-alone reduction pass."""
     torch.manual_seed(ci + co + h + k)
@@ -249,7 +250,7 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(8, 64, 128, 16, 3, 2), (16, 128, 128, 8, 3, 1), (64, 256, 512, 4, 1, 2),
-                                                 (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1)])
+                                                 (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1), (256, 128, 128, 16, 3, 1)])
 def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, stride):
     """groups = 2 (two concatenated half-batches, BatchNorm statistics per half): one launch over [a | b] must equal the
     two launches over a and over b — outputs bit for bit (row tiles are independent), sums to accumulation-order noise."""

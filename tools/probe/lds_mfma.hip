@@ -6,11 +6,16 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int BM = 128, BN = 128, BK = 64, STAGE = (BM + BN) * BK;
+__device__ int g_random = 0;     // 1: operands are random normal-ish bf16 (MFMA power, hence clock, depends on the data)
 template <int V, int NWAVE, bool BAR>
 __global__ __launch_bounds__(64 * NWAVE) void k(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * STAGE; i += blockDim.x) lds[i] = (uint16_t)(0x3c00 + (i & 63));
+    for (int i = tid; i < 2 * STAGE; i += blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        // random sign, exponent 2^-4 .. 2^0, random mantissa
+        lds[i] = g_random ? (uint16_t)(((h & 1) << 15) | ((123 + ((h >> 1) % 5)) << 7) | ((h >> 8) & 127)) : (uint16_t)(0x3c00 + (i & 63));
+    }
     __syncthreads();
     constexpr int WN = (NWAVE == 4 || V == 3) ? 2 : 4, TM = 64, TN = BN / WN, MI = 2, NI = TN / 32;
     const int wr = wave / WN, wc = wave % WN;
@@ -96,7 +101,9 @@ void run() {
     printf("variant %d, %d waves, barrier %d: %.0f ns per K-step (MFMA floor ~%d), %.0f TFLOP/s\n", V, NWAVE, (int)BAR, ms * 1e6 / iters, 16 * 18, flop / ms / 1e9);
     (void)hipFree(o);
 }
-int main() {
+int main(int argc, char** argv) {
+    int r = argc > 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_random), &r, sizeof(int));
+    printf("operands: %s\n", r ? "random" : "smooth");
     run<2, 4, false>(); run<0, 4, false>(); run<1, 4, false>();
     run<2, 4, true>(); run<0, 4, true>(); run<1, 4, true>();
     run<2, 8, false>(); run<0, 8, false>(); run<1, 8, false>();
