@@ -30,6 +30,7 @@ SIGNATURES = {
     "afan_mix_feature": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_mix_feature_nhwc": (_i, [_p, _p, _p, _l, _l, _l, _f, _i, _p]),
     "afan_lerp_points": (_i, [_p, _p, _p, _l, C.POINTER(_f), _i, _p]),
+    "afan_lerp_mix": (_i, [_p, _p, _p, _l, _l, _l, C.POINTER(_f), _i, C.c_uint, _f, _i, _p]),
     "afan_head_max_classes": (_i, []),
     "afan_head_forward": (_i, [_p, _i, _l, _l, _l, _p, _p, _l, _p, _p, _p]),
     "afan_head_backward": (_i, [_p, _p, _p, _l, _l, _l, _l, _p, _i, _p, _p, _i, _p]),

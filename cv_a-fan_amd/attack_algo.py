@@ -98,6 +98,15 @@ def mix_feature(clean_feature, adv_feature):
     return ops.mix_feature(_dense(clean_feature), _dense(adv_feature), 1e-5)      # (either dense layout; adv follows clean's)
 
 
+def sample_points_mixed(pointx, pointy, number, mix):
+    """get_sample_points followed by `points[j] = mix_feature(pointx, points[j])` for every j >= 1 with mix[j-1] set
+    (Segmentation/main_aug_final.py:186-192), fused: clean and adv are read once."""
+    px, py = _dense(pointx), _dense(pointy)
+    if py.stride() != px.stride():
+        py = _like_layout(py, px)
+    return [pointx] + ops.lerp_mix(px, py, number, [bool(f) for f in mix])
+
+
 def get_sample_points(pointx, pointy, number):
     """Segmentation/attack_algo.py:108-118: [x, lerp(x,y,1/(n-1)), ..., y]; interior points in one launch."""
     px, py = _dense(pointx), _dense(pointy)

@@ -96,19 +96,29 @@ __global__ __launch_bounds__(BLOCK) void mix_feature_nhwc_kernel(const T* __rest
     for (int64_t p = wave0; p < pixels; p += nwaves) {
         const T* pc = clean + p * C;
         const T* pa = adv + p * C;
+        // keep[] is indexed by unrolled loop counters only.  (Round 1 indexed it with the run-time channel counter behind
+        // an `if (k < KEEP)`: the compiler turned that into relative register addressing, and with C = 6000 — counter up
+        // to 93 — the launch died with a memory-aperture violation.  Found by the fused kernel's test.)
         float keep[KEEP];
         float sh_c = 0.f, s_c = 0.f, q_c = 0.f, sh_a = 0.f, s_a = 0.f, q_a = 0.f, cnt = 0.f;
         bool first = true;
-        int k = 0;
-        for (int c = lane; c < C; c += AFAN_WAVE, ++k) {
-            const float vc = Elt<T>::ld(pc + c), va = Elt<T>::ld(pa + c);
-            if (k < KEEP) keep[k] = vc;
+        auto take = [&](float vc, float va) {
             if (first) { sh_c = vc; sh_a = va; first = false; }
             const float dc = vc - sh_c, da = va - sh_a;
             s_c += dc; q_c += dc * dc;
             s_a += da; q_a += da * da;
             cnt += 1.f;
+        };
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int c = lane + k * AFAN_WAVE;
+            keep[k] = 0.f;
+            if (c < C) {
+                keep[k] = Elt<T>::ld(pc + c);
+                take(keep[k], Elt<T>::ld(pa + c));
+            }
         }
+        for (int c = lane + KEEP * AFAN_WAVE; c < C; c += AFAN_WAVE) take(Elt<T>::ld(pc + c), Elt<T>::ld(pa + c));
         Moments mc{cnt, 0.f, 0.f}, ma{cnt, 0.f, 0.f};
         if (cnt > 0.f) {
             const float dmc = s_c / cnt, dma = s_a / cnt;
@@ -128,14 +138,18 @@ __global__ __launch_bounds__(BLOCK) void mix_feature_nhwc_kernel(const T* __rest
         const float mean_c = mc.mean, std_c = sqrtf(mc.m2 / denom + eps);
         const float mean_a = ma.mean, std_a = sqrtf(ma.m2 / denom + eps);
         T* po = out + p * C;
-        k = 0;
-        for (int c = lane; c < C; c += AFAN_WAVE, ++k) {
-            const float vc = k < KEEP ? keep[k] : Elt<T>::ld(pc + c);
+        auto put = [&](int c, float vc) {
             float t = (vc - mean_c) / std_c;
             t = t * std_a;
             t = t + mean_a;
             Elt<T>::st(po + c, t);
+        };
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const int c = lane + k * AFAN_WAVE;
+            if (c < C) put(c, keep[k]);
         }
+        for (int c = lane + KEEP * AFAN_WAVE; c < C; c += AFAN_WAVE) put(c, Elt<T>::ld(pc + c));
     }
 }
 
@@ -186,6 +200,196 @@ __global__ __launch_bounds__(BLOCK) void lerp_points_kernel(const float* __restr
             const bool small = fabsf(w) < 0.5f;
             out[(int64_t)k * n + i] = fmaf(small ? w : w - 1.0f, b - a, small ? a : b);
         }
+    }
+}
+
+
+// ---- fused SAT sample points + mix_feature (SURVEY 8(a) a11 "fuse with a10") ----------------------------------------
+// Points j = 1 .. npts of get_sample_points(clean, adv, npts + 1) — the interior points lerp(clean, adv, w_j) and the end
+// point adv itself — each optionally re-normalised by mix_feature(clean, point_j) (bit j-1 of `mask`), from ONE read of
+// clean and adv: the Segmentation step's lerp + 2 x mix (main_aug_final.py:186-192) moves 9 tensors, this moves 4.
+// Arithmetic and summation order are those of lerp_points_kernel / mix_feature*_kernel, so the results are bit-identical
+// to the separate launches.  An end point without its mask bit is not written (the caller keeps adv).
+constexpr int LM_MAX = 4;
+__device__ __forceinline__ float lerp_one(float a, float b, float w) {
+    const bool small = fabsf(w) < 0.5f;
+    return fmaf(small ? w : w - 1.0f, b - a, small ? a : b);
+}
+
+template <int KEEP>
+__global__ __launch_bounds__(BLOCK) void lerp_mix_nhwc_kernel(const float* __restrict__ clean, const float* __restrict__ adv,
+                                                              float* __restrict__ out, int C, int64_t pixels, int64_t total,
+                                                              LerpW lw, int npts, unsigned mask, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (BLOCK / AFAN_WAVE);
+    for (int64_t p = wave0; p < pixels; p += nwaves) {
+        const float* pc = clean + p * C;
+        const float* pa = adv + p * C;
+        float keep[KEEP];       // (indexed by unrolled loop counters only: a run-time index would put it in scratch memory)
+        float sh_c = 0.f, s_c = 0.f, q_c = 0.f, cnt = 0.f;
+        float sh[LM_MAX], sm[LM_MAX], sq[LM_MAX];
+#pragma unroll
+        for (int k = 0; k < LM_MAX; ++k) sh[k] = sm[k] = sq[k] = 0.f;
+        bool first = true;
+        auto take = [&](float vc, float vy) {
+            if (first) sh_c = vc;
+            const float dc = vc - sh_c;
+            s_c += dc; q_c += dc * dc;
+#pragma unroll
+            for (int k = 0; k < LM_MAX; ++k)
+                if (k < npts) {
+                    const float v = k == npts - 1 ? vy : lerp_one(vc, vy, lw.w[k]);
+                    if (first) sh[k] = v;
+                    const float d = v - sh[k];
+                    sm[k] += d; sq[k] += d * d;
+                }
+            first = false;
+            cnt += 1.f;
+        };
+#pragma unroll
+        for (int kk = 0; kk < KEEP; ++kk) {
+            const int c = lane + kk * AFAN_WAVE;
+            keep[kk] = 0.f;
+            if (c < C) {
+                const float vc = pc[c];
+                keep[kk] = vc;
+                take(vc, pa[c]);
+            }
+        }
+        for (int c = lane + KEEP * AFAN_WAVE; c < C; c += AFAN_WAVE) take(pc[c], pa[c]);
+        Moments mc{cnt, 0.f, 0.f}, mk[LM_MAX];
+        if (cnt > 0.f) {
+            const float dm = s_c / cnt;
+            mc.mean = sh_c + dm; mc.m2 = fmaxf(q_c - s_c * dm, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < LM_MAX; ++k) {
+            mk[k] = Moments{cnt, 0.f, 0.f};
+            if (cnt > 0.f) {
+                const float dm = sm[k] / cnt;
+                mk[k].mean = sh[k] + dm; mk[k].m2 = fmaxf(sq[k] - sm[k] * dm, 0.f);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const bool lo = (lane & o) == 0;
+            Moments oc{__shfl_xor(mc.n, o, 64), __shfl_xor(mc.mean, o, 64), __shfl_xor(mc.m2, o, 64)};
+            mc = lo ? merge(mc, oc) : merge(oc, mc);
+#pragma unroll
+            for (int k = 0; k < LM_MAX; ++k) {
+                Moments ok{__shfl_xor(mk[k].n, o, 64), __shfl_xor(mk[k].mean, o, 64), __shfl_xor(mk[k].m2, o, 64)};
+                mk[k] = lo ? merge(mk[k], ok) : merge(ok, mk[k]);
+            }
+        }
+        const float denom = (float)C - 1.0f;
+        const float mean_c = mc.mean, std_c = sqrtf(mc.m2 / denom + eps);
+        auto put = [&](int c, float vc, float vy) {
+#pragma unroll
+            for (int k = 0; k < LM_MAX; ++k)
+                if (k < npts) {
+                    float* po = out + (int64_t)k * total + p * C;
+                    if ((mask >> k) & 1u) {
+                        float t = (vc - mean_c) / std_c;
+                        t = t * sqrtf(mk[k].m2 / denom + eps);
+                        t = t + mk[k].mean;
+                        po[c] = t;
+                    } else if (k < npts - 1) {
+                        po[c] = lerp_one(vc, vy, lw.w[k]);
+                    }
+                }
+        };
+#pragma unroll
+        for (int kk = 0; kk < KEEP; ++kk) {
+            const int c = lane + kk * AFAN_WAVE;
+            if (c < C) put(c, keep[kk], pa[c]);
+        }
+        for (int c = lane + KEEP * AFAN_WAVE; c < C; c += AFAN_WAVE) put(c, pc[c], pa[c]);
+    }
+}
+
+// NCHW: the workgroup / thread mapping of mix_feature_kernel (PIX pixels of one sample, channel groups), clean column staged.
+template <bool STAGE>
+__global__ __launch_bounds__(BLOCK) void lerp_mix_kernel(const float* __restrict__ clean, const float* __restrict__ adv,
+                                                         float* __restrict__ out, int C, int64_t HW, int PIX, int tiles_per_sample,
+                                                         int64_t total, LerpW lw, int npts, unsigned mask, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int G = BLOCK / PIX;
+    float* stats = lds;                                    // [1 + LM_MAX][G][PIX][3]
+    float* tile = lds + (1 + LM_MAX) * G * PIX * 3;        // [C][PIX]
+    const int px = threadIdx.x % PIX, grp = threadIdx.x / PIX;
+    const int64_t n = blockIdx.x / tiles_per_sample;
+    const int64_t p = (int64_t)(blockIdx.x % tiles_per_sample) * PIX + px;
+    const bool live = p < HW;
+    const int64_t base = n * (int64_t)C * HW + p;
+    float sh_c = 0.f, s_c = 0.f, q_c = 0.f, cnt = 0.f;
+    float sh[LM_MAX], sm[LM_MAX], sq[LM_MAX];
+#pragma unroll
+    for (int k = 0; k < LM_MAX; ++k) sh[k] = sm[k] = sq[k] = 0.f;
+    if (live) {
+        bool first = true;
+        for (int c = grp; c < C; c += G) {
+            const float vc = clean[base + (int64_t)c * HW], vy = adv[base + (int64_t)c * HW];
+            if (STAGE) tile[c * PIX + px] = vc;
+            if (first) sh_c = vc;
+            const float dc = vc - sh_c;
+            s_c += dc; q_c += dc * dc;
+#pragma unroll
+            for (int k = 0; k < LM_MAX; ++k)
+                if (k < npts) {
+                    const float v = k == npts - 1 ? vy : lerp_one(vc, vy, lw.w[k]);
+                    if (first) sh[k] = v;
+                    const float d = v - sh[k];
+                    sm[k] += d; sq[k] += d * d;
+                }
+            first = false;
+            cnt += 1.f;
+        }
+    }
+    {
+        Moments m{cnt, 0.f, 0.f};
+        if (cnt > 0.f) { const float dm = s_c / cnt; m.mean = sh_c + dm; m.m2 = fmaxf(q_c - s_c * dm, 0.f); }
+        float* q = stats + ((0 * G + grp) * PIX + px) * 3;
+        q[0] = m.n; q[1] = m.mean; q[2] = m.m2;
+#pragma unroll
+        for (int k = 0; k < LM_MAX; ++k) {
+            Moments mk{cnt, 0.f, 0.f};
+            if (cnt > 0.f) { const float dm = sm[k] / cnt; mk.mean = sh[k] + dm; mk.m2 = fmaxf(sq[k] - sm[k] * dm, 0.f); }
+            float* qk = stats + (((1 + k) * G + grp) * PIX + px) * 3;
+            qk[0] = mk.n; qk[1] = mk.mean; qk[2] = mk.m2;
+        }
+    }
+    __syncthreads();
+    const float denom = (float)C - 1.0f;
+    float mean_c, std_c, mean_k[LM_MAX], std_k[LM_MAX];
+    {
+        Moments t{0.f, 0.f, 0.f};
+        for (int g = 0; g < G; ++g) { const float* q = stats + ((0 * G + g) * PIX + px) * 3; t = merge(t, Moments{q[0], q[1], q[2]}); }
+        mean_c = t.mean; std_c = sqrtf(t.m2 / denom + eps);
+#pragma unroll
+        for (int k = 0; k < LM_MAX; ++k) {
+            Moments tk{0.f, 0.f, 0.f};
+            for (int g = 0; g < G; ++g) { const float* q = stats + (((1 + k) * G + g) * PIX + px) * 3; tk = merge(tk, Moments{q[0], q[1], q[2]}); }
+            mean_k[k] = tk.mean; std_k[k] = sqrtf(tk.m2 / denom + eps);
+        }
+    }
+    if (!live) return;
+    for (int c = grp; c < C; c += G) {
+        const float vc = STAGE ? tile[c * PIX + px] : clean[base + (int64_t)c * HW];
+        const float vy = adv[base + (int64_t)c * HW];
+#pragma unroll
+        for (int k = 0; k < LM_MAX; ++k)
+            if (k < npts) {
+                float* po = out + (int64_t)k * total + base + (int64_t)c * HW;
+                if ((mask >> k) & 1u) {
+                    float t = (vc - mean_c) / std_c;
+                    t = t * std_k[k];
+                    t = t + mean_k[k];
+                    *po = t;
+                } else if (k < npts - 1) {
+                    *po = lerp_one(vc, vy, lw.w[k]);
+                }
+            }
     }
 }
 
@@ -309,6 +513,56 @@ int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, cons
     const int grid = grid_for(vec ? n / 4 : n, BLOCK);
     AFAN_PROF("lerp_points_kernel", 4.0 * n * (2 + n_interior), (hipStream_t)stream);
     lerp_points_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(x, y, out, n, lw, n_interior, vec);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_lerp_mix(const float* clean, const float* adv, float* out, int64_t n, int64_t c, int64_t hw, const float* weights,
+                  int n_points, unsigned mix_mask, float eps, int layout, afan_stream_t stream) {
+    const int npts = n_points - 1;                          // points 1 .. n_points-1 (the last one is adv itself)
+    if (n < 0 || c <= 0 || hw < 0 || c > 0x7fffffffLL || npts < 1 || npts > LM_MAX || (mix_mask >> npts)) return AFAN_ESHAPE;
+    if (layout != AFAN_NCHW && layout != AFAN_NHWC) return AFAN_ELAYOUT;
+    if (n == 0 || hw == 0) return AFAN_OK;
+    if (!clean || !adv || !out || (npts > 1 && !weights)) return AFAN_ENULL;
+    if (!aligned(clean, 4) || !aligned(adv, 4) || !aligned(out, 4)) return AFAN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    LerpW lw;
+    for (int k = 0; k < 8; ++k) lw.w[k] = k < npts - 1 ? weights[k] : 0.f;
+    const int64_t total = n * c * hw;
+    AFAN_PROF("lerp_mix_kernel", 4.0 * total * (2 + npts), st);
+    if (layout == AFAN_NHWC) {
+        const int grid = grid_for(n * hw * AFAN_WAVE, BLOCK, 8192);
+        if (c <= 64 * 8) lerp_mix_nhwc_kernel<8><<<grid, BLOCK, 0, st>>>(clean, adv, out, (int)c, n * hw, total, lw, npts, mix_mask, eps);
+        else lerp_mix_nhwc_kernel<20><<<grid, BLOCK, 0, st>>>(clean, adv, out, (int)c, n * hw, total, lw, npts, mix_mask, eps);
+    } else {
+        // the pixel tile (hence the channel grouping and the summation order) is chosen exactly as afan_mix_feature does,
+        // so that the fused result equals the separate launches bit for bit
+        auto bytes = [&](int pix, bool stage) { return (size_t)(1 + LM_MAX) * (BLOCK / pix) * pix * 3 * 4 + (stage ? (size_t)c * pix * 4 : 0); };
+        int pix = 64;
+        while (pix >= 8 && (int64_t)c * pix * 4 + 2 * (BLOCK / pix) * pix * 3 * 4 > 64 * 1024) pix >>= 1;
+        bool stage = pix >= 8;
+        if (!stage) {
+            pix = 64;
+            while (pix >= 8 && (int64_t)c * pix * 4 + 2 * (BLOCK / pix) * pix * 3 * 4 > MAX_LDS_BYTES) pix >>= 1;
+            stage = pix >= 8;
+            if (!stage) pix = 64;
+        }
+        if (stage && bytes(pix, true) > (size_t)156 * 1024) stage = false;     // (same tile, clean re-read instead of staged)
+        while (pix > 8 && pix / 2 >= hw) pix >>= 1;
+        const int tiles = (int)((hw + pix - 1) / pix);
+        const int64_t blocks = n * tiles;
+        if (blocks > 0x7fffffffLL) return AFAN_ESHAPE;
+        const size_t lds = bytes(pix, stage);
+        if (stage) {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)lerp_mix_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            lerp_mix_kernel<true><<<(unsigned)blocks, BLOCK, lds, st>>>(clean, adv, out, (int)c, hw, pix, tiles, total, lw, npts, mix_mask, eps);
+        } else {
+            lerp_mix_kernel<false><<<(unsigned)blocks, BLOCK, lds, st>>>(clean, adv, out, (int)c, hw, pix, tiles, total, lw, npts, mix_mask, eps);
+        }
+    }
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

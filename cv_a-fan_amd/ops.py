@@ -336,6 +336,31 @@ def lerp_points(x, y, number):
     return out
 
 
+def lerp_mix(x, y, number, mix, eps=1e-5):
+    """Points 1 .. number-1 of get_sample_points(x, y, number), point j re-normalised by mix_feature(x, point_j) where
+    mix[j-1] is true — one launch (afan_lerp_mix).  Returns number-1 tensors; an end point without its flag is `y` itself."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    _need(y, "y", torch.float32)
+    if x.shape != y.shape or x.dim() != 4:
+        raise ValueError("x/y must be 4-d tensors of the same shape")
+    _same_layout(x, y)
+    npts = number - 1
+    if npts < 1 or npts > 4 or len(mix) != npts:
+        raise ValueError("2..5 sample points, one mix flag per point after the first")
+    n, c, hw = _nchw(x)
+    percent = 1.0 / (number - 1)
+    w = (C.c_float * max(npts - 1, 1))(*[i * percent for i in range(1, number - 1)])
+    mask = sum(1 << j for j, f in enumerate(mix) if f)
+    flat = torch.empty(npts * x.numel(), dtype=torch.float32, device=x.device)
+    out = [flat[i * x.numel():(i + 1) * x.numel()].as_strided(x.shape, x.stride()) for i in range(npts)]
+    check(lib.afan_lerp_mix(_ptr(x), _ptr(y), _ptr(flat), n, c, hw, w, number, mask, float(eps), layout_of(x), _stream(x)),
+          "afan_lerp_mix")
+    if not mix[-1]:
+        out[-1] = y
+    return out
+
+
 def mix_w(clean, adv, w_elem, out_dtype=torch.float32):
     """clean + w * (adv - clean) (main_learnable.py:226): clean/adv fp32 with identical strides, w_elem a 1-element
     fp32 DEVICE tensor (a view of the model's `w`), output in `out_dtype` with the inputs' memory layout."""

@@ -13,7 +13,7 @@ network with the library's kernels is the next slice)."""
 import torch
 
 from . import ops
-from .attack_algo import get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401 (same functions)
+from .attack_algo import get_sample_points, linfball_proj, mix_feature, sample_points_mixed, tensor_clamp  # noqa: F401 (same functions)
 from .resnet_s import dgrad_only
 
 
@@ -109,11 +109,8 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     if noise_sd != 0:
         ops.axpy_noise_(adv_sd, torch.rand(adv_sd.shape).to(adv_sd.device, non_blocking=True), gamma_sd * noise_sd)
     adv_sd_dict["adv"] = adv_sd
-    pts = get_sample_points(fm_se, adv_se.detach(), 3)
-    if f0:
-        pts[1] = mix_feature(fm_se, pts[1])
-    if f1:
-        pts[2] = mix_feature(fm_se, pts[2])
+    # get_sample_points + mix_feature on the flagged points (main_aug_final.py:186-192) in one launch
+    pts = sample_points_mixed(fm_se, adv_se.detach(), 3, (f0, f1)) if (f0 or f1) else get_sample_points(fm_se, adv_se.detach(), 3)
     o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
     o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
     o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})

@@ -107,6 +107,15 @@ int afan_mix_feature_nhwc(const void* clean, const void* adv, void* out, int64_t
 int afan_lerp_points(const float* x, const float* y, float* out, int64_t n, const float* weights,
                      int n_interior, afan_stream_t stream);
 
+/* Fused sample points + mix_feature (SURVEY 8(a) a11 "fuse with a10"; Segmentation/main_aug_final.py:186-192 runs
+ * get_sample_points(clean, adv, 3) and then mix_feature(clean, point) on the points its --mix_layer flags name).
+ * Points j = 1 .. n_points-1 (interior points lerp(clean, adv, weights[j-1]); the last one is adv) go to
+ * out + (j-1)*n*c*hw; bit j-1 of mix_mask: the stored point is mix_feature(clean, point_j, eps).  An end point without its
+ * bit is not written.  fp32, clean/adv/out in `layout` (AFAN_NCHW / AFAN_NHWC), n_points <= 5.  Results are bit-identical
+ * to afan_lerp_points followed by afan_mix_feature[_nhwc].  Algorithmic bytes: 4*(2 + n_points-1) per element. */
+int afan_lerp_mix(const float* clean, const float* adv, float* out, int64_t n, int64_t c, int64_t hw, const float* weights,
+                  int n_points, unsigned mix_mask, float eps, int layout, afan_stream_t stream);
+
 /* Learnable feature mixing of the multi-layer A-FAN (Classification/main_learnable.py:226):
  *   out[i] = clean[i] + w * (adv[i] - clean[i])      three fp32 roundings, like the eager expression
  * clean/adv fp32 [n] (same memory layout), w = one fp32 on the DEVICE (an entry of the model's `w` parameter), out in

@@ -145,7 +145,8 @@ def test_mix_feature_vs_c_oracle(pkg, gpu, c_oracle, shape):
     np.testing.assert_allclose(same.cpu().numpy(), clean, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 64, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 64, 16, 16),
+                                   (1, 6000, 2, 3)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_mix_feature_channels_last(pkg, gpu, c_oracle, shape, dt):
     """The channels-last kernel (one wave per pixel) against the C oracle / the NCHW kernel on the same values, and on
@@ -188,6 +189,32 @@ def test_mix_feature_bf16(pkg, gpu, orc):
     out = pkg.ops.mix_feature(clean.bfloat16().to(gpu), adv.bfloat16().to(gpu))
     assert out.dtype == torch.bfloat16
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 2, 3, 3), (1, 6000, 2, 3)])
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("number,mix", [(3, (True, True)), (3, (True, False)), (3, (False, True)), (5, (True, False, True, True)),
+                                        (2, (True,))])
+def test_fused_sample_points_and_mix(pkg, gpu, orc, shape, nhwc, number, mix):
+    """afan_lerp_mix (one launch) == get_sample_points followed by mix_feature on the flagged points, bit for bit against
+    the product's separate launches and within the mix_feature tolerance against the reference restatement."""
+    rng = np.random.default_rng(sum(shape) + number)
+    clean = torch.from_numpy((rng.standard_normal(shape) * 1.3 + 4.0).astype(np.float32))
+    adv = clean + torch.from_numpy((rng.standard_normal(shape) * 0.1).astype(np.float32))
+    fmt = (lambda t: t.to(gpu).contiguous(memory_format=torch.channels_last)) if nhwc else (lambda t: t.to(gpu))
+    x, y = fmt(clean), fmt(adv)
+    pts = pkg.attack_algo.sample_points_mixed(x, y, number, mix)
+    assert len(pts) == number and pts[0] is x
+    sep = pkg.attack_algo.get_sample_points(x, y, number)
+    ref = orc.get_sample_points(clean, adv, number)
+    for j in range(1, number):
+        want = pkg.attack_algo.mix_feature(x, sep[j]) if mix[j - 1] else sep[j]
+        assert pts[j].stride() == x.stride()
+        assert torch.equal(pts[j], want), (j, float((pts[j] - want).abs().max()))
+        r = orc.mix_feature(clean, ref[j]) if mix[j - 1] else ref[j]
+        np.testing.assert_allclose(pts[j].cpu().numpy(), r.numpy(), rtol=2e-5, atol=2e-5)
+    if not mix[-1]:
+        assert pts[-1] is y or pts[-1].data_ptr() == y.data_ptr()
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
