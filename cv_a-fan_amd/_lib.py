@@ -92,6 +92,7 @@ SIGNATURES = {
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),
+    "afan_pgd_init": (_i, [_p, _i, _p, _p, _p, _l, _p]),
     "afan_normalize_nchw": (_i, [_p, _p, _i, _i, _l, _l, _l, _p, _p, _p]),
     "afan_profile_enable": (_i, [_i]),
     "afan_profile_collect": (_i, [C.c_char_p, C.POINTER(_l), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -53,18 +53,18 @@ def PGD(x, loss_fn, y=None, model=None, steps=3, gamma=None, start_idx=1, layer_
         raise ops.AfanLibraryError("PGD: x must live on the MI355X (no CPU path in this build)")
     # keep whatever dense layout the feature map has (the bf16 backbone hands over channels-last tensors: a
     # .contiguous() here would transpose 64 MB to NCHW and the tail would transpose it back every PGD step)
-    x = _dense(x.detach()).float()
-    x_adv = x.clone()
     lp = getattr(model, "compute_dtype", torch.float32) == torch.bfloat16
-    shadow = torch.empty_like(x, dtype=torch.bfloat16) if lp else None
     if grad0 is not None and (randinit or steps < 1):
         raise ValueError("grad0 is the gradient at x: not with randinit, and only when there is a first step")
+    # x (bf16 from the product's backbone, or fp32) -> fp32 x, its clone x_adv and, where the first tail pass needs it, the
+    # bf16 shadow: one launch (with grad0 the first step's kernel writes the shadow; with randinit the noise kernel does)
+    x, x_adv, shadow = ops.pgd_init(_dense(x.detach()), want_shadow=lp and grad0 is None and not randinit)
+    if lp and shadow is None:
+        shadow = torch.empty_like(x, dtype=torch.bfloat16)
     if randinit:
         # the reference draws the noise on the CPU default generator (attack_algo.py:44); same stream here
         u = _like_layout(torch.rand(x_adv.shape).to(x.device, non_blocking=True), x_adv)
         ops.axpy_noise_(x_adv, u, eps, shadow)
-    elif lp and grad0 is None:
-        ops.cast_bf16(x_adv, shadow)        # (with grad0 the first step's kernel writes the shadow)
     l2 = linf = None
     loss_fn = fused_criterion(loss_fn, model)
     for t in range(steps):

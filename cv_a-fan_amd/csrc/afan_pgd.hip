@@ -267,6 +267,46 @@ __global__ __launch_bounds__(BLOCK) void cast_bf16_kernel(const float* __restric
     for (int64_t i = done + tid; i < n; i += nthreads) dst[i] = f2bf(src[i]);
 }
 
+
+// PGD's start (attack_algo.py:41 `x_adv = x.clone()` on the product's bf16 feature map): x in bf16 or fp32 -> the fp32
+// reference copy x32 (the centre of the L-inf ball and of the norms; nullable when x is fp32 already), the fp32 iterate
+// x_adv, and optionally its bf16 shadow — one pass instead of .float(), .clone() and a cast.
+template <typename S>
+__global__ __launch_bounds__(BLOCK) void pgd_init_kernel(const S* __restrict__ x, float* __restrict__ x32,
+                                                         float* __restrict__ x_adv, uint16_t* __restrict__ shadow, int64_t n, int vec) {
+    const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * BLOCK;
+    int64_t done = 0;
+    if (vec) {
+        const int64_t nvec = n >> 3;
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            const int64_t i = v << 3;
+            float o[8];
+            if constexpr (sizeof(S) == 4) {
+                float a[4], b[4];
+                Elt<float>::ldv((const float*)x + i, a);
+                Elt<float>::ldv((const float*)x + i + 4, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
+            } else {
+                Elt<uint16_t>::ldv((const uint16_t*)x + i, o);
+            }
+            const float lo[4] = {o[0], o[1], o[2], o[3]}, hi[4] = {o[4], o[5], o[6], o[7]};
+            if (x32) { Elt<float>::stv(x32 + i, lo); Elt<float>::stv(x32 + i + 4, hi); }
+            Elt<float>::stv(x_adv + i, lo);
+            Elt<float>::stv(x_adv + i + 4, hi);
+            if (shadow) Elt<uint16_t>::stv(shadow + i, o);
+        }
+        done = nvec << 3;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        const float v = Elt<S>::ld(x + i);
+        if (x32) x32[i] = v;
+        x_adv[i] = v;
+        if (shadow) shadow[i] = f2bf(v);
+    }
+}
+
 template <typename G, bool CLIP, bool SHADOW>
 int launch_step(float* x_adv, const void* grad, const float* x_clean, uint16_t* shadow, int64_t n,
                 float gamma, float eps, hipStream_t st) {
@@ -422,6 +462,23 @@ int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t str
     const int grid = grid_for(vec ? (n + 7) / 8 : n, BLOCK);
     AFAN_PROF("cast_bf16_kernel", n * 6.0, (hipStream_t)stream);
     cast_bf16_kernel<<<grid, BLOCK, 0, (hipStream_t)stream>>>(src, dst, n, vec);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_pgd_init(const void* x, int dtype, float* x32, float* x_adv, uint16_t* shadow, int64_t n, afan_stream_t stream) {
+    if (dtype != AFAN_F32 && dtype != AFAN_BF16) return AFAN_EDTYPE;
+    if (n < 0) return AFAN_ESHAPE;
+    if (n == 0) return AFAN_OK;
+    if (!x || !x_adv || (dtype == AFAN_BF16 && !x32)) return AFAN_ENULL;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(x, a) || !aligned(x_adv, 4) || (x32 && !aligned(x32, 4)) || (shadow && !aligned(shadow, 2))) return AFAN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = aligned(x, 16) && aligned(x_adv, 16) && (!x32 || aligned(x32, 16)) && (!shadow || aligned(shadow, 16));
+    const int grid = grid_for(vec ? (n + 7) / 8 : n, BLOCK);
+    AFAN_PROF("pgd_init_kernel", n * (a + 4.0 + (x32 ? 4 : 0) + (shadow ? 2 : 0)), st);
+    if (dtype == AFAN_F32) pgd_init_kernel<float><<<grid, BLOCK, 0, st>>>((const float*)x, x32, x_adv, shadow, n, vec);
+    else pgd_init_kernel<uint16_t><<<grid, BLOCK, 0, st>>>((const uint16_t*)x, x32, x_adv, shadow, n, vec);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -297,6 +297,21 @@ def cast_bf16(src, out=None):
     return out
 
 
+def pgd_init(x, want_shadow=False):
+    """PGD's start in one launch: (x as fp32, x_adv = its clone[, bf16 shadow of x_adv]) from a dense fp32 / bf16 feature
+    map, all in x's memory layout."""
+    lib = _lib.load()
+    _need(x, "x")
+    if x.dtype not in _DT:
+        raise TypeError("x must be fp32 or bf16")
+    x32 = x if x.dtype == torch.float32 else torch.empty_like(x, dtype=torch.float32)
+    x_adv = torch.empty_like(x, dtype=torch.float32)
+    shadow = torch.empty_like(x, dtype=torch.bfloat16) if want_shadow else None
+    check(lib.afan_pgd_init(_ptr(x), _DT[x.dtype], None if x32 is x else _ptr(x32), _ptr(x_adv),
+                            None if shadow is None else _ptr(shadow), x.numel(), _stream(x)), "afan_pgd_init")
+    return x32, x_adv, shadow
+
+
 # ------------------------------------------------------------------------------ mix_feature / lerp
 def mix_feature(clean, adv, eps=1e-5):
     lib = _lib.load()

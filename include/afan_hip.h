@@ -438,6 +438,10 @@ int afan_sgd_step(float* param, const float* grad, float* momentum_buf, uint16_t
 /* fp32 -> bf16 (round-to-nearest-even, NaN-preserving) and per-channel input normalisation
  * (resnet_s.py:87: (x - mean[c]) / std[c]); the input image is NCHW fp32, the output may be NHWC and/or bf16. */
 int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t stream);
+/* PGD's start, Classification/attack_algo.py:41 (`x_adv = x.clone()`), for a feature map stored in bf16 or fp32: writes the
+ * fp32 copy x32 (centre of the L-inf ball / of the norms; may be NULL when x is fp32), the fp32 iterate x_adv and,
+ * if shadow != NULL, x_adv's bf16 copy — one pass. */
+int afan_pgd_init(const void* x, int dtype, float* x32, float* x_adv, uint16_t* shadow, int64_t n, afan_stream_t stream);
 int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, int64_t n, int64_t c, int64_t hw,
                         const float* mean, const float* std, afan_stream_t stream);
 

@@ -217,6 +217,24 @@ def test_fused_sample_points_and_mix(pkg, gpu, orc, shape, nhwc, number, mix):
         assert pts[-1] is y or pts[-1].data_ptr() == y.data_ptr()
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 1000, 65536 * 4 + 3])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("want_shadow", [False, True])
+def test_pgd_init_one_launch(pkg, gpu, n, dt, want_shadow):
+    """afan_pgd_init: fp32 copy, clone and bf16 shadow of the feature map in one pass == .float(), .clone(), .bfloat16()."""
+    torch.manual_seed(n)
+    x = (torch.randn(n, device=gpu) * 3).to(dt)
+    x32, x_adv, shadow = pkg.ops.pgd_init(x, want_shadow)
+    assert x32.dtype == torch.float32 and torch.equal(x32, x.float()) and (x32 is x) == (dt == torch.float32)
+    assert x_adv.dtype == torch.float32 and torch.equal(x_adv, x.float()) and x_adv.data_ptr() != x32.data_ptr()
+    assert (shadow is None) == (not want_shadow)
+    if want_shadow:
+        assert torch.equal(shadow, x.float().bfloat16())
+    xc = torch.randn(2, 16, 5, 5, device=gpu).to(dt).contiguous(memory_format=torch.channels_last)
+    a, b, _ = pkg.ops.pgd_init(xc)
+    assert a.stride() == xc.stride() and b.stride() == xc.stride() and torch.equal(b, xc.float())
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("npts", [3, 5])
 def test_lerp_points_golden(pkg, gpu, tag, npts):
