@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no_fold_clean", action="store_true", help="separate first PGD pass and final clean pass (A/B)")
     ap.add_argument("--force_fold_clean", action="store_true", help="one clean tail pass regardless of the size heuristic (A/B)")
     ap.add_argument("--no_share_head", action="store_true", help="run the head twice per step like the reference's text (A/B)")
+    ap.add_argument("--dual_bn", action="store_true", help="A/B: auxiliary BatchNorm set for adversarial features (an option the "
+                    "reference does not have; the headline line is measured without it)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--cpu_steps", type=int, default=None, help="timed CPU-oracle steps (default 3; 1 for the DeepLab workload)")
@@ -219,7 +221,8 @@ def main():
         model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
         trainer = pkg.seg_trainer.SegTrainer(model, nn.CrossEntropyLoss(ignore_index=255, reduction="mean"), steps=args.pgd_steps,
                                              eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp",
-                                             mix_layer="11", mix_sd=True, lr=0.01, use_graph=not args.no_graph)
+                                             mix_layer="11", mix_sd=True, lr=0.01, use_graph=not args.no_graph,
+                                             dual_bn=args.dual_bn)
         side, ncls = args.side, 21
         data = [synth_seg(args.batch, side, g) for _ in range(nbuf)]
         xs, ys = [d[0].to(dev) for d in data], [d[1].to(dev) for d in data]
@@ -240,7 +243,7 @@ def main():
                                              perturb_idx=idx, lr=0.1, use_graph=not args.no_graph,
                                              batch_final=not args.no_batch_final, share_head=not args.no_share_head,
                                              fold_clean=(False if args.no_fold_clean else (True if args.force_fold_clean else None)),
-                                             async_wgrad=args.async_wgrad)
+                                             async_wgrad=args.async_wgrad, dual_bn=args.dual_bn)
         side, ncls = ARCH_INPUT.get(args.arch, (32, 10))
         xs = [torch.rand(args.batch, 3, side, side, generator=g).to(dev) for _ in range(nbuf)]
         ys = [torch.randint(0, ncls, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]
@@ -368,6 +371,8 @@ def main():
                         "adversarial pass" if trainer._fold_ok(xs[0]) else
                         f"{args.pgd_steps} PGD passes + adversarial and clean final passes"
                         + (" (one grouped pass)" if getattr(trainer, "_groupable", False) else "")))
+        if args.dual_bn:
+            workload += ", dual-BN option ON (not the reference's arithmetic)"
         line = {
             "metric": metric, "value": round(ips, 2 if seg else 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",

@@ -53,6 +53,8 @@ parser.add_argument("--arch", default="resnet56s", choices=sorted(resnet_s.ARCHS
 parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="backbone compute dtype")
 parser.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
                     help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: vendor convolutions)")
+parser.add_argument("--dual_bn", action="store_true", help="auxiliary BatchNorm set for adversarial features (not in the "
+                    "reference: extra state_dict keys <bn>.adv.*; evaluation uses the main set)")
 parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of CIFAR-10")
 parser.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
 
@@ -250,7 +252,7 @@ def main(argv=None):
     trainer = train_step.AfanTrainer(model, criterion, steps=args.steps, gamma=args.gamma, eps=args.eps,
                                      perturb_idx=args.perturb_idx, layer_number=layer_number, randinit=args.randinit,
                                      clip=args.clip, lr=args.lr, momentum=args.momentum,
-                                     weight_decay=args.weight_decay)
+                                     weight_decay=args.weight_decay, dual_bn=args.dual_bn)
     optimizer = trainer.optimizer
     vendor = resnet_s.vendor_convs(model)
     log("convolutions outside the library's kernels: {}{}".format(

@@ -31,6 +31,7 @@ class _Flags:
     block_fusion = True  # BasicBlock as one autograd node on the bf16 channels-last fast path (_BlockFn)
     wgrad_stash = False  # True: block weight gradients are not launched but their operands kept on the conv module (stash_wgrad)
     bn_groups = 1        # 2: the batch is [adv half | clean half]; BatchNorm statistics / running updates per half, in order
+    bn_branch = "main"   # "adv" inside bn_branch(model, "adv"): BatchNorms with an auxiliary set use it (dual-BN option)
 
 
 def join_wgrad_stream():
@@ -62,6 +63,38 @@ def bn_groups(g):
         yield
     finally:
         _Flags.bn_groups = old
+
+
+def enable_dual_bn(model):
+    """Dual-BN option (north-star wording; the reference has ONE BatchNorm set, SURVEY section 1 — default off): give every
+    BatchNorm2d of `model` an auxiliary parameter / running-statistics set for adversarial features, initialised as a copy
+    of the main one.  state_dict gains `<bn>.adv.{weight,bias,running_mean,running_var,num_batches_tracked}`; eval mode and
+    the clean passes use the main set.  Call before the parameter arena is built."""
+    bns = [m for m in model.modules() if isinstance(m, BatchNorm2d)]
+    for b in bns:
+        b.enable_dual()
+    model._dual_bns = bns
+    return model
+
+
+@contextlib.contextmanager
+def bn_branch(model, branch):
+    """Inside: the BatchNorms of a dual-BN model normalise with their `branch` set ("adv" or "main") — affine parameters,
+    their gradients and the running statistics.  No-op for a model without auxiliary sets."""
+    bns = getattr(model, "_dual_bns", None)
+    if not bns:
+        yield
+        return
+    old = _Flags.bn_branch
+    for b in bns:
+        b.select(branch)
+    _Flags.bn_branch = branch
+    try:
+        yield
+    finally:
+        for b in bns:
+            b.select(old)
+        _Flags.bn_branch = old
 
 
 def _bn_fwd_g(raw, b, res, relu, st, G, mom):
@@ -365,6 +398,7 @@ class _BlockFn(torch.autograd.Function):
             a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
             saved += [raw, a, s_i]
         ctx.blk, ctx.want_pgrad, ctx.n, ctx.G = blk, want_pgrad, n, G
+        ctx.branch = _Flags.bn_branch      # dual-BN: the backward reads the same parameter set from the modules
         # cross-block fusion: when x is the output of another _BlockFn, this block's input-gradient dgrad also takes the
         # reduction sums of THAT block's last BN backward (its ReLU mask is x > 0) — see backward
         prev = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
@@ -375,6 +409,21 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        blk = ctx.blk
+        bns = [b for _, b in blk._chain()] + ([blk.shortcut[1]] if blk._sc_kind == "conv" else [])
+        if all(b._branch == ctx.branch for b in bns):
+            return _BlockFn._backward(ctx, gout)
+        was = [b._branch for b in bns]
+        for b in bns:
+            b.select(ctx.branch)
+        try:
+            return _BlockFn._backward(ctx, gout)
+        finally:
+            for b, w in zip(bns, was):
+                b.select(w)
+
+    @staticmethod
+    def _backward(ctx, gout):
         x, rawsc, ssc, *saved = ctx.saved_tensors
         blk, pg, n, G = ctx.blk, ctx.want_pgrad, ctx.n, ctx.G
         chain = blk._chain()
@@ -544,6 +593,25 @@ class Conv2d(nn.Conv2d):
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameters/buffers; fused HIP execution."""
+    _branch = "main"       # which set currently sits in weight / bias / running_* (see enable_dual_bn)
+
+    def enable_dual(self):
+        if getattr(self, "adv", None) is None:
+            aux = nn.BatchNorm2d(self.num_features, eps=self.eps, momentum=self.momentum).to(self.weight.device)
+            aux.load_state_dict({k: v.clone() for k, v in nn.BatchNorm2d.state_dict(self).items() if not k.startswith("adv.")})
+            self.adv = aux         # a holder: never called, its tensors are exchanged with this module's by select()
+
+    def select(self, branch):
+        """Exchange the module's parameter / buffer ENTRIES with the auxiliary set's (no copy): afterwards `self.weight`
+        etc. are the tensors of `branch`."""
+        if getattr(self, "adv", None) is None or branch == self._branch:
+            return
+        a = self.adv
+        for k in ("weight", "bias"):
+            self._parameters[k], a._parameters[k] = a._parameters[k], self._parameters[k]
+        for k in ("running_mean", "running_var", "num_batches_tracked"):
+            self._buffers[k], a._buffers[k] = a._buffers[k], self._buffers[k]
+        self._branch = branch
 
     def fused(self, x, residual=None, relu=False, conv_stats=None):
         if _Flags.bn_groups != 1 and self.training:

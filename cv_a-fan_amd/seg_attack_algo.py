@@ -10,6 +10,8 @@ reference's `Segmentation/attack_algo.py`:
 `model({'x', 'adv', 'out_idx', 'flag', 'low_level_feat'}) -> logits | feature dict`.  The sign-step / projection / noise /
 mix / lerp arithmetic runs in libafan_hip.so; the model's own layers are whatever the caller built (the DeepLabv3+
 network with the library's kernels is the next slice)."""
+import contextlib
+
 import torch
 
 from . import ops
@@ -84,7 +86,7 @@ def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gam
 
 def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                    pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                   clip=False):
+                   clip=False, dual_bn=False):
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
     0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
@@ -99,10 +101,15 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     fm_sd = dec["adv"].detach().float()       # (bf16 activations on the product path: the A-FAN operators work in fp32)
     low = out_se["low_level"]
     fm_se = out_se["out"].detach().float()
-    adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
-                 eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip)
-    adv_sd_dict = decoder_PGD(input_dict=dec, image_batch=images, criterion=criterion, y=labels, model=model, steps=steps,
-                              eps=(eps / 255), gamma=(gamma_sd / 255), idx=pertub_idx_sd, randinit=randinit, clip=clip)
+    # dual_bn (option, no reference counterpart): every pass over adversarial features — the two PGD loops and the three
+    # perturbed forwards — normalises with the auxiliary BatchNorm set (resnet_s.enable_dual_bn); no-op otherwise
+    from .resnet_s import bn_branch
+    adv_bn = (lambda: bn_branch(model, "adv")) if dual_bn else contextlib.nullcontext
+    with adv_bn():
+        adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
+                     eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip)
+        adv_sd_dict = decoder_PGD(input_dict=dec, image_batch=images, criterion=criterion, y=labels, model=model, steps=steps,
+                                  eps=(eps / 255), gamma=(gamma_sd / 255), idx=pertub_idx_sd, randinit=randinit, clip=clip)
     adv_sd = adv_sd_dict["adv"].detach()
     if mix_sd:
         adv_sd = mix_feature(fm_sd, adv_sd)
@@ -112,9 +119,10 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     # get_sample_points + mix_feature on the flagged points (main_aug_final.py:186-192) in one launch
     pts = sample_points_mixed(fm_se, adv_se.detach(), 3, (f0, f1)) if (f0 or f1) else get_sample_points(fm_se, adv_se.detach(), 3)
     o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
-    o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
-    o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
-    o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
+    with adv_bn():
+        o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+        o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
+        o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
     wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
     if getattr(criterion, "fused", False) and all(o.is_cuda and o.dtype == torch.float32 for o in (o0, o1, o2, o3)):
         # every term's stored gradient already carries its weight: four roots, no scaling passes over the logits

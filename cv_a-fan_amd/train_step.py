@@ -164,8 +164,16 @@ class AfanTrainer:
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
                  group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True,
-                 share_head=True, fold_clean=None, segmented=None):
+                 share_head=True, fold_clean=None, segmented=None, dual_bn=False):
         self.model, self.criterion = model, criterion
+        # dual-BN option (off = the reference's single BatchNorm set): adversarial features — every PGD pass and the
+        # adversarial final pass — are normalised by an auxiliary BatchNorm set.  The first PGD pass is then no longer the
+        # clean pass and the two final passes no longer share their affine parameters: no fold, no grouped final pass.
+        self.dual_bn = bool(dual_bn)
+        if self.dual_bn:
+            from . import resnet_s
+            resnet_s.enable_dual_bn(model)
+            fold_clean, batch_final = False, False
         self.steps, self.gamma, self.eps = steps, gamma, eps
         self.perturb_idx = perturb_idx
         self.layer_number = layer_number if layer_number is not None else model.layer_number
@@ -404,9 +412,11 @@ class AfanTrainer:
             with torch.no_grad():  # (.detach()): values and BN side effects are identical
                 feature_map = m(inp, end_point=idx, start_point=0)
         feature_map = feature_map.float() if feature_map.dtype != torch.float32 else feature_map
-        feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
-                              gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
-                              randinit=self.randinit, clip=self.clip, with_norms=True)
+        from . import resnet_s as _rsb
+        with _rsb.bn_branch(m, "adv"):
+            feature_map_adv = PGD(feature_map, self.criterion, y=target, model=m, steps=self.steps,
+                                  gamma=(self.gamma / 255), start_idx=idx, layer_number=ln, eps=(self.eps / 255),
+                                  randinit=self.randinit, clip=self.clip, with_norms=True)
         l2, linf = last_norms()
         # The reference feeds the requires_grad leaf itself and so also computes a never-used d(loss)/d(x_adv)
         # (SURVEY.md §9.7); feeding the detached tensor (its bf16 shadow on the bf16 path) is parity-neutral.
@@ -427,7 +437,8 @@ class AfanTrainer:
             nb = adv_in.shape[0]
             output_adv, output_clean = out_both[:nb], out_both[nb:]
         else:
-            output_adv = m(adv_in, end_point=ln, start_point=idx)                # main_perturb.py:195
+            with _rsb.bn_branch(m, "adv"):
+                output_adv = m(adv_in, end_point=ln, start_point=idx)            # main_perturb.py:195
             output_clean = (m(fm_clean, end_point=ln, start_point=idx) if fm_clean is not None
                             else m(inp, end_point=ln, start_point=0))            # main_perturb.py:196
         from . import resnet_s as _rs

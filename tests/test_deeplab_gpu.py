@@ -177,3 +177,35 @@ def test_deeplab_checkpoint_interchange(pkg, orc, gpu):
     sd = model.state_dict()
     for k, v in ref.state_dict().items():
         assert tuple(sd[k].shape) == tuple(v.shape) and sd[k].dtype == v.dtype, k
+
+
+def test_deeplab_dual_bn_option(pkg, gpu):
+    """BASELINE configs[3] names "dual-BN"; the reference has none, so it is an option (off by default) without a golden:
+    with the auxiliary set a copy of the main one, the first fp32 iteration reproduces the shared-BN losses, the
+    auxiliary running statistics are the ones the adversarial passes updated, and the bf16 iteration is graph-captured."""
+    g = golden("seg_dl101_aspp_k1")
+    images, labels = torch.from_numpy(g["images"]).to(gpu), torch.from_numpy(g["labels"]).to(gpu)
+    steps = int(g["meta"][0])
+    res = {}
+    for dual in (False, True):
+        model, tr = _build(pkg, g, torch.float32, True, gpu, use_graph=False, dual_bn=dual)
+        res[dual] = (tr.step(images, labels), model)
+    np.testing.assert_allclose(res[True][0]["losses"].cpu().numpy(), res[False][0]["losses"].cpu().numpy(), rtol=0, atol=2e-5)
+    sd0, sd1 = res[False][1].state_dict(), res[True][1].state_dict()
+    assert [k for k in sd1 if ".adv." not in k] == list(sd0.keys())
+    # a layer4 BatchNorm (behind both perturbation points' tails): main set = the clean head pass + the clean forward of
+    # the decoder-PGD input + o0; auxiliary = SE-PGD passes + the two SE tails (the SD tail starts after the backbone)
+    k = "backbone.layer4.0.bn1"
+    shared, main, aux = (int(sd0[k + ".num_batches_tracked"]), int(sd1[k + ".num_batches_tracked"]),
+                         int(sd1[k + ".adv.num_batches_tracked"]))
+    assert shared == main + aux and aux == steps + 2 and main >= 2, (shared, main, aux)
+    assert not torch.equal(sd1[k + ".adv.running_mean"], sd1[k + ".running_mean"])
+    # a stem BatchNorm never sees adversarial features
+    assert int(sd1["backbone.bn1.adv.num_batches_tracked"]) == 0
+    model, tr = _build(pkg, g, torch.bfloat16, True, gpu, use_graph=True, graph_warmup=1, dual_bn=True)
+    losses = []
+    for _ in range(3):
+        losses.append(float(tr.step(images, labels)["loss"]))
+        tr.scheduler.step()
+    assert tr._graph is not None, tr._graph_failed
+    assert all(np.isfinite(losses))

@@ -668,3 +668,86 @@ def test_segmented_step_equals_unsegmented(pkg, orc, gpu, arch, idx, graph):
             assert int(res[True][2][k]) == int(v), k
         elif "running" in k:
             np.testing.assert_allclose(res[True][2][k].float().cpu().numpy(), v.float().cpu().numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("arch,idx,dtype", [("resnet20s", 7, torch.float32), ("resnet20s", 7, torch.bfloat16), ("resnet18", 6, torch.bfloat16)])
+def test_dual_bn_option_decomposes_the_shared_bn_step(pkg, orc, gpu, arch, idx, dtype):
+    """Dual-BN (an option with no reference counterpart; off by default): adversarial features go through an auxiliary
+    BatchNorm set.  With the auxiliary set initialised as a copy, the first step computes the same losses as the
+    shared-BN step (unfolded schedule), and what the shared set received splits between the two sets: affine gradients
+    add up, running statistics are updated by the clean passes (main) and by the K + 1 adversarial passes (auxiliary)."""
+    K = 2
+    out = {}
+    for dual in (False, True):
+        m = _build(pkg, orc, arch, gpu, dtype=dtype)
+        if dtype == torch.bfloat16:
+            m.set_channels_last(True)
+        keys0 = list(m.state_dict().keys())
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.05,
+                                        use_graph=False, fold_clean=False, batch_final=False, dual_bn=dual)
+        torch.manual_seed(0)
+        x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
+        r = tr.step(x, y)
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        out[dual] = (r, grads, {k: v.clone() for k, v in m.state_dict().items()}, keys0, m, tr)
+    (r0, g0, sd0, keys0, _, _), (r1, g1, sd1, _, m1, tr1) = out[False], out[True]
+    # fp32: the same kernels on the same values in both runs.  bf16: the convolution epilogues shift their moment sums by
+    # the BatchNorm's running mean (a rounding aid) and the auxiliary set's running mean has a different history, so
+    # statistics differ in the last bits, bf16 activations flip an ulp here and there, sign() flips follow.
+    exact = dtype == torch.float32
+    for k in ("loss", "loss_adv", "loss_clean"):
+        assert abs(float(r0[k]) - float(r1[k])) <= (1e-6 if exact else 3e-3), (k, float(r0[k]), float(r1[k]))
+    if exact:
+        assert torch.equal(r0["x_adv"], r1["x_adv"])
+    else:
+        assert float((r0["x_adv"] != r1["x_adv"]).float().mean()) <= 0.05
+    gtol = dict(rtol=2e-3, atol=2e-5) if exact else dict(rtol=0.3, atol=5e-2)
+    # keys: the reference's, plus one auxiliary set per BatchNorm
+    extra = [k for k in sd1 if k not in sd0]
+    assert [k for k in sd1 if k in sd0] == keys0 and len(extra) == 5 * sum(1 for k in keys0 if k.endswith("running_mean"))
+    assert all(".adv." in k for k in extra)
+    tail_seen = head_seen = 0
+    for n, g in g0.items():
+        if ".bn" in n or "shortcut.1" in n or n.startswith("sequential_model.2."):
+            parts = n.rsplit(".", 1)
+            ga = g1[parts[0] + ".adv." + parts[1]]
+            np.testing.assert_allclose((g1[n] + ga).cpu().numpy(), g.cpu().numpy(), err_msg=n, **gtol)
+            pre = parts[0]
+            nbt, nbt_main, nbt_adv = (int(sd0[pre + ".num_batches_tracked"]), int(sd1[pre + ".num_batches_tracked"]),
+                                      int(sd1[pre + ".adv.num_batches_tracked"]))
+            assert nbt == nbt_main + nbt_adv, n
+            if nbt_adv:                                   # a tail BatchNorm: K PGD passes + the adversarial final pass
+                assert (nbt_main, nbt_adv) == (1, K + 1) and float(ga.abs().max()) > 0
+                tail_seen += 1
+            else:                                         # a head BatchNorm never sees adversarial features
+                assert nbt_main == 2 and float(ga.abs().max()) == 0
+                head_seen += 1
+        elif exact:
+            np.testing.assert_allclose(g1[n].cpu().numpy(), g.cpu().numpy(), err_msg=n, **gtol)
+        else:
+            assert float((g1[n] - g).norm() / g.norm().clamp_min(1e-12)) <= 0.15, n
+    assert tail_seen > 0 and head_seen > 0
+    # evaluation uses the main set; the auxiliary one is still addressable and selectable
+    m1.eval()
+    with torch.no_grad():
+        e_main = m1(x)
+        with pkg.resnet_s.bn_branch(m1, "adv"):
+            e_adv = m1(x)
+    assert torch.isfinite(e_main).all() and not torch.equal(e_main, e_adv)
+    assert all(b._branch == "main" for b in m1._dual_bns)
+
+
+def test_dual_bn_step_is_graph_captured(pkg, orc, gpu):
+    res = {}
+    for graph in (False, True):
+        m = _build(pkg, orc, "resnet18", gpu, dtype=torch.bfloat16)
+        m.set_channels_last(True)
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=6, lr=0.05,
+                                        use_graph=graph, graph_warmup=1, dual_bn=True)
+        torch.manual_seed(0)
+        x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
+        res[graph] = [float(tr.step(x, y)["loss"]) for _ in range(4)]
+        if graph:
+            assert tr._graph is not None, tr._graph_failed
+    assert all(np.isfinite(res[True])) and res[True][0] > 0
+    np.testing.assert_allclose(res[True], res[False], rtol=0, atol=5e-3)
