@@ -339,6 +339,9 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
                 buf = buf + 1 == NS ? 0 : buf + 1;
             }
         } else {
+#ifdef AFAN_CONV_PRIO
+            __builtin_amdgcn_s_setprio(AFAN_CONV_PRIO);
+#endif
             int buf = 0;
             for (int ks = 0; ks < KS; ++ks) {
 #if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
@@ -505,7 +508,11 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
             }
+#if AFAN_STREAM_STORES
+            __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(pp.y + go));
+#else
             *reinterpret_cast<u16x8*>(pp.y + go) = v;
+#endif
             if (bn_bwd) {
                 const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
                 u16x8 yv = xv;
