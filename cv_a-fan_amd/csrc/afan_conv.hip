@@ -25,6 +25,9 @@
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
+#ifndef AFAN_CONV_PIPE
+#define AFAN_CONV_PIPE 0          // 1: half-step software pipeline in the MFMA waves of the producer-wave kernels (measured: no gain)
+#endif
 #ifndef AFAN_CONV_FRAG_BATCH
 #define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
 #endif
@@ -243,6 +246,36 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
         }
     };
 
+    // Half-step software pipeline of the MFMA waves (producer-wave kernels): a K-step's four k16-slices are read as two
+    // halves; the first half of the NEXT tile is requested (right after that tile's barrier) before the MFMAs of this
+    // tile's second half, and the second half before the MFMAs of the first — every LDS latency sits behind eight
+    // (or four) MFMAs of the wave itself instead of behind the barrier.  MFMA order per accumulator is unchanged.
+    constexpr int HS = BK / 32;                          // k16-slices per half
+    auto load_half = [&](int buf, int h, bf16x8 (&fx)[HS][MI], bf16x8 (&fw)[HS][NI]) {
+        const uint16_t* A = lds + buf * STAGE;
+        const uint16_t* B = A + BM * LDR;
+        const int frow = lane & 31, sw = (frow >> 1) & 7;
+#pragma unroll
+        for (int b = 0; b < HS; ++b) {
+            const int koff = ((((h * HS + b) * 2 + (lane >> 5)) ^ sw) * 8);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                fx[b][i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
+        }
+    };
+    auto mma_half = [&](const bf16x8 (&fx)[HS][MI], const bf16x8 (&fw)[HS][NI]) {
+#pragma unroll
+        for (int b = 0; b < HS; ++b)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
+    };
+
     // LDS-DMA issue of one K-step into buffer `buf`: A_ROWS + B_ROWS wave instructions, each 64 lanes x 16 B = 1 KiB of
     // consecutive LDS; padding rows read the zero page
     // Buffer form of the DMA: per-thread byte offsets (a_off / b_voff, constant over the K loop) in the VGPR operand, the
@@ -342,6 +375,33 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
 #ifdef AFAN_CONV_PRIO
             __builtin_amdgcn_s_setprio(AFAN_CONV_PRIO);
 #endif
+#if AFAN_CONV_PIPE && !AFAN_CONV_ABLATE
+            if (KS > 0) {
+                bf16x8 ax[HS][MI], aw[HS][NI], bx[HS][MI], bw[HS][NI];
+                __builtin_amdgcn_s_barrier();                              // tile 0 has landed
+                load_half(0, 0, ax, aw);
+                int buf = 0;
+                for (int ks = 0; ks < KS; ++ks) {
+                    load_half(buf, 1, bx, bw);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_half(ax, aw);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int nbuf = buf + 1 == NS ? 0 : buf + 1;
+                    // lgkmcnt(0): every read of tile ks has returned.  Outside the `if`: on the joined path the compiler
+                    // must know that the second half's registers are complete, or it waits for the NEXT tile's reads
+                    // before this tile's MFMAs (it did: lgkmcnt(5) .. (0) in front of them).
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    if (ks + 1 < KS) {
+                        __builtin_amdgcn_s_barrier();                      // tile ks+1 has landed; tile ks's buffer is free
+                        load_half(nbuf, 0, ax, aw);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mma_half(bx, bw);
+                    __builtin_amdgcn_sched_barrier(0);
+                    buf = nbuf;
+                }
+            }
+#else
             int buf = 0;
             for (int ks = 0; ks < KS; ++ks) {
 #if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
@@ -350,6 +410,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
                 compute(buf);
                 buf = buf + 1 == NS ? 0 : buf + 1;
             }
+#endif
         }
         __syncthreads();
         }
