@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
                 for (int i = 0; i < MI; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
     };
+    (void)load_half; (void)mma_half;                     // (only the AFAN_CONV_PIPE build uses them)
 
     // LDS-DMA issue of one K-step into buffer `buf`: A_ROWS + B_ROWS wave instructions, each 64 lanes x 16 B = 1 KiB of
     // consecutive LDS; padding rows read the zero page
