@@ -864,7 +864,7 @@ int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void*
 }
 int set_running_updates(int n) {
     const int old = g_running_updates;
-    g_running_updates = n < 1 ? 1 : n;
+    g_running_updates = n < 0 ? 1 : n;     // 0: normalise with the batch moments, leave the running statistics alone (a deferred update)
     return old;
 }
 // partials [2][C][MAX_G] + coef [2][C] + eval-mode stats [4][C]

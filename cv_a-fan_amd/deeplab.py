@@ -464,11 +464,12 @@ class ASPP(nn.Module):
         self.convs = nn.ModuleList(mods)
         self.project = nn.Sequential(Conv2d(5 * oc, oc, 1, bias=False), BatchNorm2d(oc), nn.ReLU(inplace=True), Dropout(0.1))
 
-    def forward(self, x):
+    def forward(self, x, pre_dropout=False):
         x = _to_compute(x, self.convs[0][0].compute_dtype)
         res = [_cbr(self.convs[0][0], self.convs[0][1], x)] + [c(x) for c in list(self.convs)[1:]]
         res = torch.cat(res, dim=1)
-        return self.project[3](_cbr(self.project[0], self.project[1], res))
+        pre = _cbr(self.project[0], self.project[1], res)
+        return pre if pre_dropout else self.project[3](pre)
 
 
 class DeepLabHeadV3Plus(nn.Module):
@@ -564,6 +565,13 @@ class DeepLabV3(nn.Module):
     def _up(self, x, input_shape):
         return interpolate(x, input_shape)
 
+    def forward_clean_folded(self, x, se_idx, sd_idx):
+        return _folded_clean_forward(self, x, se_idx, sd_idx)
+
+    def fold_ok(self, x):
+        """Can the iteration's three clean forwards run as one (forward_clean_folded)?"""
+        return bool(self.channels_last and x.is_cuda and self.training and isinstance(self.classifier, DeepLabHeadV3Plus))
+
     def forward(self, input_dict):
         flag = input_dict["flag"]
         if flag == "head":
@@ -579,6 +587,61 @@ class DeepLabV3(nn.Module):
             return features
         assert idx in ("aspp_tail", "concat_tail")
         return self._up(self.classifier(input_dict["adv"], return_type=idx), input_dict["x"].shape[-2:])
+
+
+class _FoldedClean:
+    """What DeepLabV3.forward_clean_folded hands back (see there)."""
+    __slots__ = ("low", "fm_se", "dec", "logits", "_recs")
+
+    def replay_deferred_bn(self):
+        """Apply the running-statistics updates that belong to the reference's `o0` forward (main_aug_final.py:193), which
+        comes AFTER the two PGD loops: once more for layer4 / ASPP (updated once at the start, for the decoder-PGD input
+        pass), for the first time for the decoder's BatchNorms."""
+        for r in self._recs:
+            r.replay()
+
+
+def _folded_clean_forward(self, x, se_idx, sd_idx):
+    """The three clean forwards of a Segmentation A-FAN iteration as ONE pass (the fold of DESIGN section 4, for
+    main_aug_final.py:166-193): `model(head, out_idx=se_idx)` (:166), `model(clean, out_idx=sd_idx + "_head")` (:167) and
+    `model(clean, out_idx=0)` (:193) evaluate the same layers on the same images with the same weights — the backbone up
+    to the SE point three times, layer4 + ASPP twice.  One pass with its autograd graph yields all of their values:
+      * `fm_se`, `low`: the SE point's feature map and the low-level feature (graph tensors: the decoders of the
+        perturbed forwards differentiate through `low`, exactly as they do through the head passes' graphs in the reference);
+      * `dec`: the decoder-PGD input dict (`adv` = the SD point's clean feature, with its OWN dropout draw);
+      * `logits`: the clean forward's output (a second dropout draw on the same pre-dropout ASPP output).
+    BatchNorm side effects in the reference's order: stem .. SE point: three updates now (nothing else touches them);
+    SE point .. SD point: one now (:167), one deferred (:193 comes after the PGD loops); after the SD point: deferred.
+    Channels-last kernels only (the repeat count is a feature of those launches)."""
+    bb, head = self.backbone, self.classifier
+    assert isinstance(head, DeepLabHeadV3Plus) and sd_idx in ("aspp", "concat") and se_idx in (1, 2, 3, 4)
+    stages = [bb.layer1, bb.layer2, bb.layer3, bb.layer4]
+    dt, cl = head.project[0].compute_dtype, head.channels_last
+    out = _FoldedClean()
+    with ops.bn_running_updates(3):
+        h = bb.layer1(bb._stem(x))
+        low = h
+        for st in stages[1:se_idx]:
+            h = st(h)
+    out.fm_se, out.low = h, low
+    drop = head.aspp.project[3]
+    with ops.record_bn_updates() as rec_mid:
+        for st in stages[se_idx:]:
+            h = st(h)
+        pre = head.aspp(_enter(h, dt, cl), pre_dropout=True)
+        if sd_idx == "concat":
+            low_p = _cbr(head.project[0], head.project[1], _enter(low, dt, cl))
+    with ops.bn_running_updates(0), ops.record_bn_updates() as rec_late:
+        if sd_idx == "aspp":
+            adv = drop(pre.detach())                          # :167's dropout draw
+            low_p = _cbr(head.project[0], head.project[1], _enter(low, dt, cl))
+        else:
+            adv = head._concat(low_p.detach(), drop(pre.detach()))
+        logits = head._classify(head._concat(low_p, drop(pre)))   # :193's own draw
+    out.dec = {"out": h, "low_level": low, "adv": adv}
+    out.logits = self._up(logits, x.shape[-2:])
+    out._recs = (rec_mid, rec_late)
+    return out
 
 
 def set_bn_momentum(model, momentum=0.1):

@@ -86,7 +86,7 @@ def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gam
 
 def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                    pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                   clip=False, dual_bn=False):
+                   clip=False, dual_bn=False, fold_clean=None):
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
     0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
@@ -96,11 +96,23 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     if images.is_cuda:
         ops.acc_reset(images.device)            # BatchNorm accumulator arena: one memset per iteration
     optimizer.zero_grad()
-    out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
-    dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
-    fm_sd = dec["adv"].detach().float()       # (bf16 activations on the product path: the A-FAN operators work in fp32)
-    low = out_se["low_level"]
-    fm_se = out_se["out"].detach().float()
+    # fold_clean (None: whenever the model offers it): the head pass (:166), the decoder-PGD input pass (:167) and the
+    # clean forward (:193) are the same layers on the same images with the same weights — one pass (deeplab.py
+    # forward_clean_folded) instead of three, BatchNorm running statistics updated in the reference's order.
+    fold = getattr(model, "fold_ok", None) is not None and model.fold_ok(images) and type(pertub_idx_se) == int \
+        and pertub_idx_sd in ("aspp", "concat")
+    fold = fold if fold_clean is None else (bool(fold_clean) and fold)
+    if fold:
+        fc = model.forward_clean_folded(images, pertub_idx_se, pertub_idx_sd)
+        dec, low = fc.dec, fc.low
+        fm_sd, fm_se = dec["adv"].detach().float(), fc.fm_se.detach().float()
+    else:
+        fc = None
+        out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
+        dec = model({"x": images, "adv": None, "out_idx": pertub_idx_sd + "_head", "flag": "clean"})
+        fm_sd = dec["adv"].detach().float()       # (bf16 activations on the product path: the A-FAN operators work in fp32)
+        low = out_se["low_level"]
+        fm_se = out_se["out"].detach().float()
     # dual_bn (option, no reference counterpart): every pass over adversarial features — the two PGD loops and the three
     # perturbed forwards — normalises with the auxiliary BatchNorm set (resnet_s.enable_dual_bn); no-op otherwise
     from .resnet_s import bn_branch
@@ -118,7 +130,11 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     adv_sd_dict["adv"] = adv_sd
     # get_sample_points + mix_feature on the flagged points (main_aug_final.py:186-192) in one launch
     pts = sample_points_mixed(fm_se, adv_se.detach(), 3, (f0, f1)) if (f0 or f1) else get_sample_points(fm_se, adv_se.detach(), 3)
-    o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
+    if fold:
+        fc.replay_deferred_bn()                   # :193's BatchNorm side effects, after the PGD loops as in the reference
+        o0 = fc.logits
+    else:
+        o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
     with adv_bn():
         o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
         o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})

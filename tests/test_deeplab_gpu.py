@@ -122,7 +122,7 @@ def test_deeplab_step_bf16_runs_on_the_library_kernels(pkg, gpu, case):
     r = tr.step(images, labels)
     torch.cuda.synchronize()
     ran = {k: pkg.ops.CALLS[k] - before[k] for k in before}
-    assert ran["vendor_conv"] == 0 and ran["conv_fwd"] > 300 and ran["conv_dgrad"] > 100 and ran["conv_wgrad"] > 100, ran
+    assert ran["vendor_conv"] == 0 and ran["conv_fwd"] > 150 and ran["conv_dgrad"] > 100 and ran["conv_wgrad"] > 100, ran
     loss = float(g["loss"])
     assert abs(float(r["loss"]) - loss) <= 3e-2, (float(r["loss"]), loss)
     np.testing.assert_allclose(r["losses"].cpu().numpy(), g["losses"], rtol=0, atol=3e-2)
@@ -209,3 +209,49 @@ def test_deeplab_dual_bn_option(pkg, gpu):
         tr.scheduler.step()
     assert tr._graph is not None, tr._graph_failed
     assert all(np.isfinite(losses))
+
+
+@pytest.mark.parametrize("case,dtype", [("seg_dl101_aspp_k3_damped", torch.float32), ("seg_dl101_concat_k3", torch.float32),
+                                        ("seg_dl101_aspp_k3_damped", torch.bfloat16)])
+def test_deeplab_folded_clean_forward_equals_three_passes(pkg, gpu, case, dtype):
+    """forward_clean_folded (the head pass, the decoder-PGD input pass and the clean forward as ONE pass, BatchNorm
+    running statistics updated in the reference's order with the clean forward's update deferred behind the PGD loops)
+    against the three separate passes: two iterations each from the same seed."""
+    g = golden(case)
+    images, labels = torch.from_numpy(g["images"]).to(gpu), torch.from_numpy(g["labels"]).to(gpu)
+    res = {}
+    # (the first fp32 iteration of a process differs from later ones by ~2 % in the backbone gradients — the vendor's fp32
+    # convolutions settle on their algorithms during it, tools/probe/fold_grads.py — so a discarded iteration comes first)
+    for fold in ((None, False, True) if dtype == torch.float32 else (False, True)):
+        model, tr = _build(pkg, g, dtype, True, gpu, use_graph=False, fold_clean=bool(fold))
+        before = dict(pkg.ops.CALLS)
+        out = [tr.step(images, labels)]
+        if fold is None:
+            continue
+        n_fwd = sum(pkg.ops.CALLS[k] - before[k] for k in ("conv_fwd", "vendor_conv"))     # (fp32: the vendor's convolutions)
+        grad1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        sd1_ = {k: v.clone() for k, v in model.state_dict().items()}       # after the FIRST iteration: same weights in both runs
+        tr.scheduler.step()
+        out.append(tr.step(images, labels))
+        res[fold] = (out, grad1, sd1_, n_fwd)
+    (o0, g0, sd0, n0), (o1, g1, sd1, n1) = res[False], res[True]
+    assert n1 < n0 - 150, (n0, n1)               # ResNet-101: two backbone passes to the SE point + one layer4/ASPP pass fewer
+    exact = dtype == torch.float32
+    # (undamped network: sign() flips of the K = 3 PGD steps on gradients within rounding of zero move a loss term by ~1e-4)
+    ltol = (2e-5 if "damped" in case else 1e-3) if exact else 2e-2
+    np.testing.assert_allclose(o1[0]["losses"].cpu().numpy(), o0[0]["losses"].cpu().numpy(), rtol=0, atol=ltol)
+    # second iteration: the freshly initialised 101-layer network amplifies last-bit differences of the first update
+    # (section 9.3 of DESIGN.md: 0.3 % in, 58 % out at layer3) — a sanity bound only
+    np.testing.assert_allclose(o1[1]["losses"].cpu().numpy(), o0[1]["losses"].cpu().numpy(), rtol=5e-2)
+    # gradients: the contractive ("damped") network in fp32 pins the fold tightly; the freshly initialised one amplifies
+    # summation-order noise (one graph receives what three graphs received) through its 33 blocks
+    gtol = (5e-3 if "damped" in case else 0.1) if exact else 0.35
+    for n, a in g0.items():
+        rel = float((g1[n] - a).norm() / a.norm().clamp_min(1e-12))
+        assert rel <= gtol, (n, rel)
+    for k, v in sd0.items():
+        if "num_batches_tracked" in k:
+            assert int(sd1[k]) == int(v), k       # every BatchNorm saw the reference's number of updates
+        elif "running_" in k:
+            np.testing.assert_allclose(sd1[k].float().cpu().numpy(), v.float().cpu().numpy(), err_msg=k,
+                                       **(dict(rtol=1e-4, atol=1e-5) if exact else dict(rtol=5e-2, atol=5e-3)))
