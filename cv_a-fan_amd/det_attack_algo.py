@@ -1,0 +1,126 @@
+"""Detection feature-space operators and training iteration — names, signatures and error
+behaviour of the reference's `Detection/attack_algo.py`, and the loop body of `Detection/train_aug_sat_muti_advt.py:70-172`:
+
+    compute_loss(l1, l2, l3, l4)                                                                          :21-27
+    PGD(x, image_batch, y, model, steps, eps, gamma, idx, randinit, clip)                                 :48-74
+    rpn_roi_PGD(layer, rpn_roi_output_dict, y, model, steps, eps, gamma, randinit, clip, only_roi_loss)   :77-150
+    adv_input(x, y, model, steps, eps, gamma, randinit, clip)                                             :153-178
+    get_sample_points / mix_feature / tensor_clamp / linfball_proj                      (shared with attack_algo.py)
+    det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, loss_settings)   train_aug_sat_muti_advt.py:70-172
+
+`model` is anything that follows the reference's protocol (`Detection/model.py:40-185`):
+`model.train().forward({'x', 'adv', 'out_idx', 'flag'}, bboxes, labels)` -> four per-image loss tensors, a feature map
+(flag 'head') or the ROI dict ('roi_head').  The sign step / projection / noise / clamp / mix / sample-point arithmetic runs in
+libafan_hip.so; NMS and ROIAlign for the model's own layers are in det_ops.py.  The Faster-RCNN model itself is out of
+scope."""
+import torch
+
+from . import ops
+from .attack_algo import get_sample_points, linfball_proj, mix_feature, sample_points_mixed, tensor_clamp  # noqa: F401
+from .det_ops import PGD  # noqa: F401  (Detection/attack_algo.py:48-74)
+
+
+def compute_loss(loss1, loss2, loss3, loss4):
+    """:21-27: the sum of the four means."""
+    return loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()
+
+
+def _start(x, eps, randinit):
+    if x.device.type != "cuda":
+        raise ops.AfanLibraryError("x must live on the MI355X (no CPU path in this build)")
+    x = x.detach().float()
+    x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))) else x.contiguous()
+    x_adv = x.clone()
+    if randinit:   # noise from the CPU default generator, then host -> device, like the reference (:52, :159)
+        u = torch.rand(x_adv.shape).to(x.device, non_blocking=True)
+        if u.stride() != x_adv.stride():
+            u = u.contiguous(memory_format=torch.channels_last)
+        ops.axpy_noise_(x_adv, u, eps)
+    return x, x_adv
+
+
+def _ascend(x_adv, loss_of, gamma, x, eps, clip):
+    xin = x_adv.detach().requires_grad_(True)
+    grad = torch.autograd.grad(loss_of(xin), xin, only_inputs=True)[0]
+    if grad.stride() != x_adv.stride():
+        grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
+    ops.pgd_step_(x_adv, grad, gamma, x, eps if eps is not None else 0.0, clip)     # one launch: sign step (+ projection)
+
+
+def rpn_roi_PGD(layer="roi", rpn_roi_output_dict=None, y=None, model=None, steps=1, eps=None, gamma=None, randinit=False,
+                clip=False, only_roi_loss=True):
+    """:77-150.  layer 'roi': perturbs rpn_roi_output_dict['roi_output_dict']['roi_feature_map'] in the dict (loss = the two
+    proposal losses, or all four).  clip=True names an undefined `rpn_feature1` in the reference (:110) and raises
+    NameError after the first step — so does this.  layer 'rpn': the reference runs `steps` forwards and never moves the
+    feature (:129-146: the update is commented out) — the dict comes back with an unperturbed requires_grad copy."""
+    d = rpn_roi_output_dict
+    if layer == "roi":
+        _, x_adv = _start(d["roi_output_dict"]["roi_feature_map"], eps, randinit)
+        d["roi_output_dict"]["roi_feature_map"] = x_adv
+        for _ in range(steps):
+            def loss_of(t):
+                d["roi_output_dict"]["roi_feature_map"] = t
+                ao, at, pc, pt = model.train().forward({"adv": d, "out_idx": "roi_tail", "flag": "clean"}, y["bb"], y["lb"])
+                return (pc.mean() + pt.mean()) if only_roi_loss else (ao.mean() + at.mean() + pc.mean() + pt.mean())
+            _ascend(x_adv, loss_of, gamma, None, 0.0, False)
+            if clip:
+                raise NameError("name 'rpn_feature1' is not defined")
+        d["roi_output_dict"]["roi_feature_map"] = x_adv.requires_grad_(True)
+        return d
+    if layer == "rpn":
+        _, x_adv = _start(d["rpn_feature_map_dict"]["rpn_feature"], eps, randinit)
+        x_adv.requires_grad_(True)
+        d["rpn_feature_map_dict"]["rpn_feature"] = x_adv
+        for _ in range(steps):
+            model.train().forward({"adv": d, "out_idx": "rpn_tail", "flag": "clean"}, y["bb"], y["lb"])
+        return d
+    assert False
+
+
+def adv_input(x=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False):
+    """:153-178: image-space PGD under the sum of the four losses, clamped to [0, 1] at the end."""
+    x, x_adv = _start(x, eps, randinit)
+    for _ in range(steps):
+        _ascend(x_adv, lambda t: compute_loss(*model.train().forward({"x": t, "adv": None, "out_idx": -1, "flag": "clean"},
+                                                                     y["bb"], y["lb"])), gamma, x, eps, clip)
+    ops.tensor_clamp_(x_adv, torch.zeros_like(x_adv), torch.ones_like(x_adv))
+    return x_adv.requires_grad_(True)
+
+
+def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, loss_settings=1):
+    """One iteration of Detection/train_aug_sat_muti_advt.py:70-172: adversarial image (5 steps, randinit, clip), the three
+    backbone feature maps and the ROI dict, three one-step feature PGDs (`multi-layer`), five SAT sample points of the
+    deepest one with points 1 and 2 re-normalised by mix_feature (one fused launch), the one-step ROI feature PGD +
+    mix_feature, eight forwards, and the weighted loss of :141-153 (loss_settings 1-4)."""
+    y = {"bb": bboxes_batch, "lb": labels_batch}
+    fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
+    adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+    fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
+    rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
+    clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
+    adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+    adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+    adv3 = PGD(fm[2], image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+    pts = sample_points_mixed(fm[2].float(), adv3.detach(), 5, (True, True, False, False))       # :95-97 in one launch
+    adv_rr = rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
+    adv_sd = mix_feature(clean_sd.float(), adv_rr["roi_output_dict"]["roi_feature_map"].detach())
+    adv_rr["roi_output_dict"]["roi_feature_map"] = adv_sd
+    dicts = [{"x": adv_image.detach(), "adv": None, "out_idx": 0, "flag": "clean"},
+             {"x": image_batch, "adv": adv1, "out_idx": 1, "flag": "tail"},
+             {"x": image_batch, "adv": adv2, "out_idx": 2, "flag": "tail"}] + \
+            [{"x": image_batch, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
+            [{"adv": adv_rr, "out_idx": "roi_tail", "flag": "clean"}]
+    L = [compute_loss(*fwd(d)) for d in dicts]
+    loss_clean_adv = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
+    if loss_settings == 1:
+        loss = loss_clean_adv
+    elif loss_settings in (2, 3, 4):
+        a, b = {2: (0.5, 0.5), 3: (0.4, 0.6), 4: (0.3, 0.7)}[loss_settings]
+        loss = a * loss_clean_adv + b * L[0]
+    else:
+        assert False
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return {"loss": loss.detach(), "losses": torch.stack(L).detach(), "adv_image": adv_image.detach(), "adv1": adv1.detach(),
+            "adv2": adv2.detach(), "adv3": adv3.detach(), "adv_sd": adv_sd.detach(), "fm3": fm[2]}

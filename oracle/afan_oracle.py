@@ -610,6 +610,258 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}
 
 
+# ------------------------------------------------------------- Detection (N2): step functions on a protocol-faithful toy detector
+def roi_align_torch(inp, rois, output_size, spatial_scale, sampling_ratio):
+    """Detection/support/src/cpu/ROIAlign_cpu.cpp:110-238 / cuda/ROIAlign_cuda.cu:10-122 (legacy, un-aligned ROIAlign) in
+    differentiable torch ops: rois [K, 5] = (batch index, x1, y1, x2, y2) in image coordinates; roi extent clamped to
+    >= 1; sampling_ratio > 0 samples per bin side (else ceil(roi size / bins)); a sample outside [-1, H] x [-1, W]
+    contributes 0, coordinates are clamped to [0, size-1], bilinear weights from the clamped position; bin = mean of
+    its samples.  Pinned to oracle_roi_align (C) in tests/test_det_oracle.py."""
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    n, c, h, w = inp.shape
+    out = []
+    for r in rois:
+        b = int(r[0])
+        x1, y1, x2, y2 = [float(v) * spatial_scale for v in r[1:]]
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        bh, bw = rh / ph, rw / pw
+        gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rh / ph))
+        gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(rw / pw))
+        ys = y1 + (torch.arange(ph, dtype=torch.float32)[:, None] + (torch.arange(gh, dtype=torch.float32)[None, :] + 0.5) / gh) * bh
+        xs = x1 + (torch.arange(pw, dtype=torch.float32)[:, None] + (torch.arange(gw, dtype=torch.float32)[None, :] + 0.5) / gw) * bw
+        ys, xs = ys.reshape(-1), xs.reshape(-1)                        # [ph*gh], [pw*gw]
+
+        def axis(t, size):
+            ok = (t >= -1.0) & (t <= size)
+            t = t.clamp(min=0.0)
+            lo = t.floor().long()
+            hi = lo + 1
+            top = lo >= size - 1
+            lo = torch.where(top, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(top, torch.full_like(hi, size - 1), hi)
+            t = torch.where(top, lo.float(), t)
+            l = t - lo.float()
+            return ok, lo, hi, l, 1.0 - l
+
+        oky, ylo, yhi, ly, hy = axis(ys, h)
+        okx, xlo, xhi, lx, hx = axis(xs, w)
+        f = inp[b]                                                     # [c, h, w]
+        g = lambda yy, xx: f[:, yy][:, :, xx]                          # [c, ph*gh, pw*gw]
+        v = (g(ylo, xlo) * (hy[:, None] * hx[None, :]) + g(ylo, xhi) * (hy[:, None] * lx[None, :])
+             + g(yhi, xlo) * (ly[:, None] * hx[None, :]) + g(yhi, xhi) * (ly[:, None] * lx[None, :]))
+        v = v * (oky[:, None] & okx[None, :]).float()
+        out.append(v.reshape(c, ph, gh, pw, gw).sum(dim=(2, 4)) / float(gh * gw))
+    return torch.stack(out) if out else inp.new_zeros(0, c, ph, pw)
+
+
+class TinyDetNet(nn.Module):
+    """A small detector that follows the reference's dispatch protocol — `Detection/model.py:40-185` (flag head / tail /
+    clean; integer out_idx or 'roi_head' / 'roi_tail'; training mode returns four per-image loss tensors; BatchNorm
+    frozen in eval mode inside every training forward, `:46-47`) and `backbone/resnet101_ori.py:203-262` (head = up to
+    layer out_idx, tail = the layers after it, out_idx 3 tail = identity) — on a three-stage toy backbone, a one-anchor
+    RPN head and a ROIAlign + two-layer detection head over the ground-truth boxes.  Test infrastructure: it lets the
+    reference's own `Detection/attack_algo.py` functions and the build's operators run on the same model; Faster-RCNN
+    itself (rpn/, roi/, anchors, proposals) is out of scope.  `roi_align` is pluggable: the torch restatement above on
+    the CPU, the library's HIP operator in the GPU tests."""
+
+    def __init__(self, num_classes=4, w=8, roi_align=None):
+        super().__init__()
+        self.stem = _ConvBNReLU(3, w, 3, 2)
+        self.layer1 = _ConvBNReLU(w, w)
+        self.layer2 = _ConvBNReLU(w, 2 * w, 3, 2)
+        self.layer3 = _ConvBNReLU(2 * w, 4 * w)
+        self.rpn_obj = nn.Conv2d(4 * w, 1, 1)
+        self.rpn_tr = nn.Conv2d(4 * w, 4, 1)
+        self.hidden = nn.Linear(4 * w * 2 * 2, 16)
+        self.cls = nn.Linear(16, num_classes)
+        self.reg = nn.Linear(16, 4)
+        self._bn_modules = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        self.roi_align = roi_align or roi_align_torch
+        self.stride = 4
+
+    def features(self, d):
+        layers = [self.layer1, self.layer2, self.layer3]
+        if d["flag"] == "head":
+            assert d["out_idx"] in (1, 2, 3)
+            x = self.stem(d["x"])
+            for L in layers[:d["out_idx"]]:
+                x = L(x)
+            return x
+        if d["flag"] == "tail":
+            x = d["adv"]
+            for L in layers[d["out_idx"]:]:
+                x = L(x)
+            return x
+        assert d["flag"] == "clean"
+        x = self.stem(d["x"])
+        for L in layers:
+            x = L(x)
+        return x
+
+    def rpn(self, f, bb):
+        """Per-image objectness (BCE against 'pixel centre inside a ground-truth box') and transformer (smooth-L1 of the
+        4 regression maps against the box's normalised centre offset / log size, on the positive pixels) losses."""
+        import torch.nn.functional as F
+        n, _, h, w = f.shape
+        obj, tr = self.rpn_obj(f)[:, 0], self.rpn_tr(f)
+        cy = (torch.arange(h, dtype=f.dtype, device=f.device) + 0.5) * self.stride
+        cx = (torch.arange(w, dtype=f.dtype, device=f.device) + 0.5) * self.stride
+        lo_obj, lo_tr = [], []
+        for i in range(n):
+            tgt = torch.zeros(h, w, dtype=f.dtype, device=f.device)
+            reg = torch.zeros(4, h, w, dtype=f.dtype, device=f.device)
+            for b in bb[i]:
+                x1, y1, x2, y2 = [float(v) for v in b]
+                m = ((cy[:, None] >= y1) & (cy[:, None] <= y2) & (cx[None, :] >= x1) & (cx[None, :] <= x2)).to(f.dtype)
+                tgt = torch.maximum(tgt, m)
+                bw_, bh_ = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+                t = torch.stack([((x1 + x2) / 2 - cx)[None, :].expand(h, w) / bw_, ((y1 + y2) / 2 - cy)[:, None].expand(h, w) / bh_,
+                                 torch.full((h, w), float(np.log(bw_ / 16.0)), dtype=f.dtype, device=f.device),
+                                 torch.full((h, w), float(np.log(bh_ / 16.0)), dtype=f.dtype, device=f.device)])
+                reg = torch.where(m[None] > 0, t, reg)
+            lo_obj.append(F.binary_cross_entropy_with_logits(obj[i], tgt))
+            sl = F.smooth_l1_loss(tr[i], reg, reduction="none") * tgt[None]
+            lo_tr.append(sl.sum() / tgt.sum().clamp(min=1.0))
+        return torch.stack(lo_obj), torch.stack(lo_tr)
+
+    def detection(self, f, bb=None, lb=None, return_type=None):
+        import torch.nn.functional as F
+        if return_type == "tail":
+            d = f
+            roi, bb, lb = d["roi_feature_map"], d["bboxes"], d["labels"]
+        else:
+            n, g = bb.shape[0], bb.shape[1]
+            idx = torch.arange(n, dtype=bb.dtype, device=bb.device)[:, None].expand(n, g).reshape(-1, 1)
+            rois = torch.cat([idx, bb.reshape(-1, 4)], dim=1)
+            roi = self.roi_align(f, rois, (2, 2), 1.0 / self.stride, 2)
+            if return_type == "head":
+                return {"roi_feature_map": roi, "bboxes": bb, "labels": lb}
+        n, g = bb.shape[0], bb.shape[1]
+        hid = F.relu(self.hidden(roi.flatten(1)))
+        ce = F.cross_entropy(self.cls(hid), lb.reshape(-1), reduction="none").reshape(n, g).mean(dim=1)
+        tgt = torch.stack([(bb[..., 2] - bb[..., 0]) / 32.0, (bb[..., 3] - bb[..., 1]) / 32.0,
+                           (bb[..., 0] + bb[..., 2]) / 64.0, (bb[..., 1] + bb[..., 3]) / 64.0], dim=-1).reshape(-1, 4)
+        sl = F.smooth_l1_loss(self.reg(hid), tgt, reduction="none").sum(dim=1).reshape(n, g).mean(dim=1)
+        return ce, sl
+
+    def forward(self, input_dict, gt_bboxes_batch=None, gt_classes_batch=None):
+        d = input_dict
+        if d["flag"] == "head":
+            for m in self._bn_modules:
+                m.eval()
+            return self.features(d)
+        assert d["flag"] in ("tail", "clean") and self.training
+        if type(d["out_idx"]) == int:
+            for m in self._bn_modules:
+                m.eval()
+            f = self.features(d)
+            ao, at = self.rpn(f, gt_bboxes_batch)
+            pc, pt = self.detection(f, gt_bboxes_batch, gt_classes_batch)
+            return ao, at, pc, pt
+        if d["out_idx"] == "roi_head":
+            for m in self._bn_modules:
+                m.eval()
+            f = self.features(d)
+            ao, at = self.rpn(f, gt_bboxes_batch)
+            return {"anchor_objectness_losses": ao, "anchor_transformer_losses": at,
+                    "roi_output_dict": self.detection(f, gt_bboxes_batch, gt_classes_batch, return_type="head")}
+        assert d["out_idx"] == "roi_tail"
+        u = d["adv"]
+        pc, pt = self.detection(u["roi_output_dict"], return_type="tail")
+        return u["anchor_objectness_losses"], u["anchor_transformer_losses"], pc, pt
+
+
+def det_compute_loss(l1, l2, l3, l4):
+    """Detection/attack_algo.py:21-27."""
+    return l1.mean() + l2.mean() + l3.mean() + l4.mean()
+
+
+def det_PGD(x, image_batch, y=None, model=None, steps=3, eps=None, gamma=None, idx=1, randinit=False, clip=False):
+    """Detection/attack_algo.py:48-74."""
+    x_adv = x.clone()
+    if randinit:
+        x_adv += (2.0 * torch.rand(x_adv.shape) - 1.0) * eps
+    x_adv.requires_grad_(True)
+    for _ in range(steps):
+        loss = det_compute_loss(*model.train().forward({"x": image_batch, "adv": x_adv, "out_idx": idx, "flag": "tail"}, y["bb"], y["lb"]))
+        g = torch.autograd.grad(loss, x_adv, only_inputs=True)[0]
+        x_adv.data.add_(gamma * torch.sign(g.data))
+        if clip:
+            linf_project_(x, eps, x_adv.data)
+    return x_adv
+
+
+def det_roi_PGD(rpn_roi_output_dict, y=None, model=None, steps=1, eps=None, gamma=None, randinit=False, clip=False,
+                only_roi_loss=True):
+    """Detection/attack_algo.py:77-116 (layer='roi'): perturbs roi_output_dict['roi_feature_map'] in the dict.  clip=True
+    names an undefined `rpn_feature1` there (:110) and raises NameError after the first step — kept."""
+    d = rpn_roi_output_dict
+    x_adv = d["roi_output_dict"]["roi_feature_map"].detach().clone()
+    if randinit:
+        x_adv += (2.0 * torch.rand(x_adv.shape) - 1.0) * eps
+    x_adv.requires_grad_(True)
+    d["roi_output_dict"]["roi_feature_map"] = x_adv
+    for _ in range(steps):
+        ao, at, pc, pt = model.train().forward({"adv": d, "out_idx": "roi_tail", "flag": "clean"}, y["bb"], y["lb"])
+        loss = (pc.mean() + pt.mean()) if only_roi_loss else (ao.mean() + at.mean() + pc.mean() + pt.mean())
+        g = torch.autograd.grad(loss, x_adv, only_inputs=True)[0]
+        x_adv.data.add_(gamma * torch.sign(g.data))
+        if clip:
+            raise NameError("name 'rpn_feature1' is not defined")
+    d["roi_output_dict"]["roi_feature_map"] = x_adv
+    return d
+
+
+def det_adv_input(x=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False):
+    """Detection/attack_algo.py:153-178: image-space PGD, clamped to [0, 1] at the end."""
+    x_adv = x.clone()
+    if randinit:
+        x_adv += (2.0 * torch.rand(x_adv.shape) - 1.0) * eps
+    x_adv.requires_grad_(True)
+    for _ in range(steps):
+        loss = det_compute_loss(*model.train().forward({"x": x_adv, "adv": None, "out_idx": -1, "flag": "clean"}, y["bb"], y["lb"]))
+        g = torch.autograd.grad(loss, x_adv, only_inputs=True)[0]
+        x_adv.data.add_(gamma * torch.sign(g.data))
+        if clip:
+            linf_project_(x, eps, x_adv.data)
+    return torch.clamp(x_adv, 0, 1.0)
+
+
+def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, loss_settings=1):
+    """One iteration of Detection/train_aug_sat_muti_advt.py:70-172: adversarial image (5 steps, randinit, clip), three
+    feature maps + the ROI dict, three one-step feature PGDs, five SAT sample points (two of them mixed), one-step ROI
+    feature PGD + mix_feature, eight forwards, the weighted loss of :141-153."""
+    y = {"bb": bboxes_batch, "lb": labels_batch}
+    fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
+    adv_image = det_adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+    fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
+    rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
+    clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
+    adv1 = det_PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+    adv2 = det_PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+    adv3 = det_PGD(fm[2], image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+    pts = get_sample_points(fm[2], adv3, 5)
+    pts[1] = mix_feature(fm[2], pts[1])
+    pts[2] = mix_feature(fm[2], pts[2])
+    adv_rr = det_roi_PGD(rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
+    adv_sd = mix_feature(clean_sd, adv_rr["roi_output_dict"]["roi_feature_map"].detach())
+    adv_rr["roi_output_dict"]["roi_feature_map"] = adv_sd
+    dicts = [{"x": adv_image, "adv": None, "out_idx": 0, "flag": "clean"},
+             {"x": image_batch, "adv": adv1, "out_idx": 1, "flag": "tail"},
+             {"x": image_batch, "adv": adv2, "out_idx": 2, "flag": "tail"}] + \
+            [{"x": image_batch, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
+            [{"adv": adv_rr, "out_idx": "roi_tail", "flag": "clean"}]
+    L = [det_compute_loss(*fwd(d)) for d in dicts]
+    loss_clean_adv = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
+    w = {1: (1.0, 0.0), 2: (0.5, 0.5), 3: (0.4, 0.6), 4: (0.3, 0.7)}[loss_settings]
+    loss = loss_clean_adv if loss_settings == 1 else w[0] * loss_clean_adv + w[1] * L[0]
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return {"loss": loss.detach(), "losses": torch.stack(L).detach(), "adv_image": adv_image.detach(), "adv1": adv1.detach(),
+            "adv2": adv2.detach(), "adv3": adv3.detach(), "adv_sd": adv_sd.detach(), "fm3": fm[2]}
+
+
 # ------------------------------------------------------------- DeepLabv3+ (N1, second slice): the reference's network restated
 class SegBottleneck(nn.Module):
     """Segmentation/network/backbone/resnet.py:76-119 (groups=1, base_width=64)."""

@@ -116,6 +116,73 @@ def _pgd_trace(ref_attack, model, criterion, fm, target, steps, gamma, eps, idx,
     return seen  # K+1 snapshots: x_adv before step 0 ... after step K-1
 
 
+def gen_detection(orc):
+    # ---- Detection (N2): the reference's own adv_input / PGD / rpn_roi_PGD / get_sample_points / mix_feature / compute_loss
+    # (Detection/attack_algo.py) and the loop body of Detection/train_aug_sat_muti_advt.py:70-172 driven line by line around
+    # them, on the protocol-faithful stand-in detector oracle.TinyDetNet (the reference's Faster-RCNN needs its compiled
+    # extension and torchvision weights).  `.cuda()` is the identity here (_shims). ------------------------------------
+    ref_det = _load("ref_det_attack_algo", "Detection/attack_algo.py")
+    for name, loss_settings in (("det_step_tiny_s1", 1), ("det_step_tiny_s3", 3)):
+        torch.manual_seed(11)
+        model = orc.TinyDetNet()
+        model.train()
+        optimizer = torch.optim.SGD(model.parameters(), 0.01, momentum=0.9, weight_decay=5e-4)
+        image_batch = torch.rand(2, 3, 32, 32)
+        bboxes_batch = torch.tensor([[[2., 3., 20., 18.], [10., 12., 30., 31.]], [[0., 0., 15., 15.], [8., 4., 28., 22.]]])
+        labels_batch = torch.tensor([[1, 2], [3, 0]])
+        k0, c0 = _checksums(model)
+        y = {"bb": bboxes_batch, "lb": labels_batch}
+        adv_image_batch = ref_det.adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+        inputs_all1 = {"x": image_batch, "adv": None, "out_idx": 1, "flag": "head"}
+        inputs_all2 = {"x": image_batch, "adv": None, "out_idx": 2, "flag": "head"}
+        inputs_all3 = {"x": image_batch, "adv": None, "out_idx": 3, "flag": "head"}
+        inputs_all_sd = {"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"}
+        feature_map1 = model.train().forward(inputs_all1, bboxes_batch, labels_batch).detach()
+        feature_map2 = model.train().forward(inputs_all2, bboxes_batch, labels_batch).detach()
+        feature_map3 = model.train().forward(inputs_all3, bboxes_batch, labels_batch).detach()
+        rpn_roi_output_dict = model.train().forward(inputs_all_sd, bboxes_batch, labels_batch)
+        clean_feature_map_sd = rpn_roi_output_dict["roi_output_dict"]["roi_feature_map"].detach()
+        feature_adv1 = ref_det.PGD(feature_map1, image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+        feature_adv2 = ref_det.PGD(feature_map2, image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+        feature_adv3 = ref_det.PGD(feature_map3, image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+        adv_list = ref_det.get_sample_points(feature_map3, feature_adv3, 5)
+        adv_list[1] = ref_det.mix_feature(feature_map3, adv_list[1])
+        adv_list[2] = ref_det.mix_feature(feature_map3, adv_list[2])
+        adv_rpn_roi_output_dict = ref_det.rpn_roi_PGD(rpn_roi_output_dict=rpn_roi_output_dict, y=y, model=model, steps=1,
+                                                      eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
+        adv_feature_map_sd = adv_rpn_roi_output_dict["roi_output_dict"]["roi_feature_map"].detach()
+        adv_feature_map_sd = ref_det.mix_feature(clean_feature_map_sd, adv_feature_map_sd)
+        adv_rpn_roi_output_dict["roi_output_dict"]["roi_feature_map"] = adv_feature_map_sd
+        dicts = [{"x": adv_image_batch, "adv": None, "out_idx": 0, "flag": "clean"},
+                 {"x": image_batch, "adv": feature_adv1, "out_idx": 1, "flag": "tail"},
+                 {"x": image_batch, "adv": feature_adv2, "out_idx": 2, "flag": "tail"},
+                 {"x": image_batch, "adv": adv_list[1], "out_idx": 3, "flag": "tail"},
+                 {"x": image_batch, "adv": adv_list[2], "out_idx": 3, "flag": "tail"},
+                 {"x": image_batch, "adv": adv_list[3], "out_idx": 3, "flag": "tail"},
+                 {"x": image_batch, "adv": adv_list[4], "out_idx": 3, "flag": "tail"},
+                 {"adv": adv_rpn_roi_output_dict, "out_idx": "roi_tail", "flag": "clean"}]
+        L = [ref_det.compute_loss(*model.train().forward(d, bboxes_batch, labels_batch)) for d in dicts]
+        loss0, loss1, loss2, loss3, loss4, loss5, loss6, loss7 = L
+        loss_clean_adv = 0.9 * (0.2333 * (loss0 + loss3 + loss4 + loss5 + loss6) + 0.1 * loss7) + 0.05 * (loss1 + loss2)
+        if loss_settings == 1:
+            loss = loss_clean_adv
+        elif loss_settings == 3:
+            loss = 0.4 * loss_clean_adv + 0.6 * loss0
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        k1, c1 = _checksums(model)
+        sd = model.state_dict()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), images=_np(image_batch), bboxes=_np(bboxes_batch), labels=_np(labels_batch),
+                            loss_settings=np.array(loss_settings), ck0=c0, ck1=c1, keys=np.array(k1), loss=_np(loss),
+                            losses=np.array([float(v) for v in L], dtype=np.float32), adv_image=_np(adv_image_batch),
+                            adv1=_np(feature_adv1), adv2=_np(feature_adv2), adv3=_np(feature_adv3), adv_sd=_np(adv_feature_map_sd),
+                            fm3=_np(feature_map3), **{"sd1/" + k: _np(sd[k]) for k in ("stem.0.weight", "layer3.0.weight", "rpn_obj.weight",
+                                                                                    "hidden.weight", "cls.bias", "layer2.1.running_mean")})
+        print(name, "loss", float(loss), [round(float(v), 5) for v in L])
+
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
     _shims()
@@ -452,6 +519,8 @@ def main():
     for clash in ("network", "utils"):
         sys.modules.pop(clash, None)
 
+    gen_detection(orc)
+
     # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
     torch.manual_seed(7)
     rec = {}
@@ -477,4 +546,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["det"]:           # only the Detection fixtures (the full run regenerates every file bit-identically)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        os.makedirs(OUT, exist_ok=True)
+        from oracle import afan_oracle as _orc
+        gen_detection(_orc)
+    else:
+        main()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, ptr
+from conftest import GOLDEN, golden, ptr
 
 pytestmark = pytest.mark.gpu
 
@@ -121,3 +121,59 @@ def test_detection_pgd_protocol(pkg, gpu):
     assert out.requires_grad and out.is_leaf and torch.equal(x, x0)
     k = ((out.detach() - x) / (0.5 / 255)).round()
     assert float(k.abs().max()) <= 3 and float((out.detach() - x).abs().max()) <= 2 / 255 + 1e-7
+
+
+@pytest.mark.parametrize("case", ["det_step_tiny_s1", "det_step_tiny_s3"])
+def test_detection_step_matches_reference_functions(pkg, orc, gpu, case):
+    """det_attack_algo.det_train_step (image PGD with random start, three one-step feature PGDs, fused sample points + mix,
+    ROI-feature PGD + mix, eight forwards, weighted loss, SGD) on the GPU against ONE iteration of the reference's own
+    Detection/attack_algo.py functions driven through train_aug_sat_muti_advt.py:70-172 (oracle/gen_golden.py
+    gen_detection) on oracle.TinyDetNet — here with the library's ROIAlign operator inside the model."""
+    g = golden(case)
+    torch.manual_seed(11)
+    model = orc.TinyDetNet(roi_align=pkg.det_ops.roi_align)
+    ck0 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in model.state_dict().values()])
+    np.testing.assert_allclose(ck0, g["ck0"], rtol=1e-12)
+    model.to(gpu).train()
+    opt = torch.optim.SGD(model.parameters(), 0.01, momentum=0.9, weight_decay=5e-4)
+    images = torch.rand(2, 3, 32, 32)                   # leaves the CPU generator where the reference's randinit found it
+    np.testing.assert_array_equal(images.numpy(), g["images"])
+    r = pkg.det_attack_algo.det_train_step(model, opt, images.to(gpu), torch.from_numpy(g["bboxes"]).to(gpu),
+                                           torch.from_numpy(g["labels"]).to(gpu), loss_settings=int(g["loss_settings"]))
+    np.testing.assert_allclose(r["losses"].cpu().numpy(), g["losses"], rtol=1e-4)
+    assert abs(float(r["loss"]) - float(g["loss"])) <= 1e-4 * max(1.0, abs(float(g["loss"])))
+    # perturbations: identical except where sign() flips on a gradient within rounding of zero; the image PGD is clipped to
+    # eps = 2/255 and clamped to [0, 1], the feature PGDs take one step of size gamma
+    for k, gamma in (("adv1", 0.001 / 255), ("adv2", 0.001 / 255), ("adv3", 1.0 / 255)):
+        d_got, d_ref = r[k].cpu().numpy(), g[k]
+        frac = float((np.abs(d_got - d_ref) > 0.5 * gamma).mean())
+        assert frac <= 2e-2, (k, frac)
+    np.testing.assert_allclose(r["adv_image"].cpu().numpy(), g["adv_image"], rtol=0, atol=2 * 2.0 / 255 + 1e-6)
+    assert float((np.abs(r["adv_image"].cpu().numpy() - g["adv_image"]) > 1e-6).mean()) <= 5e-2
+    assert float(r["adv_image"].min()) >= 0.0 and float(r["adv_image"].max()) <= 1.0
+    np.testing.assert_allclose(r["adv_sd"].cpu().numpy(), g["adv_sd"], rtol=1e-3, atol=1e-3)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("sd1/"):
+            np.testing.assert_allclose(sd[k[4:]].cpu().numpy(), g[k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_detection_roi_pgd_clip_error_and_rpn_branch(pkg, orc, gpu):
+    """rpn_roi_PGD keeps the reference's behaviour at its edges: clip=True raises the NameError of :110 after the first
+    step; loss_settings outside 1-4 asserts; the result of the ROI PGD lies on the sign grid."""
+    torch.manual_seed(11)
+    model = orc.TinyDetNet(roi_align=pkg.det_ops.roi_align).to(gpu).train()
+    images = torch.rand(2, 3, 32, 32, device=gpu)
+    bb = torch.tensor([[[2., 3., 20., 18.], [10., 12., 30., 31.]], [[0., 0., 15., 15.], [8., 4., 28., 22.]]], device=gpu)
+    lb = torch.tensor([[1, 2], [3, 0]], device=gpu)
+    y = {"bb": bb, "lb": lb}
+    rr = model.train().forward({"x": images, "adv": None, "out_idx": "roi_head", "flag": "clean"}, bb, lb)
+    clean = rr["roi_output_dict"]["roi_feature_map"].detach().clone()
+    out = pkg.det_attack_algo.rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=2, eps=1.0, gamma=0.25)
+    k = ((out["roi_output_dict"]["roi_feature_map"].detach() - clean) / 0.25).round()
+    assert set(k.unique().tolist()) <= {-2.0, 0.0, 2.0} and out["roi_output_dict"]["roi_feature_map"].requires_grad
+    rr = model.train().forward({"x": images, "adv": None, "out_idx": "roi_head", "flag": "clean"}, bb, lb)
+    with pytest.raises(NameError):
+        pkg.det_attack_algo.rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=1.0, gamma=0.25, clip=True)
+    with pytest.raises(AssertionError):
+        pkg.det_attack_algo.det_train_step(model, torch.optim.SGD(model.parameters(), 0.01), images, bb, lb, loss_settings=7)

@@ -79,3 +79,49 @@ def test_roi_align_oracle_closed_forms(c_oracle):
     dy = rng.standard_normal(yf.shape).astype(np.float32)
     dx = _roi(c_oracle, xr, rois2, 5, 6, 1 / 16, 0, mode=1, dy=dy)
     assert abs(float((dy * yf).sum()) - float((dx * xr).sum())) <= 1e-3 * abs(float((dy * yf).sum()))
+
+
+def test_roi_align_torch_restatement_equals_c_oracle(orc, c_oracle):
+    """oracle.roi_align_torch (the differentiable restatement TinyDetNet uses on the CPU) against oracle_roi_align (C):
+    forward values and, through autograd, the input gradient."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, 9, 11)).astype(np.float32)
+    rois = np.array([[0, 1.0, 2.0, 30.0, 25.0], [1, 0.0, 0.0, 43.0, 35.0], [1, 10.5, 3.25, 12.0, 4.0], [0, -6.0, -3.0, 20.0, 50.0]],
+                    dtype=np.float32)
+    for sr in (2, 0):
+        xt = torch.from_numpy(x).requires_grad_(True)
+        out = orc.roi_align_torch(xt, torch.from_numpy(rois), (3, 2), 0.25, sr)
+        ref = _roi(c_oracle, x, rois, 3, 2, 0.25, sr)
+        np.testing.assert_allclose(out.detach().numpy(), ref, rtol=1e-5, atol=1e-6)
+        dy = rng.standard_normal(out.shape).astype(np.float32)
+        out.backward(torch.from_numpy(dy))
+        np.testing.assert_allclose(xt.grad.numpy(), _roi(c_oracle, x, rois, 3, 2, 0.25, sr, mode=1, dy=dy), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["det_step_tiny_s1", "det_step_tiny_s3"])
+def test_detection_step_matches_reference_functions(orc, case):
+    """oracle.det_train_step == the loop body of Detection/train_aug_sat_muti_advt.py:70-172 run with the reference's own
+    attack_algo functions (oracle/gen_golden.py gen_detection) on oracle.TinyDetNet."""
+    import torch
+    from conftest import golden
+    g = golden(case)
+    torch.manual_seed(11)
+    model = orc.TinyDetNet()
+    model.train()
+    ck0 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in model.state_dict().values()])
+    np.testing.assert_allclose(ck0, g["ck0"], rtol=1e-12)
+    opt = torch.optim.SGD(model.parameters(), 0.01, momentum=0.9, weight_decay=5e-4)
+    images = torch.rand(2, 3, 32, 32)
+    np.testing.assert_array_equal(images.numpy(), g["images"])          # same generator state as the reference run had
+    r = orc.det_train_step(model, opt, images, torch.from_numpy(g["bboxes"]), torch.from_numpy(g["labels"]),
+                           loss_settings=int(g["loss_settings"]))
+    np.testing.assert_allclose(r["losses"].numpy(), g["losses"], rtol=1e-6)
+    np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=1e-6)
+    for k in ("adv_image", "adv1", "adv2", "adv3", "adv_sd"):
+        np.testing.assert_allclose(r[k].numpy(), g[k], rtol=0, atol=1e-7, err_msg=k)
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("sd1/"):
+            np.testing.assert_allclose(sd[k[4:]].numpy(), g[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    assert float(sd["layer2.1.running_mean"].abs().max()) == 0.0      # BatchNorm stays frozen (model.py:46-47)
