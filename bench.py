@@ -208,9 +208,6 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if seg and world > 1:
-        raise SystemExit("the DeepLab workload is benched per GPU (replicas only in this build; see DESIGN.md §7)")
-
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(3)                      # same initial weights on every rank (reference --seed 3)
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream

@@ -86,7 +86,7 @@ def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gam
 
 def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                    pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                   clip=False, dual_bn=False, fold_clean=None):
+                   clip=False, dual_bn=False, fold_clean=None, defer_step=False):
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
     0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
@@ -151,6 +151,7 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
         l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
         loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
         loss.backward()
-    optimizer.step()
+    if not defer_step:          # (data-parallel callers all-reduce the gradient arena first: seg_trainer.SegTrainer)
+        optimizer.step()
     return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}

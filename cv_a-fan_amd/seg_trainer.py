@@ -21,7 +21,8 @@ class SegTrainer:
     def __init__(self, model, criterion=None, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3,
                  pertub_idx_sd="aspp", mix_layer="11", mix_sd=False, noise_sd=0.0, randinit=False, clip=False, lr=0.01,
                  momentum=0.9, weight_decay=1e-4, total_itrs=30000, lr_policy="poly", step_size=10000,
-                 backbone_bn_momentum=0.01, use_graph=True, graph_warmup=2, dual_bn=False, fold_clean=None):
+                 backbone_bn_momentum=0.01, use_graph=True, graph_warmup=2, dual_bn=False, fold_clean=None, group=None,
+                 allreduce_chunks=4):
         self.model = model
         if dual_bn:      # BASELINE configs[3] "+ dual-BN": an option the reference does not have (resnet_s.enable_dual_bn); default off
             resnet_s.enable_dual_bn(model)
@@ -38,6 +39,24 @@ class SegTrainer:
             self.scheduler = PolyLR(self.optimizer, total_itrs, power=0.9)
         else:
             self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=step_size, gamma=0.1)
+        # data parallel (BASELINE configs[3] is 4 GPUs x 2 images): minibatch sharding, BatchNorm per replica like the
+        # reference's nn.DataParallel, ONE exchange per iteration — the fp32 gradient arena, summed over the ranks in
+        # chunks on a side stream after the backward, 1/world folded into the SGD kernel.  The iteration's graph ends
+        # before the optimizer step; the all-reduce and the one SGD launch follow it.
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer = None
+        if self.world > 1:
+            from .train_step import GradAllReducer
+            self.reducer = GradAllReducer(self.arena, allreduce_chunks, group)
+            self.optimizer.grad_scale = 1.0 / self.world
+            for t in (self.arena.param, self.arena.momentum_buf):      # replicas start from rank 0's state
+                dist.broadcast(t, src=0, group=group)
+            for b in model.buffers():
+                dist.broadcast(b, src=0, group=group)
+            self.arena.refresh_shadow()
+            self.kw["defer_step"] = True
         self.use_graph = bool(use_graph) and not randinit and noise_sd == 0
         self.graph_warmup = graph_warmup
         self._graph = self._graph_failed = self._static = self._out = self._key = None
@@ -45,6 +64,12 @@ class SegTrainer:
 
     def _body(self, images, labels):
         return seg_train_step(self.model, self.optimizer, self.criterion, images, labels, **self.kw)
+
+    def _exchange_and_step(self):
+        if self.reducer is not None:
+            self.reducer.begin(explicit=True)      # nothing was announced during the backward: finish() reduces everything
+            self.reducer.finish()
+            self.optimizer.step()
 
     def _graph_safe(self):
         if resnet_s.vendor_convs(self.model):
@@ -60,6 +85,7 @@ class SegTrainer:
             self._static[1].copy_(labels, non_blocking=True)
             self.optimizer._sync_lr()
             self._graph.replay()
+            self._exchange_and_step()
             small = ("loss", "losses")
             return {k: (v.clone() if k in small else v) for k, v in self._out.items()}
         if (self.use_graph and self._graph is None and self._graph_failed is None and images.is_cuda
@@ -83,4 +109,6 @@ class SegTrainer:
                 torch.cuda.synchronize()
         self._eager_steps += 1
         self.optimizer._sync_lr()
-        return self._body(images, labels)
+        out = self._body(images, labels)
+        self._exchange_and_step()
+        return out
