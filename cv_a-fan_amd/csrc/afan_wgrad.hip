@@ -65,6 +65,10 @@ struct WgradP {
     // loop and advances by 64 pixels = dn images + dho rows per step; N1 = images of the first segment
     int dn, dho, N1;
     int xcd_remap;       // 1: XCD-aware workgroup order (see the kernel)
+    // S == 1 (few pixels: the 33 x 33 stages of DeepLab at 2 images per GPU): every (tile, tap) has ONE writer, so the tile
+    // goes straight into the gradient [co][tap][ci] (added to it when `accumulate`) — no slab, no reduce launch
+    float* direct;
+    int accumulate;
 };
 
 template <int BM, int BN, bool INC>   // BM = co tile, BN = ci tile; INC: see WgradP::dn
@@ -237,7 +241,14 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wr * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int ci = ci0 + wc * TN + j * 32 + (lane & 31);
-                if (co < p.Co && ci < p.Ci) out[(int64_t)co * p.Ci + ci] = acc[i][j][r];
+                if (co < p.Co && ci < p.Ci) {
+                    if (p.direct) {
+                        float* g = p.direct + ((int64_t)co * taps + tap) * p.Ci + ci;
+                        *g = p.accumulate ? *g + acc[i][j][r] : acc[i][j][r];
+                    } else {
+                        out[(int64_t)co * p.Ci + ci] = acc[i][j][r];
+                    }
+                }
             }
 }
 
@@ -272,9 +283,17 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
     const int64_t total_steps = (P + BKP - 1) / BKP;
     static const int target = [] { const char* v = getenv("AFAN_WGRAD_WGS"); return v ? atoi(v) : 512; }();
     int64_t S = target / tiles;                    // ~2 workgroups per CU (measured: 512 beats 320 by 2 % of the step)
-    const int64_t max_s = total_steps / 16 > 0 ? total_steps / 16 : 1;   // >= 16 steps per workgroup
+    // >= 16 steps per workgroup — except for the very short reductions (DeepLab's 33 x 33 stages at 2 images per GPU: 35
+    // steps in all): there the launch is latency-bound and more, shorter slices win (DeepLab 27.1 -> 26.1 ms per iteration
+    // at 4-8 steps; ResNet-50, whose shortest reduction is 49 steps, loses 0.6 % with the same rule, hence the bound)
+    static const int min_steps_env = [] { const char* v = getenv("AFAN_WGRAD_MINSTEPS"); return v ? atoi(v) : 0; }();
+    const int min_steps = min_steps_env > 0 ? min_steps_env : (total_steps <= 40 ? 5 : 16);
+    const int64_t max_s = total_steps / min_steps > 0 ? total_steps / min_steps : 1;
     if (S > max_s) S = max_s;
     if (S < 1) S = 1;
+    // two short slices plus a reduce launch lose to one slice written straight into the gradient (see WgradP::direct)
+    static const int direct_on = [] { const char* v = getenv("AFAN_WGRAD_DIRECT"); return v ? atoi(v) : 0; }();
+    if (direct_on && S == 2 && total_steps <= 64) S = 1;
     pl.steps = (int)((total_steps + S - 1) / S);
     pl.S = (int)((total_steps + pl.steps - 1) / pl.steps);
     return pl;
@@ -370,6 +389,11 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         }
     }
     p.dWo = make_fastdiv((uint32_t)wo); p.dHo = make_fastdiv((uint32_t)ho);
+    {
+        static const int direct_on = [] { const char* v = getenv("AFAN_WGRAD_DIRECT"); return v ? atoi(v) : 0; }();
+        p.direct = (direct_on && pl.S == 1) ? grad : nullptr;
+        p.accumulate = accumulate;
+    }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     {
@@ -378,7 +402,7 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         if (pl.bm == 128) rc = pl.bn == 128 ? launch<128, 128>(p, taps, st) : launch<128, 64>(p, taps, st);
         else rc = pl.bn == 128 ? launch<64, 128>(p, taps, st) : launch<64, 64>(p, taps, st);
     }
-    if (rc) return rc;
+    if (rc || p.direct) return rc;
     const int64_t per = (int64_t)taps * co * ci;
     AFAN_PROF("conv_wgrad_reduce_kernel", 4.0 * per * (pl.S + 1 + (accumulate ? 1 : 0)), st);
     wgrad_reduce_kernel<<<grid_for(per / 4, THREADS, 1024), THREADS, 0, st>>>(workspace, grad, pl.S, taps, (int)co, (int)ci,
