@@ -305,7 +305,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                     "algo_flops_per_launch": round(v["flops"] / v["launches"]),
-                    "handwritten_ms_per_step": hand_ms}
+                    "handwritten_ms_per_step": hand_ms,
+                    "peak_note": "nominal dense bf16 MFMA peak (MI355X_MICROARCH.md); measured on this chip: bare MFMA loop "
+                                 "1.75-2.1 PFLOP/s, LDS -> MFMA consumer loop on random operands 1.13-1.41 PFLOP/s "
+                                 "(tools/probe/mfma_rate.hip, lds_mfma.hip; DESIGN.md 9.5)"}
         else:
             ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
