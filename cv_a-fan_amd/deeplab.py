@@ -565,8 +565,8 @@ class DeepLabV3(nn.Module):
     def _up(self, x, input_shape):
         return interpolate(x, input_shape)
 
-    def forward_clean_folded(self, x, se_idx, sd_idx):
-        return _folded_clean_forward(self, x, se_idx, sd_idx)
+    def forward_clean_folded(self, x, se_idx, sd_idx, pgd0=False):
+        return _folded_clean_forward(self, x, se_idx, sd_idx, pgd0)
 
     def fold_ok(self, x):
         """Can the iteration's three clean forwards run as one (forward_clean_folded)?"""
@@ -591,17 +591,21 @@ class DeepLabV3(nn.Module):
 
 class _FoldedClean:
     """What DeepLabV3.forward_clean_folded hands back (see there)."""
-    __slots__ = ("low", "fm_se", "dec", "logits", "_recs")
+    __slots__ = ("low", "fm_se", "dec", "logits", "_recs", "se_in", "low_in", "sd_t")
+
+    def replay_sd_pgd0_bn(self):
+        """With the first PGD passes folded in as well: the decoder-PGD's first pass (main_aug_final.py:179-181) updates the
+        decoder's BatchNorms AFTER the SE loop — call this between the two PGD loops."""
+        self._recs[1].replay()
 
     def replay_deferred_bn(self):
         """Apply the running-statistics updates that belong to the reference's `o0` forward (main_aug_final.py:193), which
-        comes AFTER the two PGD loops: once more for layer4 / ASPP (updated once at the start, for the decoder-PGD input
-        pass), for the first time for the decoder's BatchNorms."""
+        comes AFTER the two PGD loops."""
         for r in self._recs:
             r.replay()
 
 
-def _folded_clean_forward(self, x, se_idx, sd_idx):
+def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False):
     """The three clean forwards of a Segmentation A-FAN iteration as ONE pass (the fold of DESIGN section 4, for
     main_aug_final.py:166-193): `model(head, out_idx=se_idx)` (:166), `model(clean, out_idx=sd_idx + "_head")` (:167) and
     `model(clean, out_idx=0)` (:193) evaluate the same layers on the same images with the same weights — the backbone up
@@ -612,6 +616,15 @@ def _folded_clean_forward(self, x, se_idx, sd_idx):
       * `logits`: the clean forward's output (a second dropout draw on the same pre-dropout ASPP output).
     BatchNorm side effects in the reference's order: stem .. SE point: three updates now (nothing else touches them);
     SE point .. SD point: one now (:167), one deferred (:193 comes after the PGD loops); after the SD point: deferred.
+
+    pgd0=True (no random start, at least one PGD step): the FIRST pass of both PGD loops is this pass too — PGD starts at
+    the clean feature (attack_algo.py:42-43), so its first tail forward / cross-entropy / input gradient are the clean
+    forward's own logits, loss and d(loss)/d(feature).  The graph is then cut at the SE point and at the low-level feature
+    (`se_in`, `low_in`: leaves whose gradients the caller feeds back into the head graph at the end) so that the clean
+    loss can be back-propagated through the tail at once; `sd_t` is the SD point's tensor (retain_grad).  One dropout draw
+    then serves :167, :193 and the two first PGD passes (the reference draws four times; masks are random either way).
+    BatchNorm: SE .. SD point two updates now (:167 and the SE loop's first pass) + :193 deferred; after the SD point one
+    now (SE loop's first pass), one at `replay_sd_pgd0_bn()` (decoder loop's first pass), one at `replay_deferred_bn()`.
     Channels-last kernels only (the repeat count is a feature of those launches)."""
     bb, head = self.backbone, self.classifier
     assert isinstance(head, DeepLabHeadV3Plus) and sd_idx in ("aspp", "concat") and se_idx in (1, 2, 3, 4)
@@ -624,20 +637,32 @@ def _folded_clean_forward(self, x, se_idx, sd_idx):
         for st in stages[1:se_idx]:
             h = st(h)
     out.fm_se, out.low = h, low
+    out.se_in = out.low_in = out.sd_t = None
+    low_dec = low
+    if pgd0:
+        out.se_in = h = h.detach().requires_grad_(True)
+        out.low_in = low_dec = low.detach().requires_grad_(True)
     drop = head.aspp.project[3]
-    with ops.record_bn_updates() as rec_mid:
+    with ops.bn_running_updates(2 if pgd0 else 1), ops.record_bn_updates() as rec_mid:
         for st in stages[se_idx:]:
             h = st(h)
         pre = head.aspp(_enter(h, dt, cl), pre_dropout=True)
         if sd_idx == "concat":
-            low_p = _cbr(head.project[0], head.project[1], _enter(low, dt, cl))
-    with ops.bn_running_updates(0), ops.record_bn_updates() as rec_late:
+            low_p = _cbr(head.project[0], head.project[1], _enter(low_dec, dt, cl))
+    with ops.bn_running_updates(1 if pgd0 else 0), ops.record_bn_updates() as rec_late:
         if sd_idx == "aspp":
-            adv = drop(pre.detach())                          # :167's dropout draw
-            low_p = _cbr(head.project[0], head.project[1], _enter(low, dt, cl))
+            low_p = _cbr(head.project[0], head.project[1], _enter(low_dec, dt, cl))
+        if pgd0:
+            sd_t = drop(pre) if sd_idx == "aspp" else head._concat(low_p, drop(pre))
+            sd_t.retain_grad()
+            out.sd_t, adv = sd_t, sd_t.detach()
+            logits = head._classify(head._concat(low_p, sd_t) if sd_idx == "aspp" else sd_t)
         else:
-            adv = head._concat(low_p.detach(), drop(pre.detach()))
-        logits = head._classify(head._concat(low_p, drop(pre)))   # :193's own draw
+            if sd_idx == "aspp":
+                adv = drop(pre.detach())                      # :167's dropout draw
+            else:
+                adv = head._concat(low_p.detach(), drop(pre.detach()))
+            logits = head._classify(head._concat(low_p, drop(pre)))   # :193's own draw
     out.dec = {"out": h, "low_level": low, "adv": adv}
     out.logits = self._up(logits, x.shape[-2:])
     out._recs = (rec_mid, rec_late)

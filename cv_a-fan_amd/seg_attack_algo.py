@@ -44,29 +44,48 @@ def _ascend(x_adv, logits_of, criterion, y, gamma, x, eps, clip):
     ops.pgd_step_(x_adv, grad, gamma, x, eps, clip)          # one launch: sign step (+ projection)
 
 
+def _first_step(x_adv, grad0, gamma, x, eps, clip):
+    """The first ascent step from a gradient the caller already has (a positive multiple of d(loss)/d(x) at x itself)."""
+    g = grad0.detach()
+    if g.stride() != x_adv.stride():
+        g = g.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else g.contiguous()
+    ops.pgd_step_(x_adv, g, gamma, x, eps if eps is not None else 0.0, clip)
+
+
 def PGD(x, image_batch, low_level_feat, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
-        randinit=False, clip=False):
-    """SE-branch feature PGD (:40-59).  Returns a new fp32 leaf with requires_grad=True; `x` is not modified."""
+        randinit=False, clip=False, grad0=None):
+    """SE-branch feature PGD (:40-59).  Returns a new fp32 leaf with requires_grad=True; `x` is not modified.
+    grad0 (an addition; not with randinit): the first step's gradient, computed by the caller's clean pass."""
+    if grad0 is not None and (randinit or steps < 1):
+        raise ValueError("grad0 is the gradient at x: not with randinit, and only when there is a first step")
     x, x_adv = _start(x, eps, randinit)
-    for _ in range(steps):
+    for t in range(steps):
+        if t == 0 and grad0 is not None:
+            _first_step(x_adv, grad0, gamma, x, eps, clip)
+            continue
         _ascend(x_adv, lambda t: model({"x": image_batch, "adv": t, "out_idx": idx, "flag": "tail",
                                         "low_level_feat": low_level_feat}), criterion, y, gamma, x, eps, clip)
     return x_adv.requires_grad_(True)
 
 
 def decoder_PGD(input_dict, image_batch, criterion, y=None, model=None, steps=3, eps=None, gamma=None, idx=1,
-                randinit=False, clip=False):
+                randinit=False, clip=False, grad0=None):
     """SD-branch (decoder feature) PGD (:61-84): perturbs input_dict['adv'] in the dict and returns the dict.  The
     reference cannot clip here — its projection names an undefined `x` and raises NameError after the first step — and
     neither does this: same exception."""
+    if grad0 is not None and (randinit or steps < 1):
+        raise ValueError("grad0 is the gradient at the clean feature: not with randinit, and only when there is a first step")
     _, x_adv = _start(input_dict["adv"], eps, randinit)
     input_dict["adv"] = x_adv
-    for _ in range(steps):
+    for t in range(steps):
         def logits_of(t):
             d = dict(input_dict)
             d["adv"] = t
             return model({"x": image_batch, "adv": d, "out_idx": idx + "_tail", "flag": "clean"})
-        _ascend(x_adv, logits_of, criterion, y, gamma, None, 0.0, False)
+        if t == 0 and grad0 is not None:
+            _first_step(x_adv, grad0, gamma, None, 0.0, False)
+        else:
+            _ascend(x_adv, logits_of, criterion, y, gamma, None, 0.0, False)
         if clip:
             raise NameError("name 'x' is not defined")
     input_dict["adv"] = x_adv.requires_grad_(True)
@@ -86,7 +105,7 @@ def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gam
 
 def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                    pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                   clip=False, dual_bn=False, fold_clean=None, defer_step=False):
+                   clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None):
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
     0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
@@ -102,10 +121,27 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     fold = getattr(model, "fold_ok", None) is not None and model.fold_ok(images) and type(pertub_idx_se) == int \
         and pertub_idx_sd in ("aspp", "concat")
     fold = fold if fold_clean is None else (bool(fold_clean) and fold)
+    # fold_pgd0 (None: whenever the fold runs, PGD starts at the clean feature and takes at least one step): the first pass
+    # of BOTH PGD loops is the clean forward too — same logits, same cross-entropy, same input gradient (sign() ignores
+    # the joint loss's 0.7) — so the clean loss is back-propagated through the tail right away and the loops start at
+    # their second pass.  Not with dual_bn (the PGD passes then normalise with the other BatchNorm set).
+    pgd0 = fold and steps >= 1 and not randinit and not dual_bn and not clip
+    pgd0 = pgd0 if fold_pgd0 is None else (bool(fold_pgd0) and pgd0)
+    g_se = g_sd = l0 = None
+    wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
+    fused = getattr(criterion, "fused", False)
     if fold:
-        fc = model.forward_clean_folded(images, pertub_idx_se, pertub_idx_sd)
+        fc = model.forward_clean_folded(images, pertub_idx_se, pertub_idx_sd, pgd0)
         dec, low = fc.dec, fc.low
         fm_sd, fm_se = dec["adv"].detach().float(), fc.fm_se.detach().float()
+        if pgd0:
+            if fused and fc.logits.is_cuda and fc.logits.dtype == torch.float32:
+                l0 = criterion(fc.logits, labels, grad_scale=wts[0])
+                torch.autograd.backward([l0], [ops.one(images.device)])
+            else:
+                l0 = criterion(fc.logits, labels)
+                (wts[0] * l0).backward()
+            g_se, g_sd = fc.se_in.grad, fc.sd_t.grad
     else:
         fc = None
         out_se = model({"x": images, "adv": None, "out_idx": pertub_idx_se, "flag": "head"})
@@ -119,9 +155,12 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     adv_bn = (lambda: bn_branch(model, "adv")) if dual_bn else contextlib.nullcontext
     with adv_bn():
         adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
-                     eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip)
+                     eps=(eps / 255), gamma=(gamma_se / 255), idx=pertub_idx_se, randinit=randinit, clip=clip, grad0=g_se)
+        if pgd0:
+            fc.replay_sd_pgd0_bn()              # the decoder loop's first pass updates the decoder's BatchNorms here
         adv_sd_dict = decoder_PGD(input_dict=dec, image_batch=images, criterion=criterion, y=labels, model=model, steps=steps,
-                                  eps=(eps / 255), gamma=(gamma_sd / 255), idx=pertub_idx_sd, randinit=randinit, clip=clip)
+                                  eps=(eps / 255), gamma=(gamma_sd / 255), idx=pertub_idx_sd, randinit=randinit, clip=clip,
+                                  grad0=g_sd)
     adv_sd = adv_sd_dict["adv"].detach()
     if mix_sd:
         adv_sd = mix_feature(fm_sd, adv_sd)
@@ -139,8 +178,20 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
         o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
         o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
         o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
-    wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
-    if getattr(criterion, "fused", False) and all(o.is_cuda and o.dtype == torch.float32 for o in (o0, o1, o2, o3)):
+    if pgd0:
+        # the clean term went through the tail already; what it left at the cut (SE point, low-level feature) enters the
+        # head graph now, together with what the perturbed forwards send into it through `low`
+        extra_t, extra_g = [fc.fm_se, fc.low], [fc.se_in.grad, fc.low_in.grad]
+        if fused and all(o.is_cuda and o.dtype == torch.float32 for o in (o1, o2, o3)):
+            l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o1, o2, o3), wts[1:]))
+            one = ops.one(images.device)
+            torch.autograd.backward([l1, l2, l3] + extra_t, [one, one, one] + extra_g)
+        else:
+            l1, l2, l3 = (criterion(o, labels) for o in (o1, o2, o3))
+            torch.autograd.backward([0.1 * l1 + 0.1 * l2 + 0.1 * l3] + extra_t, [None] + extra_g)
+        with torch.no_grad():
+            loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
+    elif fused and all(o.is_cuda and o.dtype == torch.float32 for o in (o0, o1, o2, o3)):
         # every term's stored gradient already carries its weight: four roots, no scaling passes over the logits
         l0, l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o0, o1, o2, o3), wts))
         with torch.no_grad():

@@ -122,7 +122,7 @@ def test_deeplab_step_bf16_runs_on_the_library_kernels(pkg, gpu, case):
     r = tr.step(images, labels)
     torch.cuda.synchronize()
     ran = {k: pkg.ops.CALLS[k] - before[k] for k in before}
-    assert ran["vendor_conv"] == 0 and ran["conv_fwd"] > 150 and ran["conv_dgrad"] > 100 and ran["conv_wgrad"] > 100, ran
+    assert ran["vendor_conv"] == 0 and ran["conv_fwd"] > 100 and ran["conv_dgrad"] > 100 and ran["conv_wgrad"] > 100, ran
     loss = float(g["loss"])
     assert abs(float(r["loss"]) - loss) <= 3e-2, (float(r["loss"]), loss)
     np.testing.assert_allclose(r["losses"].cpu().numpy(), g["losses"], rtol=0, atol=3e-2)
