@@ -116,6 +116,35 @@ def _pgd_trace(ref_attack, model, criterion, fm, target, steps, gamma, eps, idx,
     return seen  # K+1 snapshots: x_adv before step 0 ... after step K-1
 
 
+def gen_pgd_traces(ref_attack, build, crit, only=None):
+    """x_adv before / after every step of the reference's PGD with the gradient it used: ResNet-20s (K = 3, with and
+    without clipping) and the headline network (ResNet-18, K = 5, one image: the 64 x 32 x 32 feature map of idx 6)."""
+    for name, arch, nimg, K, gamma, clip in (("pgd_trace_r20s_k3", "resnet20s", 2, 3, 0.5, False),
+                                            ("pgd_trace_r20s_k3_clip", "resnet20s", 2, 3, 1.5, True),
+                                            ("pgd_trace_r18_k5", "resnet18", 1, 5, 0.5, False)):
+        if only is not None and name not in only:
+            continue
+        torch.manual_seed(3)
+        model, idx, ln = build(arch)
+        model.train()
+        x = torch.rand(nimg, 3, 32, 32)
+        y = torch.randint(0, 10, (nimg,))
+        fm = model(x, end_point=idx, start_point=0).detach()
+        import copy
+        model_b = copy.deepcopy(model)
+        snaps = _pgd_trace(ref_attack, model, crit, fm, y, K, gamma, 2.0, idx, ln, clip)
+        # gradients the reference saw: recompute with an identical twin model fed the recorded inputs in order
+        grads = []
+        for t in range(K):
+            xin = snaps[t].clone().requires_grad_(True)
+            loss = crit(model_b(xin, end_point=ln, start_point=idx), y)
+            grads.append(torch.autograd.grad(loss, xin)[0])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), fm=_np(fm), y=_np(y),
+                            gamma_eps=np.array([gamma, 2.0]), clip=np.array(int(clip)),
+                            snaps=np.stack([_np(s) for s in snaps]), grads=np.stack([_np(g) for g in grads]))
+        print(name, "ok")
+
+
 def gen_detection(orc):
     # ---- Detection (N2): the reference's own adv_input / PGD / rpn_roi_PGD / get_sample_points / mix_feature / compute_loss
     # (Detection/attack_algo.py) and the loop body of Detection/train_aug_sat_muti_advt.py:70-172 driven line by line around
@@ -266,26 +295,7 @@ def main():
         print(name, "loss", float(r["loss"]), "l2", r["l2"].tolist())
 
     # ---- per-step PGD trace (kernel-level golden: x_adv before/after every step, with its gradient) ----
-    for name, K, gamma, clip in (("pgd_trace_r20s_k3", 3, 0.5, False), ("pgd_trace_r20s_k3_clip", 3, 1.5, True)):
-        torch.manual_seed(3)
-        model, idx, ln = build("resnet20s")
-        model.train()
-        x = torch.rand(2, 3, 32, 32)
-        y = torch.randint(0, 10, (2,))
-        fm = model(x, end_point=idx, start_point=0).detach()
-        import copy
-        model_b = copy.deepcopy(model)
-        snaps = _pgd_trace(ref_attack, model, crit, fm, y, K, gamma, 2.0, idx, ln, clip)
-        # gradients the reference saw: recompute with an identical twin model fed the recorded inputs in order
-        grads = []
-        for t in range(K):
-            xin = snaps[t].clone().requires_grad_(True)
-            loss = crit(model_b(xin, end_point=ln, start_point=idx), y)
-            grads.append(torch.autograd.grad(loss, xin)[0])
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), fm=_np(fm), y=_np(y),
-                            gamma_eps=np.array([gamma, 2.0]), clip=np.array(int(clip)),
-                            snaps=np.stack([_np(s) for s in snaps]), grads=np.stack([_np(g) for g in grads]))
-        print(name, "ok")
+    gen_pgd_traces(ref_attack, build, crit)
 
     # ---- 3-iteration trajectory with warm-up lr (main_perturb.py:167-168,288-293) ----------------------
     torch.manual_seed(3)
@@ -546,7 +556,14 @@ def main():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["det"]:           # only the Detection fixtures (the full run regenerates every file bit-identically)
+    if sys.argv[1:] == ["trace18"]:       # only the ResNet-18 PGD trace
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        os.makedirs(OUT, exist_ok=True)
+        from oracle import afan_oracle as _orc
+        _ra = _load("ref_cls_attack_algo", "Classification/attack_algo.py")
+        gen_pgd_traces(_ra, lambda a: (_orc.resnet18_cifar(), 6, 15), nn.CrossEntropyLoss(), only=("pgd_trace_r18_k5",))
+    elif sys.argv[1:] == ["det"]:         # only the Detection fixtures (the full run regenerates every file bit-identically)
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         _shims()
         os.makedirs(OUT, exist_ok=True)

@@ -16,9 +16,10 @@ def _dev(a, gpu, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------- PGD step
-@pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip"])
+@pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip", "pgd_trace_r18_k5"])
 def test_pgd_step_golden_trace(pkg, gpu, case):
-    """Reference x_adv(t), reference gradient -> x_adv(t+1): bit for bit, every step of the reference run."""
+    """Reference x_adv(t), reference gradient -> x_adv(t+1): bit for bit, every step of the reference run (ResNet-20s, and
+    the headline network's 64 x 32 x 32 feature map at K = 5: given the gradient, the perturbation is the reference's)."""
     g = golden(case)
     gamma, eps = float(g["gamma_eps"][0]) / 255, float(g["gamma_eps"][1]) / 255
     clip = bool(int(g["clip"]))

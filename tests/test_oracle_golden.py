@@ -193,7 +193,7 @@ def test_trajectory_with_warmup(orc):
     np.testing.assert_array_equal(_checks(model), g["ck"])
 
 
-@pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip"])
+@pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip", "pgd_trace_r18_k5"])
 def test_pgd_step_kernels_python_and_c(orc, c_oracle, case):
     """x_adv(t+1) from x_adv(t) and the reference's gradient: python restatement and C restatement, bit-exact."""
     g = golden(case)

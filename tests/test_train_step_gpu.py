@@ -751,3 +751,32 @@ def test_dual_bn_step_is_graph_captured(pkg, orc, gpu):
             assert tr._graph is not None, tr._graph_failed
     assert all(np.isfinite(res[True])) and res[True][0] > 0
     np.testing.assert_allclose(res[True], res[False], rtol=0, atol=5e-3)
+
+
+def test_r18_per_step_perturbation_given_reference_iterates(pkg, orc, gpu):
+    """The headline network, one PGD step at a time from the REFERENCE's own iterates (pgd_trace_r18_k5: x_adv before every
+    step and the gradient the reference computed there): the fp32 product's gradient at that point has the reference's
+    sign on all but a sliver of the elements (gradients within rounding of zero), so x_adv(t+1) is the reference's there —
+    no compounding over the K steps, no batch-2 BatchNorm chaos: the flip rate at its source."""
+    g = golden("pgd_trace_r18_k5")
+    model = _build(pkg, orc, "resnet18", gpu)                       # seed-3 weights = the reference run's
+    gamma, eps = float(g["gamma_eps"][0]) / 255, float(g["gamma_eps"][1]) / 255
+    y = torch.from_numpy(g["y"]).to(gpu)
+    fm = torch.from_numpy(g["fm"]).to(gpu)
+    crit = nn.CrossEntropyLoss()
+    worst = 0.0
+    for t in range(g["grads"].shape[0]):
+        xin = torch.from_numpy(g["snaps"][t]).to(gpu).requires_grad_(True)
+        loss = crit(model(xin, end_point=model.layer_number, start_point=6), y)
+        grad = torch.autograd.grad(loss, xin)[0]
+        ref = torch.from_numpy(g["grads"][t]).to(gpu)
+        flips = float((torch.sign(grad) != torch.sign(ref)).float().mean())
+        # where the signs differ the reference's gradient is tiny
+        if flips > 0:
+            assert float(ref[torch.sign(grad) != torch.sign(ref)].abs().max()) <= 1e-3 * float(ref.abs().max())
+        xa = xin.detach().clone()
+        pkg.ops.pgd_step_(xa, grad.contiguous(), gamma, fm, eps, False)
+        same = float((xa.cpu() == torch.from_numpy(g["snaps"][t + 1])).float().mean())
+        assert same >= 1.0 - flips - 1e-7
+        worst = max(worst, flips)
+    assert worst <= 2e-3, worst
