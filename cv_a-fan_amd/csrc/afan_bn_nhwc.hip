@@ -63,12 +63,26 @@ __device__ __forceinline__ void affine_coeffs(float mu, float is, float w, float
     beta = fmaf(-mu, alpha, b);
 }
 
+// Accumulator type of the per-thread / per-block column sums: fp32 tensors (parity mode, where the reference's own
+// arithmetic is the bar) sum in f64 — a channel mean taken as shift + sum(x - shift)/M and the sum of a BatchNorm
+// gradient (which nearly cancels) otherwise carry an absolute error of eps * |shift - mean| that is COHERENT over the
+// channel: a uniform offset of every output / gradient element (channel mean of a [4,64,65,65] map: 3e-6 -> 2e-8 relative
+// error against float64, tools/diag_bn_layout.py).  bf16 tensors keep fp32 sums (their storage rounding is 2^16 times larger).
+template <typename T> struct AccOf { typedef float type; };
+template <> struct AccOf<float> { typedef double type; };
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // Reduce per-thread values across the threads of the block that own the same channel vector (t % CV) and let
 // the first CV threads write the block partial to ws[(q*C + c)*G + blockIdx.x], q = 0..NQ-1.
-template <int VEC, int NQ>
-__device__ __forceinline__ void block_fold_store(float (&acc)[NQ][VEC], int CV, int C, int G,
+template <int VEC, int NQ, typename A>
+__device__ __forceinline__ void block_fold_store(A (&acc)[NQ][VEC], int CV, int C, int G,
                                                  float* __restrict__ ws) {
-    __shared__ float sh[NQ * VEC][BLOCK];
+    __shared__ A sh[NQ * VEC][BLOCK];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -81,19 +95,19 @@ __device__ __forceinline__ void block_fold_store(float (&acc)[NQ][VEC], int CV, 
         // column (lane % CV); fixed order, so the partial is reproducible
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int qk = wave; qk < NQ * VEC; qk += BLOCK / AFAN_WAVE) {
-            float s = (sh[qk][lane] + sh[qk][lane + 64]) + (sh[qk][lane + 128] + sh[qk][lane + 192]);
+            A s = (sh[qk][lane] + sh[qk][lane + 64]) + (sh[qk][lane + 128] + sh[qk][lane + 192]);
             for (int o = CV; o < AFAN_WAVE; o <<= 1) s += __shfl_xor(s, o, AFAN_WAVE);
-            if (lane < CV) ws[((int64_t)(qk / VEC) * C + lane * VEC + qk % VEC) * G + blockIdx.x] = s;
+            if (lane < CV) ws[((int64_t)(qk / VEC) * C + lane * VEC + qk % VEC) * G + blockIdx.x] = (float)s;
         }
         return;
     }
     const int R = BLOCK / CV;
     for (int item = threadIdx.x; item < NQ * VEC * CV; item += BLOCK) {
         const int cv = item % CV, qk = item / CV;
-        float s = 0.f;
+        A s = 0;
         for (int r = 0; r < R; ++r) s += sh[qk][cv + r * CV];
         const int q = qk / VEC, k = qk % VEC;
-        ws[((int64_t)q * C + cv * VEC + k) * G + blockIdx.x] = s;
+        ws[((int64_t)q * C + cv * VEC + k) * G + blockIdx.x] = (float)s;
     }
 }
 
@@ -118,10 +132,10 @@ int64_t acc_doubles(int64_t C);   // doubles per accumulator block (defined with
 static thread_local int g_running_updates = 1;
 static inline int running_updates() { return g_running_updates; }
 
-template <int VEC, int NQ>
-__device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV, int C, int NS,
+template <int VEC, int NQ, typename A>
+__device__ __forceinline__ void block_fold_atomic(A (&acc)[NQ][VEC], int CV, int C, int NS,
                                                   double* __restrict__ out) {
-    __shared__ float sh[NQ * VEC][BLOCK];
+    __shared__ A sh[NQ * VEC][BLOCK];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -132,7 +146,7 @@ __device__ __forceinline__ void block_fold_atomic(float (&acc)[NQ][VEC], int CV,
     double* dst = out + (int64_t)(blockIdx.x & (NS - 1)) * NQ * C;
     for (int item = threadIdx.x; item < NQ * VEC * CV; item += BLOCK) {
         const int cv = item % CV, qk = item / CV;
-        float s = 0.f;
+        A s = 0;
         for (int r = 0; r < R; ++r) s += sh[qk][cv + r * CV];
         const int q = qk / VEC, k = qk % VEC;
         unsafeAtomicAdd(dst + (int64_t)q * C + cv * VEC + k, (double)s);
@@ -147,9 +161,10 @@ __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, i
     const int cv = threadIdx.x % CV;
     float shift[VEC];
     LdV<T, VEC>::ld(x + (int64_t)cv * VEC, shift);  // first row of the tensor: same shift in every block
-    float acc[2][VEC];
+    typedef typename AccOf<T>::type A;
+    A acc[2][VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0.f;
+    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
 #pragma unroll 4
     for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
@@ -157,13 +172,13 @@ __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, i
         LdV<T, VEC>::ld(x + v * VEC, e);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            const float d = e[k] - shift[k];
+            const A d = (A)e[k] - (A)shift[k];
             acc[0][k] += d;
             acc[1][k] += d * d;
         }
     }
-    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, NS, accd);
-    else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2, A>(acc, CV, C, NS, accd);
+    else block_fold_store<VEC, 2, A>(acc, CV, C, gridDim.x, ws);
 }
 
 // generic: thread per channel, block per row slab
@@ -174,15 +189,16 @@ __global__ __launch_bounds__(BLOCK) void stats_generic_kernel(const T* __restric
     const int64_t rows_per = (M + G - 1) / G;
     const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
     for (int c = threadIdx.x; c < C; c += BLOCK) {
+        typedef typename AccOf<T>::type A;
         const float shift = Elt<T>::ld(x + c);
-        float s1 = 0.f, s2 = 0.f;
+        A s1 = 0, s2 = 0;
         for (int64_t r = r0; r < r1; ++r) {
-            const float d = Elt<T>::ld(x + r * C + c) - shift;
+            const A d = (A)Elt<T>::ld(x + r * C + c) - (A)shift;
             s1 += d;
             s2 += d * d;
         }
-        ws[((int64_t)0 * C + c) * G + blockIdx.x] = s1;
-        ws[((int64_t)1 * C + c) * G + blockIdx.x] = s2;
+        ws[((int64_t)0 * C + c) * G + blockIdx.x] = (float)s1;
+        ws[((int64_t)1 * C + c) * G + blockIdx.x] = (float)s2;
     }
 }
 
@@ -201,20 +217,20 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
     const int c = blockIdx.x * (BLOCK / AFAN_WAVE) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
-    float a = 0.f, b = 0.f;
+    double a = 0.0, b = 0.0;                // (f64 fold of the fp32 partials: see AccOf)
     for (int g = lane; g < G; g += AFAN_WAVE) {
-        a += ws[((int64_t)0 * C + c) * G + g];
-        b += ws[((int64_t)1 * C + c) * G + g];
+        a += (double)ws[((int64_t)0 * C + c) * G + g];
+        b += (double)ws[((int64_t)1 * C + c) * G + g];
     }
-    a = wave_sum(a);
-    b = wave_sum(b);
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
     if (lane != 0) return;
     if (MODE == 0) {
         // the shift the partial sums were taken around: given explicitly (conv-epilogue partials), else row 0 of x
         const float shift = shift_ptr ? shift_ptr[c] : (x ? Elt<T>::ld(x + c) : 0.f);
-        const float dm = a * inv_m;
-        const float mean = shift + dm;
-        const float m2 = fmaxf(b - a * dm, 0.f);
+        const double dmd = a / (double)m_count;        // (inv_m is a rounded fp32 reciprocal)
+        const float mean = (float)((double)shift + dmd);
+        const float m2 = (float)fmax(b - a * dmd, 0.0);
         const float is = 1.0f / sqrtf(m2 * inv_m + eps);
         float alpha, beta;
         affine_coeffs(mean, is, weight ? weight[c] : 1.f, bias ? bias[c] : 0.f, alpha, beta);
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void finalize_kernel(const float* __restrict
         if (c == 0 && nbt) *nbt += updates;
     } else {
         const float is = stats[C + c], alpha = stats[2 * C + c];
-        const float sum_g = a, sum_gx = b * is;
+        const float sum_g = (float)a, sum_gx = (float)b * is;
         coef[c] = -alpha * is * (sum_gx * inv_m);
         coef[C + c] = -alpha * (sum_g * inv_m);
         if (dbias) dbias[c] = accumulate ? dbias[c] + sum_g : sum_g;
@@ -306,9 +322,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__
         ld_coef<VEC>(stats + 2 * C, c0, alpha);
         ld_coef<VEC>(stats + 3 * C, c0, beta);
     }
-    float acc[2][VEC];
+    typedef typename AccOf<T>::type A;
+    A acc[2][VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0.f;
+    for (int k = 0; k < VEC; ++k) acc[0][k] = acc[1][k] = 0;
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
 #pragma unroll 2
     for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
@@ -323,12 +340,12 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_kernel(const T* __restrict__
                 const float act = HAVE_Y ? o[k] : fmaf(e[k], alpha[k], beta[k]);
                 g = (act > 0.f) ? g : 0.f;
             }
-            acc[0][k] += g;
-            acc[1][k] += g * (e[k] - mu[k]);   // invstd is applied once per channel in the finalize
+            acc[0][k] += (A)g;
+            acc[1][k] += (A)g * ((A)e[k] - (A)mu[k]);   // invstd is applied once per channel in the finalize
         }
     }
-    if constexpr (ATOMIC) block_fold_atomic<VEC, 2>(acc, CV, C, NS, accd);
-    else block_fold_store<VEC, 2>(acc, CV, C, gridDim.x, ws);
+    if constexpr (ATOMIC) block_fold_atomic<VEC, 2, A>(acc, CV, C, NS, accd);
+    else block_fold_store<VEC, 2, A>(acc, CV, C, gridDim.x, ws);
 }
 
 template <typename T, bool RELU, bool HAVE_Y>
@@ -341,7 +358,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_generic_kernel(const T* __re
     const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
     for (int c = threadIdx.x; c < C; c += BLOCK) {
         const float mu = stats[c], alpha = stats[2 * C + c], beta = stats[3 * C + c];
-        float sg = 0.f, sgx = 0.f;
+        typedef typename AccOf<T>::type A;
+        A sg = 0, sgx = 0;
         for (int64_t r = r0; r < r1; ++r) {
             const int64_t i = r * C + c;
             const float e = Elt<T>::ld(x + i);
@@ -350,11 +368,11 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_generic_kernel(const T* __re
                 const float act = HAVE_Y ? Elt<T>::ld(y + i) : fmaf(e, alpha, beta);
                 g = (act > 0.f) ? g : 0.f;
             }
-            sg += g;
-            sgx += g * (e - mu);
+            sg += (A)g;
+            sgx += (A)g * ((A)e - (A)mu);
         }
-        ws[((int64_t)0 * C + c) * G + blockIdx.x] = sg;
-        ws[((int64_t)1 * C + c) * G + blockIdx.x] = sgx;
+        ws[((int64_t)0 * C + c) * G + blockIdx.x] = (float)sg;
+        ws[((int64_t)1 * C + c) * G + blockIdx.x] = (float)sgx;
     }
 }
 
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
                                       : (shift ? shift[c] : Elt<T>::ld(x + c));
         const double dm = a * inv_m;
         const double m2 = fmax(b - a * dm, 0.0);
-        const float mean = sh + (float)dm;
+        const float mean = (float)((double)sh + dm);      // (not sh + (float)dm: that rounds at |sh|, not at |mean|)
         const float varb = (float)(m2 * inv_m);
         const float is = 1.0f / sqrtf(varb + eps);
         float alpha, beta;
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
                     fold_slots(ag, C, NS, c, a2, b2);
                     const float sh2 = reinterpret_cast<const float*>(ag + (int64_t)2 * NS * C)[c];
                     const double dm2 = a2 * inv_m;
-                    const float mean2 = sh2 + (float)dm2;
+                    const float mean2 = (float)((double)sh2 + dm2);
                     const float var2 = (float)(fmax(b2 - a2 * dm2, 0.0) * inv_m);
                     if (rmean) {
                         rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean2;

@@ -11,7 +11,8 @@ Host-side mirror of `Segmentation/network/`:
 What differs is execution: bf16 channels-last activations, every 1x1 / 3x3 / atrous convolution on the implicit-GEMM MFMA
 kernels (a Bottleneck is one autograd node, `resnet_s._BlockFn`), BatchNorm (+ReLU, +residual) fused, and the resize / max
 pool / average pool / classifier / dropout / per-pixel cross-entropy layers as hand-written HIP kernels (`afan_seg.hip`).
-fp32 (parity mode) keeps the vendor's fp32 convolutions, like the classification path; everything else is the same code.
+fp32 (parity mode) runs the library's general fp32-arithmetic convolutions (afan_conv_f32.hip: f32 MFMA), like the
+classification path; everything else is the same code.  No vendor convolution in either mode.
 """
 import os
 
@@ -19,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .resnet_s import (BatchNorm2d, Conv2d, NormalizeByChannelMeanStd, _BlockFn, _Flags, _accumulates_in_place,
+from .resnet_s import (BatchNorm2d, Conv2d, NormalizeByChannelMeanStd, _BlockFn, _ConvFn, _Flags, _accumulates_in_place,
                        _block_fast_path_ok, _block_params, _dense, _like_layout, _to_compute)
 
 __all__ = ["deeplabv3plus_resnet50", "deeplabv3plus_resnet101", "deeplabv3_resnet50", "deeplabv3_resnet101", "DeepLabV3",
@@ -273,15 +274,16 @@ class ClassifierConv(Conv2d):
     """_deeplab.py:45: nn.Conv2d(256, num_classes, 1) — with bias, fp32 logits."""
 
     @property
-    def own_kernel(self):       # resnet_s.vendor_convs: the pointwise kernel takes it on channels-last maps
+    def own_kernel(self):       # resnet_s.general_convs: the pointwise kernel takes it on channels-last maps
         return self.in_channels % 8 == 0 and self.out_channels <= 32 and self.in_channels * self.out_channels * 4 <= 64 * 1024
 
     def forward(self, x):
         x = _to_compute(x, self.compute_dtype)
         if ops.pointwise_supported(x, self.out_channels) and self.weight.dtype == torch.float32:
             return _PointwiseFn.apply(x, self.weight, self.bias, _Flags.param_grads)
-        ops.CALLS["vendor_conv"] += 1
-        return nn.functional.conv2d(x.float(), self.weight, self.bias)
+        xf = x if x.dtype == torch.float32 else x.float()        # NCHW maps: the general fp32 kernel, bias in its epilogue
+        return _ConvFn.apply(xf, self.weight, self.weight.detach(), None, self.stride, self.padding, _Flags.param_grads,
+                             None, self.dilation, self.bias)
 
 
 class MaxPool2d(nn.MaxPool2d):

@@ -86,7 +86,7 @@ class LearnableTrainer:
         return self._body(inp, target)
 
     def _graph_safe(self):
-        """As AfanTrainer._graph_safe: no hipGraph around vendor convolutions (fp32 parity mode, NCHW weights)."""
+        """As AfanTrainer._graph_safe (every configuration runs on the library's own kernels: nothing to exclude)."""
         if resnet_s.vendor_convs(self.model):
             self.use_graph = False
         return self.use_graph

@@ -46,7 +46,7 @@ parser.add_argument("--l1_coef", default=1, type=float, help="coefficient of the
 # ---- additions
 parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="backbone compute dtype")
 parser.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
-                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: vendor convolutions)")
+                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: the general fp32-arithmetic kernels)")
 parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of CIFAR-10")
 parser.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many iterations (0 = all)")
 
@@ -106,9 +106,9 @@ def main(argv=None):
                                          randinit=args.randinit, clip=args.clip, lr=args.lr, w_lr=args.w_lr,
                                          l1_coef=args.l1_coef, momentum=args.momentum, weight_decay=args.weight_decay)
     optimizer, optimizer_w = trainer.optimizer, trainer.optimizer_w
-    vendor = resnet_s.vendor_convs(model)
+    vendor = resnet_s.general_convs(model)
     log("convolutions outside the library's kernels: {}{}".format(
-        len(vendor), " (vendor library, eager launches; --dtype bf16 --layout nhwc is the MFMA path)" if vendor else ""))
+        len(vendor), " (general f32-MFMA kernels; --dtype bf16 --layout nhwc is the tuned bf16 MFMA path)" if vendor else ""))
     decreasing_lr = list(map(int, args.decreasing_lr.split(",")))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=decreasing_lr, gamma=0.1)
     if args.synthetic:

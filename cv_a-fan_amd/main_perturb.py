@@ -52,7 +52,7 @@ parser.add_argument("--clip", action="store_true", help="whether using clip")
 parser.add_argument("--arch", default="resnet56s", choices=sorted(resnet_s.ARCHS))
 parser.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="backbone compute dtype")
 parser.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"],
-                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: vendor convolutions)")
+                    help="internal activation / weight layout (nhwc: the library's MFMA convolutions; nchw: the general fp32-arithmetic kernels)")
 parser.add_argument("--dual_bn", action="store_true", help="auxiliary BatchNorm set for adversarial features (not in the "
                     "reference: extra state_dict keys <bn>.adv.*; evaluation uses the main set)")
 parser.add_argument("--synthetic", type=int, default=0, help="train on N synthetic images instead of CIFAR-10")
@@ -254,9 +254,9 @@ def main(argv=None):
                                      clip=args.clip, lr=args.lr, momentum=args.momentum,
                                      weight_decay=args.weight_decay, dual_bn=args.dual_bn)
     optimizer = trainer.optimizer
-    vendor = resnet_s.vendor_convs(model)
+    vendor = resnet_s.general_convs(model)
     log("convolutions outside the library's kernels: {}{}".format(
-        len(vendor), " (vendor library, eager launches; --dtype bf16 --layout nhwc is the MFMA path)" if vendor else ""))
+        len(vendor), " (general f32-MFMA kernels; --dtype bf16 --layout nhwc is the tuned bf16 MFMA path)" if vendor else ""))
     decreasing_lr = list(map(int, args.decreasing_lr.split(",")))
     scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones=decreasing_lr, gamma=0.1)
 

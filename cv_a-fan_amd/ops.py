@@ -16,7 +16,9 @@ _ws_cache = {}
 _tls = threading.local()
 # how many convolution passes ran on the library's kernels / went to the vendor library since import (tests and the
 # entry points' logs use it to show which path a configuration really takes)
-CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "vendor_conv": 0}
+# ("vendor_conv" stays in the table as the invariant the tests assert: the package holds no vendor convolution any more;
+# "conv_general" counts passes of the fp32-arithmetic general kernels, afan_conv_f32.hip)
+CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "conv_general": 0, "vendor_conv": 0}
 
 
 def _need(t, name, dtype=None):
@@ -747,6 +749,98 @@ def wgrad_pairable(x, dy, k=3, stride=1):
     if x.shape[1] % 64 == 0 and dy.shape[1] % 64 == 0:
         return (dy.shape[0] * dy.shape[2] * dy.shape[3]) % 64 == 0
     return x.shape[1] != 3 and conv_wgrad_supported(x.shape[1], dy.shape[1], k, stride, (x.shape[0], x.shape[2], x.shape[3]))
+
+
+# ---- the general convolution (afan_conv_f32.hip): fp32 arithmetic on v_mfma_f32_32x32x2_f32, any shape / layout ----------
+def _w_layout(w):
+    """(w as the kernels can address it, AFAN_NHWC for KRSC memory | AFAN_NCHW for KCRS)."""
+    if w.dim() != 4 or w.shape[2] != w.shape[3]:
+        raise ValueError("convolution weight must be [Co, Ci, k, k]")
+    if w.is_contiguous():
+        return w, AFAN_NCHW
+    if w.is_contiguous(memory_format=torch.channels_last):
+        return w, AFAN_NHWC
+    return w.contiguous(), AFAN_NCHW
+
+
+def _conv_out(i, k, stride, pad, dil):
+    return (i + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def conv_general_fwd(x, w, bias=None, stride=1, padding=0, dilation=1):
+    """y = conv2d(x, w, bias, stride, padding, dilation) with fp32 arithmetic (f32 MFMA): x, w fp32 or bf16 (same dtype),
+    x dense NCHW or channels-last (y follows), w [Co,Ci,k,k] in KCRS or KRSC memory."""
+    lib = _lib.load()
+    CALLS["conv_general"] += 1
+    _need(x, "x"), _need(w, "w", x.dtype)
+    if x.dim() != 4 or x.dtype not in _DT or w.shape[1] != x.shape[1]:
+        raise TypeError("conv_general_fwd: x [N,Ci,H,W] and w [Co,Ci,k,k], both fp32 or both bf16")
+    w, wl = _w_layout(w)
+    n, ci, hi, wi = x.shape
+    co, k = w.shape[0], w.shape[2]
+    ho, wo = _conv_out(hi, k, stride, padding, dilation), _conv_out(wi, k, stride, padding, dilation)
+    lay = layout_of(x)
+    y = torch.empty((n, co, ho, wo), dtype=x.dtype, device=x.device,
+                    memory_format=torch.channels_last if lay == AFAN_NHWC else torch.contiguous_format)
+    if bias is not None:
+        _need(bias, "bias", torch.float32)
+    check(lib.afan_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _DT[x.dtype], lay, wl, n, hi, wi, ci, co, k, int(stride),
+                            int(padding), int(dilation), _stream(x)), "afan_conv_fwd")
+    return y
+
+
+def conv_general_dgrad(dy, w, in_hw, stride=1, padding=0, dilation=1):
+    """dx [N,Ci,Hi,Wi] for y = conv2d(x, w, ...): dy in the activations' layout and dtype, w the UNTRANSPOSED weight."""
+    lib = _lib.load()
+    CALLS["conv_general"] += 1
+    _need(dy, "dy"), _need(w, "w", dy.dtype)
+    if dy.dim() != 4 or dy.dtype not in _DT or w.shape[0] != dy.shape[1]:
+        raise TypeError("conv_general_dgrad: dy [N,Co,Ho,Wo] and w [Co,Ci,k,k], both fp32 or both bf16")
+    w, wl = _w_layout(w)
+    n, co = dy.shape[0], dy.shape[1]
+    ci, k = w.shape[1], w.shape[2]
+    hi, wi = int(in_hw[0]), int(in_hw[1])
+    if (_conv_out(hi, k, stride, padding, dilation), _conv_out(wi, k, stride, padding, dilation)) != tuple(dy.shape[2:]):
+        raise ValueError("dy's spatial size does not match the convolution of an input of size in_hw")
+    lay = layout_of(dy)
+    dx = torch.empty((n, ci, hi, wi), dtype=dy.dtype, device=dy.device,
+                     memory_format=torch.channels_last if lay == AFAN_NHWC else torch.contiguous_format)
+    check(lib.afan_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _DT[dy.dtype], lay, wl, n, hi, wi, ci, co, k, int(stride),
+                              int(padding), int(dilation), _stream(dy)), "afan_conv_dgrad")
+    return dx
+
+
+def conv_general_wgrad(x, dy, k, stride=1, padding=0, dilation=1, grad=None, accumulate=False):
+    """fp32 weight gradient [Co,Ci,k,k] of y = conv2d(x, w, ...): written / added into `grad` (KCRS or KRSC memory), or
+    returned as a new tensor in the memory order that matches the activations' layout."""
+    lib = _lib.load()
+    CALLS["conv_general"] += 1
+    _need(x, "x"), _need(dy, "dy", x.dtype)
+    if x.dim() != 4 or x.dtype not in _DT:
+        raise TypeError("conv_general_wgrad: x / dy fp32 or bf16 [N,C,H,W]")
+    lay = layout_of(x)
+    if layout_of(dy) != lay and dy.numel() > 0 and not (dy.shape[1] == 1 or dy.shape[2] * dy.shape[3] == 1):
+        dy = dy.contiguous(memory_format=torch.channels_last if lay == AFAN_NHWC else torch.contiguous_format)
+    n, ci, hi, wi = x.shape
+    co = dy.shape[1]
+    if grad is None:
+        grad = torch.empty((co, ci, k, k), dtype=torch.float32, device=x.device,
+                           memory_format=torch.channels_last if lay == AFAN_NHWC else torch.contiguous_format)
+        accumulate = False
+    _need(grad, "grad", torch.float32)
+    if tuple(grad.shape) != (co, ci, k, k):
+        raise ValueError("grad must be [Co,Ci,k,k]")
+    if grad.is_contiguous():
+        wl = AFAN_NCHW
+    elif grad.is_contiguous(memory_format=torch.channels_last):
+        wl = AFAN_NHWC
+    else:
+        raise ValueError("grad must be dense in KCRS or KRSC memory order")
+    ws = _workspace(x, lib.afan_conv_wgrad_f32_workspace_floats(n, hi, wi, ci, co, k, int(stride), int(padding), int(dilation)),
+                    "wgrad_f32")
+    check(lib.afan_conv_wgrad(_ptr(x), _ptr(dy), _ptr(grad), _DT[x.dtype], lay, wl, n, hi, wi, ci, co, k, int(stride),
+                              int(padding), int(dilation), _ptr(ws), int(bool(accumulate)), _stream(x)), "afan_conv_wgrad")
+    return grad
 
 
 def transpose_weights(src_arena, dst_arena, desc_dev, n_desc, total_tiles):

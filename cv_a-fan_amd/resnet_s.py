@@ -165,80 +165,96 @@ def _like_layout(t, ref):
     return t.contiguous()
 
 
+def _sq(v, what):
+    """The convolutions of the path are square in stride / padding / dilation (every layer of the reference's networks)."""
+    if v[0] != v[1]:
+        raise ops.AfanLibraryError(f"convolution with a non-square {what} {tuple(v)} is not implemented by libafan_hip")
+    return int(v[0])
+
+
 class _ConvFn(torch.autograd.Function):
-    """Convolution on the low-precision weight copy.  bf16 channels-last tensors of supported shapes run the
-    library's implicit-GEMM MFMA kernels for forward and input-gradient (afan_conv_*_nhwc_bf16); the weight
-    gradient (3 of the step's ~24 conv-equivalents) and everything else (fp32 parity mode, the 3-channel stem) goes
-    to MIOpen through aten.  wgrad is returned for the fp32 master weight."""
+    """Convolution on the compute-dtype weight copy, always on the library's own kernels: bf16 channels-last tensors of
+    the shapes the tuned implicit-GEMM MFMA kernels take run those (afan_conv_*_nhwc_bf16: forward, input gradient,
+    weight gradient); everything else — fp32 parity mode in either layout, the 3-channel stems at odd widths, NCHW
+    bf16 — runs the general fp32-arithmetic kernels (afan_conv_fwd / _dgrad / _wgrad, v_mfma_f32_32x32x2_f32).  There is
+    no vendor-library path: a shape neither family takes raises AfanLibraryError.  wgrad is returned for (or added
+    straight into) the fp32 master weight."""
 
     @staticmethod
-    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad, stats_req=None, dilation=(1, 1)):
+    def forward(ctx, x, w_master, w_lp, wt_fn, stride, padding, want_wgrad, stats_req=None, dilation=(1, 1), bias=None):
         ctx.stride, ctx.padding, ctx.want_wgrad, ctx.wt_fn = stride, padding, want_wgrad, wt_fn
         ctx.dilation = dilation = tuple(dilation)
         ctx.w_master = w_master
-        ctx.own = _own_conv_ok(x, w_lp, stride, padding, dilation)
-        ctx.save_for_backward(x, w_lp)
+        ctx.own = _own_conv_ok(x, w_lp, stride, padding, dilation) and bias is None
+        ctx.has_bias = bias is not None
         if ctx.own:
+            ctx.save_for_backward(x, w_lp)
             if stats_req is not None:   # [shift tensor | None, reusable partials buffer | None] -> filled with ConvStats
                 y, st = ops.conv_fwd(x, w_lp, stride[0], stats_shift=stats_req[0], want_stats=True,
                                      stats_buf=stats_req[1], dilation=dilation[0])
                 stats_req.append(st)
                 return y
             return ops.conv_fwd(x, w_lp, stride[0], dilation=dilation[0])
-        ops.CALLS["vendor_conv"] += 1
-        return torch.ops.aten.convolution(x, w_lp, None, stride, padding, dilation, False, (0, 0), 1)
+        x = _dense(x)
+        ctx.save_for_backward(x, w_lp)
+        return ops.conv_general_fwd(x, w_lp, None if bias is None else bias.detach().float(), _sq(stride, "stride"),
+                                    _sq(padding, "padding"), _sq(dilation, "dilation"))
 
     @staticmethod
     def backward(ctx, gy):
         x, w_lp = ctx.saved_tensors
         need_gx = ctx.needs_input_grad[0]
         need_gw = ctx.want_wgrad and ctx.needs_input_grad[1]
+        need_gb = ctx.has_bias and ctx.want_wgrad and ctx.needs_input_grad[9]
         gy = _like_layout(gy, x) if x.dim() == 4 and gy.shape[2:] == x.shape[2:] else _dense(gy)
-        gx = gw = None
+        if ops.layout_of(gy) != ops.layout_of(x) and gy.shape[1] > 1 and gy.shape[2] * gy.shape[3] > 1:
+            gy = gy.contiguous(memory_format=torch.channels_last if ops.layout_of(x) == ops.AFAN_NHWC else torch.contiguous_format)
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx = gw = gb = None
+        k = w_lp.shape[2]
+        st, pad, dil = ctx.stride[0], ctx.padding[0], ctx.dilation[0]
         own = ctx.own and gy.is_contiguous(memory_format=torch.channels_last)
-        if need_gx and own:
-            gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], ctx.stride[0], dilation=ctx.dilation[0])
-            need_gx = False
-        if need_gw and own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], w_lp.shape[2], ctx.stride[0],
-                                                        (x.shape[0], x.shape[2], x.shape[3])):
-            w_master = ctx.w_master
-            k = w_lp.shape[2]
-            if _accumulates_in_place(w_master) and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
-                # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd.
-                # Weight gradients are off the backward's critical path (the dgrad -> BN-backward chain), so they go to
-                # a side stream and fill the SIMD slots the latency-bound chain leaves idle; joined before the SGD step.
-                side = _Flags.wgrad_stream
-                if side is not None:
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True, dilation=ctx.dilation[0])
-                    x.record_stream(side)
-                    gy.record_stream(side)
-                else:
-                    ops.conv_wgrad(x, gy, k, ctx.stride[0], w_master.grad, accumulate=True, dilation=ctx.dilation[0])
+        if need_gx:
+            if own:
+                gx = ops.conv_dgrad(gy, ctx.wt_fn(), x.shape[2:], st, dilation=dil)
             else:
-                gw = ops.conv_wgrad(x, gy, k, ctx.stride[0], dilation=ctx.dilation[0])
-            need_gw = False
-        if need_gx or need_gw:
-            ops.CALLS["vendor_conv"] += 1
-            g2, g3, _ = torch.ops.aten.convolution_backward(gy, x, w_lp, None, ctx.stride, ctx.padding, ctx.dilation, False,
-                                                            (0, 0), 1, [need_gx, need_gw, False])
-            if need_gx:
-                gx = g2
-            if need_gw:
-                gw = g3
-                w_master = ctx.w_master
-                if _accumulates_in_place(w_master):
-                    w_master.grad.add_(gw)      # bf16 wgrad summed straight into the fp32 arena view: one launch
-                    gw = None
-                elif gw.dtype != torch.float32:
-                    gw = gw.float()
-        return gx, gw, None, None, None, None, None, None, None
+                gx = ops.conv_general_dgrad(gy, w_lp, x.shape[2:], st, pad, dil)
+        if need_gw:
+            w_master = ctx.w_master
+            direct = _accumulates_in_place(w_master)
+            if own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
+                if direct and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
+                    # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd.
+                    # Weight gradients are off the backward's critical path (the dgrad -> BN-backward chain), so they go to
+                    # a side stream and fill the SIMD slots the latency-bound chain leaves idle; joined before the SGD step.
+                    side = _Flags.wgrad_stream
+                    if side is not None:
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            ops.conv_wgrad(x, gy, k, st, w_master.grad, accumulate=True, dilation=dil)
+                        x.record_stream(side)
+                        gy.record_stream(side)
+                    else:
+                        ops.conv_wgrad(x, gy, k, st, w_master.grad, accumulate=True, dilation=dil)
+                else:
+                    gw = ops.conv_wgrad(x, gy, k, st, dilation=dil)
+            elif direct and _dense_weight(w_master.grad):
+                ops.conv_general_wgrad(x, gy, k, st, pad, dil, grad=w_master.grad, accumulate=True)
+            else:
+                gw = ops.conv_general_wgrad(x, gy, k, st, pad, dil)
+        if need_gb:
+            gb = gy.float().sum(dim=(0, 2, 3))
+        return gx, gw, None, None, None, None, None, None, None, gb
+
+
+def _dense_weight(g):
+    return g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)
 
 
 def _wgrad_accumulate(x, dy, c):
-    """Weight gradient of conv module c added into its arena gradient view: the library's kernel where it tiles, else
-    (16/32-channel layers) the vendor wgrad on the same bf16 tensors plus one add into the fp32 view."""
+    """Weight gradient of conv module c added into its arena gradient view: the tuned bf16 kernels where they tile, else
+    the general fp32-arithmetic kernel on the same bf16 tensors."""
     k, st, dil = c.kernel_size[0], c.stride[0], c.dilation[0]
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
         pairable = ops.wgrad_pairable(x, dy, k, st)
@@ -254,10 +270,7 @@ def _wgrad_accumulate(x, dy, c):
             ops.conv_wgrad(pend[0], pend[1], k, st, c.weight.grad, accumulate=True, dilation=dil)
         ops.conv_wgrad(x, dy, k, st, c.weight.grad, accumulate=True, dilation=dil)
         return
-    ops.CALLS["vendor_conv"] += 1
-    gw = torch.ops.aten.convolution_backward(dy, x, c.lp_weight(), None, (st, st), c.padding, c.dilation, False, (0, 0), 1,
-                                             [False, True, False])[1]
-    c.weight.grad.add_(gw)
+    ops.conv_general_wgrad(x, dy, k, st, c.padding[0], dil, grad=c.weight.grad, accumulate=True)
 
 
 class stash_wgrad:
@@ -305,17 +318,24 @@ def _own_conv_ok_shape(w, stride, padding, dilation=(1, 1)):
     return ops.conv_supported(w.shape[1], w.shape[0], k, stride[0], d if k > 1 else 1)
 
 
-def vendor_convs(model):
-    """Names of the convolutions of `model` whose forward / input gradient would go to the vendor library in its present
-    configuration (fp32 parity mode, NCHW weights, unsupported shapes); the image stem (3 input channels) is not listed.
-    A hipGraph of the training step is only captured when this is empty: a captured vendor input-gradient pass was
-    measured reading memory the graph does not own (tools/diag_graph_piece.py; NaNs after the first validation pass)."""
-    bad = []
+def general_convs(model):
+    """Names of the convolutions of `model` that, in its present configuration, run on the general fp32-arithmetic
+    kernels (afan_conv_f32.hip: fp32 parity mode, NCHW weights, shapes the tuned bf16 kernels decline) instead of the
+    tuned bf16 MFMA kernels; the image stem (3 input channels) is not listed (it decides by image width at run time).
+    Informational: both families are the library's own and both are hipGraph-capturable."""
+    out = []
     for name, m in model.named_modules():
-        if isinstance(m, Conv2d) and m.in_channels > 4 and not getattr(m, "own_kernel", False):   # (the stem decides by image width at run time)
+        if isinstance(m, Conv2d) and m.in_channels > 4 and not getattr(m, "own_kernel", False):
             if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding, m.dilation):
-                bad.append(name)
-    return bad
+                out.append(name)
+    return out
+
+
+def vendor_convs(model):
+    """Convolutions of `model` that would leave the library for the vendor's: none, by construction — rounds 1-2 sent fp32
+    parity mode and odd shapes to MIOpen through aten; those branches are gone (see _ConvFn).  Kept as the invariant the
+    entry points log and the tests assert."""
+    return []
 
 
 def _own_conv_ok(x, w, stride, padding, dilation=(1, 1)):
@@ -753,7 +773,7 @@ class _HeadFn(torch.autograd.Function):
             else:
                 dw = torch.empty_like(weight)
                 db = torch.empty_like(bias) if bias is not None else None
-        dx = ops.head_backward(g.float(), weight, pooled, x, ctx.needs_input_grad[0], dw, db, accumulate=direct)
+        dx = ops.head_backward(g.float().contiguous(), weight, pooled, x, ctx.needs_input_grad[0], dw, db, accumulate=direct)
         if direct:
             dw = db = None
         return dx, dw, db, None
@@ -804,6 +824,57 @@ def _head_ok(x, lin):
     return (_FUSED_HEAD and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and lin.weight.dtype == torch.float32
             and (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous() or x.shape[2] * x.shape[3] == 1)
             and lin.out_features <= 16)
+
+
+def _head_in(x):
+    """The classifier-head kernels walk channels-last rows: an NCHW map (fp32 parity mode in the reference's layout) is
+    re-laid — data movement of the last, smallest feature map only."""
+    if x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.shape[2] * x.shape[3] > 1 and x.shape[1] > 1:
+        return x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+class _LinearFn(torch.autograd.Function):
+    """nn.Linear on the GPU as a 1x1 convolution of an [N, Cin, 1, 1] map on the general fp32-arithmetic kernels (no
+    vendor GEMM): y = x w^T + b."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_pgrad):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.pg, ctx.bias = want_pgrad, bias
+        n, ci = x.shape
+        y = ops.conv_general_fwd(x.view(n, ci, 1, 1), weight.detach().view(weight.shape[0], ci, 1, 1),
+                                 None if bias is None else bias.detach())
+        return y.view(n, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        n, ci = x.shape
+        co = weight.shape[0]
+        g = g.contiguous().float()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv_general_dgrad(g.view(n, co, 1, 1), weight.detach().view(co, ci, 1, 1), (1, 1)).view(n, ci)
+        if ctx.pg and ctx.needs_input_grad[1]:
+            direct = _accumulates_in_place(weight)
+            gwt = ops.conv_general_wgrad(x.view(n, ci, 1, 1), g.view(n, co, 1, 1), 1,
+                                         grad=weight.grad.view(co, ci, 1, 1) if direct else None, accumulate=direct)
+            gw = None if direct else gwt.view(co, ci)
+            bias = ctx.bias
+            if bias is not None:
+                if _accumulates_in_place(bias):
+                    bias.grad.add_(g.sum(dim=0))
+                else:
+                    gb = g.sum(dim=0)
+        return gx, gw, gb, None
+
+
+def _linear(x, lin):
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
+        return _LinearFn.apply(x, lin.weight, lin.bias, _Flags.param_grads)
+    return lin(x)
 
 
 class _HeadPool(nn.AdaptiveAvgPool2d):
@@ -878,13 +949,13 @@ class ResNet(nn.Module):
                     continue
                 x = L.fused(x)
             elif (isinstance(L, _HeadPool) and i + 2 < n and isinstance(layers[i + 1], nn.Flatten)
-                  and isinstance(layers[i + 2], nn.Linear) and _head_ok(x, layers[i + 2])):
+                  and isinstance(layers[i + 2], nn.Linear) and _head_ok(_head_in(x), layers[i + 2])):
                 lin = layers[i + 2]
-                x = _HeadFn.apply(x, lin.weight, lin.bias, _Flags.param_grads)
+                x = _HeadFn.apply(_head_in(x), lin.weight, lin.bias, _Flags.param_grads)
                 i += 3
                 continue
             elif isinstance(L, nn.Linear):
-                x = L(x.float())
+                x = _linear(x.float(), L)
             else:
                 x = L(x)
             i += 1

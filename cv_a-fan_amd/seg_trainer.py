@@ -7,7 +7,7 @@ the two-group SGD and the PolyLR schedule around `seg_attack_algo.seg_train_step
 Reference details kept: BatchNorm momentum 0.01 in the backbone (main_aug_final.py:77), SGD(momentum 0.9) with the
 backbone at 0.1 x lr (:79-82), PolyLR(power 0.9) stepped once per iteration (:261), CrossEntropyLoss(ignore_index=255).
 After `graph_warmup` eager iterations the whole iteration body is captured into a hipGraph and replayed (bf16
-channels-last configuration only: no vendor convolution inside a capture, see resnet_s.vendor_convs)."""
+every configuration: all convolutions are the library's own, see resnet_s.vendor_convs)."""
 import torch
 import torch.nn as nn
 

@@ -511,8 +511,9 @@ class AfanTrainer:
         return self._groupable
 
     def _graph_safe(self):
-        """Capture only the configuration whose convolutions all run on the library's kernels (bf16, channels-last);
-        anything else (fp32 parity mode, NCHW) keeps eager launches — see resnet_s.vendor_convs."""
+        """Every configuration runs on the library's own kernels (tuned bf16 or general f32 MFMA) and is capturable; a
+        convolution that left the library would be listed by resnet_s.vendor_convs (empty by construction) and keep the
+        step eager: rounds 1-2 measured a captured vendor input-gradient pass reading memory the graph did not own."""
         if self._graph_unsafe is None:
             from . import resnet_s
             self._graph_unsafe = resnet_s.vendor_convs(self.model) if hasattr(self.model, "sequential_model") else []

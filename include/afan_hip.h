@@ -290,6 +290,31 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
                                float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation,
                                float* workspace, int accumulate, afan_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * The GENERAL convolution, fp32-accurate (afan_conv_f32.hip): what torch.nn.Conv2d computes in the reference's fp32 training
+ * (Classification/main_perturb.py:173-201, attack_algo.py:50-52; Segmentation/network/backbone/resnet.py:143,
+ * _deeplab.py:33-45,146-155) for ANY channel counts (the 3-channel image stems included), k <= 7, padding 0..127, stride 1 or 2,
+ * dilation >= 1, optional bias — forward, input gradient and weight gradient on v_mfma_f32_32x32x2_f32 (f32 products, f32
+ * accumulate: a k-ordered fmaf chain).  `dtype` AFAN_F32: fp32 storage (parity mode — north_star's 1e-4 bar is held on these
+ * kernels) or AFAN_BF16: bf16 storage, the same fp32 arithmetic (shapes the tuned bf16 kernels above decline).  `layout` of the
+ * activations AFAN_NHWC / AFAN_NCHW, `w_layout` of the weight tensor [Co,Ci,k,k]: AFAN_NHWC = KRSC memory (the parameter
+ * arena's), AFAN_NCHW = KCRS (torch's default).  Ho = (Hi + 2 pad - dilation (k-1) - 1) / stride + 1.
+ *   fwd  : y[N,Co,Ho,Wo]  = conv(x[N,Ci,Hi,Wi], w) (+ bias[Co], fp32, nullable)
+ *   dgrad: dx[N,Ci,Hi,Wi] = conv_transpose(dy[N,Co,Ho,Wo], w) — reads the UNTRANSPOSED weight; stride 2 as four output-parity
+ *          classes (no products with inserted zeros); input positions no window reaches receive 0
+ *   wgrad: grad[Co,Ci,k,k] (fp32, `w_layout`) (+)= sum_p dy[p][co] * x[pixel(p) + tap][ci]; pixel slices reduced in fixed order
+ *          (deterministic); workspace = afan_conv_wgrad_f32_workspace_floats(...) floats, 16-byte aligned.
+ * n == 0: no launch (wgrad without accumulate zero-fills grad).  No vendor library is involved anywhere in this package. */
+int afan_conv_fwd(const void* x, const void* w, const float* bias, void* y, int dtype, int layout, int w_layout, int64_t n,
+                  int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int pad, int dilation, afan_stream_t stream);
+int afan_conv_dgrad(const void* dy, const void* w, void* dx, int dtype, int layout, int w_layout, int64_t n, int64_t hi,
+                    int64_t wi, int64_t ci, int64_t co, int k, int stride, int pad, int dilation, afan_stream_t stream);
+int64_t afan_conv_wgrad_f32_workspace_floats(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride,
+                                             int pad, int dilation);
+int afan_conv_wgrad(const void* x, const void* dy, float* grad, int dtype, int layout, int w_layout, int64_t n, int64_t hi,
+                    int64_t wi, int64_t ci, int64_t co, int k, int stride, int pad, int dilation, float* workspace,
+                    int accumulate, afan_stream_t stream);
+
 /* Fragment-major packed copy of a convolution weight tensor w[rows][taps][red] (bf16; KRSC for the forward, CRSK for the
  * input gradient): packed[row / 32][tap * ceil(red/64) + q][kk][lane][8] = the MFMA 32x32x16 operand of lane `lane` — what the
  * register-streamed-weights variant of the convolution reads with fully coalesced 1-KiB requests (afan_conv_breg.hip).

@@ -57,21 +57,29 @@ def test_captured_step_owns_its_memory(pkg, gpu, arch, idx, batch, side, classes
     assert torch.isfinite(r["l2"]).all() and torch.isfinite(tr.arena.param).all()
 
 
-def test_vendor_configurations_are_not_captured(pkg, gpu):
-    """fp32 parity mode / NCHW weights run their convolutions in the vendor library: eager launches, no hipGraph."""
-    torch.manual_seed(0)
-    model = pkg.resnet_s.resnet20()
-    model.set_compute_dtype(torch.bfloat16).to(gpu).train()          # bf16 but NCHW weights
-    assert pkg.resnet_s.vendor_convs(model)
-    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, perturb_idx=7, lr=0.01)
-    x = torch.rand(32, 3, 32, 32, device=gpu)
-    y = torch.randint(0, 10, (32,), device=gpu)
-    before = dict(pkg.ops.CALLS)
-    for _ in range(5):
+def test_general_kernel_configurations_are_captured_too(pkg, gpu):
+    """NCHW weights (bf16) and fp32 parity mode run their convolutions on the library's general fp32-arithmetic kernels
+    (afan_conv_f32.hip) — no vendor library — and the step is replayed from a hipGraph like the tuned configuration."""
+    for dtype, cl in ((torch.bfloat16, False), (torch.float32, True), (torch.float32, False)):
+        torch.manual_seed(0)
+        model = pkg.resnet_s.resnet20()
+        model.set_compute_dtype(dtype).set_channels_last(cl).to(gpu).train()
+        assert pkg.resnet_s.general_convs(model) and not pkg.resnet_s.vendor_convs(model)
+        tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, perturb_idx=7, lr=0.01)
+        x = torch.rand(32, 3, 32, 32, device=gpu)
+        y = torch.randint(0, 10, (32,), device=gpu)
+        before = dict(pkg.ops.CALLS)
+        losses = []
+        for _ in range(6):
+            r = tr.step(x, y)
+            losses.append(float(r["loss"]))
+        assert tr._graph is not None, tr._graph_failed
+        assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_general"] > before["conv_general"]
+        assert all(math.isfinite(v) for v in losses)
+        keep = _poison(gpu)
+        del keep
         r = tr.step(x, y)
-    assert tr._graph is None and tr.use_graph is False
-    assert pkg.ops.CALLS["vendor_conv"] > before["vendor_conv"]
-    assert math.isfinite(float(r["loss"]))
+        assert math.isfinite(float(r["loss"])) and torch.isfinite(tr.arena.param).all()
 
 
 def test_learnable_captured_step_owns_its_memory(pkg, gpu):

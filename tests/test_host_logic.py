@@ -87,11 +87,21 @@ def test_main_perturb_flags(pkg):
     assert (b.seed, b.save_dir, b.gamma) == (3, "x", 0.5)
 
 
-def test_vendor_convs_lists_what_leaves_the_library(pkg):
-    """resnet_s.vendor_convs decides whether the step may be captured as a hipGraph: fp32 parity mode runs every
-    convolution in the vendor library (all 16+-channel convolutions are listed); the image stem is never listed."""
+def test_no_convolution_leaves_the_library(pkg):
+    """resnet_s.general_convs lists the convolutions that run on the general fp32-arithmetic kernels (fp32 parity mode: all
+    16+-channel convolutions; the image stem is never listed); resnet_s.vendor_convs is empty by construction and the
+    package source holds no aten / functional convolution call for GPU tensors."""
     m = pkg.resnet_s.resnet20()
-    names = pkg.resnet_s.vendor_convs(m)
+    names = pkg.resnet_s.general_convs(m)
     convs = [n for n, mod in m.named_modules() if isinstance(mod, pkg.resnet_s.Conv2d) and mod.in_channels > 4]
-    assert names == convs and len(names) == 18 + 0 * len(convs)
-    assert set(pkg.ops.CALLS) == {"conv_fwd", "conv_dgrad", "conv_wgrad", "vendor_conv"}
+    assert names == convs and len(names) == 18
+    assert pkg.resnet_s.vendor_convs(m) == []
+    assert set(pkg.ops.CALLS) == {"conv_fwd", "conv_dgrad", "conv_wgrad", "conv_general", "vendor_conv"}
+    import glob
+    import os
+    import re
+    src_dir = os.path.dirname(pkg.__file__)
+    for path in glob.glob(os.path.join(src_dir, "*.py")):
+        txt = open(path).read()
+        assert not re.search(r"aten\.convolution|convolution_backward|cudnn_convolution|miopen_convolution", txt), path
+        assert not re.search(r"functional\.conv2d|F\.conv2d|F\.linear|functional\.linear", txt), path

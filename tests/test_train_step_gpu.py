@@ -70,8 +70,13 @@ def test_joint_step_fp32_matches_reference(pkg, orc, gpu, case):
     # perturbation: delta identical except sign flips (each flip moves an element by 2*gamma/255 per step)
     d_got = (r["x_adv"] - r["feature_map"]).cpu().numpy()
     d_ref = g["x_adv"] - g["feature_map"]
-    assert_close_frac(d_got, d_ref, 0, 2e-6, FLIP_BOUND[arch], "perturbation (sign-flip fraction)")
-    if K == 1 or clip:
+    # gamma = 1.5/255 against eps = 2/255 (the clip goldens): every step throws an element across the whole eps-ball, so ONE
+    # early flip (a gradient within rounding of zero) moves its neighbours' next gradients by a macroscopic amount and the
+    # difference avalanches over the remaining steps: K = 5 ends 2.4 % off on the library's f32-MFMA convolutions (the
+    # vendor's fp32 convolutions of rounds 1-2 happened to flip nothing: 0 %), K = 3 stays exact.  Bound: 5e-2 there.
+    avalanche = bool(clip) and K > 3
+    assert_close_frac(d_got, d_ref, 0, 2e-6, 5e-2 if avalanche else FLIP_BOUND[arch], "perturbation (sign-flip fraction)")
+    if K == 1 or (clip and not avalanche):
         assert_close_frac(d_got, d_ref, 0, 2e-6, 1e-4, "first-step / clipped perturbation")
     np.testing.assert_allclose(r["l2"].cpu().numpy(), g["l2"], rtol=5e-3)
     # linf = max |fl(x + k*gamma) - x|: carries the rounding of x + k*gamma, i.e. an ulp of the feature value
@@ -340,7 +345,7 @@ def test_block_fusion_matches_per_op_path(pkg, orc, gpu, bn_mode, arch, idx):
             finally:
                 pkg.resnet_s._Flags.block_fusion = True
     a, b = res[(0, False)], res[(0, True)]
-    assert abs(a[0] - b[0]) < 1e-3 and abs(a[1] - b[1]) < 1e-3
+    assert abs(a[0] - b[0]) < 2e-3 and abs(a[1] - b[1]) < 2e-3      # (27 bf16 blocks: measured 0.6e-3 .. 1.3e-3 across builds)
     rel = np.linalg.norm(b[2] - a[2]) / np.linalg.norm(a[2])
     assert rel < 0.25, rel                       # whole gradient arena: bf16 chaos floor is ~0.1 (see the batched-pass test)
     assert abs(np.linalg.norm(b[2]) / np.linalg.norm(a[2]) - 1.0) < 2e-2
@@ -641,33 +646,43 @@ def test_folded_clean_pass_equals_reference_schedule(pkg, orc, gpu, arch, idx, d
 def test_segmented_step_equals_unsegmented(pkg, orc, gpu, arch, idx, graph):
     """The data-parallel form of the folded step (tail run in segments cut at the stage transitions, backward issued piece
     by piece so that each stage's gradients can be all-reduced while the rest runs; one hipGraph per piece) against the
-    one-piece step on one GPU: same losses, gradients, weights and BatchNorm buffers after three iterations."""
-    res = {}
-    for seg in (False, True):
-        m = _build(pkg, orc, arch, gpu, dtype=torch.bfloat16)
-        m.set_channels_last(True)
-        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.05,
-                                        use_graph=graph, graph_warmup=1, segmented=seg)
-        torch.manual_seed(0)
-        x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
-        losses = [float(tr.step(x, y)["loss"])]
-        grad1 = tr.arena.grad.clone()               # after the FIRST step: identical weights in both runs
-        losses += [float(tr.step(x, y)["loss"]) for _ in range(2)]
-        if graph:
-            assert tr._graph is not None, tr._graph_failed
-            assert (tr._pieces is not None) == seg
-        if seg:
-            assert len(tr._tail_segments()) >= 2
-        res[seg] = (losses, grad1, {k: v.clone() for k, v in m.state_dict().items()})
-    np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=2e-3)
-    g0, g1 = res[False][1], res[True][1]
-    # same weights, same arithmetic except where a BatchNorm-backward reduction moved out of a dgrad epilogue at a cut
-    assert float((g1 - g0).norm() / g0.norm()) <= 1e-2, float((g1 - g0).norm() / g0.norm())
-    for k, v in res[False][2].items():
-        if "num_batches" in k:
-            assert int(res[True][2][k]) == int(v), k
-        elif "running" in k:
-            np.testing.assert_allclose(res[True][2][k].float().cpu().numpy(), v.float().cpu().numpy(), rtol=2e-2, atol=2e-3, err_msg=k)
+    one-piece step on one GPU.  The two differ only in where a BatchNorm-backward reduction is taken at a cut (stand-alone
+    slab + finalize instead of the next dgrad's epilogue: ~5e-5 of that tensor's bf16 elements land one ulp apart,
+    tools/probe/bn_bwd_paths.py).  K = 0 (no sign()): gradients equal to accumulation-order noise.  K = 2: same BatchNorm
+    side effects, losses and gradients at the level K sign() steps leave of such a difference on a freshly initialised
+    batch-16 network (tools/probe/seg_vs_unseg.py: 0 .. 7 % of the perturbation elements, depending on the build)."""
+    for K in (0, 2):
+        res = {}
+        for seg in (False, True):
+            m = _build(pkg, orc, arch, gpu, dtype=torch.bfloat16)
+            m.set_channels_last(True)
+            tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.05,
+                                            use_graph=graph, graph_warmup=1, segmented=seg, fold_clean=True if K else None)
+            torch.manual_seed(0)
+            x, y = torch.rand(16, 3, 32, 32, device=gpu), torch.randint(0, 10, (16,), device=gpu)
+            losses = [float(tr.step(x, y)["loss"])]
+            grad1 = tr.arena.grad.clone()               # after the FIRST step: identical weights in both runs
+            losses += [float(tr.step(x, y)["loss"]) for _ in range(2)]
+            if graph and K:
+                assert tr._graph is not None, tr._graph_failed
+                assert (tr._pieces is not None) == seg
+            if seg and K:
+                assert len(tr._tail_segments()) >= 2
+            res[seg] = (losses, grad1, {k: v.clone() for k, v in m.state_dict().items()})
+        g0, g1 = res[False][1], res[True][1]
+        d = float((g1 - g0).norm() / g0.norm())
+        if K == 0:
+            np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=2e-4)
+            assert d <= 2e-3, d
+        else:
+            np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-2)
+            assert d <= 0.2, d
+        for k, v in res[False][2].items():
+            if "num_batches" in k:
+                assert int(res[True][2][k]) == int(v), k
+            elif "running" in k:      # (K = 2: three SGD steps on perturbations that differ in a few per cent of the elements)
+                np.testing.assert_allclose(res[True][2][k].float().cpu().numpy(), v.float().cpu().numpy(), rtol=2e-2,
+                                           atol=2e-3 if K == 0 else 5e-2, err_msg=k)
 
 
 @pytest.mark.parametrize("arch,idx,dtype", [("resnet20s", 7, torch.float32), ("resnet20s", 7, torch.bfloat16), ("resnet18", 6, torch.bfloat16)])
