@@ -145,6 +145,52 @@ def gen_pgd_traces(ref_attack, build, crit, only=None):
         print(name, "ok")
 
 
+def gen_damped_r18(ref_attack, orc):
+    """A CONTRACTIVE ResNet-18 (CIFAR stem) step for the end-to-end comparison of the bf16 kernels: every
+    block's last-BatchNorm weight x 0.1 (weights are data), so that a residual block is identity + a small correction and
+    rounding noise is damped instead of amplified; batch 32, K = 5.  The reference's own PGD (Classification/attack_algo.py)
+    and the loop body of main_perturb.py:173-201 drive the build-defined ResNet-18 module (the reference ships none).  Stored:
+    inputs, the three losses, the perturbation as int8 multiples of gamma, every parameter's gradient norm, a few gradient
+    tensors, every BatchNorm's running statistics after the step, the state_dict fingerprint."""
+    crit = nn.CrossEntropyLoss()
+    torch.manual_seed(3)
+    model, idx, ln = orc.resnet18_cifar(), 6, 15
+    damp = 0.1
+    for m in model.modules():
+        if isinstance(m, orc.Block):
+            m.bn2.weight.data.mul_(damp)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+    bs, K, gamma, eps = 32, 5, 0.5, 2.0
+    x = torch.rand(bs, 3, 32, 32)
+    y = torch.randint(0, 10, (bs,))
+    rec = {"x": _np(x), "y": _np(y), "meta": np.array([K, idx, ln, 0, 0]), "gamma_eps": np.array([gamma, eps], dtype=np.float64),
+           "damp": np.array(damp)}
+    k0, c0 = _checksums(model)
+    rec["ck0"] = c0
+    r = _ref_step(ref_attack, model, opt, crit, x, y, K, gamma, eps, idx, ln, False, False)
+    for k in ("l2", "linf", "loss", "loss_adv", "loss_clean", "out_clean"):
+        rec[k] = _np(r[k])
+    dk = torch.round((r["x_adv"] - r["feature_map"]) / np.float32(gamma / 255))
+    assert float(dk.abs().max()) <= K
+    rec["dk"] = _np(dk).astype(np.int8)
+    rec["feature_map_sub"] = _np(r["feature_map"][:, ::4, ::2, ::2])
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    rec["param_names"] = np.array([n for n, _ in named])
+    rec["grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in named])
+    for n, p in named:
+        if n.endswith(("sequential_model.1.weight", ".4.conv1.weight", ".7.bn2.weight", ".6.conv1.weight", ".11.bn1.bias", ".14.weight", ".14.bias")):
+            rec["grad/" + n] = _np(p.grad)
+    k1, c1 = _checksums(model)
+    rec["keys"], rec["ck1"] = np.array(k1), c1
+    for k, v in model.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            rec["sd1/" + k] = _np(v)
+    np.savez_compressed(os.path.join(OUT, "step_r18_k5_b32_damped.npz"), **rec)
+    print("step_r18_k5_b32_damped loss", float(r["loss"]), float(r["loss_adv"]), float(r["loss_clean"]), "grads stored:",
+          [k for k in rec if k.startswith("grad/")])
+
+
 def gen_detection(orc):
     # ---- Detection (N2): the reference's own adv_input / PGD / rpn_roi_PGD / get_sample_points / mix_feature / compute_loss
     # (Detection/attack_algo.py) and the loop body of Detection/train_aug_sat_muti_advt.py:70-172 driven line by line around
@@ -293,6 +339,8 @@ def main():
             rec["sd1/" + k] = _np(sd[k])
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
         print(name, "loss", float(r["loss"]), "l2", r["l2"].tolist())
+
+    gen_damped_r18(ref_attack, orc)
 
     # ---- per-step PGD trace (kernel-level golden: x_adv before/after every step, with its gradient) ----
     gen_pgd_traces(ref_attack, build, crit)
@@ -563,6 +611,12 @@ if __name__ == "__main__":
         from oracle import afan_oracle as _orc
         _ra = _load("ref_cls_attack_algo", "Classification/attack_algo.py")
         gen_pgd_traces(_ra, lambda a: (_orc.resnet18_cifar(), 6, 15), nn.CrossEntropyLoss(), only=("pgd_trace_r18_k5",))
+    elif sys.argv[1:] == ["damped18"]:    # only the contractive ResNet-18 step
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        os.makedirs(OUT, exist_ok=True)
+        from oracle import afan_oracle as _orc
+        gen_damped_r18(_load("ref_cls_attack_algo", "Classification/attack_algo.py"), _orc)
     elif sys.argv[1:] == ["det"]:         # only the Detection fixtures (the full run regenerates every file bit-identically)
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         _shims()
