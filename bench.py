@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--async_wgrad", action="store_true", help="weight gradients on a side stream (measured: no gain)")
     ap.add_argument("--no_batch_final", action="store_true", help="run the adv and clean final passes separately (A/B)")
     ap.add_argument("--no_fold_clean", action="store_true", help="separate first PGD pass and final clean pass (A/B)")
+    ap.add_argument("--no_fold_pgd0", action="store_true", help="DeepLab: keep the first pass of both PGD loops separate from the clean pass (A/B)")
+    ap.add_argument("--dropout", type=float, default=None, help="DeepLab: override the head's nn.Dropout p (reference: 0.1)")
     ap.add_argument("--force_fold_clean", action="store_true", help="one clean tail pass regardless of the size heuristic (A/B)")
     ap.add_argument("--no_share_head", action="store_true", help="run the head twice per step like the reference's text (A/B)")
     ap.add_argument("--dual_bn", action="store_true", help="A/B: auxiliary BatchNorm set for adversarial features (an option the "
@@ -219,7 +221,13 @@ def main():
         trainer = pkg.seg_trainer.SegTrainer(model, nn.CrossEntropyLoss(ignore_index=255, reduction="mean"), steps=args.pgd_steps,
                                              eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp",
                                              mix_layer="11", mix_sd=True, lr=0.01, use_graph=not args.no_graph,
-                                             dual_bn=args.dual_bn)
+                                             dual_bn=args.dual_bn,
+                                             fold_clean=False if args.no_fold_clean else None,
+                                             fold_pgd0=False if (args.no_fold_clean or args.no_fold_pgd0) else None)
+        if args.dropout is not None:               # (the reference's DeepLab head has nn.Dropout(0.1), _deeplab.py:185)
+            for m_ in model.modules():
+                if isinstance(m_, nn.Dropout):
+                    m_.p = args.dropout
         side, ncls = args.side, 21
         data = [synth_seg(args.batch, side, g) for _ in range(nbuf)]
         xs, ys = [d[0].to(dev) for d in data], [d[1].to(dev) for d in data]
@@ -356,8 +364,19 @@ def main():
             workload = (f"{args.arch} output-stride 16, VOC-shape {side}x{side} synthetic, SE (layer3) + SD (aspp) feature PGD K="
                         f"{args.pgd_steps}, mix_feature 11 + mix_sd, {args.dtype}, batch {args.batch}/GPU, internal layout "
                         f"{args.layout} (BASELINE configs[3], per-GPU share)")
-            sched = ("main_aug_final.py:158-232 as written: head pass + clean decoder-head pass, K SE + K SD PGD passes, "
-                     "clean / SE1 / SE2 / SD forwards, one joint backward")
+            # which passes ran (seg_train_step reports its decisions): the reference's text is head pass (:166) + clean decoder-head
+            # pass (:167) + K SE + K SD PGD passes + clean / SE1 / SE2 / SD forwards (:193-209)
+            K_ = args.pgd_steps
+            drop_p = max([m_.p for m_ in model.modules() if isinstance(m_, nn.Dropout)] + [0.0])
+            if r.get("fold_pgd0"):
+                sched = (f"ONE clean pass standing for :166, :167, :193 AND the first pass of both PGD loops (dropout p = {drop_p}: "
+                         f"identical passes), {K_ - 1} SE + {K_ - 1} SD PGD passes, SE1 / SE2 / SD forwards, one joint backward")
+            elif r.get("fold_clean"):
+                sched = (f"ONE clean pass standing for :166, :167 and :193 (two dropout draws on its ASPP output, p = {drop_p}), "
+                         f"{K_} SE + {K_} SD PGD passes, SE1 / SE2 / SD forwards, one joint backward")
+            else:
+                sched = (f"main_aug_final.py:158-232 as written: head pass + clean decoder-head pass, {K_} SE + {K_} SD PGD passes, "
+                         "clean / SE1 / SE2 / SD forwards, one joint backward")
         else:
             metric = ("images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10" if default_cfg else
                       f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}")

@@ -624,7 +624,8 @@ def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False):
     forward's own logits, loss and d(loss)/d(feature).  The graph is then cut at the SE point and at the low-level feature
     (`se_in`, `low_in`: leaves whose gradients the caller feeds back into the head graph at the end) so that the clean
     loss can be back-propagated through the tail at once; `sd_t` is the SD point's tensor (retain_grad).  One dropout draw
-    then serves :167, :193 and the two first PGD passes (the reference draws four times; masks are random either way).
+    then serves :167, :193 and the SE loop's first pass, where the reference draws three masks — so seg_train_step only
+    asks for pgd0 when no Dropout with p > 0 is active (seg_attack_algo._dropout_active); with p = 0 the passes are identical.
     BatchNorm: SE .. SD point two updates now (:167 and the SE loop's first pass) + :193 deferred; after the SD point one
     now (SE loop's first pass), one at `replay_sd_pgd0_bn()` (decoder loop's first pass), one at `replay_deferred_bn()`.
     Channels-last kernels only (the repeat count is a feature of those launches)."""

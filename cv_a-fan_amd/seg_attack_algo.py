@@ -103,6 +103,14 @@ def adv_input(x=None, criterion=None, y=None, model=None, steps=3, eps=None, gam
     return x_adv.requires_grad_(True)
 
 
+def _dropout_active(model):
+    """A training-mode nn.Dropout with p > 0 (and no caller-supplied mask pending) anywhere in `model`."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout) and m.training and m.p > 0 and getattr(m, "mask", None) is None:
+            return True
+    return False
+
+
 def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                    pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
                    clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None):
@@ -125,7 +133,12 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     # of BOTH PGD loops is the clean forward too — same logits, same cross-entropy, same input gradient (sign() ignores
     # the joint loss's 0.7) — so the clean loss is back-propagated through the tail right away and the loops start at
     # their second pass.  Not with dual_bn (the PGD passes then normalise with the other BatchNorm set).
-    pgd0 = fold and steps >= 1 and not randinit and not dual_bn and not clip
+    # ... and not while a Dropout with p > 0 is active in the folded region: the reference draws a fresh mask in every
+    # model(...) call (_deeplab.py:185: the decoder-PGD input pass :167, the clean forward :193 and every SE-PGD pass run
+    # ASPP's dropout), so those passes are NOT the same function of the same point and sharing one pass would share one
+    # mask.  The clean fold alone keeps the reference's process: :167 and :193 each apply their own draw to the one
+    # pre-dropout ASPP output (K + 4 draws per iteration either way: tests/test_deeplab_gpu.py).
+    pgd0 = fold and steps >= 1 and not randinit and not dual_bn and not clip and not _dropout_active(model)
     pgd0 = pgd0 if fold_pgd0 is None else (bool(fold_pgd0) and pgd0)
     g_se = g_sd = l0 = None
     wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
@@ -205,4 +218,5 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     if not defer_step:          # (data-parallel callers all-reduce the gradient arena first: seg_trainer.SegTrainer)
         optimizer.step()
     return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
-            "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach()}
+            "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach(),
+            "fold_clean": bool(fold), "fold_pgd0": bool(pgd0)}          # (which schedule ran: bench.py reports it)

@@ -166,6 +166,93 @@ def test_deeplab_graph_replay_equals_eager(pkg, gpu):
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("case", ["seg_dl101_aspp_k1", "seg_dl101_concat_k3"])
+def test_deeplab_dropout_draws_per_iteration_equal_the_reference(pkg, gpu, case):
+    """The reference draws a fresh ASPP-dropout mask in every model(...) call that runs ASPP (_deeplab.py:185): the decoder-PGD
+    input pass (main_aug_final.py:167), each of the K SE-PGD passes (attack_algo.py:50), the clean forward (:193) and the two
+    perturbed SE forwards (:197-203) — K + 4 draws per iteration; the SD passes start behind ASPP and draw nothing.  With
+    p > 0 the step must keep that count under every schedule (the first PGD passes may NOT be folded into the clean pass:
+    they would share its mask); with p = 0 the folded schedule is value-identical and is taken."""
+    g = golden(case)
+    K = int(g["meta"][0])
+    images, labels = torch.from_numpy(g["images"]).to(gpu), torch.from_numpy(g["labels"]).to(gpu)
+    real = pkg.ops.dropout
+    for p_drop, fold in ((0.1, None), (0.1, False), (0.0, None)):
+        model, tr = _build(pkg, g, torch.bfloat16, True, gpu, use_graph=False, fold_clean=fold)
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = p_drop
+        draws = [0]
+
+        def counting(x, p, mask=None, used=None):
+            if used is None:
+                draws[0] += 1
+            return real(x, p, mask, used)
+        pkg.ops.dropout = counting
+        try:
+            r = tr.step(images, labels)
+        finally:
+            pkg.ops.dropout = real
+        if p_drop > 0:
+            assert draws[0] == K + 4, (p_drop, fold, draws[0])
+            assert r["fold_pgd0"] is False and r["fold_clean"] is (fold is None)
+        else:
+            assert draws[0] == 0 and r["fold_pgd0"] is True
+        assert np.isfinite(float(r["loss"]))
+
+
+def test_deeplab_full_size_properties(pkg, gpu):
+    """BASELINE configs[3]'s per-GPU share at FULL size (DeepLabv3+ ResNet-101, 2 x 3 x 513 x 513, output stride 16, SE point
+    layer3 = 1024 x 33 x 33, SD point aspp, K = 3, the reference's Dropout(0.1)) on the product path: size-independent
+    properties of the iteration, and the hipGraph replay against eager launches from the same seed."""
+    K, eps = 3, 2.0
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(2, 3, 513, 513, generator=g).to(gpu)
+    labels = torch.randint(0, 21, (2, 513, 513), generator=g)
+    labels[torch.rand(2, 513, 513, generator=g) < 0.05] = 255
+    labels = labels.to(gpu)
+    out = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(3)
+        model = pkg.deeplab.deeplabv3plus_resnet101(num_classes=21, output_stride=16)
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0 if mode != "dropout" else 0.1
+        model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+        tr = pkg.seg_trainer.SegTrainer(model, steps=K, eps=eps, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp",
+                                        mix_layer="11", mix_sd=True, lr=0.01, use_graph=(mode == "graph"), graph_warmup=1)
+        assert not pkg.resnet_s.general_convs(model)
+        before = dict(pkg.ops.CALLS)
+        losses = []
+        for _ in range(3):
+            r = tr.step(images, labels)
+            tr.scheduler.step()
+            losses.append(float(r["loss"]))
+        if mode == "graph":
+            assert tr._graph is not None, tr._graph_failed
+        assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_general"] == before["conv_general"]
+        assert all(np.isfinite(v) for v in losses)
+        fm, adv = r["fm_se"].float(), r["adv_se"].float()
+        assert fm.shape == (2, 1024, 33, 33) and r["fm_sd"].shape == (2, 256, 33, 33)
+        gam = np.float32(0.5 / 255)
+        k = ((adv - fm) / gam).round()
+        assert float(((adv - fm) / gam - k).abs().max()) < 2e-2 and float(k.abs().max()) <= K          # SE perturbation on the sign grid
+        lw = r["losses"].float().cpu().numpy()
+        assert abs(float(r["loss"]) - float(0.7 * lw[0] + 0.1 * (lw[1] + lw[2] + lw[3]))) < 1e-4        # main_aug_final.py:216
+        # BatchNorm updates per iteration, in the reference's count: stem .. SE point 3 (:166, :167, :193); layer4 / ASPP
+        # 2 + K + 2 (:167, :193, K SE-PGD passes, SE1, SE2); the decoder's 3x3 1 + 2K + 3 (:193, both PGD loops, three forwards)
+        n_it = 3
+        assert int(model.backbone.bn1.num_batches_tracked) == 3 * n_it
+        assert int(model.backbone.layer3[22].bn3.num_batches_tracked) == 3 * n_it
+        assert int(model.backbone.layer4[0].bn1.num_batches_tracked) == (K + 4) * n_it
+        assert int(model.classifier.aspp.project[1].num_batches_tracked) == (K + 4) * n_it
+        assert int(model.classifier.classifier[1].num_batches_tracked) == (2 * K + 4) * n_it
+        for name, buf in model.named_buffers():
+            assert torch.isfinite(buf.float()).all(), name
+        out[mode] = losses
+    np.testing.assert_allclose(out["graph"], out["eager"], rtol=0, atol=5e-3)
+
+
 def test_deeplab_checkpoint_interchange(pkg, orc, gpu):
     """state_dict round trip with the reference layout (oracle.SegDeepLabV3Plus has the reference's keys, verified against
     the reference's own network by tests/test_oracle_golden.py) and the two-group optimizer state_dict layout."""

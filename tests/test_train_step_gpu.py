@@ -677,6 +677,46 @@ def test_product_step_full_size_properties(pkg, orc, gpu):
     assert torch.isfinite(tr.arena.param).all() and float(tr.arena.momentum_buf.abs().max()) > 0
 
 
+def test_resnet50_full_size_properties(pkg, orc, gpu):
+    """BASELINE configs[2]'s per-GPU share at full size (ResNet-50, 64 x 3 x 224 x 224, K = 3, perturbation after layer1:
+    256 x 56 x 56) on the product path: size-independent properties of the iteration, eager and replayed from the hipGraph."""
+    K, gamma, B = 3, 0.5, 64
+    torch.manual_seed(3)
+    m = pkg.resnet_s.ARCHS["resnet50"][0]()
+    m.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+    idx = pkg.resnet_s.ARCHS["resnet50"][1]
+    tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=K, gamma=gamma, eps=2.0, perturb_idx=idx, lr=0.01)
+    assert not pkg.resnet_s.general_convs(m) and not pkg.resnet_s.vendor_convs(m)
+    torch.manual_seed(0)
+    x, y = torch.rand(B, 3, 224, 224, device=gpu), torch.randint(0, 1000, (B,), device=gpu)
+    calls = dict(pkg.ops.CALLS)
+    losses, n_steps = [], 5
+    for _ in range(n_steps):
+        r = tr.step(x, y)
+        losses.append(float(r["loss"]))
+    assert tr._graph is not None, tr._graph_failed
+    # every convolution on the tuned bf16 kernels (general_convs(m) == [] above); the 1000-class nn.Linear of the classifier
+    # head runs as a 1x1 problem on the general f32-MFMA kernel (no vendor GEMM): the only conv_general calls of the step
+    assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_fwd"] > calls["conv_fwd"]
+    assert all(np.isfinite(v) for v in losses)
+    fm, xa = r["feature_map"].float(), r["x_adv"].float()
+    assert fm.shape == (B, 256, 56, 56)
+    k = ((xa - fm) / np.float32(gamma / 255)).round()
+    assert float(((xa - fm) / np.float32(gamma / 255) - k).abs().max()) < 2e-2 and float(k.abs().max()) <= K     # the sign grid
+    assert float((k % 2 == 0).float().mean()) < 1e-2          # odd multiples unless a gradient was exactly zero at a step
+    d = (xa - fm).reshape(B, -1)
+    np.testing.assert_allclose(r["l2"].cpu().numpy(), d.double().norm(dim=1).float().cpu().numpy(), rtol=1e-5)
+    assert torch.equal(r["linf"], d.abs().amax(dim=1))
+    assert abs(float(r["loss"]) - 0.5 * (float(r["loss_adv"]) + float(r["loss_clean"]))) < 1e-5 * max(1.0, float(r["loss"]))
+    seq = m.sequential_model
+    assert int(seq[2].num_batches_tracked) == 2 * n_steps                     # stem BatchNorm: the head's two passes
+    assert int(seq[idx - 1].bn3.num_batches_tracked) == 2 * n_steps           # last head block
+    assert int(seq[idx].bn1.num_batches_tracked) == (K + 2) * n_steps         # first tail block: K PGD passes + adv + clean
+    for name, buf in m.named_buffers():
+        assert torch.isfinite(buf.float()).all(), name
+    assert torch.isfinite(tr.arena.param).all()
+
+
 @pytest.mark.parametrize("arch,idx", [("resnet20s", 7), ("resnet18", 6)])
 @pytest.mark.parametrize("dtype,clip", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
 def test_folded_clean_pass_equals_reference_schedule(pkg, orc, gpu, arch, idx, dtype, clip):
