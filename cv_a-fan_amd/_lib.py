@@ -63,9 +63,6 @@ SIGNATURES = {
     "afan_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _i, _p]),
     "afan_conv_wgrad_f32_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i, _i, _i]),
     "afan_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _i, _p, _i, _p]),
-    "afan_pack_weights_elems": (_l, [_l, _l, _l]),
-    "afan_pack_weights": (_i, [_p, _p, _l, _l, _l, _p]),
-    "afan_conv_fwd_breg_exp": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p]),
     "afan_conv_stem7_supported": (_i, [_l, _l, _i, _i]),
     "afan_conv_stem7_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "afan_conv_stem7_im2col_k": (_i, []),

@@ -29,15 +29,6 @@ template <typename T, int VEC> struct LdV {
         if constexpr (VEC == 1) v[0] = Elt<T>::ld(p); else Elt<T>::ldv(p, v);
     }
     __device__ static __forceinline__ void st(T* p, const float (&v)[VEC]) {
-#if AFAN_STREAM_STORES
-        if constexpr (VEC == 8 && sizeof(T) == 2) {       // streaming (nontemporal) stores: see afan_common.h
-            u16x8 t;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = f2bf(v[i]);
-            __builtin_nontemporal_store(t, reinterpret_cast<u16x8*>(p));
-            return;
-        }
-#endif
         if constexpr (VEC == 1) Elt<T>::st(p, v[0]); else Elt<T>::stv(p, v);
     }
 };

@@ -21,15 +21,6 @@ __device__ __forceinline__ float bf2f(uint16_t u) {
     return __builtin_bit_cast(float, ((uint32_t)u) << 16);
 }
 
-// Experiment kept as a compile-time switch (default off): store activation-sized outputs (convolution tiles, BatchNorm apply
-// passes) with the nontemporal hint.  A kernel's dirty L2 lines are written back when it ends (the eight XCD L2s are not
-// coherent with each other), and that drain — ~2.5 TB/s measured, 6 us for the 16.8 MB output of a 16x16-stage convolution
-// — is part of the kernel's time; streaming stores leave earlier (that epilogue alone: 8.6 -> 7.3 us) but the consumer then
-// finds nothing in L2.  A-B-B-A on one box: ResNet-18 step 9.613 -> 9.558 ms (-0.6 %), DeepLab (batch 2: tensors that fit
-// the L2s) 33.73 -> 34.14 ms (+1.2 %).  Not worth a per-launch policy.
-#ifndef AFAN_STREAM_STORES
-#define AFAN_STREAM_STORES 0
-#endif
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {

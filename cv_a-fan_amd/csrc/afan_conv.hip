@@ -19,15 +19,14 @@
 // remain as A/B references (AFAN_CONV_MODE).  The epilogue rounds to bf16 through LDS so that every store is a 16-byte
 // piece of a channels-last row, and carries the optional fusions (addend, BatchNorm sums per image group).
 // Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64.
+// (Measured-and-lost variants — 256-row tiles, producer waves on the two-stage launches, a half-step software pipeline,
+// streaming stores, register-streamed weights — are described in DESIGN.md 9.5 and no longer compiled in.)
 #include "afan_common.h"
 #include "afan_conv_c64.h"
 #include "afan_conv_stem.h"
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
-#ifndef AFAN_CONV_PIPE
-#define AFAN_CONV_PIPE 0          // 1: half-step software pipeline in the MFMA waves of the producer-wave kernels (measured: no gain)
-#endif
 #ifndef AFAN_CONV_FRAG_BATCH
 #define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
 #endif
@@ -246,36 +245,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
         }
     };
 
-    // Half-step software pipeline of the MFMA waves (producer-wave kernels): a K-step's four k16-slices are read as two
-    // halves; the first half of the NEXT tile is requested (right after that tile's barrier) before the MFMAs of this
-    // tile's second half, and the second half before the MFMAs of the first — every LDS latency sits behind eight
-    // (or four) MFMAs of the wave itself instead of behind the barrier.  MFMA order per accumulator is unchanged.
-    constexpr int HS = BK / 32;                          // k16-slices per half
-    auto load_half = [&](int buf, int h, bf16x8 (&fx)[HS][MI], bf16x8 (&fw)[HS][NI]) {
-        const uint16_t* A = lds + buf * STAGE;
-        const uint16_t* B = A + BM * LDR;
-        const int frow = lane & 31, sw = (frow >> 1) & 7;
-#pragma unroll
-        for (int b = 0; b < HS; ++b) {
-            const int koff = ((((h * HS + b) * 2 + (lane >> 5)) ^ sw) * 8);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                fx[b][i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
-        }
-    };
-    auto mma_half = [&](const bf16x8 (&fx)[HS][MI], const bf16x8 (&fw)[HS][NI]) {
-#pragma unroll
-        for (int b = 0; b < HS; ++b)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
-    };
-    (void)load_half; (void)mma_half;                     // (only the AFAN_CONV_PIPE build uses them)
 
     // LDS-DMA issue of one K-step into buffer `buf`: A_ROWS + B_ROWS wave instructions, each 64 lanes x 16 B = 1 KiB of
     // consecutive LDS; padding rows read the zero page
@@ -376,33 +345,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
 #ifdef AFAN_CONV_PRIO
             __builtin_amdgcn_s_setprio(AFAN_CONV_PRIO);
 #endif
-#if AFAN_CONV_PIPE && !AFAN_CONV_ABLATE
-            if (KS > 0) {
-                bf16x8 ax[HS][MI], aw[HS][NI], bx[HS][MI], bw[HS][NI];
-                __builtin_amdgcn_s_barrier();                              // tile 0 has landed
-                load_half(0, 0, ax, aw);
-                int buf = 0;
-                for (int ks = 0; ks < KS; ++ks) {
-                    load_half(buf, 1, bx, bw);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_half(ax, aw);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int nbuf = buf + 1 == NS ? 0 : buf + 1;
-                    // lgkmcnt(0): every read of tile ks has returned.  Outside the `if`: on the joined path the compiler
-                    // must know that the second half's registers are complete, or it waits for the NEXT tile's reads
-                    // before this tile's MFMAs (it did: lgkmcnt(5) .. (0) in front of them).
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    if (ks + 1 < KS) {
-                        __builtin_amdgcn_s_barrier();                      // tile ks+1 has landed; tile ks's buffer is free
-                        load_half(nbuf, 0, ax, aw);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    mma_half(bx, bw);
-                    __builtin_amdgcn_sched_barrier(0);
-                    buf = nbuf;
-                }
-            }
-#else
             int buf = 0;
             for (int ks = 0; ks < KS; ++ks) {
 #if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
@@ -411,7 +353,6 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
                 compute(buf);
                 buf = buf + 1 == NS ? 0 : buf + 1;
             }
-#endif
         }
         __syncthreads();
         }
@@ -570,11 +511,7 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
             }
-#if AFAN_STREAM_STORES
-            __builtin_nontemporal_store(v, reinterpret_cast<u16x8*>(pp.y + go));
-#else
             *reinterpret_cast<u16x8*>(pp.y + go) = v;
-#endif
             if (bn_bwd) {
                 const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
                 u16x8 yv = xv;
@@ -677,11 +614,6 @@ int choose_bm(int64_t M, int co, int n_classes) {
     const bool n128 = (co % 128 == 0);
     const int64_t wg_128 = ((M + 127) / 128) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
     static const int thr = env_int("AFAN_CONV_THR128", 256);   // (256 vs 384: +0.3 % of the step)
-    // 385..512 workgroups of 128 rows would sit two per CU on the two-stage pipeline: 256-row tiles (8 MFMA waves + 4
-    // DMA waves, three 48 KB stages) bring the launch to one workgroup per CU with a quarter less operand traffic.
-    // M % 512: whole tiles, also for each half of a two-group launch.
-    static const int tall256 = env_int("AFAN_CONV_TALL256", 0);   // measured: 29.4 vs 28.0 us in isolation, 9.98 vs 9.76 ms on the step — off
-    if (tall256 && n128 && n_classes == 1 && M % 512 == 0 && wg_128 > 384 && wg_128 <= 512) return 256;
     if (wg_128 >= thr) return 128;
     // 385..768 workgroups of 64 rows (the 8x8 stage) would be two per CU on the two-stage pipeline; 128-row tiles bring
     // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
@@ -699,7 +631,6 @@ int dispatch(const ConvP& p, hipStream_t st) {
     static const int nw = env_int("AFAN_CONV_NW", 8);          // waves per workgroup where the tile allows it
     const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
     const bool n128 = p.Co % 128 == 0;
-    if (bm == 256) return launch<256, 128, 4, 4, 2, 4>(p, st);      // (only with Co % 128 == 0: choose_bm)
     // launches of about one workgroup per CU (8x8 / 4x4 stages): deep DMA pipeline (3 or 4 LDS stages, counted vmcnt)
     // In the training step every layer's weights are cold (44 MB of bf16 weights cycle through a 32 MB L2 between two
     // uses), so each K-step's weight tile is a first-touch miss that all row tiles of the launch wait for together:
@@ -715,8 +646,6 @@ int dispatch(const ConvP& p, hipStream_t st) {
         if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
     }
     if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
-    static const int spec2 = env_int("AFAN_CONV_SPEC2", 0);  // producer waves on the two-stage launches too (measured: no gain)
-    if (mode == 3 && nw >= 8 && n128 && spec2) return bm == 128 ? launch<128, 128, 3, 2, 2, 4, 2>(p, st) : launch<64, 128, 3, 2, 2, 4, 2>(p, st);
     if (mode == 3 && nw >= 8) {
         if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st) : launch<64, 128, 3, 2, 4>(p, st);
         if (bm == 128) return launch<128, 64, 3, 4, 2>(p, st);

@@ -315,15 +315,6 @@ int afan_conv_wgrad(const void* x, const void* dy, float* grad, int dtype, int l
                     int64_t wi, int64_t ci, int64_t co, int k, int stride, int pad, int dilation, float* workspace,
                     int accumulate, afan_stream_t stream);
 
-/* Fragment-major packed copy of a convolution weight tensor w[rows][taps][red] (bf16; KRSC for the forward, CRSK for the
- * input gradient): packed[row / 32][tap * ceil(red/64) + q][kk][lane][8] = the MFMA 32x32x16 operand of lane `lane` — what the
- * register-streamed-weights variant of the convolution reads with fully coalesced 1-KiB requests (afan_conv_breg.hip).
- * afan_conv_fwd_breg_exp is the measurement entry of that variant (stride 1, Ci % 64 == 0, Co % 128 == 0, no fusions). */
-int64_t afan_pack_weights_elems(int64_t rows, int64_t taps, int64_t red);
-int afan_pack_weights(const void* w, void* packed, int64_t rows, int64_t taps, int64_t red, afan_stream_t stream);
-int afan_conv_fwd_breg_exp(const void* x, const void* wp, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
-                           int variant, afan_stream_t stream);
-
 /* The ImageNet-style image stem of the DeepLabv3+ / ResNet-50/101 backbones (Segmentation/network/backbone/resnet.py:143-144
  * `conv1`: 7x7, stride 2, padding 3, 3 -> 64 channels): forward and weight gradient, bf16 channels-last.
  * x[N,Hi,Wi,3], w[64,7,7,3] (KRSC), y / dy[N,Ho,Wo,64], Ho = (Hi-1)/2+1; grad fp32 [64,7,7,3] written or added into.

@@ -7,7 +7,7 @@ TAG=${1:-x}; shift
 ARGS="$@"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 python bench.py $ARGS $([ "$NOCPU" = 1 ] && echo --no_cpu_baseline) 2>&1 | grep "^{" > gpurun_out/${TAG}_bench.json
 python3 -c "
 import json;d=json.load(open('gpurun_out/${TAG}_bench.json'));print({k:d[k] for k in ('value','ms_per_step')}, d['roofline'] and {k:d['roofline'][k] for k in ('kernel','achieved','frac')}, d.get('conv_mfma'), d.get('cpu_baseline') and d['cpu_baseline']['value'])"
