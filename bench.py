@@ -46,6 +46,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0
 REF_GFLOP_PER_IMAGE = {("resnet18", 5): 14.1, ("resnet56s", 5): 2.99, ("resnet50", 3): 85.5}
 ARCH_INPUT = {"resnet50": (224, 1000)}                                        # (image side, classes); default (32, 10)
 SEG_ARCHS = ("deeplabv3plus_resnet101", "deeplabv3plus_resnet50")
+DET_ARCHS = ("fasterrcnn_resnet101",)
 HBM_KERNELS = ("pgd_step_kernel", "pgd_step_norms_kernel", "mix_feature_nhwc_kernel", "mix_feature_kernel", "lerp_points_kernel",
                "sgd_kernel", "cast_bf16_kernel", "upsample_bilinear_fwd_kernel", "upsample_bilinear_bwd_kernel", "ce2d_kernel",
                "maxpool_fwd_kernel", "maxpool_bwd_kernel", "bn_nhwc_apply_kernel", "bn_nhwc_bwd_apply_kernel")
@@ -186,8 +187,11 @@ def main():
     import torch.nn as nn
     pkg = importlib.import_module("cv_a-fan_amd")
     seg = args.arch in SEG_ARCHS
+    det = args.arch in DET_ARCHS
+    if det:
+        args.no_cpu_baseline = True           # (no CPU restatement of Faster-RCNN travels: the goldens come from the reference itself)
     if args.batch is None:
-        args.batch = 2 if seg else 256
+        args.batch = 2 if seg else (1 if det else 256)
     if args.pgd_steps is None:
         args.pgd_steps = 3 if seg else 5
     if args.side is None:
@@ -215,7 +219,48 @@ def main():
     g = torch.Generator().manual_seed(3 + rank)          # each rank its own shard of the synthetic stream
     nbuf = 4
     idx = None
-    if seg:
+    if det:
+        # BASELINE configs[4]: Faster-RCNN / ResNet-101, multi-layer SAT feature perturbation (train_aug_sat_muti_advt.py:70-172),
+        # VOC-shape images (config/config.py: min side 600, max side 1000), 21 classes, one image per GPU (config/train_config.py)
+        model = pkg.det_model.fasterrcnn_resnet101(21, pooler_mode="align")
+        model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
+        arena = pkg.arena.ParamArena(model, skip=())
+        opt = pkg.arena.ArenaSGD(arena, lr=0.001, momentum=0.9, weight_decay=0.0005)
+        if world > 1:       # data parallel like the reference's nn.DataParallel (train_aug_sat_muti_advt.py:36): replicas from rank 0,
+            for t in (arena.param, arena.momentum_buf):     # one SUM all-reduce of the flat gradient arena before the SGD launch
+                dist.broadcast(t, src=0)
+            for b_ in model.buffers():
+                dist.broadcast(b_, src=0)
+            arena.refresh_shadow()
+            opt.grad_scale = 1.0 / world
+            _plain_step = opt.step
+
+            def _step_with_exchange(closure=None):
+                dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM)
+                return _plain_step()
+            opt.step = _step_with_exchange
+        side, ncls = (600, 904), 21
+        xs, ys = [], []
+        for _ in range(nbuf):
+            xs.append(torch.rand(args.batch, 3, side[0], side[1], generator=g).to(dev))
+            x0 = torch.rand(args.batch, 6, 1, generator=g) * (side[1] - 260)
+            y0 = torch.rand(args.batch, 6, 1, generator=g) * (side[0] - 260)
+            wh = 60 + torch.rand(args.batch, 6, 2, generator=g) * 200
+            ys.append((torch.cat([x0, y0, x0 + wh[..., :1], y0 + wh[..., 1:]], dim=-1).to(dev),
+                       torch.randint(1, 21, (args.batch, 6), generator=g).to(dev)))
+
+        class _DetTrainer:
+            _graph = None
+
+            def step(self, images, target):
+                return pkg.det_attack_algo.det_train_step(model, opt, images, target[0], target[1], loss_settings=1)
+        trainer = _DetTrainer()
+
+        def one(i):
+            return trainer.step(xs[i % nbuf], ys[i % nbuf])
+
+        one_eager = one
+    elif seg:
         model = pkg.deeplab.MODELS[args.arch](num_classes=21, output_stride=16)
         model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
         trainer = pkg.seg_trainer.SegTrainer(model, nn.CrossEntropyLoss(ignore_index=255, reduction="mean"), steps=args.pgd_steps,
@@ -359,7 +404,13 @@ def main():
     if rank == 0:
         ips = args.batch * world * args.steps / dt
         default_cfg = args.arch == "resnet18" and args.pgd_steps == 5
-        if seg:
+        if det:
+            metric = f"images/sec (whole node) Detection multi-layer SAT A-FAN train step, {args.arch} {side[0]}x{side[1]}"
+            workload = (f"{args.arch} (frozen-BatchNorm ResNet-101, RPN 9 anchors, ROIAlign pooler), VOC-shape {side[0]}x{side[1]} synthetic, "
+                        f"image PGD 5 steps + 3 one-step feature PGDs + ROI-feature PGD, 5 SAT points, {args.dtype}, batch {args.batch}/GPU, "
+                        f"internal layout {args.layout} (BASELINE configs[4], per-GPU share)")
+            sched = "train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling); eager launches"
+        elif seg:
             metric = f"images/sec (whole node) Segmentation A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}"
             workload = (f"{args.arch} output-stride 16, VOC-shape {side}x{side} synthetic, SE (layer3) + SD (aspp) feature PGD K="
                         f"{args.pgd_steps}, mix_feature 11 + mix_sd, {args.dtype}, batch {args.batch}/GPU, internal layout "
@@ -393,7 +444,7 @@ def main():
         if args.dual_bn:
             workload += ", dual-BN option ON (not the reference's arithmetic)"
         line = {
-            "metric": metric, "value": round(ips, 2 if seg else 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "metric": metric, "value": round(ips, 2 if (seg or det) else 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": args.batch * world, "parallelism": f"dp{world}",

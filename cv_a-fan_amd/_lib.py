@@ -75,6 +75,9 @@ SIGNATURES = {
     "afan_ce2d": (_i, [_p, _p, _i, _l, _l, _l, _l, _f, _p, _p, _p, _p]),
     "afan_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _p]),
     "afan_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _p]),
+    "afan_maxpool2d_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _i, _p]),
+    "afan_maxpool2d_bwd": (_i, [_p, _p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _i, _p]),
+    "afan_affine_relu_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_avgpool_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_avgpool_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_linear_small_max_rows": (_i, []),

@@ -233,17 +233,22 @@ __global__ __launch_bounds__(BLOCK) void ce2d_finalize_kernel(const float* ws, i
     if (threadIdx.x == 0) loss[0] = s / ws[0];
 }
 
-// ---- 3x3 / stride 2 / pad 1 max pooling --------------------------------------------------------------------------------
+// ---- max pooling: k x k windows, stride s, padding p (3/2/1: backbone/resnet.py:146; 2/2/0 and the global one: Detection/
+// roi/pooler.py:43, model.py:285) -------------------------------------------------------------------------------------------
 // first maximum in (h, w) scan order, NaN wins (ATen's CPU kernel: `val > maxval || isnan(val)`), so that the backward
-// routes the gradient to the same element the reference's does — post-ReLU windows tie at 0 all the time.
+// routes the gradient to the same element the reference's does — post-ReLU windows tie at 0 all the time.  The forward can
+// leave the winner's position inside its window (r * k + s, one byte per output element); the backward then reads
+// (gradient, position) of the at most ceil(k/s)^2 windows over an input pixel instead of re-scanning k*k inputs for each.
+struct PoolGeo { int K, S, P; };
+
 template <typename T, int VEC, bool NHWC>
 __device__ __forceinline__ void pool_window(const T* __restrict__ x, int64_t n, int cv, int C, int Hi, int Wi, int oy,
-                                            int ox, float (&best)[VEC], int (&arg)[VEC]) {
-    const int h0 = oy * 2 - 1, w0 = ox * 2 - 1;
+                                            int ox, PoolGeo g, float (&best)[VEC], int (&arg)[VEC]) {
+    const int h0 = oy * g.S - g.P, w0 = ox * g.S - g.P;
     const int hs = h0 < 0 ? 0 : h0, ws = w0 < 0 ? 0 : w0;
-    const int he = h0 + 3 > Hi ? Hi : h0 + 3, we = w0 + 3 > Wi ? Wi : w0 + 3;
+    const int he = h0 + g.K > Hi ? Hi : h0 + g.K, we = w0 + g.K > Wi ? Wi : w0 + g.K;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; arg[k] = hs * Wi + ws; }
+    for (int k = 0; k < VEC; ++k) { best[k] = -INFINITY; arg[k] = (hs - h0) * g.K + (ws - w0); }
     for (int h = hs; h < he; ++h)
         for (int w = ws; w < we; ++w) {
             float v[VEC];
@@ -256,13 +261,13 @@ __device__ __forceinline__ void pool_window(const T* __restrict__ x, int64_t n, 
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
-                if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; arg[k] = h * Wi + w; }
+                if (v[k] > best[k] || v[k] != v[k]) { best[k] = v[k]; arg[k] = (h - h0) * g.K + (w - w0); }
         }
 }
 
 template <typename T, int VEC, bool NHWC>
-__global__ __launch_bounds__(BLOCK) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int C, int Hi, int Wi,
-                                                            int Ho, int Wo, int64_t total) {
+__global__ __launch_bounds__(BLOCK) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                            int C, int Hi, int Wi, int Ho, int Wo, PoolGeo g, int64_t total) {
     const int CV = C / VEC;
     for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
         int64_t t = v;
@@ -272,22 +277,28 @@ __global__ __launch_bounds__(BLOCK) void maxpool_fwd_kernel(const T* __restrict_
         else { ox = (int)(t % Wo); t /= Wo; oy = (int)(t % Ho); t /= Ho; cv = (int)(t % CV); n = t / CV; }
         float best[VEC];
         int arg[VEC];
-        pool_window<T, VEC, NHWC>(x, n, cv, C, Hi, Wi, oy, ox, best, arg);
+        pool_window<T, VEC, NHWC>(x, n, cv, C, Hi, Wi, oy, ox, g, best, arg);
         if constexpr (NHWC) {
-            T* dst = y + ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC;
-            if constexpr (VEC == 1) Elt<T>::st(dst, best[0]);
-            else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(best));
+            const int64_t o = ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC;
+            if constexpr (VEC == 1) Elt<T>::st(y + o, best[0]);
+            else Elt<T>::stv(y + o, reinterpret_cast<const float(&)[Elt<T>::VEC]>(best));
+            if (idx) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) idx[o + k] = (uint8_t)arg[k];
+            }
         } else {
             Elt<T>::st(y + v, best[0]);
+            if (idx) idx[v] = (uint8_t)arg[0];
         }
     }
 }
 
-// gather: one thread = one input pixel x VEC channels; the (at most 2 x 2) windows that contain it are re-scanned
+// gather: one thread = one input pixel x VEC channels; every window that contains it contributes its gradient if this
+// pixel won it (position byte from the forward, or — without it — the window re-scanned)
 template <typename T, int VEC, bool NHWC>
 __global__ __launch_bounds__(BLOCK) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            T* __restrict__ dx, int C, int Hi, int Wi, int Ho, int Wo,
-                                                            int64_t total) {
+                                                            const uint8_t* __restrict__ idx, T* __restrict__ dx, int C, int Hi,
+                                                            int Wi, int Ho, int Wo, PoolGeo g, int64_t total) {
     const int CV = C / VEC;
     for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
         int64_t t = v;
@@ -298,27 +309,31 @@ __global__ __launch_bounds__(BLOCK) void maxpool_bwd_kernel(const T* __restrict_
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        // windows oy with 2*oy - 1 <= iy <= 2*oy + 1
-        const int oy0 = iy / 2, oy1 = (iy + 1) / 2, ox0 = ix / 2, ox1 = (ix + 1) / 2;
-        const int me = iy * Wi + ix;
+        // windows oy with oy*S - P <= iy <= oy*S - P + K - 1
+        const int ty = iy + g.P - g.K + 1, tx = ix + g.P - g.K + 1;
+        const int oy0 = ty <= 0 ? 0 : (ty + g.S - 1) / g.S, oy1 = (iy + g.P) / g.S;
+        const int ox0 = tx <= 0 ? 0 : (tx + g.S - 1) / g.S, ox1 = (ix + g.P) / g.S;
         for (int oy = oy0; oy <= oy1; ++oy) {
             if (oy >= Ho) continue;
             for (int ox = ox0; ox <= ox1; ++ox) {
                 if (ox >= Wo) continue;
-                float best[VEC];
+                const int me = (iy - (oy * g.S - g.P)) * g.K + (ix - (ox * g.S - g.P));
                 int arg[VEC];
-                pool_window<T, VEC, NHWC>(x, n, cv, C, Hi, Wi, oy, ox, best, arg);
-                float g[VEC];
-                if constexpr (NHWC) {
-                    const T* src = dy + ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC;
-                    if constexpr (VEC == 1) g[0] = Elt<T>::ld(src);
-                    else Elt<T>::ldv(src, reinterpret_cast<float(&)[Elt<T>::VEC]>(g));
+                const int64_t o = NHWC ? ((n * Ho + oy) * (int64_t)Wo + ox) * C + cv * VEC
+                                       : ((n * C + cv) * (int64_t)Ho + oy) * Wo + ox;
+                if (idx) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) arg[k] = idx[o + k];
                 } else {
-                    g[0] = Elt<T>::ld(dy + ((n * C + cv) * (int64_t)Ho + oy) * Wo + ox);
+                    float best[VEC];
+                    pool_window<T, VEC, NHWC>(x, n, cv, C, Hi, Wi, oy, ox, g, best, arg);
                 }
+                float gr[VEC];
+                if constexpr (VEC == 1) gr[0] = Elt<T>::ld(dy + o);
+                else Elt<T>::ldv(dy + o, reinterpret_cast<float(&)[Elt<T>::VEC]>(gr));
 #pragma unroll
                 for (int k = 0; k < VEC; ++k)
-                    if (arg[k] == me) acc[k] += g[k];
+                    if (arg[k] == me) acc[k] += gr[k];
             }
         }
         if constexpr (NHWC) {
@@ -650,6 +665,40 @@ int vec_for(int64_t c, std::initializer_list<const void*> ptrs) {
 
 }  // namespace
 
+// ---- backward of y = [relu](x * alpha[c] + beta[c] [+ res]) with CONSTANT per-channel coefficients: a frozen BatchNorm
+// (Detection/model.py:27-35,46-47: eval mode, no parameter gradients) or a convolution's bias (+ ReLU) (rpn/
+// region_proposal_network.py:19-22): g = relu-masked dy (mask from the stored y), dx = g * alpha[c], d_res = g.
+template <typename T, int VEC, bool NHWC>
+__global__ __launch_bounds__(BLOCK) void affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                           const float* __restrict__ alpha, T* __restrict__ dx, T* __restrict__ dres,
+                                                           int C, int64_t HW, int relu, int64_t total) {
+    const int CV = C / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
+        const int c0 = NHWC ? (int)(v % CV) * VEC : (int)((v / HW) % C);
+        float g[VEC], o[VEC];
+        if constexpr (VEC == 1) g[0] = Elt<T>::ld(dy + v);
+        else Elt<T>::ldv(dy + v * VEC, reinterpret_cast<float(&)[Elt<T>::VEC]>(g));
+        if (relu) {
+            if constexpr (VEC == 1) o[0] = Elt<T>::ld(y + v);
+            else Elt<T>::ldv(y + v * VEC, reinterpret_cast<float(&)[Elt<T>::VEC]>(o));
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) g[k] = (o[k] > 0.f) ? g[k] : 0.f;
+        }
+        if (dres) {
+            if constexpr (VEC == 1) Elt<T>::st(dres + v, g[0]);
+            else Elt<T>::stv(dres + v * VEC, reinterpret_cast<const float(&)[Elt<T>::VEC]>(g));
+        }
+        if (dx) {
+            if (alpha) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) g[k] *= alpha[c0 + k];
+            }
+            if constexpr (VEC == 1) Elt<T>::st(dx + v, g[0]);
+            else Elt<T>::stv(dx + v * VEC, reinterpret_cast<const float(&)[Elt<T>::VEC]>(g));
+        }
+    }
+}
+
 extern "C" {
 
 #define AFAN_SEG_DISPATCH(KERNEL, ...)                                                                                   \
@@ -748,40 +797,73 @@ int afan_ce2d(const float* logits, const int64_t* target, int layout, int64_t n,
     return AFAN_OK;
 }
 
-int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
-                          afan_stream_t stream) {
+int afan_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                       int k, int stride, int pad, afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
-    if (n < 0 || c <= 0 || hi <= 0 || wi <= 0) return AFAN_ESHAPE;
+    if (n < 0 || c <= 0 || hi <= 0 || wi <= 0 || k < 1 || k > 15 || stride < 1 || pad < 0 || 2 * pad > k) return AFAN_ESHAPE;
+    if (hi + 2 * pad < k || wi + 2 * pad < k) return AFAN_ESHAPE;
     if (n == 0) return AFAN_OK;
     if (!x || !y) return AFAN_ENULL;
-    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    const int64_t ho = (hi + 2 * pad - k) / stride + 1, wo = (wi + 2 * pad - k) / stride + 1;
     const int es = dtype == AFAN_F32 ? 4 : 2;
     hipStream_t st = (hipStream_t)stream;
     const int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {x, y}) : vec_for<uint16_t>(c, {x, y})) : 1;
     const int64_t total = n * ho * wo * c / vec;
-    AFAN_PROF("maxpool_fwd_kernel", (double)es * n * c * (ho * wo + hi * wi), st);
-#define K_(T, V, L, ...) maxpool_fwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)x, (T*)y, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, total)
+    const PoolGeo g{k, stride, pad};
+    AFAN_PROF("maxpool_fwd_kernel", (double)es * n * c * (ho * wo + hi * wi) + (idx ? (double)n * c * ho * wo : 0.0), st);
+#define K_(T, V, L, ...) maxpool_fwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)x, (T*)y, idx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, g, total)
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
 
-int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi,
-                          int64_t wi, afan_stream_t stream) {
+int afan_maxpool2d_bwd(const void* dy, const void* x, const uint8_t* idx, void* dx, int dtype, int layout, int64_t n, int64_t c,
+                       int64_t hi, int64_t wi, int k, int stride, int pad, afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
-    if (n < 0 || c <= 0 || hi <= 0 || wi <= 0) return AFAN_ESHAPE;
+    if (n < 0 || c <= 0 || hi <= 0 || wi <= 0 || k < 1 || k > 15 || stride < 1 || pad < 0 || 2 * pad > k) return AFAN_ESHAPE;
+    if (hi + 2 * pad < k || wi + 2 * pad < k) return AFAN_ESHAPE;
     if (n == 0) return AFAN_OK;
-    if (!dy || !x || !dx) return AFAN_ENULL;
-    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1;
+    if (!dy || !dx || (!x && !idx)) return AFAN_ENULL;
+    const int64_t ho = (hi + 2 * pad - k) / stride + 1, wo = (wi + 2 * pad - k) / stride + 1;
     const int es = dtype == AFAN_F32 ? 4 : 2;
     hipStream_t st = (hipStream_t)stream;
     const int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {dy, x, dx}) : vec_for<uint16_t>(c, {dy, x, dx})) : 1;
     const int64_t total = n * hi * wi * c / vec;
-    AFAN_PROF("maxpool_bwd_kernel", (double)es * n * c * (ho * wo + 2 * hi * wi), st);
-#define K_(T, V, L, ...) maxpool_bwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)dy, (const T*)x, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, total)
+    const PoolGeo g{k, stride, pad};
+    AFAN_PROF("maxpool_bwd_kernel", (double)es * n * c * (ho * wo + hi * wi) + (idx ? (double)n * c * ho * wo : (double)es * n * c * hi * wi), st);
+#define K_(T, V, L, ...) maxpool_bwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)dy, (const T*)x, idx, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, g, total)
+    AFAN_SEG_DISPATCH(K_, 0);
+#undef K_
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                          afan_stream_t stream) {
+    return afan_maxpool2d_fwd(x, y, nullptr, dtype, layout, n, c, hi, wi, 3, 2, 1, stream);
+}
+
+int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi,
+                          int64_t wi, afan_stream_t stream) {
+    return afan_maxpool2d_bwd(dy, x, nullptr, dx, dtype, layout, n, c, hi, wi, 3, 2, 1, stream);
+}
+
+int afan_affine_relu_bwd(const void* dy, const void* y, const float* alpha, void* dx, void* dres, int dtype, int layout,
+                         int64_t n, int64_t c, int64_t hw, int relu, afan_stream_t stream) {
+    int e = check_t(dtype, layout);
+    if (e) return e;
+    if (n < 0 || c <= 0 || hw <= 0) return AFAN_ESHAPE;
+    if (n == 0) return AFAN_OK;
+    if (!dy || (relu && !y) || (!dx && !dres)) return AFAN_ENULL;
+    const int es = dtype == AFAN_F32 ? 4 : 2;
+    hipStream_t st = (hipStream_t)stream;
+    const int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {dy, y, dx, dres}) : vec_for<uint16_t>(c, {dy, y, dx, dres})) : 1;
+    const int64_t total = n * hw * c / vec;
+    AFAN_PROF("affine_bwd_kernel", (double)es * n * c * hw * (1 + (relu ? 1 : 0) + (dx ? 1 : 0) + (dres ? 1 : 0)), st);
+#define K_(T, V, L, ...) affine_bwd_kernel<T, V, L><<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>((const T*)dy, (const T*)y, alpha, (T*)dx, (T*)dres, (int)c, hw, relu, total)
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();

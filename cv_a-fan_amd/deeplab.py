@@ -95,16 +95,26 @@ class _LinearSmallFn(torch.autograd.Function):
 
 
 class _MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(k, stride, pad): the forward leaves each winner's position (one byte per output element) and the backward
+    gathers from it instead of re-scanning the windows."""
+
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, k=3, stride=2, pad=1):
         x = _dense(x)
-        ctx.save_for_backward(x)
-        return ops.maxpool3x3s2(x)
+        y, idx = ops.maxpool2d(x, k, stride, pad, want_idx=ctx.needs_input_grad[0])
+        ctx.geom, ctx.shape = (k, stride, pad), tuple(x.shape)
+        ctx.save_for_backward(idx if idx is not None else x)
+        ctx.have_idx = idx is not None
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return ops.maxpool3x3s2_backward(_match(g, x), x)
+        (t,) = ctx.saved_tensors
+        k, stride, pad = ctx.geom
+        g = _match(g, t)
+        if ctx.have_idx:
+            return ops.maxpool2d_backward(g, t, ctx.shape, k, stride, pad), None, None, None
+        return ops.maxpool2d_backward(g, None, ctx.shape, k, stride, pad, x=t), None, None, None
 
 
 def _match(g, ref):

@@ -1,0 +1,583 @@
+"""Faster-RCNN on a frozen-BatchNorm ResNet-101 with the reference's split-forward dict protocol, on the library's kernels
+(BASELINE configs[4]).
+
+Host-side mirror of `Detection/model.py:18-185` (`Model`: flag head / tail / clean; out_idx 1-3, 'rpn_head' / 'rpn_tail',
+'roi_head' / 'roi_tail'), `Detection/backbone/resnet101_ori.py:130-262` (the dict-dispatch ResNet whose `layer4` is the
+detection head's `hidden` module, `backbone/resnet101.py:13-35`), `Detection/rpn/region_proposal_network.py` (anchors,
+label assignment, host-`randperm` sampling, proposals through NMS), `Detection/roi/pooler.py` and `Detection/bbox.py`, with
+the reference's state_dict layout — including its aliases: `_bn_modules.<i>.*` (model.py:27-28) and `detection.hidden.*`
+(the same tensors as `features.layer4.*`).  Seeded construction reproduces the reference's tensors bit for bit
+(tests/golden/det_frcnn_*: every module is created, default-initialised and re-initialised in the reference's order).
+
+What differs is execution: every convolution runs on libafan_hip.so (tuned bf16 MFMA kernels or the general f32-MFMA ones),
+a frozen BatchNorm (eval mode, no parameter gradients: model.py:31-35,46-47) is ONE fused affine(+residual)(+ReLU) launch
+forward and one backward (`afan_bn_apply`, `afan_affine_relu_bwd`), pooling / ROIAlign / NMS are the library's kernels
+(`afan_maxpool2d_*`, `afan_roi_align_*`, `afan_nms`), the linear heads run as 1x1 problems on the general kernel.  Label
+assignment, sampling and the box arithmetic are small torch ops on the device, with the reference's host synchronisations
+(`nonzero`, `randperm` on the CPU generator — so the draws can be matched)."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
+from .det_ops import nms, roi_align
+from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _ConvFn, _dense, _Flags, _like_layout, _linear, _to_compute)
+
+__all__ = ["Model", "ResNet101", "RegionProposalNetwork", "FrozenBatchNorm2d", "fasterrcnn_resnet101"]
+
+
+# ------------------------------------------------------------------------------------------------- box arithmetic (bbox.py)
+def _centre(b):
+    return torch.stack([(b[..., 0] + b[..., 2]) / 2, (b[..., 1] + b[..., 3]) / 2, b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]], dim=-1)
+
+
+def _corners(c):
+    return torch.stack([c[..., 0] - c[..., 2] / 2, c[..., 1] - c[..., 3] / 2, c[..., 0] + c[..., 2] / 2, c[..., 1] + c[..., 3] / 2], dim=-1)
+
+
+def box_deltas(src, dst):
+    """bbox.py:41-52 `calc_transformer`."""
+    s, d = _centre(src), _centre(dst)
+    return torch.stack([(d[..., 0] - s[..., 0]) / s[..., 2], (d[..., 1] - s[..., 1]) / s[..., 3],
+                        torch.log(d[..., 2] / s[..., 2]), torch.log(d[..., 3] / s[..., 3])], dim=-1)
+
+
+def box_apply(src, t):
+    """bbox.py:54-64 `apply_transformer`."""
+    s = _centre(src)
+    return _corners(torch.stack([t[..., 0] * s[..., 2] + s[..., 0], t[..., 1] * s[..., 3] + s[..., 1],
+                                 torch.exp(t[..., 2]) * s[..., 2], torch.exp(t[..., 3]) * s[..., 3]], dim=-1))
+
+
+def box_iou(a, b):
+    """bbox.py:66-82: [B, Na, 4] x [B, Nb, 4] -> [B, Na, Nb] (no +1: continuous coordinates)."""
+    a, b = a.unsqueeze(-2), b.unsqueeze(-3)
+    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
+    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
+    w = torch.clamp(torch.min(a[..., 2], b[..., 2]) - torch.max(a[..., 0], b[..., 0]), min=0)
+    h = torch.clamp(torch.min(a[..., 3], b[..., 3]) - torch.max(a[..., 1], b[..., 1]), min=0)
+    inter = w * h
+    return inter / (area_a + area_b - inter)
+
+
+def box_clip_(b, right, bottom):
+    """bbox.py:89-92 (left = top = 0), in place."""
+    b[..., [0, 2]] = b[..., [0, 2]].clamp(min=0, max=right)
+    b[..., [1, 3]] = b[..., [1, 3]].clamp(min=0, max=bottom)
+    return b
+
+
+def beta_smooth_l1(inp, target, beta):
+    """extension/functional.py:6-10."""
+    d = torch.abs(inp - target)
+    return torch.where(d < beta, 0.5 * d ** 2 / beta, d - 0.5 * beta).sum() / (inp.numel() + 1e-8)
+
+
+# ------------------------------------------------------------------------------------------------------ fused affine layers
+class _AffineFn(torch.autograd.Function):
+    """y = [relu](x * alpha[c] + beta[c] [+ residual]) with coefficients that receive no gradient through this node (a frozen
+    BatchNorm: alpha = w / sqrt(var + eps), beta = b - mean * alpha; a bias: alpha = 1, beta = bias)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, invstd, weight, bias, residual, relu):
+        x = _dense(x)
+        if residual is not None:
+            residual = _like_layout(residual, x)
+        y = ops.bn_apply(x, mean, invstd, weight, bias, residual, relu)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.alpha = None if (weight is None and invstd is None) else (invstd if weight is None else invstd * weight.detach()).contiguous()
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _like_layout(g, y) if y is not None else _dense(g)
+        if y is not None and g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        dx, dres = ops.affine_relu_backward(g, y, ctx.alpha, ctx.relu, want_dx=ctx.needs_input_grad[0],
+                                            want_dres=ctx.has_res and ctx.needs_input_grad[5])
+        return dx, None, None, None, None, dres, None
+
+
+class FrozenBatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d's parameters and buffers (same state_dict keys), always normalising with the running statistics:
+    Detection/model.py:46-47 puts every BatchNorm in eval mode at each forward and :31-35 switches their gradients off."""
+    _coef = None
+
+    def _coefs(self):
+        key = (self.running_var._version, self.running_mean._version, self.running_var.data_ptr())
+        if self._coef is None or self._coef[0] != key:
+            self._coef = (key, torch.rsqrt(self.running_var.float() + self.eps))
+        return self._coef[1]
+
+    def fused(self, x, residual=None, relu=False, conv_stats=None):
+        return _AffineFn.apply(x, self.running_mean, self._coefs(), self.weight, self.bias, residual, relu)
+
+    def forward(self, x):
+        return self.fused(x)
+
+
+class _BiasFn(torch.autograd.Function):
+    """y = [relu](x + bias[c]) after a bias-free convolution launch; d(bias) = sum of the (masked) gradient over n, h, w."""
+
+    @staticmethod
+    def forward(ctx, x, bias, relu, want_pgrad):
+        x = _dense(x)
+        c = x.shape[1]
+        zero, one = _const(x.device, c)
+        y = ops.bn_apply(x, zero, one, None, bias.detach().float(), None, relu)
+        ctx.relu, ctx.pg = bool(relu), want_pgrad
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _like_layout(g, y) if y is not None else _dense(g)
+        if y is not None and g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        dx, _ = ops.affine_relu_backward(g, y, None, ctx.relu, want_dx=True)
+        db = dx.float().sum(dim=(0, 2, 3)) if (ctx.pg and ctx.needs_input_grad[1]) else None
+        return (dx if ctx.needs_input_grad[0] else None), db, None, None
+
+
+_consts = {}
+
+
+def _const(dev, c):
+    k = (dev.index, c)
+    if k not in _consts:
+        _consts[k] = (torch.zeros(c, device=dev), torch.ones(c, device=dev))
+    return _consts[k]
+
+
+class _GlobalMaxFn(torch.autograd.Function):
+    """F.adaptive_max_pool2d(x, 1) (model.py:285): one window over the whole map."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x)
+        h, w = x.shape[2], x.shape[3]
+        if h != w:
+            raise ops.AfanLibraryError("global max pooling of a non-square map is not on the Detection path")
+        y, idx = ops.maxpool2d(x, h, h, 0, want_idx=ctx.needs_input_grad[0])
+        ctx.shape, ctx.k, ctx.cl = tuple(x.shape), h, ops.layout_of(x) == ops.AFAN_NHWC
+        ctx.save_for_backward(idx if idx is not None else x)
+        ctx.have_idx = idx is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        g = g.contiguous()              # [R, C, 1, 1]: the same memory in either layout
+        return ops.maxpool2d_backward(g, t if ctx.have_idx else None, ctx.shape, ctx.k, ctx.k, 0, x=None if ctx.have_idx else t,
+                                      channels_last=ctx.cl)
+
+
+# ------------------------------------------------------------------------------------------------------------- backbone
+class Bottleneck(nn.Module):
+    """backbone/resnet101_ori.py:78-127 (torchvision v1.5: the 3x3 carries the stride)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1, stride=1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        x = _to_compute(x, self.conv1.compute_dtype)
+        out = self.bn1.fused(self.conv1(x), None, True)
+        out = self.bn2.fused(self.conv2(out), None, True)
+        res = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
+        return self.bn3.fused(self.conv3(out), res, True)
+
+
+class ResNet101(nn.Module):
+    """backbone/resnet101_ori.py:130-262 with layers (3, 4, 23, 3): `forward(input_dict)` returns the feature map after
+    layer `out_idx` (flag 'head'), runs the remaining layers up to layer3 from `adv` (flag 'tail'), or the whole stem ..
+    layer3 (flag 'clean').  layer4 belongs to the module (and its state_dict) but is applied by the detection head."""
+
+    def __init__(self, layers=(3, 4, 23, 3), num_classes=1000):
+        super().__init__()
+        self.normal = NormalizeByChannelMeanStd(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+        self.inplanes = 64
+        self.conv1 = StemConv(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * 4, num_classes)
+        for m in self.modules():                                            # resnet101_ori.py:166-171
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                       FrozenBatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def _stem(self, x):
+        x = self.normal(x)
+        x = self.bn1.fused(self.conv1(x), None, True)
+        return self.maxpool(x)
+
+    def forward(self, input_dict):
+        flag = input_dict["flag"]
+        stages = [self.layer1, self.layer2, self.layer3]
+        if flag in ("head", "clean"):
+            last = 3 if flag == "clean" else input_dict["out_idx"]
+            assert last in (1, 2, 3)
+            x = self._stem(input_dict["x"])
+            for st in stages[:last]:
+                x = st(x)
+            return x
+        assert flag == "tail" and input_dict["out_idx"] in (1, 2, 3)
+        x = _enter(input_dict["adv"], self.conv1.compute_dtype, self.normal.channels_last)
+        for st in stages[input_dict["out_idx"]:]:
+            x = st(x)
+        return x
+
+
+# ------------------------------------------------------------------------------------------------------------------ RPN
+def _fg_bg_sample(labels, n_fg, n_total):
+    """The reference's sampling (region_proposal_network.py:84-90, model.py:277-282): foreground / background indices in
+    nonzero() order, three `torch.randperm` draws on the HOST generator (foreground subset, background subset, shuffle)."""
+    fg = (labels > 0).nonzero()
+    bg = (labels == 0).nonzero()
+    fg = fg[torch.randperm(len(fg))[:min(len(fg), n_fg)]]
+    bg = bg[torch.randperm(len(bg))[:n_total - len(fg)]]
+    sel = torch.cat([fg, bg], dim=0)
+    return sel[torch.randperm(len(sel))].unbind(dim=1)
+
+
+def _per_image_losses(logits, deltas, gt_labels, gt_deltas, batch_size, batch_indices, beta):
+    """region_proposal_network.py:163-185 == model.py:343-367: per image, mean cross-entropy over its samples and the
+    beta-smooth-L1 of its foreground samples."""
+    ce = torch.empty(batch_size, dtype=torch.float, device=logits.device)
+    sl1 = torch.empty(batch_size, dtype=torch.float, device=deltas.device)
+    for b in range(batch_size):
+        sel = (batch_indices == b).nonzero().view(-1)
+        ce[b] = F.cross_entropy(input=logits[sel], target=gt_labels[sel])
+        fg = gt_labels[sel].nonzero().view(-1)
+        sl1[b] = beta_smooth_l1(deltas[sel][fg], gt_deltas[sel][fg], beta)
+    return ce, sl1
+
+
+class RegionProposalNetwork(nn.Module):
+    """rpn/region_proposal_network.py:13-271."""
+
+    def __init__(self, num_features_out, anchor_ratios, anchor_sizes, pre_nms_top_n, post_nms_top_n, anchor_smooth_l1_loss_beta):
+        super().__init__()
+        self._features = nn.Sequential(Conv2d(num_features_out, 512, kernel_size=3, padding=1), nn.ReLU())
+        self._anchor_ratios, self._anchor_sizes = anchor_ratios, anchor_sizes
+        num_anchors = len(anchor_ratios) * len(anchor_sizes)
+        self._pre_nms_top_n, self._post_nms_top_n = pre_nms_top_n, post_nms_top_n
+        self._anchor_smooth_l1_loss_beta = anchor_smooth_l1_loss_beta
+        self._anchor_objectness = Conv2d(512, num_anchors * 2, kernel_size=1)
+        self._anchor_transformer = Conv2d(512, num_anchors * 4, kernel_size=1)
+
+    # -- layers
+    def _trunk(self, features):
+        c = self._features[0]
+        x = _to_compute(features, c.compute_dtype)
+        y = _ConvFn.apply(x, c.weight, c.lp_weight().detach(), c.lp_weight_t, c.stride, c.padding, _Flags.param_grads, None, c.dilation)
+        return _BiasFn.apply(y, c.bias, True, _Flags.param_grads)
+
+    def _heads(self, trunk):
+        """The two 1x1 heads in fp32 (18 / 36 output channels: the general kernel, bias in its epilogue)."""
+        b = trunk.shape[0]
+        x = trunk if trunk.dtype == torch.float32 else trunk.float()
+        outs = []
+        for conv, k in ((self._anchor_objectness, 2), (self._anchor_transformer, 4)):
+            y = _ConvFn.apply(x, conv.weight, conv.weight.detach(), None, conv.stride, conv.padding, _Flags.param_grads, None,
+                              conv.dilation, conv.bias)
+            outs.append(y.permute(0, 2, 3, 1).contiguous().view(b, -1, k))
+        return outs
+
+    # -- training targets (:58-105; the reference repeats this block in its 'clean' and 'tail' branches)
+    def _losses(self, objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height):
+        b = anchor_bboxes.shape[0]
+        inside = ((anchor_bboxes[..., 0] >= 0) * (anchor_bboxes[..., 1] >= 0) * (anchor_bboxes[..., 2] <= image_width) *
+                  (anchor_bboxes[..., 3] <= image_height)).nonzero().unbind(dim=1)
+        in_boxes = anchor_bboxes[inside].view(b, -1, 4)
+        in_obj = objectnesses[inside].view(b, -1, 2)
+        in_tr = transformers[inside].view(b, -1, 4)
+        labels = torch.full((b, in_boxes.shape[1]), -1, dtype=torch.long, device=in_boxes.device)
+        ious = box_iou(in_boxes, gt_bboxes_batch)
+        anchor_max, anchor_assign = ious.max(dim=2)
+        gt_max, _ = ious.max(dim=1)
+        additions = ((ious > 0) & (ious == gt_max.unsqueeze(dim=1))).nonzero()[:, :2].unbind(dim=1)
+        labels[anchor_max < 0.3] = 0
+        labels[additions] = 1
+        labels[anchor_max >= 0.7] = 1
+        sel = _fg_bg_sample(labels, 128 * b, 256 * b)
+        boxes = in_boxes[sel]
+        gt_boxes = gt_bboxes_batch[sel[0], anchor_assign[sel]]
+        return _per_image_losses(in_obj[sel], in_tr[sel], labels[sel], box_deltas(boxes, gt_boxes), b, sel[0],
+                                 self._anchor_smooth_l1_loss_beta)
+
+    def forward(self, features, anchor_bboxes=None, gt_bboxes_batch=None, image_width=None, image_height=None, return_type="clean"):
+        if return_type == "head":
+            trunk = self._trunk(features)
+            return {"batch_size": torch.tensor([[trunk.shape[0]]], device=trunk.device), "rpn_feature": trunk}
+        if return_type == "tail":
+            trunk = features["rpn_feature"]
+        else:
+            assert return_type == "clean"
+            trunk = self._trunk(features)
+        objectnesses, transformers = self._heads(trunk)
+        if not self.training:
+            return objectnesses, transformers
+        ce, sl1 = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height)
+        return objectnesses, transformers, ce, sl1
+
+    def generate_anchors(self, image_width, image_height, num_x_anchors, num_y_anchors):
+        """:187-221: centres on a linspace grid without its end points, ratio-major / size-minor, y-major order."""
+        ys = np.linspace(start=0, stop=image_height, num=num_y_anchors + 2)[1:-1]
+        xs = np.linspace(start=0, stop=image_width, num=num_x_anchors + 2)[1:-1]
+        ratios = np.array(self._anchor_ratios)
+        ratios = ratios[:, 0] / ratios[:, 1]
+        sizes = np.array(self._anchor_sizes)
+        ys, xs, ratios, sizes = (a.reshape(-1) for a in np.meshgrid(ys, xs, ratios, sizes, indexing="ij"))
+        centre = np.stack((xs, ys, sizes * np.sqrt(1 / ratios), sizes * np.sqrt(ratios)), axis=1)
+        return _corners(torch.from_numpy(centre).float())
+
+    def generate_proposals(self, anchor_bboxes, objectnesses, transformers, image_width, image_height):
+        """:223-271: decode, clip, sort by the softmax over ALL anchors of the foreground logit, NMS at 0.7 per image (the
+        library's kernel), top-N, zero-pad to the longest image."""
+        boxes = box_clip_(box_apply(anchor_bboxes, transformers), image_width, image_height)
+        probs = F.softmax(objectnesses[:, :, 1], dim=-1)
+        _, order = torch.sort(probs, dim=-1, descending=True)
+        kept = []
+        for b in range(anchor_bboxes.shape[0]):
+            sb = boxes[b][order[b]][:self._pre_nms_top_n]
+            sp = probs[b][order[b]][:self._pre_nms_top_n]
+            keep = nms(sb, sp, 0.7)
+            kept.append(sb[keep.to(sb.device)][:self._post_nms_top_n])
+        longest = max(len(k) for k in kept)
+        return torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
+
+
+# --------------------------------------------------------------------------------------------------------------- pooler
+def pool_rois(features, proposal_bboxes, proposal_batch_indices, mode):
+    """roi/pooler.py:21-44: 14 x 14 per region — 'align': ROIAlign at scale 1/16 with adaptive sampling (afan_roi_align_*);
+    'pooling': adaptive max pooling of the box rounded to feature cells, region by region on the host like the reference
+    (its CPU-runnable mode: the one the reference goldens can be generated in) — then a 2 x 2 / stride 2 max pool."""
+    mode = getattr(mode, "value", mode)
+    _, _, fh, fw = features.shape
+    scale = 1 / 16
+    if mode == "pooling":
+        pool = []
+        for box, bi in zip(proposal_bboxes, proposal_batch_indices):
+            x0 = max(min(round(box[0].item() * scale), fw - 1), 0)
+            y0 = max(min(round(box[1].item() * scale), fh - 1), 0)
+            x1 = max(min(round(box[2].item() * scale) + 1, fw), 1)
+            y1 = max(min(round(box[3].item() * scale) + 1, fh), 1)
+            pool.append(F.adaptive_max_pool2d(input=features[bi, :, y0:y1, x0:x1], output_size=(14, 14)))
+        pool = torch.stack(pool, dim=0)
+    elif mode == "align":
+        rois = torch.cat([proposal_batch_indices.view(-1, 1).float(), proposal_bboxes], dim=1)
+        pool = roi_align(features, rois, (14, 14), scale, 0)
+    else:
+        raise ValueError(mode)
+    cl = ops.layout_of(features) == ops.AFAN_NHWC
+    pool = pool.contiguous(memory_format=torch.channels_last) if cl else pool.contiguous()
+    return _MaxPoolFn.apply(pool, 2, 2, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------- model
+class Model(nn.Module):
+    """Detection/model.py:18-185."""
+
+    def __init__(self, backbone=None, num_classes=21, pooler_mode="align", anchor_ratios=((1, 2), (1, 1), (2, 1)),
+                 anchor_sizes=(128, 256, 512), rpn_pre_nms_top_n=12000, rpn_post_nms_top_n=2000,
+                 anchor_smooth_l1_loss_beta=1.0, proposal_smooth_l1_loss_beta=1.0):
+        super().__init__()
+        self.features = backbone if backbone is not None else ResNet101()
+        hidden, num_features_out, num_hidden_out = self.features.layer4, 1024, 2048
+        for part in (self.features.conv1, self.features.bn1, self.features.layer1):        # backbone/resnet101.py:30-32
+            for p in part.parameters():
+                p.requires_grad = False
+        self._bn_modules = nn.ModuleList([m for m in self.features.modules() if isinstance(m, nn.BatchNorm2d)] +
+                                         [m for m in hidden.modules() if isinstance(m, nn.BatchNorm2d)])
+        for bn in self._bn_modules:
+            for p in bn.parameters():
+                p.requires_grad = False
+        self.rpn = RegionProposalNetwork(num_features_out, list(anchor_ratios), list(anchor_sizes), rpn_pre_nms_top_n,
+                                         rpn_post_nms_top_n, anchor_smooth_l1_loss_beta)
+        self.detection = Model.Detection(pooler_mode, hidden, num_hidden_out, num_classes, proposal_smooth_l1_loss_beta)
+        self.compute_dtype, self.channels_last = torch.float32, False
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, Conv2d) and m not in (self.rpn._anchor_objectness, self.rpn._anchor_transformer):
+                m.compute_dtype = dtype
+            elif isinstance(m, NormalizeByChannelMeanStd):
+                m.out_dtype = dtype
+        return self
+
+    def set_channels_last(self, on=True):
+        self.channels_last = bool(on)
+        for m in self.modules():
+            if isinstance(m, NormalizeByChannelMeanStd):
+                m.channels_last = self.channels_last
+        return self
+
+    def _anchors(self, features, image_shape):
+        b, _, ih, iw = image_shape
+        _, _, fh, fw = features.shape
+        return self.rpn.generate_anchors(iw, ih, num_x_anchors=fw, num_y_anchors=fh).to(features.device).repeat(b, 1, 1), iw, ih
+
+    def forward(self, input_dict, gt_bboxes_batch=None, gt_classes_batch=None):
+        flag = input_dict["flag"]
+        if flag == "head":
+            return self.features(input_dict)
+        assert flag in ("tail", "clean")
+        if not self.training:
+            features = self.features(input_dict)
+            anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
+            obj, tr = self.rpn.forward(features)
+            proposals = self.rpn.generate_proposals(anchors, obj, tr, iw, ih)
+            classes, transformers = self.detection.forward(features, proposals)
+            return self.detection.generate_detections(proposals, classes, transformers, iw, ih)
+        idx = input_dict["out_idx"]
+        if idx == "roi_tail":
+            d = input_dict["adv"]
+            _, _, pc, pt = self.detection.forward(d["roi_output_dict"], return_type="tail")
+            return d["anchor_objectness_losses"], d["anchor_transformer_losses"], pc, pt
+        if idx == "rpn_tail":
+            d = input_dict["adv"]
+            features, anchors = d["features"], d["anchor_bboxes"]
+            iw, ih = d["image_width"][0].item(), d["image_height"][0].item()
+            obj, tr, ao, at = self.rpn.forward(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
+        else:
+            features = self.features(input_dict)
+            anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
+            if idx == "rpn_head":
+                return {"features": features, "image_height": torch.tensor([[ih]], device=features.device),
+                        "image_width": torch.tensor([[iw]], device=features.device), "anchor_bboxes": anchors,
+                        "rpn_feature_map_dict": self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih, return_type="head")}
+            assert type(idx) == int or idx == "roi_head"
+            obj, tr, ao, at = self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih)
+        proposals = self.rpn.generate_proposals(anchors, obj.float(), tr.float(), iw, ih).detach()
+        if idx == "roi_head":
+            return {"anchor_objectness_losses": ao, "anchor_transformer_losses": at,
+                    "roi_output_dict": self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, return_type="head")}
+        _, _, pc, pt = self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch)
+        return ao, at, pc, pt
+
+    class Detection(nn.Module):
+        """model.py:231-367."""
+
+        def __init__(self, pooler_mode, hidden, num_hidden_out, num_classes, proposal_smooth_l1_loss_beta):
+            super().__init__()
+            self._pooler_mode = pooler_mode
+            self.hidden = hidden
+            self.num_classes = num_classes
+            self._proposal_class = nn.Linear(num_hidden_out, num_classes)
+            self._proposal_transformer = nn.Linear(num_hidden_out, num_classes * 4)
+            self._proposal_smooth_l1_loss_beta = proposal_smooth_l1_loss_beta
+            self._transformer_normalize_mean = torch.tensor([0., 0., 0., 0.], dtype=torch.float)
+            self._transformer_normalize_std = torch.tensor([.1, .1, .2, .2], dtype=torch.float)
+
+        def _roi_features(self, features, boxes, batch_indices):
+            """Pooler -> layer4 -> global max: [R, 2048, 1, 1]."""
+            h = self.hidden(pool_rois(features, boxes, batch_indices, self._pooler_mode))
+            return _GlobalMaxFn.apply(h)
+
+        def _linears(self, hidden):
+            x = hidden.view(hidden.shape[0], -1).float()
+            return _linear(x, self._proposal_class), _linear(x, self._proposal_transformer)
+
+        def _targets(self, proposal_bboxes, gt_classes_batch, gt_bboxes_batch):
+            """:256-282 (repeated at :300-326): IoU >= 0.5 takes its ground truth's class, 32 / 128 per image sampled."""
+            b = proposal_bboxes.shape[0]
+            labels = torch.full((b, proposal_bboxes.shape[1]), -1, dtype=torch.long, device=proposal_bboxes.device)
+            max_ious, assign = box_iou(proposal_bboxes, gt_bboxes_batch).max(dim=2)
+            labels[max_ious < 0.5] = 0
+            fg = max_ious >= 0.5
+            if len(fg.nonzero()) > 0:
+                labels[fg] = gt_classes_batch[fg.nonzero()[:, 0], assign[fg]]
+            sel = _fg_bg_sample(labels, 32 * b, 128 * b)
+            boxes = proposal_bboxes[sel]
+            return boxes, labels[sel], box_deltas(boxes, gt_bboxes_batch[sel[0], assign[sel]]), sel[0]
+
+        def forward(self, features, proposal_bboxes=None, gt_classes_batch=None, gt_bboxes_batch=None, return_type="clean"):
+            if return_type == "tail":
+                d = features
+                classes, transformers = self._linears(d["roi_feature_map"])
+                ce, sl1 = self.loss(classes, transformers, d["gt_proposal_classes"], d["gt_proposal_transformers"],
+                                    d["batch_size"][0].item(), d["batch_indices"])
+                return classes, transformers, ce, sl1
+            b = features.shape[0]
+            if return_type == "clean" and not self.training:
+                bi = torch.arange(end=b, dtype=torch.long, device=proposal_bboxes.device).view(-1, 1).repeat(1, proposal_bboxes.shape[1])
+                classes, transformers = self._linears(self._roi_features(features, proposal_bboxes.view(-1, 4), bi.view(-1)))
+                return classes.view(b, -1, classes.shape[-1]), transformers.view(b, -1, transformers.shape[-1])
+            boxes, gt_classes, gt_deltas, bi = self._targets(proposal_bboxes, gt_classes_batch, gt_bboxes_batch)
+            hidden = self._roi_features(features, boxes, bi)
+            if return_type == "head":
+                return {"roi_feature_map": hidden, "gt_proposal_classes": gt_classes, "gt_proposal_transformers": gt_deltas,
+                        "batch_size": torch.tensor([[b]], device=hidden.device), "batch_indices": bi}
+            assert return_type == "clean"
+            classes, transformers = self._linears(hidden)
+            ce, sl1 = self.loss(classes, transformers, gt_classes, gt_deltas, b, bi)
+            return classes, transformers, ce, sl1
+
+        def loss(self, proposal_classes, proposal_transformers, gt_proposal_classes, gt_proposal_transformers, batch_size, batch_indices):
+            """:343-367: the regression output of each sample's OWN class, targets normalised by (0, 0, 0, 0) / (.1, .1, .2, .2)."""
+            tr = proposal_transformers.view(-1, self.num_classes, 4)[torch.arange(end=len(proposal_transformers), dtype=torch.long),
+                                                                     gt_proposal_classes]
+            mean = self._transformer_normalize_mean.to(device=gt_proposal_transformers.device)
+            std = self._transformer_normalize_std.to(device=gt_proposal_transformers.device)
+            return _per_image_losses(proposal_classes, tr, gt_proposal_classes, (gt_proposal_transformers - mean) / std, batch_size,
+                                     batch_indices, self._proposal_smooth_l1_loss_beta)
+
+        def generate_detections(self, proposal_bboxes, proposal_classes, proposal_transformers, image_width, image_height):
+            """:369-407 (inference): per-class decode, clip, softmax, NMS at 0.3."""
+            b = proposal_bboxes.shape[0]
+            tr = proposal_transformers.view(b, -1, self.num_classes, 4)
+            tr = tr * self._transformer_normalize_std.to(tr.device) + self._transformer_normalize_mean.to(tr.device)
+            boxes = box_clip_(box_apply(proposal_bboxes.unsqueeze(dim=2).repeat(1, 1, self.num_classes, 1), tr), image_width, image_height)
+            probs = F.softmax(proposal_classes, dim=-1)
+            out_b, out_c, out_p, out_i = [], [], [], []
+            for bi in range(b):
+                for c in range(1, self.num_classes):
+                    cb, cp = boxes[bi, :, c, :], probs[bi, :, c]
+                    keep = nms(cb, cp, 0.3).to(cb.device)
+                    out_b.append(cb[keep])
+                    out_c.append(torch.full((len(keep),), c, dtype=torch.int))
+                    out_p.append(cp[keep])
+                    out_i.append(torch.full((len(keep),), bi, dtype=torch.long))
+            return torch.cat(out_b, dim=0), torch.cat(out_c, dim=0), torch.cat(out_p, dim=0), torch.cat(out_i, dim=0)
+
+
+def fasterrcnn_resnet101(num_classes=21, pooler_mode="align", **kw):
+    """train_aug_sat_muti_advt.py:36-44 with the VOC configuration (config/train_config.py): 21 classes, 9 anchors."""
+    return Model(ResNet101(), num_classes, pooler_mode, **kw)

@@ -926,6 +926,55 @@ def maxpool3x3s2_backward(dy, x):
     return dx
 
 
+def maxpool2d(x, k, stride, pad=0, want_idx=True):
+    """nn.MaxPool2d(k, stride, pad) (first maximum wins, NaN wins): (y, idx | None) — idx (uint8, y's shape and layout) holds
+    the winner's position inside its window for maxpool2d_backward."""
+    lib = _lib.load()
+    _need(x, "x")
+    if x.dim() != 4 or x.dtype not in _DT:
+        raise TypeError("maxpool2d: 4-D fp32 / bf16 tensor expected")
+    n, c, hi, wi = x.shape
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=_mf(x))
+    idx = torch.empty((n, c, ho, wo), dtype=torch.uint8, device=x.device, memory_format=_mf(x)) if want_idx else None
+    check(lib.afan_maxpool2d_fwd(_ptr(x), _ptr(y), _ptr(idx), _DT[x.dtype], layout_of(x), n, c, hi, wi, int(k), int(stride), int(pad),
+                                 _stream(x)), "afan_maxpool2d_fwd")
+    return y, idx
+
+
+def maxpool2d_backward(dy, idx, in_shape, k, stride, pad=0, x=None, channels_last=None):
+    """dx of maxpool2d for an input of shape in_shape, from the forward's idx (or by re-scanning x when idx is None).
+    channels_last: the layout dy / idx are in (default: dy's strides; needed for 1x1 outputs, whose strides do not tell)."""
+    lib = _lib.load()
+    _need(dy, "dy")
+    n, c, hi, wi = (int(v) for v in in_shape)
+    lay = layout_of(dy) if channels_last is None else (AFAN_NHWC if channels_last else AFAN_NCHW)
+    dx = torch.empty((n, c, hi, wi), dtype=dy.dtype, device=dy.device,
+                     memory_format=torch.channels_last if lay == AFAN_NHWC else torch.contiguous_format)
+    if channels_last is None and idx is not None and layout_of(idx) != lay and idx.numel() > 0 and not (c == 1 or dy.shape[2] * dy.shape[3] == 1):
+        raise ValueError("dy must have the forward output's memory layout")
+    check(lib.afan_maxpool2d_bwd(_ptr(dy), _ptr(x), _ptr(idx), _ptr(dx), _DT[dy.dtype], lay, n, c, hi, wi, int(k), int(stride),
+                                 int(pad), _stream(dy)), "afan_maxpool2d_bwd")
+    return dx
+
+
+def affine_relu_backward(dy, y, alpha, relu, want_dx=True, want_dres=False):
+    """Backward of y = [relu](x * alpha[c] + beta[c] [+ res]) with constant coefficients: (dx | None, d_res | None)."""
+    lib = _lib.load()
+    _need(dy, "dy")
+    if relu:
+        _need(y, "y", dy.dtype)
+        _same_layout(dy, y)
+    n, c, hw = _nchw(dy)
+    dx = torch.empty_like(dy) if want_dx else None
+    dres = torch.empty_like(dy) if want_dres else None
+    if alpha is not None:
+        _need(alpha, "alpha", torch.float32)
+    check(lib.afan_affine_relu_bwd(_ptr(dy), _ptr(y) if relu else None, _ptr(alpha), _ptr(dx), _ptr(dres), _DT[dy.dtype], layout_of(dy),
+                                   n, c, hw, int(bool(relu)), _stream(dy)), "afan_affine_relu_bwd")
+    return dx, dres
+
+
 def avgpool(x, out_fp32=False):
     """nn.AdaptiveAvgPool2d(1): [N,C,H,W] -> [N,C,1,1] (x's dtype, or fp32 with out_fp32; fp32 accumulate)."""
     lib = _lib.load()

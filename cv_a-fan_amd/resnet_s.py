@@ -324,9 +324,10 @@ def general_convs(model):
     tuned bf16 MFMA kernels; the image stem (3 input channels) is not listed (it decides by image width at run time).
     Informational: both families are the library's own and both are hipGraph-capturable."""
     out = []
+    nchw = not getattr(model, "channels_last", True)          # NCHW activations: nothing reaches the tuned (channels-last) kernels
     for name, m in model.named_modules():
         if isinstance(m, Conv2d) and m.in_channels > 4 and not getattr(m, "own_kernel", False):
-            if m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding, m.dilation):
+            if nchw or m.compute_dtype != torch.bfloat16 or not _own_conv_ok_shape(m.lp_weight(), m.stride, m.padding, m.dilation):
                 out.append(name)
     return out
 
@@ -549,9 +550,25 @@ class NormalizeByChannelMeanStd(nn.Module):
         self.channels_last = False
 
     def forward(self, x):
-        if x.requires_grad:
-            raise NotImplementedError("gradients w.r.t. the input image are not on the A-FAN feature path")
+        if x.requires_grad:        # image-space PGD (Detection / Segmentation `adv_input`): d/dx = g / std[c]
+            return _NormalizeFn.apply(x, self.mean, self.std, self.out_dtype, self.channels_last)
         return ops.normalize_nchw(x.contiguous().float(), self.mean, self.std, self.out_dtype, self.channels_last)
+
+
+class _NormalizeFn(torch.autograd.Function):
+    """(x - mean[c]) / std[c] with the gradient to the image: g / std[c] in the image's own fp32 NCHW form
+    (afan_affine_relu_bwd with alpha = 1 / std)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, std, out_dtype, channels_last):
+        ctx.inv_std = (1.0 / std.float()).contiguous()
+        return ops.normalize_nchw(x.detach().contiguous().float(), mean, std, out_dtype, channels_last)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.float().contiguous()
+        dx, _ = ops.affine_relu_backward(g, None, ctx.inv_std, False, want_dx=True)
+        return dx, None, None, None, None
 
 
 class Conv2d(nn.Conv2d):
@@ -568,7 +585,9 @@ class Conv2d(nn.Conv2d):
         if shadow is not None:  # kept fresh by afan_sgd_step (ParamArena)
             return shadow
         if self._lp is None or self._lp_version != self.weight._version or self._lp.device != self.weight.device:
-            self._lp = ops.cast_bf16(self.weight.detach().contiguous())
+            # KRSC (channels-last) memory: what the tuned kernels read — also for weights outside a parameter arena
+            # (frozen layers: Detection/backbone/resnet101.py:30-32)
+            self._lp = ops.cast_bf16(self.weight.detach().contiguous(memory_format=torch.channels_last))
             self._lp_version = self.weight._version
         return self._lp
 

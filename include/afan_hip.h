@@ -355,6 +355,21 @@ int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t
                           afan_stream_t stream);
 int afan_maxpool3x3s2_bwd(const void* dy, const void* x, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi,
                           int64_t wi, afan_stream_t stream);
+/* The general form: k x k windows (k <= 15), any stride, padding <= k/2; ho = (hi + 2 pad - k) / stride + 1.  Same winner rule.
+ * Detection/roi/pooler.py:43 (2 x 2 / 2 after ROIAlign), Detection/model.py:285,336 (adaptive_max_pool2d(., 1) = one window).
+ * idx (nullable): uint8 [output elements, the output's layout] — the winner's position inside its window (r * k + s), written
+ * by the forward; the backward given idx reads (gradient, position) of the windows over an input pixel instead of
+ * re-scanning them (x may then be NULL). */
+int afan_maxpool2d_fwd(const void* x, void* y, uint8_t* idx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                       int k, int stride, int pad, afan_stream_t stream);
+int afan_maxpool2d_bwd(const void* dy, const void* x, const uint8_t* idx, void* dx, int dtype, int layout, int64_t n, int64_t c,
+                       int64_t hi, int64_t wi, int k, int stride, int pad, afan_stream_t stream);
+/* Backward of y = [relu](x * alpha[c] + beta[c] [+ res]) with CONSTANT per-channel coefficients — a frozen (eval-mode,
+ * gradient-free) BatchNorm, Detection/model.py:27-35,46-47, whose forward is afan_bn_apply; or a convolution bias (+ ReLU),
+ * Detection/rpn/region_proposal_network.py:19-22: g = dy masked by (y > 0) when relu; dx (nullable) = g * alpha[c] (alpha
+ * NULL = 1); d_res (nullable) = g.  Tensors [n, c, hw] in `layout`. */
+int afan_affine_relu_bwd(const void* dy, const void* y, const float* alpha, void* dx, void* dres, int dtype, int layout,
+                         int64_t n, int64_t c, int64_t hw, int relu, afan_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast.
  * pooled_f32 != 0: the pooled side (y / dy) is fp32 whatever `dtype` the map has. */
 int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,

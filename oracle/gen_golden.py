@@ -258,6 +258,161 @@ def gen_detection(orc):
 
 
 
+def _import_reference_detection_model():
+    """`Detection/model.py` with the reference's own backbone / rpn / roi / bbox / extension modules on sys.path, plus the
+    stand-ins this image needs: an empty `torchvision` (backbone/resnet101.py:3 imports it, never uses it with
+    the `_ori` backbone), and a `support` package — the reference's compiled extension is absent (.MISSING_LARGE_BLOBS) and its
+    CPU sources do not compile against this torch — whose `nms` is the plain-C oracle NMS (oracle/afan_oracle.c, pinned to the
+    reference's own 9770 -> 1934 vector, tests/test_det_oracle.py; the `>` rule of the reference's GPU path, nms.cu:49) and
+    whose `ROIAlign` raises (the goldens run `--pooler_mode pooling`, roi/pooler.py:24-33: the reference's CPU-runnable mode)."""
+    import ctypes
+    import subprocess
+    det = os.path.join(REF, "Detection")
+    if det not in sys.path:
+        sys.path.insert(0, det)
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    so = os.path.join(ROOT, "oracle", "_ref", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    _p, _l = ctypes.c_void_p, ctypes.c_int64
+    lib.oracle_nms.argtypes = [_p, _p, _l, ctypes.c_float, ctypes.c_int, _p, _p]
+    lib.oracle_nms.restype = _l
+
+    def nms(bboxes, scores, threshold):
+        n = bboxes.shape[0]
+        if n == 0:
+            return torch.empty(0, dtype=torch.int64)
+        b = np.ascontiguousarray(bboxes.detach().float().numpy())
+        order = np.ascontiguousarray(torch.sort(scores.detach().float(), dim=0, descending=True)[1].numpy().astype(np.int64))
+        keep, scratch = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.uint8)
+        k = lib.oracle_nms(b.ctypes.data_as(_p), order.ctypes.data_as(_p), n, float(threshold), 0, keep.ctypes.data_as(_p),
+                           scratch.ctypes.data_as(_p))
+        return torch.from_numpy(np.sort(keep[:k]))
+
+    class ROIAlign(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, *a, **k):
+            raise RuntimeError("the reference's ROIAlign extension is not available: goldens use --pooler_mode pooling")
+
+    sup, lay, m_nms, m_ra = (types.ModuleType(n) for n in ("support", "support.layer", "support.layer.nms", "support.layer.roi_align"))
+    m_nms.nms, m_ra.ROIAlign = nms, ROIAlign
+    sup.layer, lay.nms, lay.roi_align = lay, m_nms, m_ra
+    for m in (sup, lay, m_nms, m_ra):
+        sys.modules[m.__name__] = m
+    import model as ref_model                      # Detection/model.py
+    from backbone.resnet101 import ResNet101 as RefBackbone
+    from roi.pooler import Pooler as RefPooler
+    return ref_model, RefBackbone, RefPooler
+
+
+def gen_detection_model():
+    """The reference's OWN Faster-RCNN (Detection/model.py:18-185 on backbone/resnet101_ori.py, rpn/, roi/pooler.py 'pooling'
+    mode) at a small image size, fixed seed, no pretrained weights (pretrained=False: kaiming initialisation, BatchNorm
+    running statistics at 0 / 1): det_frcnn_r101.npz.  What it pins: seeded construction (checksum of every state_dict
+    tensor, in the reference's key order incl. the `_bn_modules.*` / `detection.hidden.*` aliases), the three backbone feature
+    maps (flag head, out_idx 1-3), the RPN's logits and its proposals, the four per-image losses of one training forward
+    (host `randperm` draws from a fixed generator state) and the gradients that forward leaves; the one-step feature PGD of
+    Detection/attack_algo.py:48-74 at out_idx 3; one full iteration of train_aug_sat_muti_advt.py:70-172 (eight forwards, five
+    PGD calls, SGD step)."""
+    ref_model, RefBackbone, RefPooler = _import_reference_detection_model()
+    ref_det = _load("ref_det_attack_algo", "Detection/attack_algo.py")
+    cfg = dict(anchor_ratios=[(1, 2), (1, 1), (2, 1)], anchor_sizes=[64], rpn_pre_nms_top_n=200, rpn_post_nms_top_n=64,
+               anchor_smooth_l1_loss_beta=1.0, proposal_smooth_l1_loss_beta=1.0)
+    torch.manual_seed(7)
+    model = ref_model.Model(RefBackbone(pretrained=False), 21, pooler_mode=RefPooler.Mode.POOLING, **cfg)
+    model.train()
+    k_init, c_init = _checksums(model)                    # seeded construction, before the damping below
+    # Without pretrained weights the frozen BatchNorms are identities (running statistics 0 / 1) and 33 residual blocks
+    # multiply the activations up to 1e4: losses of 5e4, no foreground proposals.  Weights are data: every block's last
+    # BatchNorm weight x 0.2 keeps the features O(1) (the regime pretrained weights are in).
+    damp = 0.2
+    for m in model.modules():
+        if hasattr(m, "bn3") and hasattr(m, "conv3"):
+            m.bn3.weight.data.mul_(damp)
+    k0, c0 = _checksums(model)
+    g = torch.Generator().manual_seed(21)
+    images = torch.rand(2, 3, 128, 160, generator=g)
+    bboxes = torch.tensor([[[12., 20., 70., 90.], [60., 30., 150., 110.]], [[5., 8., 60., 64.], [80., 50., 140., 120.]]])
+    labels = torch.tensor([[3, 7], [12, 1]])
+    rec = {"images": _np(images), "bboxes": _np(bboxes), "labels": _np(labels), "keys": np.array(k0), "ck0": c0, "ck_init": c_init,
+           "damp": np.array(damp),
+           "anchor_sizes": np.array(cfg["anchor_sizes"]), "nms_top_n": np.array([cfg["rpn_pre_nms_top_n"], cfg["rpn_post_nms_top_n"]])}
+    # (1) head passes
+    for i in (1, 2, 3):
+        fm = model.train().forward({"x": images, "adv": None, "out_idx": i, "flag": "head"}, bboxes, labels).detach()
+        rec[f"fm{i}_sub"] = _np(fm[:, ::8, ::2, ::2])
+        rec[f"fm{i}_norm"] = np.array(float(fm.double().norm()))
+        print(f"   fm{i}: shape {tuple(fm.shape)} rms {float(fm.double().pow(2).mean().sqrt()):.3f} max {float(fm.abs().max()):.2f}")
+    fm3 = fm
+    # (2) one training forward with recorded RPN outputs / proposals, and its backward
+    seen = {}
+    real_gp = model.rpn.generate_proposals
+
+    def spy(anchor_bboxes, objectnesses, transformers, image_width, image_height):
+        out = real_gp(anchor_bboxes, objectnesses, transformers, image_width, image_height)
+        seen.update(obj=objectnesses.detach().clone(), tr=transformers.detach().clone(), proposals=out.detach().clone())
+        return out
+    model.rpn.generate_proposals = spy
+    torch.manual_seed(100)
+    ao, at, pc, pt = model.train().forward({"x": images, "adv": None, "out_idx": 0, "flag": "clean"}, bboxes, labels)
+    model.rpn.generate_proposals = real_gp
+    rec.update(rpn_obj=_np(seen["obj"]), rpn_tr=_np(seen["tr"]), proposals=_np(seen["proposals"]),
+               fwd_losses=np.stack([_np(ao), _np(at), _np(pc), _np(pt)]))
+    for p in model.parameters():
+        p.grad = None
+    (ao.mean() + at.mean() + pc.mean() + pt.mean()).backward()
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    rec["param_names"] = np.array([n for n, _ in named])
+    rec["grad_norms"] = np.array([float(p.grad.double().norm()) for _, p in named])
+    for n, p in named:
+        if n in ("features.layer2.0.conv1.weight", "features.layer3.22.conv3.weight", "rpn._anchor_objectness.weight",
+                 "rpn._anchor_objectness.bias", "detection._proposal_class.weight", "detection._proposal_transformer.bias"):
+            rec["grad/" + n] = _np(p.grad)
+    # (3) one-step feature PGD at the deepest point (train_aug_sat_muti_advt.py:91)
+    y = {"bb": bboxes, "lb": labels}
+    torch.manual_seed(101)
+    adv3 = ref_det.PGD(fm3, images, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+    rec["adv3_sign"] = _np(torch.round((adv3.detach() - fm3) / np.float32(1.0 / 255))).astype(np.int8)
+    # (4) one full iteration (loss_settings 1), SGD as train_aug_sat_muti_advt.py:46-47 / config/train_config.py
+    optimizer = torch.optim.SGD(model.parameters(), lr=0.001, momentum=0.9, weight_decay=0.0005)
+    torch.manual_seed(102)
+    fwd = lambda d: model.train().forward(d, bboxes, labels)
+    adv_image = ref_det.adv_input(x=images, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+    f1 = fwd({"x": images, "adv": None, "out_idx": 1, "flag": "head"}).detach()
+    f2 = fwd({"x": images, "adv": None, "out_idx": 2, "flag": "head"}).detach()
+    f3 = fwd({"x": images, "adv": None, "out_idx": 3, "flag": "head"}).detach()
+    rr = fwd({"x": images, "adv": None, "out_idx": "roi_head", "flag": "clean"})
+    clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
+    a1 = ref_det.PGD(f1, images, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+    a2 = ref_det.PGD(f2, images, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+    a3 = ref_det.PGD(f3, images, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+    pts = ref_det.get_sample_points(f3, a3, 5)
+    pts[1] = ref_det.mix_feature(f3, pts[1])
+    pts[2] = ref_det.mix_feature(f3, pts[2])
+    arr = ref_det.rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
+    adv_sd = ref_det.mix_feature(clean_sd, arr["roi_output_dict"]["roi_feature_map"].detach())
+    arr["roi_output_dict"]["roi_feature_map"] = adv_sd
+    dicts = [{"x": adv_image, "adv": None, "out_idx": 0, "flag": "clean"}, {"x": images, "adv": a1, "out_idx": 1, "flag": "tail"},
+             {"x": images, "adv": a2, "out_idx": 2, "flag": "tail"}] + \
+            [{"x": images, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
+            [{"adv": arr, "out_idx": "roi_tail", "flag": "clean"}]
+    L = [ref_det.compute_loss(*fwd(d)) for d in dicts]
+    loss = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    k1, c1 = _checksums(model)
+    assert k1 == k0
+    rec.update(step_loss=_np(loss), step_losses=np.array([float(v) for v in L], dtype=np.float32), ck1=c1,
+               adv_image_sub=_np(adv_image.detach()[:, :, ::4, ::4]))
+    np.savez_compressed(os.path.join(OUT, "det_frcnn_r101.npz"), **rec)
+    print("det_frcnn_r101: forward losses", rec["fwd_losses"].tolist(), "iteration loss", float(loss), [round(float(v), 4) for v in L],
+          "proposals", tuple(seen["proposals"].shape), "params with grad", len(named), "keys", len(k0))
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
     _shims()
@@ -623,5 +778,10 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True)
         from oracle import afan_oracle as _orc
         gen_detection(_orc)
+    elif sys.argv[1:] == ["frcnn"]:       # only the Faster-RCNN fixture (own process: Detection/ goes on sys.path)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        os.makedirs(OUT, exist_ok=True)
+        gen_detection_model()
     else:
         main()

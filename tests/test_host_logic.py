@@ -105,3 +105,24 @@ def test_no_convolution_leaves_the_library(pkg):
         txt = open(path).read()
         assert not re.search(r"aten\.convolution|convolution_backward|cudnn_convolution|miopen_convolution", txt), path
         assert not re.search(r"functional\.conv2d|F\.conv2d|F\.linear|functional\.linear", txt), path
+
+
+def test_faster_rcnn_seeded_construction_equals_the_reference(pkg):
+    """cv_a-fan_amd/det_model.py creates, default-initialises and re-initialises its modules in the reference's order
+    (Detection/model.py:23-38, backbone/resnet101_ori.py:130-171, rpn/region_proposal_network.py:15-36): from the same seed it
+    holds the reference's tensors bit for bit, under the reference's 1 268 state_dict keys — including the `_bn_modules.*` and
+    `detection.hidden.*` aliases (tests/golden/det_frcnn_r101.npz `ck_init`, from the reference's own Model)."""
+    import numpy as np
+    import torch
+    from conftest import golden
+    g = golden("det_frcnn_r101")
+    torch.manual_seed(7)
+    m = pkg.det_model.fasterrcnn_resnet101(21, pooler_mode="pooling", anchor_sizes=(64,), rpn_pre_nms_top_n=200, rpn_post_nms_top_n=64)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]] and len(sd) == 1268
+    ck = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in sd.values()])
+    np.testing.assert_array_equal(ck, g["ck_init"])
+    assert sd["detection.hidden.0.conv1.weight"].data_ptr() == sd["features.layer4.0.conv1.weight"].data_ptr()
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("features.layer1.") for n in frozen) and "features.conv1.weight" in frozen
+    assert all(("bn" in n or "downsample.1" in n or n.startswith(("features.conv1", "features.layer1"))) for n in frozen)
