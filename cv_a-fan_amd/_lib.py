@@ -73,6 +73,8 @@ SIGNATURES = {
     "afan_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),
     "afan_ce2d_workspace_floats": (_l, [_l]),
     "afan_ce2d": (_i, [_p, _p, _i, _l, _l, _l, _l, _f, _p, _p, _p, _p]),
+    "afan_ce2d_upsampled_workspace_floats": (_l, [_l, _l, _l, _l, _l, _l]),
+    "afan_ce2d_upsampled": (_i, [_p, _p, _l, _l, _l, _l, _l, _l, _l, _f, _p, _p, _p, _p]),
     "afan_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _p]),
     "afan_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _p]),
     "afan_maxpool2d_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _i, _p]),

@@ -233,6 +233,158 @@ __global__ __launch_bounds__(BLOCK) void ce2d_finalize_kernel(const float* ws, i
     if (threadIdx.x == 0) loss[0] = s / ws[0];
 }
 
+// ---- bilinear resize + per-pixel cross-entropy + its gradient back at the LOW resolution, fused --------------------------
+// Segmentation/network/utils.py:30,45 resizes the classifier's [N, C, h, w] logits to the image size and main_aug_final.py:95's
+// criterion takes the mean cross-entropy over the H x W pixels; the backward resizes the [N, C, H, W] gradient back.  Every
+// PGD pass and every perturbed forward does that (9 of an iteration's 10 passes need no full-resolution logits at all): four
+// trips of a 44 MB tensor through HBM (2 x 21 x 513 x 513 fp32) for 0.7 MB of information.  Here a workgroup owns a 16 x 16
+// tile of OUTPUT pixels: it stages the <= 6 x 6 source pixels the tile reads, computes each pixel's interpolated logits,
+// soft-max, loss and gradient ONCE (into LDS), and folds the tile's gradient onto its source window (per-axis weight tables
+// in LDS; separably: rows, then columns).  A source pixel on a tile border receives parts from up to four tiles: they are
+// written as per-tile partials and summed by a second small kernel in tile order — deterministic, no atomics.  Values:
+// afan_upsample_bilinear_fwd + afan_ce2d to the bit; the gradient's resize-backward is the same linear map with its double sum
+// associated separably and by tile (rounding-level differences against afan_upsample_bilinear_bwd).  Measured (rocprofv3,
+// 2 x 21 x 129 x 129 -> 513 x 513): 70 us + 7 us gather against 35 + 23 + 51 us for the three kernels it replaces — the
+// kernel is instruction-bound (~15 k instructions per wave: the soft-max of 21 classes per pixel and runtime-C index math),
+// no longer HBM-bound; 1.5 % of a DeepLab iteration.
+constexpr int UP_OT = 16;        // output tile side
+constexpr int UP_SW = 8;         // upper bound of the source window side the kernel accepts (checked by the host)
+
+__global__ __launch_bounds__(BLOCK) void ce2d_up_kernel(const float* __restrict__ lo, const int64_t* __restrict__ target,
+                                                        float* __restrict__ part, int C, int h, int w, int H, int W, float sh,
+                                                        float sw, int64_t ignore, float grad_scale,
+                                                        const float* __restrict__ ws_count, float* __restrict__ loss_part,
+                                                        int tiles_x, int tiles_y, int want_grad) {
+    extern __shared__ float lds_up[];
+    float* gt = lds_up;                           // [256][C]  gradients w.r.t. the interpolated logits
+    float* st = gt + BLOCK * C;                   // [SH * SW][C] source logits of the tile's window
+    __shared__ float wy[UP_SW][UP_OT], wx[UP_SW][UP_OT];
+    const int tile = blockIdx.x % (tiles_x * tiles_y), n = blockIdx.x / (tiles_x * tiles_y);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * UP_OT, y1 = (y0 + UP_OT < H ? y0 + UP_OT : H) - 1;
+    const int x0 = tx * UP_OT, x1 = (x0 + UP_OT < W ? x0 + UP_OT : W) - 1;
+    const int s0 = src_index(sh, y0, h).i0, s1 = src_index(sh, y1, h).i1;
+    const int t0 = src_index(sw, x0, w).i0, t1 = src_index(sw, x1, w).i1;
+    const int SH_ = s1 - s0 + 1, SW_ = t1 - t0 + 1;
+    const float* base = lo + (int64_t)n * h * w * C;
+    for (int e = threadIdx.x; e < SH_ * SW_ * C; e += BLOCK) {
+        const int c = e % C, p = e / C, r = p / SW_, q = p - r * SW_;
+        st[e] = base[((int64_t)(s0 + r) * w + (t0 + q)) * C + c];
+    }
+    if (threadIdx.x < UP_SW * UP_OT) {            // the two weight tables: [source row of the window][output row of the tile]
+        const int r = threadIdx.x / UP_OT, o = threadIdx.x % UP_OT;
+        wy[r][o] = (r < SH_ && y0 + o <= y1) ? axis_weight(sh, y0 + o, s0 + r, h) : 0.f;
+        wx[r][o] = (r < SW_ && x0 + o <= x1) ? axis_weight(sw, x0 + o, t0 + r, w) : 0.f;
+    }
+    __syncthreads();
+    const float gs = grad_scale / ws_count[0];
+    float loss = 0.f;
+    const int oyl = threadIdx.x / UP_OT, oxl = threadIdx.x % UP_OT, oy = y0 + oyl, ox = x0 + oxl;
+    const bool inside = oy <= y1 && ox <= x1;
+    if (inside) {
+        const Src a = src_index(sh, oy, h), b = src_index(sw, ox, w);
+        const int64_t t = target[((int64_t)n * H + oy) * W + ox];
+        const float* r0 = st + ((a.i0 - s0) * SW_ - t0) * C;
+        const float* r1 = st + ((a.i1 - s0) * SW_ - t0) * C;
+        float l[CE_MAX_C];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CE_MAX_C; ++c) {
+            if (c < C) {    // ATen's association, as upsample_fwd_kernel
+                const float p00 = r0[b.i0 * C + c], p01 = r0[b.i1 * C + c], p10 = r1[b.i0 * C + c], p11 = r1[b.i1 * C + c];
+                l[c] = a.l0 * (b.l0 * p00 + b.l1 * p01) + a.l1 * (b.l0 * p10 + b.l1 * p11);
+            } else {
+                l[c] = -INFINITY;
+            }
+            m = fmaxf(m, l[c]);
+        }
+        const bool live = t != ignore;
+        const bool bad = live && (t < 0 || t >= C);
+        float lt = 0.f, s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_MAX_C; ++c) {
+            if (c == (int)t) lt = l[c];
+            l[c] = c < C ? expf(l[c] - m) : 0.f;
+            s += l[c];
+        }
+        const float inv = 1.f / s;
+        if (live && !bad) loss += logf(s) + m - lt;
+        if (bad) loss = NAN;
+        if (want_grad) {
+#pragma unroll
+            for (int c = 0; c < CE_MAX_C; ++c) {
+                float g = 0.f;
+                if (live && !bad) g = (l[c] * inv - (c == (int)t ? 1.f : 0.f)) * gs;
+                if (c < C) gt[threadIdx.x * C + c] = g;
+            }
+        }
+    } else if (want_grad) {
+        for (int c = 0; c < C; ++c) gt[threadIdx.x * C + c] = 0.f;
+    }
+    __syncthreads();
+    if (want_grad) {
+        // the tile's gradient folded onto its source window, separably: rows first (T[r][b][c] = sum_a wy[r][a] g[a][b][c]),
+        // then columns (P[r][q][c] = sum_b wx[q][b] T[r][b][c]); both sums ascending, every operand from LDS, no branches
+        float* T = st;                              // (the staged source logits are dead: reuse their LDS; SH*16*C <= 8*16*C floats
+        float* P = part + (int64_t)blockIdx.x * UP_SW * UP_SW * C;   //  are reserved behind gt by the host)
+        for (int e = threadIdx.x; e < SH_ * UP_OT * C; e += BLOCK) {
+            const int c = e % C, p = e / C, r = p / UP_OT, b = p - r * UP_OT;
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < UP_OT; ++a) acc += wy[r][a] * gt[(a * UP_OT + b) * C + c];
+            T[e] = acc;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < SH_ * SW_ * C; e += BLOCK) {
+            const int c = e % C, p = e / C, r = p / SW_, q = p - r * SW_;
+            float acc = 0.f;
+#pragma unroll
+            for (int b = 0; b < UP_OT; ++b) acc += wx[q][b] * T[(r * UP_OT + b) * C + c];
+            P[(r * UP_SW + q) * C + c] = acc;
+        }
+    }
+    loss = block_sum256(loss);
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = loss;
+}
+
+// dlo[n, si, sj, c] = sum over the output tiles whose source window holds (si, sj), tile rows then tile columns ascending
+__global__ __launch_bounds__(BLOCK) void ce2d_up_gather_kernel(const float* __restrict__ part, float* __restrict__ dlo, int C, int h,
+                                                               int w, int H, int W, float sh, float sw, float ish, float isw,
+                                                               int tiles_x, int tiles_y, int64_t total) {
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < total; v += (int64_t)gridDim.x * BLOCK) {
+        const int c = (int)(v % C);
+        int64_t t = v / C;
+        const int sj = (int)(t % w);
+        t /= w;
+        const int si = (int)(t % h), n = (int)(t / h);
+        int a0, a1, b0, b1;
+        out_range(ish, si, H, a0, a1);
+        out_range(isw, sj, W, b0, b1);
+        float acc = 0.f;
+        for (int ty = a0 / UP_OT; ty <= a1 / UP_OT && ty < tiles_y; ++ty) {
+            const int y0 = ty * UP_OT, y1 = (y0 + UP_OT < H ? y0 + UP_OT : H) - 1;
+            const int s0 = src_index(sh, y0, h).i0, s1 = src_index(sh, y1, h).i1;
+            if (si < s0 || si > s1) continue;
+            for (int tx = b0 / UP_OT; tx <= b1 / UP_OT && tx < tiles_x; ++tx) {
+                const int x0 = tx * UP_OT, x1 = (x0 + UP_OT < W ? x0 + UP_OT : W) - 1;
+                const int t0 = src_index(sw, x0, w).i0, t1 = src_index(sw, x1, w).i1;
+                if (sj < t0 || sj > t1) continue;
+                const int64_t blk = ((int64_t)n * tiles_y + ty) * tiles_x + tx;
+                acc += part[(blk * UP_SW * UP_SW + (si - s0) * UP_SW + (sj - t0)) * C + c];
+            }
+        }
+        dlo[v] = acc;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void ce2d_up_finalize_kernel(const float* __restrict__ ws_count, const float* __restrict__ part,
+                                                                 int G, float* loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < G; i += BLOCK) s += part[i];
+    s = block_sum256(s);
+    if (threadIdx.x == 0) loss[0] = s / ws_count[0];
+}
+
 // ---- max pooling: k x k windows, stride s, padding p (3/2/1: backbone/resnet.py:146; 2/2/0 and the global one: Detection/
 // roi/pooler.py:43, model.py:285) -------------------------------------------------------------------------------------------
 // first maximum in (h, w) scan order, NaN wins (ATen's CPU kernel: `val > maxval || isnan(val)`), so that the backward
@@ -793,6 +945,65 @@ int afan_ce2d(const float* logits, const int64_t* target, int layout, int64_t n,
     else ce2d_kernel<false><<<G, BLOCK, 0, st>>>(logits, target, dlogits, (int)c, hw, P, ignore_index, grad_scale, workspace, G);
     AFAN_LAUNCH_CHECK();
     ce2d_finalize_kernel<<<1, BLOCK, 0, st>>>(workspace, G, loss);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// host copy of src_index's i0 (same fp32 expression): the widest source window an output tile reads
+static int host_src_i0(float scale, int dst, int in_size) {
+    float s = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    if (s < 0.f) s = 0.f;
+    int i0 = (int)s;
+    return i0 > in_size - 1 ? in_size - 1 : i0;
+}
+static int up_window(int in_size, int out_size) {
+    const float scale = (float)in_size / (float)out_size;
+    int worst = 0;
+    for (int y0 = 0; y0 < out_size; y0 += UP_OT) {
+        const int y1 = (y0 + UP_OT < out_size ? y0 + UP_OT : out_size) - 1;
+        const int s0 = host_src_i0(scale, y0, in_size), s1 = host_src_i0(scale, y1, in_size) + 1;
+        if (s1 - s0 + 1 > worst) worst = s1 - s0 + 1;
+    }
+    return worst;
+}
+
+int64_t afan_ce2d_upsampled_workspace_floats(int64_t n, int64_t c, int64_t h, int64_t w, int64_t ho, int64_t wo) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0 || ho <= 0 || wo <= 0) return 0;
+    const int64_t tiles = n * ((ho + UP_OT - 1) / UP_OT) * ((wo + UP_OT - 1) / UP_OT);
+    return 1 + (int64_t)ce2d_blocks(n * ho * wo) + tiles + tiles * UP_SW * UP_SW * c;
+}
+
+int afan_ce2d_upsampled(const float* logits, const int64_t* target, int64_t n, int64_t c, int64_t h, int64_t w, int64_t ho,
+                        int64_t wo, int64_t ignore_index, float grad_scale, float* workspace, float* loss, float* dlogits,
+                        afan_stream_t stream) {
+    if (n <= 0 || h <= 0 || w <= 0 || ho < h || wo < w || c <= 0 || c > CE_MAX_C) return AFAN_ESHAPE;
+    if (!logits || !target || !workspace || !loss) return AFAN_ENULL;
+    if (!aligned(logits, 4) || !aligned(target, 8) || !aligned(workspace, 4)) return AFAN_EALIGN;
+    if (up_window((int)h, (int)ho) > UP_SW || up_window((int)w, (int)wo) > UP_SW) return AFAN_ESHAPE;   // (down-scaling: not this kernel)
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = n * ho * wo;
+    const int Gc = ce2d_blocks(P);
+    const int tx = (int)((wo + UP_OT - 1) / UP_OT), ty = (int)((ho + UP_OT - 1) / UP_OT);
+    const int G2 = (int)(n * tx * ty);
+    float* loss_part = workspace + 1 + Gc;
+    float* part = loss_part + G2;
+    const size_t lds = ((size_t)BLOCK * c + (size_t)UP_SW * UP_OT * c) * 4;      // gt + max(source window, row-folded T)
+    AFAN_PROF("ce2d_upsampled_kernel", (double)P * 8.0 + 4.0 * n * h * w * c * (dlogits ? 2 : 1), st);
+    ce2d_count_kernel<<<Gc, BLOCK, 0, st>>>(target, P, ignore_index, workspace + 1);
+    AFAN_LAUNCH_CHECK();
+    ce2d_fold_count_kernel<<<1, BLOCK, 0, st>>>(workspace, Gc);
+    AFAN_LAUNCH_CHECK();
+    const float sh = (float)h / (float)ho, sw = (float)w / (float)wo, ish = (float)ho / (float)h, isw = (float)wo / (float)w;
+    ce2d_up_kernel<<<G2, BLOCK, lds, st>>>(logits, target, part, (int)c, (int)h, (int)w, (int)ho, (int)wo, sh, sw, ignore_index,
+                                           grad_scale, workspace, loss_part, tx, ty, dlogits ? 1 : 0);
+    AFAN_LAUNCH_CHECK();
+    if (dlogits) {
+        const int64_t total = n * h * w * c;
+        ce2d_up_gather_kernel<<<grid_for(total, BLOCK, 4096), BLOCK, 0, st>>>(part, dlogits, (int)c, (int)h, (int)w, (int)ho, (int)wo, sh,
+                                                                             sw, ish, isw, tx, ty, total);
+        AFAN_LAUNCH_CHECK();
+    }
+    ce2d_up_finalize_kernel<<<1, BLOCK, 0, st>>>(workspace, loss_part, G2, loss);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -205,6 +205,35 @@ class _CE2dFn(torch.autograd.Function):
         return dl * (g / ctx.scale), None, None, None
 
 
+class _CE2dUpFn(torch.autograd.Function):
+    """criterion(F.interpolate(logits, labels' size, 'bilinear'), labels) on the LOW-resolution logits (afan_ce2d_upsampled):
+    resize, loss and the gradient back at low resolution in one kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, grad_scale):
+        logits = _dense(logits)
+        loss, dl = ops.ce2d_upsampled(logits, target, ignore_index, grad_scale)
+        ctx.save_for_backward(dl)
+        ctx.scale = grad_scale
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        if g.data_ptr() == ops.one(g.device).data_ptr():
+            return dl, None, None, None
+        return dl * (g / ctx.scale), None, None, None
+
+
+class LowResLogits:
+    """What `model(input_dict)` returns instead of image-size logits when the dict carries "low_res": True: the classifier's
+    own [N, C, h, w] output plus the size utils.py:30,45 would resize it to.  seg_criterion's callable takes it directly."""
+    __slots__ = ("logits", "size")
+
+    def __init__(self, logits, size):
+        self.logits, self.size = logits, (int(size[0]), int(size[1]))
+
+
 def seg_criterion(criterion):
     """`criterion` as the step applies it to the upsampled logits: a plain nn.CrossEntropyLoss(ignore_index=I,
     reduction='mean') becomes the one-pass HIP form on GPU fp32 logits of up to 32 classes; anything else is unchanged.
@@ -216,11 +245,16 @@ def seg_criterion(criterion):
     ign = criterion.ignore_index
 
     def ce(out, y, grad_scale=1.0):
+        if isinstance(out, LowResLogits):
+            if tuple(y.shape[1:]) == out.size and y.dtype == torch.int64 and ops.ce2d_upsampled_ok(out.logits, out.size):
+                return _CE2dUpFn.apply(out.logits, y, ign, float(grad_scale))
+            out = interpolate(out.logits, out.size)
         if (out.is_cuda and out.dtype == torch.float32 and out.dim() == 4 and out.shape[1] <= ops.CE2D_MAX_CLASSES
                 and y.dtype == torch.int64 and y.dim() == 3):
             return _CE2dFn.apply(out, y, ign, float(grad_scale))
         return criterion(out, y)
     ce.fused = True
+    ce.low_res = os.environ.get("AFAN_CE_LOWRES", "1") != "0"      # (0: always resize first — A/B)
     return ce
 
 
@@ -574,7 +608,9 @@ class DeepLabV3(nn.Module):
         self.classifier.channels_last = self.channels_last
         return self
 
-    def _up(self, x, input_shape):
+    def _up(self, x, input_shape, low_res=False):
+        if low_res and x.is_cuda and x.dtype == torch.float32:
+            return LowResLogits(x, input_shape)        # the criterion resizes inside its own kernel (seg_criterion)
         return interpolate(x, input_shape)
 
     def forward_clean_folded(self, x, se_idx, sd_idx, pgd0=False):
@@ -590,15 +626,16 @@ class DeepLabV3(nn.Module):
             return self.backbone(input_dict)
         assert flag in ("tail", "clean")
         idx = input_dict["out_idx"]
+        lr = bool(input_dict.get("low_res", False))
         if type(idx) == int:
             features = self.backbone(input_dict)
-            return self._up(self.classifier(features), input_dict["x"].shape[-2:])
+            return self._up(self.classifier(features), input_dict["x"].shape[-2:], lr)
         if idx in ("aspp_head", "concat_head"):
             features = self.backbone(input_dict)
             features["adv"] = self.classifier(features, return_type=idx)
             return features
         assert idx in ("aspp_tail", "concat_tail")
-        return self._up(self.classifier(input_dict["adv"], return_type=idx), input_dict["x"].shape[-2:])
+        return self._up(self.classifier(input_dict["adv"], return_type=idx), input_dict["x"].shape[-2:], lr)
 
 
 class _FoldedClean:

@@ -78,6 +78,8 @@ def _workspace(ref, nfloats, tag):
 # BatchNorm sums in f64 accumulators (no partial slabs, no finalize launches) where the channel count allows it;
 # AFAN_BN_ACC=0 selects the partial-slab path everywhere (bitwise run-to-run reproducible, ~0.45 more launches per BN).
 BN_ACC = os.environ.get("AFAN_BN_ACC", "1") != "0"
+# stand-alone BatchNorm-backward reductions of tensors up to this many elements use the accumulator form (0: never)
+BN_BWD_ACC_MAX = int(os.environ.get("AFAN_BN_BWD_ACC_MAX", "0"))
 _ACC_DOUBLES = 1 << 20
 _acc_arenas = {}
 
@@ -570,6 +572,11 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     ready = acc is not None
     if groups != 1 and acc is None:
         raise ValueError("grouped BatchNorm backward needs the accumulators of a grouped dgrad")
+    if acc is None and partials is None and 0 < x.numel() <= BN_BWD_ACC_MAX and bn_acc_ok(x) and layout_of(x) == AFAN_NHWC:
+        # small maps: the reduction's block sums go to the f64 accumulators and the apply kernel folds them in its prologue —
+        # no partial slab, no finalize launch (on large maps the atomics of a stand-alone reduction arrive as one burst and
+        # serialise per address: the slab + finalize form stays there)
+        acc = acc_take(x.device, c)
     if acc is not None:
         check(lib.afan_bn_backward_acc(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
                                        _ptr(stats), int(bool(relu)), _ptr(acc), int(ready), _ptr(dweight), _ptr(dbias),
@@ -901,6 +908,34 @@ def ce2d(logits, target, ignore_index=255, grad_scale=1.0, want_grad=True):
     ws = _workspace(logits, lib.afan_ce2d_workspace_floats(n * h * w), "ce2d")
     check(lib.afan_ce2d(_ptr(logits), _ptr(target), layout_of(logits), n, c, h * w, int(ignore_index), float(grad_scale),
                         _ptr(ws), _ptr(loss), _ptr(dl), _stream(logits)), "afan_ce2d")
+    return loss, dl
+
+
+def ce2d_upsampled_ok(logits, size):
+    """The fused resize + cross-entropy kernel takes channels-last fp32 logits of up to 32 classes, resized UP."""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4 and logits.shape[1] <= CE2D_MAX_CLASSES):
+        return False
+    h, w = logits.shape[2:]
+    if layout_of(logits) != AFAN_NHWC and not (logits.shape[1] == 1 or h * w == 1):
+        return False
+    return size[0] >= h and size[1] >= w
+
+
+def ce2d_upsampled(logits, target, ignore_index=255, grad_scale=1.0, want_grad=True):
+    """nn.CrossEntropyLoss(ignore_index)(F.interpolate(logits, target.shape[1:], 'bilinear'), target) and its gradient
+    w.r.t. the LOW-resolution logits in one kernel: (loss [1], grad_scale * d(loss)/d(logits) | None)."""
+    lib = _lib.load()
+    _need(logits, "logits", torch.float32)
+    n, c, h, w = logits.shape
+    if target.dim() != 3 or target.dtype != torch.int64 or not target.is_cuda or target.shape[0] != n:
+        raise TypeError("ce2d_upsampled: logits [N,C,h,w] fp32 channels-last and target [N,H,W] int64 on the GPU")
+    ho, wo = int(target.shape[1]), int(target.shape[2])
+    target = target.contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = _workspace(logits, lib.afan_ce2d_upsampled_workspace_floats(n, c, h, w, ho, wo), "ce2d_up")
+    check(lib.afan_ce2d_upsampled(_ptr(logits), _ptr(target), n, c, h, w, ho, wo, int(ignore_index), float(grad_scale), _ptr(ws),
+                                  _ptr(loss), _ptr(dl), _stream(logits)), "afan_ce2d_upsampled")
     return loss, dl
 
 

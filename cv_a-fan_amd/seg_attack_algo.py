@@ -44,6 +44,17 @@ def _ascend(x_adv, logits_of, criterion, y, gamma, x, eps, clip):
     ops.pgd_step_(x_adv, grad, gamma, x, eps, clip)          # one launch: sign step (+ projection)
 
 
+def _low_res(criterion):
+    """True when `criterion` is seg_criterion's fused callable: the model may then hand back its low-resolution logits
+    (deeplab.LowResLogits) and the criterion resizes inside its own kernel (afan_ce2d_upsampled)."""
+    return bool(getattr(criterion, "low_res", False))
+
+
+def _f32_logits(o):
+    o = getattr(o, "logits", o)
+    return o.is_cuda and o.dtype == torch.float32
+
+
 def _first_step(x_adv, grad0, gamma, x, eps, clip):
     """The first ascent step from a gradient the caller already has (a positive multiple of d(loss)/d(x) at x itself)."""
     g = grad0.detach()
@@ -64,7 +75,7 @@ def PGD(x, image_batch, low_level_feat, criterion, y=None, model=None, steps=3, 
             _first_step(x_adv, grad0, gamma, x, eps, clip)
             continue
         _ascend(x_adv, lambda t: model({"x": image_batch, "adv": t, "out_idx": idx, "flag": "tail",
-                                        "low_level_feat": low_level_feat}), criterion, y, gamma, x, eps, clip)
+                                        "low_level_feat": low_level_feat, "low_res": _low_res(criterion)}), criterion, y, gamma, x, eps, clip)
     return x_adv.requires_grad_(True)
 
 
@@ -81,7 +92,7 @@ def decoder_PGD(input_dict, image_batch, criterion, y=None, model=None, steps=3,
         def logits_of(t):
             d = dict(input_dict)
             d["adv"] = t
-            return model({"x": image_batch, "adv": d, "out_idx": idx + "_tail", "flag": "clean"})
+            return model({"x": image_batch, "adv": d, "out_idx": idx + "_tail", "flag": "clean", "low_res": _low_res(criterion)})
         if t == 0 and grad0 is not None:
             _first_step(x_adv, grad0, gamma, None, 0.0, False)
         else:
@@ -188,14 +199,15 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     else:
         o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
     with adv_bn():
-        o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
-        o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low})
-        o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean"})
+        lr = _low_res(criterion)        # the perturbed forwards' full-resolution logits are never looked at: loss only
+        o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
+        o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
+        o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean", "low_res": lr})
     if pgd0:
         # the clean term went through the tail already; what it left at the cut (SE point, low-level feature) enters the
         # head graph now, together with what the perturbed forwards send into it through `low`
         extra_t, extra_g = [fc.fm_se, fc.low], [fc.se_in.grad, fc.low_in.grad]
-        if fused and all(o.is_cuda and o.dtype == torch.float32 for o in (o1, o2, o3)):
+        if fused and all(_f32_logits(o) for o in (o1, o2, o3)):
             l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o1, o2, o3), wts[1:]))
             one = ops.one(images.device)
             torch.autograd.backward([l1, l2, l3] + extra_t, [one, one, one] + extra_g)
@@ -204,7 +216,7 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
             torch.autograd.backward([0.1 * l1 + 0.1 * l2 + 0.1 * l3] + extra_t, [None] + extra_g)
         with torch.no_grad():
             loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
-    elif fused and all(o.is_cuda and o.dtype == torch.float32 for o in (o0, o1, o2, o3)):
+    elif fused and all(_f32_logits(o) for o in (o0, o1, o2, o3)):
         # every term's stored gradient already carries its weight: four roots, no scaling passes over the logits
         l0, l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o0, o1, o2, o3), wts))
         with torch.no_grad():

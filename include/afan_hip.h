@@ -349,6 +349,16 @@ int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, 
 int64_t afan_ce2d_workspace_floats(int64_t pixels);
 int afan_ce2d(const float* logits, const int64_t* target, int layout, int64_t n, int64_t c, int64_t hw, int64_t ignore_index,
               float grad_scale, float* workspace, float* loss, float* dlogits, afan_stream_t stream);
+/* The same loss taken on logits that Segmentation/network/utils.py:30,45 first resizes bilinearly (align_corners=False) from
+ * [n,h,w,c] (channels-last fp32, c <= 32) to the labels' [n,ho,wo] — resize, cross-entropy and both backward passes in ONE
+ * pass over 16 x 16 output tiles (+ a small gather of per-tile partials), the gradient returned at the LOW resolution:
+ * dlogits [n,h,w,c] (nullable) = grad_scale * d(loss)/d(logits).  The arithmetic is afan_upsample_bilinear_fwd + afan_ce2d +
+ * afan_upsample_bilinear_bwd operation for operation (sums grouped by tile: equal to rounding) without the four passes over
+ * the [n,ho,wo,c] tensor.  ho >= h, wo >= w (up-scaling); deterministic; workspace: afan_ce2d_upsampled_workspace_floats(...). */
+int64_t afan_ce2d_upsampled_workspace_floats(int64_t n, int64_t c, int64_t h, int64_t w, int64_t ho, int64_t wo);
+int afan_ce2d_upsampled(const float* logits, const int64_t* target, int64_t n, int64_t c, int64_t h, int64_t w, int64_t ho,
+                        int64_t wo, int64_t ignore_index, float grad_scale, float* workspace, float* loss, float* dlogits,
+                        afan_stream_t stream);
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (backbone/resnet.py:146): ho = (hi-1)/2+1.  The backward routes each
  * output gradient to the FIRST maximum of its window in (h, w) scan order, NaN winning — ATen's CPU rule. */
 int afan_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,

@@ -66,6 +66,37 @@ def test_ce2d_vs_torch(pkg, gpu, n, c, h, w, nhwc):
     np.testing.assert_allclose(dl7.cpu().numpy(), 0.7 * lr.grad.numpy(), rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("n,c,h,w,H,W", [(2, 21, 33, 33, 129, 129), (1, 21, 129, 129, 513, 513), (2, 5, 9, 13, 33, 41), (1, 32, 7, 5, 7, 5),
+                                         (3, 2, 1, 1, 4, 4)])
+def test_ce2d_upsampled_equals_resize_then_ce(pkg, gpu, n, c, h, w, H, W):
+    """afan_ce2d_upsampled (resize + cross-entropy + both backward passes in one kernel, gradient at the low resolution)
+    against the three-kernel path it replaces — same operations, sums grouped by output tile: equal to rounding — and against torch's CPU F.interpolate + nn.CrossEntropyLoss(ignore_index) with autograd."""
+    g = torch.Generator().manual_seed(n * c + h)
+    lo = torch.randn(n, c, h, w, generator=g) * 2
+    y = torch.randint(0, c, (n, H, W), generator=g)
+    y[torch.rand(n, H, W, generator=g) < 0.1] = 255
+    lod = lo.to(gpu).contiguous(memory_format=torch.channels_last)
+    yd = y.to(gpu)
+    loss, dl = pkg.ops.ce2d_upsampled(lod, yd, 255, 0.7)
+    up = pkg.ops.upsample_bilinear(lod, (H, W))
+    loss3, dup = pkg.ops.ce2d(up, yd, 255, 0.7)
+    dl3 = pkg.ops.upsample_bilinear_backward(dup, (h, w))
+    # same operations; a source pixel on a tile border sums its (up to four) tiles' parts instead of one running sum
+    np.testing.assert_allclose(dl.cpu().numpy(), dl3.cpu().numpy(), rtol=2e-6, atol=1e-9)
+    assert abs(float(loss) - float(loss3)) <= 2e-6 * max(1.0, abs(float(loss3)))
+    lo64 = lo.double().requires_grad_(True)
+    ref = nn.CrossEntropyLoss(ignore_index=255)(F.interpolate(lo64, size=(H, W), mode="bilinear", align_corners=False), y)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    np.testing.assert_allclose(dl.cpu().numpy(), 0.7 * lo64.grad.numpy(), rtol=2e-4, atol=1e-7)
+    # through the model-facing callable: a LowResLogits object in, the same loss and gradient out
+    crit = pkg.deeplab.seg_criterion(nn.CrossEntropyLoss(ignore_index=255))
+    lod2 = lod.clone().requires_grad_(True)
+    l2 = crit(pkg.deeplab.LowResLogits(lod2, (H, W)), yd, grad_scale=0.7)
+    torch.autograd.backward([l2], [pkg.ops.one(gpu)])
+    assert torch.equal(lod2.grad, dl) and float(l2) == float(loss)
+
+
 def test_ce2d_edge_cases(pkg, gpu):
     logits = torch.randn(1, 4, 3, 3, device=gpu)
     all_ign = torch.full((1, 3, 3), 255, dtype=torch.int64, device=gpu)
