@@ -434,6 +434,12 @@ def main():
             else:
                 sched = (f"main_aug_final.py:158-232 as written: head pass + clean decoder-head pass, {K_} SE + {K_} SD PGD passes, "
                          "clean / SE1 / SE2 / SD forwards, one joint backward")
+            if trainer._phased() and r.get("fold_clean"):
+                lo_, hi_ = trainer._tail_range()
+                b_ = trainer.arena.offsets + [trainer.arena.numel]
+                sched += (f"; data parallel: the backward runs in two captured parts, the all-reduce of the tail's gradients "
+                          f"({(b_[hi_] - b_[lo_]) * 4 / 2 ** 20:.0f} MiB of {trainer.arena.numel * 4 / 2 ** 20:.0f} MiB: layer4, ASPP, decoder) "
+                          "starts between them on a side stream, the head's follows the second part")
         else:
             metric = ("images/sec (whole node) A-FAN K=5 train step, ResNet-18/CIFAR-10" if default_cfg else
                       f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}")

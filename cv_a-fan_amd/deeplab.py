@@ -613,8 +613,8 @@ class DeepLabV3(nn.Module):
             return LowResLogits(x, input_shape)        # the criterion resizes inside its own kernel (seg_criterion)
         return interpolate(x, input_shape)
 
-    def forward_clean_folded(self, x, se_idx, sd_idx, pgd0=False):
-        return _folded_clean_forward(self, x, se_idx, sd_idx, pgd0)
+    def forward_clean_folded(self, x, se_idx, sd_idx, pgd0=False, cut=False):
+        return _folded_clean_forward(self, x, se_idx, sd_idx, pgd0, cut)
 
     def fold_ok(self, x):
         """Can the iteration's three clean forwards run as one (forward_clean_folded)?"""
@@ -640,7 +640,7 @@ class DeepLabV3(nn.Module):
 
 class _FoldedClean:
     """What DeepLabV3.forward_clean_folded hands back (see there)."""
-    __slots__ = ("low", "fm_se", "dec", "logits", "_recs", "se_in", "low_in", "sd_t")
+    __slots__ = ("low", "low_graph", "fm_se", "dec", "logits", "_recs", "se_in", "low_in", "sd_t")
 
     def replay_sd_pgd0_bn(self):
         """With the first PGD passes folded in as well: the decoder-PGD's first pass (main_aug_final.py:179-181) updates the
@@ -654,7 +654,7 @@ class _FoldedClean:
             r.replay()
 
 
-def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False):
+def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False, cut=False):
     """The three clean forwards of a Segmentation A-FAN iteration as ONE pass (the fold of DESIGN section 4, for
     main_aug_final.py:166-193): `model(head, out_idx=se_idx)` (:166), `model(clean, out_idx=sd_idx + "_head")` (:167) and
     `model(clean, out_idx=0)` (:193) evaluate the same layers on the same images with the same weights — the backbone up
@@ -686,12 +686,17 @@ def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False):
         low = h
         for st in stages[1:se_idx]:
             h = st(h)
-    out.fm_se, out.low = h, low
+    out.fm_se, out.low, out.low_graph = h, low, low
     out.se_in = out.low_in = out.sd_t = None
     low_dec = low
-    if pgd0:
+    if pgd0 or cut:
+        # cut = True (seg_train_phases): the same cuts without the pgd0 fold, so that the joint backward can run in two
+        # parts (tail, then head) and a data-parallel caller can exchange the tail's gradients in between.  out.low stays the
+        # leaf the perturbed forwards and PGD passes read too (their gradients w.r.t. the low-level feature accumulate in
+        # low_in.grad and enter the head with the rest); out.low_graph is the head-graph tensor the caller back-propagates from.
         out.se_in = h = h.detach().requires_grad_(True)
         out.low_in = low_dec = low.detach().requires_grad_(True)
+        out.low = low_dec
     drop = head.aspp.project[3]
     with ops.bn_running_updates(2 if pgd0 else 1), ops.record_bn_updates() as rec_mid:
         for st in stages[se_idx:]:
@@ -713,7 +718,7 @@ def _folded_clean_forward(self, x, se_idx, sd_idx, pgd0=False):
             else:
                 adv = head._concat(low_p.detach(), drop(pre.detach()))
             logits = head._classify(head._concat(low_p, drop(pre)))   # :193's own draw
-    out.dec = {"out": h, "low_level": low, "adv": adv}
+    out.dec = {"out": h, "low_level": out.low, "adv": adv}
     out.logits = self._up(logits, x.shape[-2:])
     out._recs = (rec_mid, rec_late)
     return out

@@ -122,12 +122,24 @@ def _dropout_active(model):
     return False
 
 
-def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
-                   pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                   clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None):
+def seg_train_step(model, optimizer, criterion, images, labels, **kw):
     """One iteration of Segmentation/main_aug_final.py:158-232: SE feature PGD + SD decoder PGD, three SAT sample points
     (`get_sample_points`), `mix_feature` where --mix_layer / --mix_sd say so, four forwards, loss = 0.7*clean +
-    0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34)."""
+    0.1*(se1 + se2 + sd), backward, optimizer step.  Flags carry the reference's names (args.py:19-34); see seg_train_phases."""
+    out = {}
+    for _ in seg_train_phases(model, optimizer, criterion, images, labels, out, **kw):
+        pass
+    return out
+
+
+def seg_train_phases(model, optimizer, criterion, images, labels, out, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
+                     pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
+                     clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None):
+    """The iteration as a generator (data-parallel callers, seg_trainer.SegTrainer): with the folded clean pass the graph is
+    cut at the SE point and at the low-level feature, the joint backward runs in two parts — everything behind the cuts
+    (layer4, ASPP, decoder: 53 % of the parameters), then the head — and the generator yields "tail" in between: those
+    layers' gradients are final there and their exchange can fly while the head's backward computes.  `out` is filled with
+    the step's observables at the end."""
     from .deeplab import seg_criterion
     f0, f1 = int(mix_layer[0]), int(mix_layer[1])
     criterion = seg_criterion(criterion)        # one-pass HIP cross-entropy for a plain nn.CrossEntropyLoss(ignore_index=...)
@@ -155,7 +167,7 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
     wts = (0.7, 0.1, 0.1, 0.1)                                       # main_aug_final.py:216
     fused = getattr(criterion, "fused", False)
     if fold:
-        fc = model.forward_clean_folded(images, pertub_idx_se, pertub_idx_sd, pgd0)
+        fc = model.forward_clean_folded(images, pertub_idx_se, pertub_idx_sd, pgd0, cut=True)
         dec, low = fc.dec, fc.low
         fm_sd, fm_se = dec["adv"].detach().float(), fc.fm_se.detach().float()
         if pgd0:
@@ -203,17 +215,15 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
         o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
         o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
         o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean", "low_res": lr})
+    one = ops.one(images.device) if images.is_cuda else None
     if pgd0:
-        # the clean term went through the tail already; what it left at the cut (SE point, low-level feature) enters the
-        # head graph now, together with what the perturbed forwards send into it through `low`
-        extra_t, extra_g = [fc.fm_se, fc.low], [fc.se_in.grad, fc.low_in.grad]
+        # the clean term went through the tail already (what it left at the cuts enters the head graph below)
         if fused and all(_f32_logits(o) for o in (o1, o2, o3)):
             l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o1, o2, o3), wts[1:]))
-            one = ops.one(images.device)
-            torch.autograd.backward([l1, l2, l3] + extra_t, [one, one, one] + extra_g)
+            torch.autograd.backward([l1, l2, l3], [one, one, one])
         else:
             l1, l2, l3 = (criterion(o, labels) for o in (o1, o2, o3))
-            torch.autograd.backward([0.1 * l1 + 0.1 * l2 + 0.1 * l3] + extra_t, [None] + extra_g)
+            (0.1 * l1 + 0.1 * l2 + 0.1 * l3).backward()
         with torch.no_grad():
             loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
     elif fused and all(_f32_logits(o) for o in (o0, o1, o2, o3)):
@@ -221,14 +231,20 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
         l0, l1, l2, l3 = (criterion(o, labels, grad_scale=w) for o, w in zip((o0, o1, o2, o3), wts))
         with torch.no_grad():
             loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
-        one = ops.one(images.device)
         torch.autograd.backward([l0, l1, l2, l3], [one, one, one, one])
     else:
         l0, l1, l2, l3 = (criterion(o, labels) for o in (o0, o1, o2, o3))
         loss = 0.7 * l0 + 0.1 * l1 + 0.1 * l2 + 0.1 * l3
         loss.backward()
+    if fold:
+        # behind the cuts everything is final: layer4 / ASPP / decoder parameter gradients can be exchanged now
+        yield "tail"
+        cut_t = [t for t, g in ((fc.fm_se, fc.se_in.grad), (fc.low_graph, fc.low_in.grad)) if g is not None]
+        cut_g = [g for g in (fc.se_in.grad, fc.low_in.grad) if g is not None]
+        if cut_t:
+            torch.autograd.backward(cut_t, cut_g)               # the head, traversed once
     if not defer_step:          # (data-parallel callers all-reduce the gradient arena first: seg_trainer.SegTrainer)
         optimizer.step()
-    return {"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
+    out.update({"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach(),
-            "fold_clean": bool(fold), "fold_pgd0": bool(pgd0)}          # (which schedule ran: bench.py reports it)
+            "fold_clean": bool(fold), "fold_pgd0": bool(pgd0)})         # (which schedule ran: bench.py reports it)

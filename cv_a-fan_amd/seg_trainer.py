@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import ops, resnet_s
 from .arena import ArenaSGD, ParamArena
 from .deeplab import PolyLR, set_bn_momentum
-from .seg_attack_algo import seg_train_step
+from .seg_attack_algo import seg_train_phases, seg_train_step
 
 
 class SegTrainer:
@@ -22,7 +22,7 @@ class SegTrainer:
                  pertub_idx_sd="aspp", mix_layer="11", mix_sd=False, noise_sd=0.0, randinit=False, clip=False, lr=0.01,
                  momentum=0.9, weight_decay=1e-4, total_itrs=30000, lr_policy="poly", step_size=10000,
                  backbone_bn_momentum=0.01, use_graph=True, graph_warmup=2, dual_bn=False, fold_clean=None, group=None,
-                 allreduce_chunks=4, fold_pgd0=None):
+                 allreduce_chunks=4, fold_pgd0=None, segmented=None):
         self.model = model
         if dual_bn:      # BASELINE configs[3] "+ dual-BN": an option the reference does not have (resnet_s.enable_dual_bn); default off
             resnet_s.enable_dual_bn(model)
@@ -59,22 +59,81 @@ class SegTrainer:
             self.kw["defer_step"] = True
         self.use_graph = bool(use_graph) and not randinit and noise_sd == 0
         self.graph_warmup = graph_warmup
-        self._graph = self._graph_failed = self._static = self._out = self._key = None
+        self._graph = self._graph_failed = self._static = self._out = self._key = self._pieces = None
+        self.segmented = bool(segmented)      # True: run the two-phase (cut) schedule on one GPU too (tests)
+        if self.segmented:
+            self.kw["defer_step"] = True
         self._eager_steps = 0
 
     def _body(self, images, labels):
         return seg_train_step(self.model, self.optimizer, self.criterion, images, labels, **self.kw)
 
+    # ---- data parallel: the tail's gradients (everything behind the SE point: layer4, ASPP, decoder — 53 % of DeepLabv3+
+    # ResNet-101's 58.7 M parameters, the LAST contiguous range of the arena) are final when seg_train_phases yields "tail";
+    # their all-reduce starts there, on the side stream, and runs under the head's backward.  The rest follows at finish().
+    def _tail_range(self):
+        se = self.kw["pertub_idx_se"]
+        if type(se) != int:
+            return None
+        pre = tuple(f"backbone.layer{k}." for k in range(se + 1, 5)) + ("classifier.",)
+        idx = [i for i, n in enumerate(self.arena.names) if n.startswith(pre)]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            return None
+        return idx[0], idx[-1] + 1
+
+    def _phased(self):
+        return self.segmented or self.reducer is not None
+
+    def _run_phases(self, images, labels):
+        """Eager iteration through seg_train_phases: the tail's exchange is launched at the yield."""
+        out, rng = {}, self._tail_range()
+        if self.reducer is not None:
+            self.reducer.begin(explicit=True)
+        for ph in seg_train_phases(self.model, self.optimizer, self.criterion, images, labels, out, **self.kw):
+            if ph == "tail" and self.reducer is not None and rng is not None:
+                self.reducer.launch_params(*rng)
+        return out
+
     def _exchange_and_step(self):
         if self.reducer is not None:
-            self.reducer.begin(explicit=True)      # nothing was announced during the backward: finish() reduces everything
-            self.reducer.finish()
+            self.reducer.finish()      # whatever no launch_params() announced is reduced here
+            self.optimizer.step()
+        elif self.segmented:
             self.optimizer.step()
 
     def _graph_safe(self):
         if resnet_s.vendor_convs(self.model):
             self.use_graph = False
         return self.use_graph
+
+    def _capture(self, images, labels):
+        dev = images.device
+        self._static = (images.clone(), labels.clone())
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        self.optimizer._sync_lr()
+        if not self._phased():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                out = self._body(self._static[0], self._static[1])
+            self._pieces = [(g, None)]
+            return out
+        # one hipGraph per phase (shared memory pool): between two replays the host starts the tail's all-reduce
+        out, pieces, pool = {}, [], None
+        gen = seg_train_phases(self.model, self.optimizer, self.criterion, self._static[0], self._static[1], out, **self.kw)
+        done = False
+        while not done:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
+                try:
+                    ph = next(gen)
+                except StopIteration:
+                    ph, done = None, True
+            pieces.append((g, ph))
+            pool = pieces[0][0].pool()
+        self._pieces = pieces
+        return out
 
     def step(self, images, labels):
         """One iteration (device tensors only; the scheduler is NOT stepped here — call `trainer.scheduler.step()` once
@@ -84,23 +143,21 @@ class SegTrainer:
             self._static[0].copy_(images, non_blocking=True)
             self._static[1].copy_(labels, non_blocking=True)
             self.optimizer._sync_lr()
-            self._graph.replay()
+            rng = self._tail_range()
+            if self.reducer is not None:
+                self.reducer.begin(explicit=True)
+            for g, ph in self._pieces:
+                g.replay()
+                if ph == "tail" and self.reducer is not None and rng is not None:
+                    self.reducer.launch_params(*rng)
             self._exchange_and_step()
             small = ("loss", "losses")
             return {k: (v.clone() if k in small else v) for k, v in self._out.items()}
         if (self.use_graph and self._graph is None and self._graph_failed is None and images.is_cuda
                 and self._eager_steps >= self.graph_warmup and self.model.training and self._graph_safe()):
             try:
-                dev = images.device
-                self._static = (images.clone(), labels.clone())
-                stream = torch.cuda.Stream(device=dev)
-                stream.wait_stream(torch.cuda.current_stream(dev))
-                torch.cuda.synchronize(dev)
-                self.optimizer._sync_lr()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                    out = self._body(self._static[0], self._static[1])
-                self._graph, self._out, self._key = g, out, key
+                out = self._capture(images, labels)
+                self._graph, self._out, self._key = self._pieces[0][0], out, key
                 return self.step(images, labels)
             except Exception as e:  # noqa: BLE001 — stay correct: fall back to eager launches, loudly
                 import warnings
@@ -109,6 +166,6 @@ class SegTrainer:
                 torch.cuda.synchronize()
         self._eager_steps += 1
         self.optimizer._sync_lr()
-        out = self._body(images, labels)
+        out = self._run_phases(images, labels) if self._phased() else self._body(images, labels)
         self._exchange_and_step()
         return out

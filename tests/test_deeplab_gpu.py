@@ -253,6 +253,53 @@ def test_deeplab_full_size_properties(pkg, gpu):
     np.testing.assert_allclose(out["graph"], out["eager"], rtol=0, atol=5e-3)
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_phased_iteration_equals_the_plain_one(pkg, gpu, dropout):
+    """The data-parallel schedule on ONE GPU (SegTrainer(segmented=True)): the joint backward in two parts with a yield in
+    between (seg_attack_algo.seg_train_phases), captured as one hipGraph per part, the optimizer step after the last.
+    Same kernels in the same order as the one-graph iteration: parameters after three iterations are bit-identical, and the
+    tail's parameter range — what the trainer hands to the all-reduce at the yield — is final at the yield."""
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(2, 3, 129, 129, generator=g).to(gpu)
+    labels = torch.randint(0, 21, (2, 129, 129), generator=g).to(gpu)
+    res = {}
+    for mode in ("plain", "phased_eager", "phased_graph"):
+        torch.manual_seed(3)
+        model = pkg.deeplab.deeplabv3plus_resnet50(num_classes=21, output_stride=16)
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = dropout
+        model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+        tr = pkg.seg_trainer.SegTrainer(model, steps=2, lr=0.01, use_graph=(mode != "phased_eager"), graph_warmup=1,
+                                        segmented=(mode != "plain"))
+        torch.manual_seed(9)
+        pkg.ops._dropout_state.clear()              # the device-side dropout generator is re-seeded from torch's CPU generator
+        for _ in range(3):
+            r = tr.step(images, labels)
+            tr.scheduler.step()
+        if mode != "phased_eager":
+            assert tr._graph is not None, tr._graph_failed
+            assert len(tr._pieces) == (2 if mode == "phased_graph" else 1)
+            if mode == "phased_graph":
+                assert [ph for _, ph in tr._pieces] == ["tail", None]
+        res[mode] = (tr.arena.param.clone(), float(r["loss"]))
+        if mode == "phased_eager":
+            # at the yield the tail's gradient range is final: the rest of the backward leaves it alone
+            lo, hi = tr._tail_range()
+            bounds = tr.arena.offsets + [tr.arena.numel]
+            assert hi == len(tr.arena.params) and 0.3 < (bounds[hi] - bounds[lo]) / tr.arena.numel < 0.8
+            out, snap = {}, None
+            for ph in pkg.seg_attack_algo.seg_train_phases(model, tr.optimizer, tr.criterion, images, labels, out, **tr.kw):
+                assert ph == "tail"
+                snap = tr.arena.grad[bounds[lo]:bounds[hi]].clone()
+                head_before = tr.arena.grad[:bounds[lo]].clone()
+            assert snap is not None and torch.equal(snap, tr.arena.grad[bounds[lo]:bounds[hi]])
+            assert float(snap.abs().sum()) > 0
+            assert not torch.equal(head_before, tr.arena.grad[:bounds[lo]])
+    assert torch.equal(res["plain"][0], res["phased_eager"][0])
+    assert torch.equal(res["plain"][0], res["phased_graph"][0])
+
+
 def test_deeplab_checkpoint_interchange(pkg, orc, gpu):
     """state_dict round trip with the reference layout (oracle.SegDeepLabV3Plus has the reference's keys, verified against
     the reference's own network by tests/test_oracle_golden.py) and the two-group optimizer state_dict layout."""

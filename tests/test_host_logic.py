@@ -126,3 +126,21 @@ def test_faster_rcnn_seeded_construction_equals_the_reference(pkg):
     frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
     assert any(n.startswith("features.layer1.") for n in frozen) and "features.conv1.weight" in frozen
     assert all(("bn" in n or "downsample.1" in n or n.startswith(("features.conv1", "features.layer1"))) for n in frozen)
+
+
+def test_seg_trainer_tail_range_is_the_arena_suffix_behind_the_se_point(pkg):
+    """What SegTrainer hands to the all-reduce at seg_train_phases' "tail" yield: the contiguous arena range of the layers
+    behind the SE point (backbone.layer{se+1..4} + classifier) — the LAST parameters in registration order, 53 % of
+    DeepLabv3+ ResNet-101; every earlier parameter belongs to the head and is reduced at finish()."""
+    import types
+    model = pkg.deeplab.deeplabv3plus_resnet101(num_classes=21, output_stride=16)
+    arena = pkg.arena.ParamArena(model, skip=(), bf16_shadow=False, allow_cpu=True)
+    bounds = arena.offsets + [arena.numel]
+    for se, frac in ((3, (0.5, 0.56)), (2, (0.9, 1.0)), (4, (0.1, 0.4))):
+        stub = types.SimpleNamespace(kw={"pertub_idx_se": se}, arena=arena)
+        lo, hi = pkg.seg_trainer.SegTrainer._tail_range(stub)
+        assert hi == len(arena.params)
+        assert all(not n.startswith(tuple(f"backbone.layer{k}." for k in range(se + 1, 5)) + ("classifier.",)) for n in arena.names[:lo])
+        share = (bounds[hi] - bounds[lo]) / arena.numel
+        assert frac[0] < share < frac[1], (se, share)
+    assert pkg.seg_trainer.SegTrainer._tail_range(types.SimpleNamespace(kw={"pertub_idx_se": "aspp"}, arena=arena)) is None
