@@ -64,7 +64,6 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--layout", default="nhwc", choices=["nhwc", "nchw"], help="internal activation layout")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
-    ap.add_argument("--async_wgrad", action="store_true", help="weight gradients on a side stream (measured: no gain)")
     ap.add_argument("--no_batch_final", action="store_true", help="run the adv and clean final passes separately (A/B)")
     ap.add_argument("--no_fold_clean", action="store_true", help="separate first PGD pass and final clean pass (A/B)")
     ap.add_argument("--no_fold_pgd0", action="store_true", help="DeepLab: keep the first pass of both PGD loops separate from the clean pass (A/B)")
@@ -299,7 +298,7 @@ def main():
                                              perturb_idx=idx, lr=0.1, use_graph=not args.no_graph,
                                              batch_final=not args.no_batch_final, share_head=not args.no_share_head,
                                              fold_clean=(False if args.no_fold_clean else (True if args.force_fold_clean else None)),
-                                             async_wgrad=args.async_wgrad, dual_bn=args.dual_bn)
+                                             dual_bn=args.dual_bn)
         side, ncls = ARCH_INPUT.get(args.arch, (32, 10))
         xs = [torch.rand(args.batch, 3, side, side, generator=g).to(dev) for _ in range(nbuf)]
         ys = [torch.randint(0, ncls, (args.batch,), generator=g).to(dev) for _ in range(nbuf)]

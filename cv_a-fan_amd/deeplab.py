@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .resnet_s import (BatchNorm2d, Conv2d, NormalizeByChannelMeanStd, _BlockFn, _ConvFn, _Flags, _accumulates_in_place,
+from .resnet_s import (BatchNorm2d, Conv2d, NormalizeByChannelMeanStd, _BlockFn, _ConvFn, _Flags, _WgradStream, _accumulates_in_place,
                        _block_fast_path_ok, _block_params, _dense, _like_layout, _to_compute)
 
 __all__ = ["deeplabv3plus_resnet50", "deeplabv3plus_resnet101", "deeplabv3_resnet50", "deeplabv3_resnet101", "DeepLabV3",
@@ -163,9 +163,13 @@ class _PointwiseFn(torch.autograd.Function):
                 dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
                 db = torch.empty_like(bias) if bias is not None else None
         g = g.contiguous(memory_format=torch.channels_last)
-        dx = ops.pointwise_backward(g, x, weight.detach(), ctx.needs_input_grad[0], dw, db, accumulate=direct)
-        if direct:
+        wd = weight.detach()
+        if direct:      # the 100-us parameter-gradient launch off the critical path (resnet_s._WgradStream)
+            dx = ops.pointwise_backward(g, x, wd, True, None, None) if ctx.needs_input_grad[0] else None
+            _WgradStream.run(lambda dw=dw, db=db: ops.pointwise_backward(g, x, wd, False, dw, db, accumulate=True), g, x)
             dw = db = None
+        else:
+            dx = ops.pointwise_backward(g, x, wd, ctx.needs_input_grad[0], dw, db, accumulate=False)
         return dx, dw, db, None
 
 

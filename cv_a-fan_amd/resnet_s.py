@@ -27,17 +27,10 @@ __all__ = ["ResNet", "ResNet50", "BasicBlock", "Bottleneck", "resnet20", "resnet
 class _Flags:
     param_grads = True  # False inside PGD: only d(loss)/d(feature) is needed (attack_algo.py:52 only_inputs=True)
     weight_epoch = 0    # bumped by the arena's fused SGD step (it updates weights without touching tensor versions)
-    wgrad_stream = None  # side stream for weight-gradient kernels (set by AfanTrainer; None = same stream)
     block_fusion = True  # BasicBlock as one autograd node on the bf16 channels-last fast path (_BlockFn)
     wgrad_stash = False  # True: block weight gradients are not launched but their operands kept on the conv module (stash_wgrad)
     bn_groups = 1        # 2: the batch is [adv half | clean half]; BatchNorm statistics / running updates per half, in order
     bn_branch = "main"   # "adv" inside bn_branch(model, "adv"): BatchNorms with an auxiliary set use it (dual-BN option)
-
-
-def join_wgrad_stream():
-    """Make the current stream wait for the weight-gradient kernels issued on the side stream (before SGD / all-reduce)."""
-    if _Flags.wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(_Flags.wgrad_stream)
 
 
 @contextlib.contextmanager
@@ -225,22 +218,14 @@ class _ConvFn(torch.autograd.Function):
             direct = _accumulates_in_place(w_master)
             if own and ops.conv_wgrad_supported(x.shape[1], gy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
                 if direct and (w_master.grad.is_contiguous(memory_format=torch.channels_last) or k == 1):
-                    # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd.
-                    # Weight gradients are off the backward's critical path (the dgrad -> BN-backward chain), so they go to
-                    # a side stream and fill the SIMD slots the latency-bound chain leaves idle; joined before the SGD step.
-                    side = _Flags.wgrad_stream
-                    if side is not None:
-                        side.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(side):
-                            ops.conv_wgrad(x, gy, k, st, w_master.grad, accumulate=True, dilation=dil)
-                        x.record_stream(side)
-                        gy.record_stream(side)
-                    else:
-                        ops.conv_wgrad(x, gy, k, st, w_master.grad, accumulate=True, dilation=dil)
+                    # summed by the kernel straight into the fp32 gradient arena (KRSC): nothing goes back through autograd
+                    g_ = w_master.grad
+                    _WgradStream.run(lambda: ops.conv_wgrad(x, gy, k, st, g_, accumulate=True, dilation=dil), x, gy)
                 else:
                     gw = ops.conv_wgrad(x, gy, k, st, dilation=dil)
             elif direct and _dense_weight(w_master.grad):
-                ops.conv_general_wgrad(x, gy, k, st, pad, dil, grad=w_master.grad, accumulate=True)
+                g_ = w_master.grad
+                _WgradStream.run(lambda: ops.conv_general_wgrad(x, gy, k, st, pad, dil, grad=g_, accumulate=True), x, gy)
             else:
                 gw = ops.conv_general_wgrad(x, gy, k, st, pad, dil)
         if need_gb:
@@ -252,15 +237,80 @@ def _dense_weight(g):
     return g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)
 
 
+class _WgradStream:
+    """Weight-gradient launches off the critical path: nothing in the backward waits for a weight gradient, so while the
+    autograd engine runs (and the switch is on), `_wgrad_accumulate` issues its launches on ONE side stream per device —
+    ordered after the producer of dy by an event, in program order among themselves, so the sums into the fp32 gradient
+    arena happen in the same order as on the main stream: bit-identical results (tests/test_graph_safety_gpu.py) — and the
+    engine's end-of-backward callback makes the main stream wait for it.  Tensors the launches read are held until that
+    join.  In a captured iteration the side stream is a parallel branch of the hipGraph.  Measured (MI355X, graph replay):
+    DeepLabv3+ R101 513^2 batch 8: 55.2 -> 52.6 ms; batch 2: 25.3 -> 25.5; ResNet-18 batch 256: 9.82 -> 9.95 — the replayed
+    graph overlaps the TAILS of neighbouring independent kernels, it does not run branches side by side (batching the side
+    launches in groups of 8-64 loses the gain: 55.3 ms), so it pays where kernels are long.  Hence off by default; the
+    trainers switch it on by workload size (seg_trainer.SegTrainer) and AFAN_WGRAD_STREAM=1/0 forces it."""
+    FORCE = os.environ.get("AFAN_WGRAD_STREAM")      # "1" / "0": override every trainer's choice (A/B)
+    ON = FORCE == "1"
+    streams = {}
+    held = []
+    mains = []
+
+    @classmethod
+    def run(cls, fn, *tensors):
+        t0 = tensors[0]
+        if not cls.ON or not t0.is_cuda or torch._C._current_graph_task_id() < 0:
+            return fn()                                 # outside a backward (flush_wgrad, direct calls): nothing to overlap with
+        dev = t0.device
+        side = cls.streams.get(dev.index)
+        if side is None:
+            side = cls.streams[dev.index] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        if not cls.held:
+            torch.autograd.Variable._execution_engine.queue_callback(cls.join)
+        if main not in cls.mains:
+            cls.mains.append(main)
+        cls.held.append(tensors)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+
+    @classmethod
+    def join(cls):
+        for main in cls.mains:
+            side = cls.streams.get(main.device.index)
+            if side is not None:
+                main.wait_stream(side)
+        cls.mains.clear()
+        cls.held.clear()
+
+
+@contextlib.contextmanager
+def wgrad_stream(on):
+    """Weight gradients of the backward passes inside this context on the side stream (see _WgradStream)."""
+    old = _WgradStream.ON
+    _WgradStream.ON = bool(on) if _WgradStream.FORCE is None else _WgradStream.FORCE == "1"
+    try:
+        yield
+    finally:
+        _WgradStream.ON = old
+
+
 def _wgrad_accumulate(x, dy, c):
-    """Weight gradient of conv module c added into its arena gradient view: the tuned bf16 kernels where they tile, else
-    the general fp32-arithmetic kernel on the same bf16 tensors."""
+    """Weight gradient of conv module c added into its arena gradient view (queued on the weight-gradient stream while a
+    backward runs, see _WgradStream)."""
+    if _Flags.wgrad_stash and ops.conv_wgrad_supported(x.shape[1], dy.shape[1], c.kernel_size[0], c.stride[0],
+                                                       (x.shape[0], x.shape[2], x.shape[3])) \
+            and ops.wgrad_pairable(x, dy, c.kernel_size[0], c.stride[0]):
+        c._pending_wgrad = (x, dy)          # summed into the launch of the next pass over this layer (stash_wgrad)
+        return
+    pend = getattr(c, "_pending_wgrad", None)
+    _WgradStream.run(lambda: _wgrad_launch(x, dy, c), x, dy, pend)
+
+
+def _wgrad_launch(x, dy, c):
+    """The tuned bf16 kernels where they tile, else the general fp32-arithmetic kernel on the same bf16 tensors."""
     k, st, dil = c.kernel_size[0], c.stride[0], c.dilation[0]
     if ops.conv_wgrad_supported(x.shape[1], dy.shape[1], k, st, (x.shape[0], x.shape[2], x.shape[3])):
         pairable = ops.wgrad_pairable(x, dy, k, st)
-        if _Flags.wgrad_stash and pairable:
-            c._pending_wgrad = (x, dy)          # summed into the launch of the next pass over this layer (stash_wgrad)
-            return
         pend = getattr(c, "_pending_wgrad", None)
         if pend is not None:
             c._pending_wgrad = None

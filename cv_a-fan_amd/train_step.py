@@ -163,7 +163,7 @@ class AfanTrainer:
 
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
-                 group=None, use_graph=True, graph_warmup=3, async_wgrad=False, batch_final=True,
+                 group=None, use_graph=True, graph_warmup=3, batch_final=True,
                  share_head=True, fold_clean=None, segmented=None, dual_bn=False):
         self.model, self.criterion = model, criterion
         # dual-BN option (off = the reference's single BatchNorm set): adversarial features — every PGD pass and the
@@ -192,10 +192,8 @@ class AfanTrainer:
         self.ddp_overlap = self.world > 1 and os.environ.get("AFAN_DDP_OVERLAP", "1") != "0"
         self.segmented = bool(segmented)          # True: run the segmented (piece-wise) step on one GPU too (tests)
         self._pieces = None
-        self.async_wgrad = bool(async_wgrad)
         self.batch_final = bool(batch_final)      # adv + clean final passes as one grouped pass over the tail
         self._groupable_key, self._groupable = None, False
-        self._wgrad_stream = None
         self.share_head = bool(share_head)
         self.fold_clean = fold_clean if fold_clean is None else bool(fold_clean)
         self._fold_auto = {}
@@ -232,8 +230,7 @@ class AfanTrainer:
         launches the launch-bound networks lost with it (ResNet-56s, batch 128: 11.19 -> 11.40 ms); with the shared
         launches everything measured wins: ResNet-56s 10.99 -> 10.76 ms, ResNet-20s 3.87 -> 3.71, ResNet-18 batch 256
         11.10 -> 10.03, ResNet-50/224 batch 64 31.7 -> 26.9."""
-        if self.fold_clean is False or not (self._share_head(inp) and self.steps >= 1 and not self.randinit
-                                            and not self.async_wgrad):
+        if self.fold_clean is False or not (self._share_head(inp) and self.steps >= 1 and not self.randinit):
             return False
         if self.fold_clean is None:
             key = tuple(inp.shape)
@@ -450,20 +447,11 @@ class AfanTrainer:
         if overlap_allreduce:
             self.reducer.begin()
         from . import resnet_s
-        if self.async_wgrad and inp.is_cuda:
-            if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=inp.device)
-            resnet_s._Flags.wgrad_stream = self._wgrad_stream
-            self._wgrad_stream.wait_stream(torch.cuda.current_stream())   # zero_grad before any accumulation
-        try:
-            if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
-                from . import ops as _ops
-                loss.backward(gradient=_ops.one(loss.device))
-            else:
-                loss.backward()
-        finally:
-            resnet_s.join_wgrad_stream()
-            resnet_s._Flags.wgrad_stream = None
+        if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+            from . import ops as _ops
+            loss.backward(gradient=_ops.one(loss.device))
+        else:
+            loss.backward()
         with torch.no_grad():
             prec1 = (output_clean.argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])
         return {"loss": loss.detach(), "loss_adv": loss_adv.detach(), "loss_clean": loss_clean.detach(),

@@ -132,3 +132,49 @@ def test_ragged_last_batch_runs_eagerly_beside_the_graph(pkg, gpu, orc):
     assert abs(float(r["loss"]) - float(r_ref["loss"])) < 8e-2
     r2 = tr.step(x.to(gpu), y.to(gpu))                      # the captured shape again: replay
     assert tr._graph is not None and math.isfinite(float(r2["loss"])) and r2["l2"].shape == (64,)
+
+
+@pytest.mark.parametrize("what", ["resnet18", "deeplab"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_weight_gradient_stream_changes_no_bit(pkg, gpu, what, graph):
+    """Weight-gradient launches on a side stream during the backward (resnet_s._WgradStream: a parallel branch of the
+    captured graph; switched on by workload size), joined by the autograd engine's end-of-backward callback.  They stay in
+    program order among themselves, so the fp32 sums into the gradient arena are the same sums: parameters after three iterations equal, bit for bit, those
+    of a run with everything on one stream — which also shows that no launch reads a buffer another stream has recycled."""
+    ws = pkg.resnet_s._WgradStream
+    g = torch.Generator().manual_seed(1)
+    if what == "resnet18":
+        x, y = torch.rand(64, 3, 32, 32, generator=g).to(gpu), torch.randint(0, 10, (64,), generator=g).to(gpu)
+    else:
+        x, y = torch.rand(2, 3, 129, 129, generator=g).to(gpu), torch.randint(0, 21, (2, 129, 129), generator=g).to(gpu)
+    res, old, force = {}, ws.ON, ws.FORCE
+    ws.FORCE = None
+    try:
+        for on in (True, False):
+            torch.manual_seed(0)
+            if what == "resnet18":
+                model = pkg.resnet_s.ARCHS["resnet18"][0]()
+                model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+                tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=2, gamma=0.5, eps=2.0, perturb_idx=6, lr=0.01,
+                                                use_graph=graph, graph_warmup=1)
+            else:
+                model = pkg.deeplab.deeplabv3plus_resnet50(num_classes=21, output_stride=16)
+                for m in model.modules():
+                    if isinstance(m, nn.Dropout):
+                        m.p = 0.0
+                model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+                tr = pkg.seg_trainer.SegTrainer(model, steps=2, lr=0.01, use_graph=graph, graph_warmup=1, wgrad_stream=on)
+                assert tr._wgrad_side(x) == on
+                assert pkg.seg_trainer.SegTrainer.WGRAD_STREAM_MIN_PIXELS <= 8 * 513 * 513      # the batch-8 configuration uses it
+            for _ in range(3):
+                with pkg.resnet_s.wgrad_stream(on):
+                    r = tr.step(x, y)
+            if graph:
+                assert tr._graph is not None, getattr(tr, "_graph_failed", None)
+            torch.cuda.synchronize()
+            assert not ws.held and not ws.mains          # joined at the end of every backward
+            res[on] = (tr.arena.param.clone(), float(r["loss"]))
+    finally:
+        ws.ON, ws.FORCE = old, force
+    assert math.isfinite(res[True][1])
+    assert torch.equal(res[True][0], res[False][0])

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-dispatch durations of a bench run, aggregated by (kernel, grid): gpurun_out/${TAG}_trace_by_grid.txt
-#   bash tools/gpu_trace.sh TAG [bench.py args...]
+#   [ALL=1 TOP=150] bash tools/gpu_trace.sh TAG [bench.py args...]      (ALL: every kernel, not only the convolutions)
 TAG=${1:-x}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -14,8 +14,8 @@ rows = list(csv.DictReader(open(f)))
 print(rows[0].keys())
 for r in rows:
     name = r['Kernel_Name']
-    if 'conv' not in name and 'wgrad' not in name and 'stem' not in name: continue
-    short = name.split('(')[0][-60:]
+    if not os.environ.get('ALL') and 'conv' not in name and 'wgrad' not in name and 'stem' not in name: continue
+    short = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-70:]
     key = (short, r.get('Grid_Size_X', r.get('Grid_Size')), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'), r.get('Workgroup_Size_X', r.get('Workgroup_Size')))
     agg[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 out = []
@@ -24,7 +24,7 @@ for k, v in agg.items():
     out.append((sum(v), k, len(v), v[len(v)//2], v[0], v[-1]))
 out.sort(reverse=True)
 with open('gpurun_out/%s_trace_by_grid.txt' % os.environ.get('TAG', 'x'), 'w') as fo:
-    for tot, k, n, med, lo, hi in out[:60]:
+    for tot, k, n, med, lo, hi in out[:int(os.environ.get('TOP', 60))]:
         line = f"{tot/1e6:9.3f} ms  n={n:5d} med={med/1e3:7.1f}us min={lo/1e3:7.1f} max={hi/1e3:7.1f}  {k}"
         print(line); fo.write(line + "\n")
 PY
