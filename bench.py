@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 BF16_DENSE_PEAK_TFLOPS = 2500.0
+F32_MFMA_PEAK_TFLOPS = 157.3
 # reference-schedule convolution / linear FLOPs per image (4H + (2K+6)T), for the secondary figure only
 REF_GFLOP_PER_IMAGE = {("resnet18", 5): 14.1, ("resnet56s", 5): 2.99, ("resnet50", 3): 85.5}
 ARCH_INPUT = {"resnet50": (224, 1000)}                                        # (image side, classes); default (32, 10)
@@ -359,14 +360,18 @@ def main():
         hand_ms = round(sum(q["ms"] for q in prof.values()) / NP, 3)
         if v["flops"] > 0:      # MFMA-bound kernel: algorithmic FLOPs / measured launch time vs the dense bf16 peak
             ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+            f32k = "_f32_" in name      # the general kernels multiply in fp32 (v_mfma_f32_32x32x2_f32): priced against the f32 matrix peak
+            peak = F32_MFMA_PEAK_TFLOPS if f32k else BF16_DENSE_PEAK_TFLOPS
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                     "algo_flops_per_launch": round(v["flops"] / v["launches"]),
                     "handwritten_ms_per_step": hand_ms,
-                    "peak_note": "nominal dense bf16 MFMA peak (MI355X_MICROARCH.md); measured on this chip: bare MFMA loop "
-                                 "1.75-2.1 PFLOP/s, LDS -> MFMA consumer loop on random operands 1.13-1.41 PFLOP/s "
-                                 "(tools/probe/mfma_rate.hip, lds_mfma.hip; DESIGN.md 9.5)"}
+                    "peak_note": ("f32-input MFMA peak (MI355X_MICROARCH.md: 157.3 TFLOP/s, 1/16 of the bf16 rate): fp32 parity mode"
+                                  if f32k else
+                                  "nominal dense bf16 MFMA peak (MI355X_MICROARCH.md); measured on this chip: bare MFMA loop "
+                                  "1.75-2.1 PFLOP/s, LDS -> MFMA consumer loop on random operands 1.13-1.41 PFLOP/s "
+                                  "(tools/probe/mfma_rate.hip, lds_mfma.hip; DESIGN.md 9.5)")}
         else:
             ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -385,8 +390,9 @@ def main():
         conv_ms = sum(q["ms"] for k, q in prof.items() if k.startswith("conv_")) / NP
         if cf > 0:
             tf = cf / (step_ms * 1e-3) / 1e12
+            cpeak = F32_MFMA_PEAK_TFLOPS if args.dtype == "fp32" else BF16_DENSE_PEAK_TFLOPS
             conv_exec = {"executed_GFLOP_per_step": round(cf / 1e9, 1), "achieved_TFLOPs": round(tf, 1),
-                         "peak_TFLOPs": BF16_DENSE_PEAK_TFLOPS, "frac": round(tf / BF16_DENSE_PEAK_TFLOPS, 4),
+                         "peak_TFLOPs": cpeak, "frac": round(tf / cpeak, 4),
                          "conv_kernel_ms_per_step_eager": round(conv_ms, 3),
                          "in_kernel_TFLOPs": round(cf / (conv_ms * 1e-3) / 1e12, 1) if conv_ms > 0 else None,
                          "note": "FLOPs of the convolution launches the step EXECUTES (summed over the instrumented pass), "

@@ -35,6 +35,7 @@ int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, v
 int acc_supported(int dtype, int64_t C);
 int64_t acc_doubles(int64_t C);
 int set_running_updates(int n);
+int coefs(int64_t C, const float* mean, const float* invstd, const float* w, const float* b, float* out, hipStream_t st);
 }
 
 namespace {
@@ -600,6 +601,25 @@ int afan_bn_apply(const void* x, const void* residual, void* y, int dtype, int l
     if (dtype == AFAN_F32)
         return bn_forward_impl<float>(x, residual, y, n, c, hw, 0.f, 0.f, weight, bias, relu, nullptr, m, is, nullptr, nullptr, nullptr, false, st);
     return bn_forward_impl<uint16_t>(x, residual, y, n, c, hw, 0.f, 0.f, weight, bias, relu, nullptr, m, is, nullptr, nullptr, nullptr, false, st);
+}
+
+int afan_affine_coefs(const float* mean, const float* invstd, const float* weight, const float* bias, int64_t c,
+                      float* coefs, afan_stream_t stream) {
+    if (c <= 0) return AFAN_ESHAPE;
+    if (!mean || !invstd || !coefs) return AFAN_ENULL;
+    if (!aligned(coefs, 16)) return AFAN_EALIGN;
+    return afan_nhwc::coefs(c, mean, invstd, weight, bias, coefs, (hipStream_t)stream);
+}
+
+int afan_affine_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
+                      const float* coefs, int relu, afan_stream_t stream) {
+    int e = check_common(dtype, n, c, hw);
+    if (e) return e;
+    if (!x || !y || !coefs) return AFAN_ENULL;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(x, a) || !aligned(y, a) || (residual && !aligned(residual, a))) return AFAN_EALIGN;
+    return afan_nhwc::fwd(dtype, x, residual, y, n * hw, c, 0.f, 0.f, nullptr, nullptr, relu, nullptr, const_cast<float*>(coefs),
+                          nullptr, nullptr, nullptr, nullptr, nullptr, false, (hipStream_t)stream, nullptr, 0, nullptr);
 }
 
 int afan_bn_backward(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype, int layout,

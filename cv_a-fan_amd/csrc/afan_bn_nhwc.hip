@@ -672,7 +672,7 @@ int forward(const void* x, const void* res, void* y, int64_t M, int64_t C, float
     } else if (train) {
         int e = run_stats<T>(p, x_, M, C, eps, momentum, weight, bias, ws, stats, rmean, rvar, nbt, st);
         if (e) return e;
-    } else {
+    } else if (mean_in) {       // (mean_in == NULL: `stats` already holds mean | invstd | alpha | beta — afan_affine_apply)
         AFAN_PROF("bn_nhwc_coef_kernel", 24.0 * C, st);
         coef_kernel<<<(unsigned)((C + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>((int)C, mean_in, invstd_in, weight, bias, stats);
         AFAN_LAUNCH_CHECK();
@@ -870,6 +870,12 @@ int bwd(int dtype, const void* dy, const void* x, const void* y, void* dx, void*
     return dtype == AFAN_F32
                ? backward<float>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g)
                : backward<uint16_t>(dy, x, y, dx, dres, M, C, stats_in, relu, ws, dw, db, acc, st, partials, partials_g);
+}
+int coefs(int64_t C, const float* mean, const float* invstd, const float* w, const float* b, float* out, hipStream_t st) {
+    AFAN_PROF("bn_nhwc_coef_kernel", 24.0 * C, st);
+    coef_kernel<<<(unsigned)((C + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>((int)C, mean, invstd, w, b, out);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
 }
 int set_running_updates(int n) {
     const int old = g_running_updates;

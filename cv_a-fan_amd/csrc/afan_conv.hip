@@ -62,7 +62,7 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // 12.0 us, the same plus the DMA 19.8 us, DMA alone 13.8 us on the 256-channel 8x8 layer — the two serialise inside a
 // wave); in a producer wave that stall costs no MFMA slot.
 template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>   // WM x WN waves: pixels x channels
-__global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const ConvP pp) {
+__device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
     constexpr int STG = PW ? 64 * PW : THREADS;       // threads that stage operands
@@ -575,6 +575,18 @@ __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_kernel(const C
     }
 }
 
+// The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward
+// launches from the input-gradient launches: bench.py's roofline names whichever is the larger and profiles/ can be
+// checked against it symbol by symbol.
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_fwd_kernel(const ConvP pp) {
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT>(pp);
+}
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
+__global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_dgrad_kernel(const ConvP pp) {
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT>(pp);
+}
+
 static int64_t max_rows(const ConvP& p) {
     int64_t m = 0;
     for (int c = 0; c < p.n_classes; ++c) {
@@ -585,7 +597,7 @@ static int64_t max_rows(const ConvP& p) {
 }
 
 template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
-int launch(const ConvP& p, hipStream_t st) {
+int launch(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
@@ -594,12 +606,16 @@ int launch(const ConvP& p, hipStream_t st) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, PF, WM, WN, PW, FBT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv_igemm_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
+    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
+    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -624,7 +640,7 @@ int choose_bm(int64_t M, int co, int n_classes) {
 }
 
 
-int dispatch(const ConvP& p, hipStream_t st) {
+int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
     // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
     static const int mode = env_int("AFAN_CONV_MODE", 3);
     static const int force_bm = env_int("AFAN_CONV_BM", 0);   // tuning knobs (tools/conv_bench.py A/B)
@@ -642,18 +658,18 @@ int dispatch(const ConvP& p, hipStream_t st) {
         const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
         static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
         static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
-        if (wgs <= deep_max && spec) return bm == 64 ? launch<64, 128, 5, 2, 2, 4>(p, st) : launch<128, 128, 5, 2, 2, 4>(p, st);
-        if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st) : launch<128, 128, 5, 2, 4>(p, st);   // 4 stages
+        if (wgs <= deep_max && spec) return bm == 64 ? launch<64, 128, 5, 2, 2, 4>(p, st, dgrad) : launch<128, 128, 5, 2, 2, 4>(p, st, dgrad);
+        if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st, dgrad) : launch<128, 128, 5, 2, 4>(p, st, dgrad);   // 4 stages
     }
-    if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st);
+    if (mode == 3 && nw == 16 && n128 && bm == 128) return launch<128, 128, 3, 4, 4>(p, st, dgrad);
     if (mode == 3 && nw >= 8) {
-        if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st) : launch<64, 128, 3, 2, 4>(p, st);
-        if (bm == 128) return launch<128, 64, 3, 4, 2>(p, st);
+        if (n128) return bm == 128 ? launch<128, 128, 3, 2, 4>(p, st, dgrad) : launch<64, 128, 3, 2, 4>(p, st, dgrad);
+        if (bm == 128) return launch<128, 64, 3, 4, 2>(p, st, dgrad);
     }
 #define AFAN_CONV_GO(M)                                                                                      \
     do {                                                                                                     \
-        if (n128) return bm == 128 ? launch<128, 128, M, 2, 2>(p, st) : launch<64, 128, M, 2, 2>(p, st);     \
-        return bm == 128 ? launch<128, 64, M, 2, 2>(p, st) : launch<64, 64, M, 2, 2>(p, st);                 \
+        if (n128) return bm == 128 ? launch<128, 128, M, 2, 2>(p, st, dgrad) : launch<64, 128, M, 2, 2>(p, st, dgrad);     \
+        return bm == 128 ? launch<128, 64, M, 2, 2>(p, st, dgrad) : launch<64, 64, M, 2, 2>(p, st, dgrad);                 \
     } while (0)
     if (mode == 1) AFAN_CONV_GO(1);
     if (mode == 2) AFAN_CONV_GO(2);
@@ -758,7 +774,7 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
         q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
         return afan_c64::launch(q, st);
     }
-    return dispatch(p, st);
+    return dispatch(p, st, false);
 }
 
 // number of partial slots per channel the dgrad launch of this problem writes when asked for fused BN-backward sums
@@ -837,7 +853,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
             }
         if (small_eligible(p)) return small_launch(p, st);
         if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
-        return dispatch(p, st);
+        return dispatch(p, st, true);
     }
     // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
     // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four classes (1/2/2/4 taps for k = 3) in ONE launch.
@@ -868,7 +884,7 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
     p.n_classes = nc;
     if (small_eligible(p)) return small_launch(p, st);
     if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
-    return dispatch(p, st);
+    return dispatch(p, st, true);
 }
 
 // ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------

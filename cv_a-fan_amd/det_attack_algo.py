@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .attack_algo import get_sample_points, linfball_proj, mix_feature, sample_points_mixed, tensor_clamp  # noqa: F401
 from .det_ops import PGD  # noqa: F401  (Detection/attack_algo.py:48-74)
+from .resnet_s import dgrad_only
 
 
 def compute_loss(loss1, loss2, loss3, loss4):
@@ -41,7 +42,8 @@ def _start(x, eps, randinit):
 
 def _ascend(x_adv, loss_of, gamma, x, eps, clip):
     xin = x_adv.detach().requires_grad_(True)
-    grad = torch.autograd.grad(loss_of(xin), xin, only_inputs=True)[0]
+    with dgrad_only():          # only_inputs=True (:66,:103,:170): no parameter gradient is computed, none is touched
+        grad = torch.autograd.grad(loss_of(xin), xin, only_inputs=True)[0]
     if grad.stride() != x_adv.stride():
         grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
     ops.pgd_step_(x_adv, grad, gamma, x, eps if eps is not None else 0.0, clip)     # one launch: sign step (+ projection)

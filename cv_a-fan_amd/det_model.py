@@ -78,16 +78,20 @@ def beta_smooth_l1(inp, target, beta):
 # ------------------------------------------------------------------------------------------------------ fused affine layers
 class _AffineFn(torch.autograd.Function):
     """y = [relu](x * alpha[c] + beta[c] [+ residual]) with coefficients that receive no gradient through this node (a frozen
-    BatchNorm: alpha = w / sqrt(var + eps), beta = b - mean * alpha; a bias: alpha = 1, beta = bias)."""
+    BatchNorm: alpha = w / sqrt(var + eps), beta = b - mean * alpha).  `coefs` [4, C] = mean | invstd | alpha | beta, computed
+    once per set of buffers (FrozenBatchNorm2d._coefs): one launch forward (afan_affine_apply), one backward."""
 
     @staticmethod
-    def forward(ctx, x, mean, invstd, weight, bias, residual, relu):
+    def forward(ctx, x, coefs, residual, relu, wb):
         x = _dense(x)
         if residual is not None:
             residual = _like_layout(residual, x)
-        y = ops.bn_apply(x, mean, invstd, weight, bias, residual, relu)
+        if ops.layout_of(x) == ops.AFAN_NHWC:
+            y = ops.affine_apply(x, coefs, residual, relu)
+        else:       # the reference's layout (fp32 parity mode): the NCHW kernel derives alpha / beta itself, per launch
+            y = ops.bn_apply(x, coefs[0], coefs[1], wb[0], wb[1], residual, relu)
         ctx.relu, ctx.has_res = bool(relu), residual is not None
-        ctx.alpha = None if (weight is None and invstd is None) else (invstd if weight is None else invstd * weight.detach()).contiguous()
+        ctx.alpha = coefs[2]
         ctx.save_for_backward(y if relu else None)
         return y
 
@@ -98,8 +102,8 @@ class _AffineFn(torch.autograd.Function):
         if y is not None and g.dtype != y.dtype:
             g = g.to(y.dtype)
         dx, dres = ops.affine_relu_backward(g, y, ctx.alpha, ctx.relu, want_dx=ctx.needs_input_grad[0],
-                                            want_dres=ctx.has_res and ctx.needs_input_grad[5])
-        return dx, None, None, None, None, dres, None
+                                            want_dres=ctx.has_res and ctx.needs_input_grad[2])
+        return dx, None, dres, None, None
 
 
 class FrozenBatchNorm2d(nn.BatchNorm2d):
@@ -108,13 +112,16 @@ class FrozenBatchNorm2d(nn.BatchNorm2d):
     _coef = None
 
     def _coefs(self):
-        key = (self.running_var._version, self.running_mean._version, self.running_var.data_ptr())
+        ts = (self.running_var, self.running_mean, self.weight, self.bias)
+        key = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts)
         if self._coef is None or self._coef[0] != key:
-            self._coef = (key, torch.rsqrt(self.running_var.float() + self.eps))
+            invstd = torch.rsqrt(self.running_var.float() + self.eps)
+            self._coef = (key, ops.affine_coefs(self.running_mean.float().contiguous(), invstd, self.weight.detach().float().contiguous(),
+                                                self.bias.detach().float().contiguous()))
         return self._coef[1]
 
     def fused(self, x, residual=None, relu=False, conv_stats=None):
-        return _AffineFn.apply(x, self.running_mean, self._coefs(), self.weight, self.bias, residual, relu)
+        return _AffineFn.apply(x, self._coefs(), residual, relu, (self.weight.detach(), self.bias.detach()))
 
     def forward(self, x):
         return self.fused(x)
@@ -430,6 +437,18 @@ class Model(nn.Module):
                                          rpn_post_nms_top_n, anchor_smooth_l1_loss_beta)
         self.detection = Model.Detection(pooler_mode, hidden, num_hidden_out, num_classes, proposal_smooth_l1_loss_beta)
         self.compute_dtype, self.channels_last = torch.float32, False
+
+    def train(self, mode=True):
+        """`model.train().forward(...)` is the reference's calling idiom — once per forward, 21 times per A-FAN iteration
+        (attack_algo.py:24,31, train_aug_sat_muti_advt.py:106-150); nn.Module.train walks all ~430 modules each time
+        (54 ms of host time per iteration).  Walk only when the mode changes (sub-modules switched by hand in between are
+        re-synchronised by any real mode change)."""
+        mode = bool(mode)
+        if self.training == mode and getattr(self, "_mode_walked", None) == mode:
+            return self
+        super().train(mode)
+        self._mode_walked = mode
+        return self
 
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):

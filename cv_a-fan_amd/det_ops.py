@@ -19,6 +19,7 @@ from torch.nn.modules.utils import _pair
 from . import _lib, ops
 from ._lib import check
 from .attack_algo import get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401 (Detection/attack_algo.py:236-265)
+from .resnet_s import dgrad_only
 
 _ws = {}
 
@@ -135,9 +136,10 @@ def PGD(x, image_batch, y=None, model=None, steps=3, eps=None, gamma=None, idx=1
     for _ in range(steps):
         xin = x_adv.detach().requires_grad_(True)
         inputs = {"x": image_batch, "adv": xin, "out_idx": idx, "flag": "tail"}
-        l1, l2, l3, l4 = model.train().forward(inputs, y["bb"], y["lb"])
-        loss = l1.mean() + l2.mean() + l3.mean() + l4.mean()
-        grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
+        with dgrad_only():      # only_inputs=True (:66): the library's layers skip (and must not add into) parameter gradients
+            l1, l2, l3, l4 = model.train().forward(inputs, y["bb"], y["lb"])
+            loss = l1.mean() + l2.mean() + l3.mean() + l4.mean()
+            grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
         if grad.stride() != x_adv.stride():
             grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
         ops.pgd_step_(x_adv, grad, gamma, x, eps if eps is not None else 0.0, clip)

@@ -555,6 +555,32 @@ def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
     return y
 
 
+def affine_coefs(mean, invstd, weight, bias):
+    """coefs [4, C] fp32 = mean | invstd | alpha | beta of y = x * alpha + beta (a frozen BatchNorm's constants; one launch)."""
+    lib = _lib.load()
+    _need(mean, "mean", torch.float32)
+    c = mean.numel()
+    out = torch.empty((4, c), dtype=torch.float32, device=mean.device)
+    check(lib.afan_affine_coefs(_ptr(mean), _ptr(invstd), _ptr(weight), _ptr(bias), c, _ptr(out), _stream(mean)), "afan_affine_coefs")
+    return out
+
+
+def affine_apply(x, coefs, residual=None, relu=False):
+    """y = [relu](x * alpha[c] + beta[c] [+ residual]) on a channels-last map with coefficients from affine_coefs."""
+    lib = _lib.load()
+    _need(x, "x")
+    if layout_of(x) != AFAN_NHWC:
+        raise ValueError("affine_apply takes channels-last maps")
+    if residual is not None:
+        _need(residual, "residual", x.dtype)
+        _same_layout(x, residual)
+    n, c, hw = _nchw(x)
+    y = torch.empty_like(x)
+    check(lib.afan_affine_apply(_ptr(x), _ptr(residual), _ptr(y), _DT[x.dtype], n, c, hw, _ptr(coefs), int(bool(relu)), _stream(x)),
+          "afan_affine_apply")
+    return y
+
+
 def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, dbias=None, accumulate=False,
                 partials=None, dx_out=None, dres_out=None, groups=1):
     """Returns (dx, d_residual|None). dweight/dbias (fp32 [C]) are written/accumulated when given.

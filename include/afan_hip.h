@@ -380,6 +380,14 @@ int afan_maxpool2d_bwd(const void* dy, const void* x, const uint8_t* idx, void* 
  * NULL = 1); d_res (nullable) = g.  Tensors [n, c, hw] in `layout`. */
 int afan_affine_relu_bwd(const void* dy, const void* y, const float* alpha, void* dx, void* dres, int dtype, int layout,
                          int64_t n, int64_t c, int64_t hw, int relu, afan_stream_t stream);
+/* The same layer's forward with its coefficients computed ONCE: afan_affine_coefs writes coefs[4][c] = mean | invstd |
+ * alpha | beta (alpha = invstd * weight, beta = bias - mean * alpha; weight / bias NULL = 1 / 0) — they are constants of a
+ * frozen BatchNorm (Detection/model.py:31-35: no gradient, eval mode) — and afan_affine_apply is the one streaming launch
+ * y = [relu](x * alpha[c] + beta[c] [+ residual]) on channels-last tensors [n, hw, c] (afan_bn_apply = both, per call). */
+int afan_affine_coefs(const float* mean, const float* invstd, const float* weight, const float* bias, int64_t c,
+                      float* coefs, afan_stream_t stream);
+int afan_affine_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
+                      const float* coefs, int relu, afan_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast.
  * pooled_f32 != 0: the pooled side (y / dy) is fp32 whatever `dtype` the map has. */
 int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,

@@ -16,7 +16,7 @@ LOSS_TOL = 1e-4      # |delta| <= 1e-4 * max(1, |reference loss|)
 # sign() flip on a gradient within fp32 rounding distance of zero, and flips compound over the K steps through
 # batch-2 BatchNorm statistics in the deep nets (measured on MI355X: r20s <= 3e-4, r56s / r18 at batch 2 ~ 7.5e-2).
 FLIP_BOUND = {"resnet20s": 2e-3, "resnet56s": 0.15, "resnet18": 0.15}
-FLIP_B16 = {"resnet56s": 0.12, "resnet18": 0.12}
+FLIP_B16 = {"resnet56s": 0.08, "resnet18": 0.08}      # measured on the f32-MFMA convolutions: 3.9 % / 4.3 % (profiles/r03c_parity_measurements.txt)
 ARCH = {"r20s": "resnet20s", "r56s": "resnet56s", "r18": "resnet18"}
 
 
@@ -171,7 +171,7 @@ def test_clip_projection_invariant_full_size(pkg, orc, gpu):
 @pytest.mark.parametrize("case", ["step_r56s_k5_b16", "step_r18_k5_b16"])
 def test_joint_step_fp32_batch16_matches_reference(pkg, orc, gpu, case):
     """The deep networks at batch 16 (BatchNorm statistics over >= 16k samples): loss within 1e-4 and the K = 5 perturbation
-    equal to the reference's on >= 1 - FLIP_B16 = 88 % of the elements (measured 92 %: K sign() steps through a freshly
+    equal to the reference's on >= 1 - FLIP_B16 = 92 % of the elements (measured 96 %: K sign() steps through a freshly
     initialised tail) — on the library's own f32-MFMA convolutions (vendor_conv == 0)."""
     g = golden(case)
     K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]

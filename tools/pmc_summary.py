@@ -3,11 +3,11 @@ usage: pmc_summary.py <dir with the counter CSVs> <out.json> ["<command the coun
 The `_meta` entry records the command and a hash of the kernel sources, so that bench.py can tell when a summary is stale."""
 import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = ("conv_igemm_kernel", "conv3x3_c64_kernel", "conv_small_kernel", "stem7_fwd_kernel", "stem7_wgrad_kernel", "stem_fwd_kernel",
+KEYS = ("conv_igemm_fwd_kernel", "conv_igemm_dgrad_kernel", "conv_f32_kernel", "wgrad_f32_kernel", "conv3x3_c64_kernel", "conv_small_kernel", "stem7_fwd_kernel", "stem7_wgrad_kernel", "stem_fwd_kernel",
         "wgrad_small_kernel", "wgrad_reduce", "wgrad_kernel", "stats_kernel", "finalize_kernel", "bwd_reduce_kernel", "bwd_apply_acc_kernel",
         "bwd_apply_kernel", "apply_acc_kernel", "apply_kernel", "pgd_step_norms_kernel", "pgd_step_kernel", "sgd_kernel", "cast_bf16",
         "transpose_weights", "mix_feature_nhwc_kernel", "mix_feature_kernel", "lerp_points_kernel", "upsample_fwd_kernel", "upsample_bwd_kernel",
-        "ce2d_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "pointwise_fwd_kernel", "pointwise_dx_kernel", "pointwise_dw_kernel")
+        "ce2d_up_kernel", "ce2d_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "pointwise_fwd_kernel", "pointwise_dx_kernel", "pointwise_dw_kernel")
 out = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
