@@ -108,7 +108,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(pp.x), 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(pp.w), 0, (int)((int64_t)pp.Co * pp.w_row_stride * 2), 0x00020000);
+        const_cast<uint16_t*>(pp.w + pp.w_off[blockIdx.z]), 0, (int)((int64_t)pp.Co * pp.w_row_stride * 2), 0x00020000);
     constexpr uint32_t OOB = 0x80000000u;
 
     // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each (32-bit index math) -------
@@ -489,13 +489,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         if (m0 >= half) { grp = 1; grp_m0 = half; }
     }
     const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
-    double* acc_blk = pp.acc ? pp.acc + (int64_t)grp * pp.acc_stride : nullptr;
+    double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
+    const float* shift_p = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
+    uint16_t* y_p = pp.y + pp.y_off[blockIdx.z];
     float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
         const int c = ch_ok ? n0 + pc * 8 + j : 0;
-        sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && pp.shift) ? pp.shift[c] : 0.f);   // mean or shift
+        sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && shift_p) ? shift_p[c] : 0.f);   // mean or shift
         al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : 0.f;
         be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : 0.f;
     }
@@ -511,7 +513,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
             }
-            *reinterpret_cast<u16x8*>(pp.y + go) = v;
+            *reinterpret_cast<u16x8*>(y_p + go) = v;
             if (bn_bwd) {
                 const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
                 u16x8 yv = xv;
@@ -564,8 +566,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 double* dst = acc_blk + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
                 unsafeAtomicAdd(dst + n0 + tid, (double)a);
                 unsafeAtomicAdd(dst + pp.Co + n0 + tid, (double)b);
-                if (!bn_bwd && m0 == grp_m0 && blockIdx.z == 0)   // snapshot of the shift for the BN that consumes the sums
-                    reinterpret_cast<float*>(acc_blk + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = pp.shift ? pp.shift[n0 + tid] : 0.f;
+                if (!bn_bwd && m0 == grp_m0 && (blockIdx.z == 0 || pp.multi))   // snapshot of the shift for the BN that consumes the sums
+                    reinterpret_cast<float*>(acc_blk + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = shift_p ? shift_p[n0 + tid] : 0.f;
             } else {
                 const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
                 pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
@@ -774,6 +776,60 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
         q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
         return afan_c64::launch(q, st);
     }
+    return dispatch(p, st, false);
+}
+
+// nb <= 4 forward problems of the SAME shape on the SAME input in one launch (grid.z = problem): ASPP's atrous 3x3 branches
+// (Segmentation/network/_deeplab.py:143-150,173-176: 2048 -> 256 at three dilations).  At 2 images per GPU one branch is
+// 70 workgroups with a 288-step K loop (92 us on 256 CUs); three branches in one grid take the same 92 us.  BatchNorm
+// moments go to f64 accumulator blocks (one per problem) or nowhere.
+int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
+                                  int64_t ci, int64_t co, int k, int stride, const int* dilation,
+                                  const float* const* stats_shift, double* const* stats_acc, afan_stream_t stream) {
+    if (nb < 1 || nb > 4 || !w || !y || !dilation) return nb < 1 || nb > 4 ? AFAN_ESHAPE : AFAN_ENULL;
+    int dmax = 1;
+    for (int b = 0; b < nb; ++b) {
+        int e = check_dims(n, hi, wi, ci, co, k, stride, dilation[b]);
+        if (e) return e;
+        if (!w[b] || !y[b]) return AFAN_ENULL;
+        if (!aligned(w[b], 16) || !aligned(y[b], 16)) return AFAN_EALIGN;
+        if ((stats_acc != nullptr) != (stats_shift != nullptr)) return AFAN_ESHAPE;
+        if (stats_acc && (!stats_acc[b] || !aligned(stats_acc[b], 16))) return stats_acc[b] ? AFAN_EALIGN : AFAN_ENULL;
+        if (dilation[b] > dmax) dmax = dilation[b];
+    }
+    if (!x) return AFAN_ENULL;
+    if (!aligned(x, 16)) return AFAN_EALIGN;
+    if (ci % 8 != 0 || co % 8 != 0 || ci < 40 || co < 40 || ci == 3) return AFAN_ESHAPE;
+    const int pad = k / 2;
+    ConvP p{};
+    p.max_pad = dmax;
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w[0]; p.y = (uint16_t*)y[0];
+    p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
+    p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
+    p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = nb;
+    p.multi = 1; p.groups = 1;
+    p.acc = stats_acc ? stats_acc[0] : nullptr; p.shift = stats_shift ? stats_shift[0] : nullptr;
+    p.acc_ns = afan_nhwc::acc_slot_count(co);
+    for (int b = 0; b < nb; ++b) {
+        p.w_off[b] = (const uint16_t*)w[b] - (const uint16_t*)w[0];
+        p.y_off[b] = (uint16_t*)y[b] - (uint16_t*)y[0];
+        if (stats_acc) {
+            if (!stats_shift[b] != !stats_shift[0]) return AFAN_ESHAPE;     // all problems with a shift, or none
+            p.acc_off[b] = stats_acc[b] - stats_acc[0];
+            p.shift_off[b] = stats_shift[0] ? stats_shift[b] - stats_shift[0] : 0;
+        }
+        ConvClass& c = p.cls[b];
+        c.Hg = p.Ho; c.Wg = p.Wo; c.out_h0 = 0; c.out_w0 = 0; c.T = k * k;
+        for (int r = 0; r < k; ++r)
+            for (int s = 0; s < k; ++s) {
+                const int t = r * k + s;
+                c.dh[t] = (r - pad) * dilation[b]; c.dw[t] = (s - pad) * dilation[b]; c.wofs[t] = (int)(t * ci);
+            }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const double M = (double)n * p.Ho * p.Wo;
+    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", nb * 2.0 * (M * co + (double)co * k * k * ci) + 2.0 * (double)n * hi * wi * ci,
+                    nb * 2.0 * M * co * k * k * ci, st);
     return dispatch(p, st, false);
 }
 

@@ -38,6 +38,11 @@ struct ConvP {
     int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
     int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
+    int multi;                   // 1: the classes are INDEPENDENT forward problems on the same input (ASPP's atrous branches,
+    int64_t w_off[4];            //   _deeplab.py:173-176): class z reads weights w + w_off[z], writes y + y_off[z] (elements),
+    int64_t y_off[4];            //   sums into acc + acc_off[z] (doubles) around shift + shift_off[z] (floats).  All zero
+    int64_t acc_off[4];          //   otherwise.
+    int64_t shift_off[4];
     ConvClass cls[4];
 };
 

@@ -479,6 +479,61 @@ class ASPPConv(nn.Sequential):
         return _cbr(self[0], self[1], x)
 
 
+class _ConvMultiFn(torch.autograd.Function):
+    """The atrous 3x3 branches of ASPP (_deeplab.py:173-176) as ONE forward launch (afan_conv_fwd_multi_nhwc_bf16: same input,
+    same shapes, their own weights / dilations / BatchNorm moment accumulators).  Backward: the input gradients chained
+    through the dgrad epilogue's addend (no separate sums), each branch's weight gradient into its arena view."""
+
+    @staticmethod
+    def forward(ctx, x, convs, want_wgrad, reqs, *w_masters):
+        ctx.convs, ctx.want_wgrad = convs, want_wgrad
+        ws = [c.lp_weight().detach() for c in convs]
+        ys, sts = ops.conv_fwd_multi(x, ws, convs[0].stride[0], [c.dilation[0] for c in convs],
+                                     None if reqs is None else [r[0] for r in reqs])
+        if reqs is not None:
+            for r, st in zip(reqs, sts):
+                r.append(st)
+        ctx.save_for_backward(x, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x, *ws = ctx.saved_tensors
+        convs = ctx.convs
+        gx, gws = None, []
+        for i, (c, w_lp, gy) in enumerate(zip(convs, ws, gys)):
+            gw = None
+            if gy is not None:
+                gy = _like_layout(gy, x)
+                k, st, dil = w_lp.shape[2], c.stride[0], c.dilation[0]
+                if ctx.needs_input_grad[0]:
+                    gx = ops.conv_dgrad(gy, c.lp_weight_t(), x.shape[2:], st, addend=gx, dilation=dil)
+                if ctx.want_wgrad and ctx.needs_input_grad[4 + i]:
+                    wm = c.weight
+                    if _accumulates_in_place(wm) and wm.grad.is_contiguous(memory_format=torch.channels_last):
+                        g_ = wm.grad
+                        _WgradStream.run(lambda gy=gy, k=k, st=st, g_=g_, dil=dil: ops.conv_wgrad(x, gy, k, st, g_, accumulate=True, dilation=dil), x, gy)
+                    else:
+                        gw = ops.conv_wgrad(x, gy, k, st, dilation=dil)
+            gws.append(gw)
+        return (gx, None, None, None, *gws)
+
+
+def _multi_branch_ok(x, mods):
+    """The bf16 channels-last training step, every branch a bias-free conv -> train-mode BatchNorm of the same shape."""
+    convs, bns = [m[0] for m in mods], [m[1] for m in mods]
+    c0 = convs[0]
+    if not (x.is_cuda and c0.compute_dtype == torch.bfloat16 and x.dtype == torch.bfloat16):
+        return False
+    if not all(b.training and b.track_running_stats for b in bns):
+        return False
+    if any(c.bias is not None or c.stride != c0.stride or c.weight.shape != c0.weight.shape or c.kernel_size != (3, 3)
+           or c.padding != c.dilation for c in convs):
+        return False
+    return ops.conv_fwd_multi_ok(x, [c.lp_weight() for c in convs], c0.stride[0]) and \
+        ops.conv_wgrad_supported(x.shape[1], c0.out_channels, 3, c0.stride[0], (x.shape[0], x.shape[2], x.shape[3]))
+
+
 class ASPPPooling(nn.Sequential):
     """_deeplab.py:152-163: global average pool -> 1x1 conv -> BN -> ReLU -> resize back (a broadcast)."""
 
@@ -504,6 +559,7 @@ class ASPPPooling(nn.Sequential):
 
 class ASPP(nn.Module):
     """_deeplab.py:165-193."""
+    MULTI = os.environ.get("AFAN_ASPP_MULTI", "1") != "0"      # 0: one launch per atrous branch (A/B)
 
     def __init__(self, in_channels, atrous_rates):
         super().__init__()
@@ -516,7 +572,16 @@ class ASPP(nn.Module):
 
     def forward(self, x, pre_dropout=False):
         x = _to_compute(x, self.convs[0][0].compute_dtype)
-        res = [_cbr(self.convs[0][0], self.convs[0][1], x)] + [c(x) for c in list(self.convs)[1:]]
+        atrous = [m for m in list(self.convs)[1:] if isinstance(m, ASPPConv)]
+        if ASPP.MULTI and 2 <= len(atrous) <= 4 and len(atrous) == len(self.convs) - 2 and _multi_branch_ok(x, atrous):
+            # the atrous branches in one launch: at 2 images per GPU each fills a quarter of the chip for 92 us
+            convs, bns = [m[0] for m in atrous], [m[1] for m in atrous]
+            reqs = [[b.running_mean, None] for b in bns]
+            raws = _ConvMultiFn.apply(x, convs, _Flags.param_grads, reqs, *[c.weight for c in convs])
+            mid = [b.fused(r, None, True, q[2]) for b, r, q in zip(bns, raws, reqs)]
+            res = [_cbr(self.convs[0][0], self.convs[0][1], x)] + mid + [self.convs[-1](x)]
+        else:
+            res = [_cbr(self.convs[0][0], self.convs[0][1], x)] + [c(x) for c in list(self.convs)[1:]]
         res = torch.cat(res, dim=1)
         pre = _cbr(self.project[0], self.project[1], res)
         return pre if pre_dropout else self.project[3](pre)

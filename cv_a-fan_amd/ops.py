@@ -699,6 +699,42 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
     return (y, st) if want_stats else y
 
 
+def conv_fwd_multi_ok(x, ws, stride):
+    """Same-shape bf16 channels-last problems on one input, on the tiled kernel, BatchNorm moments in accumulator blocks."""
+    w0 = ws[0]
+    return (1 <= len(ws) <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and layout_of(x) == AFAN_NHWC
+            and all(w.shape == w0.shape and w.dtype == torch.bfloat16 and w.is_contiguous(memory_format=torch.channels_last) for w in ws)
+            and w0.shape[1] == x.shape[1] and w0.shape[2] == w0.shape[3] and w0.shape[1] >= 64 and w0.shape[0] >= 64
+            and w0.shape[1] % 8 == 0 and _conv_acc_ok(w0.shape[0])
+            and bool(_lib.load().afan_conv_supported(w0.shape[1], w0.shape[0], w0.shape[2], stride)))
+
+
+def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
+    """[conv2d(x, w_b, padding=d_b*(k//2), stride, dilation=d_b) for b] in ONE launch (afan_conv_fwd_multi_nhwc_bf16).
+    Returns ([y_b], [ConvStats_b | None])."""
+    lib = _lib.load()
+    nb = len(ws)
+    CALLS["conv_fwd"] += nb
+    _cl4(x, "x")
+    n, ci, hi, wi = x.shape
+    co, _, k, _ = ws[0].shape
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    yall = torch.empty((nb * n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    ys = [yall[b * n:(b + 1) * n] for b in range(nb)]
+    sts = [None] * nb
+    arr_p = C.c_void_p * nb
+    shifts = accs = None
+    if stats_shifts is not None:
+        sts = [ConvStats(None, 0, stats_shifts[b], acc_take(x.device, co)) for b in range(nb)]
+        shifts = arr_p(*[t.data_ptr() for t in stats_shifts])
+        accs = arr_p(*[st.acc.data_ptr() for st in sts])
+    check(lib.afan_conv_fwd_multi_nhwc_bf16(_ptr(x), arr_p(*[w.data_ptr() for w in ws]), arr_p(*[y.data_ptr() for y in ys]), nb,
+                                            n, hi, wi, ci, co, k, stride, (C.c_int * nb)(*[int(d) for d in dilations]),
+                                            shifts, accs, _stream(x)), "afan_conv_fwd_multi_nhwc_bf16")
+    return ys, sts
+
+
 def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1, dilation=1):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient

@@ -284,3 +284,73 @@ def test_conv_stats_fusion_on_ragged_channels_is_declined(pkg, gpu):
     w = torch.randn(48, 256, 1, 1, device=gpu).bfloat16().contiguous(memory_format=torch.channels_last)
     y, st = pkg.ops.conv_fwd(x, w, 1, stats_shift=torch.zeros(48, device=gpu), want_stats=True)
     assert st is None and tuple(y.shape) == (1, 48, 9, 9)
+
+
+@pytest.mark.parametrize("n,ci,co,h,w,dils", [(2, 2048, 256, 33, 33, (6, 12, 18)), (1, 512, 128, 17, 21, (2, 5)),
+                                              (2, 256, 256, 9, 9, (12, 24, 36, 1))])
+def test_conv_fwd_multi_equals_separate_launches(pkg, gpu, n, ci, co, h, w, dils):
+    """ASPP's atrous branches as ONE launch (afan_conv_fwd_multi_nhwc_bf16, _deeplab.py:143-150,173-176): outputs bit-identical
+    to one launch per branch, BatchNorm moment accumulators equal to accumulation-order noise (f64 atomics), and the module
+    path (ASPP.MULTI) leaves the same gradients as the per-branch path."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(n, ci, h, w, generator=g) * 0.5).to(gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * 0.02).to(gpu).bfloat16().contiguous(memory_format=torch.channels_last) for _ in dils]
+    shifts = [torch.randn(co, generator=g).to(gpu) * 0.1 for _ in dils]
+    assert ops.conv_fwd_multi_ok(x, ws, 1)
+    ops.acc_reset(gpu)
+    ys, sts = ops.conv_fwd_multi(x, ws, 1, dils, shifts)
+    accs = [st.acc.clone() for st in sts]
+    ys = [y.clone() for y in ys]
+    for b, d in enumerate(dils):
+        y1, st1 = ops.conv_fwd(x, ws[b], 1, stats_shift=shifts[b], want_stats=True, dilation=d)
+        assert torch.equal(y1, ys[b]), f"branch {b}"
+        a1, a2 = st1.acc.double(), accs[b].double()
+        assert a1.shape == a2.shape
+        # sum over the accumulator copies of (sum, sum of squares) per channel
+        k = int(pkg._lib.load().afan_bn_acc_doubles(co))
+        body1, body2 = a1[:k], a2[:k]
+        torch.testing.assert_close(body1.sum(), body2.sum(), rtol=1e-9, atol=1e-9)
+        ref = F.conv2d(x.float(), ws[b].float(), padding=d, dilation=d)
+        assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
+    ys2, sts2 = ops.conv_fwd_multi(x, ws, 1, dils, None)
+    assert sts2 == [None] * len(dils) and all(torch.equal(a, b_) for a, b_ in zip(ys2, ys))
+
+
+def test_aspp_multi_launch_equals_per_branch_path(pkg, gpu):
+    dl = pkg.deeplab
+    res = {}
+    old = dl.ASPP.MULTI
+    try:
+        for multi in (True, False):
+            dl.ASPP.MULTI = multi
+            torch.manual_seed(5)
+            aspp = dl.ASPP(512, (6, 12, 18))
+            for m in aspp.modules():
+                if isinstance(m, nn.Dropout):
+                    m.p = 0.0
+                if hasattr(m, "compute_dtype"):
+                    m.compute_dtype = torch.bfloat16
+            aspp.to(gpu).train()
+            pkg.arena.ParamArena(aspp, skip=())
+            g = torch.Generator().manual_seed(7)
+            x = torch.randn(2, 512, 33, 33, generator=g).relu().to(gpu).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            pkg.ops.acc_reset(gpu)
+            before = pkg.ops.CALLS["conv_fwd"]
+            y = aspp(x)
+            gy = (torch.randn(y.shape, generator=g) * 1e-2).to(gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[multi] = (y.detach().float(), x.grad.float(), {k: p.grad.float().clone() for k, p in aspp.named_parameters()},
+                          {k: b.clone() for k, b in aspp.named_buffers()})
+            assert pkg.ops.CALLS["conv_fwd"] - before == 5        # 1x1, three atrous, projection (the pooling branch is a linear layer)
+    finally:
+        dl.ASPP.MULTI = old
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    # the input gradient: three dgrads chained through the epilogue addend vs summed by autograd — bf16 rounding of partial sums
+    assert float((a[1] - b[1]).norm() / b[1].norm()) < 6e-3
+    for k in b[2]:
+        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=1e-6, msg=k)
+    for k in b[3]:
+        torch.testing.assert_close(a[3][k].float(), b[3][k].float(), rtol=1e-5, atol=1e-6, msg=k)
