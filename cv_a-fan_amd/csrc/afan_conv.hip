@@ -107,8 +107,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // rows beyond M) costs one v_cndmask per load instead of a branch around it.  All offsets are 32-bit bytes.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(pp.x), 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2), 0x00020000);
+    const int w_row_stride = pp.multi ? pp.w_rs[blockIdx.z] : pp.w_row_stride;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(pp.w + pp.w_off[blockIdx.z]), 0, (int)((int64_t)pp.Co * pp.w_row_stride * 2), 0x00020000);
+        const_cast<uint16_t*>(pp.w + pp.w_off[blockIdx.z]), 0, (int)((int64_t)pp.Co * w_row_stride * 2), 0x00020000);
     constexpr uint32_t OOB = 0x80000000u;
 
     // ---- per-thread gather bookkeeping: A_ROWS rows, one 16-byte channel piece each (32-bit index math) -------
@@ -150,9 +151,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         }
         out_off[r] = off;
     }
-    const uint32_t b_off = ((uint32_t)(n0 + row0) * pp.w_row_stride + piece * 8) * 2u;
+    const uint32_t b_off = ((uint32_t)(n0 + row0) * w_row_stride + piece * 8) * 2u;
     const int b_rows_ok = pp.Co - n0 - row0;                      // weight row (row0 + RPP * i) exists iff RPP * i < b_rows_ok
-    const uint32_t b_row32 = (uint32_t)RPP * pp.w_row_stride * 2u;
+    const uint32_t b_row32 = (uint32_t)RPP * w_row_stride * 2u;
 
     // accumulators: acc[j][i] = channels tile j x pixels tile i (weights are the MFMA A operand, so a lane ends up
     // with 4 consecutive CHANNELS of one pixel per register quad: 8-byte packed bf16 on the way out)
@@ -779,40 +780,50 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     return dispatch(p, st, false);
 }
 
-// nb <= 4 forward problems of the SAME shape on the SAME input in one launch (grid.z = problem): ASPP's atrous 3x3 branches
-// (Segmentation/network/_deeplab.py:143-150,173-176: 2048 -> 256 at three dilations).  At 2 images per GPU one branch is
-// 70 workgroups with a 288-step K loop (92 us on 256 CUs); three branches in one grid take the same 92 us.  BatchNorm
-// moments go to f64 accumulator blocks (one per problem) or nowhere.
+// nb <= 4 forward problems on the SAME input with the SAME output shape in one launch (grid.z = problem): ASPP's atrous 3x3
+// branches (Segmentation/network/_deeplab.py:143-150,173-176: 2048 -> 256 at three dilations) — at 2 images per GPU one
+// branch is 70 workgroups with a 288-step K loop (92 us on 256 CUs), three branches in one grid take the same 92 us — and
+// a BasicBlock's first 3x3 convolution with its 1x1 projection shortcut (Classification/resnet_s.py:52-77 option B: both
+// read x at stride 2 and write [N, planes, H/2, W/2]).  ksize[b] in {1, 3}, padding dilation[b] * (ksize[b] / 2).
+// BatchNorm moments go to f64 accumulator blocks (one per problem) or nowhere.
 int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
-                                  int64_t ci, int64_t co, int k, int stride, const int* dilation,
+                                  int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
                                   const float* const* stats_shift, double* const* stats_acc, afan_stream_t stream) {
-    if (nb < 1 || nb > 4 || !w || !y || !dilation) return nb < 1 || nb > 4 ? AFAN_ESHAPE : AFAN_ENULL;
+    if (nb < 1 || nb > 4) return AFAN_ESHAPE;
+    if (!w || !y || !dilation || !ksize) return AFAN_ENULL;
+    if ((stats_acc != nullptr) != (stats_shift != nullptr)) return AFAN_ESHAPE;
     int dmax = 1;
+    int64_t ho = -1, wo = -1;
     for (int b = 0; b < nb; ++b) {
-        int e = check_dims(n, hi, wi, ci, co, k, stride, dilation[b]);
+        int e = check_dims(n, hi, wi, ci, co, ksize[b], stride, dilation[b]);
         if (e) return e;
         if (!w[b] || !y[b]) return AFAN_ENULL;
         if (!aligned(w[b], 16) || !aligned(y[b], 16)) return AFAN_EALIGN;
-        if ((stats_acc != nullptr) != (stats_shift != nullptr)) return AFAN_ESHAPE;
         if (stats_acc && (!stats_acc[b] || !aligned(stats_acc[b], 16))) return stats_acc[b] ? AFAN_EALIGN : AFAN_ENULL;
         if (dilation[b] > dmax) dmax = dilation[b];
+        const int pad = ksize[b] / 2;                 // (a dilated 3x3 at stride 1 keeps the spatial size, like the plain one)
+        const int64_t h_b = (hi + 2 * pad - ksize[b]) / stride + 1, w_b = (wi + 2 * pad - ksize[b]) / stride + 1;
+        if (b && (h_b != ho || w_b != wo)) return AFAN_ESHAPE;
+        ho = h_b; wo = w_b;
     }
     if (!x) return AFAN_ENULL;
     if (!aligned(x, 16)) return AFAN_EALIGN;
     if (ci % 8 != 0 || co % 8 != 0 || ci < 40 || co < 40 || ci == 3) return AFAN_ESHAPE;
-    const int pad = k / 2;
     ConvP p{};
     p.max_pad = dmax;
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w[0]; p.y = (uint16_t*)y[0];
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
-    p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
-    p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = nb;
+    p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
+    p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(ksize[0] * ksize[0] * ci); p.n_classes = nb;
     p.multi = 1; p.groups = 1;
     p.acc = stats_acc ? stats_acc[0] : nullptr; p.shift = stats_shift ? stats_shift[0] : nullptr;
     p.acc_ns = afan_nhwc::acc_slot_count(co);
+    double flops = 0, wbytes = 0;
     for (int b = 0; b < nb; ++b) {
+        const int k = ksize[b], pad = k / 2;
         p.w_off[b] = (const uint16_t*)w[b] - (const uint16_t*)w[0];
         p.y_off[b] = (uint16_t*)y[b] - (uint16_t*)y[0];
+        p.w_rs[b] = (int)(k * k * ci);
         if (stats_acc) {
             if (!stats_shift[b] != !stats_shift[0]) return AFAN_ESHAPE;     // all problems with a shift, or none
             p.acc_off[b] = stats_acc[b] - stats_acc[0];
@@ -825,11 +836,11 @@ int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* con
                 const int t = r * k + s;
                 c.dh[t] = (r - pad) * dilation[b]; c.dw[t] = (s - pad) * dilation[b]; c.wofs[t] = (int)(t * ci);
             }
+        flops += 2.0 * n * ho * wo * co * k * k * ci;
+        wbytes += 2.0 * co * k * k * ci;
     }
     hipStream_t st = (hipStream_t)stream;
-    const double M = (double)n * p.Ho * p.Wo;
-    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", nb * 2.0 * (M * co + (double)co * k * k * ci) + 2.0 * (double)n * hi * wi * ci,
-                    nb * 2.0 * M * co * k * k * ci, st);
+    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", nb * 2.0 * n * ho * wo * co + wbytes + 2.0 * (double)n * hi * wi * ci, flops, st);
     return dispatch(p, st, false);
 }
 

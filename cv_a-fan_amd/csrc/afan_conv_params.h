@@ -43,6 +43,7 @@ struct ConvP {
     int64_t y_off[4];            //   sums into acc + acc_off[z] (doubles) around shift + shift_off[z] (floats).  All zero
     int64_t acc_off[4];          //   otherwise.
     int64_t shift_off[4];
+    int w_rs[4];                 //   and its weight rows are w_rs[z] elements apart (problems may differ in kernel size)
     ConvClass cls[4];
 };
 

@@ -700,17 +700,21 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
 
 
 def conv_fwd_multi_ok(x, ws, stride):
-    """Same-shape bf16 channels-last problems on one input, on the tiled kernel, BatchNorm moments in accumulator blocks."""
+    """Problems on one bf16 channels-last input with one output shape (same Co, k in {1, 3}), on the tiled kernel, BatchNorm
+    moments in accumulator blocks."""
     w0 = ws[0]
+    lib = _lib.load()
     return (1 <= len(ws) <= 4 and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and layout_of(x) == AFAN_NHWC
-            and all(w.shape == w0.shape and w.dtype == torch.bfloat16 and w.is_contiguous(memory_format=torch.channels_last) for w in ws)
-            and w0.shape[1] == x.shape[1] and w0.shape[2] == w0.shape[3] and w0.shape[1] >= 64 and w0.shape[0] >= 64
+            and all(w.shape[:2] == w0.shape[:2] and w.dtype == torch.bfloat16 and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)
+                    and (w.is_contiguous(memory_format=torch.channels_last) or w.shape[2] == 1) for w in ws)
+            and w0.shape[1] == x.shape[1] and w0.shape[1] >= 64 and w0.shape[0] >= 64
             and w0.shape[1] % 8 == 0 and _conv_acc_ok(w0.shape[0])
-            and bool(_lib.load().afan_conv_supported(w0.shape[1], w0.shape[0], w0.shape[2], stride)))
+            and (stride == 1 or (x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0) or all(w.shape[2] == w0.shape[2] for w in ws))
+            and all(bool(lib.afan_conv_supported(w.shape[1], w.shape[0], w.shape[2], stride)) for w in ws))
 
 
 def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
-    """[conv2d(x, w_b, padding=d_b*(k//2), stride, dilation=d_b) for b] in ONE launch (afan_conv_fwd_multi_nhwc_bf16).
+    """[conv2d(x, w_b, padding=d_b*(k_b//2), stride, dilation=d_b) for b] in ONE launch (afan_conv_fwd_multi_nhwc_bf16).
     Returns ([y_b], [ConvStats_b | None])."""
     lib = _lib.load()
     nb = len(ws)
@@ -730,8 +734,9 @@ def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
         shifts = arr_p(*[t.data_ptr() for t in stats_shifts])
         accs = arr_p(*[st.acc.data_ptr() for st in sts])
     check(lib.afan_conv_fwd_multi_nhwc_bf16(_ptr(x), arr_p(*[w.data_ptr() for w in ws]), arr_p(*[y.data_ptr() for y in ys]), nb,
-                                            n, hi, wi, ci, co, k, stride, (C.c_int * nb)(*[int(d) for d in dilations]),
-                                            shifts, accs, _stream(x)), "afan_conv_fwd_multi_nhwc_bf16")
+                                            n, hi, wi, ci, co, (C.c_int * nb)(*[int(w.shape[2]) for w in ws]), stride,
+                                            (C.c_int * nb)(*[int(d) for d in dilations]), shifts, accs, _stream(x)),
+          "afan_conv_fwd_multi_nhwc_bf16")
     return ys, sts
 
 

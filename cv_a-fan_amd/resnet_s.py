@@ -442,6 +442,7 @@ class _BlockFn(torch.autograd.Function):
     epilogue (no separate add launches), parameter gradients are accumulated by the kernels into the arena views, and
     the dgrad producing the gradient for the PREVIOUS block's output also takes that block's last-BN backward sums.
     `params` only tell autograd which leaves the node depends on; values are read from the modules."""
+    MULTI_SC = os.environ.get("AFAN_BLOCK_MULTI_SC", "1") != "0"     # 0: the projection shortcut as its own launch (A/B)
 
     @staticmethod
     def forward(ctx, x, blk, want_pgrad, *params):
@@ -449,12 +450,22 @@ class _BlockFn(torch.autograd.Function):
         n = len(chain)
         G = _Flags.bn_groups
         mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
-        rawsc = ssc = None
+        rawsc = ssc = first = None
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
-            rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
-                                      stats_buf=csc._stats_buf, groups=G)      # (1x1: no dilation)
-            csc._stats_buf = stc.partials
+            c1, b1 = chain[0]
+            if (_BlockFn.MULTI_SC and G == 1 and c1.stride == csc.stride and c1.dilation[0] == 1
+                    and c1.out_channels == csc.out_channels
+                    and ops.conv_fwd_multi_ok(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0])):
+                # a BasicBlock's first 3x3 and its 1x1 projection read the same x at the same stride and write the same
+                # shape: one launch, two problems (afan_conv_fwd_multi_nhwc_bf16)
+                (raw1, rawsc), (st1, stc) = ops.conv_fwd_multi(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0], [1, 1],
+                                                               [b1.running_mean, bsc.running_mean])
+                first = (raw1, st1)
+            else:
+                rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
+                                          stats_buf=csc._stats_buf, groups=G)      # (1x1: no dilation)
+                csc._stats_buf = stc.partials
             res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
         elif blk._sc_kind == "pad":
             # option-A shortcut (resnet_s.py:64-65): every second pixel, zero channels either side — data movement only
@@ -463,9 +474,12 @@ class _BlockFn(torch.autograd.Function):
             res = x
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
-            raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
-                                   stats_buf=c._stats_buf, groups=G, dilation=c.dilation[0])
-            c._stats_buf = st.partials
+            if i == 0 and first is not None:
+                raw, st = first
+            else:
+                raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
+                                       stats_buf=c._stats_buf, groups=G, dilation=c.dilation[0])
+                c._stats_buf = st.partials
             a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
             saved += [raw, a, s_i]
         ctx.blk, ctx.want_pgrad, ctx.n, ctx.G = blk, want_pgrad, n, G

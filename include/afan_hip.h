@@ -245,13 +245,15 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
                             int64_t co, int k, int stride, int dilation, float* stats_partials, const float* stats_shift,
                             double* stats_acc, int groups, afan_stream_t stream);
 
-/* nb (1..4) forward convolutions of the SAME shape on the SAME input x in ONE launch: w[b] / y[b] / dilation[b] per problem
- * (host arrays of device pointers), BatchNorm moments of y[b] around stats_shift[b] into the f64 accumulator block
- * stats_acc[b] (both arrays NULL: no moments).  The atrous branches of ASPP, Segmentation/network/_deeplab.py:143-150,
- * 173-176 (three 3x3 2048 -> 256 convolutions of one feature map at dilations 6/12/18 or 12/24/36): at 2 images per GPU
- * one branch fills a quarter of the chip, the three together cost the time of one. */
+/* nb (1..4) forward convolutions on the SAME input x with the SAME output shape in ONE launch: w[b] / y[b] / ksize[b] (1 or 3)
+ * / dilation[b] per problem (host arrays; device pointers inside), BatchNorm moments of y[b] around stats_shift[b] into the
+ * f64 accumulator block stats_acc[b] (both arrays NULL: no moments).  (1) The atrous branches of ASPP,
+ * Segmentation/network/_deeplab.py:143-150,173-176 (three 3x3 2048 -> 256 convolutions of one feature map at dilations
+ * 6/12/18 or 12/24/36): at 2 images per GPU one branch fills a quarter of the chip, the three together cost the time of
+ * one.  (2) A BasicBlock's first 3x3 / stride-2 convolution and its 1x1 / stride-2 projection shortcut
+ * (Classification/resnet_s.py:52-77, option B). */
 int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi,
-                                  int64_t wi, int64_t ci, int64_t co, int k, int stride, const int* dilation,
+                                  int64_t wi, int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
                                   const float* const* stats_shift, double* const* stats_acc, afan_stream_t stream);
 /* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
  * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
