@@ -32,9 +32,11 @@ def _workspace_bytes(dev, nbytes):
     return w
 
 
-def nms(bboxes, scores, threshold, inclusive=False):
+def nms(bboxes, scores, threshold, inclusive=False, padded=False):
     """Kept indices (ascending) of greedy NMS over boxes in descending-score order; IoU with +1 (inclusive corners).
-    inclusive=False suppresses at IoU > threshold (the reference's GPU path, nms.cu:49), True at >= (its CPU path)."""
+    inclusive=False suppresses at IoU > threshold (the reference's GPU path, nms.cu:49), True at >= (its CPU path).
+    padded=True: no host synchronisation — returns (keep [n] int64 on the device, of which the first count[0] are valid,
+    count [1] int64 on the device) for callers that can consume a padded result."""
     if bboxes.device.type != "cuda":
         raise ops.AfanLibraryError("nms: tensors must live on the MI355X (no CPU path in this build)")
     n = bboxes.shape[0] if bboxes.dim() > 0 else 0
@@ -49,6 +51,8 @@ def nms(bboxes, scores, threshold, inclusive=False):
     st = C.c_void_p(torch.cuda.current_stream(boxes.device).cuda_stream)
     check(lib.afan_nms(C.c_void_p(boxes.data_ptr()), C.c_void_p(order.data_ptr()), n, float(threshold), int(bool(inclusive)),
                        C.c_void_p(ws.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(count.data_ptr()), st), "afan_nms")
+    if padded:
+        return keep, count
     return keep[:int(count.item())]       # the result's length is data dependent: one read-back (the reference copies the whole mask)
 
 

@@ -394,6 +394,11 @@ def _own_conv_ok(x, w, stride, padding, dilation=(1, 1)):
         return False
     if x.shape[1] == 3 and x.shape[3] % 32:      # the stem kernel walks 32-pixel row segments
         return False
+    # the tuned kernels address activations with 32-bit byte offsets (afan_conv.hip check_dims: the larger of the two
+    # tensors + the DMA descriptor's bias); a larger problem goes to the general kernels (64-bit strides) instead of raising
+    c = max(int(w.shape[0]), int(w.shape[1]))
+    if x.shape[0] * x.shape[2] * x.shape[3] * c * 2 + 2 * int(dilation[0]) * (x.shape[3] + 1) * c > 0x7FFFFFFF:
+        return False
     return _own_conv_ok_shape(w, stride, padding, dilation)
 
 
@@ -583,7 +588,10 @@ def _block_fast_path_ok(blk, x):
     if not all(m.training and m.track_running_stats for m in mods):
         return False
     for c in convs:
-        if not _own_conv_ok_shape(c.lp_weight(), c.stride, c.padding):
+        if not _own_conv_ok_shape(c.lp_weight(), c.stride, c.padding, c.dilation):
+            return False
+        cm = max(c.in_channels, c.out_channels)         # 32-bit byte offsets in the tuned kernels (see _own_conv_ok)
+        if x.shape[0] * x.shape[2] * x.shape[3] * cm * 2 + 2 * c.dilation[0] * (x.shape[3] + 1) * cm > 0x7FFFFFFF:
             return False
     if _Flags.param_grads and torch.is_grad_enabled():
         ps = [c.weight for c in convs] + [m.weight for m in mods] + [m.bias for m in mods]

@@ -1,5 +1,6 @@
 #!/bin/bash
 # do kernels of the replayed step overlap in time (parallel graph branches)?  kernel trace -> overlapped time per step
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf /tmp/trace_ov; cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_ov -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 4 --no_cpu_baseline --no_roofline "$@" > /tmp/bench_ov.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 cd /tmp

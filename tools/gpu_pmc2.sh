@@ -1,6 +1,7 @@
 #!/bin/bash
 # Memory-path counters of one conv shape (SHAPE=ci,co,h,k,s N=batch): texture addresser / L1 / L2 busy and stall cycles,
 # L1->L2 read latency, LDS FIFO stalls.  Separate --pmc passes (no trace domains besides kernel-trace).
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc2
 export TMPDIR=/tmp
 cd /tmp

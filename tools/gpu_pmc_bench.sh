@@ -1,6 +1,7 @@
 #!/bin/bash
 # HBM traffic counters for the bench step (separate --pmc passes: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 #   bash tools/gpu_pmc_bench.sh [TAG [bench.py args...]]   -> gpurun_out/pmcb_TAG/summary.json
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 TAG=${1:-r18}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcb_$TAG
 mkdir -p $OUT

@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the default bench (NHWC) -> gpurun_out/prof_$1
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 TAG=${1:-x}
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-dispatch durations of a bench run, aggregated by (kernel, grid): gpurun_out/${TAG}_trace_by_grid.txt
 #   [ALL=1 TOP=150] bash tools/gpu_trace.sh TAG [bench.py args...]      (ALL: every kernel, not only the convolutions)
+GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; export GRAFT_REPO_ROOT
 TAG=${1:-x}; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
