@@ -80,11 +80,31 @@ class ParamArena:
                         desc.append((o, t_off, k_, r_ * s_, c_, tiles, m, p))
                         t_off += p.numel()
                         tiles += ((k_ + 63) // 64) * r_ * s_ * ((c_ + 63) // 64)
+            # a residual block's 3x3 / stride-2 convolution and its 1x1 / stride-2 projection also share ONE [C][10][K]
+            # operand (slots 0-8: the 3x3 taps, slot 9: the projection) for afan_conv_dgrad_sc_nhwc_bf16
+            by_mod = {id(d[6]): d for d in desc}
+            pairs = []
+            for blk in model.modules():
+                if getattr(blk, "_sc_kind", None) == "conv" and hasattr(blk, "_chain"):
+                    c1, csc = blk._chain()[0][0], blk.shortcut[0]
+                    d1, dsc = by_mod.get(id(c1)), by_mod.get(id(csc))
+                    if (d1 is not None and dsc is not None and c1.kernel_size == (3, 3) and csc.kernel_size == (1, 1)
+                            and c1.stride == (2, 2) and csc.stride == (2, 2) and c1.dilation == (1, 1)
+                            and c1.out_channels == csc.out_channels and c1.in_channels == csc.in_channels):
+                        pairs.append((c1, d1, dsc, t_off))
+                        t_off += c1.in_channels * 10 * c1.out_channels
             if desc:
                 # CRSK copies of the conv weights (dgrad operands), rebuilt by ONE launch after every SGD step
                 self.shadow_t = torch.zeros(t_off, dtype=torch.bfloat16, device=dev)
-                self._tdesc = torch.tensor([d[:6] for d in desc], dtype=torch.int64, device=dev).contiguous()
-                self._t_ndesc, self._t_tiles = len(desc), tiles
+                rows = [list(d[:6]) + [d[3], 0] for d in desc]
+                for (c1, d1, dsc, to10) in pairs:
+                    for d, rs0 in ((d1, 0), (dsc, 9)):
+                        o, _, k_, rs, c_ = d[:5]
+                        rows.append([o, to10, k_, rs, c_, tiles, 10, rs0])
+                        tiles += ((k_ + 63) // 64) * rs * ((c_ + 63) // 64)
+                    c1._arena_wt10 = self.shadow_t[to10:to10 + c1.in_channels * 10 * c1.out_channels]
+                self._tdesc = torch.tensor(rows, dtype=torch.int64, device=dev).contiguous()
+                self._t_ndesc, self._t_tiles = len(rows), tiles
                 for (o, to, k_, rs, c_, _, m, p) in desc:
                     r_ = p.shape[2]
                     m._arena_wt = self.shadow_t[to:to + p.numel()].view(c_, r_, rs // r_, k_).permute(0, 3, 1, 2)

@@ -106,7 +106,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // Buffer descriptors: out-of-range offsets read as zero in hardware, so the zero padding of the convolution (and
     // rows beyond M) costs one v_cndmask per load instead of a branch around it.  All offsets are 32-bit bytes.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t*>(pp.x), 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2), 0x00020000);
+        const_cast<uint16_t*>(pp.x), 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2 + pp.a_extra), 0x00020000);
     const int w_row_stride = pp.multi ? pp.w_rs[blockIdx.z] : pp.w_row_stride;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint16_t*>(pp.w + pp.w_off[blockIdx.z]), 0, (int)((int64_t)pp.Co * w_row_stride * 2), 0x00020000);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 
     auto gload = [&](int ks, u32x4 (&ra)[A_ROWS], u32x4 (&rb)[B_ROWS]) {
         const int t = ks / chunks, q = ks - t * chunks;
-        const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK) * 2);   // may be "negative": wraps
+        const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK + cc.aofs[t]) * 2);   // may be "negative": wraps
         const uint32_t b_tap = (uint32_t)((cc.wofs[t] + q * BK) * 2);
         const bool pk = q + 1 < chunks || last_ok;
 #pragma unroll
@@ -257,7 +257,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // as zero), so num_records = tensor bytes + A_BIAS; an invalid row is VGPR offset 2^31 (LDS gets zeros).
     const uint32_t A_BIAS = (uint32_t)(((pp.max_pad * Wi + pp.max_pad) * Ci) * 2);
     const __amdgpu_buffer_rsrc_t xdma = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(const_cast<uint16_t*>(pp.x)) - A_BIAS, 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2 + A_BIAS), 0x00020000);
+        reinterpret_cast<char*>(const_cast<uint16_t*>(pp.x)) - A_BIAS, 0, (int)((int64_t)pp.N * Hi * Wi * Ci * 2 + A_BIAS + pp.a_extra), 0x00020000);
     uint32_t b_voff[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) b_voff[i] = RPP * i < b_rows_ok ? b_off + i * b_row32 : OOB;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // from call to call instead of being recomputed from ks (an integer division and three scalar loads of the tap table
     // per step, with the s_waitcnt lgkmcnt(0) they drag along: 63 SALU instructions per K-step before).
     int dma_t = 0, dma_q = 0;
-    int dma_a = T > 0 ? ((cc.dh[0] * Wi + cc.dw[0]) * Ci) * 2 + (int)A_BIAS : 0;
+    int dma_a = T > 0 ? ((cc.dh[0] * Wi + cc.dw[0]) * Ci + cc.aofs[0]) * 2 + (int)A_BIAS : 0;
     int dma_b = T > 0 ? cc.wofs[0] * 2 : 0;
     auto gdma = [&](int /*ks*/, int buf) {
         const int t = dma_t;
@@ -287,7 +287,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             dma_q = 0;
             ++dma_t;
             if (dma_t < T) {
-                dma_a = ((cc.dh[dma_t] * Wi + cc.dw[dma_t]) * Ci) * 2 + (int)A_BIAS;
+                dma_a = ((cc.dh[dma_t] * Wi + cc.dw[dma_t]) * Ci + cc.aofs[dma_t]) * 2 + (int)A_BIAS;
                 dma_b = cc.wofs[dma_t] * 2;
             }
         } else {
@@ -709,6 +709,106 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
     return AFAN_OK;
 }
 
+static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
+                      int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
+                      const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials, double* bn_acc, int groups,
+                      afan_stream_t stream) {
+    int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
+    if (e) return e;
+    if (!dy || !wt || !dx) return AFAN_ENULL;
+    if (!aligned(dy, 16) || !aligned(wt, 16) || !aligned(dx, 16)) return AFAN_EALIGN;
+    const int pad = k / 2;
+    const int ho = (int)((hi + 2 * pad - k) / stride + 1), wo = (int)((wi + 2 * pad - k) / stride + 1);
+    hipStream_t st = (hipStream_t)stream;
+    ConvP p{};
+    p.x = (const uint16_t*)dy; p.w = (const uint16_t*)wt; p.y = (uint16_t*)dx;
+    p.N = (int)n; p.Hi = ho; p.Wi = wo; p.Ci = (int)co;      // GEMM input = dy
+    p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
+    p.w_row_stride = (int)(k * k * co);
+    int64_t sc_off = 0;                                      // elements from dy to dy_sc
+    if (dy_sc) {
+        if (k != 3 || stride != 2 || dilation != 1 || groups > 1 || co % 8 || ci % 8 || co < 40 || ci < 40) return AFAN_ESHAPE;
+        if (!aligned(dy_sc, 16)) return AFAN_EALIGN;
+        sc_off = (const uint16_t*)dy_sc - (const uint16_t*)dy;
+        const int64_t tensor = n * ho * wo * co;
+        if (sc_off < tensor || (sc_off + tensor) * 2 > 0x7fffffffLL) return AFAN_ESHAPE;   // behind dy, inside 32-bit byte offsets
+        p.w_row_stride = (int)(10 * co);
+        p.a_extra = sc_off * 2;
+    }
+    p.max_pad = dilation;
+    p.addend = (const uint16_t*)addend;
+    if (bn_partials && bn_acc) return AFAN_ESHAPE;
+    if (bn_partials || bn_acc) {
+        if (!bn_x || !bn_stats) return AFAN_ENULL;
+        if (bn_acc && !aligned(bn_acc, 16)) return AFAN_EALIGN;
+        // image groups: every parity class of a stride-2 launch has at least (hi/2)*(wi/2) positions per image, a
+        // multiple of that class's own count is what matters; the smallest class decides
+        if ((e = set_groups(p, groups, n, stride == 1 ? hi * wi : (hi / 2) * (wi / 2), ci, bn_acc != nullptr))) return e;
+        if (groups == 2 && stride == 2 && ((hi | wi) & 1)) return AFAN_ESHAPE;
+        p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
+        p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
+    }
+    const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
+    AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes + (dy_sc ? 2.0 * ((double)n * ho * wo * co + (double)co * ci) : 0.0),
+                    2.0 * (double)n * ho * wo * co * (k * k + (dy_sc ? 1 : 0)) * ci, st);
+    p.in_s = 1;
+    if (!dy_sc && !bn_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
+        afan_c64::Params q{};
+        q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
+        q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu; q.bny = p.bny;
+        q.addend = p.addend;
+        return afan_c64::launch(q, st);
+    }
+    if (stride == 1) {
+        // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]
+        p.out_s = 1; p.n_classes = 1;
+        ConvClass& c0 = p.cls[0];
+        c0.Hg = (int)hi; c0.Wg = (int)wi; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
+        for (int r = 0; r < k; ++r)
+            for (int s = 0; s < k; ++s) {
+                const int t = r * k + s;
+                c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
+            }
+        if (small_eligible(p)) return small_launch(p, st);
+        if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
+        return dispatch(p, st, true);
+    }
+    // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
+    // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four classes (1/2/2/4 taps for k = 3) in ONE launch.
+    p.out_s = 2;
+    int nc = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            ConvClass& c = p.cls[nc];
+            c.Hg = (int)((hi - ph + 1) / 2); c.Wg = (int)((wi - pw + 1) / 2);
+            if (c.Hg <= 0 || c.Wg <= 0) continue;
+            c.out_h0 = ph; c.out_w0 = pw;
+            int T = 0;
+            for (int r = 0; r < k; ++r)
+                for (int s = 0; s < k; ++s) {
+                    const int a = ph + pad - r, b = pw + pad - s;
+                    if ((a & 1) || (b & 1)) continue;
+                    c.dh[T] = a / 2; c.dw[T] = b / 2; c.wofs[T] = (int)((r * k + s) * co);
+                    ++T;
+                }
+            if (dy_sc && ph == 0 && pw == 0) {               // the 1x1 / 2 projection: one more tap of the even/even class
+                c.dh[T] = 0; c.dw[T] = 0; c.wofs[T] = (int)(9 * co); c.aofs[T] = (int)sc_off;
+                ++T;
+            }
+            if (T == 0) {
+                // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  One all-invalid tap makes
+                // the kernel write zeros through its normal path.
+                T = 1; c.dh[0] = -(ho + 2); c.dw[0] = 0; c.wofs[0] = 0;   // (small enough for the 32-bit tap offset)
+            }
+            c.T = T;
+            ++nc;
+        }
+    p.n_classes = nc;
+    if (!dy_sc && small_eligible(p)) return small_launch(p, st);
+    if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
+    return dispatch(p, st, true);
+}
+
 }  // namespace
 
 extern "C" {
@@ -873,98 +973,36 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                               int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
                               double* bn_acc, int groups, afan_stream_t stream) {
-    int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
-    if (e) return e;
-    if (!dy || !wt || !dx) return AFAN_ENULL;
-    if (!aligned(dy, 16) || !aligned(wt, 16) || !aligned(dx, 16)) return AFAN_EALIGN;
-    const int pad = k / 2;
-    const int ho = (int)((hi + 2 * pad - k) / stride + 1), wo = (int)((wi + 2 * pad - k) / stride + 1);
-    hipStream_t st = (hipStream_t)stream;
-    ConvP p{};
-    p.x = (const uint16_t*)dy; p.w = (const uint16_t*)wt; p.y = (uint16_t*)dx;
-    p.N = (int)n; p.Hi = ho; p.Wi = wo; p.Ci = (int)co;      // GEMM input = dy
-    p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)ci;          // GEMM output = dx
-    p.w_row_stride = (int)(k * k * co);
-    p.max_pad = dilation;
-    p.addend = (const uint16_t*)addend;
-    if (bn_partials && bn_acc) return AFAN_ESHAPE;
-    if (bn_partials || bn_acc) {
-        if (!bn_x || !bn_stats) return AFAN_ENULL;
-        if (bn_acc && !aligned(bn_acc, 16)) return AFAN_EALIGN;
-        // image groups: every parity class of a stride-2 launch has at least (hi/2)*(wi/2) positions per image, a
-        // multiple of that class's own count is what matters; the smallest class decides
-        if ((e = set_groups(p, groups, n, stride == 1 ? hi * wi : (hi / 2) * (wi / 2), ci, bn_acc != nullptr))) return e;
-        if (groups == 2 && stride == 2 && ((hi | wi) & 1)) return AFAN_ESHAPE;
-        p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
-        p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
-    }
-    const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
-    AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes, 2.0 * (double)n * ho * wo * co * k * k * ci, st);
-    p.in_s = 1;
-    if (!bn_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
-        afan_c64::Params q{};
-        q.x = p.x; q.w = p.w; q.y = p.y; q.N = p.N; q.H = (int)hi; q.W = (int)wi; q.flip = 1;
-        q.acc = bn_acc; q.acc_ns = p.acc_ns; q.bnx = p.bnx; q.bn_stats = p.bn_stats; q.bn_relu = p.bn_relu; q.bny = p.bny;
-        q.addend = p.addend;
-        return afan_c64::launch(q, st);
-    }
-    if (stride == 1) {
-        // dx[h,w] = sum_{r,s} dy[h + pad - r, w + pad - s] * w[., r, s, .]
-        p.out_s = 1; p.n_classes = 1;
-        ConvClass& c0 = p.cls[0];
-        c0.Hg = (int)hi; c0.Wg = (int)wi; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
-        for (int r = 0; r < k; ++r)
-            for (int s = 0; s < k; ++s) {
-                const int t = r * k + s;
-                c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
-            }
-        if (small_eligible(p)) return small_launch(p, st);
-        if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
-        return dispatch(p, st, true);
-    }
-    // stride 2: output pixel (2h'+ph, 2w'+pw) receives tap (r,s) iff (ph + pad - r) and (pw + pad - s) are even;
-    // then the dy pixel is (h' + (ph+pad-r)/2, w' + (pw+pad-s)/2).  Four classes (1/2/2/4 taps for k = 3) in ONE launch.
-    p.out_s = 2;
-    int nc = 0;
-    for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
-            ConvClass& c = p.cls[nc];
-            c.Hg = (int)((hi - ph + 1) / 2); c.Wg = (int)((wi - pw + 1) / 2);
-            if (c.Hg <= 0 || c.Wg <= 0) continue;
-            c.out_h0 = ph; c.out_w0 = pw;
-            int T = 0;
-            for (int r = 0; r < k; ++r)
-                for (int s = 0; s < k; ++s) {
-                    const int a = ph + pad - r, b = pw + pad - s;
-                    if ((a & 1) || (b & 1)) continue;
-                    c.dh[T] = a / 2; c.dw[T] = b / 2; c.wofs[T] = (int)((r * k + s) * co);
-                    ++T;
-                }
-            if (T == 0) {
-                // no tap reaches this parity class (1x1 stride 2): its gradient is zero.  One all-invalid tap makes
-                // the kernel write zeros through its normal path.
-                T = 1; c.dh[0] = -(ho + 2); c.dw[0] = 0; c.wofs[0] = 0;   // (small enough for the 32-bit tap offset)
-            }
-            c.T = T;
-            ++nc;
-        }
-    p.n_classes = nc;
-    if (small_eligible(p)) return small_launch(p, st);
-    if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
-    return dispatch(p, st, true);
+    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, k, stride, dilation, addend, bn_x, bn_stats, bn_relu, bn_y,
+                      bn_partials, bn_acc, groups, stream);
 }
 
+// The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77, option B):
+// dx = conv_transpose(dy, w1: 3x3 / 2) + conv_transpose(dy_sc, w_sc: 1x1 / 2).  dy and dy_sc are [N, Ho, Wo, Co] tensors in
+// ONE allocation (dy_sc behind dy); wt10 is [Ci][10][Co]: the nine taps of w1 transposed, the tenth slot w_sc transposed
+// (afan_transpose_weights writes both, see its descriptor).  The projection is one more tap of the even/even output-parity
+// class, gathered from dy_sc: no second launch, no dx_sc tensor, no addend read in the epilogue.
+int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* wt10, void* dx, int64_t n, int64_t hi,
+                                 int64_t wi, int64_t ci, int64_t co, const void* bn_x, const float* bn_stats, int bn_relu,
+                                 const void* bn_y, float* bn_partials, double* bn_acc, afan_stream_t stream) {
+    if (!dy_sc) return AFAN_ENULL;
+    return dgrad_impl(dy, dy_sc, wt10, dx, n, hi, wi, ci, co, 3, 2, 1, nullptr, bn_x, bn_stats, bn_relu, bn_y, bn_partials,
+                      bn_acc, 1, stream);
+}
 // ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------
-// desc[i] = {src_off, dst_off, K, RS, C, first_tile}; tiles of 64(k) x 64(c) at fixed rs, ceil(K/64)*RS*ceil(C/64) of them
-// per tensor (partial tiles are masked); K % 8 == 0, C % 8 == 0.
+// desc[i] = {src_off, dst_off, K, RS, C, first_tile, dst_RS, rs0}; tiles of 64(k) x 64(c) at fixed rs,
+// ceil(K/64)*RS*ceil(C/64) of them per tensor (partial tiles are masked); K % 8 == 0, C % 8 == 0.  The destination rows hold
+// dst_RS >= RS tap slots and this tensor's taps land in slots rs0 .. rs0 + RS - 1 (dst_RS = RS, rs0 = 0: the plain CRSK copy;
+// a block's 3x3 weights with dst_RS = 10 and its 1x1 projection with rs0 = 9 share one [C][10][K] operand:
+// afan_conv_dgrad_sc_nhwc_bf16).
 __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(const uint16_t* __restrict__ src,
                                                                 uint16_t* __restrict__ dst,
                                                                 const int64_t* __restrict__ desc, int n_desc) {
     __shared__ uint16_t tile[64][64 + 8];
     int d = 0;
-    while (d + 1 < n_desc && (int64_t)blockIdx.x >= desc[(d + 1) * 6 + 5]) ++d;
-    const int64_t* D = desc + d * 6;
-    const int64_t K = D[2], RS = D[3], Cc = D[4];
+    while (d + 1 < n_desc && (int64_t)blockIdx.x >= desc[(d + 1) * 8 + 5]) ++d;
+    const int64_t* D = desc + d * 8;
+    const int64_t K = D[2], RS = D[3], Cc = D[4], DRS = D[6], rs0 = D[7];
     int64_t t = blockIdx.x - D[5];
     const int64_t ctiles = (Cc + 63) / 64;
     const int64_t ct = t % ctiles; t /= ctiles;
@@ -988,7 +1026,7 @@ __global__ __launch_bounds__(TRANSPOSE_THREADS) void transpose_weights_kernel(co
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = tile[piece * 8 + j][c];
         if (ct * 64 + c < Cc && kt * 64 + piece * 8 < K)
-            *reinterpret_cast<u16x8*>(o + ((ct * 64 + c) * RS + rs) * K + kt * 64 + piece * 8) = v;
+            *reinterpret_cast<u16x8*>(o + ((ct * 64 + c) * DRS + rs0 + rs) * K + kt * 64 + piece * 8) = v;
     }
 }
 

@@ -13,6 +13,8 @@ struct ConvClass {
     int out_h0, out_w0;          // output coordinate = g * out_s + out_0
     int T;                       // number of taps
     int dh[MAX_TAPS], dw[MAX_TAPS], wofs[MAX_TAPS];  // tap offsets and weight element offset of the tap inside a row
+    int aofs[MAX_TAPS];          // element offset added to the gathered tensor's address for this tap: 0, or the distance to a
+                                 //   SECOND gathered tensor of the same shape in the same allocation (ConvP::a_extra covers it)
 };
 
 struct ConvP {
@@ -38,6 +40,7 @@ struct ConvP {
     int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
     int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
+    int64_t a_extra;             // bytes beyond the gathered tensor x that taps with aofs != 0 may reach (descriptor range)
     int multi;                   // 1: the classes are INDEPENDENT forward problems on the same input (ASPP's atrous branches,
     int64_t w_off[4];            //   _deeplab.py:173-176): class z reads weights w + w_off[z], writes y + y_off[z] (elements),
     int64_t y_off[4];            //   sums into acc + acc_off[z] (doubles) around shift + shift_off[z] (floats).  All zero

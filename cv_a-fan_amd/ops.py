@@ -740,11 +740,13 @@ def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
     return ys, sts
 
 
-def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1, dilation=1):
+def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1, dilation=1, sc=None):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient
     entering that BatchNorm's backward -> also returns a ConvStats with its reduction partials (for bn_backward).
-    bn_y: that BatchNorm's output after residual add + ReLU (dx's shape): the ReLU mask is bn_y > 0 instead of recomputed."""
+    bn_y: that BatchNorm's output after residual add + ReLU (dx's shape): the ReLU mask is bn_y > 0 instead of recomputed.
+    sc = (dy_sc, wt10): the block's 1x1 / stride-2 projection in the same launch (afan_conv_dgrad_sc_nhwc_bf16): dy_sc of
+    dy's shape in the same allocation behind dy, wt10 the flat [Ci][10][Co] operand (then `wt` is only read for its shape)."""
     lib = _lib.load()
     CALLS["conv_dgrad"] += 1
     _cl4(dy, "dy"), _cl4(wt, "wt")
@@ -752,6 +754,14 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
     ci, co2, k, _ = wt.shape
     if co2 != co:
         raise ValueError("transposed weight shape does not match dy")
+    if sc is not None:
+        dy_sc, wt10 = sc
+        _cl4(dy_sc, "dy_sc")
+        _need(wt10, "wt10", torch.bfloat16)
+        if dy_sc.shape != dy.shape or wt10.numel() != ci * 10 * co or k != 3 or stride != 2 or dilation != 1 or groups != 1 \
+                or addend is not None:
+            raise ValueError("fused projection gradient: 3x3 / stride 2 with a same-shape dy_sc and a [Ci][10][Co] operand")
+        CALLS["conv_dgrad"] += 1
     hi, wi = in_hw
     dx = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     if addend is not None:
@@ -779,6 +789,12 @@ def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=Non
             if partials_buf is None or partials_buf.numel() < 2 * ci * g:
                 partials_buf = torch.empty(2 * ci * g, dtype=torch.float32, device=dy.device)
             st = ConvStats(partials_buf, g, None)
+    if sc is not None:
+        check(lib.afan_conv_dgrad_sc_nhwc_bf16(_ptr(dy), _ptr(sc[0]), _ptr(sc[1]), _ptr(dx), n, hi, wi, ci, co, _ptr(bnx),
+                                               _ptr(bstats), int(bool(relu)), _ptr(bn_y) if st else None,
+                                               _ptr(st.partials) if st else None, _ptr(st.acc) if st else None, _stream(dy)),
+              "afan_conv_dgrad_sc_nhwc_bf16")
+        return (dx, st) if bn_bwd is not None else dx
     check(lib.afan_conv_dgrad_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, stride, int(dilation), _ptr(addend),
                                         _ptr(bnx), _ptr(bstats), int(bool(relu)), _ptr(bn_y) if st else None,
                                         _ptr(st.partials) if st else None, _ptr(st.acc) if st else None,

@@ -106,10 +106,11 @@ def _bn_fwd_g(raw, b, res, relu, st, G, mom):
     return y, stats
 
 
-def _bn_bwd_g(dy, raw, y, stats, b, relu, want_dres, pg, part, G):
+def _bn_bwd_g(dy, raw, y, stats, b, relu, want_dres, pg, part, G, dx_out=None):
     gw, gb = (b.weight.grad, b.bias.grad) if pg else (None, None)
     if G == 1 or (part is not None and part.acc is not None):
-        return ops.bn_backward(dy, raw, y, stats, b.weight, b.bias, relu, want_dres, gw, gb, pg, partials=part, groups=G)
+        return ops.bn_backward(dy, raw, y, stats, b.weight, b.bias, relu, want_dres, gw, gb, pg, partials=part, groups=G,
+                               dx_out=dx_out)
     c, n = raw.shape[1], raw.shape[0] // G
     dx = torch.empty_like(raw)
     dres = torch.empty_like(raw) if want_dres else None
@@ -526,6 +527,16 @@ class _BlockFn(torch.autograd.Function):
         # last BN (+residual, ReLU mask from `out`): gradient to its conv output and to the shortcut branch
         bl = chain[-1][1]
         d_raw, dres = _bn_bwd_g(gout, raws[-1], out, stats[-1], bl, True, True, pg, pre, G)
+        # the first convolution's and the projection's output gradients side by side in one buffer: their input gradients
+        # are ONE launch (afan_conv_dgrad_sc_nhwc_bf16) when the arena holds the block's combined [Ci][10][Co] operand
+        c1 = chain[0][0]
+        wt10 = getattr(c1, "_arena_wt10", None) if (_BlockFn.MULTI_SC and blk._sc_kind == "conv" and G == 1 and need_dx
+                                                     and n >= 2) else None
+        pair = None
+        if wt10 is not None:
+            r0 = raws[0]
+            pair = torch.empty((2 * r0.shape[0],) + tuple(r0.shape[1:]), dtype=r0.dtype, device=r0.device,
+                               memory_format=torch.channels_last)
         for i in range(n - 1, 0, -1):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
@@ -535,8 +546,8 @@ class _BlockFn(torch.autograd.Function):
             c._bwd_buf = part.partials
             if pg:
                 _wgrad_accumulate(acts[i - 1], d_raw, c)
-            d_raw, _ = _bn_bwd_g(d_a, raws[i - 1], None, stats[i - 1], bp, True, False, pg, part, G)
-        c1 = chain[0][0]
+            d_raw, _ = _bn_bwd_g(d_a, raws[i - 1], None, stats[i - 1], bp, True, False, pg, part, G,
+                                 dx_out=pair[:r0.shape[0]] if (pair is not None and i == 1) else None)
         if pg:
             _wgrad_accumulate(x, d_raw, c1)
         dx = None
@@ -546,10 +557,13 @@ class _BlockFn(torch.autograd.Function):
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             if pg or need_dx:
-                d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G)
+                d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G,
+                                       dx_out=pair[r0.shape[0]:] if pair is not None else None)
                 if pg:
                     _wgrad_accumulate(x, d_rawsc, csc)
-                if need_dx:
+                if need_dx and pair is not None:
+                    dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], sc=(d_rawsc, wt10), **fuse)
+                elif need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])
                     dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif blk._sc_kind == "pad":

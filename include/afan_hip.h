@@ -269,6 +269,16 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                               int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
                               double* bn_acc, int groups, afan_stream_t stream);
+
+/* The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77 with the
+ * option-B projection): dx = conv_transpose(dy, w1: 3x3 / 2, pad 1) + conv_transpose(dy_sc, w_sc: 1x1 / 2) — what autograd
+ * computes as two input gradients and a sum at main_perturb.py:200 / attack_algo.py:52.  dy, dy_sc: [N, hi/2, wi/2, co] bf16
+ * in ONE allocation, dy_sc behind dy; wt10: [ci][10][co] (nine transposed taps of w1, then w_sc transposed:
+ * afan_transpose_weights); dx [N, hi, wi, ci].  bn_*: the same BatchNorm-backward epilogue fusion as
+ * afan_conv_dgrad_nhwc_bf16. */
+int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* wt10, void* dx, int64_t n, int64_t hi,
+                                 int64_t wi, int64_t ci, int64_t co, const void* bn_x, const float* bn_stats, int bn_relu,
+                                 const void* bn_y, float* bn_partials, double* bn_acc, afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
  *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
  *               both the main branch and the shortcut;
@@ -478,8 +488,11 @@ int afan_cross_entropy(const float* logits, const int64_t* target, int64_t n, in
                        afan_stream_t stream);
 
 /* Batched KRSC -> CRSK transpose of every convolution weight of the parameter arena (the dgrad operands `wt`), one
- * launch per SGD step.  desc_dev: device array of n_desc x 6 int64 {src_off, dst_off, K, RS, C, first_tile} (element
- * offsets into src_arena / dst_arena, K % 8 == 0, C % 8 == 0, first_tile = running sum of ceil(K/64)*RS*ceil(C/64)). */
+ * launch per SGD step.  desc_dev: device array of n_desc x 8 int64 {src_off, dst_off, K, RS, C, first_tile, dst_RS, rs0}
+ * (element offsets into src_arena / dst_arena, K % 8 == 0, C % 8 == 0, first_tile = running sum of
+ * ceil(K/64)*RS*ceil(C/64)); the destination is [C][dst_RS][K] and the tensor's RS taps fill slots rs0 .. rs0+RS-1
+ * (dst_RS = RS, rs0 = 0: the plain CRSK copy; a 3x3 weight with dst_RS = 10 plus its block's 1x1 projection at rs0 = 9:
+ * the operand of afan_conv_dgrad_sc_nhwc_bf16). */
 int afan_transpose_weights(const void* src_arena, void* dst_arena, const int64_t* desc_dev, int n_desc,
                            int64_t total_tiles, afan_stream_t stream);
 

@@ -397,3 +397,40 @@ def test_wgrad_two_operand_pairs_in_one_launch(pkg, gpu, n, n2, ci, co, h, k, st
     with pytest.raises(pkg.AfanLibraryError):                                            # 3 * 5 * 5 pixels: not a multiple of 64
         xs, dys = _cl(torch.randn(3, 64, 5, 5, device=gpu).bfloat16()), _cl(torch.randn(3, 64, 5, 5, device=gpu).bfloat16())
         pkg.ops.conv_wgrad(xs, dys, 3, 1, second=(xs, dys))
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(4, 64, 128, 32, 32), (2, 128, 256, 16, 16), (3, 256, 512, 8, 8), (2, 64, 128, 14, 10)])
+def test_dgrad_with_fused_projection_equals_two_launches(pkg, gpu, n, ci, co, h, w):
+    """afan_conv_dgrad_sc_nhwc_bf16: the input gradients of a BasicBlock's 3x3 / stride-2 convolution and of its 1x1 / stride-2
+    projection (resnet_s.py:52-77) as ONE launch — the projection is a tenth tap of the even/even parity class, gathered from
+    the second tensor of the pair buffer, its weights the tenth slot of the [Ci][10][Co] operand afan_transpose_weights
+    builds.  Against the two launches + addend it replaces (same kernels: differences are one bf16 rounding of the
+    intermediate sum) and against float64."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(2)
+    cl = torch.channels_last
+    w1 = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).to(gpu).bfloat16().contiguous(memory_format=cl)
+    wsc = (torch.randn(co, ci, 1, 1, generator=g) * 0.1).to(gpu).bfloat16().contiguous(memory_format=cl)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    pair = (torch.randn(2 * n, co, ho, wo, generator=g) * 0.5).to(gpu).bfloat16().contiguous(memory_format=cl)
+    dy, dy_sc = pair[:n], pair[n:]
+    wt1 = w1.permute(1, 0, 2, 3).contiguous(memory_format=cl)          # [Ci, Co, 3, 3] CRSK memory
+    wtsc = wsc.permute(1, 0, 2, 3).contiguous(memory_format=cl)
+    # the combined operand, built by the library's transpose kernel from KRSC sources exactly as the arena does
+    src = torch.cat([w1.permute(0, 2, 3, 1).reshape(-1), wsc.permute(0, 2, 3, 1).reshape(-1)]).contiguous()
+    dst = torch.zeros(ci * 10 * co, dtype=torch.bfloat16, device=gpu)
+    t1 = ((co + 63) // 64) * 9 * ((ci + 63) // 64)
+    desc = torch.tensor([[0, 0, co, 9, ci, 0, 10, 0], [w1.numel(), 0, co, 1, ci, t1, 10, 9]], dtype=torch.int64, device=gpu)
+    ops.transpose_weights(src, dst, desc, 2, t1 + ((co + 63) // 64) * ((ci + 63) // 64))
+    ref10 = torch.cat([wt1.permute(0, 2, 3, 1).reshape(ci, 9, co), wtsc.permute(0, 2, 3, 1).reshape(ci, 1, co)], dim=1)
+    assert torch.equal(dst.view(ci, 10, co), ref10)
+    fused = ops.conv_dgrad(dy, wt1, (h, w), 2, sc=(dy_sc, dst))
+    two = ops.conv_dgrad(dy, wt1, (h, w), 2, addend=ops.conv_dgrad(dy_sc, wtsc, (h, w), 2))
+    x = torch.zeros(n, ci, h, w, dtype=torch.float64, device=gpu, requires_grad=True)
+    y = F.conv2d(x, w1.double(), stride=2, padding=1)
+    ysc = F.conv2d(x, wsc.double(), stride=2)
+    (gx,) = torch.autograd.grad([y, ysc], x, [dy.double(), dy_sc.double()])
+    e_f = float((fused.double() - gx).norm() / gx.norm())
+    e_t = float((two.double() - gx).norm() / gx.norm())
+    assert e_f < 4e-3 and e_f <= e_t * 1.05 + 1e-6, (e_f, e_t)       # one rounding instead of two
+    assert fused.is_contiguous(memory_format=cl)
