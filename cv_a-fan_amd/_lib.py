@@ -45,6 +45,8 @@ SIGNATURES = {
     "afan_bn_running_update": (_i, [_p, _l, C.c_double, _f, _f, _p, _p, _p, _p]),
     "afan_bn_running_update_batched": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "afan_bn_train_forward_acc": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p]),
+    "afan_bn_train_forward_acc_dual": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p,
+                                            _p, _p, _p, _p]),
     "afan_bn_backward_acc": (_i, [_p, _p, _p, _p, _p, _i, _l, _l, _l, _p, _i, _p, _i, _p, _p, _i, _i, _p]),
     "afan_bn_stats": (_i, [_p, _i, _i, _l, _l, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
     "afan_bn_train_forward": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _p, _p, _p, _p, _p]),

@@ -35,6 +35,10 @@ int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, v
 int acc_supported(int dtype, int64_t C);
 int64_t acc_doubles(int64_t C);
 int set_running_updates(int n);
+int fwd_acc_dual(int dtype, const void* xa, const void* xb, void* y, int64_t M, int64_t C, float eps_a, float mom_a,
+                 const float* w_a, const float* b_a, double* acc_a, float* stats_a, float* rm_a, float* rv_a, int64_t* nbt_a,
+                 float eps_b, float mom_b, const float* w_b, const float* b_b, double* acc_b, float* stats_b, float* rm_b,
+                 float* rv_b, int64_t* nbt_b, hipStream_t st);
 int coefs(int64_t C, const float* mean, const float* invstd, const float* w, const float* b, float* out, hipStream_t st);
 }
 
@@ -702,6 +706,25 @@ int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int 
     if (groups < 1 || n % groups != 0) return AFAN_ESHAPE;
     return afan_nhwc::fwd_acc(dtype, x, residual, y, (n / groups) * hw, c, eps, momentum, weight, bias, relu, acc, acc_ready,
                               save_stats, running_mean, running_var, num_batches, (hipStream_t)stream, groups);
+}
+
+int afan_bn_train_forward_acc_dual(const void* x_a, const void* x_b, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
+                                   float eps_a, float momentum_a, const float* weight_a, const float* bias_a, double* acc_a,
+                                   float* save_stats_a, float* running_mean_a, float* running_var_a, int64_t* num_batches_a,
+                                   float eps_b, float momentum_b, const float* weight_b, const float* bias_b, double* acc_b,
+                                   float* save_stats_b, float* running_mean_b, float* running_var_b, int64_t* num_batches_b,
+                                   afan_stream_t stream) {
+    int e = check_common(dtype, n, c, hw);
+    if (e) return e;
+    if (!x_a || !x_b || !y || !acc_a || !acc_b || !save_stats_a || !save_stats_b) return AFAN_ENULL;
+    if ((running_mean_a == nullptr) != (running_var_a == nullptr) || (running_mean_b == nullptr) != (running_var_b == nullptr))
+        return AFAN_ENULL;
+    if (!afan_nhwc::acc_supported(dtype, c)) return AFAN_ESHAPE;
+    const size_t a = dtype == AFAN_F32 ? 4 : 2;
+    if (!aligned(x_a, a) || !aligned(x_b, a) || !aligned(y, a) || !aligned(acc_a, 16) || !aligned(acc_b, 16)) return AFAN_EALIGN;
+    return afan_nhwc::fwd_acc_dual(dtype, x_a, x_b, y, n * hw, c, eps_a, momentum_a, weight_a, bias_a, acc_a, save_stats_a,
+                                   running_mean_a, running_var_a, num_batches_a, eps_b, momentum_b, weight_b, bias_b, acc_b,
+                                   save_stats_b, running_mean_b, running_var_b, num_batches_b, (hipStream_t)stream);
 }
 
 int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,

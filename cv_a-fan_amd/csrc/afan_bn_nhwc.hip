@@ -529,6 +529,80 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
     }
 }
 
+// The end of a residual block with a projection shortcut (Classification/resnet_s.py:72-77, option B):
+//   y = relu(bn_a(x_a) + bn_b(x_b))      x_a = the block's last convolution output, x_b = the 1x1 projection's output
+// as ONE launch: both BatchNorms' coefficients are derived in the prologue from their own accumulator blocks (filled by the
+// producing convolutions' epilogues), block 0 publishes both stats[4][C] blocks and applies both running-statistics
+// updates; the projection's normalised tensor is never written (one launch, one tensor write and one read less than
+// apply_acc(x_b) followed by apply_acc(x_a, res)).
+struct DualBN {
+    const double* acc;
+    const float* weight;
+    const float* bias;
+    float* stats;
+    float* rmean;
+    float* rvar;
+    int64_t* nbt;
+    float eps, momentum;
+};
+template <typename T, int VEC>
+__global__ __launch_bounds__(BLOCK) void apply_acc_dual_kernel(const T* __restrict__ xa, const T* __restrict__ xb,
+                                                               T* __restrict__ y, int64_t nvec, int CV, int C, int NS,
+                                                               DualBN A, DualBN B, double inv_m, float unbias, int updates) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];   // [4][C]: alpha_a | beta_a | alpha_b | beta_b
+    for (int c = threadIdx.x; c < C; c += BLOCK) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const DualBN& P = q ? B : A;
+            const float wv = P.weight ? P.weight[c] : 1.f, bv = P.bias ? P.bias[c] : 0.f;
+            double a, b;
+            fold_slots(P.acc, C, NS, c, a, b);
+            const float sh = reinterpret_cast<const float*>(P.acc + (int64_t)2 * NS * C)[c];
+            const double dm = a * inv_m;
+            const double m2 = fmax(b - a * dm, 0.0);
+            const float mean = (float)((double)sh + dm);
+            const float varb = (float)(m2 * inv_m);
+            const float is = 1.0f / sqrtf(varb + P.eps);
+            float alpha, beta;
+            affine_coeffs(mean, is, wv, bv, alpha, beta);
+            coef[(2 * q) * C + c] = alpha;
+            coef[(2 * q + 1) * C + c] = beta;
+            if (blockIdx.x == 0) {
+                P.stats[c] = mean;
+                P.stats[C + c] = is;
+                P.stats[2 * C + c] = alpha;
+                P.stats[3 * C + c] = beta;
+                if (P.rmean)
+                    for (int u = 0; u < updates; ++u) {
+                        P.rmean[c] = (1.0f - P.momentum) * P.rmean[c] + P.momentum * mean;
+                        P.rvar[c] = (1.0f - P.momentum) * P.rvar[c] + P.momentum * (varb * unbias);
+                    }
+                if (c == 0 && P.nbt) *P.nbt += updates;
+            }
+        }
+    }
+    __syncthreads();
+    const int c0 = (threadIdx.x % CV) * VEC;
+    float aa[VEC], ba[VEC], ab[VEC], bb[VEC];
+    ld_coef<VEC>(coef, c0, aa);
+    ld_coef<VEC>(coef + C, c0, ba);
+    ld_coef<VEC>(coef + 2 * C, c0, ab);
+    ld_coef<VEC>(coef + 3 * C, c0, bb);
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+#pragma unroll 4
+    for (int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x; v < nvec; v += stride) {
+        float e[VEC], r[VEC];
+        LdV<T, VEC>::ld(xa + v * VEC, e);
+        LdV<T, VEC>::ld(xb + v * VEC, r);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float t = fmaf(e[k], aa[k], ba[k]) + fmaf(r[k], ab[k], bb[k]);
+            e[k] = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+        }
+        LdV<T, VEC>::st(y + v * VEC, e);
+    }
+}
+
 // backward: acc[slot][0][c] = sum g, acc[slot][1][c] = sum g*(x - mean) (f64) -> B, D per channel, same block-level
 // prologue; block 0 writes dweight / dbias.
 template <typename T, int VEC, bool RELU, bool HAVE_Y, bool DRES, bool GROUPED>
@@ -791,6 +865,24 @@ int forward_acc(const void* x, const void* res, void* y, int64_t M, int64_t C, f
 }
 
 template <typename T>
+int forward_acc_dual(const void* xa, const void* xb, void* y, int64_t M, int64_t C, const DualBN& A, const DualBN& B,
+                     hipStream_t st) {
+    Plan p;
+    if (!make_plan<T>(M, C, {xa, xb, y}, p)) return AFAN_ESHAPE;
+    if (!p.vec || !aligned(A.stats, 16) || !aligned(B.stats, 16) || !aligned(A.acc, 16) || !aligned(B.acc, 16)) return AFAN_ESHAPE;
+    constexpr int NV = Elt<T>::VEC;
+    const int NS = acc_slots(C);
+    const size_t lds = (size_t)4 * C * sizeof(float);
+    const double inv_m = 1.0 / (double)M;
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+    AFAN_PROF("bn_nhwc_apply_kernel", p.tensor_bytes * 3, st);
+    apply_acc_dual_kernel<T, NV><<<apply_grid(p, M * C), BLOCK, lds, st>>>((const T*)xa, (const T*)xb, (T*)y, p.nvec, p.CV, (int)C,
+                                                                           NS, A, B, inv_m, unbias, running_updates());
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+template <typename T>
 int backward_acc(const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
                  const float* stats, int relu, double* acc, int acc_ready, float* dweight, float* dbias,
                  int accumulate, hipStream_t st, int groups = 1) {
@@ -835,6 +927,13 @@ int fwd_acc(int dtype, const void* x, const void* res, void* y, int64_t M, int64
             int64_t* nbt, hipStream_t st, int groups) {
     return dtype == AFAN_F32 ? forward_acc<float>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st, groups)
                              : forward_acc<uint16_t>(x, res, y, M, C, eps, mom, w, b, relu, acc, acc_ready, stats, rm, rv, nbt, st, groups);
+}
+int fwd_acc_dual(int dtype, const void* xa, const void* xb, void* y, int64_t M, int64_t C, float eps_a, float mom_a,
+                 const float* w_a, const float* b_a, double* acc_a, float* stats_a, float* rm_a, float* rv_a, int64_t* nbt_a,
+                 float eps_b, float mom_b, const float* w_b, const float* b_b, double* acc_b, float* stats_b, float* rm_b,
+                 float* rv_b, int64_t* nbt_b, hipStream_t st) {
+    const DualBN A{acc_a, w_a, b_a, stats_a, rm_a, rv_a, nbt_a, eps_a, mom_a}, B{acc_b, w_b, b_b, stats_b, rm_b, rv_b, nbt_b, eps_b, mom_b};
+    return dtype == AFAN_F32 ? forward_acc_dual<float>(xa, xb, y, M, C, A, B, st) : forward_acc_dual<uint16_t>(xa, xb, y, M, C, A, B, st);
 }
 int bwd_acc(int dtype, const void* dy, const void* x, const void* y, void* dx, void* dres, int64_t M, int64_t C,
             const float* stats_in, int relu, double* acc, int acc_ready, float* dw, float* db, int accumulate,

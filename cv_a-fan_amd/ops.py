@@ -540,6 +540,27 @@ def bn_train_forward(x, weight, bias, residual, relu, eps, momentum, running_mea
     return y, stats
 
 
+def bn_train_forward_dual(xa, bna, sta, mom_a, xb, bnb, stb, mom_b):
+    """y = relu(bn_a(xa) + bn_b(xb)) in ONE launch (afan_bn_train_forward_acc_dual): a residual block's last BatchNorm and its
+    projection shortcut's, both fed by convolution-epilogue accumulators (ConvStats sta / stb).  bna / bnb: the modules
+    (weight, bias, eps, running buffers).  Returns (y, stats_a [4, C], stats_b [4, C])."""
+    lib = _lib.load()
+    _need(xa, "xa"), _need(xb, "xb", xa.dtype)
+    _same_layout(xa, xb)
+    n, c, hw = _nchw(xa)
+    y = torch.empty_like(xa)
+    stats = torch.empty((2, 4, c), dtype=torch.float32, device=xa.device)
+    _bn_record(bnb.running_mean, bnb.running_var, bnb.num_batches_tracked, stats[1], n * hw, bnb.eps, mom_b, 1)
+    _bn_record(bna.running_mean, bna.running_var, bna.num_batches_tracked, stats[0], n * hw, bna.eps, mom_a, 1)
+    check(lib.afan_bn_train_forward_acc_dual(
+        _ptr(xa), _ptr(xb), _ptr(y), _DT[xa.dtype], n, c, hw,
+        float(bna.eps), float(mom_a), _ptr(bna.weight), _ptr(bna.bias), _ptr(sta.acc), _ptr(stats[0]), _ptr(bna.running_mean),
+        _ptr(bna.running_var), _ptr(bna.num_batches_tracked),
+        float(bnb.eps), float(mom_b), _ptr(bnb.weight), _ptr(bnb.bias), _ptr(stb.acc), _ptr(stats[1]), _ptr(bnb.running_mean),
+        _ptr(bnb.running_var), _ptr(bnb.num_batches_tracked), _stream(xa)), "afan_bn_train_forward_acc_dual")
+    return y, stats[0], stats[1]
+
+
 def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
     lib = _lib.load()
     _need(x, "x")

@@ -457,6 +457,7 @@ class _BlockFn(torch.autograd.Function):
         G = _Flags.bn_groups
         mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
         rawsc = ssc = first = None
+        dual_sc = False
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             c1, b1 = chain[0]
@@ -472,7 +473,11 @@ class _BlockFn(torch.autograd.Function):
                 rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
                                           stats_buf=csc._stats_buf, groups=G)      # (1x1: no dilation)
                 csc._stats_buf = stc.partials
-            res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
+            # with both convolutions' moments in accumulator blocks the projection's BatchNorm is applied by the block's
+            # LAST launch (ops.bn_train_forward_dual: relu(bn_n(raw_n) + bn_sc(raw_sc))), its output tensor never written
+            dual_sc = first is not None and stc.acc is not None
+            if not dual_sc:
+                res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
         elif blk._sc_kind == "pad":
             # option-A shortcut (resnet_s.py:64-65): every second pixel, zero channels either side — data movement only
             res = blk.shortcut(x).contiguous(memory_format=torch.channels_last)
@@ -486,7 +491,12 @@ class _BlockFn(torch.autograd.Function):
                 raw, st = ops.conv_fwd(a, c.lp_weight(), c.stride[0], stats_shift=b.running_mean, want_stats=True,
                                        stats_buf=c._stats_buf, groups=G, dilation=c.dilation[0])
                 c._stats_buf = st.partials
-            a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
+            if i == n - 1 and dual_sc and st.acc is not None:
+                a, s_i, ssc = ops.bn_train_forward_dual(raw, b, st, mom(b), rawsc, bsc, stc, mom(bsc))
+            else:
+                if i == n - 1 and dual_sc:          # (the last convolution's moments did not go to accumulators after all)
+                    res, ssc = _bn_fwd_g(rawsc, bsc, None, False, stc, G, mom(bsc))
+                a, s_i = _bn_fwd_g(raw, b, res if i == n - 1 else None, True, st, G, mom(b))
             saved += [raw, a, s_i]
         ctx.blk, ctx.want_pgrad, ctx.n, ctx.G = blk, want_pgrad, n, G
         ctx.branch = _Flags.bn_branch      # dual-BN: the backward reads the same parameter set from the modules

@@ -218,6 +218,19 @@ int afan_bn_train_forward_acc(const void* x, const void* residual, void* y, int 
                               int64_t hw, float eps, float momentum, const float* weight, const float* bias,
                               int relu, double* acc, int acc_ready, float* save_stats, float* running_mean,
                               float* running_var, int64_t* num_batches, int groups, afan_stream_t stream);
+
+/* The end of a residual block with a projection shortcut (Classification/resnet_s.py:72-77, option B), one launch:
+ *   y = relu(bn_a(x_a) + bn_b(x_b)),  x_a = the block's last convolution output, x_b = the 1x1 projection's output,
+ * both train-mode BatchNorms with their moments already in accumulator blocks acc_a / acc_b (filled by the producing
+ * convolutions' epilogues, shift snapshot behind them).  Writes both save_stats blocks, applies both running-statistics
+ * updates (afan_bn_set_running_updates times) — the same values as afan_bn_train_forward_acc(x_b) followed by
+ * afan_bn_train_forward_acc(x_a, residual = its result, relu), without the bf16 rounding of the intermediate tensor. */
+int afan_bn_train_forward_acc_dual(const void* x_a, const void* x_b, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
+                                   float eps_a, float momentum_a, const float* weight_a, const float* bias_a, double* acc_a,
+                                   float* save_stats_a, float* running_mean_a, float* running_var_a, int64_t* num_batches_a,
+                                   float eps_b, float momentum_b, const float* weight_b, const float* bias_b, double* acc_b,
+                                   float* save_stats_b, float* running_mean_b, float* running_var_b, int64_t* num_batches_b,
+                                   afan_stream_t stream);
 int afan_bn_backward_acc(const void* dy, const void* x, const void* y, void* dx, void* d_residual, int dtype,
                          int64_t n, int64_t c, int64_t hw, const float* save_stats, int relu, double* acc,
                          int acc_ready, float* dweight, float* dbias, int accumulate, int groups,

@@ -33,14 +33,25 @@ import torch.nn.functional as F
 _EMU = [False]
 
 
+_EMU_ROUND_PROJECTION = [False]
+
+
 class emulate_bf16:
+    """round_projection: the BasicBlock's projection-shortcut BatchNorm output is a stored bf16 tensor (the product's
+    per-launch path: slab statistics, grouped passes) instead of staying in registers inside the block's last launch (the
+    product's default since round 3: afan_bn_train_forward_acc_dual)."""
+
+    def __init__(self, round_projection=False):
+        self.round_projection = bool(round_projection)
+
     def __enter__(self):
-        self.old = _EMU[0]
+        self.old = (_EMU[0], _EMU_ROUND_PROJECTION[0])
         _EMU[0] = True
+        _EMU_ROUND_PROJECTION[0] = self.round_projection
         return self
 
     def __exit__(self, *exc):
-        _EMU[0] = self.old
+        _EMU[0], _EMU_ROUND_PROJECTION[0] = self.old
         return False
 
 
@@ -148,7 +159,11 @@ class Block(nn.Module):
             o = _r(F.relu(self.bn1(_conv(self.conv1, t))))
             o = self.bn2(_conv(self.conv2, o))
             sc = self.shortcut
-            res = _r(sc[1](_conv(sc[0], t))) if (isinstance(sc, nn.Sequential) and len(sc) == 2) else sc(t)
+            if isinstance(sc, nn.Sequential) and len(sc) == 2:
+                res = sc[1](_conv(sc[0], t))
+                res = _r(res) if _EMU_ROUND_PROJECTION[0] else res
+            else:
+                res = sc(t)
             return _r(F.relu(o + res))
         o = F.relu(self.bn1(self.conv1(t)))
         o = self.bn2(self.conv2(o))

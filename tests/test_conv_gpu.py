@@ -434,3 +434,46 @@ def test_dgrad_with_fused_projection_equals_two_launches(pkg, gpu, n, ci, co, h,
     e_t = float((two.double() - gx).norm() / gx.norm())
     assert e_f < 4e-3 and e_f <= e_t * 1.05 + 1e-6, (e_f, e_t)       # one rounding instead of two
     assert fused.is_contiguous(memory_format=cl)
+
+
+@pytest.mark.parametrize("n,ci,co,h", [(8, 64, 128, 32), (4, 128, 256, 16), (2, 256, 512, 8)])
+def test_block_end_dual_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h):
+    """afan_bn_train_forward_acc_dual: relu(bn_a(raw_a) + bn_b(raw_b)) with both BatchNorms' moments taken from convolution
+    epilogues — one launch for the end of a projection block (resnet_s.py:72-77).  Against the two launches it replaces:
+    statistics blocks and running buffers bit-identical, output equal up to the bf16 rounding of the intermediate tensor
+    the fused kernel no longer stores (compared in fp32 against the unrounded formula)."""
+    import torch.nn as nn
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(4)
+    cl = torch.channels_last
+    x = torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl)
+    w1 = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).to(gpu).bfloat16().contiguous(memory_format=cl)
+    wsc = (torch.randn(co, ci, 1, 1, generator=g) * 0.1).to(gpu).bfloat16().contiguous(memory_format=cl)
+    res = {}
+    for mode in ("dual", "two"):
+        bna, bnb = nn.BatchNorm2d(co).to(gpu), nn.BatchNorm2d(co).to(gpu)
+        with torch.no_grad():
+            for b_, s_ in ((bna, 1), (bnb, 2)):
+                gg = torch.Generator().manual_seed(s_)
+                b_.weight.copy_(1 + 0.2 * torch.randn(co, generator=gg))
+                b_.bias.copy_(0.1 * torch.randn(co, generator=gg))
+                b_.running_mean.copy_(0.05 * torch.randn(co, generator=gg))
+        ops.acc_reset(gpu)
+        (ra, rb), (sta, stb) = ops.conv_fwd_multi(x, [w1, wsc], 2, [1, 1], [bna.running_mean, bnb.running_mean])
+        if mode == "dual":
+            y, sa, sb = ops.bn_train_forward_dual(ra, bna, sta, 0.1, rb, bnb, stb, 0.1)
+        else:
+            r_, sb = ops.bn_train_forward(rb, bnb.weight, bnb.bias, None, False, bnb.eps, 0.1, bnb.running_mean, bnb.running_var,
+                                          bnb.num_batches_tracked, stb)
+            y, sa = ops.bn_train_forward(ra, bna.weight, bna.bias, r_, True, bna.eps, 0.1, bna.running_mean, bna.running_var,
+                                         bna.num_batches_tracked, sta)
+        res[mode] = (y.float(), sa.clone(), sb.clone(), {k: v.clone() for b_ in (bna, bnb) for k, v in b_.state_dict().items() if "running" in k or "num" in k},
+                     ra.float(), rb.float())
+    d, t = res["dual"], res["two"]
+    assert torch.equal(d[1], t[1]) and torch.equal(d[2], t[2])
+    for k in t[3]:
+        assert torch.equal(d[3][k], t[3][k]), k
+    exact = torch.relu(d[4] * d[1][2].view(1, -1, 1, 1) + d[1][3].view(1, -1, 1, 1) + d[5] * d[2][2].view(1, -1, 1, 1) + d[2][3].view(1, -1, 1, 1))
+    e_dual = float((d[0] - exact).norm() / exact.norm())
+    e_two = float((t[0] - exact).norm() / exact.norm())
+    assert e_dual < 3e-3 and e_dual <= e_two, (e_dual, e_two)          # one bf16 rounding instead of two
