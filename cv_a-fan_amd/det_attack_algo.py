@@ -97,7 +97,10 @@ def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, lo
     y = {"bb": bboxes_batch, "lb": labels_batch}
     fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
     adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
-    fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
+    if hasattr(model, "head_features"):      # the three head passes (:78-80) are prefixes of one another: one pass, no graph
+        fm = model.train().head_features(image_batch, (1, 2, 3))
+    else:
+        fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
     rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
     clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
     adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)

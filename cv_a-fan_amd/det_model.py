@@ -251,6 +251,20 @@ class ResNet101(nn.Module):
         x = self.bn1.fused(self.conv1(x), None, True)
         return self.maxpool(x)
 
+    def head_features(self, x, idxs=(1, 2, 3)):
+        """The feature maps after layers `idxs` from ONE pass, detached: what the three `flag: 'head'` calls of
+        train_aug_sat_muti_advt.py:78-80 return (same images, frozen BatchNorm, no dropout: each is a prefix of the next)."""
+        out = {}
+        with torch.no_grad():
+            x = self._stem(x)
+            for i, st in enumerate([self.layer1, self.layer2, self.layer3], start=1):
+                if i > max(idxs):
+                    break
+                x = st(x)
+                if i in idxs:
+                    out[i] = x
+        return [out[i] for i in idxs]
+
     def forward(self, input_dict):
         flag = input_dict["flag"]
         stages = [self.layer1, self.layer2, self.layer3]
@@ -449,6 +463,10 @@ class Model(nn.Module):
         super().train(mode)
         self._mode_walked = mode
         return self
+
+    def head_features(self, x, idxs=(1, 2, 3)):
+        """[forward({'x': x, 'flag': 'head', 'out_idx': i}).detach() for i in idxs] from one backbone pass."""
+        return self.features.head_features(x, idxs)
 
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):

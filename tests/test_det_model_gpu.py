@@ -141,3 +141,15 @@ def test_faster_rcnn_bf16_align_mode_runs_on_library_kernels(pkg, gpu):
     with torch.no_grad():
         boxes, classes, probs, idx = m({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
     assert boxes.shape[1] == 4 and len(boxes) == len(classes) == len(probs) == len(idx)
+
+
+def test_head_features_equal_the_three_head_forwards(pkg, gpu):
+    """Model.head_features: the three `flag: 'head'` forwards of train_aug_sat_muti_advt.py:78-80 as one pass without an autograd
+    graph — bit-identical feature maps (frozen BatchNorm, deterministic kernels)."""
+    g = golden("det_frcnn_r101")
+    m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+    x = torch.from_numpy(g["images"]).to(gpu)
+    one = m.head_features(x, (1, 2, 3))
+    for i, f in zip((1, 2, 3), one):
+        ref = m.train().forward({"x": x, "adv": None, "out_idx": i, "flag": "head"}).detach()
+        assert not f.requires_grad and torch.equal(f, ref), i
