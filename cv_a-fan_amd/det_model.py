@@ -451,6 +451,7 @@ class Model(nn.Module):
                                          rpn_post_nms_top_n, anchor_smooth_l1_loss_beta)
         self.detection = Model.Detection(pooler_mode, hidden, num_hidden_out, num_classes, proposal_smooth_l1_loss_beta)
         self.compute_dtype, self.channels_last = torch.float32, False
+        self._anchor_cache = {}
 
     def train(self, mode=True):
         """`model.train().forward(...)` is the reference's calling idiom — once per forward, 21 times per A-FAN iteration
@@ -487,9 +488,18 @@ class Model(nn.Module):
         return self
 
     def _anchors(self, features, image_shape):
+        """The anchor grid of this (image, feature map) geometry on the device, computed once: the reference rebuilds it in
+        numpy at every forward (model.py:75-77); on a 256-core host the small CPU tensor ops behind it cost 5 ms per forward."""
         b, _, ih, iw = image_shape
         _, _, fh, fw = features.shape
-        return self.rpn.generate_anchors(iw, ih, num_x_anchors=fw, num_y_anchors=fh).to(features.device).repeat(b, 1, 1), iw, ih
+        key = (int(iw), int(ih), int(fw), int(fh), int(b), features.device)
+        a = self._anchor_cache.get(key)
+        if a is None:
+            a = self.rpn.generate_anchors(iw, ih, num_x_anchors=fw, num_y_anchors=fh).to(features.device).repeat(b, 1, 1)
+            if len(self._anchor_cache) > 64:
+                self._anchor_cache.clear()
+            self._anchor_cache[key] = a
+        return a, iw, ih
 
     def forward(self, input_dict, gt_bboxes_batch=None, gt_classes_batch=None):
         flag = input_dict["flag"]

@@ -959,7 +959,15 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.pg, ctx.bias = want_pgrad, bias
         n, ci = x.shape
-        y = ops.conv_general_fwd(x.view(n, ci, 1, 1), weight.detach().view(weight.shape[0], ci, 1, 1),
+        co = weight.shape[0]
+        if ci >= 1024 and n <= 1024 and x.dtype == torch.float32 and weight.dtype == torch.float32:
+            # few rows, long reduction (the detection heads: 128 ROIs x 2048 -> 21 / 84): as a 1x1 convolution this is ONE
+            # workgroup walking the whole K chain (290-390 us); read as a weight-gradient problem — y^T[co, n] = sum_k
+            # w[co, k] x[n, k], k in the role of the pixels — the same kernels split the reduction over workgroups (~25 us)
+            yt = ops.conv_general_wgrad(x.view(1, n, ci, 1), weight.detach().contiguous().view(1, co, ci, 1), 1)
+            y = yt.view(co, n).t()
+            return (y + bias.detach()) if bias is not None else y.contiguous()
+        y = ops.conv_general_fwd(x.view(n, ci, 1, 1), weight.detach().view(co, ci, 1, 1),
                                  None if bias is None else bias.detach())
         return y.view(n, -1)
 
