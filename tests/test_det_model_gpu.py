@@ -153,3 +153,36 @@ def test_head_features_equal_the_three_head_forwards(pkg, gpu):
     for i, f in zip((1, 2, 3), one):
         ref = m.train().forward({"x": x, "adv": None, "out_idx": i, "flag": "head"}).detach()
         assert not f.requires_grad and torch.equal(f, ref), i
+
+
+def test_frozen_bottleneck_node_equals_layer_by_layer_path(pkg, gpu):
+    """det_model._FrozenBlockFn (a frozen-BatchNorm bottleneck as one autograd node: same launches, one Function.apply) against
+    the layer-by-layer modules on the same bf16 kernels: a training forward's four losses and every parameter gradient.  The
+    only arithmetic difference is the identity shortcut's gradient, added in the dgrad epilogue instead of by a bf16 add."""
+    g = golden("det_frcnn_r101")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    fn = pkg.det_model._FrozenBlockFn
+    res, old = {}, fn.ON
+    try:
+        for on in (True, False):
+            fn.ON = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            arena = pkg.arena.ParamArena(m, skip=())
+            torch.manual_seed(11)                                   # the host randperm draws of the RPN / ROI sampling
+            x = images.clone().requires_grad_(True)
+            before = pkg.ops.CALLS["conv_fwd"]
+            losses = m.train().forward({"x": x, "adv": None, "out_idx": 0, "flag": "clean"}, bboxes, labels)
+            convs = pkg.ops.CALLS["conv_fwd"] - before
+            arena.zero_grad()
+            sum(l.mean() for l in losses).backward()
+            torch.cuda.synchronize()
+            res[on] = ([float(l.detach().mean()) for l in losses], {n: p.grad.float().clone() for n, p in zip(arena.names, arena.params)},
+                       x.grad.float().clone(), convs)
+    finally:
+        fn.ON = old
+    a, b = res[True], res[False]
+    assert a[3] == b[3] > 100                                       # the same convolution launches either way
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-3, atol=2e-4)
+    assert _rel(a[2].cpu().numpy(), b[2].cpu().numpy()) < 3e-2      # image gradient through 33 bf16 blocks
+    worst = max((_rel(a[1][n].cpu().numpy(), b[1][n].cpu().numpy()), n) for n in b[1] if float(b[1][n].abs().max()) > 0)
+    assert worst[0] < 3e-2, worst
