@@ -62,6 +62,8 @@ SIGNATURES = {
     "afan_conv_dgrad_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
+    "afan_conv_wgrad_plan": (_i, [_l, _l, _l, _l, _l, _i, _i]),
+    "afan_conv_wgrad_multi_nhwc_bf16": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "afan_conv_wgrad2_nhwc_bf16": (_i, [_p, _p, _l, _p, _p, _l, _p, _l, _l, _l, _l, _i, _i, _i, _p, _i, _p]),
     "afan_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _i, _p]),
     "afan_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, _i, _i, _p]),

@@ -72,7 +72,8 @@ struct WgradP {
 };
 
 template <int BM, int BN, bool INC>   // BM = co tile, BN = ci tile; INC: see WgradP::dn
-__global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
+__device__ __forceinline__ void wgrad_body(const WgradP& p, const uint32_t lin, const uint32_t tiles_, const uint32_t taps_,
+                                           const uint32_t total) {
     constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 32, NI = TN / 32;
     constexpr int LDA = BM + 32, LDB = BN + 32;            // elements per LDS row
     constexpr int PA = BM / 8, PB = BN / 8;                // 16-byte pieces per row
@@ -91,8 +92,6 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
     // index that is contiguous per XCD, with the tap fastest: the nine taps of a group run back to back on ONE XCD.
     int tap, slice, tile;
     {
-        const uint32_t taps_ = gridDim.y, tiles_ = gridDim.x, total = gridDim.x * gridDim.y * gridDim.z;
-        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         uint32_t logical = lin;
         if (p.xcd_remap) {
             const uint32_t per = total >> 3, main_ = per << 3;           // the last total % 8 slots keep their index
@@ -252,6 +251,57 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
             }
 }
 
+template <int BM, int BN, bool INC>
+__global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
+    wgrad_body<BM, BN, INC>(p, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y,
+                            gridDim.x * gridDim.y * gridDim.z);
+}
+
+// Up to MAXQ independent weight-gradient problems (different layers, the same tile configuration) in ONE launch: the three
+// convolutions of a bottleneck at 33 x 33 pixels and 2 images are 35-step reductions — 13-25 us launches that do not fill the
+// chip and cost mostly their own ramp.  Workgroup `blockIdx.x` belongs to problem q with first[q] <= blockIdx.x < first[q+1]
+// and keeps that problem's own (tile, tap, slice) order, XCD remap included.
+constexpr int MAXQ = 4;
+struct WgradPN {
+    int n;
+    uint32_t first[MAXQ + 1];
+    uint32_t tiles[MAXQ], taps[MAXQ];
+    WgradP p[MAXQ];
+};
+template <int BM, int BN, bool INC>
+__global__ __launch_bounds__(THREADS) void wgrad_multi_kernel(const WgradPN pn) {
+    int q = 0;
+    while (q + 1 < pn.n && blockIdx.x >= pn.first[q + 1]) ++q;
+    wgrad_body<BM, BN, INC>(pn.p[q], blockIdx.x - pn.first[q], pn.tiles[q], pn.taps[q], pn.first[q + 1] - pn.first[q]);
+}
+
+struct RedPN {
+    const float* slab[MAXQ];
+    float* grad[MAXQ];
+    int S[MAXQ], taps[MAXQ], Co[MAXQ], Ci[MAXQ];
+};
+// the slab reductions of those problems in one launch (blockIdx.y = problem; same arithmetic and order as wgrad_reduce_kernel)
+__global__ __launch_bounds__(THREADS) void wgrad_reduce_multi_kernel(const RedPN r, int accumulate) {
+    const int q = blockIdx.y;
+    const float* __restrict__ slab = r.slab[q];
+    float* __restrict__ grad = r.grad[q];
+    const int S = r.S[q], taps = r.taps[q], Co = r.Co[q], Ci = r.Ci[q];
+    const int64_t per = (int64_t)taps * Co * Ci;
+    const int64_t nvec = per / 4;
+    for (int64_t v = (int64_t)blockIdx.x * THREADS + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * THREADS) {
+        const int64_t e = v * 4;
+        const int ci = (int)(e % Ci);
+        const int64_t t2 = e / Ci;
+        const int co = (int)(t2 % Co);
+        const int tap = (int)(t2 / Co);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slab + k * per + e);
+        float* g = grad + ((int64_t)co * taps + tap) * Ci + ci;
+        if (accumulate) s += *reinterpret_cast<const f32x4*>(g);
+        *reinterpret_cast<f32x4*>(g) = s;
+    }
+}
+
 // grad[co][tap][ci] (+)= sum_s slab[s][tap][co][ci], slices added in index order
 __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad,
                                                                int S, int taps, int Co, int Ci, int accumulate) {
@@ -298,6 +348,10 @@ Plan make_plan(int64_t P, int co, int ci, int taps) {
     pl.S = (int)((total_steps + pl.steps - 1) / pl.steps);
     return pl;
 }
+
+int build_problem(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2, float* grad, int64_t hi,
+                  int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation, float* workspace, int accumulate,
+                  WgradP& p, Plan& pl);
 
 template <int BM, int BN>
 int launch(const WgradP& p, int taps, hipStream_t st) {
@@ -359,6 +413,36 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         if (n2 > 0 && (!aligned(x2, 16) || !aligned(dy2, 16))) return AFAN_EALIGN;
         return afan_wgrad_small::launch(x, dy, grad, n, hi, wi, ci, co, stride, workspace, accumulate, st, x2, dy2, n2);
     }
+    WgradP p{};
+    Plan pl;
+    int e = build_problem(x, dy, n, x2, dy2, n2, grad, hi, wi, ci, co, k, stride, dilation, workspace, accumulate, p, pl);
+    if (e) return e;
+    const int taps = k * k;
+    const int64_t P = (n + n2) * (int64_t)p.Ho * p.Wo;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    {
+        AFAN_PROF_FLOPS("conv_wgrad_kernel", 2.0 * (double)(P * co + n * hi * wi * ci) + 4.0 * pl.S * taps * co * ci,
+                        2.0 * (double)P * co * ci * taps, st);
+        if (pl.bm == 128) rc = pl.bn == 128 ? launch<128, 128>(p, taps, st) : launch<128, 64>(p, taps, st);
+        else rc = pl.bn == 128 ? launch<64, 128>(p, taps, st) : launch<64, 64>(p, taps, st);
+    }
+    if (rc || p.direct) return rc;
+    const int64_t per = (int64_t)taps * co * ci;
+    AFAN_PROF("conv_wgrad_reduce_kernel", 4.0 * per * (pl.S + 1 + (accumulate ? 1 : 0)), st);
+    wgrad_reduce_kernel<<<grid_for(per / 4, THREADS, 1024), THREADS, 0, st>>>(workspace, grad, pl.S, taps, (int)co, (int)ci,
+                                                                              accumulate);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// the tiled kernel's problem description (operands checked, plan chosen): shared by the single and the multi launch
+int build_problem(const void* x, const void* dy, int64_t n, const void* x2, const void* dy2, int64_t n2, float* grad, int64_t hi,
+                  int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation, float* workspace, int accumulate,
+                  WgradP& p, Plan& pl) {
     if (ci % 8 || co % 8 || ci < 40 || co < 40 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
     if (!x || !dy || !grad || !workspace) return AFAN_ENULL;
     if (!aligned(x, 16) || !aligned(dy, 16) || !aligned(grad, 16) || !aligned(workspace, 16)) return AFAN_EALIGN;
@@ -368,8 +452,7 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
     if (P * co * 2 > 0x7fffffffLL || (n + n2) * hi * wi * ci * 2 > 0x7fffffffLL) return AFAN_ESHAPE;
     if (n2 > 0 && (P1 % BKP != 0 || !aligned(x2, 16) || !aligned(dy2, 16))) return n2 > 0 && P1 % BKP != 0 ? AFAN_ESHAPE : AFAN_EALIGN;
     const int taps = k * k;
-    const Plan pl = make_plan(P, (int)co, (int)ci, taps);
-    WgradP p{};
+    pl = make_plan(P, (int)co, (int)ci, taps);
     p.x = (const uint16_t*)x; p.dy = (const uint16_t*)dy; p.slab = workspace;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci; p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
     p.k = k; p.stride = stride; p.pad = pad; p.dil = dilation; p.S = pl.S; p.steps_per_slice = pl.steps; p.P = (uint32_t)P;
@@ -394,19 +477,81 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
         p.direct = (direct_on && pl.S == 1) ? grad : nullptr;
         p.accumulate = accumulate;
     }
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    {
-        AFAN_PROF_FLOPS("conv_wgrad_kernel", 2.0 * (double)(P * co + n * hi * wi * ci) + 4.0 * pl.S * taps * co * ci,
-                        2.0 * (double)P * co * ci * taps, st);
-        if (pl.bm == 128) rc = pl.bn == 128 ? launch<128, 128>(p, taps, st) : launch<128, 64>(p, taps, st);
-        else rc = pl.bn == 128 ? launch<64, 128>(p, taps, st) : launch<64, 64>(p, taps, st);
+    return AFAN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// what the tiled kernel would do with this problem: 0 = not its problem (stem / small-channel / unsupported), else
+// bm | bn << 8 | (incremental pixel walk ? 1 << 16 : 0) | 1 << 17 — problems with equal codes can share a multi launch
+int afan_conv_wgrad_plan(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride) {
+    if (ci == 3 || afan_wgrad_small::eligible(n, hi, wi, ci, co, k, stride)) return 0;
+    if (n <= 0 || hi <= 0 || wi <= 0 || ci % 8 || co % 8 || ci < 40 || co < 40 || !(k == 1 || k == 3) || !(stride == 1 || stride == 2))
+        return 0;
+    const int64_t ho = (hi + 2 * (k / 2) - k) / stride + 1, wo = (wi + 2 * (k / 2) - k) / stride + 1;
+    const Plan pl = make_plan(n * ho * wo, (int)co, (int)ci, k * k);
+    static const bool inc_on = [] { const char* v = getenv("AFAN_WGRAD_INC"); return !v || atoi(v) != 0; }();
+    const int inc = (inc_on && BKP % wo == 0) ? 1 : 0;
+    return pl.bm | (pl.bn << 8) | (inc << 16) | (1 << 17);
+}
+
+// nb (2..4) weight gradients of DIFFERENT layers in one launch + one reduction launch: grad[b] (+)= wgrad(x[b], dy[b]) with the
+// per-problem shapes given as arrays; all problems must have the same afan_conv_wgrad_plan code.  workspace: the sum of the
+// problems' afan_conv_wgrad_workspace_floats.  Results are bit-identical to nb separate afan_conv_wgrad_nhwc_bf16 calls.
+int afan_conv_wgrad_multi_nhwc_bf16(int nb, const void* const* x, const void* const* dy, float* const* grad, const int64_t* n,
+                                    const int64_t* hi, const int64_t* wi, const int64_t* ci, const int64_t* co, const int* k,
+                                    const int* stride, const int* dilation, float* workspace, int accumulate,
+                                    afan_stream_t stream) {
+    if (nb < 1 || nb > MAXQ) return AFAN_ESHAPE;
+    if (!x || !dy || !grad || !n || !hi || !wi || !ci || !co || !k || !stride || !dilation || !workspace) return AFAN_ENULL;
+    WgradPN pn{};
+    RedPN rp{};
+    pn.n = nb;
+    int code0 = 0;
+    int64_t woff = 0, max_vec = 0;
+    double bytes = 0, flops = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int code = afan_conv_wgrad_plan(n[b], hi[b], wi[b], ci[b], co[b], k[b], stride[b]);
+        if (!code || (b && code != code0)) return AFAN_ESHAPE;
+        code0 = code;
+        if (dilation[b] < 1 || (dilation[b] > 1 && (k[b] != 3 || stride[b] != 1))) return AFAN_ESHAPE;
+        Plan pl;
+        int e = build_problem(x[b], dy[b], n[b], nullptr, nullptr, 0, grad[b], hi[b], wi[b], ci[b], co[b], k[b], stride[b],
+                              dilation[b], workspace + woff, accumulate, pn.p[b], pl);
+        if (e) return e;
+        if (pn.p[b].direct) return AFAN_ESHAPE;                      // (the direct form has no slab: single launches only)
+        const int taps = k[b] * k[b];
+        const int bm = code & 0xff, bn = (code >> 8) & 0xff;
+        pn.tiles[b] = (uint32_t)(((co[b] + bm - 1) / bm) * ((ci[b] + bn - 1) / bn));
+        pn.taps[b] = (uint32_t)taps;
+        pn.first[b + 1] = pn.first[b] + pn.tiles[b] * taps * (uint32_t)pl.S;
+        rp.slab[b] = workspace + woff; rp.grad[b] = grad[b]; rp.S[b] = pl.S; rp.taps[b] = taps; rp.Co[b] = (int)co[b]; rp.Ci[b] = (int)ci[b];
+        const int64_t per = (int64_t)taps * co[b] * ci[b];
+        woff += (int64_t)pl.S * per;
+        if (per / 4 > max_vec) max_vec = per / 4;
+        const double P = (double)n[b] * pn.p[b].Ho * pn.p[b].Wo;
+        bytes += 2.0 * (P * co[b] + (double)n[b] * hi[b] * wi[b] * ci[b]) + 4.0 * pl.S * per;
+        flops += 2.0 * P * co[b] * ci[b] * taps;
     }
-    if (rc || p.direct) return rc;
-    const int64_t per = (int64_t)taps * co * ci;
-    AFAN_PROF("conv_wgrad_reduce_kernel", 4.0 * per * (pl.S + 1 + (accumulate ? 1 : 0)), st);
-    wgrad_reduce_kernel<<<grid_for(per / 4, THREADS, 1024), THREADS, 0, st>>>(workspace, grad, pl.S, taps, (int)co, (int)ci,
-                                                                              accumulate);
+    hipStream_t st = (hipStream_t)stream;
+    const int bm = code0 & 0xff, bn = (code0 >> 8) & 0xff;
+    const bool inc = (code0 >> 16) & 1;
+    const unsigned G = pn.first[nb];
+    {
+    AFAN_PROF_FLOPS("conv_wgrad_kernel", bytes, flops, st);
+#define AFAN_WM(BM_, BN_)                                                                                   \
+    do {                                                                                                    \
+        if (inc) wgrad_multi_kernel<BM_, BN_, true><<<G, THREADS, 0, st>>>(pn);                             \
+        else wgrad_multi_kernel<BM_, BN_, false><<<G, THREADS, 0, st>>>(pn);                                \
+    } while (0)
+    if (bm == 128) { if (bn == 128) AFAN_WM(128, 128); else AFAN_WM(128, 64); }
+    else { if (bn == 128) AFAN_WM(64, 128); else AFAN_WM(64, 64); }
+#undef AFAN_WM
+    AFAN_LAUNCH_CHECK();
+    }
+    AFAN_PROF("conv_wgrad_reduce_kernel", 4.0 * (double)woff, st);
+    wgrad_reduce_multi_kernel<<<dim3((unsigned)grid_for(max_vec, THREADS, 1024), (unsigned)nb), THREADS, 0, st>>>(rp, accumulate);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

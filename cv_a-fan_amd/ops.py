@@ -924,6 +924,40 @@ def conv_general_dgrad(dy, w, in_hw, stride=1, padding=0, dilation=1):
     return dx
 
 
+def conv_wgrad_plan(x, dy, k, stride):
+    """Tile-configuration code of the tuned weight-gradient kernel for this problem (0: not on that kernel); equal codes can
+    share a conv_wgrad_multi launch."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and dy.dtype == torch.bfloat16 and dy.is_contiguous(memory_format=torch.channels_last)):
+        return 0
+    n, ci, hi, wi = x.shape
+    return int(_lib.load().afan_conv_wgrad_plan(n, hi, wi, ci, dy.shape[1], int(k), int(stride)))
+
+
+def conv_wgrad_multi(items):
+    """items = [(x, dy, k, stride, dilation, grad)] (2..4 layers, equal conv_wgrad_plan codes): grad += wgrad(x, dy) for all of
+    them in ONE launch + one reduction launch (afan_conv_wgrad_multi_nhwc_bf16), bit-identical to separate conv_wgrad calls."""
+    lib = _lib.load()
+    nb = len(items)
+    CALLS["conv_wgrad"] += nb
+    total = 0
+    for (x, dy, k, st, dil, grad) in items:
+        _cl4(x, "x"), _cl4(dy, "dy")
+        n, ci, hi, wi = x.shape
+        co = dy.shape[1]
+        if tuple(grad.shape) != (co, ci, k, k) or grad.dtype != torch.float32 or not (grad.is_contiguous(memory_format=torch.channels_last) or k == 1 or ci == 1):
+            raise ValueError("grad must be fp32 [Co,Ci,k,k] with channels_last strides")
+        total += lib.afan_conv_wgrad_workspace_floats(n, hi, wi, ci, co, k, st)
+    ws = _workspace(items[0][0], total, "wgrad")
+    ap, al, ai = C.c_void_p * nb, C.c_int64 * nb, C.c_int * nb
+    check(lib.afan_conv_wgrad_multi_nhwc_bf16(
+        nb, ap(*[i[0].data_ptr() for i in items]), ap(*[i[1].data_ptr() for i in items]), ap(*[i[5].data_ptr() for i in items]),
+        al(*[i[0].shape[0] for i in items]), al(*[i[0].shape[2] for i in items]), al(*[i[0].shape[3] for i in items]),
+        al(*[i[0].shape[1] for i in items]), al(*[i[1].shape[1] for i in items]), ai(*[int(i[2]) for i in items]),
+        ai(*[int(i[3]) for i in items]), ai(*[int(i[4]) for i in items]), _ptr(ws), 1, _stream(items[0][0])),
+        "afan_conv_wgrad_multi_nhwc_bf16")
+
+
 def conv_general_wgrad(x, dy, k, stride=1, padding=0, dilation=1, grad=None, accumulate=False):
     """fp32 weight gradient [Co,Ci,k,k] of y = conv2d(x, w, ...): written / added into `grad` (KCRS or KRSC memory), or
     returned as a new tensor in the memory order that matches the activations' layout."""

@@ -295,9 +295,40 @@ def wgrad_stream(on):
         _WgradStream.ON = old
 
 
-def _wgrad_accumulate(x, dy, c):
+class _WgradBatch:
+    """Inside a block's backward: the block's weight-gradient problems are collected and issued together at the end — those
+    that the tuned kernel takes with the SAME tile configuration as ONE launch + one reduction launch
+    (ops.conv_wgrad_multi: bit-identical to separate launches), the rest one by one.  At DeepLab's per-GPU share a
+    bottleneck's three weight gradients are 35-step reductions of 13-25 us each; together they cost the time of one."""
+    ON = os.environ.get("AFAN_WGRAD_MULTI", "1") != "0"
+    pending = None          # list while a block backward collects
+
+    @classmethod
+    def flush(cls):
+        items, cls.pending = cls.pending, None
+        if not items:
+            return
+        groups = {}
+        for it in items:
+            x, dy, c = it
+            ok = (not _Flags.wgrad_stash and getattr(c, "_pending_wgrad", None) is None and _accumulates_in_place(c.weight)
+                  and (c.weight.grad.is_contiguous(memory_format=torch.channels_last) or c.kernel_size[0] == 1))
+            groups.setdefault(ops.conv_wgrad_plan(x, dy, c.kernel_size[0], c.stride[0]) if ok else 0, []).append(it)
+        for code, its in groups.items():
+            while code and len(its) >= 2:
+                chunk, its = its[:4], its[4:]
+                args = [(x, dy, c.kernel_size[0], c.stride[0], c.dilation[0], c.weight.grad) for x, dy, c in chunk]
+                _WgradStream.run(lambda args=args: ops.conv_wgrad_multi(args), *[t for a in args for t in a[:2]])
+            for x, dy, c in its:
+                _wgrad_accumulate(x, dy, c, batch=False)
+
+
+def _wgrad_accumulate(x, dy, c, batch=True):
     """Weight gradient of conv module c added into its arena gradient view (queued on the weight-gradient stream while a
-    backward runs, see _WgradStream)."""
+    backward runs, see _WgradStream; collected per block, see _WgradBatch)."""
+    if batch and _WgradBatch.pending is not None:
+        _WgradBatch.pending.append((x, dy, c))
+        return
     if _Flags.wgrad_stash and ops.conv_wgrad_supported(x.shape[1], dy.shape[1], c.kernel_size[0], c.stride[0],
                                                        (x.shape[0], x.shape[2], x.shape[3])) \
             and ops.wgrad_pairable(x, dy, c.kernel_size[0], c.stride[0]):
@@ -525,6 +556,19 @@ class _BlockFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, gout):
+        if not (_WgradBatch.ON and ctx.want_pgrad and _WgradBatch.pending is None):
+            return _BlockFn._backward_impl(ctx, gout)
+        _WgradBatch.pending = []
+        try:
+            out = _BlockFn._backward_impl(ctx, gout)
+        except BaseException:
+            _WgradBatch.pending = None
+            raise
+        _WgradBatch.flush()
+        return out
+
+    @staticmethod
+    def _backward_impl(ctx, gout):
         x, rawsc, ssc, *saved = ctx.saved_tensors
         blk, pg, n, G = ctx.blk, ctx.want_pgrad, ctx.n, ctx.G
         chain = blk._chain()

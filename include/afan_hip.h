@@ -324,6 +324,21 @@ int afan_conv_wgrad2_nhwc_bf16(const void* x, const void* dy, int64_t n, const v
                                float* grad, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride, int dilation,
                                float* workspace, int accumulate, afan_stream_t stream);
 
+/* Which tile configuration the tiled weight-gradient kernel would use for this problem: 0 = not its problem (image stem,
+ * small-channel layers, unsupported shapes), else an opaque code; problems with EQUAL codes can share one
+ * afan_conv_wgrad_multi_nhwc_bf16 launch. */
+int afan_conv_wgrad_plan(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k, int stride);
+/* nb (1..4) weight gradients of DIFFERENT layers — e.g. the three convolutions of a bottleneck
+ * (Segmentation/network/backbone/resnet.py:97-119) once all three output gradients exist — in ONE launch and one slab
+ * reduction: grad[b] (+)= wgrad(x[b], dy[b]), shapes per problem in the arrays (host arrays; device pointers inside).
+ * workspace = the sum of the problems' afan_conv_wgrad_workspace_floats.  Bit-identical to nb afan_conv_wgrad_nhwc_bf16
+ * calls (same slices, same order); at 33 x 33 pixels and 2 images each of those is a 35-step reduction that costs mostly
+ * its own launch. */
+int afan_conv_wgrad_multi_nhwc_bf16(int nb, const void* const* x, const void* const* dy, float* const* grad, const int64_t* n,
+                                    const int64_t* hi, const int64_t* wi, const int64_t* ci, const int64_t* co, const int* k,
+                                    const int* stride, const int* dilation, float* workspace, int accumulate,
+                                    afan_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * The GENERAL convolution, fp32-accurate (afan_conv_f32.hip): what torch.nn.Conv2d computes in the reference's fp32 training
  * (Classification/main_perturb.py:173-201, attack_algo.py:50-52; Segmentation/network/backbone/resnet.py:143,

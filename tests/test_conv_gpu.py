@@ -477,3 +477,27 @@ def test_block_end_dual_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h):
     e_dual = float((d[0] - exact).norm() / exact.norm())
     e_two = float((t[0] - exact).norm() / exact.norm())
     assert e_dual < 3e-3 and e_dual <= e_two, (e_dual, e_two)          # one bf16 rounding instead of two
+
+
+@pytest.mark.parametrize("shapes", [
+    [(2, 1024, 256, 33, 1, 1, 1), (2, 256, 256, 33, 3, 1, 1), (2, 256, 1024, 33, 1, 1, 1)],          # a layer3 bottleneck at 2 images
+    [(2, 2048, 512, 33, 1, 1, 1), (2, 512, 512, 33, 3, 1, 2), (2, 512, 2048, 33, 1, 1, 1), (2, 2048, 256, 33, 1, 1, 1)],
+    [(8, 128, 128, 16, 3, 1, 1), (8, 128, 128, 16, 3, 1, 1)]])
+def test_wgrad_multi_equals_separate_launches(pkg, gpu, shapes):
+    """afan_conv_wgrad_multi_nhwc_bf16: the weight gradients of several layers in one launch + one reduction launch, added
+    into their fp32 gradient tensors — bit-identical to one launch per layer (same slices, same order)."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(6)
+    cl = torch.channels_last
+    items, refs = [], []
+    for (n, ci, co, h, k, st, dil) in shapes:
+        x = torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl)
+        dy = (torch.randn(n, co, h, h, generator=g) * 0.1).to(gpu).bfloat16().contiguous(memory_format=cl)
+        g0 = torch.randn(co, ci, k, k, generator=g).to(gpu).contiguous(memory_format=cl)
+        items.append((x, dy, k, st, dil, g0.clone()))
+        refs.append(ops.conv_wgrad(x, dy, k, st, g0.clone(), accumulate=True, dilation=dil))
+    codes = {ops.conv_wgrad_plan(x, dy, k, st) for (x, dy, k, st, _, _) in items}
+    assert len(codes) == 1 and 0 not in codes
+    ops.conv_wgrad_multi(items)
+    for it, ref in zip(items, refs):
+        assert torch.equal(it[5], ref)
