@@ -81,8 +81,6 @@ def _workspace(ref, nfloats, tag):
 # BatchNorm sums in f64 accumulators (no partial slabs, no finalize launches) where the channel count allows it;
 # AFAN_BN_ACC=0 selects the partial-slab path everywhere (bitwise run-to-run reproducible, ~0.45 more launches per BN).
 BN_ACC = os.environ.get("AFAN_BN_ACC", "1") != "0"
-# stand-alone BatchNorm-backward reductions of tensors up to this many elements use the accumulator form (0: never)
-BN_BWD_ACC_MAX = int(os.environ.get("AFAN_BN_BWD_ACC_MAX", "0"))
 _ACC_DOUBLES = 1 << 20
 _acc_arenas = {}
 
@@ -622,11 +620,6 @@ def bn_backward(dy, x, y, stats, weight, bias, relu, want_dres, dweight=None, db
     ready = acc is not None
     if groups != 1 and acc is None:
         raise ValueError("grouped BatchNorm backward needs the accumulators of a grouped dgrad")
-    if acc is None and partials is None and 0 < x.numel() <= BN_BWD_ACC_MAX and bn_acc_ok(x) and layout_of(x) == AFAN_NHWC:
-        # small maps: the reduction's block sums go to the f64 accumulators and the apply kernel folds them in its prologue —
-        # no partial slab, no finalize launch (on large maps the atomics of a stand-alone reduction arrive as one burst and
-        # serialise per address: the slab + finalize form stays there)
-        acc = acc_take(x.device, c)
     if acc is not None:
         check(lib.afan_bn_backward_acc(_ptr(dy), _ptr(x), _ptr(y), _ptr(dx), _ptr(dres), _DT[x.dtype], n, c, hw,
                                        _ptr(stats), int(bool(relu)), _ptr(acc), int(ready), _ptr(dweight), _ptr(dbias),
