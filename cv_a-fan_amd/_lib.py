@@ -87,6 +87,10 @@ SIGNATURES = {
     "afan_maxpool2d_bwd": (_i, [_p, _p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _i, _p]),
     "afan_affine_relu_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_affine_coefs": (_i, [_p, _p, _p, _p, _l, _p, _p]),
+    "afan_frozen_bottleneck_fwd": (_i, [_p, _l, _l, _l, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "afan_frozen_bottleneck_bwd_scratch": (_l, [_l, _l, _l, _l, _l, _i]),
+    "afan_frozen_bottleneck_bwd": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                        _p, _p]),
     "afan_affine_apply": (_i, [_p, _p, _p, _i, _l, _l, _l, _p, _i, _p]),
     "afan_avgpool_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_avgpool_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),

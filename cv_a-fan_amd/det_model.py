@@ -26,7 +26,7 @@ from . import ops
 from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
 from .det_ops import nms, roi_align
 from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear,
-                       _own_conv_ok, _to_compute, _wgrad_accumulate)
+                       _own_conv_ok, _to_compute, _WgradStream)
 
 __all__ = ["Model", "ResNet101", "RegionProposalNetwork", "FrozenBatchNorm2d", "fasterrcnn_resnet101"]
 
@@ -192,59 +192,34 @@ class _FrozenBlockFn(torch.autograd.Function):
     """A frozen-BatchNorm bottleneck (backbone/resnet101_ori.py:78-127) as ONE autograd node on the bf16 channels-last path:
     the same launches as the layer-by-layer form — three (four) tuned convolutions, three (four) fused affine(+residual)
     (+ReLU) launches forward; affine backward, input gradient and weight gradient per layer backward, the identity shortcut's
-    gradient added in the first convolution's dgrad epilogue — but one `Function.apply` and one backward node instead of
-    seven each: the Detection iteration is bound by Python dispatch (2 600 applies per iteration before this node)."""
+    gradient added in the first convolution's dgrad epilogue — but one `Function.apply`, one backward node and ONE native call
+    each way (afan_frozen_bottleneck_fwd / _bwd issue the launches from C++) instead of seven of each: the Detection
+    iteration is bound by Python dispatch (2 600 applies per iteration before this node)."""
 
     @staticmethod
     def forward(ctx, x, blk, want_pgrad, *params):
         c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-        k1, k2, k3 = blk.bn1._coefs(), blk.bn2._coefs(), blk.bn3._coefs()
-        a1 = ops.affine_apply(ops.conv_fwd(x, c1.lp_weight(), 1), k1, None, True)
-        a2 = ops.affine_apply(ops.conv_fwd(a1, c2.lp_weight(), c2.stride[0]), k2, None, True)
-        r3 = ops.conv_fwd(a2, c3.lp_weight(), 1)
-        kd = None
-        if blk.downsample is not None:
-            cd, kd = blk.downsample[0], blk.downsample[1]._coefs()
-            res = ops.affine_apply(ops.conv_fwd(x, cd.lp_weight(), cd.stride[0]), kd, None, False)
-        else:
-            res = x
-        out = ops.affine_apply(r3, k3, res, True)
+        cd = blk.downsample[0] if blk.downsample is not None else None
+        ks = (blk.bn1._coefs(), blk.bn2._coefs(), blk.bn3._coefs(), blk.downsample[1]._coefs() if cd is not None else None)
+        out, a1, a2 = ops.frozen_bottleneck_fwd(x, c1.out_channels, c2.stride[0],
+                                                (c1.lp_weight(), c2.lp_weight(), c3.lp_weight(), cd.lp_weight() if cd is not None else None), ks)
         ctx.blk, ctx.pg = blk, want_pgrad
-        ctx.alphas = (k1[2], k2[2], k3[2], None if kd is None else kd[2])
+        ctx.alphas = tuple(None if k is None else k[2] for k in ks)
         ctx.save_for_backward(x, a1, a2, out)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, a1, a2, out = ctx.saved_tensors
-        blk, pg = ctx.blk, ctx.pg
-        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-        al1, al2, al3, ald = ctx.alphas
-        need_dx = ctx.needs_input_grad[0]
+        blk = ctx.blk
+        convs = [blk.conv1, blk.conv2, blk.conv3, blk.downsample[0] if blk.downsample is not None else None]
         g = _like_layout(g, out)
         if g.dtype != out.dtype:
             g = g.to(out.dtype)
-
-        def wgrad(c, inp, dy):
-            if pg and c.weight.requires_grad:
-                _wgrad_accumulate(inp, dy, c)
-
-        d3, dres = ops.affine_relu_backward(g, out, al3, True, want_dx=True, want_dres=True)
-        wgrad(c3, a2, d3)
-        d2, _ = ops.affine_relu_backward(ops.conv_dgrad(d3, c3.lp_weight_t(), a2.shape[2:], 1), a2, al2, True)
-        wgrad(c2, a1, d2)
-        d1, _ = ops.affine_relu_backward(ops.conv_dgrad(d2, c2.lp_weight_t(), a1.shape[2:], c2.stride[0]), a1, al1, True)
-        wgrad(c1, x, d1)
-        dx = None
-        if blk.downsample is not None:
-            cd = blk.downsample[0]
-            dd, _ = ops.affine_relu_backward(dres, None, ald, False)
-            wgrad(cd, x, dd)
-            if need_dx:
-                dx = ops.conv_dgrad(d1, c1.lp_weight_t(), x.shape[2:], 1,
-                                    addend=ops.conv_dgrad(dd, cd.lp_weight_t(), x.shape[2:], cd.stride[0]))
-        elif need_dx:
-            dx = ops.conv_dgrad(d1, c1.lp_weight_t(), x.shape[2:], 1, addend=dres)
+        gws = [c.weight.grad if (c is not None and ctx.pg and c.weight.requires_grad) else None for c in convs]
+        dx = ops.frozen_bottleneck_bwd(g, x, a1, a2, out, convs[0].out_channels, convs[1].stride[0],
+                                       [None if c is None else c.lp_weight_t() for c in convs], ctx.alphas, gws,
+                                       ctx.needs_input_grad[0])
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
@@ -259,9 +234,10 @@ def _frozen_block_ok(blk, x):
             return False
         if not ops.conv_wgrad_supported(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]):
             return False
-        if _Flags.param_grads and torch.is_grad_enabled() and c.weight.requires_grad and not _accumulates_in_place(c.weight):
+        if _Flags.param_grads and torch.is_grad_enabled() and c.weight.requires_grad and not (
+                _accumulates_in_place(c.weight) and (c.weight.grad.is_contiguous(memory_format=torch.channels_last) or c.kernel_size[0] == 1)):
             return False
-    return True
+    return not _Flags.wgrad_stash and not _WgradStream.ON
 
 
 _FrozenBlockFn.ON = os.environ.get("AFAN_DET_BLOCK_NODE", "1") != "0"      # 0: layer-by-layer autograd nodes (A/B)

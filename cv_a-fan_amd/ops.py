@@ -559,6 +559,47 @@ def bn_train_forward_dual(xa, bna, sta, mom_a, xb, bnb, stb, mom_b):
     return y, stats[0], stats[1]
 
 
+def frozen_bottleneck_fwd(x, planes, stride, ws, ks):
+    """One native call for a frozen-BatchNorm bottleneck's forward (afan_frozen_bottleneck_fwd): ws = (w1, w2, w3, wd | None)
+    KRSC bf16, ks = (k1, k2, k3, kd | None) coefficient blocks.  Returns (out, a1, a2)."""
+    lib = _lib.load()
+    _cl4(x, "x")
+    n, cin, h, w = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    co = 4 * planes
+    cl = torch.channels_last
+    a1 = torch.empty((n, planes, h, w), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    a2 = torch.empty((n, planes, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    out = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    scratch = _workspace(x, (n * (planes * h * w + 2 * co * ho * wo) + 1) // 2, "fbk_fwd")
+    CALLS["conv_fwd"] += 3 + (ws[3] is not None)
+    check(lib.afan_frozen_bottleneck_fwd(_ptr(x), n, h, w, cin, planes, int(stride), _ptr(ws[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(ws[3]),
+                                         _ptr(ks[0]), _ptr(ks[1]), _ptr(ks[2]), _ptr(ks[3]), _ptr(scratch), _ptr(a1), _ptr(a2),
+                                         _ptr(out), _stream(x)), "afan_frozen_bottleneck_fwd")
+    return out, a1, a2
+
+
+def frozen_bottleneck_bwd(g, x, a1, a2, out, planes, stride, wts, als, gws, want_dx):
+    """The backward of the same block in one native call: wts = transposed weights, als = alpha rows, gws = fp32 arena gradient
+    views to add into (None entries: not wanted).  Returns dx | None."""
+    lib = _lib.load()
+    n, cin, h, w = x.shape
+    co = 4 * planes
+    scratch = _workspace(x, (lib.afan_frozen_bottleneck_bwd_scratch(n, h, w, cin, planes, int(stride)) + 1) // 2, "fbk_bwd")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    shapes = ((n, ho, wo, planes, co, 1, 1), (n, h, w, planes, planes, 3, stride), (n, h, w, cin, planes, 1, 1), (n, h, w, cin, co, 1, stride))
+    total = sum(lib.afan_conv_wgrad_workspace_floats(*sh) for sh, gw in zip(shapes, (gws[2], gws[1], gws[0], gws[3])) if gw is not None)
+    wws = _workspace(x, total, "wgrad") if total else None
+    dx = torch.empty_like(x) if want_dx else None
+    CALLS["conv_dgrad"] += 2 + (1 if want_dx else 0) + (1 if (want_dx and wts[3] is not None) else 0)
+    CALLS["conv_wgrad"] += sum(gw is not None for gw in gws)
+    check(lib.afan_frozen_bottleneck_bwd(_ptr(g), _ptr(x), _ptr(a1), _ptr(a2), _ptr(out), n, h, w, cin, planes, int(stride),
+                                         _ptr(wts[0]), _ptr(wts[1]), _ptr(wts[2]), _ptr(wts[3]), _ptr(als[0]), _ptr(als[1]),
+                                         _ptr(als[2]), _ptr(als[3]), _ptr(gws[0]), _ptr(gws[1]), _ptr(gws[2]), _ptr(gws[3]),
+                                         _ptr(wws), _ptr(scratch), _ptr(dx), _stream(x)), "afan_frozen_bottleneck_bwd")
+    return dx
+
+
 def bn_apply(x, mean, invstd, weight, bias, residual=None, relu=False):
     lib = _lib.load()
     _need(x, "x")

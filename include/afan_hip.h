@@ -437,6 +437,24 @@ int afan_affine_coefs(const float* mean, const float* invstd, const float* weigh
                       float* coefs, afan_stream_t stream);
 int afan_affine_apply(const void* x, const void* residual, void* y, int dtype, int64_t n, int64_t c, int64_t hw,
                       const float* coefs, int relu, afan_stream_t stream);
+
+/* A frozen-BatchNorm bottleneck (Detection/backbone/resnet101_ori.py:78-127 under Detection/model.py:27-35,46-47) as ONE host
+ * call each way — no new kernel, the block's launches issued from native code (afan_block.hip): the eager Detection iteration
+ * is bound by per-launch Python dispatch.  Shapes: x [n, cin, h, w] -> out [n, 4 planes, ho, wo], ho = (h - 1) / stride + 1;
+ * all activations bf16 channels-last; w1 / w2 / w3 / wd KRSC bf16 (wd NULL: identity shortcut), wt*: their CRSK transposes;
+ * k*: afan_affine_coefs blocks, al*: their alpha rows.  fwd scratch: n * (planes*h*w + 2 * 4planes*ho*wo) bf16 elements;
+ * a1 [n, planes, h, w], a2 [n, planes, ho, wo] are what the backward needs besides x and out.  bwd: gw* (nullable) fp32 KRSC
+ * gradients ADDED into; wgrad_ws: the sum of the wanted layers' afan_conv_wgrad_workspace_floats; dx nullable. */
+int afan_frozen_bottleneck_fwd(const void* x, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t planes, int stride,
+                               const void* w1, const void* w2, const void* w3, const void* wd, const float* k1, const float* k2,
+                               const float* k3, const float* kd, void* scratch, void* a1, void* a2, void* out,
+                               afan_stream_t stream);
+int64_t afan_frozen_bottleneck_bwd_scratch(int64_t n, int64_t h, int64_t w, int64_t cin, int64_t planes, int stride);
+int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, const void* a2, const void* out, int64_t n,
+                               int64_t h, int64_t w, int64_t cin, int64_t planes, int stride, const void* wt1, const void* wt2,
+                               const void* wt3, const void* wtd, const float* al1, const float* al2, const float* al3,
+                               const float* ald, float* gw1, float* gw2, float* gw3, float* gwd, float* wgrad_ws, void* scratch,
+                               void* dx, afan_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast.
  * pooled_f32 != 0: the pooled side (y / dy) is fp32 whatever `dtype` the map has. */
 int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,

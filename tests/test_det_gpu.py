@@ -177,3 +177,16 @@ def test_detection_roi_pgd_clip_error_and_rpn_branch(pkg, orc, gpu):
         pkg.det_attack_algo.rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=1.0, gamma=0.25, clip=True)
     with pytest.raises(AssertionError):
         pkg.det_attack_algo.det_train_step(model, torch.optim.SGD(model.parameters(), 0.01), images, bb, lb, loss_settings=7)
+
+
+def test_nms_padded_form_needs_no_host_read(pkg, gpu):
+    """nms(padded=True): (keep [n], count [1]) on the device — the first count entries equal the reference-signature result."""
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(3000, 2, generator=g) * 400
+    wh = torch.rand(3000, 2, generator=g) * 60 + 4
+    boxes = torch.cat([xy, xy + wh], dim=1).to(gpu)
+    scores = torch.rand(3000, generator=g).to(gpu)
+    ref = pkg.det_ops.nms(boxes, scores, 0.5)
+    keep, count = pkg.det_ops.nms(boxes, scores, 0.5, padded=True)
+    assert keep.is_cuda and count.is_cuda and keep.shape == (3000,) and count.shape == (1,)
+    assert int(count) == ref.numel() and torch.equal(keep[:int(count)], ref)
