@@ -67,6 +67,8 @@ def _worker(rank, world, port, ret):
         # explicit ranges (what the segmented A-FAN step uses: the library's layers add parameter gradients straight into
         # the arena, so no autograd hook can announce them): launched before finish(), in backward order, no hook fires;
         # whatever the ranges leave out is reduced by finish(); nothing is reduced twice
+        # [(npar - 2, npar)] alone is SegTrainer's schedule (seg_trainer.py: the arena SUFFIX behind the SE point is announced at
+        # seg_train_phases' "tail" yield, the head's range is left to finish()); the three-range form is AfanTrainer's stages
         npar = len(arena.params)
         for covered in ([(npar - 2, npar), (2, npar - 2), (0, 2)], [(npar - 2, npar)], []):
             arena.zero_grad()
