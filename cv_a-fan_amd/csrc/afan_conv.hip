@@ -18,7 +18,8 @@
 // the launch is about one workgroup per CU (see dispatch()).  Register-staged variants (PF 1 / 2: 144-byte padded rows)
 // remain as A/B references (AFAN_CONV_MODE).  The epilogue rounds to bf16 through LDS so that every store is a 16-byte
 // piece of a channels-last row, and carries the optional fusions (addend, BatchNorm sums per image group).
-// Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64.
+// Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64,
+// AFAN_CONV_HALO.
 // (Measured-and-lost variants — 256-row tiles, producer waves on the two-stage launches, a half-step software pipeline,
 // streaming stores, register-streamed weights — are described in DESIGN.md 9.5 and no longer compiled in.)
 #include "afan_common.h"
@@ -61,7 +62,15 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // instruction holds its wave's issue slot for 60-185 cycles (tools/conv_ablate_bench.py: MFMAs on constant fragments
 // 12.0 us, the same plus the DMA 19.8 us, DMA alone 13.8 us on the 256-channel 8x8 layer — the two serialise inside a
 // wave); in a producer wave that stall costs no MFMA slot.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>   // WM x WN waves: pixels x channels
+// HL > 0 (capacity in pixels): the activation HALO of the row tile stays in LDS across the nine taps of a 3x3 / stride 1
+// problem — per 64-channel chunk the producers fetch the tile's pixels plus their one-pixel border ONCE (a contiguous range
+// of the zero-padded raster, HL pixels at most) and only weight tiles stream per K-step: 9 x 16 KB + ~25 KB of L2 requests
+// per chunk instead of 9 x 32 KB.  The K loop runs chunk-outer / tap-inner; an MFMA wave reads its fragment rows at the
+// tap's displacement inside the halo.  Swizzle: pixel j keeps 16-byte piece q at q ^ ((v >> 1) & 7) with v = the pixel's
+// linear position in the UNPADDED raster (n*H*W + y*W + x, also for border pixels): 16 consecutive output pixels at any
+// tap are 16 consecutive v, and j - v is even everywhere, so (j & 1, (v >> 1) & 7) takes 16 distinct values — conflict-free
+// ds_read_b128 for image rows of 4, 8, 16 or 33 pixels alike (round 1's halo kernel lost to exactly those conflicts).
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>   // WM x WN waves: pixels x channels
 __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
@@ -91,7 +100,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     constexpr bool GLDS = (PF >= 3);                 // operands go global -> LDS by DMA (no VGPR staging, no ds_write)
     constexpr int NS = PF <= 3 ? 2 : PF - 1;         // LDS stages: PF 3 -> 2, PF 4 -> 3, PF 5 -> 4 (tiles in flight: NS - 1)
     constexpr int LDR = GLDS ? BK : LDK;             // LDS row length: DMA rows are unpadded 128 B, XOR-swizzled instead
-    constexpr int STAGE = (BM + BN) * LDR;           // elements per buffer
+    constexpr int STAGE = HL ? BN * LDR : (BM + BN) * LDR;   // elements per buffer (halo form: weight tiles only)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     __shared__ int out_off[BM];
 
@@ -126,7 +135,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         const uint32_t m = m0 + row0 + RPP * i;
         a_off[i] = 0;
         a_valid[i] = 0;
-        if (m < M && (!PW || producer)) {
+        if (!HL && m < M && (!PW || producer)) {
             const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
             const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
             const int hi0 = (int)hg * pp.in_s, wi0 = (int)wg * pp.in_s;
@@ -178,7 +187,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     u32x4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
 
     auto gload = [&](int ks, u32x4 (&ra)[A_ROWS], u32x4 (&rb)[B_ROWS]) {
-        const int t = ks / chunks, q = ks - t * chunks;
+        const int q = ks / T, t = ks - q * T;            // chunk-outer, tap-inner: the one K order of every tiled variant
         const uint32_t a_tap = (uint32_t)(((cc.dh[t] * Wi + cc.dw[t]) * Ci + q * BK + cc.aofs[t]) * 2);   // may be "negative": wraps
         const uint32_t b_tap = (uint32_t)((cc.wofs[t] + q * BK) * 2);
         const bool pk = q + 1 < chunks || last_ok;
@@ -261,15 +270,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     uint32_t b_voff[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) b_voff[i] = RPP * i < b_rows_ok ? b_off + i * b_row32 : OOB;
-    // K-steps are issued strictly in order 0, 1, 2, ...: the (tap, chunk) position and the two scalar offsets are carried
-    // from call to call instead of being recomputed from ks (an integer division and three scalar loads of the tap table
-    // per step, with the s_waitcnt lgkmcnt(0) they drag along: 63 SALU instructions per K-step before).
+    // K-steps are issued strictly in order 0, 1, 2, ... = (chunk 0: taps 0..T-1), (chunk 1: taps 0..T-1), ...: the order of
+    // the halo form, so that every tiled variant adds an output's products in the same sequence (a half-batch launched
+    // alone may take another variant than the concatenated batch; the two must still agree bit for bit).  The (tap,
+    // chunk) position is carried from call to call (no integer division per step); the next tap's table entries are
+    // requested at the end of a call and turned into the two scalar offsets at the start of the next, a K-step later.
     int dma_t = 0, dma_q = 0;
-    int dma_a = T > 0 ? ((cc.dh[0] * Wi + cc.dw[0]) * Ci + cc.aofs[0]) * 2 + (int)A_BIAS : 0;
-    int dma_b = T > 0 ? cc.wofs[0] * 2 : 0;
+    int tap_a = T > 0 ? (cc.dh[0] * Wi + cc.dw[0]) * Ci + cc.aofs[0] : 0;
+    int tap_b = T > 0 ? cc.wofs[0] : 0;
     auto gdma = [&](int /*ks*/, int buf) {
         const int t = dma_t;
-        const int a_tap = dma_a, b_tap = dma_b;
+        const int a_tap = (tap_a + dma_q * BK) * 2 + (int)A_BIAS, b_tap = (tap_b + dma_q * BK) * 2;
         const bool pk = dma_q + 1 < chunks || last_ok;
         uint16_t* A = lds + buf * STAGE + swave * 512;          // wave-uniform: M0 base; hardware adds lane * 16 B
         uint16_t* B = A + BM * LDR;
@@ -283,20 +294,158 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         for (int i = 0; i < B_ROWS; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr)(B + i * (RPP * 64)), 16, pk ? (int)b_voff[i] : (int)OOB, b_tap, 0, 0);
         // advance to the next K-step
-        if (++dma_q == chunks) {
-            dma_q = 0;
-            ++dma_t;
-            if (dma_t < T) {
-                dma_a = ((cc.dh[dma_t] * Wi + cc.dw[dma_t]) * Ci + cc.aofs[dma_t]) * 2 + (int)A_BIAS;
-                dma_b = cc.wofs[dma_t] * 2;
-            }
-        } else {
-            dma_a += BK * 2;
-            dma_b += BK * 2;
+        if (++dma_t == T) {
+            dma_t = 0;
+            ++dma_q;
         }
+        tap_a = (cc.dh[dma_t] * Wi + cc.dw[dma_t]) * Ci + cc.aofs[dma_t];
+        tap_b = cc.wofs[dma_t];
     };
 
-    if constexpr (PW > 0) {
+    if constexpr (HL > 0) {
+        static_assert(PW > 0 && GLDS && NS == 4, "halo form: producer waves, four weight stages");
+        constexpr int HPM = HL;                              // pixels per halo buffer
+        uint16_t* const Hbase = lds + NS * STAGE;            // two halo buffers of HPM x 64 channels
+        uint16_t* const pad_zone = Hbase + 2 * HPM * BK;     // 1 KiB landing zone for the padding DMAs (below)
+        typedef __attribute__((address_space(3))) void* lptr;
+        const uint32_t W2 = Wg + 2, H2 = Hg + 2;
+        auto p0 = [&](uint32_t m) -> int {                   // position of output pixel m's top-left tap in the padded raster
+            const uint32_t t1 = m / Wg, x = m - t1 * Wg;
+            const uint32_t n = t1 / Hg, y = t1 - n * Hg;
+            return (int)((n * H2 + y) * W2 + x);
+        };
+        const uint32_t m_last = (m0 + BM < M ? m0 + BM : M) - 1;
+        const int Pb = p0(m0);
+        const int HPn = p0(m_last) + 2 * (int)W2 + 2 - Pb + 1;     // halo pixels of this tile (host: <= HPM)
+        const int G = (HPn + 7) >> 3;                              // DMA groups of 8 pixels (1 KiB of LDS)
+        __shared__ int2 htab[HPM];                                 // per halo pixel: byte offset of its channel row (or OOB), swizzle key
+        for (int j = tid; j < HPM; j += THREADS) {
+            int2 e = {(int)OOB, 0};
+            if (j < HPn) {
+                const uint32_t P = (uint32_t)(Pb + j), t1 = P / W2, hx = P - t1 * W2;
+                const uint32_t n = t1 / H2, hy = t1 - n * H2;
+                if (n < (uint32_t)pp.N && hy >= 1 && hy <= Hg && hx >= 1 && hx <= Wg)
+                    e.x = (int)((((n * Hg + hy - 1) * Wg + hx - 1) * Ci) * 2u);
+                const int v = (int)(n * Hg * Wg) + ((int)hy - 1) * (int)Wg + (int)hx - 1;
+                e.y = (v >> 1) & 7;
+            }
+            htab[j] = e;
+        }
+        int tj[9], tv[9], two[9];                             // per tap: displacement in the padded raster / in v, weight offset
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            tj[t] = (cc.dh[t] + 1) * (int)W2 + cc.dw[t] + 1;
+            tv[t] = cc.dh[t] * (int)Wg + cc.dw[t];
+            two[t] = cc.wofs[t] * 2;
+        }
+        int jrow[MI], vrow[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            uint32_t m = m0 + wr * TM + i * 32 + (lane & 31);
+            if (m > m_last) m = m_last;
+            jrow[i] = p0(m) - Pb;
+            vrow[i] = (int)m;
+        }
+        __syncthreads();                                      // htab (and out_off) are written
+
+        auto compute_h = [&](int buf, int hb, int tjt, int tvt) {
+            const uint16_t* B = lds + buf * STAGE;
+            const uint16_t* Hh = Hbase + hb * (HPM * BK);
+            const int frow = lane & 31;
+            const int sw = (frow >> 1) & 7;
+            int arow[MI], akey[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                arow[i] = (jrow[i] + tjt) * BK;
+                akey[i] = ((vrow[i] + tvt) >> 1) & 7;
+            }
+            constexpr int FB = FBT;
+#pragma unroll
+            for (int k0 = 0; k0 < BK / 16; k0 += FB) {
+                bf16x8 fx[FB][MI], fw[FB][NI];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const int c2 = (k0 + b) * 2 + (lane >> 5);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        fx[b][i] = *reinterpret_cast<const bf16x8*>(Hh + arow[i] + ((c2 ^ akey[i]) * 8));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + ((c2 ^ sw) * 8));
+                }
+                if (FB > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
+                if (FB > 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // Every K-step's issue is exactly LPT = B_ROWS + 2 DMA instructions per producer wave (the counted vmcnt waits
+        // need a fixed number): the weight tile and two halo groups of the NEXT chunk; a slot with no group left is a
+        // DMA of zeros into the landing zone.
+        constexpr int LPT = B_ROWS + 2;
+        uint32_t b_vo[B_ROWS];
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) b_vo[i] = RPP * i < b_rows_ok ? b_off + i * b_row32 : OOB;
+        auto hdma = [&](int hb, int k, int q) {               // group k*4 + swave of chunk q -> halo buffer hb
+            const int gi = k * 4 + swave;
+            if (gi < G) {
+                const int2 e = htab[gi * 8 + (lane >> 3)];
+                const uint32_t voff = (uint32_t)e.x + (uint32_t)((((lane & 7) ^ e.y)) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr)(Hbase + hb * (HPM * BK) + gi * 512), 16, (int)voff, q * (BK * 2), 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr)pad_zone, 16, (int)OOB, 0, 0, 0);
+            }
+        };
+        auto bdma = [&](int buf, int wo2, int q) {
+            uint16_t* Bd = lds + buf * STAGE + swave * 512;
+#pragma unroll
+            for (int i = 0; i < B_ROWS; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr)(Bd + i * (RPP * 64)), 16, (int)b_vo[i], wo2 + q * (BK * 2), 0, 0);
+        };
+        if (producer) {
+            for (int k = 0; k * 4 < G; ++k) hdma(0, k, 0);     // chunk 0's halo (older than every counted instruction)
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s) {
+                bdma(s, two[s], 0);
+                hdma(0, 1 << 20, 0);                           // (group index beyond G: padding DMA)
+                hdma(0, 1 << 20, 0);
+            }
+            for (int q = 0; q < chunks; ++q) {
+                const bool more = q + 1 < chunks;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    // tiles after (q, t): min(that, 2) of them are in flight behind it
+                    if (t <= 6 || more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * 2));
+                    else if (t == 7) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
+                    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+                    __builtin_amdgcn_s_barrier();              // tile (q, t) is in LDS for everyone; the buffer of the tile before is free
+                    const int nb = (q + t + 3) & 3;            // 9 = 1 (mod 4): tile 9 q + t lives in weight buffer (q + t) & 3
+                    if (t + 3 < 9 || more) {
+                        bdma(nb, two[(t + 3) % 9], t + 3 < 9 ? q : q + 1);
+                        // chunk q + 1's halo goes into the buffer chunk q - 1 used (free since this chunk's first barrier),
+                        // two groups per K-step from t = 0: issued by t = 4 (HPM <= 320), complete at chunk q + 1's first wait
+                        hdma((q + 1) & 1, more ? 2 * t : 1 << 20, q + 1);
+                        hdma((q + 1) & 1, more ? 2 * t + 1 : 1 << 20, q + 1);
+                    }
+                }
+            }
+        } else {
+            for (int q = 0; q < chunks; ++q) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    __builtin_amdgcn_s_barrier();
+                    compute_h((q + t) & 3, q & 1, tj[t], tv[t]);
+                }
+            }
+        }
+        __syncthreads();
+    } else if constexpr (PW > 0) {
         static_assert(GLDS, "producer waves: LDS-DMA only");
         constexpr int LPT = A_ROWS + B_ROWS;
         if constexpr (NS == 2) {
@@ -581,13 +730,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 // The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward
 // launches from the input-gradient launches: bench.py's roofline names whichever is the larger and profiles/ can be
 // checked against it symbol by symbol.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_fwd_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL>(pp);
 }
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_dgrad_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL>(pp);
 }
 
 static int64_t max_rows(const ConvP& p) {
@@ -599,26 +748,28 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
 int launch(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
-    constexpr size_t stage_bytes = (size_t)(PF <= 3 ? 2 : PF - 1) * (BM + BN) * (PF >= 3 ? BK : LDK) * 2;
+    // halo form: (PF - 1) weight stages + two halo buffers of HL pixels + the 1 KiB landing zone of the padding DMAs
+    constexpr size_t stage_bytes = HL ? (size_t)(PF - 1) * BN * BK * 2 + (size_t)2 * HL * BK * 2 + 1024
+                                      : (size_t)(PF <= 3 ? 2 : PF - 1) * (BM + BN) * (PF >= 3 ? BK : LDK) * 2;
     constexpr size_t epi_bytes = (size_t)BM * (BN + 8) * 2;
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT>,
+            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
-    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT><<<grid, THREADS, lds, st>>>(p);
+    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL><<<grid, THREADS, lds, st>>>(p);
+    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -643,6 +794,28 @@ int choose_bm(int64_t M, int co, int n_classes) {
 }
 
 
+// LDS-resident halo (conv_igemm_body's HL form): one dense 3x3 / stride 1 problem on whole 64-channel chunks whose every
+// row tile's halo — the contiguous range of the zero-padded raster between its first pixel's top-left tap and its last
+// pixel's bottom-right tap — fits the buffer
+constexpr int HALO_PIXELS = 320;
+static bool halo_ok(const ConvP& p, int bm) {
+    const ConvClass& c = p.cls[0];
+    if (p.n_classes != 1 || p.multi || p.a_extra || p.in_s != 1 || p.out_s != 1 || p.max_pad != 1 || c.T != 9) return false;
+    if (c.Hg != p.Hi || c.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.Ci % 64 || p.Co % 128) return false;
+    if (c.out_h0 || c.out_w0) return false;
+    for (int t = 0; t < 9; ++t)
+        if (c.dh[t] < -1 || c.dh[t] > 1 || c.dw[t] < -1 || c.dw[t] > 1 || c.aofs[t]) return false;
+    const int64_t H = p.Hi, W = p.Wi, M = (int64_t)p.N * H * W;
+    auto p0 = [&](int64_t m) { const int64_t t1 = m / W, x = m % W, n = t1 / H, y = t1 % H; return (n * (H + 2) + y) * (W + 2) + x; };
+    // the longest halo: tiles repeat with period lcm(bm, H*W) pixels; walking one image pair's worth of tiles covers every phase
+    const int64_t tiles = (M + bm - 1) / bm, walk = tiles < 4096 ? tiles : 4096;
+    for (int64_t i = 0; i < walk; ++i) {
+        const int64_t m0 = i * bm, m1 = (m0 + bm < M ? m0 + bm : M) - 1;
+        if (p0(m1) + 2 * (W + 2) + 2 - p0(m0) + 1 > HALO_PIXELS) return false;
+    }
+    return true;
+}
+
 int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
     // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
     static const int mode = env_int("AFAN_CONV_MODE", 3);
@@ -661,6 +834,10 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
         static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
         static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
+        static const int halo = env_int("AFAN_CONV_HALO", 1);   // 0: per-tap operand tiles everywhere (A/B)
+        if (wgs <= deep_max && spec && halo && halo_ok(p, bm))
+            return bm == 64 ? launch<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
+                            : launch<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);
         if (wgs <= deep_max && spec) return bm == 64 ? launch<64, 128, 5, 2, 2, 4>(p, st, dgrad) : launch<128, 128, 5, 2, 2, 4>(p, st, dgrad);
         if (wgs <= deep_max) return bm == 64 ? launch<64, 128, 5, 2, 4>(p, st, dgrad) : launch<128, 128, 5, 2, 4>(p, st, dgrad);   // 4 stages
     }

@@ -249,6 +249,40 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
     np.testing.assert_array_equal(outs[1][2], outs[0][2])
 
 
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 256, 256, 33, 33), (3, 128, 256, 19, 19), (5, 64, 128, 7, 7), (9, 128, 128, 4, 4),
+                                         (2, 192, 128, 13, 29), (1, 64, 256, 5, 61), (64, 512, 512, 7, 7)])
+def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
+    """The LDS-resident-halo form of the tiled kernel (launches of about one workgroup per CU: 3x3 / stride 1, whole
+    64-channel chunks) against (a) torch on the same bf16 values and (b) the per-tap form bit for bit: the same images
+    inside a batch repeated until the launch has more than 384 workgroups take the per-tap form, and both forms add an
+    output's products in one order.  Odd widths, tiles that straddle image rows and images, ragged last tiles."""
+    torch.manual_seed(n + ci + co + h + w)
+    x = _cl(torch.randn(n, ci, h, w, device=gpu).bfloat16())
+    wgt = _cl((torch.randn(co, ci, 3, 3, device=gpu) / (ci * 9) ** 0.5).bfloat16())
+    y = pkg.ops.conv_fwd(x, wgt, 1)
+    ref = F.conv2d(x.float(), wgt.float(), None, 1, 1)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
+    rep = 1
+    while ((n * rep * h * w + 127) // 128) * (co // 128) <= 384:
+        rep += 1
+    xb = _cl(x.repeat(rep, 1, 1, 1))
+    yb = pkg.ops.conv_fwd(xb, wgt, 1)
+    for r in (0, rep // 2, rep - 1):
+        assert torch.equal(yb[r * n:(r + 1) * n], y)
+    dy = _cl(torch.randn(n, co, h, w, device=gpu).bfloat16())
+    wt = _cl(wgt.permute(1, 0, 2, 3))
+    dx = pkg.ops.conv_dgrad(dy, wt, (h, w), 1)
+    refd = torch.nn.grad.conv2d_input((n, ci, h, w), wgt.float(), dy.float(), padding=1)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), refd.cpu().numpy(), rtol=1e-2, atol=2e-2)
+    if ci % 128 == 0:                                  # (the gradient's GEMM has ci output channels: tiled kernel, 128-wide)
+        rep = 1
+        while ((n * rep * h * w + 127) // 128) * (ci // 128) <= 384:
+            rep += 1
+        dxb = pkg.ops.conv_dgrad(_cl(dy.repeat(rep, 1, 1, 1)), wt, (h, w), 1)
+        for r in (0, rep - 1):
+            assert torch.equal(dxb[r * n:(r + 1) * n], dx)
+
+
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(8, 64, 128, 16, 3, 2), (16, 128, 128, 8, 3, 1), (64, 256, 512, 4, 1, 2),
                                                  (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1), (256, 128, 128, 16, 3, 1)])
 def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, stride):

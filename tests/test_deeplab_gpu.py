@@ -132,8 +132,12 @@ def test_deeplab_step_bf16_runs_on_the_library_kernels(pkg, gpu, case):
     ran = {k: pkg.ops.CALLS[k] - before[k] for k in before}
     assert ran["vendor_conv"] == 0 and ran["conv_fwd"] > 100 and ran["conv_dgrad"] > 100 and ran["conv_wgrad"] > 100, ran
     loss = float(g["loss"])
-    assert abs(float(r["loss"]) - loss) <= 3e-2, (float(r["loss"]), loss)
-    np.testing.assert_allclose(r["losses"].cpu().numpy(), g["losses"], rtol=0, atol=3e-2)
+    # The freshly initialised network is chaotic: + 1e-3 of noise on the images moves the bf16 loss by up to 0.036 from the
+    # fp32 golden (six draws, two builds of the library: profiles/r03j_deeplab_loss_spread.txt), so its bound only says
+    # "same regime"; on the contractive network the same draws stay within 1.2e-3 and the bound means something.
+    tol = 5e-3 if float(g["damp"]) != 1.0 else 6e-2
+    assert abs(float(r["loss"]) - loss) <= tol, (float(r["loss"]), loss)
+    np.testing.assert_allclose(r["losses"].cpu().numpy(), g["losses"], rtol=0, atol=tol)
     if float(g["damp"]) != 1.0:
         # On the contractive network the bf16 run tracks the fp32 reference end to end (a freshly initialised 101-layer
         # BatchNorm network amplifies ANY 0.3 % perturbation to ~60 % by layer3 — tools/diag_deeplab_layers.py shows
