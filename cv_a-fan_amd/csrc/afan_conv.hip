@@ -437,6 +437,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         } else {
             for (int q = 0; q < chunks; ++q) {
+                // (opaque per chunk: otherwise the nine taps' fragment addresses are hoisted out of the chunk loop as
+                // 40-odd loop-invariant registers, which the 168-register variant spills)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     __builtin_amdgcn_s_barrier();
@@ -696,7 +700,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 s1[j] += __shfl_xor(s1[j], o, 64);
                 s2[j] += __shfl_xor(s2[j], o, 64);
             }
-        __shared__ float red[THREADS / 64][2][BN];
+        // per-wave partial sums: static LDS, or (halo form: the static budget is spent) the second halo buffer, idle by now
+        __shared__ float red_static[HL ? 1 : THREADS / 64][2][BN];
+        float (*red)[2][BN] = red_static;
+        if constexpr (HL > 0) red = reinterpret_cast<float (*)[2][BN]>(lds + ((PF - 1) * BN * BK + HL * BK));
         if (lane < PIECES) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -797,8 +804,9 @@ int choose_bm(int64_t M, int co, int n_classes) {
 // LDS-resident halo (conv_igemm_body's HL form): one dense 3x3 / stride 1 problem on whole 64-channel chunks whose every
 // row tile's halo — the contiguous range of the zero-padded raster between its first pixel's top-left tap and its last
 // pixel's bottom-right tap — fits the buffer
-constexpr int HALO_PIXELS = 320;
-static bool halo_ok(const ConvP& p, int bm) {
+constexpr int HALO_PIXELS = 320;       // 128- and 64-row tiles
+constexpr int HALO_PIXELS_256 = 328;   // 256-row tiles: one 16x16 image with its border is 18 x 18 = 324 pixels
+static bool halo_ok(const ConvP& p, int bm, int cap = HALO_PIXELS) {
     const ConvClass& c = p.cls[0];
     if (p.n_classes != 1 || p.multi || p.a_extra || p.in_s != 1 || p.out_s != 1 || p.max_pad != 1 || c.T != 9) return false;
     if (c.Hg != p.Hi || c.Wg != p.Wi || p.Ho != p.Hi || p.Wo != p.Wi || p.Ci % 64 || p.Co % 128) return false;
@@ -811,7 +819,7 @@ static bool halo_ok(const ConvP& p, int bm) {
     const int64_t tiles = (M + bm - 1) / bm, walk = tiles < 4096 ? tiles : 4096;
     for (int64_t i = 0; i < walk; ++i) {
         const int64_t m0 = i * bm, m1 = (m0 + bm < M ? m0 + bm : M) - 1;
-        if (p0(m1) + 2 * (W + 2) + 2 - p0(m0) + 1 > HALO_PIXELS) return false;
+        if (p0(m1) + 2 * (W + 2) + 2 - p0(m0) + 1 > cap) return false;
     }
     return true;
 }
@@ -835,6 +843,13 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
         static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
         static const int halo = env_int("AFAN_CONV_HALO", 1);   // 0: per-tap operand tiles everywhere (A/B)
+        // 385..768 workgroups of 128 rows (ResNet-18's 16x16 stage: two per CU on the two-stage kernel): 256-row tiles
+        // bring the launch to one workgroup per CU on the halo form — eight MFMA waves + four producers, a whole 16x16
+        // image and its border per tile (the partial-slab statistics' slot count is tied to choose_bm(): not with those)
+        static const int halo256 = env_int("AFAN_CONV_HALO256", 1);
+        if (halo && halo256 && spec && bm == 128 && wgs > deep_max && wgs <= 2 * deep_max && !p.stats
+            && (p.groups != 2 || ((int64_t)(p.N / 2) * p.cls[0].Hg * p.cls[0].Wg) % 256 == 0) && halo_ok(p, 256, HALO_PIXELS_256))
+            return launch<256, 128, 5, 4, 2, 4, 2, HALO_PIXELS_256>(p, st, dgrad);   // (two k16-slices of fragments in flight: 168 registers per wave at three waves per SIMD)
         if (wgs <= deep_max && spec && halo && halo_ok(p, bm))
             return bm == 64 ? launch<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
                             : launch<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);

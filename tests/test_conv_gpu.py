@@ -250,11 +250,13 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
 
 
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 256, 256, 33, 33), (3, 128, 256, 19, 19), (5, 64, 128, 7, 7), (9, 128, 128, 4, 4),
-                                         (2, 192, 128, 13, 29), (1, 64, 256, 5, 61), (64, 512, 512, 7, 7)])
+                                         (2, 192, 128, 13, 29), (1, 64, 256, 5, 61), (64, 512, 512, 7, 7),
+                                         # 385..768 workgroups of 128 rows: the 256-row halo tile (a whole 16x16 image per tile)
+                                         (256, 128, 128, 16, 16), (100, 128, 256, 16, 16), (150, 64, 128, 8, 40), (37, 128, 128, 15, 17)])
 def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
     """The LDS-resident-halo form of the tiled kernel (launches of about one workgroup per CU: 3x3 / stride 1, whole
     64-channel chunks) against (a) torch on the same bf16 values and (b) the per-tap form bit for bit: the same images
-    inside a batch repeated until the launch has more than 384 workgroups take the per-tap form, and both forms add an
+    inside a batch repeated until the launch has more than 768 workgroups take the per-tap form, and both forms add an
     output's products in one order.  Odd widths, tiles that straddle image rows and images, ragged last tiles."""
     torch.manual_seed(n + ci + co + h + w)
     x = _cl(torch.randn(n, ci, h, w, device=gpu).bfloat16())
@@ -263,7 +265,7 @@ def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
     ref = F.conv2d(x.float(), wgt.float(), None, 1, 1)
     np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=1e-2)
     rep = 1
-    while ((n * rep * h * w + 127) // 128) * (co // 128) <= 384:
+    while ((n * rep * h * w + 127) // 128) * (co // 128) <= 768:
         rep += 1
     xb = _cl(x.repeat(rep, 1, 1, 1))
     yb = pkg.ops.conv_fwd(xb, wgt, 1)
@@ -276,7 +278,7 @@ def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
     np.testing.assert_allclose(dx.float().cpu().numpy(), refd.cpu().numpy(), rtol=1e-2, atol=2e-2)
     if ci % 128 == 0:                                  # (the gradient's GEMM has ci output channels: tiled kernel, 128-wide)
         rep = 1
-        while ((n * rep * h * w + 127) // 128) * (ci // 128) <= 384:
+        while ((n * rep * h * w + 127) // 128) * (ci // 128) <= 768:
             rep += 1
         dxb = pkg.ops.conv_dgrad(_cl(dy.repeat(rep, 1, 1, 1)), wt, (h, w), 1)
         for r in (0, rep - 1):

@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [(256, 256, 256, 8), (256, 512, 512, 4), (2, 256, 256, 33), (8, 256, 256, 33), (256, 128, 128, 16), (64, 512, 512, 7), (3, 128, 256, 19)]
+SHAPES = [(256, 256, 256, 8), (256, 512, 512, 4), (2, 256, 256, 33), (8, 256, 256, 33), (256, 128, 128, 16), (64, 512, 512, 7), (3, 128, 256, 19),
+          (128, 256, 256, 14)]
 
 
 def child():
@@ -61,7 +62,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for halo in ("0", "1", "0", "1"):
-            env = dict(os.environ, AFAN_CONV_HALO=halo)
+        for halo, h256 in (("0", "0"), ("1", "0"), ("1", "1")) * 2:       # (HALO256: 256-row halo tiles for the 385..768-workgroup launches)
+            env = dict(os.environ, AFAN_CONV_HALO=halo, AFAN_CONV_HALO256=h256)
             r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
-            print(f"--- AFAN_CONV_HALO={halo}\n{r.stdout}{r.stderr[-1500:] if r.returncode else ''}", flush=True)
+            print(f"--- AFAN_CONV_HALO={halo} AFAN_CONV_HALO256={h256}\n{r.stdout}{r.stderr[-1500:] if r.returncode else ''}", flush=True)
