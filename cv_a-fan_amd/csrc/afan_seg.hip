@@ -36,7 +36,7 @@ __device__ __forceinline__ Src src_index(float scale, int dst, int in_size) {
 // vector) of that row — one 32-bit division per thread, the row's source rows and weights are wave-uniform.
 template <typename T, int VEC, bool NHWC>
 __global__ __launch_bounds__(BLOCK) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int C, int Hi,
-                                                             int Wi, int Ho, int Wo, float sh, float sw) {
+                                                             int Wi, int Ho, int Wo, float sh, float sw, int ldy) {
     const uint32_t CV = NHWC ? C / VEC : 1;
     const uint32_t row = blockIdx.x, oy = row % Ho, plane = row / Ho;      // plane = n (NHWC) or n * C + c (NCHW)
     const uint32_t t = blockIdx.y * BLOCK + threadIdx.x;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void upsample_fwd_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < VEC; ++k)     // ATen's association: h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11)
             o[k] = a.l0 * (b.l0 * p00[k] + b.l1 * p01[k]) + a.l1 * (b.l0 * p10[k] + b.l1 * p11[k]);
-        T* dst = y + (((int64_t)plane * Ho + oy) * Wo + ox) * C + cv * VEC;
+        T* dst = y + (((int64_t)plane * Ho + oy) * Wo + ox) * ldy + cv * VEC;     // (ldy = C, or the pixel stride of a wider tensor)
         if constexpr (VEC == 1) Elt<T>::st(dst, o[0]);
         else Elt<T>::stv(dst, reinterpret_cast<const float(&)[Elt<T>::VEC]>(o));
     } else {
@@ -88,7 +88,8 @@ __device__ __forceinline__ float axis_weight(float scale, int o, int i, int in_s
 // summing the output gradients it fed, rows then columns in increasing order (deterministic).
 template <typename T, int VEC, bool NHWC>
 __global__ __launch_bounds__(BLOCK) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int C, int Hi,
-                                                             int Wi, int Ho, int Wo, float sh, float sw, float ish, float isw) {
+                                                             int Wi, int Ho, int Wo, float sh, float sw, float ish, float isw,
+                                                             int ldy) {
     const uint32_t CV = NHWC ? C / VEC : 1;
     const uint32_t row = blockIdx.x, iy = row % Hi, plane = row / Hi;
     const uint32_t t = blockIdx.y * BLOCK + threadIdx.x;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(BLOCK) void upsample_bwd_kernel(const T* __restrict
             if (wx == 0.f) continue;
             const float w = wy * wx;
             if constexpr (NHWC) {
-                const T* src = dy + (((int64_t)plane * Ho + oy) * Wo + ox) * C + cv * VEC;
+                const T* src = dy + (((int64_t)plane * Ho + oy) * Wo + ox) * ldy + cv * VEC;
                 if constexpr (VEC == 1) acc[0] += w * Elt<T>::ld(src);
                 else {
                     float g[VEC];
@@ -903,17 +904,22 @@ static int check_t(int dtype, int layout) {
     return AFAN_OK;
 }
 
-int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
-                               int64_t ho, int64_t wo, afan_stream_t stream) {
+// ld > 0: y (forward) / dy (backward) is a channel slice of a wider channels-last tensor — its pixels are ld elements apart
+// (the decoder's concat, Segmentation/network/_deeplab.py:54-56: the resized ASPP output is written straight into channels
+// 48..303 of the 304-channel tensor and its gradient is read from there).  NHWC only; ld = 0: dense.
+static int upsample_fwd_impl(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                             int64_t ho, int64_t wo, int64_t ld, afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
     if (n < 0 || c <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return AFAN_ESHAPE;
+    if (ld && (layout != AFAN_NHWC || ld < c || ld > 0x7fffffffLL)) return AFAN_ESHAPE;
     if (n == 0) return AFAN_OK;
     if (!x || !y) return AFAN_ENULL;
     const int es = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(x, es) || !aligned(y, es)) return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {x, y}) : vec_for<uint16_t>(c, {x, y})) : 1;
+    int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {x, y}) : vec_for<uint16_t>(c, {x, y})) : 1;
+    if (ld && (ld * es) % 16 != 0) vec = 1;
     const int64_t total = n * ho * wo * c / vec;
     const float sh = (float)hi / (float)ho, sw = (float)wi / (float)wo;
     AFAN_PROF("upsample_bilinear_fwd_kernel", (double)es * n * c * (ho * wo + hi * wi), st);
@@ -921,24 +927,26 @@ int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, in
     if (rows > 0x7fffffffLL || (per_row + BLOCK - 1) / BLOCK > 65535) return AFAN_ESHAPE;
     (void)total;
     const dim3 ugrid((unsigned)rows, (unsigned)((per_row + BLOCK - 1) / BLOCK));
-#define K_(T, V, L, ...) upsample_fwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)x, (T*)y, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw)
+#define K_(T, V, L, ...) upsample_fwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)x, (T*)y, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, (int)(ld ? ld : c))
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
 
-int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
-                               int64_t ho, int64_t wo, afan_stream_t stream) {
+static int upsample_bwd_impl(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                             int64_t ho, int64_t wo, int64_t ld, afan_stream_t stream) {
     int e = check_t(dtype, layout);
     if (e) return e;
     if (n < 0 || c <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return AFAN_ESHAPE;
+    if (ld && (layout != AFAN_NHWC || ld < c || ld > 0x7fffffffLL)) return AFAN_ESHAPE;
     if (n == 0) return AFAN_OK;
     if (!dy || !dx) return AFAN_ENULL;
     const int es = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(dy, es) || !aligned(dx, es)) return AFAN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {dy, dx}) : vec_for<uint16_t>(c, {dy, dx})) : 1;
+    int vec = layout == AFAN_NHWC ? (dtype == AFAN_F32 ? vec_for<float>(c, {dy, dx}) : vec_for<uint16_t>(c, {dy, dx})) : 1;
+    if (ld && (ld * es) % 16 != 0) vec = 1;
     const int64_t total = n * hi * wi * c / vec;
     const float sh = (float)hi / (float)ho, sw = (float)wi / (float)wo;
     const float ish = (float)ho / (float)hi, isw = (float)wo / (float)wi;
@@ -947,11 +955,33 @@ int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, 
     if (rows > 0x7fffffffLL || (per_row + BLOCK - 1) / BLOCK > 65535) return AFAN_ESHAPE;
     (void)total;
     const dim3 ugrid((unsigned)rows, (unsigned)((per_row + BLOCK - 1) / BLOCK));
-#define K_(T, V, L, ...) upsample_bwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)dy, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, ish, isw)
+#define K_(T, V, L, ...) upsample_bwd_kernel<T, V, L><<<ugrid, BLOCK, 0, st>>>((const T*)dy, (T*)dx, (int)c, (int)hi, (int)wi, (int)ho, (int)wo, sh, sw, ish, isw, (int)(ld ? ld : c))
     AFAN_SEG_DISPATCH(K_, 0);
 #undef K_
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
+}
+
+int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                               int64_t ho, int64_t wo, afan_stream_t stream) {
+    return upsample_fwd_impl(x, y, dtype, layout, n, c, hi, wi, ho, wo, 0, stream);
+}
+
+int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
+                               int64_t ho, int64_t wo, afan_stream_t stream) {
+    return upsample_bwd_impl(dy, dx, dtype, layout, n, c, hi, wi, ho, wo, 0, stream);
+}
+
+int afan_upsample_bilinear_fwd_slice(const void* x, void* y, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
+                                     int64_t wo, int64_t ld, afan_stream_t stream) {
+    if (ld <= 0) return AFAN_ESHAPE;
+    return upsample_fwd_impl(x, y, dtype, AFAN_NHWC, n, c, hi, wi, ho, wo, ld, stream);
+}
+
+int afan_upsample_bilinear_bwd_slice(const void* dy, void* dx, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
+                                     int64_t wo, int64_t ld, afan_stream_t stream) {
+    if (ld <= 0) return AFAN_ESHAPE;
+    return upsample_bwd_impl(dy, dx, dtype, AFAN_NHWC, n, c, hi, wi, ho, wo, ld, stream);
 }
 
 static int ce2d_blocks(int64_t pixels) { return grid_for(pixels, BLOCK, 2048); }

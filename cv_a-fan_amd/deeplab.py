@@ -45,6 +45,25 @@ class _UpsampleFn(torch.autograd.Function):
         return ops.upsample_bilinear_backward(g, ctx.in_hw), None
 
 
+class _UpsampleCatFn(torch.autograd.Function):
+    """torch.cat([low, F.interpolate(hi, low's size)], dim=1) (_deeplab.py:54-56) as one node: the resized tensor is written
+    into its channel slice of the result and its gradient is read from there (ops.upsample_concat): no concat pass over the
+    256-channel half, no copy of the gradient slice."""
+
+    @staticmethod
+    def forward(ctx, low, hi):
+        low, hi = _dense(low), _dense(hi)
+        ctx.c0, ctx.in_hw = low.shape[1], tuple(hi.shape[2:])
+        return ops.upsample_concat(low, hi)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous(memory_format=torch.channels_last)
+        d_low = g[:, :ctx.c0] if ctx.needs_input_grad[0] else None
+        d_hi = ops.upsample_concat_backward(g, ctx.c0, ctx.in_hw) if ctx.needs_input_grad[1] else None
+        return d_low, d_hi
+
+
 def interpolate(x, size):
     size = (int(size[0]), int(size[1]))
     if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
@@ -602,10 +621,15 @@ class DeepLabHeadV3Plus(nn.Module):
         return self.classifier[3](_cbr(self.classifier[0], self.classifier[1], cat))
 
     channels_last = False     # set by DeepLabV3.set_channels_last
+    CAT_FUSED = os.environ.get("AFAN_SEG_CAT_FUSED", "1") != "0"     # resize written into the concat's channel slice (A/B knob)
 
     def _concat(self, low, hi):
-        hi = interpolate(_enter(hi, self.project[0].compute_dtype, self.channels_last), low.shape[2:])
-        return torch.cat([low, hi], dim=1)
+        hi = _enter(hi, self.project[0].compute_dtype, self.channels_last)
+        if (self.CAT_FUSED and self.channels_last and hi.is_cuda and hi.dtype == low.dtype and hi.dtype in (torch.float32, torch.bfloat16)
+                and tuple(hi.shape[2:]) != tuple(low.shape[2:]) and ops.layout_of(hi) == ops.AFAN_NHWC
+                and ops.layout_of(low) == ops.AFAN_NHWC):
+            return _UpsampleCatFn.apply(low, hi)
+        return torch.cat([low, interpolate(hi, low.shape[2:])], dim=1)
 
     def forward(self, feature, return_type=None):
         dt, cl = self.project[0].compute_dtype, self.channels_last

@@ -1065,6 +1065,38 @@ def upsample_bilinear_backward(dy, in_hw):
     return dx
 
 
+def upsample_concat(low, hi):
+    """torch.cat([low, F.interpolate(hi, low's size, 'bilinear')], dim=1) for bf16 / fp32 channels-last tensors
+    (_deeplab.py:54-56) without the concat's pass over the resized tensor: it is written straight into its channel slice
+    (afan_upsample_bilinear_fwd_slice); `low` is copied into the first channels."""
+    lib = _lib.load()
+    _need(low, "low"), _need(hi, "hi")
+    if low.dim() != 4 or hi.dim() != 4 or low.dtype != hi.dtype or low.shape[0] != hi.shape[0] or layout_of(hi) != AFAN_NHWC:
+        raise TypeError("upsample_concat: two channels-last 4-D tensors of one dtype and batch size expected")
+    n, c0, ho, wo = low.shape
+    c, hi_h, hi_w = hi.shape[1], hi.shape[2], hi.shape[3]
+    out = torch.empty((n, c0 + c, ho, wo), dtype=hi.dtype, device=hi.device, memory_format=torch.channels_last)
+    out[:, :c0].copy_(low)
+    es = out.element_size()
+    check(lib.afan_upsample_bilinear_fwd_slice(_ptr(hi), out.data_ptr() + c0 * es, _DT[hi.dtype], n, c, hi_h, hi_w, ho, wo,
+                                               c0 + c, _stream(hi)), "afan_upsample_bilinear_fwd_slice")
+    return out
+
+
+def upsample_concat_backward(g, c0, in_hw):
+    """Gradient of upsample_concat w.r.t. `hi`, read from channels c0.. of the channels-last dense g [N, c0 + c, Ho, Wo]."""
+    lib = _lib.load()
+    _need(g, "g")
+    if layout_of(g) != AFAN_NHWC or not g.is_contiguous(memory_format=torch.channels_last):
+        raise TypeError("upsample_concat_backward: dense channels-last gradient expected")
+    n, ct, ho, wo = g.shape
+    c, hi, wi = ct - c0, int(in_hw[0]), int(in_hw[1])
+    dx = torch.empty((n, c, hi, wi), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+    check(lib.afan_upsample_bilinear_bwd_slice(g.data_ptr() + c0 * g.element_size(), _ptr(dx), _DT[g.dtype], n, c, hi, wi, ho, wo,
+                                               ct, _stream(g)), "afan_upsample_bilinear_bwd_slice")
+    return dx
+
+
 CE2D_MAX_CLASSES = 32
 
 

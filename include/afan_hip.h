@@ -391,6 +391,15 @@ int afan_upsample_bilinear_fwd(const void* x, void* y, int dtype, int layout, in
                                int64_t ho, int64_t wo, afan_stream_t stream);
 int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, int64_t n, int64_t c, int64_t hi, int64_t wi,
                                int64_t ho, int64_t wo, afan_stream_t stream);
+/* The same resize where the HIGH-resolution side is a channel slice of a wider channels-last tensor: y (forward) / dy (backward)
+ * points at the slice's first channel and consecutive pixels are `ld` elements apart (ld >= c).  The decoder's concat,
+ * torch.cat([low_level_feature, F.interpolate(aspp_out, ...)], dim=1) at Segmentation/network/_deeplab.py:54-56, without the
+ * concat's own pass: the resized tensor is written into channels 48..303 of the 304-channel tensor, and its gradient is read
+ * from there.  Channels-last only. */
+int afan_upsample_bilinear_fwd_slice(const void* x, void* y, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
+                                     int64_t wo, int64_t ld, afan_stream_t stream);
+int afan_upsample_bilinear_bwd_slice(const void* dy, void* dx, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
+                                     int64_t wo, int64_t ld, afan_stream_t stream);
 /* Per-pixel cross-entropy, nn.CrossEntropyLoss(ignore_index=I, reduction='mean') of Segmentation/main_aug_final.py:95:
  * logits fp32 [n,c,hw] (NCHW) or [n,hw,c] (NHWC), c <= 32; target int64 [n,hw].  loss[0] = sum over pixels with
  * target != I of (logsumexp - logit[target]) / count; dlogits (nullable, same layout) = grad_scale * d(loss)/d(logits)

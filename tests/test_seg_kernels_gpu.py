@@ -48,6 +48,27 @@ def test_upsample_bilinear_bf16_nhwc(pkg, gpu):
     np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), rtol=1e-2, atol=6e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("n,c0,c,lo,hi", [(2, 48, 256, (129, 129), (33, 33)), (1, 8, 16, (40, 31), (17, 23)), (3, 24, 40, (9, 9), (5, 7)),
+                                          (1, 4, 6, (7, 7), (3, 3))])
+def test_upsample_concat_equals_cat_of_the_resize(pkg, gpu, dtype, n, c0, c, lo, hi):
+    """The decoder's concat node (deeplab._UpsampleCatFn: resize written into its channel slice, gradient read from the slice)
+    against torch.cat of the library's dense resize and the dense backward on a copied slice: bit for bit, both ways."""
+    torch.manual_seed(4)
+    low = _fmt(torch.randn(n, c0, *lo, device=gpu).to(dtype), True).requires_grad_(True)
+    x = _fmt(torch.randn(n, c, *hi, device=gpu).to(dtype), True).requires_grad_(True)
+    out = pkg.deeplab._UpsampleCatFn.apply(low, x)
+    ref = torch.cat([low.detach(), pkg.ops.upsample_bilinear(x.detach(), lo)], dim=1)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, ref)
+    g = _fmt(torch.randn(n, c0 + c, *lo, device=gpu).to(dtype), True)
+    out.backward(g)
+    assert torch.equal(low.grad, g[:, :c0])
+    assert torch.equal(x.grad, pkg.ops.upsample_bilinear_backward(g[:, c0:].contiguous(memory_format=torch.channels_last), hi))
+    with pytest.raises(TypeError):
+        pkg.ops.upsample_concat(low.detach(), x.detach().contiguous())          # NCHW operand: not this entry's case
+
+
 @pytest.mark.parametrize("nhwc", [False, True])
 @pytest.mark.parametrize("n,c,h,w", [(2, 21, 65, 65), (1, 19, 33, 47), (2, 5, 33, 33), (1, 32, 8, 8)])
 def test_ce2d_vs_torch(pkg, gpu, n, c, h, w, nhwc):
