@@ -78,7 +78,8 @@ SIGNATURES = {
     "afan_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),
     "afan_upsample_bilinear_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),
     "afan_upsample_bilinear_fwd_slice": (_i, [_p, _p, _i, _l, _l, _l, _l, _l, _l, _l, _p]),
-    "afan_upsample_bilinear_bwd_slice": (_i, [_p, _p, _i, _l, _l, _l, _l, _l, _l, _l, _p]),
+    "afan_upsample_bilinear_bwd_workspace_floats": (_l, [_l, _l, _l, _l]),
+    "afan_upsample_bilinear_bwd_slice": (_i, [_p, _p, _i, _l, _l, _l, _l, _l, _l, _l, _p, _p]),
     "afan_ce2d_workspace_floats": (_l, [_l]),
     "afan_ce2d": (_i, [_p, _p, _i, _l, _l, _l, _l, _f, _p, _p, _p, _p]),
     "afan_ce2d_upsampled_workspace_floats": (_l, [_l, _l, _l, _l, _l, _l]),

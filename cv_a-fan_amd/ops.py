@@ -1092,8 +1092,9 @@ def upsample_concat_backward(g, c0, in_hw):
     n, ct, ho, wo = g.shape
     c, hi, wi = ct - c0, int(in_hw[0]), int(in_hw[1])
     dx = torch.empty((n, c, hi, wi), dtype=g.dtype, device=g.device, memory_format=torch.channels_last)
+    ws = _workspace(g, lib.afan_upsample_bilinear_bwd_workspace_floats(n, c, wi, ho), "upsample_bwd")    # two separable passes
     check(lib.afan_upsample_bilinear_bwd_slice(g.data_ptr() + c0 * g.element_size(), _ptr(dx), _DT[g.dtype], n, c, hi, wi, ho, wo,
-                                               ct, _stream(g)), "afan_upsample_bilinear_bwd_slice")
+                                               ct, _ptr(ws), _stream(g)), "afan_upsample_bilinear_bwd_slice")
     return dx
 
 

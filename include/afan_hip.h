@@ -398,8 +398,12 @@ int afan_upsample_bilinear_bwd(const void* dy, void* dx, int dtype, int layout, 
  * from there.  Channels-last only. */
 int afan_upsample_bilinear_fwd_slice(const void* x, void* y, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
                                      int64_t wo, int64_t ld, afan_stream_t stream);
+/* bwd: ws = afan_upsample_bilinear_bwd_workspace_floats(n, c, wi, ho) floats of scratch (16-byte aligned) selects the two-pass
+ * separable form (sum over output columns into ws, then over output rows: ~scale loads per thread twice instead of ~scale^2
+ * once on a small grid); NULL (or a shape whose accesses are not 16-byte vectors): the one-pass gather of the dense entry. */
+int64_t afan_upsample_bilinear_bwd_workspace_floats(int64_t n, int64_t c, int64_t wi, int64_t ho);
 int afan_upsample_bilinear_bwd_slice(const void* dy, void* dx, int dtype, int64_t n, int64_t c, int64_t hi, int64_t wi, int64_t ho,
-                                     int64_t wo, int64_t ld, afan_stream_t stream);
+                                     int64_t wo, int64_t ld, float* ws, afan_stream_t stream);
 /* Per-pixel cross-entropy, nn.CrossEntropyLoss(ignore_index=I, reduction='mean') of Segmentation/main_aug_final.py:95:
  * logits fp32 [n,c,hw] (NCHW) or [n,hw,c] (NHWC), c <= 32; target int64 [n,hw].  loss[0] = sum over pixels with
  * target != I of (logsumexp - logit[target]) / count; dlogits (nullable, same layout) = grad_scale * d(loss)/d(logits)

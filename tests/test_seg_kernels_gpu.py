@@ -53,7 +53,7 @@ def test_upsample_bilinear_bf16_nhwc(pkg, gpu):
                                           (1, 4, 6, (7, 7), (3, 3))])
 def test_upsample_concat_equals_cat_of_the_resize(pkg, gpu, dtype, n, c0, c, lo, hi):
     """The decoder's concat node (deeplab._UpsampleCatFn: resize written into its channel slice, gradient read from the slice)
-    against torch.cat of the library's dense resize and the dense backward on a copied slice: bit for bit, both ways."""
+    against torch.cat of the library's dense resize (bit for bit) and the dense backward on a copied slice (to rounding)."""
     torch.manual_seed(4)
     low = _fmt(torch.randn(n, c0, *lo, device=gpu).to(dtype), True).requires_grad_(True)
     x = _fmt(torch.randn(n, c, *hi, device=gpu).to(dtype), True).requires_grad_(True)
@@ -64,7 +64,13 @@ def test_upsample_concat_equals_cat_of_the_resize(pkg, gpu, dtype, n, c0, c, lo,
     g = _fmt(torch.randn(n, c0 + c, *lo, device=gpu).to(dtype), True)
     out.backward(g)
     assert torch.equal(low.grad, g[:, :c0])
-    assert torch.equal(x.grad, pkg.ops.upsample_bilinear_backward(g[:, c0:].contiguous(memory_format=torch.channels_last), hi))
+    # (the slice entry sums columns, then rows — two separable passes; the dense one sums the products in one pass: rounding)
+    want = pkg.ops.upsample_bilinear_backward(g[:, c0:].contiguous(memory_format=torch.channels_last), hi)
+    tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), want.float().cpu().numpy(), rtol=tol, atol=tol)
+    xr = x.detach().float().requires_grad_(True)                          # and against torch's own adjoint
+    F.interpolate(xr, size=lo, mode="bilinear", align_corners=False).backward(g[:, c0:].float())
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), xr.grad.cpu().numpy(), rtol=5 * tol, atol=(6e-2 if dtype == torch.bfloat16 else 1e-5))
     with pytest.raises(TypeError):
         pkg.ops.upsample_concat(low.detach(), x.detach().contiguous())          # NCHW operand: not this entry's case
 
