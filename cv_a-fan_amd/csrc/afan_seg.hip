@@ -804,28 +804,32 @@ __global__ __launch_bounds__(BLOCK) void pointwise_dw_reduce_kernel(const float*
 // backbone gradients off by 30-60 %).  The branch therefore stays in fp32 from the pooled vector to the broadcast:
 //   y[n][co] = sum_ci x[n][ci] * w[co][ci]      (n <= LIN_MAX_N rows, fp32 master weights)
 constexpr int LIN_MAX_N = 16;
+// NN = the row count rounded up to {2, 4, 8, 16}: a compile-time row loop without branches (as a run-time `if (n < N)` inside
+// the channel loop every load sat behind its own scalar branch: ~96 dependent latencies, 28 us for 2 MB of weights); rows
+// beyond N re-read row N - 1 and are not stored.  Each lane's own sum keeps its order.
+template <int NN>
 __global__ __launch_bounds__(BLOCK) void linear_small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  float* __restrict__ y, int N, int Ci, int Co) {
     const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (co >= Co) return;
-    float acc[LIN_MAX_N];
+    float acc[NN];
+    const float* xr[NN];
 #pragma unroll
-    for (int n = 0; n < LIN_MAX_N; ++n) acc[n] = 0.f;
-    // (unrolled: eight iterations' loads are requested together — as a rolled loop this was 32 dependent load latencies for
-    //  2048 input channels, 32 us for 2 MB of weights; each lane's own sum keeps its order)
-#pragma unroll 8
+    for (int n = 0; n < NN; ++n) {
+        acc[n] = 0.f;
+        xr[n] = x + (int64_t)(n < N ? n : N - 1) * Ci;
+    }
+    const float* wr = w + (int64_t)co * Ci;
+#pragma unroll 4
     for (int c = lane; c < Ci; c += 64) {
-        const float wv = w[(int64_t)co * Ci + c];
+        const float wv = wr[c];
 #pragma unroll
-        for (int n = 0; n < LIN_MAX_N; ++n)
-            if (n < N) acc[n] = fmaf(x[(int64_t)n * Ci + c], wv, acc[n]);
+        for (int n = 0; n < NN; ++n) acc[n] = fmaf(xr[n][c], wv, acc[n]);
     }
 #pragma unroll
-    for (int n = 0; n < LIN_MAX_N; ++n) {
-        if (n < N) {
-            const float s = wave_sum(acc[n]);
-            if (lane == 0) y[(int64_t)n * Co + co] = s;
-        }
+    for (int n = 0; n < NN; ++n) {
+        const float s = wave_sum(acc[n]);
+        if (n < N && lane == 0) y[(int64_t)n * Co + co] = s;
     }
 }
 // dx[n][ci] = sum_co dy[n][co] * w[co][ci]
@@ -1359,7 +1363,11 @@ int afan_linear_small_fwd(const float* x, const float* w, float* y, int64_t n, i
     if (!x || !w || !y) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
     AFAN_PROF("linear_small_fwd_kernel", 4.0 * (ci * co + n * (ci + co)), st);
-    linear_small_fwd_kernel<<<(unsigned)((co + 3) / 4), BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
+    const unsigned lg = (unsigned)((co + 3) / 4);
+    if (n <= 2) linear_small_fwd_kernel<2><<<lg, BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
+    else if (n <= 4) linear_small_fwd_kernel<4><<<lg, BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
+    else if (n <= 8) linear_small_fwd_kernel<8><<<lg, BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
+    else linear_small_fwd_kernel<LIN_MAX_N><<<lg, BLOCK, 0, st>>>(x, w, y, (int)n, (int)ci, (int)co);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
