@@ -172,15 +172,49 @@ __global__ __launch_bounds__(BLOCK) void stats_kernel(const T* __restrict__ x, i
     else block_fold_store<VEC, 2, A>(acc, CV, C, gridDim.x, ws);
 }
 
-// generic: thread per channel, block per row slab
+// generic (channel counts the 16-byte mapping does not take, e.g. DeepLab's 48-channel projection): block per row slab;
+// C <= BLOCK: the block's threads cover BLOCK / C rows at once — thread t reads element t of a run of consecutive rows
+// (coalesced) — and the row lanes of a channel are summed through LDS; larger C: thread per channel.
+template <typename A>
+__device__ __forceinline__ void fold_row_lanes(A s1, A s2, int C, int R, int G, float* __restrict__ ws) {
+    __shared__ A sh[2][BLOCK];
+    sh[0][threadIdx.x] = s1;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        A a = 0, b = 0;
+        for (int k = 0; k < R; ++k) {
+            a += sh[0][threadIdx.x + k * C];
+            b += sh[1][threadIdx.x + k * C];
+        }
+        ws[((int64_t)0 * C + threadIdx.x) * G + blockIdx.x] = (float)a;
+        ws[((int64_t)1 * C + threadIdx.x) * G + blockIdx.x] = (float)b;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void stats_generic_kernel(const T* __restrict__ x, int64_t M, int C,
                                                               float* __restrict__ ws) {
     const int G = gridDim.x;
     const int64_t rows_per = (M + G - 1) / G;
     const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    typedef typename AccOf<T>::type A;
+    if (C <= BLOCK) {
+        const int R = BLOCK / C, c = threadIdx.x % C, lane_r = threadIdx.x / C;
+        A s1 = 0, s2 = 0;
+        if (lane_r < R) {
+            const float shift = Elt<T>::ld(x + c);
+#pragma unroll 4
+            for (int64_t r = r0 + lane_r; r < r1; r += R) {
+                const A d = (A)Elt<T>::ld(x + r * C + c) - (A)shift;
+                s1 += d;
+                s2 += d * d;
+            }
+        }
+        fold_row_lanes<A>(s1, s2, C, R, G, ws);
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += BLOCK) {
-        typedef typename AccOf<T>::type A;
         const float shift = Elt<T>::ld(x + c);
         A s1 = 0, s2 = 0;
         for (int64_t r = r0; r < r1; ++r) {
@@ -347,21 +381,32 @@ __global__ __launch_bounds__(BLOCK) void bwd_reduce_generic_kernel(const T* __re
     const int G = gridDim.x;
     const int64_t rows_per = (M + G - 1) / G;
     const int64_t r0 = blockIdx.x * rows_per, r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    typedef typename AccOf<T>::type A;
+    auto term = [&](int64_t i, float mu, float alpha, float beta, A& sg, A& sgx) {
+        const float e = Elt<T>::ld(x + i);
+        float g = Elt<T>::ld(dy + i);
+        if (RELU) {
+            const float act = HAVE_Y ? Elt<T>::ld(y + i) : fmaf(e, alpha, beta);
+            g = (act > 0.f) ? g : 0.f;
+        }
+        sg += (A)g;
+        sgx += (A)g * ((A)e - (A)mu);
+    };
+    if (C <= BLOCK) {       // BLOCK / C rows at once, as stats_generic_kernel
+        const int R = BLOCK / C, c = threadIdx.x % C, lane_r = threadIdx.x / C;
+        A sg = 0, sgx = 0;
+        if (lane_r < R) {
+            const float mu = stats[c], alpha = stats[2 * C + c], beta = stats[3 * C + c];
+#pragma unroll 4
+            for (int64_t r = r0 + lane_r; r < r1; r += R) term(r * C + c, mu, alpha, beta, sg, sgx);
+        }
+        fold_row_lanes<A>(sg, sgx, C, R, G, ws);
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += BLOCK) {
         const float mu = stats[c], alpha = stats[2 * C + c], beta = stats[3 * C + c];
-        typedef typename AccOf<T>::type A;
         A sg = 0, sgx = 0;
-        for (int64_t r = r0; r < r1; ++r) {
-            const int64_t i = r * C + c;
-            const float e = Elt<T>::ld(x + i);
-            float g = Elt<T>::ld(dy + i);
-            if (RELU) {
-                const float act = HAVE_Y ? Elt<T>::ld(y + i) : fmaf(e, alpha, beta);
-                g = (act > 0.f) ? g : 0.f;
-            }
-            sg += (A)g;
-            sgx += (A)g * ((A)e - (A)mu);
-        }
+        for (int64_t r = r0; r < r1; ++r) term(r * C + c, mu, alpha, beta, sg, sgx);
         ws[((int64_t)0 * C + c) * G + blockIdx.x] = (float)sg;
         ws[((int64_t)1 * C + c) * G + blockIdx.x] = (float)sgx;
     }

@@ -392,7 +392,8 @@ def _cl(t):
 
 
 NHWC_SHAPES = [(4, 16, 32, 32), (2, 64, 16, 16), (8, 512, 4, 4), (3, 304, 5, 7), (2, 3, 9, 9), (64, 128, 16, 16),
-               (2, 1024, 3, 3), (1, 8, 1, 1)]
+               (2, 1024, 3, 3), (1, 8, 1, 1),
+               (2, 48, 33, 29), (5, 200, 6, 5)]     # generic mapping, several rows per block pass (DeepLab's 48-channel projection)
 
 
 @pytest.mark.parametrize("shape", NHWC_SHAPES)
