@@ -108,6 +108,7 @@ SIGNATURES = {
     "afan_dropout": (_i, [_p, _p, _i, _l, _f, _p, _p, _p, _i, _p]),
     "afan_nms_workspace_bytes": (_l, [_l]),
     "afan_nms": (_i, [_p, _p, _l, _f, _i, _p, _p, _p, _p]),
+    "afan_nms_top": (_i, [_p, _p, _l, _f, _i, _p, _p, _p, _l, _p]),
     "afan_roi_align_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_roi_align_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),

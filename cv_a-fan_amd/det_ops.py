@@ -32,11 +32,13 @@ def _workspace_bytes(dev, nbytes):
     return w
 
 
-def nms(bboxes, scores, threshold, inclusive=False, padded=False):
+def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0):
     """Kept indices (ascending) of greedy NMS over boxes in descending-score order; IoU with +1 (inclusive corners).
     inclusive=False suppresses at IoU > threshold (the reference's GPU path, nms.cu:49), True at >= (its CPU path).
     padded=True: no host synchronisation — returns (keep [n] int64 on the device, of which the first count[0] are valid,
-    count [1] int64 on the device) for callers that can consume a padded result."""
+    count [1] int64 on the device) for callers that can consume a padded result.
+    max_keep > 0 (afan_nms_top): the caller passes boxes ALREADY in score order and looks at the first max_keep survivors
+    only — the scan stops once it has them (the result may hold up to 63 more); its first max_keep entries are nms()'s."""
     if bboxes.device.type != "cuda":
         raise ops.AfanLibraryError("nms: tensors must live on the MI355X (no CPU path in this build)")
     n = bboxes.shape[0] if bboxes.dim() > 0 else 0
@@ -49,8 +51,13 @@ def nms(bboxes, scores, threshold, inclusive=False, padded=False):
     count = torch.empty(1, dtype=torch.int64, device=boxes.device)
     ws = _workspace_bytes(boxes.device, lib.afan_nms_workspace_bytes(n))
     st = C.c_void_p(torch.cuda.current_stream(boxes.device).cuda_stream)
-    check(lib.afan_nms(C.c_void_p(boxes.data_ptr()), C.c_void_p(order.data_ptr()), n, float(threshold), int(bool(inclusive)),
-                       C.c_void_p(ws.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(count.data_ptr()), st), "afan_nms")
+    if max_keep and max_keep > 0:
+        check(lib.afan_nms_top(C.c_void_p(boxes.data_ptr()), C.c_void_p(order.data_ptr()), n, float(threshold), int(bool(inclusive)),
+                               C.c_void_p(ws.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(count.data_ptr()), int(max_keep), st),
+              "afan_nms_top")
+    else:
+        check(lib.afan_nms(C.c_void_p(boxes.data_ptr()), C.c_void_p(order.data_ptr()), n, float(threshold), int(bool(inclusive)),
+                           C.c_void_p(ws.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(count.data_ptr()), st), "afan_nms")
     if padded:
         return keep, count
     return keep[:int(count.item())]       # the result's length is data dependent: one read-back (the reference copies the whole mask)

@@ -514,6 +514,14 @@ int afan_dropout(const void* x, void* y, int dtype, int64_t n, float p, const ui
 int64_t afan_nms_workspace_bytes(int64_t n);
 int afan_nms(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
              int64_t* keep_out, int64_t* count_out, afan_stream_t stream);
+/* afan_nms_top — the same for a caller that looks at the first max_keep survivors only, the proposal layer's
+ * `nms(...)` followed by `[:post_nms_top_n]` (rpn/region_proposal_network.py:88-93 with boxes pre-sorted by score): the scan
+ * stops after the 64-box block in which the kept count reaches max_keep (> 0), since what greedy NMS keeps first never depends
+ * on later boxes.  count_out[0] may exceed max_keep by up to 63; keep_out is ascending by ORIGINAL index as above, so "first
+ * max_keep" means first by score only when the boxes were passed in score order (then the result's first max_keep entries
+ * equal afan_nms's).  max_keep = 0: afan_nms. */
+int afan_nms_top(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
+                 int64_t* keep_out, int64_t* count_out, int64_t max_keep, afan_stream_t stream);
 /* afan_roi_align_{fwd,bwd} — `support._C.roi_align_forward / roi_align_backward` (ROIAlign.h:12-47 -> ROIAlign_cuda.cu:256-346).
  * x [N,C,H,W], rois [num_rois,5] fp32 = (batch index, x1, y1, x2, y2) in image coordinates (scaled by spatial_scale, NOT
  * rounded), y [num_rois,C,PH,PW]; sampling_ratio <= 0: ceil(roi extent / pooled extent) sample points per bin and axis.

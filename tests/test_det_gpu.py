@@ -43,7 +43,7 @@ def test_nms_small_cases(pkg, gpu):
         nms(b.cpu(), s.cpu(), 0.5)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4097])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 128, 129, 1000, 4097, 12000])
 def test_nms_random_vs_c_oracle(pkg, gpu, c_oracle, n):
     rng = np.random.default_rng(n)
     xy = rng.uniform(0, 400, (n, 2)).astype(np.float32)
@@ -190,3 +190,23 @@ def test_nms_padded_form_needs_no_host_read(pkg, gpu):
     keep, count = pkg.det_ops.nms(boxes, scores, 0.5, padded=True)
     assert keep.is_cuda and count.is_cuda and keep.shape == (3000,) and count.shape == (1,)
     assert int(count) == ref.numel() and torch.equal(keep[:int(count)], ref)
+
+
+@pytest.mark.parametrize("n,spread", [(12000, 900.0), (5000, 250.0), (700, 100.0)])
+def test_nms_top_stops_at_the_first_survivors(pkg, gpu, n, spread):
+    """nms(max_keep=k) on boxes in score order (the proposal layer's call, region_proposal_network.py:88-93 followed by
+    [:post_nms_top_n]): the first k survivors are those of the full scan, and the scan really stopped (fewer survivors
+    reported than the full scan finds) whenever the full scan finds more than k + 63."""
+    g = torch.Generator().manual_seed(n)
+    xy = torch.rand(n, 2, generator=g) * spread
+    wh = torch.rand(n, 2, generator=g) * 60 + 4
+    boxes = torch.cat([xy, xy + wh], dim=1).to(gpu)
+    scores = torch.sort(torch.rand(n, generator=g), descending=True)[0].to(gpu)
+    full = pkg.det_ops.nms(boxes, scores, 0.7)
+    for k in (1, 50, 300, 2000):
+        top = pkg.det_ops.nms(boxes, scores, 0.7, max_keep=k)
+        m = min(k, full.numel())
+        assert torch.equal(top[:m], full[:m]), (n, k)
+        assert top.numel() <= max(full.numel(), 0) and (top.numel() < k + 64 or full.numel() < k + 64), (n, k, top.numel(), full.numel())
+        if full.numel() >= k:
+            assert top.numel() >= k
