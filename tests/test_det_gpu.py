@@ -70,9 +70,10 @@ def _oracle_roi(lib, x, rois, ph, pw, scale, sr, dy=None):
 
 @pytest.mark.parametrize("nhwc", [False, True])
 @pytest.mark.parametrize("sr", [0, 2])
-def test_roi_align_vs_c_oracle(pkg, gpu, c_oracle, nhwc, sr):
+@pytest.mark.parametrize("C", [24, 192])        # (192 channels-last: the geometry-once-per-bin kernels, both directions)
+def test_roi_align_vs_c_oracle(pkg, gpu, c_oracle, nhwc, sr, C):
     rng = np.random.default_rng(3)
-    N, C, H, W = 2, 24, 38, 57                                           # a 600 x 901 image at stride 16 (rpn docstring)
+    N, H, W = 2, 38, 57                                                  # a 600 x 901 image at stride 16 (rpn docstring)
     x = rng.standard_normal((N, C, H, W)).astype(np.float32)
     rois = np.array([[0, 10, 20, 300, 220], [1, 0, 0, 900, 599], [1, 450.5, 100.25, 470.75, 130.5], [0, 880, 580, 905, 610],
                      [0, 33, 44, 34, 45], [1, -30, -10, 50, 80]], np.float32)
@@ -92,14 +93,20 @@ def test_roi_align_vs_c_oracle(pkg, gpu, c_oracle, nhwc, sr):
     assert tuple(p.shape) == (len(rois), C, 7, 7)
 
 
-def test_roi_align_bf16_nhwc(pkg, gpu, c_oracle):
+@pytest.mark.parametrize("C", [64, 256])         # (256: 32 channel vectors — the geometry-once-per-bin kernels)
+def test_roi_align_bf16_nhwc(pkg, gpu, c_oracle, C):
     rng = np.random.default_rng(4)
-    x = torch.from_numpy(rng.standard_normal((1, 64, 20, 30)).astype(np.float32)).bfloat16()
-    rois = np.array([[0, 16, 32, 208, 160], [0, 100, 40, 400, 300]], np.float32)
+    x = torch.from_numpy(rng.standard_normal((1, C, 20, 30)).astype(np.float32)).bfloat16()
+    rois = np.array([[0, 16, 32, 208, 160], [0, 100, 40, 400, 300], [0, -20, 5, 90, 500]], np.float32)
     ref = _oracle_roi(c_oracle, x.float().numpy(), rois, 7, 7, 1 / 16, 0)
-    y = pkg.det_ops.roi_align(x.to(gpu).contiguous(memory_format=torch.channels_last), torch.from_numpy(rois).to(gpu), 7, 1 / 16, 0)
+    xt = x.to(gpu).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = pkg.det_ops.roi_align(xt, torch.from_numpy(rois).to(gpu), 7, 1 / 16, 0)
     assert y.dtype == torch.bfloat16
-    np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
+    dy = torch.from_numpy(rng.standard_normal(ref.shape).astype(np.float32)).bfloat16()
+    y.backward(dy.to(gpu).contiguous(memory_format=torch.channels_last))
+    dref = _oracle_roi(c_oracle, x.float().numpy(), rois, 7, 7, 1 / 16, 0, dy=dy.float().numpy())
+    np.testing.assert_allclose(xt.grad.float().cpu().numpy(), dref, rtol=2e-2, atol=2e-2)      # (the gradient is stored in bf16)
 
 
 def test_detection_pgd_protocol(pkg, gpu):
