@@ -457,7 +457,8 @@ class RegionProposalNetwork(nn.Module):
         for b in range(anchor_bboxes.shape[0]):
             sb = boxes[b][order[b]][:self._pre_nms_top_n]
             sp = probs[b][order[b]][:self._pre_nms_top_n]
-            keep = nms(sb, sp, 0.7, max_keep=self._post_nms_top_n)      # (sb is in score order: the scan stops at top-N survivors)
+            # (sb / sp are in descending score order: no second sort, and the scan stops at the top-N survivors)
+            keep = nms(sb, sp, 0.7, max_keep=self._post_nms_top_n, presorted=True)
             kept.append(sb[keep.to(sb.device)][:self._post_nms_top_n])
         longest = max(len(k) for k in kept)
         return torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)

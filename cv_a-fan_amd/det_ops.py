@@ -32,13 +32,18 @@ def _workspace_bytes(dev, nbytes):
     return w
 
 
-def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0):
+_arange_cache = {}
+
+
+def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0, presorted=False):
     """Kept indices (ascending) of greedy NMS over boxes in descending-score order; IoU with +1 (inclusive corners).
     inclusive=False suppresses at IoU > threshold (the reference's GPU path, nms.cu:49), True at >= (its CPU path).
     padded=True: no host synchronisation — returns (keep [n] int64 on the device, of which the first count[0] are valid,
     count [1] int64 on the device) for callers that can consume a padded result.
     max_keep > 0 (afan_nms_top): the caller passes boxes ALREADY in score order and looks at the first max_keep survivors
-    only — the scan stops once it has them (the result may hold up to 63 more); its first max_keep entries are nms()'s."""
+    only — the scan stops once it has them (the result may hold up to 63 more); its first max_keep entries are nms()'s.
+    presorted=True: the caller vouches that `scores` is already descending (the proposal layer sorts before it slices the
+    top pre-NMS candidates): the sort of nms.cu:73-75 is skipped, the order is 0..n-1."""
     if bboxes.device.type != "cuda":
         raise ops.AfanLibraryError("nms: tensors must live on the MI355X (no CPU path in this build)")
     n = bboxes.shape[0] if bboxes.dim() > 0 else 0
@@ -46,7 +51,13 @@ def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0):
         return torch.empty(0, dtype=torch.int64)          # nms.h:17-18 returns an empty CPU tensor
     lib = _lib.load()
     boxes = bboxes.detach().float().contiguous()
-    order = torch.sort(scores.detach().float(), dim=0, descending=True)[1].contiguous()      # nms.cu:73-75
+    if presorted:
+        key = (boxes.device.index, n)
+        order = _arange_cache.get(key)
+        if order is None:
+            order = _arange_cache[key] = torch.arange(n, dtype=torch.int64, device=boxes.device)
+    else:
+        order = torch.sort(scores.detach().float(), dim=0, descending=True)[1].contiguous()      # nms.cu:73-75
     keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
     count = torch.empty(1, dtype=torch.int64, device=boxes.device)
     ws = _workspace_bytes(boxes.device, lib.afan_nms_workspace_bytes(n))

@@ -212,6 +212,7 @@ def test_nms_top_stops_at_the_first_survivors(pkg, gpu, n, spread):
     full = pkg.det_ops.nms(boxes, scores, 0.7)
     for k in (1, 50, 300, 2000):
         top = pkg.det_ops.nms(boxes, scores, 0.7, max_keep=k)
+        assert torch.equal(pkg.det_ops.nms(boxes, scores, 0.7, max_keep=k, presorted=True), top)     # (scores ARE sorted here)
         m = min(k, full.numel())
         assert torch.equal(top[:m], full[:m]), (n, k)
         assert top.numel() <= max(full.numel(), 0) and (top.numel() < k + 64 or full.numel() < k + 64), (n, k, top.numel(), full.numel())
