@@ -129,3 +129,25 @@ def test_module_fp32_conv_autograd_matches_torch_cpu(pkg, gpu):
             assert torch.allclose(xd.grad.double().cpu(), x64.grad, rtol=1e-5, atol=1e-5)
             assert torch.allclose(m.weight.grad.double().cpu(), w64.grad, rtol=1e-5, atol=5e-4)      # sums of ~600 O(1) products
     assert pkg.ops.CALLS["vendor_conv"] == 0
+
+
+@pytest.mark.parametrize("n,ci,co", [(64, 2048, 1000), (128, 2048, 84), (5, 1024, 21), (16, 64, 10), (3, 300, 700)])
+def test_linear_on_the_general_kernels_matches_float64(pkg, gpu, n, ci, co):
+    """resnet_s._LinearFn (nn.Linear without a vendor GEMM): output, input gradient, weight and bias gradients against
+    float64 — including the two re-readings as weight-gradient problems (few rows with a long reduction: the forward for
+    ci >= 1024, the input gradient for co >= 512)."""
+    torch.manual_seed(n + ci + co)
+    lin = torch.nn.Linear(ci, co).to(gpu)
+    x = torch.randn(n, ci, device=gpu, requires_grad=True)
+    y = pkg.resnet_s._LinearFn.apply(x, lin.weight, lin.bias, True)
+    g = torch.randn(n, co, device=gpu)
+    y.backward(g)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64, b64 = lin.weight.detach().double().cpu().requires_grad_(True), lin.bias.detach().double().cpu().requires_grad_(True)
+    y64 = F.linear(x64, w64, b64)
+    y64.backward(g.double().cpu())
+    assert torch.allclose(y.double().cpu(), y64.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(x.grad.double().cpu(), x64.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(lin.weight.grad.double().cpu(), w64.grad, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(lin.bias.grad.double().cpu(), b64.grad, rtol=1e-5, atol=1e-4)
+    assert pkg.ops.CALLS["vendor_conv"] == 0

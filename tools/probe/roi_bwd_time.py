@@ -30,5 +30,5 @@ for size in (64, 128, 224, 400, 800):
     e1.record()
     e1.synchronize()
     cells = size / 16
-    samples = -(-cells // 14) ** 2
+    samples = int(-(-cells // 14)) ** 2
     print(f"roi {size:4d} px = {cells:5.1f} cells, {int(samples)} samples per bin: backward {e0.elapsed_time(e1) / 5 * 1e3:8.1f} us (incl. memset + bf16 cast of the map)")
