@@ -282,14 +282,17 @@ def seg_criterion(criterion):
 
 
 class _Stem7Fn(torch.autograd.Function):
-    """conv1 (7x7 / 2, 3 -> 64) on the image; images carry no gradient.  im2col (afan_conv_stem7_im2col: 152 columns, the
-    147 taps in the weights' KRSC order + 5 zeros) turns forward and weight gradient into 1x1 problems for the MFMA
-    kernels; the column tensor is kept for the backward.  AFAN_STEM7_DIRECT=1 selects the direct FMA kernels (A/B)."""
+    """conv1 (7x7 / 2, 3 -> 64) on the image.  im2col (afan_conv_stem7_im2col: 152 columns, the 147 taps in the weights'
+    KRSC order + 5 zeros) turns forward and weight gradient into 1x1 problems for the MFMA kernels; the column tensor is
+    kept for the backward.  An image that carries a gradient (Detection's image-level perturbation,
+    train_aug_sat_muti_advt.py:82-95) takes the same forward — 70 us instead of 527 on the general kernel at 600 x 904 —
+    and gets its gradient from the general input-gradient kernel.  AFAN_STEM7_DIRECT=1 selects the direct FMA kernels (A/B)."""
     DIRECT = os.environ.get("AFAN_STEM7_DIRECT", "0") == "1"
 
     @staticmethod
     def forward(ctx, x, w_master, w_lp, want_wgrad):
         ctx.w_master, ctx.want = w_master, want_wgrad
+        ctx.w_lp, ctx.in_hw = (w_lp, tuple(x.shape[2:])) if ctx.needs_input_grad[0] else (None, None)
         if _Stem7Fn.DIRECT:
             ctx.save_for_backward(x)
             return ops.conv_stem7_fwd(x, w_lp)
@@ -319,7 +322,10 @@ class _Stem7Fn(torch.autograd.Function):
                     wm.grad.permute(0, 2, 3, 1).reshape(64, 147).add_(g)                 # (a view of the KRSC arena slice)
                 else:
                     gw = g.reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
-        return None, gw, None, None
+        gx = None
+        if ctx.needs_input_grad[0] and ctx.w_lp is not None:
+            gx = ops.conv_general_dgrad(gy.contiguous(memory_format=torch.channels_last), ctx.w_lp, ctx.in_hw, 2, 3, 1)
+        return gx, gw, None, None
 
 
 # ---------------------------------------------------------------------------------------------------- layers
@@ -329,7 +335,8 @@ class StemConv(Conv2d):
     def forward(self, x):
         x = _to_compute(x, self.compute_dtype)
         w = self.lp_weight()
-        if not x.requires_grad and ops.conv_stem7_ok(x, w, self.stride, self.padding) and w.is_contiguous(memory_format=torch.channels_last):
+        if ops.conv_stem7_ok(x, w, self.stride, self.padding) and w.is_contiguous(memory_format=torch.channels_last) \
+                and (not x.requires_grad or not _Stem7Fn.DIRECT):
             return _Stem7Fn.apply(x, self.weight, w.detach(), _Flags.param_grads)
         return super().forward(x)
 

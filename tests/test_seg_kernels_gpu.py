@@ -381,3 +381,25 @@ def test_aspp_multi_launch_equals_per_branch_path(pkg, gpu):
         torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=1e-6, msg=k)
     for k in b[3]:
         torch.testing.assert_close(a[3][k].float(), b[3][k].float(), rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_stem_conv_with_an_image_gradient(pkg, gpu):
+    """StemConv on an image that requires a gradient (Detection's image-level perturbation): forward through the im2col +
+    MFMA path like the gradient-free case (bit-equal to it), input gradient from the general kernel — against an fp32
+    convolution of the same bf16 values."""
+    torch.manual_seed(5)
+    m = pkg.deeplab.StemConv(3, 64, kernel_size=7, stride=2, padding=3, bias=False).to(gpu)
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(2, 3, 37, 53, device=gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+    y0 = m(x)
+    xr = x.clone().requires_grad_(True)
+    y = m(xr)
+    assert torch.equal(y, y0)
+    g = torch.randn_like(y)
+    y.backward(g)
+    w = m.lp_weight().float()
+    xf = x.float().requires_grad_(True)
+    ref = F.conv2d(xf, w, None, 2, 3)
+    ref.backward(g.float())
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(xr.grad.float().cpu().numpy(), xf.grad.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(xf.grad.abs().max()))
