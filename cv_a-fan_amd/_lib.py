@@ -73,6 +73,7 @@ SIGNATURES = {
     "afan_conv_stem7_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p]),
     "afan_conv_stem7_im2col_k": (_i, []),
     "afan_conv_stem7_im2col": (_i, [_p, _p, _l, _l, _l, _p]),
+    "afan_conv_stem7_col2im": (_i, [_p, _p, _l, _l, _l, _p]),
     "afan_conv_stem7_wgrad_workspace_floats": (_l, [_l, _l, _l]),
     "afan_conv_stem7_wgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _p, _i, _p]),
     "afan_upsample_bilinear_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _l, _l, _l, _p]),

@@ -146,6 +146,37 @@ __global__ __launch_bounds__(BLOCK) void stem7_im2col_kernel(const uint16_t* __r
     }
 }
 
+// The adjoint of the im2col: dx[n, h, w, c] = sum over the taps (r, s) whose window covers input pixel (h, w) — (h + 3 - r) and
+// (w + 3 - s) even, output pixel ((h + 3 - r) / 2, (w + 3 - s) / 2) inside the map — of dcols[n, ho, wo, (r*7 + s)*3 + c].
+// With dcols = dy x W (a 1x1 input-gradient problem on the MFMA kernel, 64 -> 152 columns) this is the stem's input gradient:
+// the image-level perturbation of Detection (train_aug_sat_muti_advt.py:82-95) needs it in five of an iteration's eight
+// forwards, and the general kernel spends 527 us on a 3-channel output (3 of 32 MFMA columns used).  One thread per input pixel,
+// 12-16 taps x 3 channels; fp32 sums, taps in increasing (r, s).
+__global__ __launch_bounds__(BLOCK) void stem7_col2im_kernel(const uint16_t* __restrict__ dcols, uint16_t* __restrict__ dx,
+                                                             int Hi, int Wi, int Ho, int Wo, int64_t pixels) {
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= pixels) return;
+    const int w = (int)(p % Wi), h = (int)((p / Wi) % Hi);
+    const int64_t n = p / Wi / Hi;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int r = (h + 3) & 1; r < KK; r += 2) {            // (h + 3 - r) even
+        const int ho = (h + 3 - r) >> 1;
+        if (ho < 0 || ho >= Ho) continue;
+        for (int s = (w + 3) & 1; s < KK; s += 2) {
+            const int wo = (w + 3 - s) >> 1;
+            if (wo < 0 || wo >= Wo) continue;
+            const uint16_t* src = dcols + (((int64_t)n * Ho + ho) * Wo + wo) * KP + (r * KK + s) * 3;
+            a0 += bf2f(src[0]);
+            a1 += bf2f(src[1]);
+            a2 += bf2f(src[2]);
+        }
+    }
+    uint16_t* dst = dx + p * 3;
+    dst[0] = f2bf(a0);
+    dst[1] = f2bf(a1);
+    dst[2] = f2bf(a2);
+}
+
 int wgrad_blocks(int64_t tiles) { return (int)(tiles < 512 ? tiles : 512); }
 
 }  // namespace
@@ -192,6 +223,20 @@ int afan_conv_stem7_im2col(const void* x, void* cols, int64_t n, int64_t hi, int
     AFAN_PROF("stem7_im2col_kernel", 2.0 * ((double)n * hi * wi * 3 + (double)n * ho * wo * KP), st);
     dim3 grid((unsigned)((wo + SEG - 1) / SEG), (unsigned)ho, (unsigned)n);
     stem7_im2col_kernel<<<grid, BLOCK, 0, st>>>((const uint16_t*)x, (uint16_t*)cols, (int)hi, (int)wi, (int)ho, (int)wo);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// dx[N,Hi,Wi,3] (bf16) = col2im of dcols[N*Ho*Wo][152] (bf16): the adjoint of afan_conv_stem7_im2col (columns >= 147 ignored).
+int afan_conv_stem7_col2im(const void* dcols, void* dx, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream) {
+    if (n <= 0 || hi <= 0 || wi <= 0 || n * hi * wi > 0x7fffffffLL * BLOCK) return AFAN_ESHAPE;
+    if (!dcols || !dx) return AFAN_ENULL;
+    if (!aligned(dcols, 2) || !aligned(dx, 2)) return AFAN_EALIGN;
+    const int64_t ho = (hi - 1) / 2 + 1, wo = (wi - 1) / 2 + 1, pixels = n * hi * wi;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("stem7_col2im_kernel", 2.0 * ((double)pixels * 3 + (double)n * ho * wo * K), st);
+    stem7_col2im_kernel<<<(unsigned)((pixels + BLOCK - 1) / BLOCK), BLOCK, 0, st>>>((const uint16_t*)dcols, (uint16_t*)dx, (int)hi, (int)wi,
+                                                                                   (int)ho, (int)wo, pixels);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -285,8 +285,10 @@ class _Stem7Fn(torch.autograd.Function):
     """conv1 (7x7 / 2, 3 -> 64) on the image.  im2col (afan_conv_stem7_im2col: 152 columns, the 147 taps in the weights'
     KRSC order + 5 zeros) turns forward and weight gradient into 1x1 problems for the MFMA kernels; the column tensor is
     kept for the backward.  An image that carries a gradient (Detection's image-level perturbation,
-    train_aug_sat_muti_advt.py:82-95) takes the same forward — 70 us instead of 527 on the general kernel at 600 x 904 —
-    and gets its gradient from the general input-gradient kernel.  AFAN_STEM7_DIRECT=1 selects the direct FMA kernels (A/B)."""
+    train_aug_sat_muti_advt.py:82-95) takes the same forward — ~50 us instead of 169 on the general kernel at 600 x 904 —
+    and gets its gradient as dy x W (a 1x1 problem on the MFMA kernel, 64 -> 152 columns) followed by
+    afan_conv_stem7_col2im: ~65 us instead of 527 (a 3-channel output uses 3 of the general kernel's 32 MFMA columns).
+    AFAN_STEM7_DIRECT=1 selects the direct FMA kernels (A/B)."""
     DIRECT = os.environ.get("AFAN_STEM7_DIRECT", "0") == "1"
 
     @staticmethod
@@ -300,6 +302,9 @@ class _Stem7Fn(torch.autograd.Function):
         k = cols.shape[1]
         wp = torch.zeros((64, k, 1, 1), dtype=torch.bfloat16, device=x.device)
         wp.view(64, k)[:, :147] = w_lp.permute(0, 2, 3, 1).reshape(64, 147)        # KRSC memory: a plain row copy
+        # (image gradient wanted: dcols = dy x W as a 1x1 problem with the transposed operand, then col2im)
+        ctx.wp_t = wp.view(64, k).t().contiguous().view(k, 64, 1, 1).contiguous(memory_format=torch.channels_last) \
+            if ctx.needs_input_grad[0] else None
         ctx.save_for_backward(cols)
         return ops.conv_fwd(cols, wp.contiguous(memory_format=torch.channels_last), 1)
 
@@ -324,7 +329,11 @@ class _Stem7Fn(torch.autograd.Function):
                     gw = g.reshape(64, 7, 7, 3).permute(0, 3, 1, 2)
         gx = None
         if ctx.needs_input_grad[0] and ctx.w_lp is not None:
-            gx = ops.conv_general_dgrad(gy.contiguous(memory_format=torch.channels_last), ctx.w_lp, ctx.in_hw, 2, 3, 1)
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            if getattr(ctx, "wp_t", None) is not None and gy.dtype == torch.bfloat16:
+                gx = ops.conv_stem7_col2im(ops.conv_fwd(gy, ctx.wp_t, 1), ctx.in_hw)       # 1x1 on the MFMA kernel + gather
+            else:
+                gx = ops.conv_general_dgrad(gy, ctx.w_lp, ctx.in_hw, 2, 3, 1)
         return gx, gw, None, None
 
 

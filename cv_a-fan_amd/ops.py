@@ -1354,6 +1354,19 @@ def conv_stem7_im2col(x):
     return cols
 
 
+def conv_stem7_col2im(dcols, in_hw):
+    """dx [N,3,Hi,Wi] bf16 channels-last from dcols [N,152,Ho,Wo] (the adjoint of conv_stem7_im2col)."""
+    lib = _lib.load()
+    _cl4(dcols, "dcols")
+    n, k = dcols.shape[0], dcols.shape[1]
+    hi, wi = int(in_hw[0]), int(in_hw[1])
+    if k != lib.afan_conv_stem7_im2col_k() or tuple(dcols.shape[2:]) != ((hi - 1) // 2 + 1, (wi - 1) // 2 + 1) or dcols.dtype != torch.bfloat16:
+        raise ValueError("conv_stem7_col2im: dcols must be the bf16 column tensor of an input of size in_hw")
+    dx = torch.empty((n, 3, hi, wi), dtype=torch.bfloat16, device=dcols.device, memory_format=torch.channels_last)
+    check(lib.afan_conv_stem7_col2im(_ptr(dcols), _ptr(dx), n, hi, wi, _stream(dcols)), "afan_conv_stem7_col2im")
+    return dx
+
+
 def conv_stem7_fwd(x, w):
     """The 7x7 / stride 2 image stem: x [N,3,H,W] bf16 channels-last, w [64,3,7,7] bf16 in KRSC memory."""
     lib = _lib.load()

@@ -376,6 +376,10 @@ int afan_conv_stem7_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t
  * afan_conv_wgrad_nhwc_bf16 (ci = 152) on the MFMA kernels. */
 int afan_conv_stem7_im2col_k(void);
 int afan_conv_stem7_im2col(const void* x, void* cols, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream);
+/* The adjoint: dx[N,Hi,Wi,3] bf16 = sum of the columns of dcols[N*Ho*Wo][K] over the taps that cover each input pixel.  With
+ * dcols = dy x W (afan_conv_fwd_nhwc_bf16 as a 1x1 problem, 64 -> 152) it is the stem's input gradient — the image-level
+ * perturbation of Detection/train_aug_sat_muti_advt.py:82-95 differentiates through conv1. */
+int afan_conv_stem7_col2im(const void* dcols, void* dx, int64_t n, int64_t hi, int64_t wi, afan_stream_t stream);
 int64_t afan_conv_stem7_wgrad_workspace_floats(int64_t n, int64_t hi, int64_t wi);
 int afan_conv_stem7_wgrad_nhwc_bf16(const void* x, const void* dy, float* grad, int64_t n, int64_t hi, int64_t wi,
                                     float* workspace, int accumulate, afan_stream_t stream);
