@@ -806,6 +806,7 @@ int choose_bm(int64_t M, int co, int n_classes) {
 // pixel's bottom-right tap — fits the buffer
 constexpr int HALO_PIXELS = 320;       // 128- and 64-row tiles
 constexpr int HALO_PIXELS_256 = 328;   // 256-row tiles: one 16x16 image with its border is 18 x 18 = 324 pixels
+constexpr int HALO_PIXELS_256N = 400;  // 256-row x 64-channel tiles (8 KB weight stages leave the room): four 8x8 images, 4 x 100
 static bool halo_ok(const ConvP& p, int bm, int cap = HALO_PIXELS) {
     const ConvClass& c = p.cls[0];
     if (p.n_classes != 1 || p.multi || p.a_extra || p.in_s != 1 || p.out_s != 1 || p.max_pad != 1 || c.T != 9) return false;
@@ -861,6 +862,24 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         if (halo && halo256 && spec && bm == 128 && wgs > deep_max && wgs <= 2 * deep_max && !p.stats
             && (p.groups != 2 || ((int64_t)(p.N / 2) * p.cls[0].Hg * p.cls[0].Wg) % 256 == 0) && halo_ok(p, 256, HALO_PIXELS_256))
             return launch<256, 128, 5, 4, 2, 4, 2, HALO_PIXELS_256>(p, st, dgrad);   // (two k16-slices of fragments in flight: 168 registers per wave at three waves per SIMD)
+        // 64-row launches whose weights dominate the L2 traffic (ResNet-18's 4x4 stage: 64 row tiles each stream the 4.7 MB of
+        // a 512 -> 512 layer's weights, 300 MB of L2 requests per launch): the same workgroup count as 128-row x 64-channel
+        // tiles — half as many row tiles read the weights, each tile's halo is read by twice as many channel tiles (it is
+        // the small operand) — a third less L2 traffic per launch
+        static const int n64 = env_int("AFAN_CONV_HALO_N64", 1);
+        if (halo && n64 && spec && bm == 64 && !p.stats && p.Co % 64 == 0 && p.Ci >= 256) {
+            const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 127) / 128) * p.n_classes;
+            if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 128))
+                return launch<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);
+        }
+        // and the 128-row launches of the same kind (the 8x8 stage) as 256-row x 64-channel tiles: 4 images and their borders
+        // per tile (400 pixels), 8 KB weight stages
+        if (halo && n64 && spec && bm == 128 && wgs <= deep_max && !p.stats && p.Co % 64 == 0 && p.Ci >= 256 &&
+            (p.groups != 2 || ((int64_t)(p.N / 2) * p.cls[0].Hg * p.cls[0].Wg) % 256 == 0)) {
+            const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 255) / 256) * p.n_classes;
+            if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 256, HALO_PIXELS_256N))
+                return launch<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N>(p, st, dgrad);
+        }
         if (wgs <= deep_max && spec && halo && halo_ok(p, bm))
             return bm == 64 ? launch<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
                             : launch<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);

@@ -252,7 +252,9 @@ def test_dgrad_epilogue_fusions(pkg, gpu, bn_mode, n, ci, co, h, k, stride):
 @pytest.mark.parametrize("n,ci,co,h,w", [(2, 256, 256, 33, 33), (3, 128, 256, 19, 19), (5, 64, 128, 7, 7), (9, 128, 128, 4, 4),
                                          (2, 192, 128, 13, 29), (1, 64, 256, 5, 61), (64, 512, 512, 7, 7),
                                          # 385..768 workgroups of 128 rows: the 256-row halo tile (a whole 16x16 image per tile)
-                                         (256, 128, 128, 16, 16), (100, 128, 256, 16, 16), (150, 64, 128, 8, 40), (37, 128, 128, 15, 17)])
+                                         (256, 128, 128, 16, 16), (100, 128, 256, 16, 16), (150, 64, 128, 8, 40), (37, 128, 128, 15, 17),
+                                         # weight-heavy launches (Ci >= 256): 128-row x 64-channel and 256-row x 64-channel halo tiles
+                                         (256, 512, 512, 4, 4), (256, 256, 256, 8, 8), (200, 512, 256, 8, 8), (30, 256, 192, 9, 11)])
 def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
     """The LDS-resident-halo form of the tiled kernel (launches of about one workgroup per CU: 3x3 / stride 1, whole
     64-channel chunks) against (a) torch on the same bf16 values and (b) the per-tap form bit for bit: the same images
