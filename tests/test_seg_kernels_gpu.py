@@ -337,7 +337,9 @@ def test_conv_fwd_multi_equals_separate_launches(pkg, gpu, n, ci, co, h, w, dils
         # sum over the accumulator copies of (sum, sum of squares) per channel
         k = int(pkg._lib.load().afan_bn_acc_doubles(co))
         body1, body2 = a1[:k], a2[:k]
-        torch.testing.assert_close(body1.sum(), body2.sum(), rtol=1e-9, atol=1e-9)
+        # (the tiles' column sums are fp32 before they are added in f64, and the single launch may take another tile shape
+        #  than the multi-problem one — e.g. the 128-row x 64-channel halo tile for the dilation-1 branch: fp32 grouping noise)
+        torch.testing.assert_close(body1.sum(), body2.sum(), rtol=2e-7, atol=1e-6)
         ref = F.conv2d(x.float(), ws[b].float(), padding=d, dilation=d)
         assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
     ys2, sts2 = ops.conv_fwd_multi(x, ws, 1, dils, None)
