@@ -174,9 +174,12 @@ void oracle_sgd_step(float* p, const float* g, float* m, int64_t n, float lr, fl
 /* ------------------------------------------------------------------------------------------------------------------
  * Detection operators.  NMS is pinned to the reference's own golden (Detection/test/nms/
  * nms-large-{input,output}.npy, copied as data into tests/golden/) and to the three small cases of
- * Detection/test/nms/test_nms.py:21-37.  ROIAlign: the reference holds no vector and its CPU source does not compile
- * against this image's torch — PARITY UNPINNED for ROIAlign: the restatement below follows
- * Detection/support/src/cuda/ROIAlign_cuda.cu line by line and is itself checked against closed-form cases.
+ * Detection/test/nms/test_nms.py:21-37.  ROIAlign: the reference holds no vector, and the at::Tensor wrapper of its CPU
+ * source does not compile against this image's torch — but the kernel templates under it
+ * (Detection/support/src/cpu/ROIAlign_cpu.cpp:4-219) are plain C++: oracle/Makefile compiles them unedited and
+ * oracle/gen_golden.py stores their outputs (tests/golden/roi_align_fwd_*.npz).  PINNED: the forward below equals those
+ * vectors bit for bit in fp32 and f64 (tests/test_det_oracle.py); the backward (no CPU reference, ROIAlign.h:44) is the
+ * exact adjoint of that forward, checked in f64 and as a full transposed Jacobian.
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* Greedy NMS over boxes visited in `order` (descending score).  inclusive = 1: suppress at IoU >= thresh
@@ -208,60 +211,68 @@ int64_t oracle_nms(const float* boxes, const int64_t* order, int64_t n, float th
     return k;
 }
 
-typedef struct { int yl, xl, yh, xh; float w1, w2, w3, w4; int empty; } oracle_bilin;
-/* ROIAlign_cuda.cu:16-62 / :125-170 */
-static oracle_bilin oracle_bilin_prep(int height, int width, float y, float x) {
-    oracle_bilin b;
-    b.empty = (y < -1.0f || y > (float)height || x < -1.0f || x > (float)width);
-    b.yl = b.xl = b.yh = b.xh = -1; b.w1 = b.w2 = b.w3 = b.w4 = 0.f;
-    if (b.empty) return b;
-    if (y <= 0) y = 0;
-    if (x <= 0) x = 0;
-    b.yl = (int)y; b.xl = (int)x;
-    if (b.yl >= height - 1) { b.yh = b.yl = height - 1; y = (float)b.yl; } else b.yh = b.yl + 1;
-    if (b.xl >= width - 1) { b.xh = b.xl = width - 1; x = (float)b.xl; } else b.xh = b.xl + 1;
-    const float ly = y - b.yl, lx = x - b.xl, hy = 1.f - ly, hx = 1.f - lx;
-    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
-    return b;
+/* ROIAlign, restated once and instantiated for float (what the reference's GPU path and its CPU path compute in) and
+ * double (the adjoint identity <bwd(dy), x> == <dy, fwd(x)> is checked in f64, tests/test_det_oracle.py).
+ * PIN: the forward is held bit for bit to the reference's own CPU kernel (Detection/support/src/cpu/ROIAlign_cpu.cpp:4-219,
+ * compiled unedited by oracle/Makefile -> _ref/libref_roialign.so at fixture time: tests/golden/roi_align_fwd_*.npz); the
+ * backward has no CPU reference (Detection/support/src/ROIAlign.h:44) and is pinned as the exact adjoint of that linear
+ * forward (same samples, same weights, ROIAlign_cuda.cu:125-170,178-254). */
+#define ORACLE_ROI_ALIGN(SUF, T, CEIL, FMAX)                                                                                      \
+typedef struct { int yl, xl, yh, xh; T w1, w2, w3, w4; int empty; } oracle_bilin##SUF;                                            \
+/* ROIAlign_cuda.cu:16-62 / :125-170 == ROIAlign_cpu.cpp:45-103 */                                                                \
+static oracle_bilin##SUF oracle_bilin_prep##SUF(int height, int width, T y, T x) {                                                \
+    oracle_bilin##SUF b;                                                                                                          \
+    b.empty = (y < (T)-1.0 || y > (T)height || x < (T)-1.0 || x > (T)width);                                                      \
+    b.yl = b.xl = b.yh = b.xh = -1; b.w1 = b.w2 = b.w3 = b.w4 = (T)0;                                                             \
+    if (b.empty) return b;                                                                                                        \
+    if (y <= 0) y = 0;                                                                                                            \
+    if (x <= 0) x = 0;                                                                                                            \
+    b.yl = (int)y; b.xl = (int)x;                                                                                                 \
+    if (b.yl >= height - 1) { b.yh = b.yl = height - 1; y = (T)b.yl; } else b.yh = b.yl + 1;                                      \
+    if (b.xl >= width - 1) { b.xh = b.xl = width - 1; x = (T)b.xl; } else b.xh = b.xl + 1;                                        \
+    const T ly = y - b.yl, lx = x - b.xl, hy = (T)1 - ly, hx = (T)1 - lx;                                                         \
+    b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;                                                               \
+    return b;                                                                                                                     \
+}                                                                                                                                 \
+/* mode 0: forward (ROIAlign_cuda.cu:65-122 == ROIAlign_cpu.cpp:110-219): y[num_rois,C,PH,PW] from x[N,C,H,W] (NCHW);            \
+ * mode 1: backward (:178-254): x is the zero-initialised gradient map that dy = y scatters into, in index order. */              \
+void oracle_roi_align##SUF(T* x, const T* rois, T* y, int64_t num_rois, int64_t C, int64_t H, int64_t W, int PH, int PW,          \
+                           T scale, int sampling_ratio, int mode) {                                                               \
+    for (int64_t n = 0; n < num_rois; ++n) {                                                                                      \
+        const T* r = rois + n * 5;                                                                                                \
+        const int b = (int)r[0];                                                                                                  \
+        const T sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;                                       \
+        const T rw = FMAX(ew - sw, (T)1), rh = FMAX(eh - sh, (T)1);                                                               \
+        const T bh = rh / (T)PH, bw = rw / (T)PW;                                                                                 \
+        const int gh = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rh / (T)PH);                                               \
+        const int gw = sampling_ratio > 0 ? sampling_ratio : (int)CEIL(rw / (T)PW);                                               \
+        const T count = (T)(gh * gw);                                                                                             \
+        for (int64_t c = 0; c < C; ++c) {                                                                                         \
+            T* plane = x + ((int64_t)b * C + c) * H * W;                                                                          \
+            for (int ph = 0; ph < PH; ++ph)                                                                                       \
+                for (int pw = 0; pw < PW; ++pw) {                                                                                 \
+                    T* out = y + ((n * C + c) * PH + ph) * PW + pw;                                                               \
+                    T acc = (T)0;                                                                                                 \
+                    for (int iy = 0; iy < gh; ++iy) {                                                                             \
+                        const T yy = sh + ph * bh + (T)((float)iy + .5f) * bh / (T)gh;                                            \
+                        for (int ix = 0; ix < gw; ++ix) {                                                                         \
+                            const T xx = sw + pw * bw + (T)((float)ix + .5f) * bw / (T)gw;                                        \
+                            const oracle_bilin##SUF q = oracle_bilin_prep##SUF((int)H, (int)W, yy, xx);                           \
+                            if (q.empty) continue;                                                                                \
+                            if (mode == 0) {                                                                                      \
+                                acc += q.w1 * plane[q.yl * W + q.xl] + q.w2 * plane[q.yl * W + q.xh] +                            \
+                                       q.w3 * plane[q.yh * W + q.xl] + q.w4 * plane[q.yh * W + q.xh];                             \
+                            } else {                                                                                              \
+                                const T g = *out;                                                                                 \
+                                plane[q.yl * W + q.xl] += g * q.w1 / count; plane[q.yl * W + q.xh] += g * q.w2 / count;           \
+                                plane[q.yh * W + q.xl] += g * q.w3 / count; plane[q.yh * W + q.xh] += g * q.w4 / count;           \
+                            }                                                                                                     \
+                        }                                                                                                         \
+                    }                                                                                                             \
+                    if (mode == 0) *out = acc / count;                                                                            \
+                }                                                                                                                 \
+        }                                                                                                                         \
+    }                                                                                                                             \
 }
-
-/* mode 0: forward (ROIAlign_cuda.cu:65-122): y[num_rois,C,PH,PW] from x[N,C,H,W] (NCHW fp32);
- * mode 1: backward (:178-254): x is the zero-initialised gradient map that dy = y scatters into, in index order. */
-void oracle_roi_align(float* x, const float* rois, float* y, int64_t num_rois, int64_t C, int64_t H, int64_t W, int PH, int PW,
-                      float scale, int sampling_ratio, int mode) {
-    for (int64_t n = 0; n < num_rois; ++n) {
-        const float* r = rois + n * 5;
-        const int b = (int)r[0];
-        const float sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
-        const float rw = fmaxf(ew - sw, 1.f), rh = fmaxf(eh - sh, 1.f);
-        const float bh = rh / (float)PH, bw = rw / (float)PW;
-        const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
-        const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
-        const float count = (float)(gh * gw);
-        for (int64_t c = 0; c < C; ++c) {
-            float* plane = x + ((int64_t)b * C + c) * H * W;
-            for (int ph = 0; ph < PH; ++ph)
-                for (int pw = 0; pw < PW; ++pw) {
-                    float* out = y + ((n * C + c) * PH + ph) * PW + pw;
-                    float acc = 0.f;
-                    for (int iy = 0; iy < gh; ++iy) {
-                        const float yy = sh + ph * bh + ((float)iy + .5f) * bh / (float)gh;
-                        for (int ix = 0; ix < gw; ++ix) {
-                            const float xx = sw + pw * bw + ((float)ix + .5f) * bw / (float)gw;
-                            const oracle_bilin q = oracle_bilin_prep((int)H, (int)W, yy, xx);
-                            if (q.empty) continue;
-                            if (mode == 0) {
-                                acc += q.w1 * plane[q.yl * W + q.xl] + q.w2 * plane[q.yl * W + q.xh] + q.w3 * plane[q.yh * W + q.xl] +
-                                       q.w4 * plane[q.yh * W + q.xh];
-                            } else {
-                                const float g = *out;
-                                plane[q.yl * W + q.xl] += g * q.w1 / count; plane[q.yl * W + q.xh] += g * q.w2 / count;
-                                plane[q.yh * W + q.xl] += g * q.w3 / count; plane[q.yh * W + q.xh] += g * q.w4 / count;
-                            }
-                        }
-                    }
-                    if (mode == 0) *out = acc / count;
-                }
-        }
-    }
-}
+ORACLE_ROI_ALIGN(, float, ceilf, fmaxf)
+ORACLE_ROI_ALIGN(_f64, double, ceil, fmax)

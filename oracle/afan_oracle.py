@@ -626,12 +626,26 @@ def seg_train_step(model, optimizer, criterion, images, labels, *, steps=1, eps=
 
 
 # ------------------------------------------------------------- Detection (N2): step functions on a protocol-faithful toy detector
+def synth_field(shape, seed):
+    """A deterministic fp32 field in [-2, 2) from a closed form (splitmix64 of the flat index; 24 random bits per element, so
+    every value is exact in fp32): lets a fixture name a 17 MB ROIAlign input by (shape, seed) instead of storing it.  Integer
+    arithmetic only — independent of numpy's generator streams."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        z = (np.arange(n, dtype=np.uint64) + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (((z >> np.uint64(40)).astype(np.float32) / np.float32(1 << 24)) * np.float32(4.0) - np.float32(2.0)).reshape(shape)
+
+
 def roi_align_torch(inp, rois, output_size, spatial_scale, sampling_ratio):
     """Detection/support/src/cpu/ROIAlign_cpu.cpp:110-238 / cuda/ROIAlign_cuda.cu:10-122 (legacy, un-aligned ROIAlign) in
     differentiable torch ops: rois [K, 5] = (batch index, x1, y1, x2, y2) in image coordinates; roi extent clamped to
     >= 1; sampling_ratio > 0 samples per bin side (else ceil(roi size / bins)); a sample outside [-1, H] x [-1, W]
     contributes 0, coordinates are clamped to [0, size-1], bilinear weights from the clamped position; bin = mean of
-    its samples.  Pinned to oracle_roi_align (C) in tests/test_det_oracle.py."""
+    its samples.  Pinned to oracle_roi_align (C) in tests/test_det_oracle.py, which is itself pinned bit for bit to the
+    reference's own CPU kernel (tests/golden/roi_align_fwd_*.npz)."""
     ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
     n, c, h, w = inp.shape
     out = []

@@ -12,7 +12,13 @@ Only those arrays travel to the GPU box; no reference source does.  `main_pertur
 imported (top-level torchvision/matplotlib imports, main_perturb.py:15-23), so its loop body (lines
 173-201, 288-293) is driven here line by line around the reference's PGD and ResNet.
 
-Usage:  python oracle/gen_golden.py            (rewrites tests/golden/)
+The one compiled piece of the reference on this path, Detection's CPU ROIAlign forward (Detection/support/src/cpu/ROIAlign_cpu.cpp:
+4-219, plain templates), is built unedited from where it lies by oracle/Makefile (-> oracle/_ref/libref_roialign.so) and produces
+tests/golden/roi_align_fwd_*.npz and the `align`-mode Faster-RCNN fixture.
+
+Usage:  python oracle/gen_golden.py            (rewrites tests/golden/ except the two Faster-RCNN files)
+        python oracle/gen_golden.py frcnn      (det_frcnn_r101.npz, det_frcnn_r101_align.npz; own process: Detection/ on sys.path)
+        python oracle/gen_golden.py roialign   (only roi_align_fwd_*.npz)
 """
 import importlib.util
 import os
@@ -258,13 +264,93 @@ def gen_detection(orc):
 
 
 
+def _reference_roialign():
+    """ctypes handle on the REFERENCE's CPU ROIAlign forward: Detection/support/src/cpu/ROIAlign_cpu.cpp:4-219 compiled unedited
+    (oracle/Makefile, oracle/ref_roialign_driver.cpp) — the at::Tensor wrapper :221-257 is not used (it does not compile against
+    this torch); its only content besides dispatch is output_size = R*PH*PW*C, repeated in the driver."""
+    import ctypes
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_roialign.so"))
+    _p, _l, _i = ctypes.c_void_p, ctypes.c_long, ctypes.c_int
+    lib.ref_roi_align_forward_f32.argtypes = [_p, _p, _p, _l, _l, _l, _l, _i, _i, ctypes.c_float, _i]
+    lib.ref_roi_align_forward_f64.argtypes = [_p, _p, _p, _l, _l, _l, _l, _i, _i, ctypes.c_double, _i]
+    lib.ref_roi_align_forward_f32.restype = lib.ref_roi_align_forward_f64.restype = None
+
+    def fwd(x, rois, ph, pw, scale, sampling_ratio):
+        dt = x.dtype
+        assert dt in (np.float32, np.float64) and rois.dtype == dt
+        x, rois = np.ascontiguousarray(x), np.ascontiguousarray(rois)
+        n, c, h, w = x.shape
+        out = np.zeros((len(rois), c, ph, pw), dt)
+        f = lib.ref_roi_align_forward_f32 if dt == np.float32 else lib.ref_roi_align_forward_f64
+        f(x.ctypes.data, rois.ctypes.data, out.ctypes.data, len(rois), c, h, w, ph, pw, scale, sampling_ratio)
+        return out
+    return fwd
+
+
+def _roi_boxes(rng, n, n_img, img_h, img_w):
+    """[n, 5] (batch index, x1, y1, x2, y2) in image coordinates: RPN-like boxes clipped to the image, plus boxes that cross each
+    border, sub-pixel (malformed: extent forced to 1 cell, ROIAlign_cpu.cpp:143-144), whole-image and fully-outside ones."""
+    b = np.zeros((n, 5), np.float32)
+    b[:, 0] = rng.integers(0, n_img, n)
+    cx, cy = rng.uniform(0, img_w, n), rng.uniform(0, img_h, n)
+    w = np.exp(rng.uniform(np.log(12), np.log(img_w), n))
+    h = np.exp(rng.uniform(np.log(12), np.log(img_h), n))
+    x1, y1, x2, y2 = cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2
+    clip = rng.random(n) < 0.7                                        # proposals are clipped to the image (rpn/..._network.py:128)
+    x1, x2 = np.where(clip, np.clip(x1, 0, img_w), x1), np.where(clip, np.clip(x2, 0, img_w), x2)
+    y1, y2 = np.where(clip, np.clip(y1, 0, img_h), y1), np.where(clip, np.clip(y2, 0, img_h), y2)
+    b[:, 1], b[:, 2], b[:, 3], b[:, 4] = x1, y1, x2, y2
+    special = [[0, 0, 0, img_w, img_h], [n_img - 1, -40, -24, img_w + 56, img_h + 40], [0, 100.3, 50.7, 100.9, 51.2],
+               [n_img - 1, 300, 200, 290, 180], [0, img_w + 40, img_h + 40, img_w + 200, img_h + 120], [0, -300, -300, -100, -120],
+               [n_img - 1, img_w - 8, img_h - 8, img_w + 8, img_h + 8], [0, -16, 33, 15.99, 400], [0, 0, 0, 16, 16]]
+    k = min(len(special), n)
+    b[:k] = np.array(special[:k], np.float32)
+    return b
+
+
+def gen_roi_align(orc):
+    """tests/golden/roi_align_fwd_{small,cfg5_r128,cfg5_r300}.npz: outputs of the reference's own CPU forward
+    (`_reference_roialign`).  small: complete fp32 and f64 outputs, sampling_ratio 0 and 2.  cfg5: the shapes of BASELINE
+    configs[4] (C=1024 ResNet-101 conv4 map of a 600 x 904 image = 38 x 57, 14 x 14 bins, scale 1/16, sampling_ratio 0:
+    roi/pooler.py:21-22,35-38); the 17.7 MB input is oracle.synth_field(shape, seed), the 100-235 MB output is stored for
+    four channels plus f64 sums of the fp32 output per ROI (over C, PH, PW) and per channel (over R, PH, PW)."""
+    fwd = _reference_roialign()
+    rng = np.random.default_rng(20261004)
+    # small, complete
+    N, C, H, W, PH, PW = 2, 4, 20, 30, 14, 14
+    x = orc.synth_field((N, C, H, W), 77)
+    rois = _roi_boxes(rng, 24, N, H * 16, W * 16)
+    rec = {"x_shape": np.array([N, C, H, W]), "x_seed": np.array(77), "rois": rois, "pooled": np.array([PH, PW]), "scale": np.array(1 / 16)}
+    for sr in (0, 2):
+        rec[f"y_sr{sr}"] = fwd(x, rois, PH, PW, 1 / 16, sr)
+        rec[f"y64_sr{sr}"] = fwd(x.astype(np.float64), rois.astype(np.float64), PH, PW, 1 / 16, sr)
+    rec["y_7x5_sr0"] = fwd(x, rois, 7, 5, 1 / 16, 0)                   # non-square bins
+    np.savez_compressed(os.path.join(OUT, "roi_align_fwd_small.npz"), **rec)
+    print("roi_align_fwd_small", rec["y_sr0"].shape, float(np.abs(rec["y_sr0"]).max()))
+    # cfg5 shapes
+    N, C, H, W = 2, 1024, 38, 57
+    chans = np.array([0, 1, 511, 1023])
+    for name, R, seed in (("cfg5_r128", 128, 101), ("cfg5_r300", 300, 102)):
+        x = orc.synth_field((N, C, H, W), seed)
+        rois = _roi_boxes(rng, R, N, 600, 904)
+        y = fwd(x, rois, PH, PW, 1 / 16, 0)
+        np.savez_compressed(os.path.join(OUT, f"roi_align_fwd_{name}.npz"), x_shape=np.array([N, C, H, W]), x_seed=np.array(seed),
+                            rois=rois, pooled=np.array([PH, PW]), scale=np.array(1 / 16), channels=chans, y_sub=y[:, chans],
+                            roi_sums=y.astype(np.float64).sum(axis=(1, 2, 3)), chan_sums=y.astype(np.float64).sum(axis=(0, 2, 3)))
+        print("roi_align_fwd_" + name, y.shape, "rms", float(np.sqrt((y.astype(np.float64) ** 2).mean())))
+
+
 def _import_reference_detection_model():
     """`Detection/model.py` with the reference's own backbone / rpn / roi / bbox / extension modules on sys.path, plus the
     stand-ins this image needs: an empty `torchvision` (backbone/resnet101.py:3 imports it, never uses it with
     the `_ori` backbone), and a `support` package — the reference's compiled extension is absent (.MISSING_LARGE_BLOBS) and its
     CPU sources do not compile against this torch — whose `nms` is the plain-C oracle NMS (oracle/afan_oracle.c, pinned to the
     reference's own 9770 -> 1934 vector, tests/test_det_oracle.py; the `>` rule of the reference's GPU path, nms.cu:49) and
-    whose `ROIAlign` raises (the goldens run `--pooler_mode pooling`, roi/pooler.py:24-33: the reference's CPU-runnable mode)."""
+    whose `ROIAlign` runs the reference's own CPU forward kernel with the adjoint backward (`_RefROIAlign` below): both pooler
+    modes of roi/pooler.py:24-42 run — `pooling` (det_frcnn_r101.npz) and the reference's default `align`
+    (config/config.py:14; det_frcnn_r101_align.npz)."""
     import ctypes
     import subprocess
     det = os.path.join(REF, "Detection")
@@ -290,12 +376,41 @@ def _import_reference_detection_model():
                            scratch.ctypes.data_as(_p))
         return torch.from_numpy(np.sort(keep[:k]))
 
-    class ROIAlign(nn.Module):
-        def __init__(self, *a, **k):
-            super().__init__()
+    ref_fwd = _reference_roialign()
+    lib.oracle_roi_align.argtypes = [_p, _p, _p, _l, _l, _l, _l, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    lib.oracle_roi_align.restype = None
 
-        def forward(self, *a, **k):
-            raise RuntimeError("the reference's ROIAlign extension is not available: goldens use --pooler_mode pooling")
+    class _RefROIAlign(torch.autograd.Function):
+        """support/layer/roi_align.py:11-48 with `_C.roi_align_forward` = the reference's own CPU kernel (ROIAlign_cpu.cpp:4-219,
+        compiled unedited: _reference_roialign) and `_C.roi_align_backward` — which the reference only has for CUDA
+        (ROIAlign.h:44) — = the C oracle's backward, held to be the exact adjoint of that forward in f64
+        (tests/test_det_oracle.py::test_roi_align_backward_is_the_adjoint_of_the_pinned_forward)."""
+        @staticmethod
+        def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
+            ctx.save_for_backward(roi)
+            ctx.geom = (tuple(input.shape), tuple(output_size), float(spatial_scale), int(sampling_ratio))
+            y = ref_fwd(input.detach().float().contiguous().numpy(), roi.detach().float().contiguous().numpy(), output_size[0],
+                        output_size[1], float(spatial_scale), int(sampling_ratio))
+            return torch.from_numpy(y)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            (roi,) = ctx.saved_tensors
+            shape, (ph, pw), scale, sr = ctx.geom
+            dy = np.ascontiguousarray(grad_output.detach().float().numpy())
+            r = np.ascontiguousarray(roi.detach().float().numpy())
+            dx = np.zeros(shape, np.float32)
+            lib.oracle_roi_align(dx.ctypes.data_as(_p), r.ctypes.data_as(_p), dy.ctypes.data_as(_p), len(r), shape[1], shape[2], shape[3],
+                                 ph, pw, scale, sr, 1)
+            return torch.from_numpy(dx), None, None, None, None
+
+    class ROIAlign(nn.Module):
+        def __init__(self, output_size, spatial_scale, sampling_ratio):
+            super().__init__()
+            self.output_size, self.spatial_scale, self.sampling_ratio = output_size, spatial_scale, sampling_ratio
+
+        def forward(self, input, rois):
+            return _RefROIAlign.apply(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
 
     sup, lay, m_nms, m_ra = (types.ModuleType(n) for n in ("support", "support.layer", "support.layer.nms", "support.layer.roi_align"))
     m_nms.nms, m_ra.ROIAlign = nms, ROIAlign
@@ -308,10 +423,10 @@ def _import_reference_detection_model():
     return ref_model, RefBackbone, RefPooler
 
 
-def gen_detection_model():
-    """The reference's OWN Faster-RCNN (Detection/model.py:18-185 on backbone/resnet101_ori.py, rpn/, roi/pooler.py 'pooling'
-    mode) at a small image size, fixed seed, no pretrained weights (pretrained=False: kaiming initialisation, BatchNorm
-    running statistics at 0 / 1): det_frcnn_r101.npz.  What it pins: seeded construction (checksum of every state_dict
+def gen_detection_model(mode="pooling"):
+    """The reference's OWN Faster-RCNN (Detection/model.py:18-185 on backbone/resnet101_ori.py, rpn/, roi/pooler.py in `mode`)
+    at a small image size, fixed seed, no pretrained weights (pretrained=False: kaiming initialisation, BatchNorm
+    running statistics at 0 / 1): det_frcnn_r101.npz ('pooling') / det_frcnn_r101_align.npz ('align', the reference's default).  What it pins: seeded construction (checksum of every state_dict
     tensor, in the reference's key order incl. the `_bn_modules.*` / `detection.hidden.*` aliases), the three backbone feature
     maps (flag head, out_idx 1-3), the RPN's logits and its proposals, the four per-image losses of one training forward
     (host `randperm` draws from a fixed generator state) and the gradients that forward leaves; the one-step feature PGD of
@@ -322,7 +437,7 @@ def gen_detection_model():
     cfg = dict(anchor_ratios=[(1, 2), (1, 1), (2, 1)], anchor_sizes=[64], rpn_pre_nms_top_n=200, rpn_post_nms_top_n=64,
                anchor_smooth_l1_loss_beta=1.0, proposal_smooth_l1_loss_beta=1.0)
     torch.manual_seed(7)
-    model = ref_model.Model(RefBackbone(pretrained=False), 21, pooler_mode=RefPooler.Mode.POOLING, **cfg)
+    model = ref_model.Model(RefBackbone(pretrained=False), 21, pooler_mode=RefPooler.Mode(mode), **cfg)
     model.train()
     k_init, c_init = _checksums(model)                    # seeded construction, before the damping below
     # Without pretrained weights the frozen BatchNorms are identities (running statistics 0 / 1) and 33 residual blocks
@@ -338,7 +453,7 @@ def gen_detection_model():
     bboxes = torch.tensor([[[12., 20., 70., 90.], [60., 30., 150., 110.]], [[5., 8., 60., 64.], [80., 50., 140., 120.]]])
     labels = torch.tensor([[3, 7], [12, 1]])
     rec = {"images": _np(images), "bboxes": _np(bboxes), "labels": _np(labels), "keys": np.array(k0), "ck0": c0, "ck_init": c_init,
-           "damp": np.array(damp),
+           "damp": np.array(damp), "pooler_mode": np.array(mode),
            "anchor_sizes": np.array(cfg["anchor_sizes"]), "nms_top_n": np.array([cfg["rpn_pre_nms_top_n"], cfg["rpn_post_nms_top_n"]])}
     # (1) head passes
     for i in (1, 2, 3):
@@ -408,8 +523,9 @@ def gen_detection_model():
     assert k1 == k0
     rec.update(step_loss=_np(loss), step_losses=np.array([float(v) for v in L], dtype=np.float32), ck1=c1,
                adv_image_sub=_np(adv_image.detach()[:, :, ::4, ::4]))
-    np.savez_compressed(os.path.join(OUT, "det_frcnn_r101.npz"), **rec)
-    print("det_frcnn_r101: forward losses", rec["fwd_losses"].tolist(), "iteration loss", float(loss), [round(float(v), 4) for v in L],
+    fname = "det_frcnn_r101" + ("" if mode == "pooling" else "_" + mode)
+    np.savez_compressed(os.path.join(OUT, fname + ".npz"), **rec)
+    print(fname + ": forward losses", rec["fwd_losses"].tolist(), "iteration loss", float(loss), [round(float(v), 4) for v in L],
           "proposals", tuple(seen["proposals"].shape), "params with grad", len(named), "keys", len(k0))
 
 
@@ -733,6 +849,7 @@ def main():
         sys.modules.pop(clash, None)
 
     gen_detection(orc)
+    gen_roi_align(orc)
 
     # ---- Segmentation operators: mix_feature, get_sample_points (reference functions, direct) ----------
     torch.manual_seed(7)
@@ -778,10 +895,16 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True)
         from oracle import afan_oracle as _orc
         gen_detection(_orc)
+    elif sys.argv[1:] == ["roialign"]:    # only the ROIAlign vectors (the reference's own CPU kernel, compiled by oracle/Makefile)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        os.makedirs(OUT, exist_ok=True)
+        from oracle import afan_oracle as _orc
+        gen_roi_align(_orc)
     elif sys.argv[1:] == ["frcnn"]:       # only the Faster-RCNN fixture (own process: Detection/ goes on sys.path)
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         _shims()
         os.makedirs(OUT, exist_ok=True)
-        gen_detection_model()
+        gen_detection_model("pooling")
+        gen_detection_model("align")
     else:
         main()

@@ -50,10 +50,52 @@ def _c_oracle():
     lib.oracle_nms.restype = _l
     lib.oracle_roi_align.argtypes = [_p, _p, _p, _l, _l, _l, _l, _i, _i, _f, _i, _i]
     lib.oracle_roi_align.restype = None
+    lib.oracle_roi_align_f64.argtypes = [_p, _p, _p, _l, _l, _l, _l, _i, _i, ctypes.c_double, _i, _i]
+    lib.oracle_roi_align_f64.restype = None
     for n in ("oracle_pgd_step", "oracle_axpy_noise", "oracle_perturb_norms", "oracle_mix_feature",
               "oracle_lerp_points", "oracle_bn_train_forward", "oracle_bn_backward", "oracle_sgd_step"):
         getattr(lib, n).restype = None
     return lib
+
+
+def oracle_roi(lib, x, rois, ph, pw, scale, sr, mode=0, dy=None):
+    """oracle_roi_align / oracle_roi_align_f64 by dtype of x.  mode 0: forward -> [R, C, ph, pw]; mode 1: backward of dy -> x.shape."""
+    dt = np.float64 if x.dtype == np.float64 else np.float32
+    f = lib.oracle_roi_align_f64 if dt == np.float64 else lib.oracle_roi_align
+    n_roi, (N, Cc, H, W) = len(rois), x.shape
+    rois = np.ascontiguousarray(rois, dt)
+    if mode == 0:
+        y = np.zeros((n_roi, Cc, ph, pw), dt)
+        xx = np.ascontiguousarray(x, dt)
+        f(ptr(xx), ptr(rois), ptr(y), n_roi, Cc, H, W, ph, pw, scale, sr, 0)
+        return y
+    dx = np.zeros(x.shape, dt)
+    dyc = np.ascontiguousarray(dy, dt)
+    f(ptr(dx), ptr(rois), ptr(dyc), n_roi, Cc, H, W, ph, pw, scale, sr, 1)
+    return dx
+
+
+def reference_roialign():
+    """The REFERENCE's CPU ROIAlign forward (oracle/_ref/libref_roialign.so: Detection/support/src/cpu/ROIAlign_cpu.cpp:4-219 built
+    unedited by oracle/Makefile in the build container; the prebuilt file travels to the GPU box) or None when it is not there —
+    the committed vectors tests/golden/roi_align_fwd_*.npz are the pin either way."""
+    path = os.path.join(ROOT, "oracle", "_ref", "libref_roialign.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lg = ctypes.c_long
+    lib.ref_roi_align_forward_f32.argtypes = [_p, _p, _p, lg, lg, lg, lg, _i, _i, ctypes.c_float, _i]
+    lib.ref_roi_align_forward_f64.argtypes = [_p, _p, _p, lg, lg, lg, lg, _i, _i, ctypes.c_double, _i]
+    lib.ref_roi_align_forward_f32.restype = lib.ref_roi_align_forward_f64.restype = None
+
+    def fwd(x, rois, ph, pw, scale, sr):
+        dt = np.float64 if x.dtype == np.float64 else np.float32
+        x, rois = np.ascontiguousarray(x, dt), np.ascontiguousarray(rois, dt)
+        out = np.zeros((len(rois), x.shape[1], ph, pw), dt)
+        f = lib.ref_roi_align_forward_f64 if dt == np.float64 else lib.ref_roi_align_forward_f32
+        f(ptr(x), ptr(rois), ptr(out), len(rois), x.shape[1], x.shape[2], x.shape[3], ph, pw, scale, sr)
+        return out
+    return fwd
 
 
 def ptr(a):

@@ -1,12 +1,14 @@
 """Detection operators on the GPU through the C-ABI: NMS against the reference's own golden (9770 -> 1934 boxes,
-Detection/test/nms/test_nms.py) and the C oracle; ROIAlign forward / backward against the C oracle, both layouts."""
+Detection/test/nms/test_nms.py) and the C oracle; ROIAlign forward against the outputs of the reference's own CPU kernel
+(tests/golden/roi_align_fwd_*.npz, incl. BASELINE configs[4] shapes) and the C oracle, backward against the C oracle (the pinned
+adjoint) and by the adjoint identity at full size, both layouts."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden, ptr
+from conftest import GOLDEN, golden, oracle_roi, ptr, reference_roialign
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +93,73 @@ def test_roi_align_vs_c_oracle(pkg, gpu, c_oracle, nhwc, sr, C):
     # the reference's pooler on top (roi/pooler.py:35-44)
     p = pkg.det_ops.Pooler.apply(xt.detach(), torch.from_numpy(rois[:, 1:]).to(gpu), torch.from_numpy(rois[:, 0]).long().to(gpu), "align")
     assert tuple(p.shape) == (len(rois), C, 7, 7)
+
+
+def _hip_roi(pkg, gpu, x, rois, ph, pw, scale, sr, nhwc, grad=False):
+    xt = torch.from_numpy(x).to(gpu)
+    xt = xt.contiguous(memory_format=torch.channels_last) if nhwc else xt
+    if grad:
+        xt.requires_grad_(True)
+    return xt, pkg.det_ops.roi_align(xt, torch.from_numpy(rois).to(gpu), (ph, pw), scale, sr)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_roi_align_fwd_matches_reference_kernel_small(pkg, gpu, orc, nhwc):
+    """The reference's own CPU kernel's outputs (fp32): adaptive and fixed sampling grids, 14 x 14 and 7 x 5 bins, boxes over
+    every border / malformed / outside.  <= 1e-5 absolute (the values are O(1); measured: bit-identical or 1 ulp)."""
+    g = golden("roi_align_fwd_small")
+    x = orc.synth_field(tuple(g["x_shape"]), int(g["x_seed"]))
+    scale = float(g["scale"])
+    for key, ph, pw, sr in (("y_sr0", 14, 14, 0), ("y_sr2", 14, 14, 2), ("y_7x5_sr0", 7, 5, 0)):
+        _, y = _hip_roi(pkg, gpu, x, g["rois"], ph, pw, scale, sr, nhwc)
+        np.testing.assert_allclose(y.cpu().numpy(), g[key], rtol=0, atol=1e-5, err_msg=key)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("case", ["cfg5_r128", "cfg5_r300"])
+def test_roi_align_fwd_matches_reference_kernel_cfg5(pkg, gpu, orc, case, nhwc):
+    """BASELINE configs[4] shapes (2 x 1024 x 38 x 57, 128 / 300 ROIs, 14 x 14, scale 1/16, sampling_ratio 0): the stored channels
+    of the reference kernel's output <= 1e-5, its per-ROI and per-channel f64 checksums over the complete output to 1e-6
+    relative of the absolute mass; then the backward at this size by the adjoint identity against that pinned forward."""
+    g = golden("roi_align_fwd_" + case)
+    x = orc.synth_field(tuple(g["x_shape"]), int(g["x_seed"]))
+    ph, pw = (int(v) for v in g["pooled"])
+    xt, y = _hip_roi(pkg, gpu, x, g["rois"], ph, pw, float(g["scale"]), 0, nhwc, grad=True)
+    yd = y.detach()
+    np.testing.assert_allclose(yd[:, torch.from_numpy(g["channels"]).to(gpu)].cpu().numpy(), g["y_sub"], rtol=0, atol=1e-5)
+    mass = float(yd.double().abs().sum())
+    np.testing.assert_allclose(yd.double().sum(dim=(1, 2, 3)).cpu().numpy(), g["roi_sums"], rtol=0, atol=1e-6 * mass / len(g["rois"]))
+    np.testing.assert_allclose(yd.double().sum(dim=(0, 2, 3)).cpu().numpy(), g["chan_sums"], rtol=0, atol=1e-6 * mass / x.shape[1])
+    gen = torch.Generator().manual_seed(9)
+    dy = torch.randn(y.shape, generator=gen).to(gpu)
+    dy = dy.contiguous(memory_format=torch.channels_last) if nhwc else dy
+    y.backward(dy)
+    lhs = float((xt.grad.double() * xt.detach().double()).sum())
+    rhs = float((dy.double() * yd.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * float((dy.double() * yd.double()).abs().sum()), (lhs, rhs)
+    # bwd(dy) is independent of x: a second field, its forward through the C oracle's ... library forward again
+    x2 = torch.randn(xt.shape, generator=gen).to(gpu)
+    x2 = x2.contiguous(memory_format=torch.channels_last) if nhwc else x2
+    y2 = pkg.det_ops.roi_align(x2, torch.from_numpy(g["rois"]).to(gpu), (ph, pw), float(g["scale"]), 0)
+    assert abs(float((xt.grad.double() * x2.double()).sum()) - float((dy.double() * y2.double()).sum())) \
+        <= 1e-5 * float((dy.double() * y2.double()).abs().sum())
+
+
+def test_roi_align_vs_reference_binary_random(pkg, gpu):
+    """When the reference's compiled CPU kernel travelled with the snapshot (oracle/_ref/libref_roialign.so): fresh random boxes
+    and fields, straight against it."""
+    ref = reference_roialign()
+    if ref is None:
+        pytest.skip("oracle/_ref/libref_roialign.so not present")
+    rng = np.random.default_rng(21)
+    for (N, C, H, W, R, ph, pw, sr) in ((2, 40, 38, 57, 64, 14, 14, 0), (1, 256, 24, 32, 100, 14, 14, 0), (3, 8, 9, 7, 30, 7, 7, 3)):
+        x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        xy = np.sort(rng.uniform(-32, 16 * max(H, W) + 32, (R, 2, 2)), axis=1)
+        rois = np.concatenate([rng.integers(0, N, (R, 1)), xy[:, 0, :], xy[:, 1, :]], axis=1).astype(np.float32)
+        want = ref(x, rois, ph, pw, 1 / 16, sr)
+        for nhwc in (False, True):
+            _, y = _hip_roi(pkg, gpu, x, rois, ph, pw, 1 / 16, sr, nhwc)
+            np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("C", [64, 256])         # (256: 32 channel vectors — the geometry-once-per-bin kernels)

@@ -1,15 +1,16 @@
 """Faster-RCNN / frozen-BatchNorm ResNet-101 on the library's kernels (cv_a-fan_amd/det_model.py) against the reference's OWN
-`Detection/model.py` (+ backbone/resnet101_ori.py, rpn/, roi/pooler.py in 'pooling' mode, bbox.py), run by
-oracle/gen_golden.py `frcnn` at 2 x 3 x 128 x 160 with `support.layer.nms` supplied by the plain-C oracle NMS (pinned to the
-reference's own nms vector): tests/golden/det_frcnn_r101.npz.
+`Detection/model.py` (+ backbone/resnet101_ori.py, rpn/, roi/pooler.py, bbox.py), run by oracle/gen_golden.py `frcnn` at
+2 x 3 x 128 x 160 in BOTH pooler modes — 'pooling' (tests/golden/det_frcnn_r101.npz) and the reference's default 'align'
+(config/config.py:14; det_frcnn_r101_align.npz) — with `support.layer.nms` supplied by the plain-C oracle NMS (pinned to the
+reference's own nms vector) and `support.layer.roi_align` by the reference's own CPU forward kernel (ROIAlign_cpu.cpp:4-219
+compiled unedited) with the adjoint backward (pinned: tests/test_det_oracle.py).
 
 Held tightly: seeded construction (tests/test_host_logic.py, CPU), the three backbone feature maps, the RPN logits, the
 proposals, the four per-image losses of a training forward with the reference's host `randperm` draws, the gradients of
 that forward, the signs of the one-step feature PGD.  Held loosely, and said so: the full iteration of
 train_aug_sat_muti_advt.py:70-172 — its adversarial image is five sign() steps on 61 440 pixels; a flipped pixel moves every
 anchor's logit by ~1e-3, which reorders proposals of nearly equal score, and `randperm` then samples by POSITION: two correct
-fp32 implementations leave that iteration a per cent apart.  ROIAlign ('align' mode, the product path) has no reference
-vector (parity unpinned): it is exercised for finiteness and protocol only."""
+fp32 implementations leave that iteration a per cent apart."""
 import numpy as np
 import pytest
 import torch
@@ -37,10 +38,17 @@ def _rel(a, b):
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
 
 
+def _golden_for(mode):
+    g = golden("det_frcnn_r101" + ("" if mode == "pooling" else "_" + mode))
+    assert str(g["pooler_mode"]) == mode
+    return g
+
+
+@pytest.mark.parametrize("mode", ["pooling", "align"])
 @pytest.mark.parametrize("nhwc", [False, True])
-def test_faster_rcnn_fp32_matches_reference_model(pkg, gpu, nhwc):
-    g = golden("det_frcnn_r101")
-    m = _build(pkg, g, gpu, torch.float32, nhwc, "pooling")
+def test_faster_rcnn_fp32_matches_reference_model(pkg, gpu, nhwc, mode):
+    g = _golden_for(mode)
+    m = _build(pkg, g, gpu, torch.float32, nhwc, mode)
     images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
     before = dict(pkg.ops.CALLS)
     # (1) head passes: model.py:42-50 -> resnet101_ori.py:203-237
@@ -89,11 +97,12 @@ def test_faster_rcnn_fp32_matches_reference_model(pkg, gpu, nhwc):
     assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_general"] > before["conv_general"]
 
 
-def test_faster_rcnn_iteration_on_reference_golden(pkg, gpu):
+@pytest.mark.parametrize("mode", ["pooling", "align"])
+def test_faster_rcnn_iteration_on_reference_golden(pkg, gpu, mode):
     """One iteration of train_aug_sat_muti_advt.py:70-172 (det_attack_algo.det_train_step) on the real model: the eight losses
     within 2 % of the reference's (see the module docstring for why not 1e-4), the weights after the SGD step by checksum."""
-    g = golden("det_frcnn_r101")
-    m = _build(pkg, g, gpu, torch.float32, True, "pooling")
+    g = _golden_for(mode)
+    m = _build(pkg, g, gpu, torch.float32, True, mode)
     images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
     arena = pkg.arena.ParamArena(m, skip=())
     opt = pkg.arena.ArenaSGD(arena, lr=0.001, momentum=0.9, weight_decay=0.0005)
