@@ -120,6 +120,7 @@ SIGNATURES = {
     "afan_profile_enable": (_i, [_i]),
     "afan_profile_collect": (_i, [C.c_char_p, C.POINTER(_l), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), _i]),
+    "afan_profile_event_overhead": (_i, [_i, C.POINTER(_f), _p]),
 }
 
 _lib = None

@@ -73,4 +73,30 @@ int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, d
     return (int)names.size();
 }
 
+// Elapsed time of an EMPTY (event, event) bracket on `stream`, averaged over n pairs: what every instrumented launch's
+// duration carries on top of the kernel itself (timestamp write + command-processor gap).
+int afan_profile_event_overhead(int n, float* us_out, afan_stream_t stream) {
+    if (!us_out) return AFAN_ENULL;
+    if (n <= 0 || n > 4096) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return AFAN_ESHAPE;
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventRecord(ev[2 * i], st);
+        (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    double tot = 0;
+    for (int i = 0; i < n && e == hipSuccess; ++i) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        tot += ms;
+    }
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    if (e != hipSuccess) return (int)e;
+    *us_out = (float)(tot / n * 1e3);
+    return AFAN_OK;
+}
+
 }  // extern "C"

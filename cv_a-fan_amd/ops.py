@@ -1432,6 +1432,14 @@ def profile_enable(on=True):
     check(_lib.load().afan_profile_enable(int(bool(on))), "afan_profile_enable")
 
 
+def profile_event_overhead(n=256):
+    """Microseconds an empty (event, event) bracket reads on the current stream: the per-launch bias of profile_collect()'s durations."""
+    out = C.c_float(0.0)
+    check(_lib.load().afan_profile_event_overhead(int(n), C.byref(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "afan_profile_event_overhead")
+    return float(out.value)
+
+
 def profile_collect(max_kernels=96):
     """{kernel: {"launches", "ms", "bytes"}} for the launches recorded since profile_enable(True)."""
     lib = _lib.load()

@@ -599,6 +599,10 @@ int afan_normalize_nchw(const float* x, void* y, int out_dtype, int out_layout, 
 int afan_profile_enable(int on);
 int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, double* total_bytes,
                          double* total_flops, int max_kernels);
+/* The bias of one (event, launch, event) bracket on `stream`: the elapsed time of n back-to-back event pairs with NOTHING between
+ * them, averaged, in microseconds -> *us_out (host float).  bench.py subtracts it per launch from the instrumented durations
+ * (they otherwise read ~5-8 % longer than rocprofv3's kernel durations on 10-20 us kernels).  Synchronises the stream. */
+int afan_profile_event_overhead(int n, float* us_out, afan_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+import os
+
+from conftest import ROOT, golden
 
 
 def test_state_dict_keys_match_reference(pkg):
@@ -144,3 +146,44 @@ def test_seg_trainer_tail_range_is_the_arena_suffix_behind_the_se_point(pkg):
         share = (bounds[hi] - bounds[lo]) / arena.numel
         assert frac[0] < share < frac[1], (se, share)
     assert pkg.seg_trainer.SegTrainer._tail_range(types.SimpleNamespace(kw={"pertub_idx_se": "aspp"}, arena=arena)) is None
+
+
+def test_bench_starts_its_own_ranks_as_child_processes(monkeypatch):
+    """`python bench.py --gpus N` with no launcher: N ranks through `python -m torch.distributed.run` as a CHILD (subprocess.call —
+    never an exec of a process that may have touched the GPU), rendezvous on 127.0.0.1, dmabuf IPC kept in the environment, the
+    user's flags passed through; decided before torch is imported."""
+    import importlib
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 7)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7 and len(calls) == 1                         # the child's exit code is ours
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src
+
+
+def test_bench_device_identity_is_16_bytes():
+    import importlib
+    import sys
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+
+    class P:
+        name, pci_bus_id, pci_device_id, pci_domain_id = "MI355X", 5, 0, 0
+    fake = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda d: P()))
+    a = bench.device_uuid(fake, types.SimpleNamespace(index=0))
+    P.pci_bus_id = 6
+    b = bench.device_uuid(fake, types.SimpleNamespace(index=1))
+    assert len(a) == len(b) == 16 and a != b
