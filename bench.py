@@ -296,21 +296,9 @@ def main():
             if isinstance(b_, pkg.det_model.Bottleneck):
                 b_.bn3.weight.data.mul_(0.2)
         model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
-        arena = pkg.arena.ParamArena(model, skip=())
-        opt = pkg.arena.ArenaSGD(arena, lr=0.001, momentum=0.9, weight_decay=0.0005)
-        if world > 1:       # data parallel like the reference's nn.DataParallel (train_aug_sat_muti_advt.py:36): replicas from rank 0,
-            for t in (arena.param, arena.momentum_buf):     # one SUM all-reduce of the flat gradient arena before the SGD launch
-                dist.broadcast(t, src=0)
-            for b_ in model.buffers():
-                dist.broadcast(b_, src=0)
-            arena.refresh_shadow()
-            opt.grad_scale = 1.0 / world
-            _plain_step = opt.step
-
-            def _step_with_exchange(closure=None):
-                dist.all_reduce(arena.grad, op=dist.ReduceOp.SUM)
-                return _plain_step()
-            opt.step = _step_with_exchange
+        # data parallel like the reference's nn.DataParallel (train_aug_sat_muti_advt.py:36): det_trainer.DetTrainer — replicas from
+        # rank 0, the fp32 gradient arena summed tail first under the backbone's backward, 1/world in the SGD launch
+        trainer = pkg.det_trainer.DetTrainer(model, lr=0.001, momentum=0.9, weight_decay=0.0005, loss_settings=1)
         side, ncls = (600, 904), 21
         xs, ys = [], []
         for _ in range(nbuf):
@@ -321,15 +309,8 @@ def main():
             ys.append((torch.cat([x0, y0, x0 + wh[..., :1], y0 + wh[..., 1:]], dim=-1).to(dev),
                        torch.randint(1, 21, (args.batch, 6), generator=g).to(dev)))
 
-        class _DetTrainer:
-            _graph = None
-
-            def step(self, images, target):
-                return pkg.det_attack_algo.det_train_step(model, opt, images, target[0], target[1], loss_settings=1)
-        trainer = _DetTrainer()
-
         def one(i):
-            return trainer.step(xs[i % nbuf], ys[i % nbuf])
+            return trainer.step(xs[i % nbuf], ys[i % nbuf][0], ys[i % nbuf][1])
 
         one_eager = one
     elif seg:

@@ -90,7 +90,10 @@ class ParamArena:
                     d1, dsc = by_mod.get(id(c1)), by_mod.get(id(csc))
                     if (d1 is not None and dsc is not None and c1.kernel_size == (3, 3) and csc.kernel_size == (1, 1)
                             and c1.stride == (2, 2) and csc.stride == (2, 2) and c1.dilation == (1, 1)
-                            and c1.out_channels == csc.out_channels and c1.in_channels == csc.in_channels):
+                            and c1.out_channels == csc.out_channels and c1.in_channels == csc.in_channels
+                            # afan_conv_dgrad_sc_nhwc_bf16 has no small-channel form (it declines ci < 40 or co < 40, like
+                            # the plain dgrad's tiled kernels): narrower option-B blocks keep the two-launch backward
+                            and c1.in_channels >= 40 and c1.out_channels >= 40):
                         pairs.append((c1, d1, dsc, t_off))
                         t_off += c1.in_channels * 10 * c1.out_channels
             if desc:

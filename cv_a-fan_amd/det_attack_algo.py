@@ -7,6 +7,7 @@ behaviour of the reference's `Detection/attack_algo.py`, and the loop body of `D
     adv_input(x, y, model, steps, eps, gamma, randinit, clip)                                             :153-178
     get_sample_points / mix_feature / tensor_clamp / linfball_proj                      (shared with attack_algo.py)
     det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, loss_settings)   train_aug_sat_muti_advt.py:70-172
+    det_train_phases(...)                         the same iteration as a generator with the backward cut at the backbone's output
 
 `model` is anything that follows the reference's protocol (`Detection/model.py:40-185`):
 `model.train().forward({'x', 'adv', 'out_idx', 'flag'}, bboxes, labels)` -> four per-image loss tensors, a feature map
@@ -90,10 +91,25 @@ def adv_input(x=None, y=None, model=None, steps=3, eps=None, gamma=None, randini
 
 
 def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, loss_settings=1):
-    """One iteration of Detection/train_aug_sat_muti_advt.py:70-172: adversarial image (5 steps, randinit, clip), the three
-    backbone feature maps and the ROI dict, three one-step feature PGDs (`multi-layer`), five SAT sample points of the
-    deepest one with points 1 and 2 re-normalised by mix_feature (one fused launch), the one-step ROI feature PGD +
-    mix_feature, eight forwards, and the weighted loss of :141-153 (loss_settings 1-4)."""
+    """One iteration of Detection/train_aug_sat_muti_advt.py:70-172 (see det_train_phases)."""
+    out = {}
+    for _ in det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, out, loss_settings=loss_settings):
+        pass
+    return out
+
+
+def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, out, *, loss_settings=1, cut=False, defer_step=False):
+    """One iteration of Detection/train_aug_sat_muti_advt.py:70-172 as a generator: adversarial image (5 steps, randinit,
+    clip), the three backbone feature maps and the ROI dict, three one-step feature PGDs (`multi-layer`), five SAT sample
+    points of the deepest one with points 1 and 2 re-normalised by mix_feature (one fused launch), the one-step ROI feature
+    PGD + mix_feature, eight forwards, and the weighted loss of :141-153 (loss_settings 1-4).
+
+    cut=True (data-parallel callers, det_trainer.DetTrainer; needs a model with `cut_features`): the eight training forwards'
+    graphs are cut at the backbone's output (the conv4 feature map every forward hands to the RPN and the ROI head), the joint
+    backward runs in two parts — everything behind the cuts (RPN, ROIAlign, layer4, the two heads: 8 passes), then the
+    backbone (layer3 / layer2: the passes that reach it) — and the generator yields "tail" in between: the gradients of
+    layer4 / rpn / detection heads (the arena's suffix) are final there and their all-reduce can fly under the backbone's
+    backward.  Same arithmetic: what the tails leave at the cuts enters the backbone graph as its output gradient."""
     y = {"bb": bboxes_batch, "lb": labels_batch}
     fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
     adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
@@ -115,7 +131,14 @@ def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, lo
              {"x": image_batch, "adv": adv2, "out_idx": 2, "flag": "tail"}] + \
             [{"x": image_batch, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
             [{"adv": adv_rr, "out_idx": "roi_tail", "flag": "clean"}]
-    L = [compute_loss(*fwd(d)) for d in dicts]
+    cuts = []
+    if cut:
+        if not hasattr(model, "cut_features"):
+            raise ops.AfanLibraryError("det_train_phases(cut=True) needs a model with cut_features() (det_model.Model)")
+        with model.cut_features(cuts):
+            L = [compute_loss(*fwd(d)) for d in dicts]
+    else:
+        L = [compute_loss(*fwd(d)) for d in dicts]
     loss_clean_adv = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
     if loss_settings == 1:
         loss = loss_clean_adv
@@ -126,6 +149,12 @@ def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, lo
         assert False
     optimizer.zero_grad()
     loss.backward()
-    optimizer.step()
-    return {"loss": loss.detach(), "losses": torch.stack(L).detach(), "adv_image": adv_image.detach(), "adv1": adv1.detach(),
-            "adv2": adv2.detach(), "adv3": adv3.detach(), "adv_sd": adv_sd.detach(), "fm3": fm[2]}
+    if cut:
+        yield "tail"            # behind the cuts everything is final
+        live = [(f, c.grad) for f, c in cuts if c.grad is not None]
+        if live:
+            torch.autograd.backward([f for f, _ in live], [g for _, g in live])         # the backbone, every pass at once
+    if not defer_step:
+        optimizer.step()
+    out.update({"loss": loss.detach(), "losses": torch.stack(L).detach(), "adv_image": adv_image.detach(), "adv1": adv1.detach(),
+                "adv2": adv2.detach(), "adv3": adv3.detach(), "adv_sd": adv_sd.detach(), "fm3": fm[2], "cuts": len(cuts)})

@@ -312,6 +312,31 @@ class ResNet101(nn.Module):
         x = self.bn1.fused(self.conv1(x), None, True)
         return self.maxpool(x)
 
+    _cuts = None
+
+    def cut_features(self, cuts):
+        """Context: every training forward inside it detaches the backbone's output `features` (where it carries a graph)
+        into a fresh leaf and appends (features, leaf) to `cuts`; the RPN and the ROI head consume the leaf.  A backward from
+        the losses then stops at the leaves; `torch.autograd.backward([f...], [leaf.grad...])` finishes it
+        (det_attack_algo.det_train_phases: the two-part backward of the data-parallel iteration)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._cuts = self._cuts, cuts
+            try:
+                yield cuts
+            finally:
+                self._cuts = old
+        return ctx()
+
+    def _cut(self, features):
+        if self._cuts is None or features.grad_fn is None:
+            return features
+        leaf = features.detach().requires_grad_(True)
+        self._cuts.append((features, leaf))
+        return leaf
+
     def head_features(self, x, idxs=(1, 2, 3)):
         """The feature maps after layers `idxs` from ONE pass, detached: what the three `flag: 'head'` calls of
         train_aug_sat_muti_advt.py:78-80 return (same images, frozen BatchNorm, no dropout: each is a prefix of the next)."""
@@ -586,7 +611,7 @@ class Model(nn.Module):
             iw, ih = d["image_width"][0].item(), d["image_height"][0].item()
             obj, tr, ao, at = self.rpn.forward(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
         else:
-            features = self.features(input_dict)
+            features = self._cut(self.features(input_dict))
             anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
             if idx == "rpn_head":
                 return {"features": features, "image_height": torch.tensor([[ih]], device=features.device),

@@ -86,6 +86,46 @@ def test_resnet18_blocks_match_bf16_oracle_blocks(pkg, orc, gpu):
     assert pkg.ops.CALLS["vendor_conv"] == 0
 
 
+def test_narrow_option_b_blocks_take_the_two_launch_backward(pkg, orc, gpu):
+    """a narrow option-B ResNet (16 -> 32 -> 64 projection blocks) in bf16 channels-last.  The fused
+    3x3/s2 + 1x1/s2 input gradient (afan_conv_dgrad_sc_nhwc_bf16) has no small-channel form, so the arena must not hand such
+    blocks its [Ci][10][Co] operand — the backward of every block runs (two launches) and matches the bf16-emulating oracle."""
+    torch.manual_seed(3)
+    ref = orc.SlicedResNet([16, 32, 64], [1, 1, 1], "B")
+    ref.train()
+    m = pkg.resnet_s.ResNet(pkg.resnet_s.BasicBlock, [1, 1, 1], widths=(16, 32, 64), option="B")
+    m.load_state_dict(ref.state_dict())
+    m.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+    arena = pkg.arena.ParamArena(m)
+    narrow = [b for b in m.modules() if getattr(b, "_sc_kind", None) == "conv"]
+    assert len(narrow) == 2 and all(getattr(b._chain()[0][0], "_arena_wt10", None) is None for b in narrow)
+    wide = pkg.resnet_s.ARCHS["resnet18"][0]().set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu)
+    pkg.arena.ParamArena(wide)
+    assert all(getattr(b._chain()[0][0], "_arena_wt10", None) is not None for b in wide.modules() if getattr(b, "_sc_kind", None) == "conv")
+    torch.manual_seed(5)
+    x = torch.rand(32, 3, 32, 32)
+    g = torch.Generator().manual_seed(11)
+    n = len(ref.sequential_model)
+    for a in range(5, n - 3):                      # the two projection blocks
+        with orc.emulate_bf16():
+            with torch.no_grad():
+                t_in = ref(x, end_point=a, start_point=0)
+            t_in = t_in.detach().clone().requires_grad_(True)
+            for p in ref.parameters():
+                p.grad = None
+            y_ref = ref(t_in, end_point=a + 1, start_point=a)
+            gy = _bf(torch.randn(y_ref.shape, generator=g) * 1e-2)
+            y_ref.backward(gy)
+        arena.zero_grad()
+        pkg.ops.acc_reset(gpu)
+        xin = _to_dev(t_in.detach(), gpu).requires_grad_(True)
+        y = m(xin, end_point=a + 1, start_point=a)
+        y.backward(gy.to(gpu).to(y.dtype).contiguous(memory_format=torch.channels_last))
+        grads_ref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+        grads = {k: p.grad for k, p in m.named_parameters() if k in grads_ref}
+        _check(f"narrow option-B block {a}", y, y_ref, xin.grad, t_in.grad, grads, grads_ref)
+
+
 # ------------------------------------------------------------------------------------------ DeepLabv3+ R101, configs[3]
 def _emu_cbr(orc, conv, bn, t, relu=True):
     o = bn(orc._conv(conv, t))

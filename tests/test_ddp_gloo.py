@@ -1,5 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the flat-arena gradient all-reduce (GradAllReducer), the
-1/world scaling contract and the per-rank sharding of a global batch.  No GPU kernels run here: the model is plain
+"""N>1 path on CPU: world_size-2 / -4 / -8 gloo processes exercise the flat-arena gradient all-reduce (GradAllReducer), the
+1/world scaling contract, the per-rank sharding of a global batch and the explicit range schedules of the three trainers
+(AfanTrainer's backward stages, SegTrainer's / DetTrainer's arena suffix behind the cut) incl. ranges whose sizes the world does
+not divide and empty ranges.  No GPU kernels run here: the model is plain
 torch modules (the reducer is generic over any nn.Module's parameters); the fused SGD step itself is covered on the GPU."""
 import os
 import socket
@@ -22,9 +24,10 @@ def _free_port():
 
 
 def _make_model():
+    """(odd sizes on purpose: 3*7*9 = 189, 7, 7, 7*7*9 = 441, 7, 7*36*5 = 1260, 5 elements — none divides by 8)"""
     torch.manual_seed(7)
-    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
-                               torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 5))
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 7, 3, padding=1), torch.nn.BatchNorm2d(7), torch.nn.ReLU(),
+                               torch.nn.Conv2d(7, 7, 3, padding=1), torch.nn.Flatten(), torch.nn.Linear(7 * 6 * 6, 5))
 
 
 def _worker(rank, world, port, ret):
@@ -41,8 +44,8 @@ def _worker(rank, world, port, ret):
         assert reducer.world == world and len(reducer.chunks) >= 2
         # the global batch, and this rank's shard of it (main_perturb.DeviceLoader slices the same way)
         g = torch.Generator().manual_seed(11)
-        xs, ys = torch.randn(8, 3, 6, 6, generator=g), torch.randint(0, 5, (8,), generator=g)
-        per = 8 // world
+        xs, ys = torch.randn(16, 3, 6, 6, generator=g), torch.randint(0, 5, (16,), generator=g)
+        per = 16 // world
         x, y = xs[rank * per:(rank + 1) * per], ys[rank * per:(rank + 1) * per]
         crit = torch.nn.CrossEntropyLoss()
         for it in range(2):                      # two iterations: hooks must re-arm
@@ -70,14 +73,21 @@ def _worker(rank, world, port, ret):
         # [(npar - 2, npar)] alone is SegTrainer's schedule (seg_trainer.py: the arena SUFFIX behind the SE point is announced at
         # seg_train_phases' "tail" yield, the head's range is left to finish()); the three-range form is AfanTrainer's stages
         npar = len(arena.params)
-        for covered in ([(npar - 2, npar), (2, npar - 2), (0, 2)], [(npar - 2, npar)], []):
+        # (tensor sizes are ragged — 189, 7, 441, 1260, 5 elements — but every tensor starts on a 64-float boundary of the arena, so
+        # any announced range is a multiple of 256 bytes whatever the world size: no rank ever sees a remainder)
+        assert all(o % 64 == 0 for o in arena.offsets + [arena.numel]) and any(p.numel() % world for p in arena.params)
+        # ... DetTrainer's: the suffix behind the backbone's output (det_trainer.tail_range; the parent test checks it on the real
+        # Faster-RCNN names) with the backbone left to finish(); an EMPTY range (a stage without parameters) is a no-op
+        for covered in ([(npar - 2, npar), (2, npar - 2), (0, 2)], [(npar - 2, npar)], [(npar - 3, npar)], [(3, 3), (npar - 1, npar)],
+                        [(0, npar)], []):
             arena.zero_grad()
             reducer.begin(explicit=True)
             crit(model(x), y).backward()
             assert not reducer._pending                                   # hooks are off in explicit mode
             for lo, hi in covered:
+                before = len(reducer._pending)
                 reducer.launch_params(lo, hi)
-                assert len(reducer._pending) >= 1                         # started before finish()
+                assert len(reducer._pending) == before + (1 if hi > lo else 0)   # started before finish(); empty range: nothing
             reducer.finish()
             torch.testing.assert_close(arena.grad, ref, rtol=1e-5, atol=1e-6)
         # a chunk whose parameters got no gradient this step is still reduced by finish()
@@ -93,19 +103,34 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_grad_allreduce_world2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_grad_allreduce_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
+    os.environ.setdefault("OMP_NUM_THREADS", "1")          # 8 ranks on 8 host CPUs
     procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(150)
+        p.join(240)
         if p.is_alive():
             p.kill()
-    assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+    assert dict(ret) == {r: "ok" for r in range(world)}, dict(ret)
+
+
+def test_trainers_tail_ranges_are_arena_suffixes(pkg):
+    """The ranges the Segmentation / Detection trainers announce at their "tail" yield, on the real models' parameter names:
+    contiguous suffixes of the arena (what GradAllReducer.launch_params(lo, hi) needs), the rest left to finish()."""
+    m = pkg.det_model.fasterrcnn_resnet101(21)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    lo, hi = pkg.det_trainer.tail_range(names)
+    assert hi == len(names) and names[lo] == "features.layer4.0.conv1.weight" and names[lo - 1].startswith("features.layer3.")
+    assert all(n.startswith(("features.layer2.", "features.layer3.")) for n in names[:lo])
+    assert pkg.det_trainer.tail_range(names[::-1]) is None and pkg.det_trainer.tail_range(names[:lo]) is None
+    sz = [p.numel() for n, p in m.named_parameters() if p.requires_grad]
+    assert 0.4 < sum(sz[lo:]) / sum(sz) < 0.5                          # 22.0 of 49.2 M parameters fly under the backbone's backward
 
 
 def test_trainer_sets_grad_scale_from_world(pkg):

@@ -119,6 +119,32 @@ def test_faster_rcnn_iteration_on_reference_golden(pkg, gpu, mode):
     assert pkg.ops.CALLS["vendor_conv"] == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_det_trainer_cut_backward_equals_one_backward(pkg, gpu, dtype):
+    """det_trainer.DetTrainer's two-part backward (graphs cut at the backbone's output, "tail" announced in between: what the
+    data-parallel exchange hangs on) against the one-backward iteration: the same forwards (identical losses), the same
+    gradients up to summation order (ROIAlign's atomics), the same weights after the step; three cuts (the passes that reach
+    the backbone: adversarial image, out_idx 1, out_idx 2)."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    res = {}
+    for seg in (False, True):
+        m = _build(pkg, g, gpu, dtype, True, "align")
+        tr = pkg.det_trainer.DetTrainer(m, segmented=seg)
+        assert tr.tail_range() == (83, 105)
+        torch.manual_seed(102)
+        r = tr.step(images, bboxes, labels)
+        torch.cuda.synchronize()
+        res[seg] = (r, tr.arena.grad.clone(), tr.arena.param.clone())
+    assert res[False][0]["cuts"] == 0 and res[True][0]["cuts"] == 3
+    assert torch.equal(res[False][0]["losses"], res[True][0]["losses"]) and torch.equal(res[False][0]["adv_image"], res[True][0]["adv_image"])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2          # (bf16: the gradient at the cut is stored once in bf16 instead of being summed in bf16 by autograd)
+    assert _rel(res[True][1].cpu().numpy(), res[False][1].cpu().numpy()) <= tol
+    lo = tr.arena.offsets[83]
+    assert float(res[True][1][lo:].abs().sum()) > 0 and float(res[True][1][:lo].abs().sum()) > 0
+    assert _rel(res[True][2].cpu().numpy(), res[False][2].cpu().numpy()) <= 1e-6
+
+
 def test_faster_rcnn_bf16_align_mode_runs_on_library_kernels(pkg, gpu):
     """The product configuration: bf16 channels-last backbone on the tuned MFMA kernels, ROIAlign + NMS + pooling kernels of
     the library, fp32 RPN / detection heads: a full iteration at a VOC-like image size; finite, protocol intact."""
