@@ -112,6 +112,8 @@ SIGNATURES = {
     "afan_nms_top": (_i, [_p, _p, _l, _f, _i, _p, _p, _p, _l, _p]),
     "afan_roi_align_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_roi_align_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
+    "afan_roi_align_bwd_workspace_bytes": (_l, [_l, _l, _l]),
+    "afan_roi_align_bwd_ws": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p, _p]),
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),

@@ -342,7 +342,232 @@ __global__ __launch_bounds__(256) void roi_align_fwd_bins_kernel(const T* __rest
     }
 }
 
+// Channels-last backward WITHOUT atomics: gather by map tile.  The scatter above issues one fp32 atomic per (sample corner,
+// channel) — 8.6 per pooled element on the bench's proposals, 220 M per launch: 664 us at the chip's ~325 G atomics/s.  Two facts
+// remove them.  (1) ROIAlign is separable: a sample's weight is wy(y) * wx(x), its validity (ROIAlign_cuda.cu:134-139) is
+// valid_y && valid_x and the clamps (:141-163) act per axis, so the gradient one ROI leaves on the map is
+//     dx[Y, X, c] = sum_ph sum_pw  Wy[Y][ph] * Wx[X][pw] * dy[ph, pw, c] / count,
+//     Wy[Y][ph] = sum over the bin's iy samples of (hy if y_low == Y) + (ly if y_high == Y)            (Wx alike)
+// — the same samples, weights and 1/count as :178-254, summed in a fixed order.  (2) A workgroup that owns a 4 x 4 cell x
+// 16-vector tile of the map can visit the ROIs overlapping it, accumulate in registers and store once: deterministic, no
+// memset, no atomics.  One wave = one map row of the tile (lane = column x channel vector); the waves run their ROI loops
+// independently (no barrier after the culling): per ROI, lanes 0..PH-1 build the row's Wy, lanes (col, pw) the four columns'
+// Wx, ballots give the non-zero bin ranges and shuffles hand the weights out.  A row meets at most 3 bins of an ROI whose bins
+// are at least one cell tall (samples within (Y-1, Y+1)): that case is 9 unconditional, independent 16-byte loads; ROIs smaller
+// than 14 cells (which meet few tiles) take the bin-by-bin loop.
+constexpr int RG_TH = 4, RG_TW = 4, RG_NV = 16, RG_MAXP = 16, RG_THREADS = 256, RG_LIST = 1024;
+
+struct AxisW { int lo, hi; float l, h; bool valid; };
+// one axis of bilinear_interpolate_gradient (ROIAlign_cuda.cu:125-170)
+__device__ __forceinline__ AxisW axis_prep(int size, float t) {
+    AxisW a;
+    a.valid = !(t < -1.0f || t > (float)size);
+    if (t <= 0) t = 0;
+    a.lo = (int)t;
+    if (a.lo >= size - 1) { a.hi = a.lo = size - 1; t = (float)a.lo; } else a.hi = a.lo + 1;
+    a.l = t - (float)a.lo;
+    a.h = 1.f - a.l;
+    return a;
+}
+
+// The per-(ROI, row, bin) and per-(ROI, column, bin) weights of the gather below, once per launch instead of once per wave
+// (each (tile row, channel slab) wave would rebuild them: 8 slabs x 4 rows of redundant divisions — measured 4.3 us per ROI and
+// wave on 800-pixel boxes, VALU-bound).  One thread per (roi, row) / (roi, column): wy[16] / wx[16] (zero where the bin does not
+// reach the line) and the non-zero bin range packed lo | hi << 8 (hi < lo: none).
+__global__ __launch_bounds__(256) void roi_bwd_tables_kernel(const float* __restrict__ rois, int R, float scale, int H, int Wd, int PH, int PW,
+                                                             int sampling_ratio, float* __restrict__ Wy, float* __restrict__ Wx,
+                                                             int* __restrict__ Ry, int* __restrict__ Rx) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)R * (H + Wd)) return;
+    const int r = (int)(t / (H + Wd)), pos = (int)(t - (int64_t)r * (H + Wd));
+    const RoiGeom g = roi_geom(rois + (int64_t)r * 5, scale, PH, PW, sampling_ratio);
+    const bool isy = pos < H;
+    const int line = isy ? pos : pos - H, size = isy ? H : Wd, P = isy ? PH : PW, grid = isy ? g.grid_h : g.grid_w;
+    const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+    float* out = isy ? Wy + ((int64_t)r * H + line) * RG_MAXP : Wx + ((int64_t)r * Wd + line) * RG_MAXP;
+    int lo = 1, hi = 0;
+    for (int p = 0; p < RG_MAXP; ++p) {
+        float w = 0.f;
+        if (p < P) {
+            for (int i = 0; i < grid; ++i) {
+                const AxisW a = axis_prep(size, start + p * bin + ((float)i + .5f) * bin / (float)grid);
+                if (a.valid) w += (a.lo == line ? a.h : 0.f) + (a.hi == line ? a.l : 0.f);
+            }
+            if (isy) w = w / g.count;
+        }
+        out[p] = w;
+        if (w != 0.f) { if (hi < lo) lo = p; hi = p; }
+    }
+    (isy ? Ry + (int64_t)r * H : Rx + (int64_t)r * Wd)[line] = lo | (hi << 8);
+}
+
+template <typename T, bool TAB>
+__global__ __launch_bounds__(RG_THREADS) void roi_align_bwd_gather_kernel(const T* __restrict__ dy, const float* __restrict__ rois,
+                                                                          float* __restrict__ dx, int R, float scale, int C, int H, int Wd,
+                                                                          int PH, int PW, int sampling_ratio, int tiles_x, int tiles_y,
+                                                                          int slabs, const float* __restrict__ Wy, const float* __restrict__ Wx,
+                                                                          const int* __restrict__ Ry, const int* __restrict__ Rx) {
+    constexpr int VEC = Elt<T>::VEC, CS = RG_NV * VEC;
+    static_assert(RG_TH * 64 == RG_THREADS && RG_TW * RG_NV == 64 && RG_TW * RG_MAXP <= 64, "one wave per tile row");
+    __shared__ int list[RG_LIST];
+    __shared__ int wcnt[RG_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int b = blockIdx.x;
+    const int slab = b % slabs; b /= slabs;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
+    const int y0 = ty * RG_TH, x0 = tx * RG_TW, c0 = slab * CS;
+    const int Y = y0 + wave, col = lane >> 4, X = x0 + col, ch = c0 + (lane & 15) * VEC;
+    const bool lane_ok = X < Wd && ch < C;
+    const int ch_safe = ch < C ? ch : c0;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+
+    for (int rbase = 0; rbase < R; rbase += RG_LIST) {
+        // ---- which ROIs of this chunk touch the tile (conservative footprint: every sample lies in [start, start + extent]),
+        //      compacted in ascending ROI index: a fixed summation order
+        __syncthreads();
+        int total = 0;
+        for (int k = 0; k < RG_LIST / RG_THREADS && rbase + k * RG_THREADS < R; ++k) {
+            const int r = rbase + k * RG_THREADS + tid;
+            bool hit = false;
+            if (r < R) {
+                const float* roi = rois + (int64_t)r * 5;
+                if ((int)roi[0] == n) {
+                    const float sw = roi[1] * scale, sh = roi[2] * scale;
+                    const float rw = fmaxf(roi[3] * scale - sw, 1.f), rh = fmaxf(roi[4] * scale - sh, 1.f);
+                    const int ylo = sh < 0.f ? 0 : (int)floorf(sh), yhi = min(H - 1, (int)floorf(sh + rh) + 1);
+                    const int xlo = sw < 0.f ? 0 : (int)floorf(sw), xhi = min(Wd - 1, (int)floorf(sw + rw) + 1);
+                    hit = ylo <= y0 + RG_TH - 1 && yhi >= y0 && xlo <= x0 + RG_TW - 1 && xhi >= x0;
+                }
+            }
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = total;
+#pragma unroll
+            for (int w = 0; w < RG_THREADS / 64; ++w) { if (w < wave) off += wcnt[w]; total += wcnt[w]; }
+            if (hit) list[off + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+            __syncthreads();
+        }
+        if (Y >= H) continue;                              // (wave-uniform; the wave still takes part in the next chunk's barriers)
+
+        for (int i = 0; i < total; ++i) {
+            const int rr = list[i];
+            float wy = 0.f, wx = 0.f;                      // (!TAB: lane-held weights, handed out by shuffles)
+            const float* wyp = nullptr;                    // (TAB: the precomputed tables)
+            const float* wxp = nullptr;
+            int plo, phi, qlo, qhi;
+            unsigned long long mxa = 0;
+            if (TAB) {
+                const int ry = Ry[(int64_t)rr * H + Y];    // wave-uniform
+                plo = ry & 0xff; phi = (ry >> 8) & 0xff;
+                if (phi < plo) continue;                   // the ROI does not reach this row
+                const int Xs = X < Wd ? X : Wd - 1;
+                const int rx = X < Wd ? Rx[(int64_t)rr * Wd + Xs] : 1;
+                qlo = rx & 0xff; qhi = ((rx >> 8) & 0xff) - (X < Wd ? 0 : 1);
+                if (__ballot(qhi >= qlo) == 0) continue;
+                if (qhi < qlo) { qlo = 0; qhi = -1; }
+                wyp = Wy + ((int64_t)rr * H + Y) * RG_MAXP;
+                wxp = Wx + ((int64_t)rr * Wd + Xs) * RG_MAXP;
+            } else {
+                const RoiGeom g = roi_geom(rois + (int64_t)rr * 5, scale, PH, PW, sampling_ratio);
+                // the row's weights per bin: lane = ph
+                if (lane < PH) {
+                    for (int iy = 0; iy < g.grid_h; ++iy) {
+                        const AxisW a = axis_prep(H, g.start_h + lane * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h);
+                        if (a.valid) wy += (a.lo == Y ? a.h : 0.f) + (a.hi == Y ? a.l : 0.f);
+                    }
+                    wy = wy / g.count;
+                }
+                const unsigned long long my = __ballot(wy != 0.f);
+                if (my == 0) continue;                     // the ROI does not reach this row
+                // the four columns' weights per bin: lane = column * 16 + pw
+                {
+                    const int bc = lane >> 4, pw = lane & 15, Xc = x0 + bc;
+                    if (pw < PW && Xc < Wd)
+                        for (int ix = 0; ix < g.grid_w; ++ix) {
+                            const AxisW a = axis_prep(Wd, g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w);
+                            if (a.valid) wx += (a.lo == Xc ? a.h : 0.f) + (a.hi == Xc ? a.l : 0.f);
+                        }
+                }
+                mxa = __ballot(wx != 0.f);
+                if (mxa == 0) continue;
+                plo = __ffsll((long long)my) - 1; phi = 63 - __clzll((long long)my);
+                const unsigned mx = (unsigned)((mxa >> (col * 16)) & 0xffffULL);          // this lane's column
+                qlo = mx ? __ffs((int)mx) - 1 : 0; qhi = mx ? 31 - __clz((int)mx) : -1;
+            }
+            const T* base = dy + (int64_t)rr * PH * PW * C + ch_safe;
+            const bool small = (phi - plo) < 3 && __ballot(qhi - qlo >= 3) == 0;
+            if (small) {
+                float wyi[3], wxj[3];
+                int phs[3], pws[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    phs[a] = min(plo + a, phi);
+                    const float w = TAB ? wyp[phs[a]] : __shfl(wy, phs[a], 64);
+                    wyi[a] = (plo + a <= phi) ? w : 0.f;
+                    pws[a] = qhi < 0 ? 0 : min(qlo + a, qhi);
+                    const float u = TAB ? wxp[pws[a]] : __shfl(wx, col * 16 + pws[a], 64);
+                    wxj[a] = (qlo + a <= qhi) ? u : 0.f;
+                }
+                float d[9][VEC];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Elt<T>::ldv(base + (int64_t)(phs[a] * PW + pws[c]) * C, d[a * 3 + c]);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float w = wyi[a] * wxj[c];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, d[a * 3 + c][q], acc[q]);
+                    }
+            } else {
+                int qmin, qmax;
+                if (TAB) {                                 // the union of the four columns' ranges (wave-uniform loop bounds)
+                    qmin = qhi < qlo ? RG_MAXP : qlo; qmax = qhi;
+#pragma unroll
+                    for (int o = 16; o < 64; o <<= 1) { qmin = min(qmin, __shfl_xor(qmin, o, 64)); qmax = max(qmax, __shfl_xor(qmax, o, 64)); }
+                } else {
+                    qmin = __ffsll((long long)(mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffff) - 1;
+                    qmax = 63 - __clzll((long long)((mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffffULL));
+                }
+                for (int ph = plo; ph <= phi; ++ph) {
+                    const float wyv = TAB ? wyp[ph] : __shfl(wy, ph, 64);
+                    for (int pw = qmin; pw <= qmax; ++pw) {
+                        const float w = wyv * (TAB ? wxp[pw] : __shfl(wx, col * 16 + pw, 64));
+                        if (w != 0.f) {
+                            float d[VEC];
+                            Elt<T>::ldv(base + (int64_t)(ph * PW + pw) * C, d);
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, d[q], acc[q]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (Y < H && lane_ok) {
+        float* o = dx + (((int64_t)n * H + Y) * Wd + X) * C + ch;
+#pragma unroll
+        for (int q = 0; q < VEC; q += 4) {
+            const f32x4 t = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
+            *reinterpret_cast<f32x4*>(o + q) = t;
+        }
+    }
+}
+
 }  // namespace
+
+// AFAN_ROI_BWD_GATHER=0: the scatter-with-atomics backward everywhere (A/B measurements, tools/probe/roi_bwd_time.py)
+static bool afan_roi_bwd_gather_enabled() {
+    static const int on = [] { const char* e = getenv("AFAN_ROI_BWD_GATHER"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
 
 extern "C" {
 
@@ -435,19 +660,61 @@ int afan_roi_align_fwd(const void* x, const float* rois, void* y, int dtype, int
 }
 
 // dx[N, C, H, W] fp32 (zeroed here, in `layout`) += scatter of dy[num_rois, C, PH, PW] (`dtype`, same layout convention)
+// bytes of scratch afan_roi_align_bwd_ws takes for the per-(roi, row) / (roi, column) weight tables (0: shape outside the gather form)
+int64_t afan_roi_align_bwd_workspace_bytes(int64_t num_rois, int64_t h, int64_t w) {
+    if (num_rois <= 0 || h <= 0 || w <= 0) return 0;
+    return num_rois * (h + w) * (RG_MAXP * 4 + 4);
+}
+
 int afan_roi_align_bwd(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
                        int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                        afan_stream_t stream) {
+    return afan_roi_align_bwd_ws(dy, rois, dx, dtype, layout, num_rois, n, c, h, w, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                 nullptr, stream);
+}
+
+// The same with caller-owned scratch (afan_roi_align_bwd_workspace_bytes, 16-byte aligned; NULL: the waves build the weights
+// themselves): the channels-last gather reads its bilinear weights from tables one small launch fills.
+int afan_roi_align_bwd_ws(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
+                          int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
+                          afan_stream_t stream) {
     int e = roi_check(dtype, layout, num_rois, c, h, w, pooled_h, pooled_w);
     if (e) return e;
     if (n <= 0) return AFAN_ESHAPE;
     if (!dx) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
+    const int64_t total = num_rois * c * pooled_h * pooled_w;
+    const int vec = dtype == AFAN_F32 ? 4 : 8;
+    // channels-last with 16-byte channel vectors: the atomic-free gather by map tile (deterministic; writes every cell itself)
+    if (layout == AFAN_NHWC && num_rois > 0 && c % vec == 0 && pooled_h <= RG_MAXP && pooled_w <= RG_MAXP && aligned(dx, 16) &&
+        dy && aligned(dy, 16) && num_rois < (1 << 24) && afan_roi_bwd_gather_enabled()) {
+        if (!rois) return AFAN_ENULL;
+        const int cs = RG_NV * vec, tiles_x = (int)((w + RG_TW - 1) / RG_TW), tiles_y = (int)((h + RG_TH - 1) / RG_TH), slabs = (int)((c + cs - 1) / cs);
+        const int64_t blocks = n * tiles_y * tiles_x * slabs;
+        if (blocks < (1LL << 31)) {
+            AFAN_PROF("roi_align_bwd_kernel", (double)total * (dtype == AFAN_F32 ? 4 : 2) + 4.0 * n * c * h * w, st);
+            float *Wy = nullptr, *Wx = nullptr;
+            int *Ry = nullptr, *Rx = nullptr;
+            if (workspace) {
+                if (!aligned(workspace, 16)) return AFAN_EALIGN;
+                Wy = (float*)workspace; Wx = Wy + num_rois * h * RG_MAXP;
+                Ry = (int*)(Wx + num_rois * w * RG_MAXP); Rx = Ry + num_rois * h;
+                const int64_t tt = num_rois * (h + w);
+                roi_bwd_tables_kernel<<<(unsigned)((tt + 255) / 256), 256, 0, st>>>(rois, (int)num_rois, spatial_scale, (int)h, (int)w, pooled_h, pooled_w, sampling_ratio, Wy, Wx, Ry, Rx);
+                AFAN_LAUNCH_CHECK();
+            }
+#define RGK_(T, TAB) roi_align_bwd_gather_kernel<T, TAB><<<(unsigned)blocks, RG_THREADS, 0, st>>>((const T*)dy, rois, dx, (int)num_rois, spatial_scale, (int)c, (int)h, (int)w, pooled_h, pooled_w, sampling_ratio, tiles_x, tiles_y, slabs, Wy, Wx, Ry, Rx)
+            if (dtype == AFAN_F32) { if (workspace) RGK_(float, true); else RGK_(float, false); }
+            else { if (workspace) RGK_(uint16_t, true); else RGK_(uint16_t, false); }
+#undef RGK_
+            AFAN_LAUNCH_CHECK();
+            return AFAN_OK;
+        }
+    }
     hipError_t he = hipMemsetAsync(dx, 0, (size_t)(n * c * h * w) * 4, st);
     if (he != hipSuccess) return (int)he;
     if (num_rois == 0) return AFAN_OK;
     if (!dy || !rois) return AFAN_ENULL;
-    const int64_t total = num_rois * c * pooled_h * pooled_w;
     const int grid = grid_for(total, 256, 8192);
     AFAN_PROF("roi_align_bwd_kernel", (double)total * ((dtype == AFAN_F32 ? 4 : 2) + 16.0) + 4.0 * n * c * h * w, st);
 #define RB_(T, L) roi_align_bwd_kernel<T, L><<<grid, 256, 0, st>>>((const T*)dy, rois, dx, total, spatial_scale, (int)c, (int)h, (int)w, pooled_h, pooled_w, sampling_ratio)

@@ -497,6 +497,13 @@ int afan_mix_feature(const void* clean, const void* adv, void* out, int64_t n, i
     if (!clean || !adv || !out) return AFAN_ENULL;
     const size_t a = dtype == AFAN_F32 ? 4 : 2;
     if (!aligned(clean, a) || !aligned(adv, a) || !aligned(out, a)) return AFAN_EALIGN;
+    // hw == 1 (Detection's pooled ROI feature, [128, 2048, 1, 1]: attack_algo.py:254-265 on roi_feature_map): NCHW and NHWC are the
+    // same bytes, and the pixel-tile kernel would run 1 live pixel column per workgroup on 32 of 256 threads (40.9 us for 3.1 MB);
+    // one wave per row with coalesced channel accesses is the channels-last kernel
+    if (hw == 1) {
+        if (dtype == AFAN_F32) return mix_nhwc_impl<float>(clean, adv, out, n, c, eps, (hipStream_t)stream);
+        return mix_nhwc_impl<uint16_t>(clean, adv, out, n, c, eps, (hipStream_t)stream);
+    }
     if (dtype == AFAN_F32) return mix_impl<float>(clean, adv, out, n, c, hw, eps, (hipStream_t)stream);
     return mix_impl<uint16_t>(clean, adv, out, n, c, hw, eps, (hipStream_t)stream);
 }
@@ -530,7 +537,7 @@ int afan_lerp_mix(const float* clean, const float* adv, float* out, int64_t n, i
     for (int k = 0; k < 8; ++k) lw.w[k] = k < npts - 1 ? weights[k] : 0.f;
     const int64_t total = n * c * hw;
     AFAN_PROF("lerp_mix_kernel", 4.0 * total * (2 + npts), st);
-    if (layout == AFAN_NHWC) {
+    if (layout == AFAN_NHWC || hw == 1) {       // (hw == 1: the same bytes either way; afan_mix_feature takes this form too — bit-equal)
         const int grid = grid_for(n * hw * AFAN_WAVE, BLOCK, 8192);
         if (c <= 64 * 8) lerp_mix_nhwc_kernel<8><<<grid, BLOCK, 0, st>>>(clean, adv, out, (int)c, n * hw, total, lw, npts, mix_mask, eps);
         else lerp_mix_nhwc_kernel<20><<<grid, BLOCK, 0, st>>>(clean, adv, out, (int)c, n * hw, total, lw, npts, mix_mask, eps);

@@ -312,31 +312,6 @@ class ResNet101(nn.Module):
         x = self.bn1.fused(self.conv1(x), None, True)
         return self.maxpool(x)
 
-    _cuts = None
-
-    def cut_features(self, cuts):
-        """Context: every training forward inside it detaches the backbone's output `features` (where it carries a graph)
-        into a fresh leaf and appends (features, leaf) to `cuts`; the RPN and the ROI head consume the leaf.  A backward from
-        the losses then stops at the leaves; `torch.autograd.backward([f...], [leaf.grad...])` finishes it
-        (det_attack_algo.det_train_phases: the two-part backward of the data-parallel iteration)."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            old, self._cuts = self._cuts, cuts
-            try:
-                yield cuts
-            finally:
-                self._cuts = old
-        return ctx()
-
-    def _cut(self, features):
-        if self._cuts is None or features.grad_fn is None:
-            return features
-        leaf = features.detach().requires_grad_(True)
-        self._cuts.append((features, leaf))
-        return leaf
-
     def head_features(self, x, idxs=(1, 2, 3)):
         """The feature maps after layers `idxs` from ONE pass, detached: what the three `flag: 'head'` calls of
         train_aug_sat_muti_advt.py:78-80 return (same images, frozen BatchNorm, no dropout: each is a prefix of the next)."""
@@ -551,6 +526,31 @@ class Model(nn.Module):
         super().train(mode)
         self._mode_walked = mode
         return self
+
+    _cuts = None
+
+    def cut_features(self, cuts):
+        """Context: every training forward inside it detaches the backbone's output `features` (where it carries a graph)
+        into a fresh leaf and appends (features, leaf) to `cuts`; the RPN and the ROI head consume the leaf.  A backward from
+        the losses then stops at the leaves; `torch.autograd.backward([f...], [leaf.grad...])` finishes it
+        (det_attack_algo.det_train_phases: the two-part backward of the data-parallel iteration)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old, self._cuts = self._cuts, cuts
+            try:
+                yield cuts
+            finally:
+                self._cuts = old
+        return ctx()
+
+    def _cut(self, features):
+        if self._cuts is None or features.grad_fn is None:
+            return features
+        leaf = features.detach().requires_grad_(True)
+        self._cuts.append((features, leaf))
+        return leaf
 
     def head_features(self, x, idxs=(1, 2, 3)):
         """[forward({'x': x, 'flag': 'head', 'out_idx': i}).detach() for i in idxs] from one backbone pass."""

@@ -107,8 +107,10 @@ class _ROIAlign(torch.autograd.Function):
         dx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device,
                          memory_format=torch.channels_last if lay == ops.AFAN_NHWC else torch.contiguous_format)
         st = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
-        check(lib.afan_roi_align_bwd(C.c_void_p(g.data_ptr()), C.c_void_p(rois.data_ptr()), C.c_void_p(dx.data_ptr()),
-                                     ops._DT[dtype], lay, rois.shape[0], n, c, h, w, ph, pw, scale, sr, st), "afan_roi_align_bwd")
+        ws = _workspace_bytes(g.device, lib.afan_roi_align_bwd_workspace_bytes(rois.shape[0], h, w))      # the weight tables of the gather form
+        check(lib.afan_roi_align_bwd_ws(C.c_void_p(g.data_ptr()), C.c_void_p(rois.data_ptr()), C.c_void_p(dx.data_ptr()),
+                                        ops._DT[dtype], lay, rois.shape[0], n, c, h, w, ph, pw, scale, sr, C.c_void_p(ws.data_ptr()), st),
+              "afan_roi_align_bwd_ws")
         return dx.to(dtype), None, None, None, None
 
 

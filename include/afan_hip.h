@@ -537,6 +537,13 @@ int afan_roi_align_fwd(const void* x, const float* rois, void* y, int dtype, int
 int afan_roi_align_bwd(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
                        int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
                        afan_stream_t stream);
+/* The same with caller-owned scratch for the channels-last form's bilinear weight tables (per (roi, map row) and (roi, map
+ * column): 16 weights + the non-zero bin range), filled by one small launch: afan_roi_align_bwd_workspace_bytes(num_rois, h, w)
+ * bytes, 16-byte aligned; NULL = afan_roi_align_bwd. */
+int64_t afan_roi_align_bwd_workspace_bytes(int64_t num_rois, int64_t h, int64_t w);
+int afan_roi_align_bwd_ws(const void* dy, const float* rois, float* dx, int dtype, int layout, int64_t num_rois, int64_t n, int64_t c,
+                          int64_t h, int64_t w, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, void* workspace,
+                          afan_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Classifier head of the slice protocol: AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear (resnet_s.py:108-110), run at the

@@ -19,6 +19,7 @@ tests/golden/roi_align_fwd_*.npz and the `align`-mode Faster-RCNN fixture.
 Usage:  python oracle/gen_golden.py            (rewrites tests/golden/ except the two Faster-RCNN files)
         python oracle/gen_golden.py frcnn      (det_frcnn_r101.npz, det_frcnn_r101_align.npz; own process: Detection/ on sys.path)
         python oracle/gen_golden.py roialign   (only roi_align_fwd_*.npz)
+        python oracle/gen_golden.py floor      (ref_noise_floor.npz: the reference against itself in float64 / other fp32 summation orders)
 """
 import importlib.util
 import os
@@ -195,6 +196,163 @@ def gen_damped_r18(ref_attack, orc):
     np.savez_compressed(os.path.join(OUT, "step_r18_k5_b32_damped.npz"), **rec)
     print("step_r18_k5_b32_damped loss", float(r["loss"]), float(r["loss_adv"]), float(r["loss_clean"]), "grads stored:",
           [k for k in rec if k.startswith("grad/")])
+
+
+def _variant_ctx(kind):
+    """Arithmetic variants of the SAME reference code on the SAME inputs: what two correct implementations may differ by."""
+    import contextlib
+    if kind.endswith("nomkldnn"):       # ATen's native convolution / GEMM path instead of oneDNN: another summation order, still fp32
+        return torch.backends.mkldnn.flags(enabled=False)
+    return contextlib.nullcontext()
+
+
+def _to_variant(kind, model, tensors):
+    if kind.startswith("t_") or kind == "t":
+        # the whole problem transposed (H <-> W): every convolution kernel and every image / label map transposed.  Convolutions,
+        # pooling, BatchNorm and bilinear resizing with the same stride / padding on both axes are equivariant, so every feature
+        # map is the transpose of the baseline's — mathematically; the sums run in another order.
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.weight.data = m.weight.data.transpose(2, 3).contiguous()
+                    assert m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1] and m.dilation[0] == m.dilation[1]
+        tensors = [t.transpose(-1, -2).contiguous() if t.dim() >= 3 else t for t in tensors]
+        kind = kind[2:] if kind.startswith("t_") else "base"
+    if kind == "f64":            # float64 throughout, results compared after rounding to the sign grid
+        return model.double(), [t.double() if t.is_floating_point() else t for t in tensors]
+    if kind == "cl":             # channels-last weights and activations: oneDNN picks other kernels / blockings
+        return model.to(memory_format=torch.channels_last), [t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+                                                              for t in tensors]
+    return model, list(tensors)
+
+
+def gen_noise_floor(ref_attack, build, ref_seg=None, ref_network=None):
+    """tests/golden/ref_noise_floor.npz — how far the REFERENCE is from itself.  For every deep-network golden case the
+    reference's own PGD (same code, same seed, same inputs) is re-run in six other arithmetics — float64, ATen-native fp32
+    (oneDNN off), channels-last fp32, and the same three on the TRANSPOSED problem (every kernel and image with H and W swapped: the
+    same mathematics, another summation order) — and the fraction of feature elements whose perturbation (an integer multiple of gamma
+    on the sign grid) differs from the fp32 baseline's is stored: after every step (`<case>/<variant>/per_step`) and after K steps
+    (`.../final`).  A sign() flips where a gradient sits within rounding distance of zero, and flips compound through the
+    remaining steps: this is the floor below which no fp32 implementation can be told from the reference, and
+    the tests bound the product's flip fraction by max(2 x floor, 1e-4) instead of by hand-set constants."""
+    import copy
+    crit = nn.CrossEntropyLoss()
+    rec = {}
+    variants = ("f64", "nomkldnn", "cl", "t", "t_nomkldnn", "t_cl")
+    untr = lambda kind, a: a.swapaxes(-1, -2) if (kind == "t" or kind.startswith("t_")) else a
+
+    def record(case, base_steps, runs):
+        for kind, steps in runs.items():
+            per = [float((np.rint(a) != np.rint(b)).mean()) for a, b in zip(steps, base_steps)]
+            rec[f"{case}/{kind}/per_step"] = np.array(per)
+            rec[f"{case}/{kind}/final"] = np.array(per[-1])
+        rec[f"{case}/floor"] = np.array(max(float(rec[f"{case}/{k}/final"]) for k in runs))
+        print(f"   {case}: " + "  ".join(f"{k} {float(rec[f'{case}/{k}/final']):.5f}" for k in runs) + f"  -> floor {float(rec[case + '/floor']):.5f}")
+
+    # ---- Classification (main_perturb.py:173-185): head pass, K-step PGD
+    for case, arch, bs, K, gamma, clip in (("step_r18_k5", "resnet18", 2, 5, 0.5, False), ("step_r56s_k5", "resnet56s", 2, 5, 0.5, False),
+                                           ("step_r18_k5_b16", "resnet18", 16, 5, 0.5, False), ("step_r56s_k5_b16", "resnet56s", 16, 5, 0.5, False),
+                                           ("step_r20s_k1", "resnet20s", 4, 1, 0.5, False),
+                                           ("step_r20s_k5", "resnet20s", 4, 5, 0.5, False), ("step_r20s_k5_clip", "resnet20s", 4, 5, 1.5, True),
+                                           ("step_r18_k5_b32_damped", "resnet18", 32, 5, 0.5, False)):
+        torch.manual_seed(3)
+        model0, idx, ln = build(arch)
+        if case.endswith("_damped"):                      # gen_damped_r18: every block's last-BatchNorm weight x 0.1
+            for m in model0.modules():
+                if hasattr(m, "bn2") and hasattr(m, "conv2"):
+                    m.bn2.weight.data.mul_(0.1)
+        model0.train()
+        x, y = torch.rand(bs, 3, 32, 32), torch.randint(0, 10, (bs,))
+
+        def run(kind):
+            model, (xx,) = _to_variant(kind, copy.deepcopy(model0), [x])
+            with _variant_ctx(kind):
+                fm = model(xx, end_point=idx, start_point=0).detach()
+                snaps = _pgd_trace(ref_attack, model, crit, fm, y, K, gamma, 2.0, idx, ln, clip)
+            g_ = (gamma / 255)
+            return [untr(kind, ((s_.double() - fm.double()) / g_).contiguous(memory_format=torch.contiguous_format).numpy()) for s_ in snaps[1:]]
+        base = run("base")
+        gold = np.load(os.path.join(OUT, case + ".npz"))
+        if "dk" in gold.files:
+            assert np.array_equal(np.rint(base[-1]).astype(np.int8), gold["dk"]), case
+        else:
+            assert np.array_equal(np.rint(base[-1]), np.rint((gold["x_adv"] - gold["feature_map"]) / (gamma / 255))), case
+        record(case, base, {k: run(k) for k in variants})
+
+    # ---- the flip rate at its source: one gradient from the reference's OWN iterate (pgd_trace_r18_k5.npz: x_adv before every step
+    # and the gradient the baseline computed there), recomputed in each variant: fraction of elements whose sign differs
+    tr = np.load(os.path.join(OUT, "pgd_trace_r18_k5.npz"))
+    torch.manual_seed(3)
+    model0, idx, ln = build("resnet18")
+    model0.train()
+    y = torch.from_numpy(tr["y"])
+    worst = 0.0
+    for kind in variants:
+        per = []
+        for t in range(tr["grads"].shape[0]):
+            model, (xin,) = _to_variant(kind, copy.deepcopy(model0), [torch.from_numpy(tr["snaps"][t])])
+            xin = xin.clone().requires_grad_(True)
+            with _variant_ctx(kind):
+                gr = torch.autograd.grad(crit(model(xin, end_point=ln, start_point=idx), y), xin)[0]
+            gr = untr(kind, gr.contiguous(memory_format=torch.contiguous_format).numpy())
+            per.append(float((np.sign(gr) != np.sign(tr["grads"][t])).mean()))
+        rec[f"pgd_trace_r18_k5/{kind}/per_step"] = np.array(per)
+        worst = max(worst, max(per))
+    rec["pgd_trace_r18_k5/floor"] = np.array(worst)
+    print("   pgd_trace_r18_k5 (sign of one gradient from the reference's iterate): " +
+          "  ".join(f"{k} {rec[f'pgd_trace_r18_k5/{k}/per_step'].max():.5f}" for k in variants) + f"  -> floor {worst:.5f}")
+
+    # ---- Segmentation (main_aug_final.py:164-197): SE head pass, K-step SE feature PGD on the reference's own DeepLabv3+ / ResNet-101
+    if ref_network is not None:
+        seg_crit = nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
+        for case, steps, gamma_se, side, damp, bs in (("seg_dl101_aspp_k1", 1, 0.5, 129, 1.0, 2), ("seg_dl101_concat_k3", 3, 0.5, 129, 1.0, 2),
+                                                      ("seg_dl101_aspp_k3_damped", 3, 0.5, 129, 0.1, 4)):
+            torch.manual_seed(3)
+            net0 = ref_network.deeplabv3plus_resnet101(num_classes=21, output_stride=16, pretrained_backbone=False)
+            net0.classifier.aspp.project[3].p = 0.0
+            if damp != 1.0:
+                for m in net0.backbone.modules():
+                    if isinstance(m, ref_network.backbone.resnet.Bottleneck):
+                        m.bn3.weight.data.mul_(damp)
+            for m in net0.backbone.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.momentum = 0.01
+            net0.train()
+            images = torch.rand(bs, 3, side, side)
+            if bs == 4:
+                for i, (sc, of) in enumerate([(1.0, 0.0), (0.3, 0.6), (0.6, 0.0), (0.5, 0.4)]):
+                    images[i] = images[i] * sc + of
+            labels = torch.randint(0, 21, (bs, side, side))
+            labels[torch.rand(bs, side, side) < 0.05] = 255
+            gold = np.load(os.path.join(OUT, case + ".npz"))
+            assert np.array_equal(_np(images), gold["images"]) and np.array_equal(_np(labels), gold["labels"]), case
+
+            def run_seg(kind):
+                net, (im, lab) = _to_variant(kind, copy.deepcopy(net0), [images, labels])
+                seen = []
+
+                class Spy(nn.Module):
+                    def __init__(self, m):
+                        super().__init__()
+                        self.m = m
+
+                    def forward(self, d):
+                        if d.get("flag") == "tail":
+                            seen.append(d["adv"].detach().clone())
+                        return self.m(d)
+                with _variant_ctx(kind):
+                    out_se = net({"x": im, "adv": None, "out_idx": 3, "flag": "head"})
+                    net({"x": im, "adv": None, "out_idx": "aspp_head", "flag": "clean"})          # (:167: its BatchNorm side effects precede the PGD)
+                    fm = out_se["out"].detach()
+                    adv = ref_seg.PGD(x=fm, image_batch=im, low_level_feat=out_se["low_level"], criterion=seg_crit, y=lab,
+                                      model=Spy(net), steps=steps, eps=(2.0 / 255), gamma=(gamma_se / 255), idx=3, randinit=False, clip=False)
+                seen.append(adv.detach().clone())
+                g_ = gamma_se / 255
+                return [untr(kind, ((s_.double() - fm.double()) / g_).contiguous(memory_format=torch.contiguous_format).numpy()) for s_ in seen[1:]]
+            base = run_seg("base")
+            assert np.array_equal(np.rint(base[-1]), np.rint((gold["adv_se"].astype(np.float64) - gold["fm_se"]) / (gamma_se / 255))), case
+            record(case, base, {k: run_seg(k) for k in variants})
+    np.savez_compressed(os.path.join(OUT, "ref_noise_floor.npz"), **rec)
 
 
 def gen_detection(orc):
@@ -895,6 +1053,30 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True)
         from oracle import afan_oracle as _orc
         gen_detection(_orc)
+    elif sys.argv[1:] == ["floor"]:       # only ref_noise_floor.npz (reads the step goldens it refers to)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        from oracle import afan_oracle as _orc
+        _ra = _load("ref_cls_attack_algo", "Classification/attack_algo.py")
+        _rr = _load("ref_cls_resnet_s", "Classification/resnet_s.py")
+        _rs = _load("ref_seg_attack_algo", "Segmentation/attack_algo.py")
+        _tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+        _tvm = sys.modules.setdefault("torchvision.models", types.ModuleType("torchvision.models"))
+        _tvu = types.ModuleType("torchvision.models.utils")
+        _tvu.load_state_dict_from_url = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no network"))
+        sys.modules["torchvision.models.utils"] = _tvu
+        _tv.models, _tvm.utils = _tvm, _tvu
+        sys.path.insert(0, os.path.join(REF, "Segmentation"))
+        import network as _ref_network        # noqa: E402  (Segmentation/network)
+        sys.path.pop(0)
+
+        def _build(arch):
+            if arch == "resnet20s":
+                return _rr.ResNet(_rr.BasicBlock, [3, 3, 3]), 7, 16
+            if arch == "resnet56s":
+                return _rr.resnet56(), 13, 34
+            return _orc.resnet18_cifar(), 6, 15
+        gen_noise_floor(_ra, _build, _rs, _ref_network)
     elif sys.argv[1:] == ["roialign"]:    # only the ROIAlign vectors (the reference's own CPU kernel, compiled by oracle/Makefile)
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         os.makedirs(OUT, exist_ok=True)

@@ -94,8 +94,14 @@ def test_deeplab_step_fp32_matches_reference(pkg, gpu, case, nhwc):
     # 2 where a gradient sits within rounding distance of zero; on the freshly initialised network the
     # gradient reaching layer3's output has crossed the chaotic layer4 + ASPP in vendor-fp32 vs CPU-fp32 arithmetic.
     k_got, k_ref = np.rint(d / gam), np.rint((g["adv_se"] - g["fm_se"]) / gam)
-    agree = float((k_got == k_ref).mean())
-    assert agree >= (0.97 if float(g["damp"]) != 1.0 else 0.6), agree
+    # bound: the reference against itself (tests/golden/ref_noise_floor.npz: its own SE PGD re-run in float64, ATen-native fp32,
+    # channels-last fp32 and on the transposed problem differs from its baseline on `floor` of the elements), times two
+    fl = golden("ref_noise_floor")
+    floor = float(fl[case + "/floor"])
+    flips = 1.0 - float((k_got == k_ref).mean())
+    print(f"PARITY {case} [fp32 {'NHWC' if nhwc else 'NCHW'}]: perturbation elements off the reference's {flips:.5f}   "
+          f"reference-vs-reference floor {floor:.5f}   bound {max(2 * floor, 1e-4):.5f}")
+    assert flips <= max(2.0 * floor, 1e-4), (flips, floor)
     sd = model.state_dict()
     for k in g.files:
         if k.startswith("sd1/") and k.endswith("num_batches_tracked"):

@@ -162,6 +162,36 @@ def test_roi_align_vs_reference_binary_random(pkg, gpu):
             np.testing.assert_allclose(y.cpu().numpy(), want, rtol=0, atol=1e-5)
 
 
+def test_roi_align_bwd_gather_forms_are_deterministic_and_equal(pkg, gpu, orc):
+    """The channels-last backward is a gather by map tile (no atomics): run to run bit-identical, and the two forms of it —
+    weights built by the waves (afan_roi_align_bwd) or read from the tables one launch fills (afan_roi_align_bwd_ws, what
+    det_ops.roi_align's backward calls) — give the same bits; against the scatter-with-atomics kernel (NCHW path) to rounding."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    g = golden("roi_align_fwd_cfg5_r128")
+    rois = torch.from_numpy(g["rois"]).to(gpu)
+    N, Cc, H, W = (int(v) for v in g["x_shape"])
+    gen = torch.Generator().manual_seed(4)
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        dy = torch.randn(len(g["rois"]), 14, 14, Cc, generator=gen).to(gpu).to(dt)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        ws = torch.empty(lib.afan_roi_align_bwd_workspace_bytes(len(g["rois"]), H, W), dtype=torch.uint8, device=gpu)
+        outs = []
+        for w in (None, ws, ws, None):
+            dx = torch.full((N, H, W, Cc), float("nan"), device=gpu)         # the gather writes every cell itself: no memset needed
+            pkg._lib.check(lib.afan_roi_align_bwd_ws(C.c_void_p(dy.data_ptr()), C.c_void_p(rois.data_ptr()), C.c_void_p(dx.data_ptr()), code, 1,
+                                                     len(g["rois"]), N, Cc, H, W, 14, 14, 1 / 16, 0, None if w is None else C.c_void_p(w.data_ptr()), st), "bwd")
+            outs.append(dx)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.isfinite(outs[0]).all()
+        # the NCHW scatter on the same values
+        dy_nchw = dy.permute(0, 3, 1, 2).contiguous()
+        dxs = torch.empty(N, Cc, H, W, device=gpu)
+        pkg._lib.check(lib.afan_roi_align_bwd(C.c_void_p(dy_nchw.data_ptr()), C.c_void_p(rois.data_ptr()), C.c_void_p(dxs.data_ptr()), code, 0,
+                                              len(g["rois"]), N, Cc, H, W, 14, 14, 1 / 16, 0, st), "bwd nchw")
+        ref = dxs.permute(0, 2, 3, 1)
+        assert float((outs[0] - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("C", [64, 256])         # (256: 32 channel vectors — the geometry-once-per-bin kernels)
 def test_roi_align_bf16_nhwc(pkg, gpu, c_oracle, C):
     rng = np.random.default_rng(4)

@@ -131,7 +131,7 @@ def test_mix_feature_golden(pkg, gpu, tag):
 
 
 @pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 256, 33, 33), (1, 304, 20, 129), (2, 2, 3, 3),
-                                   (1, 2048, 5, 7), (1, 6000, 2, 3)])
+                                   (1, 2048, 5, 7), (1, 6000, 2, 3), (128, 2048, 1, 1), (3, 19, 1, 1)])   # (.., 1, 1): Detection's pooled ROI feature
 def test_mix_feature_vs_c_oracle(pkg, gpu, c_oracle, shape):
     rng = np.random.default_rng(sum(shape))
     clean = (rng.standard_normal(shape) * 1.3 + 4.0).astype(np.float32)   # |mean| >> std stresses the variance
@@ -192,7 +192,8 @@ def test_mix_feature_bf16(pkg, gpu, orc):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 2, 3, 3), (1, 6000, 2, 3)])
+@pytest.mark.parametrize("shape", [(2, 1024, 33, 33), (1, 304, 20, 129), (3, 19, 7, 9), (1, 2048, 5, 7), (2, 2, 3, 3), (1, 6000, 2, 3),
+                                   (128, 2048, 1, 1)])
 @pytest.mark.parametrize("nhwc", [False, True])
 @pytest.mark.parametrize("number,mix", [(3, (True, True)), (3, (True, False)), (3, (False, True)), (5, (True, False, True, True)),
                                         (2, (True,))])

@@ -12,11 +12,27 @@ from conftest import assert_close_frac, golden
 pytestmark = pytest.mark.gpu
 
 LOSS_TOL = 1e-4      # |delta| <= 1e-4 * max(1, |reference loss|)
-# Fraction of feature elements whose K-step perturbation may differ from the reference's: every difference is a
-# sign() flip on a gradient within fp32 rounding distance of zero, and flips compound over the K steps through
-# batch-2 BatchNorm statistics in the deep nets (measured on MI355X: r20s <= 3e-4, r56s / r18 at batch 2 ~ 7.5e-2).
-FLIP_BOUND = {"resnet20s": 2e-3, "resnet56s": 0.15, "resnet18": 0.15}
-FLIP_B16 = {"resnet56s": 0.08, "resnet18": 0.08}      # measured on the f32-MFMA convolutions: 3.9 % / 4.3 % (profiles/r03c_parity_measurements.txt)
+# Fraction of feature elements whose K-step perturbation may differ from the reference's: every difference is a sign() flip on a
+# gradient within fp32 rounding distance of zero, and flips compound over the K steps.  The bound is not a constant of
+# ours: tests/golden/ref_noise_floor.npz (oracle/gen_golden.py floor) holds how far the REFERENCE is from ITSELF on the same case
+# when its own code runs in six other arithmetics (float64, ATen-native fp32, channels-last fp32, and those three on the transposed
+# problem); the product may differ from the reference by at most max(2 x that floor, 1e-4).
+_FLOOR = golden("ref_noise_floor")
+
+
+def flip_floor(case):
+    return float(_FLOOR[case + "/floor"])
+
+
+def flip_bound(case):
+    return max(2.0 * flip_floor(case), 1e-4)
+
+
+def report_flips(case, what, flips):
+    print(f"PARITY {case} [{what}]: perturbation elements off the reference's {flips:.5f}   reference-vs-reference floor "
+          f"{flip_floor(case):.5f}   bound {flip_bound(case):.5f}")
+
+
 ARCH = {"r20s": "resnet20s", "r56s": "resnet56s", "r18": "resnet18"}
 
 
@@ -72,11 +88,13 @@ def test_joint_step_fp32_matches_reference(pkg, orc, gpu, case):
     d_ref = g["x_adv"] - g["feature_map"]
     # gamma = 1.5/255 against eps = 2/255 (the clip goldens): every step throws an element across the whole eps-ball, so ONE
     # early flip (a gradient within rounding of zero) moves its neighbours' next gradients by a macroscopic amount and the
-    # difference avalanches over the remaining steps: K = 5 ends 2.4 % off on the library's f32-MFMA convolutions (the
-    # vendor's fp32 convolutions of rounds 1-2 happened to flip nothing: 0 %), K = 3 stays exact.  Bound: 5e-2 there.
-    avalanche = bool(clip) and K > 3
-    assert_close_frac(d_got, d_ref, 0, 2e-6, 5e-2 if avalanche else FLIP_BOUND[arch], "perturbation (sign-flip fraction)")
-    if K == 1 or (clip and not avalanche):
+    # difference avalanches over the remaining steps: K = 5 ends 2.4 % off on the library's f32-MFMA convolutions, K = 3 stays exact
+    # (the reference itself avalanches there: its transposed-problem runs end 0.3 - 2.1 % off its baseline, ref_noise_floor.npz)
+    fcase = case if (case + "/floor") in _FLOOR.files else "step_r20s_k5_clip"      # (k3_clip_rand: the K = 5 clipped case's floor)
+    flips = float((np.abs(d_got - d_ref) > 2e-6).mean())
+    report_flips(fcase, f"{case} fp32 NCHW", flips)
+    assert_close_frac(d_got, d_ref, 0, 2e-6, flip_bound(fcase), "perturbation (sign-flip fraction)")
+    if K == 1 or (clip and K <= 3):
         assert_close_frac(d_got, d_ref, 0, 2e-6, 1e-4, "first-step / clipped perturbation")
     np.testing.assert_allclose(r["l2"].cpu().numpy(), g["l2"], rtol=5e-3)
     # linf = max |fl(x + k*gamma) - x|: carries the rounding of x + k*gamma, i.e. an ulp of the feature value
@@ -171,8 +189,8 @@ def test_clip_projection_invariant_full_size(pkg, orc, gpu):
 @pytest.mark.parametrize("case", ["step_r56s_k5_b16", "step_r18_k5_b16"])
 def test_joint_step_fp32_batch16_matches_reference(pkg, orc, gpu, case):
     """The deep networks at batch 16 (BatchNorm statistics over >= 16k samples): loss within 1e-4 and the K = 5 perturbation
-    equal to the reference's on >= 1 - FLIP_B16 = 92 % of the elements (measured 96 %: K sign() steps through a freshly
-    initialised tail) — on the library's own f32-MFMA convolutions (vendor_conv == 0)."""
+    within the reference's own noise floor of the reference's (measured 4 % of the elements differ; the reference run in another
+    fp32 summation order differs from itself on 6 - 11 %: K sign() steps through a freshly initialised tail) — on the library's own f32-MFMA convolutions (vendor_conv == 0)."""
     g = golden(case)
     K, idx, ln, randinit, clip = [int(v) for v in g["meta"]]
     gamma, eps = [float(v) for v in g["gamma_eps"]]
@@ -191,9 +209,9 @@ def test_joint_step_fp32_batch16_matches_reference(pkg, orc, gpu, case):
     flips = float((dk != g["dk"]).mean())
     # K = 5 sign() steps through 6 (ResNet-18) / 18 (ResNet-56s) freshly initialised residual blocks: an element whose
     # gradient sits within fp32 rounding of zero flips, and the flipped perturbation feeds the next step's gradient
-    # (measured on MI355X: see FLIP_B16).  The batch-2 goldens allowed 0.15.
-    print(f"{case}: perturbation elements off the reference's {flips:.4f}")
-    assert flips <= FLIP_B16[arch], flips
+    # (bound: flip_bound(case)).
+    report_flips(case, "fp32 NCHW", flips)
+    assert flips <= flip_bound(case), flips
     assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_general"] > 0
     np.testing.assert_allclose(r["l2"].cpu().numpy(), g["l2"], rtol=2e-3)
     np.testing.assert_allclose(r["out_clean"].cpu().numpy(), g["out_clean"], rtol=1e-3, atol=2e-4)
@@ -248,7 +266,10 @@ def test_step_matches_contractive_reference_golden(pkg, orc, gpu, dtype):
     dk = torch.round((r["x_adv"].float() - r["feature_map"].float()) / np.float32(gamma / 255)).cpu().numpy().astype(np.int8)
     # K = 5 sign() steps; bf16 gradients carry 2^-9 relative rounding per element, so many more of them sit "within rounding of
     # zero" than in fp32 (measured: fp32 1.2 % of the elements differ from the reference's, bf16 14 %)
-    hold("perturbation elements off the reference's", float((dk != g["dk"]).mean()), 0.02 if f32 else 0.20)
+    fl = float((dk != g["dk"]).mean())
+    report_flips("step_r18_k5_b32_damped", f"{'fp32' if f32 else 'bf16'} NHWC", fl)
+    # fp32: the reference's own floor; bf16 is not the reference's arithmetic (compared on the loss): stated bound
+    hold("perturbation elements off the reference's", fl, flip_bound("step_r18_k5_b32_damped") if f32 else 0.20)
     names = [str(k) for k in g["param_names"]]
     assert tr.arena.names == names
     got = np.array([float(tr.arena.view(tr.arena.grad, i).double().norm()) for i in range(len(names))])
@@ -390,7 +411,9 @@ def test_joint_step_fp32_channels_last_matches_reference(pkg, orc, gpu, bn_mode,
     adv_tol = LOSS_TOL if arch == "resnet20s" else 3 * LOSS_TOL
     assert abs(float(r["loss_adv"]) - float(g["loss_adv"])) <= adv_tol * max(1.0, abs(float(g["loss_adv"])))
     d_got = (r["x_adv"] - r["feature_map"]).cpu().numpy()
-    assert_close_frac(d_got, g["x_adv"] - g["feature_map"], 0, 2e-6, FLIP_BOUND[arch], "perturbation")
+    fcase = case if (case + "/floor") in _FLOOR.files else "step_r20s_k5_clip"
+    report_flips(fcase, f"{case} fp32 NHWC fold={fold} bn={bn_mode}", float((np.abs(d_got - (g["x_adv"] - g["feature_map"])) > 2e-6).mean()))
+    assert_close_frac(d_got, g["x_adv"] - g["feature_map"], 0, 2e-6, flip_bound(fcase), "perturbation")
     np.testing.assert_allclose(r["l2"].cpu().numpy(), g["l2"], rtol=5e-3)
     sd1 = model.state_dict()
     assert int(sd1[f"sequential_model.{idx}.bn1.num_batches_tracked"]) == K + 2
@@ -919,4 +942,5 @@ def test_r18_per_step_perturbation_given_reference_iterates(pkg, orc, gpu):
         same = float((xa.cpu() == torch.from_numpy(g["snaps"][t + 1])).float().mean())
         assert same >= 1.0 - flips - 1e-7
         worst = max(worst, flips)
-    assert worst <= 2e-3, worst
+    report_flips("pgd_trace_r18_k5", "sign of one gradient from the reference's own iterate, worst step", worst)
+    assert worst <= flip_bound("pgd_trace_r18_k5"), worst
