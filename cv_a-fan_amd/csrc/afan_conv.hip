@@ -76,9 +76,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     constexpr int THREADS = 64 * (NW + PW);
     constexpr int STG = PW ? 64 * PW : THREADS;       // threads that stage operands
     constexpr int RPP = STG / 8;                      // rows staged per pass of the workgroup
-#if AFAN_CONV_ABLATE == 7
-    return;
-#endif
     const ConvClass& cc = pp.cls[blockIdx.z];
     const uint32_t Wg = (uint32_t)cc.Wg, Hg = (uint32_t)cc.Hg;
     const uint32_t M = (uint32_t)pp.N * Hg * Wg;
@@ -178,11 +175,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // 64-channel chunk of a tap is partly beyond Ci — those 16-byte pieces are requested at an out-of-range offset (zeros
     // from the hardware range check) for BOTH operands, and weight rows / output channels >= Co are masked the same way.
     const int chunks = (Ci + BK - 1) / BK;
-#if AFAN_CONV_ABLATE == 5
-    const int KS = 0;
-#else
     const int KS = T * chunks;
-#endif
     const bool last_ok = (chunks - 1) * BK + piece * 8 < Ci;      // this thread's piece exists in the last chunk
     u32x4 ra0[A_ROWS], rb0[B_ROWS], ra1[A_ROWS], rb1[B_ROWS];
 
@@ -211,9 +204,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             *reinterpret_cast<u32x4*>(B + (row0 + RPP * i) * LDK + piece * 8) = rb[i];
     };
     auto compute = [&](int buf) {
-#if AFAN_CONV_ABLATE == 2
-        return;
-#endif
         const uint16_t* A = lds + buf * STAGE;
         const uint16_t* B = A + BM * LDR;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
@@ -229,19 +219,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             for (int b = 0; b < FB; ++b) {
                 const int kk = k0 + b;
                 const int koff = GLDS ? (((kk * 2 + (lane >> 5)) ^ sw) * 8) : (kk * 16 + fk);
-#if AFAN_CONV_ABLATE == 3 || AFAN_CONV_ABLATE == 8
-#pragma unroll
-                for (int i = 0; i < MI; ++i) fx[b][i] = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)lane, (uint32_t)buf, 0u, 0u});
-#pragma unroll
-                for (int j = 0; j < NI; ++j) fw[b][j] = __builtin_bit_cast(bf16x8, u32x4{(uint32_t)lane, (uint32_t)kk, 0u, 0u});
-#else
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     fx[b][i] = *reinterpret_cast<const bf16x8*>(A + (wr * TM + i * 32 + frow) * LDR + koff);
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + koff);
-#endif
             }
             if (FB > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -303,7 +286,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     };
 
     if constexpr (HL > 0) {
-        static_assert(PW > 0 && GLDS && NS == 4, "halo form: producer waves, four weight stages");
+        static_assert(PW == 4 && GLDS && NS == 4, "halo form: FOUR producer waves (hdma's group index is k * 4 + swave), four weight stages");
+        // a chunk's halo is issued two groups (of 8 pixels per producer wave: 64 pixels) per K-step from t = 0 and must be complete
+        // before the next chunk's first tile waits with vmcnt(2 * LPT): all groups issued by t <= 6, i.e. at most 7 x 64 pixels
+        static_assert(HL <= 448, "halo form: the next chunk's halo must be issued within 7 K-steps (2 groups x 4 waves x 8 pixels each)");
         constexpr int HPM = HL;                              // pixels per halo buffer
         uint16_t* const Hbase = lds + NS * STAGE;            // two halo buffers of HPM x 64 channels
         uint16_t* const pad_zone = Hbase + 2 * HPM * BK;     // 1 KiB landing zone for the padding DMAs (below)
@@ -429,7 +415,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     if (t + 3 < 9 || more) {
                         bdma(nb, two[(t + 3) % 9], t + 3 < 9 ? q : q + 1);
                         // chunk q + 1's halo goes into the buffer chunk q - 1 used (free since this chunk's first barrier),
-                        // two groups per K-step from t = 0: issued by t = 4 (HPM <= 320), complete at chunk q + 1's first wait
+                        // two groups per K-step from t = 0: issued by t = 6 at the latest (HPM <= 448, asserted above; 400 pixels: t = 6), complete at chunk q + 1's first wait
                         hdma((q + 1) & 1, more ? 2 * t : 1 << 20, q + 1);
                         hdma((q + 1) & 1, more ? 2 * t + 1 : 1 << 20, q + 1);
                     }
@@ -487,12 +473,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 if (rem >= NS - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * (NS - 2)));
                 else if (NS == 4 && rem == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
                 else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
                 __builtin_amdgcn_s_barrier();            // tile ks is in LDS for everyone; buffer of tile ks-1 is free
-#endif
-#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
                 if (ks + NS - 1 < KS) gdma(ks + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-#endif
                 buf = buf + 1 == NS ? 0 : buf + 1;
             }
         } else {
@@ -501,9 +483,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #endif
             int buf = 0;
             for (int ks = 0; ks < KS; ++ks) {
-#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
                 __builtin_amdgcn_s_barrier();
-#endif
                 compute(buf);
                 buf = buf + 1 == NS ? 0 : buf + 1;
             }
@@ -525,12 +505,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             if (rem >= NS - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * (NS - 2)));
             else if (NS == 4 && rem == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             __builtin_amdgcn_s_barrier();                // tile ks is in LDS for everyone; buffer of tile ks-1 is free
-#endif
-#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             if (ks + NS - 1 < KS) gdma(ks + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-#endif
             compute(buf);
             buf = buf + 1 == NS ? 0 : buf + 1;
         }
@@ -540,13 +516,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         __syncthreads();                     // (the compiler drains vmcnt before the barrier)
         for (int ks = 0; ks < KS; ++ks) {
             const int buf = ks & 1;
-#if AFAN_CONV_ABLATE != 1 && AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             if (ks + 1 < KS) gdma(ks + 1, buf ^ 1);   // lands while this step's MFMAs run
-#endif
             compute(buf);
-#if AFAN_CONV_ABLATE != 4 && AFAN_CONV_ABLATE != 8
             __syncthreads();
-#endif
         }
     } else if constexpr (PF == 1) {
         gload(0, ra0, rb0);
@@ -583,9 +555,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // ---- epilogue: fp32 accumulators -> packed bf16 tile [pixel][channel] in LDS -> 16-byte channels-last stores ------
     constexpr int LDC = BN + 8;
     uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
-#if AFAN_CONV_ABLATE == 6
-    if (acc[0][0][0] != 1.2345e30f) return;
-#endif
     if (!producer)
 #pragma unroll
     for (int j = 0; j < NI; ++j)

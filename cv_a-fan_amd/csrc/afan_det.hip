@@ -454,25 +454,25 @@ __global__ __launch_bounds__(RG_THREADS) void roi_align_bwd_gather_kernel(const 
         }
         if (Y >= H) continue;                              // (wave-uniform; the wave still takes part in the next chunk's barriers)
 
+        // TAB: the lane-held weights (lane = ph for the row, lane = column * 16 + pw for the columns) come from the tables, two
+        // coalesced loads per ROI issued one ROI ahead; !TAB: the wave builds them
+        const int bc = lane >> 4, bpw = lane & 15, Xc = x0 + bc;
+        float wy_n = 0.f, wx_n = 0.f;
+        auto fetch = [&](int i) {
+            if (TAB && i < total) {
+                const int r2 = list[i];
+                wy_n = lane < RG_MAXP ? Wy[((int64_t)r2 * H + Y) * RG_MAXP + lane] : 0.f;
+                wx_n = Xc < Wd ? Wx[((int64_t)r2 * Wd + Xc) * RG_MAXP + bpw] : 0.f;
+            }
+        };
+        fetch(0);
         for (int i = 0; i < total; ++i) {
             const int rr = list[i];
-            float wy = 0.f, wx = 0.f;                      // (!TAB: lane-held weights, handed out by shuffles)
-            const float* wyp = nullptr;                    // (TAB: the precomputed tables)
-            const float* wxp = nullptr;
-            int plo, phi, qlo, qhi;
-            unsigned long long mxa = 0;
+            float wy = wy_n, wx = wx_n;
             if (TAB) {
-                const int ry = Ry[(int64_t)rr * H + Y];    // wave-uniform
-                plo = ry & 0xff; phi = (ry >> 8) & 0xff;
-                if (phi < plo) continue;                   // the ROI does not reach this row
-                const int Xs = X < Wd ? X : Wd - 1;
-                const int rx = X < Wd ? Rx[(int64_t)rr * Wd + Xs] : 1;
-                qlo = rx & 0xff; qhi = ((rx >> 8) & 0xff) - (X < Wd ? 0 : 1);
-                if (__ballot(qhi >= qlo) == 0) continue;
-                if (qhi < qlo) { qlo = 0; qhi = -1; }
-                wyp = Wy + ((int64_t)rr * H + Y) * RG_MAXP;
-                wxp = Wx + ((int64_t)rr * Wd + Xs) * RG_MAXP;
+                fetch(i + 1);
             } else {
+                wy = 0.f; wx = 0.f;
                 const RoiGeom g = roi_geom(rois + (int64_t)rr * 5, scale, PH, PW, sampling_ratio);
                 // the row's weights per bin: lane = ph
                 if (lane < PH) {
@@ -482,23 +482,20 @@ __global__ __launch_bounds__(RG_THREADS) void roi_align_bwd_gather_kernel(const 
                     }
                     wy = wy / g.count;
                 }
-                const unsigned long long my = __ballot(wy != 0.f);
-                if (my == 0) continue;                     // the ROI does not reach this row
                 // the four columns' weights per bin: lane = column * 16 + pw
-                {
-                    const int bc = lane >> 4, pw = lane & 15, Xc = x0 + bc;
-                    if (pw < PW && Xc < Wd)
-                        for (int ix = 0; ix < g.grid_w; ++ix) {
-                            const AxisW a = axis_prep(Wd, g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w);
-                            if (a.valid) wx += (a.lo == Xc ? a.h : 0.f) + (a.hi == Xc ? a.l : 0.f);
-                        }
-                }
-                mxa = __ballot(wx != 0.f);
-                if (mxa == 0) continue;
-                plo = __ffsll((long long)my) - 1; phi = 63 - __clzll((long long)my);
-                const unsigned mx = (unsigned)((mxa >> (col * 16)) & 0xffffULL);          // this lane's column
-                qlo = mx ? __ffs((int)mx) - 1 : 0; qhi = mx ? 31 - __clz((int)mx) : -1;
+                if (bpw < PW && Xc < Wd)
+                    for (int ix = 0; ix < g.grid_w; ++ix) {
+                        const AxisW a = axis_prep(Wd, g.start_w + bpw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w);
+                        if (a.valid) wx += (a.lo == Xc ? a.h : 0.f) + (a.hi == Xc ? a.l : 0.f);
+                    }
             }
+            const unsigned long long my = __ballot(wy != 0.f);
+            if (my == 0) continue;                         // the ROI does not reach this row
+            const unsigned long long mxa = __ballot(wx != 0.f);
+            if (mxa == 0) continue;
+            const int plo = __ffsll((long long)my) - 1, phi = 63 - __clzll((long long)my);
+            const unsigned mx = (unsigned)((mxa >> (col * 16)) & 0xffffULL);          // this lane's column
+            const int qlo = mx ? __ffs((int)mx) - 1 : 0, qhi = mx ? 31 - __clz((int)mx) : -1;
             const T* base = dy + (int64_t)rr * PH * PW * C + ch_safe;
             const bool small = (phi - plo) < 3 && __ballot(qhi - qlo >= 3) == 0;
             if (small) {
@@ -507,10 +504,10 @@ __global__ __launch_bounds__(RG_THREADS) void roi_align_bwd_gather_kernel(const 
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     phs[a] = min(plo + a, phi);
-                    const float w = TAB ? wyp[phs[a]] : __shfl(wy, phs[a], 64);
+                    const float w = __shfl(wy, phs[a], 64);
                     wyi[a] = (plo + a <= phi) ? w : 0.f;
                     pws[a] = qhi < 0 ? 0 : min(qlo + a, qhi);
-                    const float u = TAB ? wxp[pws[a]] : __shfl(wx, col * 16 + pws[a], 64);
+                    const float u = __shfl(wx, col * 16 + pws[a], 64);
                     wxj[a] = (qlo + a <= qhi) ? u : 0.f;
                 }
                 float d[9][VEC];
@@ -527,19 +524,12 @@ __global__ __launch_bounds__(RG_THREADS) void roi_align_bwd_gather_kernel(const 
                         for (int q = 0; q < VEC; ++q) acc[q] = fmaf(w, d[a * 3 + c][q], acc[q]);
                     }
             } else {
-                int qmin, qmax;
-                if (TAB) {                                 // the union of the four columns' ranges (wave-uniform loop bounds)
-                    qmin = qhi < qlo ? RG_MAXP : qlo; qmax = qhi;
-#pragma unroll
-                    for (int o = 16; o < 64; o <<= 1) { qmin = min(qmin, __shfl_xor(qmin, o, 64)); qmax = max(qmax, __shfl_xor(qmax, o, 64)); }
-                } else {
-                    qmin = __ffsll((long long)(mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffff) - 1;
-                    qmax = 63 - __clzll((long long)((mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffffULL));
-                }
+                const int qmin = __ffsll((long long)(mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffff) - 1;
+                const int qmax = 63 - __clzll((long long)((mxa | (mxa >> 16) | (mxa >> 32) | (mxa >> 48)) & 0xffffULL));
                 for (int ph = plo; ph <= phi; ++ph) {
-                    const float wyv = TAB ? wyp[ph] : __shfl(wy, ph, 64);
+                    const float wyv = __shfl(wy, ph, 64);
                     for (int pw = qmin; pw <= qmax; ++pw) {
-                        const float w = wyv * (TAB ? wxp[pw] : __shfl(wx, col * 16 + pw, 64));
+                        const float w = wyv * __shfl(wx, col * 16 + pw, 64);
                         if (w != 0.f) {
                             float d[VEC];
                             Elt<T>::ldv(base + (int64_t)(ph * PW + pw) * C, d);

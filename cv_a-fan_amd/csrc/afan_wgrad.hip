@@ -14,6 +14,16 @@
 // [slice][tap][co][ci]; a second launch sums the slices IN ORDER (deterministic, no float atomics) and ADDS the result
 // into the fp32 gradient arena (KRSC), so autograd's AccumulateGrad, the bf16->fp32 cast and the split-K workspace
 // zero/cast passes of the vendor path all disappear.
+//
+// Measured in round 4 and NOT kept (profiles/r04_wgrad_experiments.txt):
+//  * in-launch reduction (ticket per (tile, tap); the last slice to arrive folds the slices in slice order — bit-identical results):
+//    with __threadfence() the kernel ran 3.6x slower (215 vs 60 us: the agent-scope release writes back and invalidates the L2
+//    every other workgroup streams its operands through); in the write-through form of cdna_hip_programming.md (16-byte sc1 slab
+//    stores, sc1 loads, agent-scope ticket) the last arriver reads S x 64 KB alone at the cross-XCD rate (~65 GB/s) — S = 14-56
+//    here, a 14-55 us serial tail per tile against the 8-17 us of a reduce launch that uses the whole chip: 147 vs 52 + 10 us per
+//    layer inside the step.  The guide's rule (combine in-launch only when S x slab bytes per tile is a few tens of KB) says the same.
+//  * operand tiles three K-steps ahead in registers with unconditional loads (vmcnt(23..16) in the steady state instead of a
+//    drain per step): 8.93 vs 8.92 ms per step, every layer within 2 % — the K loop is not waiting for its loads.
 #include "afan_common.h"
 #include "afan_conv_stem.h"
 #include "afan_wgrad_small.h"
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
 constexpr int MAXQ = 4;
 struct WgradPN {
     int n;
-    uint32_t first[MAXQ + 1];
+    uint32_t first[MAXQ + 1];      // multiples of 8: the XCD remap of wgrad_body reads the dispatch slot's XCD as lin % 8
+    uint32_t count[MAXQ];          // workgroups of problem q (the slots up to first[q + 1] beyond them stay idle)
     uint32_t tiles[MAXQ], taps[MAXQ];
     WgradP p[MAXQ];
 };
@@ -272,7 +283,9 @@ template <int BM, int BN, bool INC>
 __global__ __launch_bounds__(THREADS) void wgrad_multi_kernel(const WgradPN pn) {
     int q = 0;
     while (q + 1 < pn.n && blockIdx.x >= pn.first[q + 1]) ++q;
-    wgrad_body<BM, BN, INC>(pn.p[q], blockIdx.x - pn.first[q], pn.tiles[q], pn.taps[q], pn.first[q + 1] - pn.first[q]);
+    const uint32_t lin = blockIdx.x - pn.first[q];
+    if (lin >= pn.count[q]) return;
+    wgrad_body<BM, BN, INC>(pn.p[q], lin, pn.tiles[q], pn.taps[q], pn.count[q]);
 }
 
 struct RedPN {
@@ -520,12 +533,13 @@ int afan_conv_wgrad_multi_nhwc_bf16(int nb, const void* const* x, const void* co
         int e = build_problem(x[b], dy[b], n[b], nullptr, nullptr, 0, grad[b], hi[b], wi[b], ci[b], co[b], k[b], stride[b],
                               dilation[b], workspace + woff, accumulate, pn.p[b], pl);
         if (e) return e;
-        if (pn.p[b].direct) return AFAN_ESHAPE;                      // (the direct form has no slab: single launches only)
+        pn.p[b].direct = nullptr;                                    // (a one-slice problem takes the slab + reduce here too)
         const int taps = k[b] * k[b];
         const int bm = code & 0xff, bn = (code >> 8) & 0xff;
         pn.tiles[b] = (uint32_t)(((co[b] + bm - 1) / bm) * ((ci[b] + bn - 1) / bn));
         pn.taps[b] = (uint32_t)taps;
-        pn.first[b + 1] = pn.first[b] + pn.tiles[b] * taps * (uint32_t)pl.S;
+        pn.count[b] = pn.tiles[b] * taps * (uint32_t)pl.S;
+        pn.first[b + 1] = (pn.first[b] + pn.count[b] + 7u) & ~7u;
         rp.slab[b] = workspace + woff; rp.grad[b] = grad[b]; rp.S[b] = pl.S; rp.taps[b] = taps; rp.Co[b] = (int)co[b]; rp.Ci[b] = (int)ci[b];
         const int64_t per = (int64_t)taps * co[b] * ci[b];
         woff += (int64_t)pl.S * per;

@@ -254,6 +254,7 @@ class _WgradStream:
     streams = {}
     held = []
     mains = []
+    task = -1            # the graph task whose end-of-backward callback is queued
 
     @classmethod
     def run(cls, fn, *tensors):
@@ -265,7 +266,13 @@ class _WgradStream:
         if side is None:
             side = cls.streams[dev.index] = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
-        if not cls.held:
+        # one join per backward (graph task): keyed on the task id, not on `held` being empty — a backward that raised after
+        # its first side launch never ran its callback, and its leftovers must not keep later backwards from queueing theirs
+        task = torch._C._current_graph_task_id()
+        if task != cls.task:
+            if cls.held:                                # leftovers of an aborted backward: wait for them here
+                cls.join()
+            cls.task = task
             torch.autograd.Variable._execution_engine.queue_callback(cls.join)
         if main not in cls.mains:
             cls.mains.append(main)
@@ -282,6 +289,7 @@ class _WgradStream:
                 main.wait_stream(side)
         cls.mains.clear()
         cls.held.clear()
+        cls.task = -1
 
 
 @contextlib.contextmanager
