@@ -427,7 +427,7 @@ def main():
                                   if f32k else
                                   "nominal dense bf16 MFMA peak (MI355X_MICROARCH.md); measured on this chip: bare MFMA loop "
                                   "1.75-2.1 PFLOP/s, LDS -> MFMA consumer loop on random operands 1.13-1.41 PFLOP/s "
-                                  "(tools/probe/mfma_rate.hip, lds_mfma.hip; DESIGN.md 9.5)")}
+                                  "(tools/probe/mfma_rate.hip, lds_mfma.hip; NOTES.md 9.5)")}
         else:
             ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

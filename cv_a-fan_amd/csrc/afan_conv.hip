@@ -21,7 +21,7 @@
 // Knobs (tuning / A-B only): AFAN_CONV_MODE, AFAN_CONV_BM, AFAN_CONV_NW, AFAN_CONV_DEEP, AFAN_CONV_TALL, AFAN_CONV_C64,
 // AFAN_CONV_HALO.
 // (Measured-and-lost variants — 256-row tiles, producer waves on the two-stage launches, a half-step software pipeline,
-// streaming stores, register-streamed weights — are described in DESIGN.md 9.5 and no longer compiled in.)
+// streaming stores, register-streamed weights — are described in NOTES.md 9.5 and no longer compiled in.)
 #include "afan_common.h"
 #include "afan_conv_c64.h"
 #include "afan_conv_stem.h"

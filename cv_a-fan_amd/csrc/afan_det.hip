@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const T* __restrict_
 // above redo the index split, the ROI geometry and every sample point's bilinear setup for each of the bin's C channels
 // (~300 instructions per element: 222 us for 128 rois x 14 x 14 x 1024 channels); here a thread
 // does them once per bin and then runs over 16-byte channel vectors.  Same arithmetic per element as above.  (Forward only:
-// the backward is bound by its fp32 atomics, not by this arithmetic — two re-mappings measured slower)
+// the backward is bound by its fp32 atomics, not by this arithmetic — two re-mappings measured slower, NOTES.md 10.8.)
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_fwd_bins_kernel(const T* __restrict__ x, const float* __restrict__ rois, T* __restrict__ y,
                                                                  int64_t bins, float scale, int C, int H, int Wd, int PH, int PW,

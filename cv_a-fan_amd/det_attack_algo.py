@@ -13,7 +13,7 @@ behaviour of the reference's `Detection/attack_algo.py`, and the loop body of `D
 `model.train().forward({'x', 'adv', 'out_idx', 'flag'}, bboxes, labels)` -> four per-image loss tensors, a feature map
 (flag 'head') or the ROI dict ('roi_head').  The sign step / projection / noise / clamp / mix / sample-point arithmetic runs in
 libafan_hip.so; NMS and ROIAlign for the model's own layers are in det_ops.py.  The Faster-RCNN model itself is out of
-scope."""
+scope; the Faster-RCNN model is det_model.py."""
 import torch
 
 from . import ops

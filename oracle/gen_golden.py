@@ -351,6 +351,8 @@ def gen_noise_floor(ref_attack, build, ref_seg=None, ref_network=None):
                 return [untr(kind, ((s_.double() - fm.double()) / g_).contiguous(memory_format=torch.contiguous_format).numpy()) for s_ in seen[1:]]
             base = run_seg("base")
             assert np.array_equal(np.rint(base[-1]), np.rint((gold["adv_se"].astype(np.float64) - gold["fm_se"]) / (gamma_se / 255))), case
+            if damp != 1.0:      # the baseline's perturbation after EVERY step (multiples of gamma): lets a test see where flips start
+                rec[f"{case}/base_dk_per_step"] = np.stack([np.rint(b_).astype(np.int8) for b_ in base])
             record(case, base, {k: run_seg(k) for k in variants})
     np.savez_compressed(os.path.join(OUT, "ref_noise_floor.npz"), **rec)
 

@@ -178,6 +178,46 @@ def test_faster_rcnn_bf16_align_mode_runs_on_library_kernels(pkg, gpu):
     assert boxes.shape[1] == 4 and len(boxes) == len(classes) == len(probs) == len(idx)
 
 
+def test_faster_rcnn_full_size_iteration_properties(pkg, gpu):
+    """BASELINE configs[4] at the size bench.py times it (one 600 x 904 image per GPU, bf16 channels-last, the reference's default
+    `align` pooler, 12 000 -> 2 000 proposals): one DetTrainer iteration, held to what does not depend on the size — every loss
+    finite; the adversarial image inside the eps-ball and [0, 1]; each one-step feature perturbation exactly +-gamma (or 0) off its
+    feature map (Detection/attack_algo.py:67: x + gamma * sign(g)); the 38 x 57 conv4 map; both halves of the gradient arena
+    written; and the whole iteration REPRODUCIBLE bit for bit from the same state and host seed (no atomics left on the path: the
+    channels-last ROIAlign backward is a gather)."""
+    def run():
+        torch.manual_seed(7)
+        m = pkg.det_model.fasterrcnn_resnet101(21, pooler_mode="align")
+        for b in m.modules():
+            if isinstance(b, pkg.det_model.Bottleneck):
+                b.bn3.weight.data.mul_(0.2)
+        m.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+        tr = pkg.det_trainer.DetTrainer(m, lr=0.001, momentum=0.9, weight_decay=0.0005)
+        gen = torch.Generator().manual_seed(3)
+        images = torch.rand(1, 3, 600, 904, generator=gen).to(gpu)
+        x0, y0 = torch.rand(1, 6, 1, generator=gen) * 640, torch.rand(1, 6, 1, generator=gen) * 340
+        wh = 60 + torch.rand(1, 6, 2, generator=gen) * 200
+        bboxes = torch.cat([x0, y0, x0 + wh[..., :1], y0 + wh[..., 1:]], dim=-1).to(gpu)
+        labels = torch.randint(1, 21, (1, 6), generator=gen).to(gpu)
+        torch.manual_seed(1)
+        r = tr.step(images, bboxes, labels)
+        torch.cuda.synchronize()
+        return tr, images, r
+    tr, images, r = run()
+    assert torch.isfinite(r["losses"]).all() and np.isfinite(float(r["loss"])) and r["losses"].shape == (8,)
+    assert float((r["adv_image"] - images).abs().max()) <= 2.0 / 255 + 1e-6 and 0.0 <= float(r["adv_image"].min()) and float(r["adv_image"].max()) <= 1.0
+    assert tuple(r["fm3"].shape) == (1, 1024, 38, 57) and tuple(r["adv3"].shape) == (1, 1024, 38, 57)
+    for key, gamma in (("adv3", 1.0 / 255),):
+        d = (r[key].float() - r["fm3"].float()) / gamma
+        assert float((d - d.round()).abs().max()) <= 2e-3 and float(d.abs().max()) <= 1.0 + 2e-3          # one sign() step
+        assert float((d.round() != 0).float().mean()) > 0.5
+    lo = tr.arena.offsets[tr.tail_range()[0]]
+    assert float(tr.arena.grad[:lo].abs().sum()) > 0 and float(tr.arena.grad[lo:].abs().sum()) > 0 and torch.isfinite(tr.arena.param).all()
+    assert pkg.ops.CALLS["vendor_conv"] == 0
+    tr2, _, r2 = run()
+    assert torch.equal(r["losses"], r2["losses"]) and torch.equal(tr.arena.grad, tr2.arena.grad) and torch.equal(tr.arena.param, tr2.arena.param)
+
+
 def test_head_features_equal_the_three_head_forwards(pkg, gpu):
     """Model.head_features: the three `flag: 'head'` forwards of train_aug_sat_muti_advt.py:78-80 as one pass without an autograd
     graph — bit-identical feature maps (frozen BatchNorm, deterministic kernels)."""

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Functional run of the N>1 code path of bench.py on a 1-GPU box: two ranks (gloo, both on cuda:0) through
-# torch.distributed.run — the launcher starts before any GPU call.  Proves that the piece-wise captured step, the
-# stage-by-stage all-reduce on the side stream and the replica broadcast execute on hardware; RCCL itself needs 2 GPUs.
+# Functional run of the N>1 code path of bench.py on a 1-GPU box: two ranks (gloo, both on cuda:0).  `python bench.py --gpus 2`
+# with no launcher around it starts its own ranks (bench.launch_ranks: torch.distributed.run as a child process, before any GPU
+# call).  Proves that the piece-wise captured step, the tail-first all-reduce on the side stream, the replica broadcast and the
+# ranks_seen gather execute on hardware; RCCL itself needs 2 GPUs.
 #   [LOG=name] bash tools/ddp_one_gpu.sh [bench.py args]   -> gpurun_out/${LOG:-ddp2_one_gpu}.log   (later args win: --batch 2 ...)
 mkdir -p gpurun_out
 LOG=gpurun_out/${LOG:-ddp2_one_gpu}.log
 export AFAN_BENCH_ONE_DEVICE=1 AFAN_DIST_BACKEND=gloo
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 2 --steps 6 --warmup 5 --batch 128 --no_cpu_baseline "$@" > $LOG 2>&1
-echo "rc=$?"; grep "^{" $LOG | cut -c1-700; grep -i "error\|Traceback" -A8 $LOG | head -30
+python bench.py --gpus 2 --steps 6 --warmup 5 --batch 128 --no_cpu_baseline "$@" > $LOG 2>&1
+echo "rc=$?"; grep "^{" $LOG | cut -c1-900; grep -i "error\|Traceback" -A8 $LOG | head -30

@@ -1,5 +1,5 @@
 // Implicit-GEMM convolution with the WEIGHT operand streamed global -> VGPRs from a fragment-major packed copy (no LDS for
-// it) and only the activation operand staged in LDS by LDS-DMA.  Why (DESIGN.md "Where the convolution stands"): the tiled
+// it) and only the activation operand staged in LDS by LDS-DMA.  Why (NOTES.md section 8, "Where the convolution stands"): the tiled
 // kernel's K loop is bound by memory latency x bytes in flight, and the bytes in flight are capped by LDS capacity
 // (2 workgroups x 1 tile, or 1 x 3 in the deep variant).  Here the weights ride in registers NB K-steps ahead (the VGPR file
 // is 3x the LDS), which both adds in-flight bytes and halves the LDS traffic (writes: A only; reads: 8 instead of 12
