@@ -197,30 +197,47 @@ class _FrozenBlockFn(torch.autograd.Function):
     iteration is bound by Python dispatch (2 600 applies per iteration before this node)."""
 
     @staticmethod
-    def forward(ctx, x, blk, want_pgrad, *params):
-        c1, c2, c3 = blk.conv1, blk.conv2, blk.conv3
-        cd = blk.downsample[0] if blk.downsample is not None else None
-        ks = (blk.bn1._coefs(), blk.bn2._coefs(), blk.bn3._coefs(), blk.downsample[1]._coefs() if cd is not None else None)
-        out, a1, a2 = ops.frozen_bottleneck_fwd(x, c1.out_channels, c2.stride[0],
-                                                (c1.lp_weight(), c2.lp_weight(), c3.lp_weight(), cd.lp_weight() if cd is not None else None), ks)
-        ctx.blk, ctx.pg = blk, want_pgrad
-        ctx.alphas = tuple(None if k is None else k[2] for k in ks)
+    def forward(ctx, x, blk, plan, *params):
+        out, a1, a2 = ops.frozen_bottleneck_fwd_plan(x, plan)
+        ctx.plan = plan
         ctx.save_for_backward(x, a1, a2, out)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, a1, a2, out = ctx.saved_tensors
-        blk = ctx.blk
-        convs = [blk.conv1, blk.conv2, blk.conv3, blk.downsample[0] if blk.downsample is not None else None]
         g = _like_layout(g, out)
         if g.dtype != out.dtype:
             g = g.to(out.dtype)
-        gws = [c.weight.grad if (c is not None and ctx.pg and c.weight.requires_grad) else None for c in convs]
-        dx = ops.frozen_bottleneck_bwd(g, x, a1, a2, out, convs[0].out_channels, convs[1].stride[0],
-                                       [None if c is None else c.lp_weight_t() for c in convs], ctx.alphas, gws,
-                                       ctx.needs_input_grad[0])
+        dx = ops.frozen_bottleneck_bwd_plan(g, x, a1, a2, out, ctx.plan, ctx.needs_input_grad[0])
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+def _block_plan(blk, x):
+    """The block's cached ops.FrozenBlockPlan for this input shape and autograd mode, or False where the one-node form does not
+    apply (then the layer-by-layer modules run).  Valid for one weight epoch (an optimizer step or a shadow refresh bumps
+    _Flags.weight_epoch: low-precision copies, transposed copies and coefficient rows are re-read then)."""
+    if blk._plan_epoch != _Flags.weight_epoch:
+        blk._plans, blk._plan_epoch = {}, _Flags.weight_epoch
+    pg = bool(_Flags.param_grads and torch.is_grad_enabled())
+    if blk._ver is None:      # tensors whose in-place edits (load_state_dict, manual surgery) must invalidate the cached pointers
+        blk._ver = [t for m in blk.modules() if isinstance(m, (nn.Conv2d, nn.BatchNorm2d))
+                    for t in ((m.weight,) if isinstance(m, nn.Conv2d) else (m.weight, m.bias, m.running_mean, m.running_var))]
+    key = (tuple(x.shape), x.device.index, pg, _Flags.wgrad_stash, _WgradStream.ON, _FrozenBlockFn.ON,
+           sum(t._version for t in blk._ver), blk._ver[0].data_ptr())
+    plan = blk._plans.get(key)
+    if plan is None:
+        plan = False
+        if _frozen_block_ok(blk, x):
+            convs = [blk.conv1, blk.conv2, blk.conv3, blk.downsample[0] if blk.downsample is not None else None]
+            ks = (blk.bn1._coefs(), blk.bn2._coefs(), blk.bn3._coefs(), blk.downsample[1]._coefs() if convs[3] is not None else None)
+            gws = [c.weight.grad if (c is not None and pg and c.weight.requires_grad) else None for c in convs]
+            plan = ops.frozen_bottleneck_plan(x, blk.conv1.out_channels, blk.conv2.stride[0],
+                                              tuple(None if c is None else c.lp_weight() for c in convs), ks,
+                                              tuple(None if c is None else c.lp_weight_t() for c in convs),
+                                              tuple(None if k is None else k[2] for k in ks), gws)
+        blk._plans[key] = plan
+    return plan
 
 
 def _frozen_block_ok(blk, x):
@@ -259,11 +276,17 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    _plans, _plan_epoch, _params, _ver = None, -1, None, None
+
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
-        if _frozen_block_ok(self, x):
-            ps = [c.weight for c in (self.conv1, self.conv2, self.conv3)] + ([self.downsample[0].weight] if self.downsample is not None else [])
-            return _FrozenBlockFn.apply(x, self, _Flags.param_grads, *ps)
+        if x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last):
+            plan = _block_plan(self, x)
+            if plan:
+                if self._params is None:
+                    self._params = tuple(c.weight for c in (self.conv1, self.conv2, self.conv3)) + \
+                        ((self.downsample[0].weight,) if self.downsample is not None else ())
+                return _FrozenBlockFn.apply(x, self, plan, *self._params)
         out = self.bn1.fused(self.conv1(x), None, True)
         out = self.bn2.fused(self.conv2(out), None, True)
         res = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))

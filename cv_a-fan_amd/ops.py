@@ -579,6 +579,65 @@ def frozen_bottleneck_fwd(x, planes, stride, ws, ks):
     return out, a1, a2
 
 
+class FrozenBlockPlan:
+    """Everything about one frozen bottleneck at one input shape that does not change between optimizer steps — sizes, scratch
+    requirements, the ctypes pointer objects of its weights / transposed weights / coefficient rows / gradient views — gathered
+    once (det_model._block_plan) so that a block's forward and backward are a few allocations and ONE ctypes call each: the
+    Detection iteration runs 388 block forwards and ~250 block backwards, and at ~100 us of Python per call (eligibility
+    checks, 20 pointer wrappers, four workspace-size queries) the host, not the GPU, set its pace."""
+    __slots__ = ("n", "cin", "h", "w", "ho", "wo", "planes", "co", "stride", "fwd_scratch", "bwd_scratch", "wgrad_ws", "w_ptrs", "k_ptrs",
+                 "wt_ptrs", "al_ptrs", "gw_ptrs", "n_fwd", "n_wgrad", "has_ds", "keep")
+
+
+def frozen_bottleneck_plan(x, planes, stride, ws, ks, wts, als, gws):
+    lib = _lib.load()
+    p = FrozenBlockPlan()
+    p.n, p.cin, p.h, p.w = (int(v) for v in x.shape)
+    p.ho, p.wo = (p.h - 1) // stride + 1, (p.w - 1) // stride + 1
+    p.planes, p.co, p.stride = int(planes), 4 * int(planes), int(stride)
+    p.fwd_scratch = (p.n * (p.planes * p.h * p.w + 2 * p.co * p.ho * p.wo) + 1) // 2
+    p.bwd_scratch = (lib.afan_frozen_bottleneck_bwd_scratch(p.n, p.h, p.w, p.cin, p.planes, p.stride) + 1) // 2
+    shapes = ((p.n, p.ho, p.wo, p.planes, p.co, 1, 1), (p.n, p.h, p.w, p.planes, p.planes, 3, p.stride), (p.n, p.h, p.w, p.cin, p.planes, 1, 1),
+              (p.n, p.h, p.w, p.cin, p.co, 1, p.stride))
+    p.wgrad_ws = sum(lib.afan_conv_wgrad_workspace_floats(*sh) for sh, gw in zip(shapes, (gws[2], gws[1], gws[0], gws[3])) if gw is not None)
+    p.w_ptrs, p.k_ptrs = tuple(_ptr(t) for t in ws), tuple(_ptr(t) for t in ks)
+    p.wt_ptrs, p.al_ptrs, p.gw_ptrs = tuple(_ptr(t) for t in wts), tuple(_ptr(t) for t in als), tuple(_ptr(t) for t in gws)
+    p.has_ds = ws[3] is not None
+    p.n_fwd, p.n_wgrad = 3 + int(p.has_ds), sum(gw is not None for gw in gws)
+    p.keep = (ws, ks, wts, als, gws)              # the tensors behind the pointers
+    return p
+
+
+def frozen_bottleneck_fwd_plan(x, p):
+    lib = _lib.load()
+    cl, dev = torch.channels_last, x.device
+    a1 = torch.empty((p.n, p.planes, p.h, p.w), dtype=torch.bfloat16, device=dev, memory_format=cl)
+    a2 = torch.empty((p.n, p.planes, p.ho, p.wo), dtype=torch.bfloat16, device=dev, memory_format=cl)
+    out = torch.empty((p.n, p.co, p.ho, p.wo), dtype=torch.bfloat16, device=dev, memory_format=cl)
+    scratch = _workspace(x, p.fwd_scratch, "fbk_fwd")
+    CALLS["conv_fwd"] += p.n_fwd
+    w, k = p.w_ptrs, p.k_ptrs
+    check(lib.afan_frozen_bottleneck_fwd(C.c_void_p(x.data_ptr()), p.n, p.h, p.w, p.cin, p.planes, p.stride, w[0], w[1], w[2], w[3], k[0], k[1], k[2], k[3],
+                                         C.c_void_p(scratch.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(a2.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), C.c_void_p(_raw_stream(dev.index))), "afan_frozen_bottleneck_fwd")
+    return out, a1, a2
+
+
+def frozen_bottleneck_bwd_plan(g, x, a1, a2, out, p, want_dx):
+    lib = _lib.load()
+    scratch = _workspace(x, p.bwd_scratch, "fbk_bwd")
+    wws = _workspace(x, p.wgrad_ws, "wgrad") if p.wgrad_ws else None
+    dx = torch.empty_like(x) if want_dx else None
+    CALLS["conv_dgrad"] += 2 + (1 if want_dx else 0) + (1 if (want_dx and p.has_ds) else 0)
+    CALLS["conv_wgrad"] += p.n_wgrad
+    wt, al, gw = p.wt_ptrs, p.al_ptrs, p.gw_ptrs
+    check(lib.afan_frozen_bottleneck_bwd(C.c_void_p(g.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(a2.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), p.n, p.h, p.w, p.cin, p.planes, p.stride, wt[0], wt[1], wt[2], wt[3],
+                                         al[0], al[1], al[2], al[3], gw[0], gw[1], gw[2], gw[3], _ptr(wws), C.c_void_p(scratch.data_ptr()),
+                                         _ptr(dx), C.c_void_p(_raw_stream(x.device.index))), "afan_frozen_bottleneck_bwd")
+    return dx
+
+
 def frozen_bottleneck_bwd(g, x, a1, a2, out, planes, stride, wts, als, gws, want_dx):
     """The backward of the same block in one native call: wts = transposed weights, als = alpha rows, gws = fp32 arena gradient
     views to add into (None entries: not wanted).  Returns dx | None."""
