@@ -240,6 +240,72 @@ def _block_plan(blk, x):
     return plan
 
 
+class _FrozenStageFn(torch.autograd.Function):
+    """A whole stage (layer1 .. layer4: 3 / 4 / 23 / 3 frozen-BatchNorm bottlenecks) as ONE autograd node: the same native calls
+    as one `_FrozenBlockFn` per block, issued in a loop — the per-node cost of `Function.apply` and of the engine's scheduling
+    (~50 us a block and direction on this host) is paid once per stage instead of 33 times per backbone pass, 27 passes per
+    Detection iteration."""
+
+    @staticmethod
+    def forward(ctx, x, plans, *params):
+        saved = []
+        for plan in plans:
+            out, a1, a2 = ops.frozen_bottleneck_fwd_plan(x, plan)
+            saved += [x, a1, a2, out]
+            x = out
+        ctx.plans = plans
+        ctx.save_for_backward(*saved)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        saved, plans = ctx.saved_tensors, ctx.plans
+        last = saved[-1]
+        g = _like_layout(g, last)
+        if g.dtype != last.dtype:
+            g = g.to(last.dtype)
+        for i in range(len(plans) - 1, -1, -1):
+            x, a1, a2, out = saved[4 * i:4 * i + 4]
+            g = ops.frozen_bottleneck_bwd_plan(g, x, a1, a2, out, plans[i], i > 0 or ctx.needs_input_grad[0])
+        return (g, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def _run_stage(stage, x):
+    """`stage(x)` for an nn.Sequential of Bottlenecks: one `_FrozenStageFn` node when every block takes the one-call form at the
+    shape it will see, else block by block."""
+    if not (_FrozenStageFn.ON and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)):
+        return stage(x)
+    plans, shape_probe = [], x
+    for blk in stage:
+        plan = _block_plan(blk, shape_probe)
+        if not plan:
+            return stage(x)
+        plans.append(plan)
+        shape_probe = _ShapeOnly((plan.n, plan.co, plan.ho, plan.wo), x)
+    params = getattr(stage, "_stage_params", None)
+    if params is None:
+        params = stage._stage_params = tuple(p for blk in stage for p in blk._block_params())
+    return _FrozenStageFn.apply(x, tuple(plans), *params)
+
+
+class _ShapeOnly:
+    """What `_block_plan` / `_frozen_block_ok` look at of a block's input, for a tensor that does not exist yet (the previous
+    block's output inside a stage node)."""
+    __slots__ = ("shape", "device", "dtype", "is_cuda")
+
+    def __init__(self, shape, like):
+        self.shape, self.device, self.dtype, self.is_cuda = torch.Size(shape), like.device, like.dtype, like.is_cuda
+
+    def dim(self):
+        return len(self.shape)
+
+    def is_contiguous(self, memory_format=None):
+        return True
+
+
+_FrozenStageFn.ON = os.environ.get("AFAN_DET_STAGE_NODE", "1") != "0"      # 0: one node per block (A/B)
+
+
 def _frozen_block_ok(blk, x):
     """bf16 channels-last map, every convolution of the block on the tuned kernels, trainable weights owned by the arena."""
     if not (_FrozenBlockFn.ON and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
@@ -278,15 +344,18 @@ class Bottleneck(nn.Module):
 
     _plans, _plan_epoch, _params, _ver = None, -1, None, None
 
+    def _block_params(self):
+        if self._params is None:
+            self._params = tuple(c.weight for c in (self.conv1, self.conv2, self.conv3)) + \
+                ((self.downsample[0].weight,) if self.downsample is not None else ())
+        return self._params
+
     def forward(self, x):
         x = _to_compute(x, self.conv1.compute_dtype)
         if x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last):
             plan = _block_plan(self, x)
             if plan:
-                if self._params is None:
-                    self._params = tuple(c.weight for c in (self.conv1, self.conv2, self.conv3)) + \
-                        ((self.downsample[0].weight,) if self.downsample is not None else ())
-                return _FrozenBlockFn.apply(x, self, plan, *self._params)
+                return _FrozenBlockFn.apply(x, self, plan, *self._block_params())
         out = self.bn1.fused(self.conv1(x), None, True)
         out = self.bn2.fused(self.conv2(out), None, True)
         res = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
@@ -344,7 +413,7 @@ class ResNet101(nn.Module):
             for i, st in enumerate([self.layer1, self.layer2, self.layer3], start=1):
                 if i > max(idxs):
                     break
-                x = st(x)
+                x = _run_stage(st, x)
                 if i in idxs:
                     out[i] = x
         return [out[i] for i in idxs]
@@ -357,12 +426,12 @@ class ResNet101(nn.Module):
             assert last in (1, 2, 3)
             x = self._stem(input_dict["x"])
             for st in stages[:last]:
-                x = st(x)
+                x = _run_stage(st, x)
             return x
         assert flag == "tail" and input_dict["out_idx"] in (1, 2, 3)
         x = _enter(input_dict["adv"], self.conv1.compute_dtype, self.normal.channels_last)
         for st in stages[input_dict["out_idx"]:]:
-            x = st(x)
+            x = _run_stage(st, x)
         return x
 
 
@@ -380,14 +449,19 @@ def _fg_bg_sample(labels, n_fg, n_total):
 
 def _per_image_losses(logits, deltas, gt_labels, gt_deltas, batch_size, batch_indices, beta):
     """region_proposal_network.py:163-185 == model.py:343-367: per image, mean cross-entropy over its samples and the
-    beta-smooth-L1 of its foreground samples."""
-    ce = torch.empty(batch_size, dtype=torch.float, device=logits.device)
-    sl1 = torch.empty(batch_size, dtype=torch.float, device=deltas.device)
-    for b in range(batch_size):
-        sel = (batch_indices == b).nonzero().view(-1)
-        ce[b] = F.cross_entropy(input=logits[sel], target=gt_labels[sel])
-        fg = gt_labels[sel].nonzero().view(-1)
-        sl1[b] = beta_smooth_l1(deltas[sel][fg], gt_deltas[sel][fg], beta)
+    beta-smooth-L1 of its foreground samples (sum over the 4 coordinates / (4 x foreground samples + 1e-8): extension/functional.py).
+    Written with per-sample terms and 0 / 1 masks instead of the reference's `nonzero()` index lists (two host synchronisations per
+    image and call, 66 per Detection iteration): the same sums over the same samples — an image without samples gives nan for its
+    cross-entropy (the mean of nothing) and one without foreground 0 for its smooth-L1, like the reference."""
+    ce_i = F.cross_entropy(input=logits, target=gt_labels, reduction="none")
+    d = torch.abs(deltas - gt_deltas)
+    sl_i = torch.where(d < beta, 0.5 * d ** 2 / beta, d - 0.5 * beta).sum(dim=1)
+    fg = (gt_labels != 0).to(sl_i.dtype)
+    if batch_size == 1:                                  # (every sample belongs to image 0)
+        return (ce_i.sum() / ce_i.numel()).view(1), ((sl_i * fg).sum() / (4.0 * fg.sum() + 1e-8)).view(1)
+    m = (batch_indices.view(1, -1) == torch.arange(batch_size, device=logits.device).view(-1, 1)).to(ce_i.dtype)      # [B, S]
+    ce = (m * ce_i.view(1, -1)).sum(dim=1) / m.sum(dim=1)
+    sl1 = (m * (sl_i * fg).view(1, -1)).sum(dim=1) / (4.0 * (m * fg.view(1, -1)).sum(dim=1) + 1e-8)
     return ce, sl1
 
 
@@ -403,6 +477,7 @@ class RegionProposalNetwork(nn.Module):
         self._anchor_smooth_l1_loss_beta = anchor_smooth_l1_loss_beta
         self._anchor_objectness = Conv2d(512, num_anchors * 2, kernel_size=1)
         self._anchor_transformer = Conv2d(512, num_anchors * 4, kernel_size=1)
+        self._inside_cache = {}
 
     # -- layers
     def _trunk(self, features):
@@ -425,8 +500,17 @@ class RegionProposalNetwork(nn.Module):
     # -- training targets (:58-105; the reference repeats this block in its 'clean' and 'tail' branches)
     def _losses(self, objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height):
         b = anchor_bboxes.shape[0]
-        inside = ((anchor_bboxes[..., 0] >= 0) * (anchor_bboxes[..., 1] >= 0) * (anchor_bboxes[..., 2] <= image_width) *
-                  (anchor_bboxes[..., 3] <= image_height)).nonzero().unbind(dim=1)
+        # (the anchors inside the image: a function of the cached anchor grid, computed — and synchronised on — once per grid)
+        ikey = (anchor_bboxes.data_ptr(), tuple(anchor_bboxes.shape), int(image_width), int(image_height))
+        inside = self._inside_cache.get(ikey)
+        if inside is None:
+            inside = ((anchor_bboxes[..., 0] >= 0) * (anchor_bboxes[..., 1] >= 0) * (anchor_bboxes[..., 2] <= image_width) *
+                      (anchor_bboxes[..., 3] <= image_height)).nonzero().unbind(dim=1)
+            if len(self._inside_cache) > 64:
+                self._inside_cache.clear()
+            self._inside_cache[ikey] = (inside, anchor_bboxes)          # (holding the grid keeps its address from being reused)
+        else:
+            inside = inside[0]
         in_boxes = anchor_bboxes[inside].view(b, -1, 4)
         in_obj = objectnesses[inside].view(b, -1, 2)
         in_tr = transformers[inside].view(b, -1, 4)
@@ -665,7 +749,7 @@ class Model(nn.Module):
 
         def _roi_features(self, features, boxes, batch_indices):
             """Pooler -> layer4 -> global max: [R, 2048, 1, 1]."""
-            h = self.hidden(pool_rois(features, boxes, batch_indices, self._pooler_mode))
+            h = _run_stage(self.hidden, _to_compute(pool_rois(features, boxes, batch_indices, self._pooler_mode), self.hidden[0].conv1.compute_dtype))
             return _GlobalMaxFn.apply(h)
 
         def _linears(self, hidden):
@@ -679,8 +763,9 @@ class Model(nn.Module):
             max_ious, assign = box_iou(proposal_bboxes, gt_bboxes_batch).max(dim=2)
             labels[max_ious < 0.5] = 0
             fg = max_ious >= 0.5
-            if len(fg.nonzero()) > 0:
-                labels[fg] = gt_classes_batch[fg.nonzero()[:, 0], assign[fg]]
+            fgi = fg.nonzero()                              # (one host read for both uses)
+            if len(fgi) > 0:
+                labels[fg] = gt_classes_batch[fgi[:, 0], assign[fg]]
             sel = _fg_bg_sample(labels, 32 * b, 128 * b)
             boxes = proposal_bboxes[sel]
             return boxes, labels[sel], box_deltas(boxes, gt_bboxes_batch[sel[0], assign[sel]]), sel[0]
