@@ -29,18 +29,24 @@ int afan_frozen_bottleneck_fwd(const void* x, int64_t n, int64_t h, int64_t w, i
     uint16_t* r3 = r1 + n * planes * h * w;                  // [n, co, ho, wo]
     uint16_t* rd = r3 + n * co * ho * wo;                    // [n, co, ho, wo]: the projection branch, raw then normalised in place
     int e;
-    if ((e = afan_conv_fwd_nhwc_bf16(x, w1, r1, n, h, w, cin, planes, 1, 1, 1, nullptr, nullptr, nullptr, 1, stream))) return e;
-    if ((e = afan_affine_apply(r1, nullptr, a1, AFAN_BF16, n, planes, h * w, k1, 1, stream))) return e;
-    if ((e = afan_conv_fwd_nhwc_bf16(a1, w2, r1, n, h, w, planes, planes, 3, stride, 1, nullptr, nullptr, nullptr, 1, stream))) return e;
-    if ((e = afan_affine_apply(r1, nullptr, a2, AFAN_BF16, n, planes, ho * wo, k2, 1, stream))) return e;
+    // a convolution and its frozen BatchNorm (+ residual) (+ ReLU) as ONE launch where the tiled kernel takes the shape
+    // (afan_conv_fwd_affine_nhwc_bf16: the same bits), else the two launches
+    auto conv_bn = [&](const void* in, const void* wt, void* raw, void* dst, int64_t hi_, int64_t wi_, int64_t ci_, int64_t co_, int k, int st_,
+                       const float* kc, const void* res, int relu) -> int {
+        int rc = afan_conv_fwd_affine_nhwc_bf16(in, wt, dst, n, hi_, wi_, ci_, co_, k, st_, kc, res, relu, stream);
+        if (rc != AFAN_ESHAPE) return rc;
+        if ((rc = afan_conv_fwd_nhwc_bf16(in, wt, raw, n, hi_, wi_, ci_, co_, k, st_, 1, nullptr, nullptr, nullptr, 1, stream))) return rc;
+        const int64_t ho_ = (hi_ - 1) / st_ + 1, wo_ = (wi_ - 1) / st_ + 1;
+        return afan_affine_apply(raw, res, dst, AFAN_BF16, n, co_, ho_ * wo_, kc, relu, stream);
+    };
+    if ((e = conv_bn(x, w1, r1, a1, h, w, cin, planes, 1, 1, k1, nullptr, 1))) return e;
+    if ((e = conv_bn(a1, w2, r1, a2, h, w, planes, planes, 3, stride, k2, nullptr, 1))) return e;
     const void* res = x;
     if (wd) {
-        if ((e = afan_conv_fwd_nhwc_bf16(x, wd, rd, n, h, w, cin, co, 1, stride, 1, nullptr, nullptr, nullptr, 1, stream))) return e;
-        if ((e = afan_affine_apply(rd, nullptr, rd, AFAN_BF16, n, co, ho * wo, kd, 0, stream))) return e;      // elementwise: in place
+        if ((e = conv_bn(x, wd, rd, rd, h, w, cin, co, 1, stride, kd, nullptr, 0))) return e;      // (raw == dst: the apply is elementwise)
         res = rd;
     }
-    if ((e = afan_conv_fwd_nhwc_bf16(a2, w3, r3, n, ho, wo, planes, co, 1, 1, 1, nullptr, nullptr, nullptr, 1, stream))) return e;
-    return afan_affine_apply(r3, res, out, AFAN_BF16, n, co, ho * wo, k3, 1, stream);
+    return conv_bn(a2, w3, r3, out, ho, wo, planes, co, 1, 1, k3, res, 1);
 }
 
 // bf16 elements of scratch the backward needs: two gradient buffers of the larger shapes
@@ -75,12 +81,18 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
     uint16_t* dxs = d1 + n * planes * h * w;                 // [n, cin, h, w]
     int e;
     if ((e = afan_affine_relu_bwd(g, out, al3, d3, dres, AFAN_BF16, AFAN_NHWC, n, co, ho * wo, 1, stream))) return e;
-    if ((e = afan_conv_dgrad_nhwc_bf16(d3, wt3, t2, n, ho, wo, planes, co, 1, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                       nullptr, 1, stream))) return e;
-    if ((e = afan_affine_relu_bwd(t2, a2, al2, d2, nullptr, AFAN_BF16, AFAN_NHWC, n, planes, ho * wo, 1, stream))) return e;
-    if ((e = afan_conv_dgrad_nhwc_bf16(d2, wt2, t1, n, h, w, planes, planes, 3, stride, 1, nullptr, nullptr, nullptr, 0, nullptr,
-                                       nullptr, nullptr, 1, stream))) return e;
-    if ((e = afan_affine_relu_bwd(t1, a1, al1, d1, nullptr, AFAN_BF16, AFAN_NHWC, n, planes, h * w, 1, stream))) return e;
+    // an input gradient and the backward of the frozen BatchNorm + ReLU it runs into as ONE launch where the tiled kernel takes the
+    // shape (afan_conv_dgrad_affine_nhwc_bf16: the same bits), else the two launches
+    auto dgrad_bn = [&](const void* dyp, const void* wt, void* raw, void* dst, int64_t hi_, int64_t wi_, int64_t ci_, int64_t co_, int k, int st_,
+                        const float* al, const void* act) -> int {
+        int rc = afan_conv_dgrad_affine_nhwc_bf16(dyp, wt, dst, n, hi_, wi_, ci_, co_, k, st_, al, act, stream);
+        if (rc != AFAN_ESHAPE) return rc;
+        if ((rc = afan_conv_dgrad_nhwc_bf16(dyp, wt, raw, n, hi_, wi_, ci_, co_, k, st_, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                            nullptr, 1, stream))) return rc;
+        return afan_affine_relu_bwd(raw, act, al, dst, nullptr, AFAN_BF16, AFAN_NHWC, n, ci_, hi_ * wi_, 1, stream);
+    };
+    if ((e = dgrad_bn(d3, wt3, t2, d2, ho, wo, planes, co, 1, 1, al2, a2))) return e;
+    if ((e = dgrad_bn(d2, wt2, t1, d1, h, w, planes, planes, 3, stride, al1, a1))) return e;
     const void* addend = dres;
     if (wtd) {
         if ((e = afan_affine_relu_bwd(dres, nullptr, ald, dres, nullptr, AFAN_BF16, AFAN_NHWC, n, co, ho * wo, 0, stream))) return e;   // dd, in place

@@ -585,17 +585,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool ch_ok = n0 + pc * 8 < pp.Co;      // this thread's 8 output channels exist (Co % 8 == 0)
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
+    const uint16_t* addp = pp.aff ? pp.aff_res : pp.addend;     // the one extra output-shaped operand of either fusion
     u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];
     {
         const int out_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
-        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.addend), 0, pp.addend ? out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), 0, addp ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bnx), 0, bn_bwd ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bny), 0, (bn_bwd && pp.bny) ? out_bytes : 0, 0x00020000);
 #pragma unroll
         for (int q = 0; q < EPI_ROWS; ++q) {
             const int off = epi_on ? out_off[pr + q * ROWS_PER_PASS] : -1;
             const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
-            if (pp.addend) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
+            if (addp) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
             if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
             if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
         }
@@ -621,8 +622,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         s1[j] = s2[j] = 0.f;
         const int c = ch_ok ? n0 + pc * 8 + j : 0;
         sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && shift_p) ? shift_p[c] : 0.f);   // mean or shift
-        al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : 0.f;
-        be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : 0.f;
+        al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : (pp.aff ? pp.aff[(pp.aff_bwd ? 0 : 2 * pp.Co) + c] : 0.f);
+        be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : ((pp.aff && !pp.aff_bwd) ? pp.aff[3 * pp.Co + c] : 0.f);
     }
 #pragma unroll
     for (int q = 0; q < EPI_ROWS; ++q) {
@@ -631,7 +632,28 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         if (off >= 0 && ch_ok) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
-            if (pp.addend) {
+            if (pp.aff && pp.aff_bwd) {
+                // the backward of the frozen BatchNorm + ReLU in front of this convolution, on the bf16-rounded input gradient:
+                // affine_bwd_kernel's expression (mask from the stored activation, then the plain multiply)
+                const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = (bf2f(a[j]) > 0.f) ? bf2f(v[j]) : 0.f;
+                    t *= al[j];
+                    v[j] = f2bf(t);
+                }
+            } else if (pp.aff) {
+                // a frozen BatchNorm (+ residual) (+ ReLU) on the bf16-rounded convolution output: afan_nhwc::apply_kernel's
+                // expression, term for term (fmaf, then the residual, then the NaN-passing ReLU)
+                const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = fmaf(bf2f(v[j]), al[j], be[j]);
+                    if (pp.aff_res) t += bf2f(a[j]);
+                    if (pp.aff_relu) t = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+                    v[j] = f2bf(t);
+                }
+            } else if (pp.addend) {
                 const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
@@ -903,7 +925,7 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
 static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                       int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                       const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials, double* bn_acc, int groups,
-                      afan_stream_t stream) {
+                      afan_stream_t stream, const float* aff_alpha = nullptr, const void* aff_act = nullptr) {
     int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
     if (e) return e;
     if (!dy || !wt || !dx) return AFAN_ENULL;
@@ -928,6 +950,12 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
     }
     p.max_pad = dilation;
     p.addend = (const uint16_t*)addend;
+    if (aff_alpha) {                                         // the layer in front's frozen BatchNorm + ReLU backward in the epilogue
+        if (!aff_act) return AFAN_ENULL;
+        if (addend || bn_partials || bn_acc || dy_sc || groups > 1 || !aligned(aff_act, 16)) return AFAN_ESHAPE;
+        if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;      // (that kernel's epilogue has no such form)
+        p.aff = aff_alpha; p.aff_res = (const uint16_t*)aff_act; p.aff_bwd = 1;
+    }
     if (bn_partials && bn_acc) return AFAN_ESHAPE;
     if (bn_partials || bn_acc) {
         if (!bn_x || !bn_stats) return AFAN_ENULL;
@@ -960,7 +988,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
                 const int t = r * k + s;
                 c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
             }
-        if (small_eligible(p)) return small_launch(p, st);
+        if (small_eligible(p)) return p.aff ? AFAN_ESHAPE : small_launch(p, st);
         if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
         return dispatch(p, st, true);
     }
@@ -995,7 +1023,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
             ++nc;
         }
     p.n_classes = nc;
-    if (!dy_sc && small_eligible(p)) return small_launch(p, st);
+    if (!dy_sc && small_eligible(p)) return p.aff ? AFAN_ESHAPE : small_launch(p, st);
     if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
     return dispatch(p, st, true);
 }
@@ -1068,6 +1096,43 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
         q.acc = stats_acc; q.acc_ns = p.acc_ns; q.shift = stats_shift;
         return afan_c64::launch(q, st);
     }
+    return dispatch(p, st, false);
+}
+
+// The same convolution with a FROZEN BatchNorm (+ residual) (+ ReLU) applied in its epilogue: y = [relu](bf16(conv(x, w)) * alpha
+// + beta [+ residual]), coefs = an afan_affine_coefs block — bit for bit the convolution launch followed by afan_affine_apply,
+// without the raw tensor's round trip and the second launch (Detection's frozen bottlenecks: seven launches of 5-13 us per block
+// become three or four).  Shapes of the tiled kernel only: AFAN_ESHAPE for the stem, the small-channel and the 64 -> 64
+// weights-in-registers kernels (their epilogues have no such form; the caller issues the two launches).
+int afan_conv_fwd_affine_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co,
+                                   int k, int stride, const float* coefs, const void* residual, int relu, afan_stream_t stream) {
+    int e = check_dims(n, hi, wi, ci, co, k, stride, 1);
+    if (e) return e;
+    if (!x || !w || !y || !coefs) return AFAN_ENULL;
+    if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y, 16) || (residual && !aligned(residual, 16))) return AFAN_EALIGN;
+    if (ci % 8 != 0 || co % 8 != 0 || ci < 40 || co < 40) return AFAN_ESHAPE;
+    const int pad = k / 2;
+    ConvP p{};
+    p.max_pad = 1;
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y;
+    p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
+    p.Ho = (int)((hi + 2 * pad - k) / stride + 1); p.Wo = (int)((wi + 2 * pad - k) / stride + 1); p.Co = (int)co;
+    p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = 1;
+    p.acc_ns = afan_nhwc::acc_slot_count(co);
+    if ((e = set_groups(p, 1, n, (int64_t)p.Ho * p.Wo, co, false))) return e;
+    p.aff = coefs; p.aff_res = (const uint16_t*)residual; p.aff_relu = relu ? 1 : 0;
+    ConvClass& c0 = p.cls[0];
+    c0.Hg = p.Ho; c0.Wg = p.Wo; c0.out_h0 = 0; c0.out_w0 = 0; c0.T = k * k;
+    for (int r = 0; r < k; ++r)
+        for (int s = 0; s < k; ++s) {
+            const int t = r * k + s;
+            c0.dh[t] = r - pad; c0.dw[t] = s - pad; c0.wofs[t] = (int)(t * ci);
+        }
+    if (small_eligible(p) || afan_c64::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const double M = (double)n * p.Ho * p.Wo;
+    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co * (residual ? 2 : 1) + (double)n * hi * wi * ci + (double)co * k * k * ci),
+                    2.0 * M * co * k * k * ci, st);
     return dispatch(p, st, false);
 }
 
@@ -1166,6 +1231,17 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                               double* bn_acc, int groups, afan_stream_t stream) {
     return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, k, stride, dilation, addend, bn_x, bn_stats, bn_relu, bn_y,
                       bn_partials, bn_acc, groups, stream);
+}
+
+// The input gradient of a convolution whose INPUT came out of a frozen BatchNorm + ReLU (Detection's bottlenecks), with that layer's
+// backward applied on the way out: dx = bf16((act > 0 ? bf16(dgrad(dy)) : 0) * alpha[c]) — bit for bit afan_conv_dgrad_nhwc_bf16
+// followed by afan_affine_relu_bwd(relu = 1), without the raw gradient's round trip and the second launch.  alpha = that layer's
+// alpha row [ci], act = its stored output [n, ci, hi, wi].  AFAN_ESHAPE where another kernel owns the shape.
+int afan_conv_dgrad_affine_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co,
+                                     int k, int stride, const float* alpha, const void* act, afan_stream_t stream) {
+    if (!alpha || !act) return AFAN_ENULL;
+    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, k, stride, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 1, stream,
+                      alpha, act);
 }
 
 // The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77, option B):

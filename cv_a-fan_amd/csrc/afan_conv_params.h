@@ -40,6 +40,12 @@ struct ConvP {
     int groups;                  // 1, or 2: the batch is two concatenated half-batches with SEPARATE BatchNorm statistics
     int acc_stride;              //   (adv | clean): images >= N/2 use acc + acc_stride (doubles) and bn_stats + 4*Co
     const uint16_t* addend;      // optional tensor of y's shape added to y before it is stored (residual-gradient sum)
+    const float* aff;            // optional [4][Co] coefficient block (mean | invstd | alpha | beta) of a FROZEN BatchNorm behind this
+    const uint16_t* aff_res;     //   convolution: y = [relu](bf16(conv) * alpha + beta [+ aff_res]) — the arithmetic, rounding points
+    int aff_relu;                //   included, of the convolution launch followed by afan_affine_apply (Detection's bottlenecks)
+    int aff_bwd;                 // 1: the BACKWARD of such a layer applied to an input gradient on its way out: aff = that layer's alpha
+                                 //   row [Co], aff_res = its stored OUTPUT: y = bf16((aff_res > 0 ? bf16(dgrad) : 0) * alpha) —
+                                 //   afan_affine_relu_bwd's expression on the dgrad launch's rounded result
     int64_t a_extra;             // bytes beyond the gathered tensor x that taps with aofs != 0 may reach (descriptor range)
     int multi;                   // 1: the classes are INDEPENDENT forward problems on the same input (ASPP's atrous branches,
     int64_t w_off[4];            //   _deeplab.py:173-176): class z reads weights w + w_off[z], writes y + y_off[z] (elements),

@@ -813,6 +813,26 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
     return (y, st) if want_stats else y
 
 
+def conv_fwd_affine(x, w, stride, coefs, residual=None, relu=False):
+    """[relu](bf16(conv2d(x, w)) * alpha + beta [+ residual]) in ONE launch (afan_conv_fwd_affine_nhwc_bf16): a convolution with the
+    frozen BatchNorm behind it in its epilogue.  Returns None where the shape belongs to a kernel without that epilogue (the
+    caller issues conv_fwd + affine_apply: the same bits)."""
+    lib = _lib.load()
+    _cl4(x, "x"), _cl4(w, "w")
+    n, ci, hi, wi = x.shape
+    co, _, k, _ = w.shape
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    y = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    rc = lib.afan_conv_fwd_affine_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), n, hi, wi, ci, co, k, int(stride), _ptr(coefs), _ptr(residual),
+                                            int(bool(relu)), _stream(x))
+    if rc == -3:
+        return None
+    check(rc, "afan_conv_fwd_affine_nhwc_bf16")
+    CALLS["conv_fwd"] += 1
+    return y
+
+
 def conv_fwd_multi_ok(x, ws, stride):
     """Problems on one bf16 channels-last input with one output shape (same Co, k in {1, 3}), on the tiled kernel, BatchNorm
     moments in accumulator blocks."""
@@ -1257,6 +1277,24 @@ def maxpool2d_backward(dy, idx, in_shape, k, stride, pad=0, x=None, channels_las
         raise ValueError("dy must have the forward output's memory layout")
     check(lib.afan_maxpool2d_bwd(_ptr(dy), _ptr(x), _ptr(idx), _ptr(dx), _DT[dy.dtype], lay, n, c, hi, wi, int(k), int(stride),
                                  int(pad), _stream(dy)), "afan_maxpool2d_bwd")
+    return dx
+
+
+def conv_dgrad_affine(dy, wt, in_hw, stride, alpha, act):
+    """dx = bf16((act > 0 ? bf16(dgrad(dy, wt)) : 0) * alpha[c]) in ONE launch (afan_conv_dgrad_affine_nhwc_bf16): an input gradient
+    with the backward of the frozen BatchNorm + ReLU it runs into.  None where another kernel owns the shape (the caller issues
+    conv_dgrad + affine_relu_backward: the same bits)."""
+    lib = _lib.load()
+    _cl4(dy, "dy"), _cl4(wt, "wt"), _cl4(act, "act")
+    n, co, ho, wo = dy.shape
+    ci, _, k, _ = wt.shape
+    hi, wi = in_hw
+    dx = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    rc = lib.afan_conv_dgrad_affine_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), n, hi, wi, ci, co, k, int(stride), _ptr(alpha), _ptr(act), _stream(dy))
+    if rc == -3:
+        return None
+    check(rc, "afan_conv_dgrad_affine_nhwc_bf16")
+    CALLS["conv_dgrad"] += 1
     return dx
 
 

@@ -258,6 +258,12 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
                             int64_t co, int k, int stride, int dilation, float* stats_partials, const float* stats_shift,
                             double* stats_acc, int groups, afan_stream_t stream);
 
+/* afan_conv_fwd_affine_nhwc_bf16 — a convolution of Detection's frozen-BatchNorm backbone (backbone/resnet101_ori.py:97-119 under
+ * model.py:27-35,46-47: every BatchNorm in eval mode) with that BatchNorm (+ the block's residual) (+ ReLU) applied in the epilogue:
+ * y = [relu](bf16(conv(x, w)) * alpha + beta [+ residual]); coefs = an afan_affine_coefs block [4][co].  Bit for bit
+ * afan_conv_fwd_nhwc_bf16 followed by afan_affine_apply.  AFAN_ESHAPE for shapes the stem / small-channel / 64 -> 64 kernels take. */
+int afan_conv_fwd_affine_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co,
+                                   int k, int stride, const float* coefs, const void* residual, int relu, afan_stream_t stream);
 /* nb (1..4) forward convolutions on the SAME input x with the SAME output shape in ONE launch: w[b] / y[b] / ksize[b] (1 or 3)
  * / dilation[b] per problem (host arrays; device pointers inside), BatchNorm moments of y[b] around stats_shift[b] into the
  * f64 accumulator block stats_acc[b] (both arrays NULL: no moments).  (1) The atrous branches of ASPP,
@@ -283,6 +289,12 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
                               const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials,
                               double* bn_acc, int groups, afan_stream_t stream);
 
+/* afan_conv_dgrad_affine_nhwc_bf16 — the input gradient of a convolution whose input came out of a frozen BatchNorm + ReLU
+ * (backbone/resnet101_ori.py:97-119 under model.py:27-35,46-47), with that layer's backward applied in the epilogue:
+ * dx = bf16((act > 0 ? bf16(dgrad(dy)) : 0) * alpha[c]); alpha = the layer's alpha row [ci], act = its stored output.  Bit for bit
+ * afan_conv_dgrad_nhwc_bf16 followed by afan_affine_relu_bwd(relu = 1).  AFAN_ESHAPE where another kernel owns the shape. */
+int afan_conv_dgrad_affine_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co,
+                                     int k, int stride, const float* alpha, const void* act, afan_stream_t stream);
 /* The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77 with the
  * option-B projection): dx = conv_transpose(dy, w1: 3x3 / 2, pad 1) + conv_transpose(dy_sc, w_sc: 1x1 / 2) — what autograd
  * computes as two input gradients and a sum at main_perturb.py:200 / attack_algo.py:52.  dy, dy_sc: [N, hi/2, wi/2, co] bf16

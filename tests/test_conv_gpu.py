@@ -539,3 +539,52 @@ def test_wgrad_multi_equals_separate_launches(pkg, gpu, shapes):
     ops.conv_wgrad_multi(items)
     for it, ref in zip(items, refs):
         assert torch.equal(it[5], ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 1024, 256, 38, 57, 1, 1), (1, 256, 256, 38, 57, 3, 1), (1, 256, 1024, 38, 57, 1, 1), (2, 512, 512, 30, 41, 3, 2),
+                                   (1, 512, 2048, 38, 57, 1, 2), (128, 512, 512, 7, 7, 3, 1), (3, 64, 256, 20, 24, 1, 1)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_conv_with_frozen_batchnorm_epilogue_equals_two_launches(pkg, gpu, shape, res, relu):
+    """afan_conv_fwd_affine_nhwc_bf16 (Detection's frozen bottlenecks: convolution + BatchNorm(eval) (+ residual) (+ ReLU) in one
+    launch) against the convolution launch followed by afan_affine_apply: the same bits."""
+    n, ci, co, h, w, k, st = shape
+    g = torch.Generator().manual_seed(ci + co + k)
+    cl = torch.channels_last
+    x = torch.randn(n, ci, h, w, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl)
+    wt = (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(gpu).bfloat16().contiguous(memory_format=cl)
+    mean, var = torch.randn(co, generator=g).to(gpu), (torch.rand(co, generator=g) + 0.5).to(gpu)
+    coefs = pkg.ops.affine_coefs(mean, torch.rsqrt(var + 1e-5), (torch.rand(co, generator=g) + 0.5).to(gpu), torch.randn(co, generator=g).to(gpu))
+    raw = pkg.ops.conv_fwd(x, wt, st)
+    r = torch.randn(raw.shape, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl) if res else None
+    want = pkg.ops.affine_apply(raw, coefs, r, relu)
+    got = pkg.ops.conv_fwd_affine(x, wt, st, coefs, r, relu)
+    assert got is not None and got.stride() == want.stride()
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+def test_conv_with_frozen_batchnorm_epilogue_declines_other_kernels_shapes(pkg, gpu):
+    cl = torch.channels_last
+    x = torch.randn(2, 64, 32, 32, device=gpu).bfloat16().contiguous(memory_format=cl)
+    w = torch.randn(64, 64, 3, 3, device=gpu).bfloat16().contiguous(memory_format=cl)
+    coefs = pkg.ops.affine_coefs(torch.zeros(64, device=gpu), torch.ones(64, device=gpu), torch.ones(64, device=gpu), torch.zeros(64, device=gpu))
+    assert pkg.ops.conv_fwd_affine(x, w, 1, coefs) is None            # the 64 -> 64 weights-in-registers kernel's shape
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 1024, 38, 57, 1, 1), (1, 256, 256, 38, 57, 3, 1), (2, 512, 512, 30, 41, 3, 2), (128, 512, 2048, 7, 7, 1, 1),
+                                   (1, 128, 128, 75, 113, 3, 2), (3, 64, 256, 20, 24, 1, 1)])
+def test_dgrad_with_frozen_batchnorm_backward_epilogue_equals_two_launches(pkg, gpu, shape):
+    """afan_conv_dgrad_affine_nhwc_bf16 (an input gradient + the backward of the frozen BatchNorm + ReLU in front of that convolution
+    in one launch, stride 1 and the four parity classes of stride 2) against afan_conv_dgrad_nhwc_bf16 followed by
+    afan_affine_relu_bwd: the same bits."""
+    n, ci, co, h, w, k, st = shape
+    g = torch.Generator().manual_seed(ci + co + k + st)
+    cl = torch.channels_last
+    ho, wo = (h - 1) // st + 1, (w - 1) // st + 1
+    dy = torch.randn(n, co, ho, wo, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl)
+    wt = (torch.randn(ci, co, k, k, generator=g) / (co * k * k) ** 0.5).to(gpu).bfloat16().contiguous(memory_format=cl)
+    act = torch.relu(torch.randn(n, ci, h, w, generator=g)).to(gpu).bfloat16().contiguous(memory_format=cl)      # ~half zeros
+    alpha = (torch.rand(ci, generator=g) + 0.5).to(gpu)
+    raw = pkg.ops.conv_dgrad(dy, wt, (h, w), st)
+    want, _ = pkg.ops.affine_relu_backward(raw, act, alpha, True)
+    got = pkg.ops.conv_dgrad_affine(dy, wt, (h, w), st, alpha, act)
+    assert got is not None and torch.equal(got, want), float((got.float() - want.float()).abs().max())
