@@ -5,9 +5,16 @@
 // by Python dispatch — seven ctypes calls of ~20 us each per block and pass, 390 block passes per iteration — and this is
 // the runtime answering that in native code.
 #include "afan_common.h"
+#include <stdlib.h>
 #include "../../include/afan_hip.h"
 
 using namespace afan;
+
+// AFAN_BLOCK_FUSE_AFFINE=0: every frozen BatchNorm as its own launch again (A/B of the epilogue forms)
+static bool fuse_affine() {
+    static const int on = [] { const char* e = getenv("AFAN_BLOCK_FUSE_AFFINE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
 
 extern "C" {
 
@@ -33,7 +40,7 @@ int afan_frozen_bottleneck_fwd(const void* x, int64_t n, int64_t h, int64_t w, i
     // (afan_conv_fwd_affine_nhwc_bf16: the same bits), else the two launches
     auto conv_bn = [&](const void* in, const void* wt, void* raw, void* dst, int64_t hi_, int64_t wi_, int64_t ci_, int64_t co_, int k, int st_,
                        const float* kc, const void* res, int relu) -> int {
-        int rc = afan_conv_fwd_affine_nhwc_bf16(in, wt, dst, n, hi_, wi_, ci_, co_, k, st_, kc, res, relu, stream);
+        int rc = fuse_affine() ? afan_conv_fwd_affine_nhwc_bf16(in, wt, dst, n, hi_, wi_, ci_, co_, k, st_, kc, res, relu, stream) : AFAN_ESHAPE;
         if (rc != AFAN_ESHAPE) return rc;
         if ((rc = afan_conv_fwd_nhwc_bf16(in, wt, raw, n, hi_, wi_, ci_, co_, k, st_, 1, nullptr, nullptr, nullptr, 1, stream))) return rc;
         const int64_t ho_ = (hi_ - 1) / st_ + 1, wo_ = (wi_ - 1) / st_ + 1;
@@ -85,7 +92,7 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
     // shape (afan_conv_dgrad_affine_nhwc_bf16: the same bits), else the two launches
     auto dgrad_bn = [&](const void* dyp, const void* wt, void* raw, void* dst, int64_t hi_, int64_t wi_, int64_t ci_, int64_t co_, int k, int st_,
                         const float* al, const void* act) -> int {
-        int rc = afan_conv_dgrad_affine_nhwc_bf16(dyp, wt, dst, n, hi_, wi_, ci_, co_, k, st_, al, act, stream);
+        int rc = fuse_affine() ? afan_conv_dgrad_affine_nhwc_bf16(dyp, wt, dst, n, hi_, wi_, ci_, co_, k, st_, al, act, stream) : AFAN_ESHAPE;
         if (rc != AFAN_ESHAPE) return rc;
         if ((rc = afan_conv_dgrad_nhwc_bf16(dyp, wt, raw, n, hi_, wi_, ci_, co_, k, st_, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                             nullptr, 1, stream))) return rc;
