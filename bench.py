@@ -312,7 +312,13 @@ def main():
         def one(i):
             return trainer.step(xs[i % nbuf], ys[i % nbuf][0], ys[i % nbuf][1])
 
-        one_eager = one
+        def one_eager(i):          # the instrumented pass times launches with events: the backbone stages un-replayed
+            old_ = pkg.det_model._StageGraphs.ON
+            pkg.det_model._StageGraphs.ON = False
+            try:
+                return one(i)
+            finally:
+                pkg.det_model._StageGraphs.ON = old_
     elif seg:
         model = pkg.deeplab.MODELS[args.arch](num_classes=21, output_stride=16)
         model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
@@ -380,7 +386,7 @@ def main():
 
     # ---- instrumented pass (not part of `value`): per-launch HIP-event timing of the hand-written kernels ----
     roof, kernels, conv_exec, hbm = None, None, None, None
-    graphed = trainer._graph is not None
+    graphed = trainer._graph is not None or (det and bool(pkg.det_model._StageGraphs.cache))
     NP = 2
     if not args.no_roofline:
         # per-launch event timing needs eager launches: the same step body, un-captured.  EVERY rank runs it (the step
@@ -477,7 +483,11 @@ def main():
             workload = (f"{args.arch} (frozen-BatchNorm ResNet-101, RPN 9 anchors, ROIAlign pooler), VOC-shape {side[0]}x{side[1]} synthetic, "
                         f"image PGD 5 steps + 3 one-step feature PGDs + ROI-feature PGD, 5 SAT points, {args.dtype}, batch {args.batch}/GPU, "
                         f"internal layout {args.layout} (BASELINE configs[4], per-GPU share)")
-            sched = "train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling); eager launches"
+            sched = ("train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling); the backbone's stages "
+                     "(frozen-BatchNorm bottlenecks, BatchNorm in the convolution epilogues) replayed from hipGraphs forward and backward, "
+                     "RPN / proposal / ROI heads launched eagerly (their shapes follow the proposals)"
+                     if pkg.det_model._StageGraphs.ON and pkg.det_model._StageGraphs.cache else
+                     "train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling); eager launches")
         elif seg:
             metric = f"images/sec (whole node) Segmentation A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}"
             workload = (f"{args.arch} output-stride 16, VOC-shape {side}x{side} synthetic, SE (layer3) + SD (aspp) feature PGD K="

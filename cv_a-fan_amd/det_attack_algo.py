@@ -112,6 +112,8 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
     backward.  Same arithmetic: what the tails leave at the cuts enters the backbone graph as its output gradient."""
     y = {"bb": bboxes_batch, "lb": labels_batch}
     fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
+    if hasattr(model, "begin_iteration"):
+        model.begin_iteration()
     adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
     if hasattr(model, "head_features"):      # the three head passes (:78-80) are prefixes of one another: one pass, no graph
         fm = model.train().head_features(image_batch, (1, 2, 3))

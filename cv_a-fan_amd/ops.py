@@ -586,7 +586,7 @@ class FrozenBlockPlan:
     Detection iteration runs 388 block forwards and ~250 block backwards, and at ~100 us of Python per call (eligibility
     checks, 20 pointer wrappers, four workspace-size queries) the host, not the GPU, set its pace."""
     __slots__ = ("n", "cin", "h", "w", "ho", "wo", "planes", "co", "stride", "fwd_scratch", "bwd_scratch", "wgrad_ws", "w_ptrs", "k_ptrs",
-                 "wt_ptrs", "al_ptrs", "gw_ptrs", "n_fwd", "n_wgrad", "has_ds", "keep")
+                 "wt_ptrs", "al_ptrs", "gw_ptrs", "n_fwd", "n_wgrad", "has_ds", "keep", "sig")
 
 
 def frozen_bottleneck_plan(x, planes, stride, ws, ks, wts, als, gws):
@@ -605,6 +605,8 @@ def frozen_bottleneck_plan(x, planes, stride, ws, ks, wts, als, gws):
     p.has_ds = ws[3] is not None
     p.n_fwd, p.n_wgrad = 3 + int(p.has_ds), sum(gw is not None for gw in gws)
     p.keep = (ws, ks, wts, als, gws)              # the tensors behind the pointers
+    # every address a launch of this plan bakes in: two plans with equal signatures issue identical launches (hipGraph reuse)
+    p.sig = (p.n, p.cin, p.h, p.w, p.planes, p.stride) + tuple(None if t is None else t.data_ptr() for grp in p.keep for t in grp)
     return p
 
 

@@ -218,6 +218,33 @@ def test_faster_rcnn_full_size_iteration_properties(pkg, gpu):
     assert torch.equal(r["losses"], r2["losses"]) and torch.equal(tr.arena.grad, tr2.arena.grad) and torch.equal(tr.arena.param, tr2.arena.param)
 
 
+def test_backbone_stage_graphs_equal_eager_launches(pkg, gpu):
+    """det_model._StageGraphs (AFAN_DET_GRAPHS=1: the backbone's stages replayed from hipGraphs forward and backward, instances with
+    private pools) against the eager stage nodes over four iterations from the same state: the same launches on the same data —
+    identical losses and parameters, iteration by iteration (the whole iteration is deterministic)."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    sg = pkg.det_model._StageGraphs
+    old, res = sg.ON, {}
+    try:
+        for on in (False, True):
+            sg.ON = on
+            sg.cache.clear(), sg.warm.clear()
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m)
+            torch.manual_seed(5)
+            losses = []
+            for _ in range(4):
+                losses.append(tr.step(images, bboxes, labels)["losses"].clone())
+            torch.cuda.synchronize()
+            res[on] = (torch.stack(losses), tr.arena.param.clone(), len(sg.cache))
+    finally:
+        sg.ON = old
+        sg.cache.clear(), sg.warm.clear()
+    assert res[True][2] > 0 and res[False][2] == 0                       # stages WERE captured and replayed
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_head_features_equal_the_three_head_forwards(pkg, gpu):
     """Model.head_features: the three `flag: 'head'` forwards of train_aug_sat_muti_advt.py:78-80 as one pass without an autograd
     graph — bit-identical feature maps (frozen BatchNorm, deterministic kernels)."""
