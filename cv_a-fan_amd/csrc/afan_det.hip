@@ -7,9 +7,10 @@
 // one to one onto wave64: one wave per tile, lane = row box, bit = column box, a 64-bit word per (row, column block).  Only
 // tiles on or above the diagonal are computed (the scan never reads the others).  The reference then copies the whole mask
 // to the HOST and scans it there (12 MB and a device sync per call at 9 770 boxes); here the greedy scan stays on the
-// device: one wave walks the column blocks in order, resolves a diagonal tile with 64 scalar steps on its 64 words, and ORs
-// the kept rows' words into the running `removed` bit set (LDS) for the blocks to the right.  Kept boxes are flagged at
-// their ORIGINAL index and compacted by a prefix sum — ascending original indices, what nms_cuda returns after its sort.
+// device: one workgroup walks the column blocks in order — a scanner wave resolves each diagonal tile and the band of tiles
+// right of it, worker waves OR the kept rows' words of the far column blocks into the running `removed` bit set (LDS); see
+// nms_scan_kernel.  Kept boxes are flagged at their ORIGINAL index and compacted by a prefix sum — ascending original
+// indices, what nms_cuda returns after its sort.
 // Suppression test: IoU > threshold like nms.cu:49 (inclusive = 0) or IoU >= threshold like nms_cpu.cpp:62 (inclusive = 1);
 // areas and intersections with the reference's +1 (pixel-inclusive corners).
 #include "afan_common.h"
@@ -20,148 +21,297 @@ namespace {
 
 constexpr int W64 = 64;
 
-__device__ __forceinline__ float iou_incl(const float* a, const float* b) {
-    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+// "IoU(a, b) > thresh" (inclusive: >=) with the reference's arithmetic — fp32, corners inclusive (+1), inter / (sa + sb -
+// inter) by an IEEE division (nms.cu:36-49) — WITHOUT the division for all but the closest calls: with u = sa + sb - inter
+// and q = fl(thresh * u), inter outside q (1 -+ 2e-6) decides the comparison of the ROUNDED quotient as well (the quotient,
+// q and its two bounds are each within 2^-24 of their exact values, 30 times less than the margin); if any lane of the wave
+// sits inside the margin, or has a degenerate union, the wave divides.  sa / sb: the boxes' areas, computed once per box;
+// t_sane: the threshold is in [1e-3, 1] (wave-uniform).  ~28 instructions per pair against ~50 with the division's branches
+// (the mask kernel is VALU-bound: 72 M pairs for 12 000 boxes).
+__device__ __forceinline__ float box_area_incl(const float* a) { return (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f); }
+// v_max / v_min without the canonicalisation fmaxf() adds for operands straight from memory (a NaN box is nobody's input)
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ bool iou_over(const float* a, float sa, const float* b, float sb, float thresh, int inclusive, bool t_sane) {
+    const float left = vmax(a[0], b[0]), right = vmin(a[2], b[2]);
+    const float top = vmax(a[1], b[1]), bottom = vmin(a[3], b[3]);
     const float w = fmaxf(right - left + 1.f, 0.f), h = fmaxf(bottom - top + 1.f, 0.f);
     const float inter = w * h;
-    const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
-    const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
-    return inter / (sa + sb - inter);
+    const float u = sa + sb - inter;
+    const float q = thresh * u;
+    const bool sane = t_sane && u >= 1.f && u <= 1e30f;
+    bool hit = sane && inter > q * 1.000002f;
+    const bool decided = hit || (sane && inter < q * 0.999998f);
+    if (__ballot(!decided)) {                                      // wave-uniform, rare
+        const float v = inter / u;
+        hit = decided ? hit : (inclusive ? (v >= thresh) : (v > thresh));
+    }
+    return hit;
 }
 
-// grid (col_blocks, col_blocks), one wave per tile
+// The scan (below) resolves, per 64-box block, the diagonal tile AND the SC_D column blocks right of it by itself; for those
+// "band" tiles it wants the TRANSPOSED words — one 64-bit word per COLUMN box, bit = row box — because "is column c struck
+// by a kept row of this block" is then (word[c] & keep) != 0: one AND per column, lane-parallel, no reduction over rows.
+#ifndef AFAN_SC_D
+#define AFAN_SC_D 12
+#endif
+constexpr int SC_D = AFAN_SC_D;
+
+// grid (col_blocks, col_blocks), one wave per tile.  The diagonal tile and the SC_D tiles right of it store the TRANSPOSED
+// tile into bandT[row block][0 = diagonal, 1..SC_D][column] — the comparison's wave-wide ballot IS the column's word — and
+// no row form: the scan reads rows only of the tiles further right.
 __global__ __launch_bounds__(W64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ order, int n,
                                                        float thresh, int inclusive, unsigned long long* __restrict__ mask,
-                                                       int col_blocks) {
+                                                       unsigned long long* __restrict__ bandT, int col_blocks) {
     const int rb = blockIdx.y, cb = blockIdx.x;
     if (cb < rb) return;
     const int row_size = min(n - rb * W64, W64), col_size = min(n - cb * W64, W64);
-    __shared__ float cbox[W64 * 4];
+    __shared__ __attribute__((aligned(16))) float cbox[W64 * 4];
+    __shared__ float carea[W64];
     if ((int)threadIdx.x < col_size) {
         const float* src = boxes + order[cb * W64 + threadIdx.x] * 4;
         cbox[threadIdx.x * 4 + 0] = src[0]; cbox[threadIdx.x * 4 + 1] = src[1];
         cbox[threadIdx.x * 4 + 2] = src[2]; cbox[threadIdx.x * 4 + 3] = src[3];
+        carea[threadIdx.x] = box_area_incl(src);
     }
     __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int i = rb * W64 + threadIdx.x;
+    const bool t_sane = thresh >= 1e-3f && thresh <= 1.f;
+    const bool valid = (int)threadIdx.x < row_size;
+    const int i = rb * W64 + threadIdx.x;
+    float cur[4] = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
         const float* p = boxes + order[i] * 4;
-        const float cur[4] = {p[0], p[1], p[2], p[3]};
-        unsigned long long t = 0;
-        const int start = (rb == cb) ? threadIdx.x + 1 : 0;
-        for (int j = start; j < col_size; ++j) {
-            const float v = iou_incl(cur, cbox + j * 4);
-            if (inclusive ? (v >= thresh) : (v > thresh)) t |= 1ULL << j;
+        cur[0] = p[0]; cur[1] = p[1]; cur[2] = p[2]; cur[3] = p[3];
+    }
+    const float area = box_area_incl(cur);
+    if (cb - rb <= SC_D) {
+        const int first = (rb == cb) ? (int)threadIdx.x + 1 : 0;   // the diagonal tile: boxes after this row's only
+        unsigned long long tw = 0;                                 // lane c: column c's word
+        for (int j = 0; j < col_size; ++j) {
+            const bool hit = valid && j >= first && iou_over(cur, area, cbox + j * 4, carea[j], thresh, inclusive, t_sane);
+            const unsigned long long col = __ballot(hit);
+            if ((int)threadIdx.x == j) tw = col;
         }
-        mask[(int64_t)i * col_blocks + cb] = t;
+        bandT[((int64_t)rb * (SC_D + 1) + (cb - rb)) * W64 + threadIdx.x] = tw;
+    } else if (valid) {
+        unsigned long long t = 0;
+        for (int j = 0; j < col_size; ++j) {
+            if (iou_over(cur, area, cbox + j * 4, carea[j], thresh, inclusive, t_sane)) t |= 1ULL << j;
+        }
+        mask[(int64_t)i * col_blocks + cb] = t;                    // (row form: read by the scan's workers, far tiles only)
     }
 }
 
-// ONE workgroup; removed[] (col_blocks words) in LDS.  Wave 0 is the SCANNER: per 64-box block it reads removed[b], runs the
-// greedy recurrence over the block's diagonal words in scalar registers, flags the kept boxes, and ORs the kept rows' words
-// of the NEXT column block (prefetched one iteration ahead, one word per lane) into removed[b + 1] — the only word the next
-// iteration waits for.  Waves 1.. are WORKERS: during iteration b they OR the rows block b - 1 kept (its keep word sits in
-// LDS) into the column blocks from b + 1 on — their global loads run beside the scanner's recurrence instead of behind it,
-// and removed[j] is complete one barrier before iteration j needs it (block j - 1 by the scanner's fast path, block j - 2
-// by the workers during iteration j - 1, older blocks earlier).  An OR does not care about order: deterministic.
-// max_keep > 0: stop after the block in which the kept count reaches it — the caller takes the first max_keep survivors
-// (region_proposal_network.py:88-93: nms(...)[:post_nms_top_n]), and what greedy NMS keeps first never depends on later boxes.
-// History: one wave doing everything 1.42 ms for 12 000 boxes; 16 waves, rows after the recurrence, 0.87 ms.
+// ---- the scan ---------------------------------------------------------------------------------------------------------------
+// One workgroup of 16 waves in three roles that meet only through LDS words (no workgroup barrier inside the loop; every
+// wave of the one workgroup is resident, so a spin always has someone to wait for):
+//   SCANNER (wave 0), per block b: removed[b] and the block's SC_D + 1 transposed tiles in ONE LDS round trip (flags first,
+//     the data they guard behind them) -> the greedy recurrence on the diagonal tile, by rounds -> the keep word; then the
+//     band: lane c of tile k asks (column word & keep) != 0 and the ballot is removed[b + k]'s update.  It touches no global
+//     memory: what it needs sits in a ring of SC_R prefetched blocks.
+//   PREFETCHERS (waves 4, 8, 12 — the scanner's SIMD, where they mostly sleep on memory): the transposed tiles of the
+//     blocks up to SC_R ahead of the scanner into the ring.
+//   WORKERS (the other 12 waves), block p to worker p mod 12: the kept rows' words of the column blocks from p + SC_D + 1
+//     on, OR-ed into removed[] — due only when the scanner reaches block p + SC_D + 1, so a worker's memory round trips
+//     (1.5 - 3 us) hide behind SC_D + 1 scanner iterations.  The owner of block p also writes its kept flags.
+// removed[j] is complete when the scanner reads it: blocks j - SC_D .. j - 1 by its own band updates (same wave, LDS in
+// order), block j - SC_D - 1 by the worker it waits for, older blocks by the waits of earlier iterations.  ORs commute:
+// the result does not depend on timing.
+// History (12 000 boxes, the headline step's proposals, ~1 800 survivors, all 188 blocks scanned): one wave doing everything
+// 1.42 ms; 16 waves between two barriers per block, a scalar step per kept box, 283 us; this form 108 us — the scanner's
+// ~250 instructions per block are what is left (SC_D 6 .. 12 and SC_R 8 .. 12 within 3 %: tools/probe/nms_time.py).
 constexpr int SCAN_WAVES = 16;
+#ifndef AFAN_SC_R
+#define AFAN_SC_R 8
+#endif
+constexpr int SC_R = AFAN_SC_R;         // ring slots
+constexpr int SC_P = 3;                 // prefetch waves
+constexpr int SC_G = 2;                 // blocks a prefetch wave requests per round trip
+constexpr int SC_NW = SCAN_WAVES - 1 - SC_P;
+constexpr int SC_KW = 32;               // ring of keep words (a worker is never more than SC_D + 1 blocks behind)
+constexpr int SC_RC = 12;               // kept rows a worker requests per round trip (x 3 stretches of 64 column blocks)
+static_assert(SC_R >= SC_P * SC_G && SC_KW > SC_D + 2, "ring sizes");
+
+struct ScanShared {
+    unsigned long long bt[SC_R][SC_D + 1][W64];                   // [slot][0]: the diagonal tile, [1..]: the band, by column
+    unsigned long long keepw[SC_KW];
+    int pf_ready[SC_R];
+    int work_done[SC_NW];
+    int scan_pos, stop;
+};
+
+// wave-uniform by construction (every lane reads the same word): handed back in a scalar register so the loops on it are
+// scalar branches, not exec-mask loops
+__device__ __forceinline__ int lds_acquire(const int* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ unsigned long long to_scalar(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// The LDS unit executes one wave's instructions in issue order; where both sides of a hand-over are LDS accesses of the SAME
+// wave order (flag read before data reads; data writes before flag write) a compiler barrier is all the fence it takes —
+// no s_waitcnt between them, the round trips overlap.
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+// tiles K .. SC_D of the band: the ballot of "a kept row strikes this lane's column" is tile K's update of removed[b + K];
+// v_writelane drops it into lane K - 1 (no clang builtin for it)
+template <int K>
+__device__ __forceinline__ void band_verdicts(const unsigned long long (&bw)[SC_D + 1], unsigned long long keep, int& ulo, int& uhi) {
+    if constexpr (K <= SC_D) {
+        const unsigned long long hit = __ballot((bw[K] & keep) != 0ULL);
+        // (s_nop 1: gfx950 wants two wait states between a VALU writing an SGPR — the compare behind the ballot — and a VALU
+        // reading it; the compiler pads its own code, not this)
+        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                     : "+v"(ulo), "+v"(uhi) : "s"((int)hit), "s"((int)(hit >> 32)), "n"(K - 1));
+        band_verdicts<K + 1>(bw, keep, ulo, uhi);
+    }
+}
+
 __global__ __launch_bounds__(W64 * SCAN_WAVES) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                                    const unsigned long long* __restrict__ bandT,
                                                                     const int64_t* __restrict__ order, int n, int col_blocks,
                                                                     uint8_t* __restrict__ kept_flag, int max_keep) {
     extern __shared__ unsigned long long removed[];
-    __shared__ unsigned long long keepw[2];
-    __shared__ int stop;
-    const int lane = threadIdx.x & (W64 - 1), wave = threadIdx.x / W64;
+    __shared__ ScanShared S;
+    const int lane = threadIdx.x & (W64 - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / W64);
     for (int j = threadIdx.x; j < col_blocks; j += W64 * SCAN_WAVES) removed[j] = 0;
-    if (threadIdx.x == 0) stop = 0;
+    if (threadIdx.x < SC_R) S.pf_ready[threadIdx.x] = 0;
+    if (threadIdx.x < SC_NW) S.work_done[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { S.scan_pos = 0; S.stop = 0; }
     __syncthreads();
-    // scanner state: this block's diagonal words and its rows' words of the next column block, one per lane
-    unsigned long long diag = 0, nextw = 0;
-    if (wave == 0 && lane < min(n, W64)) {
-        diag = mask[(int64_t)lane * col_blocks];
-        if (col_blocks > 1) nextw = mask[(int64_t)lane * col_blocks + 1];
-    }
-    int kept_total = 0;
-    for (int b = 0; b < col_blocks; ++b) {
-        if (wave == 0) {
+
+    if (wave == 0) {
+        // ---- scanner ----
+        int kept_total = 0;
+        for (int b = 0; b < col_blocks; ++b) {
+            const int slot = b % SC_R;
+            const int need = b - SC_D - 1;
+            const int wslot = need >= 0 ? need % SC_NW : 0;
+            unsigned long long bw[SC_D + 1], rem_v;
+            // one LDS round trip on the optimistic path: the two flags first, then everything they guard
+            for (;;) {
+                LDS_ORDER();                                       // (what a retry read before is stale)
+                const int r1 = S.pf_ready[slot], r2 = S.work_done[wslot];
+                LDS_ORDER();
+                rem_v = removed[b];
+#pragma unroll
+                for (int k = 0; k <= SC_D; ++k) bw[k] = S.bt[slot][k][lane];
+                LDS_ORDER();                                       // (issued before the branch on the flags, not after it)
+                if (__builtin_amdgcn_readfirstlane(r1) == b + 1 && (need < 0 || __builtin_amdgcn_readfirstlane(r2) > need)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
             const int size = min(n - b * W64, W64);
-            const int nb = b + 1, nsize = min(n - nb * W64, W64);
-            unsigned long long diag_next = 0, nextw_next = 0;      // issued now, consumed next iteration
-            if (nb < col_blocks && lane < nsize) {
-                const unsigned long long* row = mask + (int64_t)(nb * W64 + lane) * col_blocks;
-                diag_next = row[nb];
-                if (nb + 1 < col_blocks) nextw_next = row[nb + 1];
-            }
-            // the greedy recurrence in SCALAR registers: row r's diagonal word by v_readlane with a constant lane (a shuffle
-            // with a run-time lane goes through the LDS crossbar: ~250 cycles per row)
-            const unsigned long long rem_v = removed[b];
-            unsigned long long rem = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rem_v >> 32)) << 32) |
-                                     (unsigned)__builtin_amdgcn_readfirstlane((int)rem_v);
-            if (size < W64) rem |= ~0ULL << size;                  // rows beyond n: never kept
-            const int dlo = (int)diag, dhi = (int)(diag >> 32);
-            // over the boxes still alive only: take the first, keep it, strike what it overlaps (its diagonal word by
-            // v_readlane with a scalar lane index), repeat — as many steps as the block keeps, not 64
-            unsigned long long keep = 0, alive = ~rem;
+            unsigned long long alive = ~to_scalar(rem_v);
+            if (size < W64) alive &= ~(~0ULL << size);             // rows beyond n: never kept
+            // the greedy recurrence by ROUNDS on the diagonal tile in column form (bw[0]: bit r = earlier box r strikes this
+            // lane's box): an undecided box no undecided earlier box overlaps is kept — every earlier overlapping box is
+            // decided, and a kept one would have struck it — so all such boxes are kept at once and strike theirs.  The
+            // first undecided box always qualifies; a block takes as many rounds as its longest chain of overlaps (2 - 4),
+            // not one scalar step per kept box.
+            unsigned long long keep = 0;
             while (alive) {
-                const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
-                const unsigned long long dr = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, r) << 32) |
-                                              (unsigned)__builtin_amdgcn_readlane(dlo, r);
-                keep |= 1ULL << r;
-                alive &= ~(dr | (1ULL << r));
+                const unsigned long long newly = __ballot((bw[0] & alive) == 0ULL) & alive;
+                keep |= newly;
+                alive &= ~(newly | __ballot((bw[0] & newly) != 0ULL));
             }
-            const bool mine = lane < size && ((keep >> lane) & 1ULL);
-            if (mine) kept_flag[order[b * W64 + lane]] = 1;
-            // fast path: the kept rows' words of column block b + 1 (same-address LDS atomics: cheaper than a 64-bit butterfly)
-            if (mine && nextw && nb < col_blocks) atomicOr(&removed[nb], nextw);
+            // the band: lane k - 1 collects tile k's 64 column verdicts
+            int ulo = 0, uhi = 0;
+            band_verdicts<1>(bw, keep, ulo, uhi);
+            const unsigned long long upd = ((unsigned long long)(unsigned)uhi << 32) | (unsigned)ulo;
+            if (lane < SC_D && upd && b + 1 + lane < col_blocks) atomicOr(&removed[b + 1 + lane], upd);
             kept_total += __popcll(keep);
+            const bool fin = max_keep > 0 && kept_total >= max_keep;
+            LDS_ORDER();
             if (lane == 0) {
-                keepw[b & 1] = keep;
-                if (max_keep > 0 && kept_total >= max_keep) stop = 1;
+                S.keepw[b % SC_KW] = keep;
+                LDS_ORDER();
+                S.scan_pos = b + 1;
+                LDS_ORDER();
+                if (fin) S.stop = 1;                               // after scan_pos: who sees stop sees the last block too
             }
-            diag = diag_next;
-            nextw = nextw_next;
-        } else if (b >= 1) {
-            // workers: block b - 1's kept rows into the column blocks from b + 1 on.  Worker w takes the kept rows of rank
-            // w, w + 15, w + 30, ... (at most five) and requests ALL their words of a 192-column stretch before the first
-            // OR: one memory round trip per stretch instead of one per row.
-            unsigned long long kk = keepw[(b - 1) & 1];
-            const int pb = b - 1;
-            constexpr int NW = SCAN_WAVES - 1, RPW = (W64 + NW - 1) / NW;       // workers, rows per worker
-            int rsel[RPW];
-            int rank = 0;
-#pragma unroll
-            for (int q = 0; q < RPW; ++q) {
-                const int target = wave - 1 + NW * q;
-                while (kk && rank < target) { kk &= kk - 1; ++rank; }
-                rsel[q] = (kk && rank == target) ? __ffsll((long long)kk) - 1 : -1;
+            LDS_ORDER();
+            if (fin) break;
+        }
+    } else if ((wave & 3) == 0) {
+        // ---- prefetchers ----
+        const int q = wave / 4 - 1;
+        for (int b0 = q * SC_G; b0 < col_blocks; b0 += SC_P * SC_G) {
+            bool quit = false;
+            while (lds_acquire(&S.scan_pos) < b0 + SC_G - SC_R) {  // the slots of b0 .. b0 + G - 1 are free
+                if (lds_acquire(&S.stop)) { quit = true; break; }
+                __builtin_amdgcn_s_sleep(2);
             }
-            if (rsel[0] >= 0) {
-                for (int j0 = b + 1; j0 < col_blocks; j0 += 3 * W64) {
-                    unsigned long long v[RPW][3];
+            if (quit) break;
+            unsigned long long w[SC_G][SC_D + 1];
 #pragma unroll
-                    for (int q = 0; q < RPW; ++q)
+            for (int t = 0; t < SC_G; ++t) {
+                const int blk = b0 + t;
+#pragma unroll
+                for (int k = 0; k <= SC_D; ++k)
+                    w[t][k] = (blk + k < col_blocks) ? bandT[((int64_t)blk * (SC_D + 1) + k) * W64 + lane] : 0ULL;
+            }
+#pragma unroll
+            for (int t = 0; t < SC_G; ++t) {
+                const int blk = b0 + t;
+                if (blk >= col_blocks) break;
+                const int slot = blk % SC_R;
+#pragma unroll
+                for (int k = 0; k <= SC_D; ++k) S.bt[slot][k][lane] = w[t][k];
+                if (lane == 0) lds_release(&S.pf_ready[slot], blk + 1);
+            }
+        }
+    } else {
+        // ---- workers ----
+        const int wi = wave - 1 - wave / 4;                        // waves 1,2,3,5,6,7,... -> 0..11
+        for (int p = wi; p < col_blocks; p += SC_NW) {
+            int sp;
+            bool stopped = false;
+            for (;;) {
+                sp = lds_acquire(&S.scan_pos);
+                if (sp > p) break;
+                if (lds_acquire(&S.stop)) { sp = lds_acquire(&S.scan_pos); stopped = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (sp <= p) break;                                    // the scan ended before this block
+            stopped = stopped || lds_acquire(&S.stop) != 0;
+            const unsigned long long keep = to_scalar(S.keepw[p % SC_KW]);
+            const int jf = p + SC_D + 1;
+            if (!stopped && jf < col_blocks) {
+                unsigned long long kk = keep;
+                while (kk) {
+                    int rsel[SC_RC];
+#pragma unroll
+                    for (int q = 0; q < SC_RC; ++q) {
+                        rsel[q] = kk ? __ffsll((long long)kk) - 1 : -1;
+                        kk &= kk - 1;
+                    }
+                    for (int j0 = jf; j0 < col_blocks; j0 += 3 * W64) {
+                        unsigned long long v[SC_RC][3];
+#pragma unroll
+                        for (int q = 0; q < SC_RC; ++q)
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                const int j = j0 + t * W64 + lane;
+                                v[q][t] = (rsel[q] >= 0 && j < col_blocks) ? mask[((int64_t)p * W64 + rsel[q]) * col_blocks + j] : 0ULL;
+                            }
 #pragma unroll
                         for (int t = 0; t < 3; ++t) {
+                            unsigned long long o = 0;
+#pragma unroll
+                            for (int q = 0; q < SC_RC; ++q) o |= v[q][t];
                             const int j = j0 + t * W64 + lane;
-                            v[q][t] = (rsel[q] >= 0 && j < col_blocks) ? mask[(int64_t)(pb * W64 + rsel[q]) * col_blocks + j] : 0ULL;
+                            if (o) atomicOr(&removed[j], o);
                         }
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        unsigned long long o = 0;
-#pragma unroll
-                        for (int q = 0; q < RPW; ++q) o |= v[q][t];
-                        const int j = j0 + t * W64 + lane;
-                        if (o) atomicOr(&removed[j], o);
                     }
                 }
             }
+            if (lane == 0) lds_release(&S.work_done[wi], p + 1);
+            // the flags last: the release above must not wait for these stores
+            const int size = min(n - p * W64, W64);
+            if (lane < size && ((keep >> lane) & 1ULL)) kept_flag[order[p * W64 + lane]] = 1;
         }
-        __syncthreads();
-        if (stop) break;
     }
 }
 
@@ -561,11 +711,12 @@ static bool afan_roi_bwd_gather_enabled() {
 
 extern "C" {
 
-// bytes of scratch afan_nms needs for n boxes: the overlap mask (n x ceil(n/64) 64-bit words) + one flag per box
+// bytes of scratch afan_nms needs for n boxes: the overlap mask (n x ceil(n/64) 64-bit words) + one flag per box + the
+// band tiles in transposed form (SC_D per row block)
 int64_t afan_nms_workspace_bytes(int64_t n) {
     if (n <= 0) return 0;
     const int64_t cb = (n + W64 - 1) / W64;
-    return n * cb * 8 + ((n + 7) & ~(int64_t)7);
+    return n * cb * 8 + ((n + 7) & ~(int64_t)7) + cb * (SC_D + 1) * W64 * 8;      // + the band tiles transposed
 }
 
 // boxes [n,4] fp32 (left, top, right, bottom; corners inclusive), order [n] int64 = indices by DESCENDING score;
@@ -603,9 +754,15 @@ static int nms_impl(const float* boxes, const int64_t* order, int64_t n, float t
     hipError_t e = hipMemsetAsync(flag, 0, (size_t)n, st);
     if (e != hipSuccess) return (int)e;
     AFAN_PROF("nms_kernel", 16.0 * n + 8.0 * n * cb, st);
-    nms_mask_kernel<<<dim3(cb, cb), W64, 0, st>>>(boxes, order, (int)n, threshold, inclusive, mask, cb);
+    unsigned long long* bandT = (unsigned long long*)(flag + ((n + 7) & ~(int64_t)7));
+    nms_mask_kernel<<<dim3(cb, cb), W64, 0, st>>>(boxes, order, (int)n, threshold, inclusive, mask, bandT, cb);
     AFAN_LAUNCH_CHECK();
-    nms_scan_kernel<<<1, W64 * SCAN_WAVES, (size_t)cb * 8, st>>>(mask, order, (int)n, cb, flag, (int)(max_keep > 0x7fffffffLL ? 0 : max_keep));
+    const int mk = (int)(max_keep > 0x7fffffffLL ? 0 : max_keep);
+    if ((size_t)cb * 8 > 8 * 1024) {                               // the static ring + removed[] pass the default 64 KB of LDS
+        static const hipError_t attr = hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (attr != hipSuccess) return (int)attr;
+    }
+    nms_scan_kernel<<<1, W64 * SCAN_WAVES, (size_t)cb * 8, st>>>(mask, bandT, order, (int)n, cb, flag, mk);
     AFAN_LAUNCH_CHECK();
     nms_compact_kernel<<<1, CP_THREADS, 0, st>>>(flag, (int)n, keep_out, count_out);
     AFAN_LAUNCH_CHECK();

@@ -526,7 +526,8 @@ int afan_dropout(const void* x, void* y, int dtype, int64_t n, float p, const ui
  * (inclusive = 0: nms.cu:49) or >= threshold (inclusive = 1: the CPU path, nms_cpu.cpp:62).  keep_out [n] int64 receives the
  * kept boxes' ORIGINAL indices in ascending order (what nms_cuda returns after its final sort), count_out[0] how many.  The
  * greedy scan runs on the device (the reference copies the n x n/64 mask to the host and syncs).  workspace:
- * afan_nms_workspace_bytes(n) bytes, 8-byte aligned. */
+ * afan_nms_workspace_bytes(n) bytes, 8-byte aligned (the mask, a flag per box, and the 13 tiles at and right of the diagonal
+ * of every row block once more in column form).  n <= 524 288. */
 int64_t afan_nms_workspace_bytes(int64_t n);
 int afan_nms(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
              int64_t* keep_out, int64_t* count_out, afan_stream_t stream);

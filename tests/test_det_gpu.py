@@ -58,6 +58,41 @@ def test_nms_random_vs_c_oracle(pkg, gpu, c_oracle, n):
         assert got.cpu().tolist() == ref.tolist(), (n, thr, inclusive)
 
 
+def test_nms_thresholds_on_exact_ties(pkg, gpu, c_oracle):
+    """The mask kernel decides IoU > t without the division unless inter is within 2e-6 of t * union: small integer boxes give
+    thousands of pairs whose quotient IS the threshold (or its fp32 neighbour), where only the reference's division
+    (nms.cu:36-49) separates > from >=."""
+    rng = np.random.default_rng(5)
+    n = 700
+    xy = rng.integers(0, 24, (n, 2)).astype(np.float32)
+    wh = rng.integers(0, 12, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], axis=1)
+    scores = rng.permutation(n).astype(np.float32) / n
+    for thr in (0.5, 0.25, 1 / 3, 2 / 3, 0.2, 0.75, 0.6):
+        for inclusive in (0, 1):
+            ref = _oracle_nms(c_oracle, boxes, scores, np.float32(thr), inclusive)
+            got = pkg.det_ops.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(scores).to(gpu), float(np.float32(thr)), inclusive=bool(inclusive))
+            assert got.cpu().tolist() == ref.tolist(), (thr, inclusive)
+    # and the two modes really differ on this set (ties exist)
+    a = pkg.det_ops.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(scores).to(gpu), 0.5, inclusive=False)
+    b = pkg.det_ops.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(scores).to(gpu), 0.5, inclusive=True)
+    assert a.numel() > b.numel()
+
+
+def test_nms_more_column_blocks_than_the_default_lds(pkg, gpu, c_oracle):
+    """66 000 boxes = 1 032 column blocks: removed[] (8 KB +) beside the scan's 53 KB ring passes the 64 KB a kernel gets by
+    default (afan_nms raises the limit for its scan kernel); scattered boxes keep the oracle's greedy loop short."""
+    rng = np.random.default_rng(9)
+    n = 66000
+    xy = rng.uniform(0, 1800, (n, 2)).astype(np.float32)
+    wh = rng.uniform(20, 160, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([xy, xy + wh], axis=1)
+    scores = rng.permutation(n).astype(np.float32) / n
+    ref = _oracle_nms(c_oracle, boxes, scores, 0.3, 0)
+    got = pkg.det_ops.nms(torch.from_numpy(boxes).to(gpu), torch.from_numpy(scores).to(gpu), 0.3)
+    assert 1000 < len(ref) < n and got.cpu().tolist() == ref.tolist()
+
+
 def _oracle_roi(lib, x, rois, ph, pw, scale, sr, dy=None):
     n_roi, (N, C, H, W) = len(rois), x.shape
     r = np.ascontiguousarray(rois, np.float32)
