@@ -112,6 +112,12 @@ SIGNATURES = {
     "afan_nms_workspace_bytes": (_l, [_l]),
     "afan_nms": (_i, [_p, _p, _l, _f, _i, _p, _p, _p, _p]),
     "afan_nms_top": (_i, [_p, _p, _l, _f, _i, _p, _p, _p, _l, _p]),
+    "afan_box_decode_clip": (_i, [_p, _p, _p, _l, _f, _f, _p]),
+    "afan_box_assign": (_i, [_p, _p, _l, _l, _l, _i, _f, _f, _p, _p, _p, _p, _p]),
+    "afan_sample_lists": (_i, [_p, _l, _p, _p, _p, _p]),
+    "afan_sample_gather": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p]),
+    "afan_det_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _f, _p, _p, _p, _p, _p]),
+    "afan_det_loss_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _p]),
     "afan_roi_align_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_roi_align_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_roi_align_bwd_workspace_bytes": (_l, [_l, _l, _l]),

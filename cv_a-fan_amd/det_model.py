@@ -24,11 +24,24 @@ import torch.nn.functional as F
 
 from . import ops
 from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
-from .det_ops import nms, roi_align
+from .det_ops import box_assign, box_decode_clip, fg_bg_sample, nms, per_image_losses, roi_align
 from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear,
                        _own_conv_ok, _to_compute, _WgradStream)
 
 __all__ = ["Model", "ResNet101", "RegionProposalNetwork", "FrozenBatchNorm2d", "fasterrcnn_resnet101"]
+
+
+def _int_tensor(v, device):
+    """The reference's dicts carry sizes as [[v]] tensors on the device (model.py:104-108, :337): the same tensor, with the
+    Python value riding along so that this package's own reader needs no device read (`_int_of`)."""
+    t = torch.tensor([[v]], device=device)
+    t._afan_int = int(v)
+    return t
+
+
+def _int_of(t):
+    v = getattr(t, "_afan_int", None)
+    return v if v is not None else t[0].item()
 
 
 # ------------------------------------------------------------------------------------------------- box arithmetic (bbox.py)
@@ -40,13 +53,6 @@ def _corners(c):
     return torch.stack([c[..., 0] - c[..., 2] / 2, c[..., 1] - c[..., 3] / 2, c[..., 0] + c[..., 2] / 2, c[..., 1] + c[..., 3] / 2], dim=-1)
 
 
-def box_deltas(src, dst):
-    """bbox.py:41-52 `calc_transformer`."""
-    s, d = _centre(src), _centre(dst)
-    return torch.stack([(d[..., 0] - s[..., 0]) / s[..., 2], (d[..., 1] - s[..., 1]) / s[..., 3],
-                        torch.log(d[..., 2] / s[..., 2]), torch.log(d[..., 3] / s[..., 3])], dim=-1)
-
-
 def box_apply(src, t):
     """bbox.py:54-64 `apply_transformer`."""
     s = _centre(src)
@@ -54,28 +60,11 @@ def box_apply(src, t):
                                  torch.exp(t[..., 2]) * s[..., 2], torch.exp(t[..., 3]) * s[..., 3]], dim=-1))
 
 
-def box_iou(a, b):
-    """bbox.py:66-82: [B, Na, 4] x [B, Nb, 4] -> [B, Na, Nb] (no +1: continuous coordinates)."""
-    a, b = a.unsqueeze(-2), b.unsqueeze(-3)
-    area_a = (a[..., 2] - a[..., 0]) * (a[..., 3] - a[..., 1])
-    area_b = (b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])
-    w = torch.clamp(torch.min(a[..., 2], b[..., 2]) - torch.max(a[..., 0], b[..., 0]), min=0)
-    h = torch.clamp(torch.min(a[..., 3], b[..., 3]) - torch.max(a[..., 1], b[..., 1]), min=0)
-    inter = w * h
-    return inter / (area_a + area_b - inter)
-
-
 def box_clip_(b, right, bottom):
     """bbox.py:89-92 (left = top = 0), in place."""
     b[..., [0, 2]] = b[..., [0, 2]].clamp(min=0, max=right)
     b[..., [1, 3]] = b[..., [1, 3]].clamp(min=0, max=bottom)
     return b
-
-
-def beta_smooth_l1(inp, target, beta):
-    """extension/functional.py:6-10."""
-    d = torch.abs(inp - target)
-    return torch.where(d < beta, 0.5 * d ** 2 / beta, d - 0.5 * beta).sum() / (inp.numel() + 1e-8)
 
 
 # ------------------------------------------------------------------------------------------------------ fused affine layers
@@ -543,41 +532,6 @@ class ResNet101(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------ RPN
-def _fg_bg_sample(labels, n_fg, n_total):
-    """The reference's sampling (region_proposal_network.py:84-90, model.py:277-282): foreground / background indices in
-    nonzero() order, three `torch.randperm` draws on the HOST generator (foreground subset, background subset, shuffle).  The two
-    counts the host draws need come back in ONE read; the index lists themselves are then built without another
-    (`nonzero_static` with the known size)."""
-    fgm, bgm = labels > 0, labels == 0
-    if labels.is_cuda:
-        nf, nb = torch.stack([fgm.sum(), bgm.sum()]).tolist()
-        fg, bg = torch.nonzero_static(fgm, size=nf), torch.nonzero_static(bgm, size=nb)
-    else:
-        fg, bg = fgm.nonzero(), bgm.nonzero()
-    fg = fg[torch.randperm(len(fg))[:min(len(fg), n_fg)]]
-    bg = bg[torch.randperm(len(bg))[:n_total - len(fg)]]
-    sel = torch.cat([fg, bg], dim=0)
-    return sel[torch.randperm(len(sel))].unbind(dim=1)
-
-
-def _per_image_losses(logits, deltas, gt_labels, gt_deltas, batch_size, batch_indices, beta):
-    """region_proposal_network.py:163-185 == model.py:343-367: per image, mean cross-entropy over its samples and the
-    beta-smooth-L1 of its foreground samples (sum over the 4 coordinates / (4 x foreground samples + 1e-8): extension/functional.py).
-    Written with per-sample terms and 0 / 1 masks instead of the reference's `nonzero()` index lists (two host synchronisations per
-    image and call, 66 per Detection iteration): the same sums over the same samples — an image without samples gives nan for its
-    cross-entropy (the mean of nothing) and one without foreground 0 for its smooth-L1, like the reference."""
-    ce_i = F.cross_entropy(input=logits, target=gt_labels, reduction="none")
-    d = torch.abs(deltas - gt_deltas)
-    sl_i = torch.where(d < beta, 0.5 * d ** 2 / beta, d - 0.5 * beta).sum(dim=1)
-    fg = (gt_labels != 0).to(sl_i.dtype)
-    if batch_size == 1:                                  # (every sample belongs to image 0)
-        return (ce_i.sum() / ce_i.numel()).view(1), ((sl_i * fg).sum() / (4.0 * fg.sum() + 1e-8)).view(1)
-    m = (batch_indices.view(1, -1) == torch.arange(batch_size, device=logits.device).view(-1, 1)).to(ce_i.dtype)      # [B, S]
-    ce = (m * ce_i.view(1, -1)).sum(dim=1) / m.sum(dim=1)
-    sl1 = (m * (sl_i * fg).view(1, -1)).sum(dim=1) / (4.0 * (m * fg.view(1, -1)).sum(dim=1) + 1e-8)
-    return ce, sl1
-
-
 class RegionProposalNetwork(nn.Module):
     """rpn/region_proposal_network.py:13-271."""
 
@@ -612,41 +566,30 @@ class RegionProposalNetwork(nn.Module):
 
     # -- training targets (:58-105; the reference repeats this block in its 'clean' and 'tail' branches)
     def _losses(self, objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height):
+        """Labels (:66-82), sampling (:84-90), regression targets (:92-100) and the two per-image losses (:163-185) on the anchors
+        inside the image: four launches and one host read (det_ops.box_assign / fg_bg_sample / per_image_losses) where the
+        reference's tensor operations are about a hundred."""
         b = anchor_bboxes.shape[0]
         # (the anchors inside the image: a function of the cached anchor grid, computed — and synchronised on — once per grid)
         ikey = (anchor_bboxes.data_ptr(), tuple(anchor_bboxes.shape), int(image_width), int(image_height))
-        inside = self._inside_cache.get(ikey)
-        if inside is None:
+        hit = self._inside_cache.get(ikey)
+        if hit is None:
             inside = ((anchor_bboxes[..., 0] >= 0) * (anchor_bboxes[..., 1] >= 0) * (anchor_bboxes[..., 2] <= image_width) *
                       (anchor_bboxes[..., 3] <= image_height)).nonzero().unbind(dim=1)
+            in_boxes = anchor_bboxes[inside].view(b, -1, 4).contiguous()
+            flat = (inside[0] * anchor_bboxes.shape[1] + inside[1]).contiguous()
             if len(self._inside_cache) > 64:
                 self._inside_cache.clear()
-            self._inside_cache[ikey] = (inside, anchor_bboxes)          # (holding the grid keeps its address from being reused)
-        else:
-            inside = inside[0]
-        in_boxes = anchor_bboxes[inside].view(b, -1, 4)
-        in_obj = objectnesses[inside].view(b, -1, 2)
-        in_tr = transformers[inside].view(b, -1, 4)
-        labels = torch.full((b, in_boxes.shape[1]), -1, dtype=torch.long, device=in_boxes.device)
-        ious = box_iou(in_boxes, gt_bboxes_batch)
-        anchor_max, anchor_assign = ious.max(dim=2)
-        gt_max, _ = ious.max(dim=1)
-        # (:76-80 index `labels` with the nonzero() list of the anchors that tie a ground truth's best IoU: the same set as a mask,
-        # without the host read)
-        additions = ((ious > 0) & (ious == gt_max.unsqueeze(dim=1))).any(dim=2)
-        labels[anchor_max < 0.3] = 0
-        labels[additions] = 1
-        labels[anchor_max >= 0.7] = 1
-        sel = _fg_bg_sample(labels, 128 * b, 256 * b)
-        boxes = in_boxes[sel]
-        gt_boxes = gt_bboxes_batch[sel[0], anchor_assign[sel]]
-        return _per_image_losses(in_obj[sel], in_tr[sel], labels[sel], box_deltas(boxes, gt_boxes), b, sel[0],
-                                 self._anchor_smooth_l1_loss_beta)
+            hit = self._inside_cache[ikey] = (in_boxes, flat, anchor_bboxes)      # (holding the grid keeps its address from being reused)
+        in_boxes, flat = hit[0], hit[1]
+        labels, assign = box_assign(in_boxes, gt_bboxes_batch, "anchor", 0.3, 0.7)
+        sel, _, lab, gt_deltas, bi = fg_bg_sample(labels, assign, in_boxes, gt_bboxes_batch, 128 * b, 256 * b)
+        return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
 
     def forward(self, features, anchor_bboxes=None, gt_bboxes_batch=None, image_width=None, image_height=None, return_type="clean"):
         if return_type == "head":
             trunk = self._trunk(features)
-            return {"batch_size": torch.tensor([[trunk.shape[0]]], device=trunk.device), "rpn_feature": trunk}
+            return {"batch_size": _int_tensor(trunk.shape[0], trunk.device), "rpn_feature": trunk}
         if return_type == "tail":
             trunk = features["rpn_feature"]
         else:
@@ -672,16 +615,17 @@ class RegionProposalNetwork(nn.Module):
     def generate_proposals(self, anchor_bboxes, objectnesses, transformers, image_width, image_height):
         """:223-271: decode, clip, sort by the softmax over ALL anchors of the foreground logit, NMS at 0.7 per image (the
         library's kernel), top-N, zero-pad to the longest image."""
-        boxes = box_clip_(box_apply(anchor_bboxes, transformers), image_width, image_height)
+        boxes = box_decode_clip(anchor_bboxes, transformers, image_width, image_height)
         probs = F.softmax(objectnesses[:, :, 1], dim=-1)
         _, order = torch.sort(probs, dim=-1, descending=True)
         kept = []
         for b in range(anchor_bboxes.shape[0]):
-            sb = boxes[b][order[b]][:self._pre_nms_top_n]
-            sp = probs[b][order[b]][:self._pre_nms_top_n]
-            # (sb / sp are in descending score order: no second sort, and the scan stops at the top-N survivors)
-            keep = nms(sb, sp, 0.7, max_keep=self._post_nms_top_n, presorted=True)
+            sb = boxes[b][order[b][:self._pre_nms_top_n]]
+            # (sb is in descending score order: no second sort, and the scan stops at the top-N survivors)
+            keep = nms(sb, None, 0.7, max_keep=self._post_nms_top_n, presorted=True)
             kept.append(sb[keep.to(sb.device)][:self._post_nms_top_n])
+        if len(kept) == 1:
+            return kept[0].unsqueeze(0)
         longest = max(len(k) for k in kept)
         return torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
 
@@ -834,14 +778,14 @@ class Model(nn.Module):
         if idx == "rpn_tail":
             d = input_dict["adv"]
             features, anchors = d["features"], d["anchor_bboxes"]
-            iw, ih = d["image_width"][0].item(), d["image_height"][0].item()
+            iw, ih = _int_of(d["image_width"]), _int_of(d["image_height"])
             obj, tr, ao, at = self.rpn.forward(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
         else:
             features = self._cut(self.features(input_dict))
             anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
             if idx == "rpn_head":
-                return {"features": features, "image_height": torch.tensor([[ih]], device=features.device),
-                        "image_width": torch.tensor([[iw]], device=features.device), "anchor_bboxes": anchors,
+                return {"features": features, "image_height": _int_tensor(ih, features.device),
+                        "image_width": _int_tensor(iw, features.device), "anchor_bboxes": anchors,
                         "rpn_feature_map_dict": self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih, return_type="head")}
             assert type(idx) == int or idx == "roi_head"
             obj, tr, ao, at = self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih)
@@ -878,22 +822,16 @@ class Model(nn.Module):
         def _targets(self, proposal_bboxes, gt_classes_batch, gt_bboxes_batch):
             """:256-282 (repeated at :300-326): IoU >= 0.5 takes its ground truth's class, 32 / 128 per image sampled."""
             b = proposal_bboxes.shape[0]
-            labels = torch.full((b, proposal_bboxes.shape[1]), -1, dtype=torch.long, device=proposal_bboxes.device)
-            max_ious, assign = box_iou(proposal_bboxes, gt_bboxes_batch).max(dim=2)
-            labels[max_ious < 0.5] = 0
-            fg = max_ious >= 0.5
-            # (:262-264 assign through nonzero() index lists: the same values per element, no host read)
-            labels = torch.where(fg, torch.gather(gt_classes_batch, 1, assign), labels)
-            sel = _fg_bg_sample(labels, 32 * b, 128 * b)
-            boxes = proposal_bboxes[sel]
-            return boxes, labels[sel], box_deltas(boxes, gt_bboxes_batch[sel[0], assign[sel]]), sel[0]
+            labels, assign = box_assign(proposal_bboxes, gt_bboxes_batch, "proposal", 0.5, gt_classes=gt_classes_batch)
+            _, boxes, lab, deltas, bi = fg_bg_sample(labels, assign, proposal_bboxes, gt_bboxes_batch, 32 * b, 128 * b)
+            return boxes, lab, deltas, bi
 
         def forward(self, features, proposal_bboxes=None, gt_classes_batch=None, gt_bboxes_batch=None, return_type="clean"):
             if return_type == "tail":
                 d = features
                 classes, transformers = self._linears(d["roi_feature_map"])
                 ce, sl1 = self.loss(classes, transformers, d["gt_proposal_classes"], d["gt_proposal_transformers"],
-                                    d["batch_size"][0].item(), d["batch_indices"])
+                                    _int_of(d["batch_size"]), d["batch_indices"])
                 return classes, transformers, ce, sl1
             b = features.shape[0]
             if return_type == "clean" and not self.training:
@@ -904,7 +842,7 @@ class Model(nn.Module):
             hidden = self._roi_features(features, boxes, bi)
             if return_type == "head":
                 return {"roi_feature_map": hidden, "gt_proposal_classes": gt_classes, "gt_proposal_transformers": gt_deltas,
-                        "batch_size": torch.tensor([[b]], device=hidden.device), "batch_indices": bi}
+                        "batch_size": _int_tensor(b, hidden.device), "batch_indices": bi}
             assert return_type == "clean"
             classes, transformers = self._linears(hidden)
             ce, sl1 = self.loss(classes, transformers, gt_classes, gt_deltas, b, bi)
@@ -912,12 +850,9 @@ class Model(nn.Module):
 
         def loss(self, proposal_classes, proposal_transformers, gt_proposal_classes, gt_proposal_transformers, batch_size, batch_indices):
             """:343-367: the regression output of each sample's OWN class, targets normalised by (0, 0, 0, 0) / (.1, .1, .2, .2)."""
-            tr = proposal_transformers.view(-1, self.num_classes, 4)[torch.arange(end=len(proposal_transformers), dtype=torch.long),
-                                                                     gt_proposal_classes]
-            mean = self._transformer_normalize_mean.to(device=gt_proposal_transformers.device)
-            std = self._transformer_normalize_std.to(device=gt_proposal_transformers.device)
-            return _per_image_losses(proposal_classes, tr, gt_proposal_classes, (gt_proposal_transformers - mean) / std, batch_size,
-                                     batch_indices, self._proposal_smooth_l1_loss_beta)
+            norm = tuple(self._transformer_normalize_mean.tolist()) + tuple(self._transformer_normalize_std.tolist())
+            return per_image_losses(proposal_classes, proposal_transformers, None, gt_proposal_classes, gt_proposal_transformers,
+                                    batch_indices, batch_size, self._proposal_smooth_l1_loss_beta, norm=norm)
 
         def generate_detections(self, proposal_bboxes, proposal_classes, proposal_transformers, image_width, image_height):
             """:369-407 (inference): per-class decode, clip, softmax, NMS at 0.3."""

@@ -74,6 +74,134 @@ def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0, pr
     return keep[:int(count.item())]       # the result's length is data dependent: one read-back (the reference copies the whole mask)
 
 
+# ------------------------------------------------------------------------- training targets and losses (afan_det_targets.hip)
+def _f32c(t, what):
+    if t.device.type != "cuda":
+        raise ops.AfanLibraryError(f"{what}: tensors must live on the MI355X (no CPU path in this build)")
+    t = t.detach()
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def box_decode_clip(src, transformers, right, bottom):
+    """BBox.clip(BBox.apply_transformer(src, transformers), 0, 0, right, bottom) (bbox.py:54-64, :89-92) in one launch."""
+    src, t = _f32c(src, "box_decode_clip"), _f32c(transformers, "box_decode_clip")
+    if src.shape != t.shape or src.shape[-1] != 4:
+        raise ValueError("box_decode_clip: [..., 4] boxes and transformers of one shape")
+    out = torch.empty_like(src)
+    check(_lib.load().afan_box_decode_clip(_ptr(src), _ptr(t), _ptr(out), src.numel() // 4, float(right), float(bottom), _stream(src.device)),
+          "afan_box_decode_clip")
+    return out
+
+
+def box_assign(boxes, gt_bboxes, mode, lo, hi=0.0, gt_classes=None):
+    """(labels [B, N] int64, assign [B, N] int64) of boxes [B, N, 4] against gt [B, G, 4]: mode 'anchor'
+    (region_proposal_network.py:66-82, thresholds lo / hi) or 'proposal' (model.py:256-264, threshold lo, classes [B, G])."""
+    boxes, gt = _f32c(boxes, "box_assign"), _f32c(gt_bboxes, "box_assign")
+    B, N, _ = boxes.shape
+    G = gt.shape[1]
+    if gt.shape[0] != B or gt.shape[2] != 4 or boxes.shape[2] != 4:
+        raise ValueError("box_assign: boxes [B, N, 4], gt [B, G, 4]")
+    labels = torch.empty((B, N), dtype=torch.int64, device=boxes.device)
+    assign = torch.empty((B, N), dtype=torch.int64, device=boxes.device)
+    m = {"anchor": 0, "proposal": 1}[mode]
+    cls = None
+    if m == 1:
+        cls = gt_classes.detach().to(torch.int64).contiguous()
+        if tuple(cls.shape) != (B, G):
+            raise ValueError("box_assign: gt_classes [B, G]")
+    ws = _workspace_bytes(boxes.device, B * G * 4) if m == 0 else None
+    check(_lib.load().afan_box_assign(_ptr(boxes), _ptr(gt), B, N, G, m, float(lo), float(hi), _ptr(cls), _ptr(labels), _ptr(assign), _ptr(ws),
+                                      _stream(boxes.device)), "afan_box_assign")
+    return labels, assign
+
+
+def fg_bg_sample(labels, assign, boxes, gt_bboxes, n_fg, n_total):
+    """The reference's sampling (region_proposal_network.py:84-90, model.py:277-282) and what is gathered at the sample right
+    after it: three `torch.randperm` draws on the HOST generator (foreground subset, background subset, shuffle) over the
+    `nonzero()` lists of labels > 0 / == 0.  One launch builds both lists, ONE host read brings their lengths, the three draws
+    are composed on the host into a position list, one launch gathers.  Returns (sel [S] flat positions in [B * N), boxes [S, 4],
+    labels [S], regression targets [S, 4] = calc_transformer(box, its ground truth) (bbox.py:41-52), batch indices [S])."""
+    lib = _lib.load()
+    dev = labels.device
+    B, N = labels.shape
+    G = gt_bboxes.shape[1]
+    boxes, gt = _f32c(boxes, "fg_bg_sample"), _f32c(gt_bboxes, "fg_bg_sample")
+    M = B * N
+    lists = torch.empty(2 * M + 2, dtype=torch.int64, device=dev)
+    fg, bg, counts = lists[:M], lists[M:2 * M], lists[2 * M:]
+    st = _stream(dev)
+    check(lib.afan_sample_lists(_ptr(labels), M, _ptr(fg), _ptr(bg), _ptr(counts), st), "afan_sample_lists")
+    nf, nb = counts.tolist()                                     # the iteration's host read for this sampling
+    p1 = torch.randperm(nf)[:min(nf, n_fg)]
+    p2 = torch.randperm(nb)[:n_total - len(p1)]
+    pos = torch.cat([p1, -(p2 + 1)])
+    pos = pos[torch.randperm(len(pos))].to(dev, non_blocking=True)
+    S = pos.numel()
+    sel = torch.empty(S, dtype=torch.int64, device=dev)
+    out_l = torch.empty(S, dtype=torch.int64, device=dev)
+    out_bi = torch.empty(S, dtype=torch.int64, device=dev)
+    out_b = torch.empty((S, 4), dtype=torch.float32, device=dev)
+    out_d = torch.empty((S, 4), dtype=torch.float32, device=dev)
+    if S:
+        check(lib.afan_sample_gather(_ptr(fg), _ptr(bg), _ptr(pos), S, _ptr(boxes), _ptr(gt), _ptr(assign), _ptr(labels), N, G, _ptr(sel),
+                                     _ptr(out_b), _ptr(out_l), _ptr(out_d), _ptr(out_bi), st), "afan_sample_gather")
+    return sel, out_b, out_l, out_d, out_bi
+
+
+class _DetLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, deltas, rows, gt_labels, gt_deltas, batch, batch_size, beta, norm):
+        lib = _lib.load()
+        if logits.device.type != "cuda":
+            raise ops.AfanLibraryError("per_image_losses: tensors must live on the MI355X (no CPU path in this build)")
+        lg = logits if (logits.dtype == torch.float32 and logits.is_contiguous()) else logits.float().contiguous()
+        dl = deltas if (deltas.dtype == torch.float32 and deltas.is_contiguous()) else deltas.float().contiguous()
+        C_ = lg.shape[-1]
+        R = lg.numel() // C_
+        K = dl.numel() // (R * 4)
+        if K * R * 4 != dl.numel() or K not in (1, C_):
+            raise ValueError("per_image_losses: deltas must be [R, 4] or [R, C * 4] for logits [R, C]")
+        S, B = gt_labels.numel(), int(batch_size)
+        dev = lg.device
+        gd = gt_deltas.detach().float().contiguous()
+        out = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        save = torch.empty(S * 4 + S * C_ + 2 * B, dtype=torch.float32, device=dev)
+        nrm = (C.c_float * 8)(*norm) if norm is not None else None
+        check(lib.afan_det_loss_fwd(_ptr(lg), _ptr(dl), _ptr(rows), _ptr(gt_labels), _ptr(gd), _ptr(batch), S, B, C_, K, float(beta), nrm,
+                                    _ptr(out), C.c_void_p(out.data_ptr() + 4 * B), _ptr(save), _stream(dev)), "afan_det_loss_fwd")
+        ctx.save_for_backward(save, rows, gt_labels, batch)
+        ctx.dims = (S, B, C_, K, R, logits.shape, deltas.shape, logits.dtype, deltas.dtype)
+        return out[:B], out[B:]
+
+    @staticmethod
+    def backward(ctx, g_ce, g_sl):
+        save, rows, gt_labels, batch = ctx.saved_tensors
+        S, B, C_, K, R, lshape, dshape, ldt, ddt = ctx.dims
+        dev = save.device
+        g_ce, g_sl = g_ce.float().contiguous(), g_sl.float().contiguous()
+        d_l = torch.empty(lshape, dtype=torch.float32, device=dev)
+        d_d = torch.empty(dshape, dtype=torch.float32, device=dev)
+        check(_lib.load().afan_det_loss_bwd(_ptr(g_ce), _ptr(g_sl), _ptr(save), _ptr(rows), _ptr(gt_labels), _ptr(batch), S, B, C_, K, R, _ptr(d_l),
+                                            _ptr(d_d), _stream(dev)), "afan_det_loss_bwd")
+        return d_l.to(ldt), d_d.to(ddt), None, None, None, None, None, None, None
+
+
+def per_image_losses(logits, deltas, rows, gt_labels, gt_deltas, batch_indices, batch_size, beta, norm=None):
+    """region_proposal_network.py:163-185 == model.py:343-367 in one launch (and one for the backward): per image the mean
+    cross-entropy of its samples and the beta-smooth-L1 of its foreground samples.  Sample s reads row rows[s] (None: s) of
+    logits [..., C] and deltas [..., 4] or [..., C * 4] (then the 4 of the sample's own class); norm: (mean[4] + std[4]) applied
+    to the targets (model.py:352-354).  Returns (cross_entropies [B], smooth_l1_losses [B])."""
+    return _DetLoss.apply(logits, deltas, rows, gt_labels, gt_deltas, batch_indices, batch_size, beta, norm)
+
+
 class _ROIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):

@@ -539,6 +539,37 @@ int afan_nms(const float* boxes, const int64_t* order, int64_t n, float threshol
  * equal afan_nms's).  max_keep = 0: afan_nms. */
 int afan_nms_top(const float* boxes, const int64_t* order, int64_t n, float threshold, int inclusive, void* workspace,
                  int64_t* keep_out, int64_t* count_out, int64_t max_keep, afan_stream_t stream);
+
+/* Training targets and per-image losses of the Faster-RCNN step as single launches (the reference composes each from dozens of
+ * tensor operations: bbox.py:41-92, rpn/region_proposal_network.py:58-105,163-185, model.py:256-282,343-367).  fp32, boxes as
+ * (left, top, right, bottom), indices int64, all pointers device memory.
+ *
+ * afan_box_decode_clip — bbox.py:54-64 `apply_transformer` then :89-92 `clip` to [0, right] x [0, bottom]; n boxes.
+ * afan_box_assign — IoU (bbox.py:66-82) of boxes [B,N,4] with gt [B,G,4]: assign [B,N] = the best ground truth (first maximum),
+ *   labels [B,N] by mode 0 (anchors, region_proposal_network.py:66-82: -1; 0 below lo; 1 at hi and above, or tying a ground truth's
+ *   best positive IoU) or mode 1 (proposals, model.py:256-264: -1; 0 below lo; gt_classes[b, assign] at lo and above).  workspace:
+ *   B*G*4 bytes (mode 0).
+ * afan_sample_lists — fg / bg [M]: the ascending positions of labels > 0 / == 0 (`nonzero()` order), counts[2] their lengths:
+ *   what the host's `randperm` draws (region_proposal_network.py:84-90, model.py:277-282) need to know.
+ * afan_sample_gather — the S drawn rows: pos[i] >= 0 names fg[pos[i]], pos[i] < 0 names bg[-pos[i]-1]; out: sel (flat position),
+ *   the row's box, label, image index and regression target bbox.py:41-52 `calc_transformer`(box, gt[b, assign]).
+ * afan_det_loss_fwd / _bwd — region_proposal_network.py:163-185 == model.py:343-367: per image the mean cross-entropy of its
+ *   samples and the beta-smooth-L1 (extension/functional.py:6-10) of its foreground samples over 4 x foreground + 1e-8.  Sample s
+ *   reads row rows[s] (or s) of logits [R,C] and deltas [R,K,4], K = 1 or C (the sample's own class); norm = NULL or mean[4],
+ *   std[4] for the targets.  save: S*4 + S*C + 2*B floats, kept for _bwd, which writes DENSE d_logits [R,C] / d_deltas [R,K,4]. */
+int afan_box_decode_clip(const float* src, const float* t, float* out, int64_t n, float right, float bottom, afan_stream_t stream);
+int afan_box_assign(const float* boxes, const float* gt, int64_t B, int64_t N, int64_t G, int mode, float lo, float hi,
+                    const int64_t* gt_classes, int64_t* labels, int64_t* assign, void* workspace, afan_stream_t stream);
+int afan_sample_lists(const int64_t* labels, int64_t M, int64_t* fg, int64_t* bg, int64_t* counts, afan_stream_t stream);
+int afan_sample_gather(const int64_t* fg, const int64_t* bg, const int64_t* pos, int64_t S, const float* boxes, const float* gt,
+                       const int64_t* assign, const int64_t* labels, int64_t N, int64_t G, int64_t* sel, float* out_boxes,
+                       int64_t* out_labels, float* out_deltas, int64_t* out_batch, afan_stream_t stream);
+int afan_det_loss_fwd(const float* logits, const float* deltas, const int64_t* rows, const int64_t* gt_labels, const float* gt_deltas,
+                      const int64_t* batch, int64_t S, int64_t B, int64_t C, int64_t K, float beta, const float* norm, float* ce, float* sl1,
+                      float* save, afan_stream_t stream);
+int afan_det_loss_bwd(const float* g_ce, const float* g_sl1, const float* save, const int64_t* rows, const int64_t* gt_labels,
+                      const int64_t* batch, int64_t S, int64_t B, int64_t C, int64_t K, int64_t R, float* d_logits, float* d_deltas,
+                      afan_stream_t stream);
 /* afan_roi_align_{fwd,bwd} — `support._C.roi_align_forward / roi_align_backward` (ROIAlign.h:12-47 -> ROIAlign_cuda.cu:256-346).
  * x [N,C,H,W], rois [num_rois,5] fp32 = (batch index, x1, y1, x2, y2) in image coordinates (scaled by spatial_scale, NOT
  * rounded), y [num_rois,C,PH,PW]; sampling_ratio <= 0: ceil(roi extent / pooled extent) sample points per bin and axis.
