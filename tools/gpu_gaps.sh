@@ -12,7 +12,7 @@ tail -1 /tmp/bench_gaps.log | cut -c1-300
 python3 - > gpurun_out/${TAG}_gaps.txt <<'PY'
 import csv, glob, collections
 f = glob.glob('/tmp/trace_gaps/**/*kernel_trace.csv', recursive=True)[0]
-rows = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')[-70:])
+rows = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').replace('at::native::', '').split('(')[0][:64])
               for r in csv.DictReader(open(f)))
 rows = rows[len(rows) * 2 // 3:]            # the last third: steady state steps
 span = rows[-1][1] - rows[0][0]
