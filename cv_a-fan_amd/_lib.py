@@ -60,6 +60,7 @@ SIGNATURES = {
     "afan_bn_train_forward_partials": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _l, _p, _p, _p, _p, _p, _p]),
     "afan_conv_dgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),
     "afan_conv_dgrad_affine_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p]),
+    "afan_conv_dgrad_dual_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _p]),
     "afan_conv_dgrad_sc_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _i, _p, _p, _p, _p]),
     "afan_conv_dgrad_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),
@@ -97,6 +98,8 @@ SIGNATURES = {
     "afan_frozen_bottleneck_bwd_scratch": (_l, [_l, _l, _l, _l, _l, _i]),
     "afan_frozen_bottleneck_bwd": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                         _p, _p]),
+    "afan_frozen_bottleneck_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                              _p, _p, _p, _p, _p, _p]),
     "afan_affine_apply": (_i, [_p, _p, _p, _i, _l, _l, _l, _p, _i, _p]),
     "afan_avgpool_fwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),
     "afan_avgpool_bwd": (_i, [_p, _p, _i, _i, _l, _l, _l, _i, _p]),

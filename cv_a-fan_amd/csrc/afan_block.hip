@@ -73,7 +73,25 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
                                const void* wt3, const void* wtd, const float* al1, const float* al2, const float* al3,
                                const float* ald, float* gw1, float* gw2, float* gw3, float* gwd, float* wgrad_ws, void* scratch,
                                void* dx, afan_stream_t stream) {
-    if (!g || !x || !a1 || !a2 || !out || !wt1 || !wt2 || !wt3 || !al1 || !al2 || !al3 || !scratch) return AFAN_ENULL;
+    return afan_frozen_bottleneck_bwd_chain(g, nullptr, nullptr, x, a1, a2, out, n, h, w, cin, planes, stride, wt1, wt2, wt3, wtd, al1, al2, al3,
+                                            ald, gw1, gw2, gw3, gwd, wgrad_ws, scratch, dx, nullptr, nullptr, nullptr, stream);
+}
+
+// The same inside a chain of blocks (a stage: block i + 1's input IS block i's output).  Entering: g as above, or — g NULL — the
+// first step of this block's backward already done by the block behind it: pre_d3 = bf16(m * al3), pre_dres = m with m = the
+// output's ReLU mask applied to the gradient (pre_dres may be overwritten).  Leaving: dx as above, or — dx NULL, prev_al3 given —
+// that first step of the block IN FRONT done here, in the epilogue of this block's last input-gradient launch
+// (afan_conv_dgrad_dual_nhwc_bf16; where that kernel does not take the shape: the gradient into prev_dres, then the separate
+// launch): prev_d3 / prev_dres [n, cin, h, w] with prev_al3 = the block in front's last alpha row, its stored output = x.
+// One launch per block and pass less (the Detection iteration: ~410 of 4 800).  Same bits either way.
+int afan_frozen_bottleneck_bwd_chain(const void* g, void* pre_d3, void* pre_dres, const void* x, const void* a1, const void* a2,
+                                     const void* out, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t planes, int stride,
+                                     const void* wt1, const void* wt2, const void* wt3, const void* wtd, const float* al1, const float* al2,
+                                     const float* al3, const float* ald, float* gw1, float* gw2, float* gw3, float* gwd, float* wgrad_ws,
+                                     void* scratch, void* dx, const float* prev_al3, void* prev_d3, void* prev_dres, afan_stream_t stream) {
+    if (!x || !a1 || !a2 || !out || !wt1 || !wt2 || !wt3 || !al1 || !al2 || !al3 || !scratch) return AFAN_ENULL;
+    if (!g && (!pre_d3 || !pre_dres)) return AFAN_ENULL;
+    if (prev_al3 && (dx || !prev_d3 || !prev_dres)) return AFAN_ENULL;
     if (wtd && !ald) return AFAN_ENULL;
     if ((gw1 || gw2 || gw3 || gwd) && !wgrad_ws) return AFAN_ENULL;
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || planes <= 0 || !(stride == 1 || stride == 2)) return AFAN_ESHAPE;
@@ -82,12 +100,13 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
     uint16_t* d3 = (uint16_t*)scratch;                       // [n, co, ho, wo]
     uint16_t* dres = d3 + n * co * ho * wo;                  // [n, co, ho, wo]
     uint16_t* t2 = dres + n * co * ho * wo;                  // [n, planes, ho, wo]
+    if (!g) { d3 = (uint16_t*)pre_d3; dres = (uint16_t*)pre_dres; }
     uint16_t* d2 = t2 + n * planes * ho * wo;                // [n, planes, ho, wo]
     uint16_t* t1 = d2 + n * planes * ho * wo;                // [n, planes, h, w]
     uint16_t* d1 = t1 + n * planes * h * w;                  // [n, planes, h, w]
     uint16_t* dxs = d1 + n * planes * h * w;                 // [n, cin, h, w]
     int e;
-    if ((e = afan_affine_relu_bwd(g, out, al3, d3, dres, AFAN_BF16, AFAN_NHWC, n, co, ho * wo, 1, stream))) return e;
+    if (g && (e = afan_affine_relu_bwd(g, out, al3, d3, dres, AFAN_BF16, AFAN_NHWC, n, co, ho * wo, 1, stream))) return e;
     // an input gradient and the backward of the frozen BatchNorm + ReLU it runs into as ONE launch where the tiled kernel takes the
     // shape (afan_conv_dgrad_affine_nhwc_bf16: the same bits), else the two launches
     auto dgrad_bn = [&](const void* dyp, const void* wt, void* raw, void* dst, int64_t hi_, int64_t wi_, int64_t ci_, int64_t co_, int k, int st_,
@@ -101,9 +120,10 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
     if ((e = dgrad_bn(d3, wt3, t2, d2, ho, wo, planes, co, 1, 1, al2, a2))) return e;
     if ((e = dgrad_bn(d2, wt2, t1, d1, h, w, planes, planes, 3, stride, al1, a1))) return e;
     const void* addend = dres;
+    const bool want_dx = dx || prev_al3;
     if (wtd) {
         if ((e = afan_affine_relu_bwd(dres, nullptr, ald, dres, nullptr, AFAN_BF16, AFAN_NHWC, n, co, ho * wo, 0, stream))) return e;   // dd, in place
-        if (dx) {
+        if (want_dx) {
             if ((e = afan_conv_dgrad_nhwc_bf16(dres, wtd, dxs, n, h, w, cin, co, 1, stride, 1, nullptr, nullptr, nullptr, 0, nullptr,
                                                nullptr, nullptr, 1, stream))) return e;
             addend = dxs;
@@ -111,6 +131,15 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
     }
     if (dx && (e = afan_conv_dgrad_nhwc_bf16(d1, wt1, dx, n, h, w, cin, planes, 1, 1, 1, addend, nullptr, nullptr, 0, nullptr, nullptr,
                                              nullptr, 1, stream))) return e;
+    if (prev_al3) {
+        e = fuse_affine() ? afan_conv_dgrad_dual_nhwc_bf16(d1, wt1, prev_d3, prev_dres, n, h, w, cin, planes, 1, 1, addend, prev_al3, x, stream) : AFAN_ESHAPE;
+        if (e == AFAN_ESHAPE) {
+            if ((e = afan_conv_dgrad_nhwc_bf16(d1, wt1, prev_dres, n, h, w, cin, planes, 1, 1, 1, addend, nullptr, nullptr, 0, nullptr, nullptr,
+                                               nullptr, 1, stream))) return e;
+            e = afan_affine_relu_bwd(prev_dres, x, prev_al3, prev_d3, prev_dres, AFAN_BF16, AFAN_NHWC, n, cin, h * w, 1, stream);
+        }
+        if (e) return e;
+    }
     // weight gradients: one multi launch when the tuned kernel would tile the wanted problems alike, else one by one
     const void* xs[4]; const void* dys[4]; float* gws[4];
     int64_t ns[4], hs[4], ws_[4], cis[4], cos[4];

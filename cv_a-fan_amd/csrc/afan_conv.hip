@@ -586,10 +586,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
     const uint16_t* addp = pp.aff ? pp.aff_res : pp.addend;     // the one extra output-shaped operand of either fusion
-    u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];
+    const bool dual = pp.aff && pp.aff_bwd == 2;
+    u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS], pre_d[EPI_ROWS];
     {
         const int out_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), 0, addp ? out_bytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.addend), 0, (dual && pp.addend) ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t bxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bnx), 0, bn_bwd ? out_bytes : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bny), 0, (bn_bwd && pp.bny) ? out_bytes : 0, 0x00020000);
 #pragma unroll
@@ -597,6 +599,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             const int off = epi_on ? out_off[pr + q * ROWS_PER_PASS] : -1;
             const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
             if (addp) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
+            if (dual && pp.addend) pre_d[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)bo, 0, 0));
             if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
             if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
         }
@@ -632,7 +635,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         if (off >= 0 && ch_ok) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
-            if (pp.aff && pp.aff_bwd) {
+            if (dual) {
+                // a residual block's output, backwards: the gradient (this launch's + the other branch's, rounded like the
+                // dgrad-with-addend launch rounds it), masked by the block's stored output, leaves twice — as it is for the
+                // shortcut, times alpha for the last convolution's frozen BatchNorm (affine_bwd_kernel's two outputs)
+                const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
+                const u16x8 d = __builtin_bit_cast(u16x8, pre_d[q]);
+                u16x8 m;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = bf2f(v[j]);
+                    if (pp.addend) g = bf2f(f2bf(g + bf2f(d[j])));
+                    const float t = (bf2f(a[j]) > 0.f) ? g : 0.f;
+                    m[j] = f2bf(t);
+                    v[j] = f2bf(t * al[j]);
+                }
+                *reinterpret_cast<u16x8*>(pp.y2 + go) = m;
+            } else if (pp.aff && pp.aff_bwd) {
                 // the backward of the frozen BatchNorm + ReLU in front of this convolution, on the bf16-rounded input gradient:
                 // affine_bwd_kernel's expression (mask from the stored activation, then the plain multiply)
                 const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
@@ -925,7 +944,7 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
 static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                       int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                       const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials, double* bn_acc, int groups,
-                      afan_stream_t stream, const float* aff_alpha = nullptr, const void* aff_act = nullptr) {
+                      afan_stream_t stream, const float* aff_alpha = nullptr, const void* aff_act = nullptr, void* dx2 = nullptr) {
     int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
     if (e) return e;
     if (!dy || !wt || !dx) return AFAN_ENULL;
@@ -952,9 +971,10 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
     p.addend = (const uint16_t*)addend;
     if (aff_alpha) {                                         // the layer in front's frozen BatchNorm + ReLU backward in the epilogue
         if (!aff_act) return AFAN_ENULL;
-        if (addend || bn_partials || bn_acc || dy_sc || groups > 1 || !aligned(aff_act, 16)) return AFAN_ESHAPE;
+        if ((addend && !dx2) || bn_partials || bn_acc || dy_sc || groups > 1 || !aligned(aff_act, 16)) return AFAN_ESHAPE;
+        if (dx2 && (!aligned(dx2, 16) || (addend && !aligned(addend, 16)))) return AFAN_EALIGN;
         if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;      // (that kernel's epilogue has no such form)
-        p.aff = aff_alpha; p.aff_res = (const uint16_t*)aff_act; p.aff_bwd = 1;
+        p.aff = aff_alpha; p.aff_res = (const uint16_t*)aff_act; p.aff_bwd = dx2 ? 2 : 1; p.y2 = (uint16_t*)dx2;
     }
     if (bn_partials && bn_acc) return AFAN_ESHAPE;
     if (bn_partials || bn_acc) {
@@ -1242,6 +1262,20 @@ int afan_conv_dgrad_affine_nhwc_bf16(const void* dy, const void* wt, void* dx, i
     if (!alpha || !act) return AFAN_ENULL;
     return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, k, stride, 1, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 1, stream,
                       alpha, act);
+}
+
+// The input gradient that arrives at the OUTPUT of a frozen-BatchNorm residual block (Detection's bottlenecks: out = relu(bn3(conv3) +
+// shortcut)), with that block's first backward step applied on the way out: g = bf16(bf16(dgrad(dy)) + addend) (addend optional:
+// the consumer block's own shortcut share), m = act > 0 ? g : 0, dres = m, d3 = bf16(m * alpha[c]) — bit for bit
+// afan_conv_dgrad_nhwc_bf16(addend) followed by afan_affine_relu_bwd(relu = 1, dx = d3, dres = dres).  alpha: the producing block's
+// LAST BatchNorm's alpha row [ci]; act: its stored output (= this convolution's input tensor) [n, ci, hi, wi].  AFAN_ESHAPE where
+// another kernel owns the shape.
+int afan_conv_dgrad_dual_nhwc_bf16(const void* dy, const void* wt, void* d3, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                                   int64_t co, int k, int stride, const void* addend, const float* alpha, const void* act,
+                                   afan_stream_t stream) {
+    if (!alpha || !act || !dres) return AFAN_ENULL;
+    return dgrad_impl(dy, nullptr, wt, d3, n, hi, wi, ci, co, k, stride, 1, addend, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 1, stream,
+                      alpha, act, dres);
 }
 
 // The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77, option B):

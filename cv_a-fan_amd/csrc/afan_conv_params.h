@@ -46,6 +46,10 @@ struct ConvP {
     int aff_bwd;                 // 1: the BACKWARD of such a layer applied to an input gradient on its way out: aff = that layer's alpha
                                  //   row [Co], aff_res = its stored OUTPUT: y = bf16((aff_res > 0 ? bf16(dgrad) : 0) * alpha) —
                                  //   afan_affine_relu_bwd's expression on the dgrad launch's rounded result
+                                 // 2: the same at a residual block's OUTPUT, where the gradient splits: g = bf16(bf16(dgrad) + addend)
+                                 //   (addend optional), m = aff_res > 0 ? g : 0; y2 = m (the shortcut's share), y = bf16(m * alpha) (the
+                                 //   last convolution's) — afan_affine_relu_bwd with both outputs, on the dgrad-with-addend launch's result
+    uint16_t* y2;                //   (aff_bwd == 2 only)
     int64_t a_extra;             // bytes beyond the gathered tensor x that taps with aofs != 0 may reach (descriptor range)
     int multi;                   // 1: the classes are INDEPENDENT forward problems on the same input (ASPP's atrous branches,
     int64_t w_off[4];            //   _deeplab.py:173-176): class z reads weights w + w_off[z], writes y + y_off[z] (elements),

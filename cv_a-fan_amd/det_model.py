@@ -229,6 +229,22 @@ def _block_plan(blk, x):
     return plan
 
 
+def _stage_backward(plans, saved, g, want_dx):
+    """The blocks of a stage backwards.  Block i + 1's input is block i's output, so the first step of block i's backward — the
+    gradient masked by that output's ReLU, once as it is (the shortcut's share) and once times the last BatchNorm's alpha — rides in
+    the epilogue of block i + 1's last input-gradient launch (ops.frozen_bottleneck_bwd_plan `prev`): no launch of its own."""
+    pre = None
+    for i in range(len(plans) - 1, -1, -1):
+        x, a1, a2, out = saved[4 * i:4 * i + 4]
+        res = ops.frozen_bottleneck_bwd_plan(g if pre is None else None, x, a1, a2, out, plans[i], i > 0 or want_dx, pre=pre,
+                                             prev=plans[i - 1] if i > 0 else None)
+        if i > 0:
+            pre = res
+        else:
+            g = res
+    return g
+
+
 class _FrozenStageFn(torch.autograd.Function):
     """A whole stage (layer1 .. layer4: 3 / 4 / 23 / 3 frozen-BatchNorm bottlenecks) as ONE autograd node: the same native calls
     as one `_FrozenBlockFn` per block, issued in a loop — the per-node cost of `Function.apply` and of the engine's scheduling
@@ -253,9 +269,7 @@ class _FrozenStageFn(torch.autograd.Function):
         g = _like_layout(g, last)
         if g.dtype != last.dtype:
             g = g.to(last.dtype)
-        for i in range(len(plans) - 1, -1, -1):
-            x, a1, a2, out = saved[4 * i:4 * i + 4]
-            g = ops.frozen_bottleneck_bwd_plan(g, x, a1, a2, out, plans[i], i > 0 or ctx.needs_input_grad[0])
+        g = _stage_backward(plans, saved, g, ctx.needs_input_grad[0])
         return (g, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
@@ -326,10 +340,7 @@ class _StageGraphs:
         torch.cuda.synchronize(it.out.device)
         g = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):       # (runs on the engine's thread; private pool)
-            cur = it.g
-            for i in range(len(it.plans) - 1, -1, -1):
-                x, a1, a2, out = it.saved[4 * i:4 * i + 4]
-                cur = ops.frozen_bottleneck_bwd_plan(cur, x, a1, a2, out, it.plans[i], i > 0 or it.want_dx)
+            cur = _stage_backward(it.plans, it.saved, it.g, it.want_dx)
         it.dx, it.bwd = cur, g
 
 

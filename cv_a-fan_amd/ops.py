@@ -625,19 +625,28 @@ def frozen_bottleneck_fwd_plan(x, p):
     return out, a1, a2
 
 
-def frozen_bottleneck_bwd_plan(g, x, a1, a2, out, p, want_dx):
+def frozen_bottleneck_bwd_plan(g, x, a1, a2, out, p, want_dx, pre=None, prev=None):
+    """One block's backward.  Inside a stage's chain (det_model._stage_backward): `pre` = (d3, dres), this block's first backward
+    step as the block behind it left it (g is then None); `prev` = the plan of the block in front, whose first step this call's
+    last input-gradient launch performs on the way out — returns that block's (d3, dres) instead of dx
+    (afan_frozen_bottleneck_bwd_chain)."""
     lib = _lib.load()
     scratch = _workspace(x, p.bwd_scratch, "fbk_bwd")
     wws = _workspace(x, p.wgrad_ws, "wgrad") if p.wgrad_ws else None
-    dx = torch.empty_like(x) if want_dx else None
     CALLS["conv_dgrad"] += 2 + (1 if want_dx else 0) + (1 if (want_dx and p.has_ds) else 0)
     CALLS["conv_wgrad"] += p.n_wgrad
     wt, al, gw = p.wt_ptrs, p.al_ptrs, p.gw_ptrs
-    check(lib.afan_frozen_bottleneck_bwd(C.c_void_p(g.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(a2.data_ptr()),
-                                         C.c_void_p(out.data_ptr()), p.n, p.h, p.w, p.cin, p.planes, p.stride, wt[0], wt[1], wt[2], wt[3],
-                                         al[0], al[1], al[2], al[3], gw[0], gw[1], gw[2], gw[3], _ptr(wws), C.c_void_p(scratch.data_ptr()),
-                                         _ptr(dx), C.c_void_p(_raw_stream(x.device.index))), "afan_frozen_bottleneck_bwd")
-    return dx
+    dx = nd3 = ndres = None
+    if prev is not None:
+        nd3, ndres = torch.empty_like(x), torch.empty_like(x)
+    elif want_dx:
+        dx = torch.empty_like(x)
+    check(lib.afan_frozen_bottleneck_bwd_chain(_ptr(g), _ptr(pre[0]) if pre else None, _ptr(pre[1]) if pre else None, C.c_void_p(x.data_ptr()),
+                                               C.c_void_p(a1.data_ptr()), C.c_void_p(a2.data_ptr()), C.c_void_p(out.data_ptr()), p.n, p.h, p.w, p.cin,
+                                               p.planes, p.stride, wt[0], wt[1], wt[2], wt[3], al[0], al[1], al[2], al[3], gw[0], gw[1], gw[2], gw[3],
+                                               _ptr(wws), C.c_void_p(scratch.data_ptr()), _ptr(dx), prev.al_ptrs[2] if prev is not None else None,
+                                               _ptr(nd3), _ptr(ndres), C.c_void_p(_raw_stream(x.device.index))), "afan_frozen_bottleneck_bwd_chain")
+    return (nd3, ndres) if prev is not None else dx
 
 
 def frozen_bottleneck_bwd(g, x, a1, a2, out, planes, stride, wts, als, gws, want_dx):
@@ -1298,6 +1307,27 @@ def conv_dgrad_affine(dy, wt, in_hw, stride, alpha, act):
     check(rc, "afan_conv_dgrad_affine_nhwc_bf16")
     CALLS["conv_dgrad"] += 1
     return dx
+
+
+def conv_dgrad_dual(dy, wt, in_hw, stride, addend, alpha, act):
+    """(d3, dres) = the gradient arriving at a frozen-BatchNorm residual block's output with that block's first backward step
+    applied on the way out, in ONE launch (afan_conv_dgrad_dual_nhwc_bf16): g = bf16(bf16(dgrad(dy, wt)) + addend) (addend may be
+    None), m = act > 0 ? g : 0, dres = m, d3 = bf16(m * alpha[c]).  None where another kernel owns the shape (the caller issues
+    conv_dgrad(addend) + affine_relu_backward with both outputs: the same bits)."""
+    lib = _lib.load()
+    _cl4(dy, "dy"), _cl4(wt, "wt"), _cl4(act, "act")
+    n, co, ho, wo = dy.shape
+    ci, _, k, _ = wt.shape
+    hi, wi = in_hw
+    d3 = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    dres = torch.empty_like(d3)
+    rc = lib.afan_conv_dgrad_dual_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(d3), _ptr(dres), n, hi, wi, ci, co, k, int(stride), _ptr(addend), _ptr(alpha),
+                                            _ptr(act), _stream(dy))
+    if rc == -3:
+        return None
+    check(rc, "afan_conv_dgrad_dual_nhwc_bf16")
+    CALLS["conv_dgrad"] += 1
+    return d3, dres
 
 
 def affine_relu_backward(dy, y, alpha, relu, want_dx=True, want_dres=False):

@@ -295,6 +295,13 @@ int afan_conv_dgrad_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t 
  * afan_conv_dgrad_nhwc_bf16 followed by afan_affine_relu_bwd(relu = 1).  AFAN_ESHAPE where another kernel owns the shape. */
 int afan_conv_dgrad_affine_nhwc_bf16(const void* dy, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co,
                                      int k, int stride, const float* alpha, const void* act, afan_stream_t stream);
+/* The gradient arriving at the OUTPUT of a frozen-BatchNorm residual block with that block's first backward step applied on the way
+ * out: g = bf16(bf16(dgrad(dy)) + addend) (addend optional), m = act > 0 ? g : 0, dres = m, d3 = bf16(m * alpha[c]) — bit for bit
+ * afan_conv_dgrad_nhwc_bf16(addend) followed by afan_affine_relu_bwd(relu = 1) with both outputs (Detection/backbone/
+ * resnet101_ori.py:118-125 backwards).  AFAN_ESHAPE where another kernel owns the shape. */
+int afan_conv_dgrad_dual_nhwc_bf16(const void* dy, const void* wt, void* d3, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                                   int64_t co, int k, int stride, const void* addend, const float* alpha, const void* act,
+                                   afan_stream_t stream);
 /* The input gradient of a residual block's two stride-2 branches in ONE launch (Classification/resnet_s.py:52-77 with the
  * option-B projection): dx = conv_transpose(dy, w1: 3x3 / 2, pad 1) + conv_transpose(dy_sc, w_sc: 1x1 / 2) — what autograd
  * computes as two input gradients and a sum at main_perturb.py:200 / attack_algo.py:52.  dy, dy_sc: [N, hi/2, wi/2, co] bf16
@@ -484,6 +491,15 @@ int afan_frozen_bottleneck_bwd(const void* g, const void* x, const void* a1, con
                                const void* wt3, const void* wtd, const float* al1, const float* al2, const float* al3,
                                const float* ald, float* gw1, float* gw2, float* gw3, float* gwd, float* wgrad_ws, void* scratch,
                                void* dx, afan_stream_t stream);
+/* The same inside a chain of blocks (a stage: block i + 1's input is block i's output): g NULL -> the first step of this block's
+ * backward was done by the block behind it (pre_d3 = bf16(m * al3), pre_dres = m, m = the output's ReLU mask applied to the
+ * gradient; pre_dres may be overwritten); dx NULL and prev_al3 given -> that step of the block in front is done HERE, in the
+ * epilogue of the last input-gradient launch (afan_conv_dgrad_dual_nhwc_bf16): prev_d3 / prev_dres [n, cin, h, w]. */
+int afan_frozen_bottleneck_bwd_chain(const void* g, void* pre_d3, void* pre_dres, const void* x, const void* a1, const void* a2,
+                                     const void* out, int64_t n, int64_t h, int64_t w, int64_t cin, int64_t planes, int stride,
+                                     const void* wt1, const void* wt2, const void* wt3, const void* wtd, const float* al1, const float* al2,
+                                     const float* al3, const float* ald, float* gw1, float* gw2, float* gw3, float* gwd, float* wgrad_ws,
+                                     void* scratch, void* dx, const float* prev_al3, void* prev_d3, void* prev_dres, afan_stream_t stream);
 /* nn.AdaptiveAvgPool2d(1) (_deeplab.py:133): y[n,c] = mean over hw (fp32 accumulate); dx = dy / hw broadcast.
  * pooled_f32 != 0: the pooled side (y / dy) is fp32 whatever `dtype` the map has. */
 int afan_avgpool_fwd(const void* x, void* y, int dtype, int layout, int64_t n, int64_t c, int64_t hw, int pooled_f32,

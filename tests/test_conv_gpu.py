@@ -588,3 +588,25 @@ def test_dgrad_with_frozen_batchnorm_backward_epilogue_equals_two_launches(pkg, 
     want, _ = pkg.ops.affine_relu_backward(raw, act, alpha, True)
     got = pkg.ops.conv_dgrad_affine(dy, wt, (h, w), st, alpha, act)
     assert got is not None and torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("with_addend", [False, True])
+@pytest.mark.parametrize("shape", [(1, 1024, 256, 38, 57, 1, 1), (1, 256, 64, 150, 226, 1, 1), (2, 512, 128, 40, 56, 1, 1), (128, 2048, 512, 7, 7, 1, 1),
+                                   (1, 256, 256, 38, 57, 3, 1)])
+def test_dgrad_with_block_output_backward_epilogue_equals_two_launches(pkg, gpu, shape, with_addend):
+    """afan_conv_dgrad_dual_nhwc_bf16 (the input gradient that arrives at a frozen-BatchNorm residual block's output, plus the other
+    branch's share, masked by that output and leaving twice: as it is for the shortcut, times alpha for the last convolution)
+    against afan_conv_dgrad_nhwc_bf16(addend) followed by afan_affine_relu_bwd with both outputs: the same bits."""
+    n, ci, co, h, w, k, st = shape
+    g = torch.Generator().manual_seed(ci + co + k + int(with_addend))
+    cl = torch.channels_last
+    dy = torch.randn(n, co, h, w, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl)
+    wt = (torch.randn(ci, co, k, k, generator=g) / (co * k * k) ** 0.5).to(gpu).bfloat16().contiguous(memory_format=cl)
+    act = torch.relu(torch.randn(n, ci, h, w, generator=g)).to(gpu).bfloat16().contiguous(memory_format=cl)      # ~half zeros
+    add = torch.randn(n, ci, h, w, generator=g).to(gpu).bfloat16().contiguous(memory_format=cl) if with_addend else None
+    alpha = (torch.rand(ci, generator=g) + 0.5).to(gpu)
+    raw = pkg.ops.conv_dgrad(dy, wt, (h, w), st, addend=add)
+    want = pkg.ops.affine_relu_backward(raw, act, alpha, True, want_dx=True, want_dres=True)
+    got = pkg.ops.conv_dgrad_dual(dy, wt, (h, w), st, add, alpha, act)
+    assert got is not None
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])

@@ -288,3 +288,34 @@ def test_frozen_bottleneck_node_equals_layer_by_layer_path(pkg, gpu):
     assert _rel(a[2].cpu().numpy(), b[2].cpu().numpy()) < 3e-2      # image gradient through 33 bf16 blocks
     worst = max((_rel(a[1][n].cpu().numpy(), b[1][n].cpu().numpy()), n) for n in b[1] if float(b[1][n].abs().max()) > 0)
     assert worst[0] < 3e-2, worst
+
+
+def test_stage_backward_chain_equals_block_by_block(pkg, gpu):
+    """det_model._stage_backward hands block i's first backward step (the gradient masked by its output, once plain and once times
+    the last BatchNorm's alpha) to the epilogue of block i + 1's last input-gradient launch (afan_frozen_bottleneck_bwd_chain);
+    with one autograd node per block (`_FrozenStageFn.ON = False`) every block issues its own launch for it.  Same bits: the four
+    losses of a training forward, the image gradient and every parameter gradient."""
+    g = golden("det_frcnn_r101")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    fn = pkg.det_model._FrozenStageFn
+    res, old = {}, fn.ON
+    try:
+        for on in (True, False):
+            fn.ON = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            arena = pkg.arena.ParamArena(m, skip=())
+            torch.manual_seed(11)                                   # the host randperm draws of the RPN / ROI sampling
+            x = images.clone().requires_grad_(True)
+            losses = m.train().forward({"x": x, "adv": None, "out_idx": 0, "flag": "clean"}, bboxes, labels)
+            arena.zero_grad()
+            sum(l.mean() for l in losses).backward()
+            torch.cuda.synchronize()
+            res[on] = ([l.detach().clone() for l in losses], {n: p.grad.clone() for n, p in zip(arena.names, arena.params)}, x.grad.clone())
+    finally:
+        fn.ON = old
+    a, b = res[True], res[False]
+    assert all(torch.equal(u, v) for u, v in zip(a[0], b[0]))
+    assert torch.equal(a[2], b[2])
+    assert a[1].keys() == b[1].keys()
+    for n in a[1]:
+        assert torch.equal(a[1][n], b[1][n]), n
