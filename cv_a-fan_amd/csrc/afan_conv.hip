@@ -609,16 +609,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
     //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
     // image group of this row tile (tiles never straddle the two halves: checked on the host)
-    int grp = 0;
-    uint32_t grp_m0 = 0;
-    if (pp.groups == 2) {
-        const uint32_t half = (uint32_t)(pp.N / 2) * Hg * Wg;
-        if (m0 >= half) { grp = 1; grp_m0 = half; }
-    }
-    const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
-    double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
+    // Image groups (two half-batches with their own BatchNorm sums): a tile belongs to the half its rows are in; the ONE tile
+    // of a launch that holds rows of both (half-batches of any size: the row count need not be a multiple of the tile) walks
+    // its rows twice, once per group, each row stored and summed in the pass of its own group.
+    const uint32_t half = pp.groups == 2 ? (uint32_t)(pp.N / 2) * Hg * Wg : 0u;
+    const bool straddle = pp.groups == 2 && m0 < half && m0 + BM > half;
+    const int n_pass = straddle ? 2 : 1;
     const float* shift_p = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
     uint16_t* y_p = pp.y + pp.y_off[blockIdx.z];
+    for (int gpass = 0; gpass < n_pass; ++gpass) {
+    const int grp = straddle ? gpass : ((pp.groups == 2 && m0 >= half) ? 1 : 0);
+    const bool grp_first = grp == 0 ? m0 == 0 : (straddle || m0 == half);     // this tile holds the group's first row
+    const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
+    double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -631,7 +634,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
     for (int q = 0; q < EPI_ROWS; ++q) {
         const int r = pr + q * ROWS_PER_PASS;
-        const int off = epi_on ? out_off[r] : -1;
+        const int off = (epi_on && (!straddle || ((m0 + (uint32_t)r >= half) == (grp == 1)))) ? out_off[r] : -1;
         if (off >= 0 && ch_ok) {
             u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
             const int64_t go = (int64_t)off + n0 + pc * 8;
@@ -733,7 +736,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 double* dst = acc_blk + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
                 unsafeAtomicAdd(dst + n0 + tid, (double)a);
                 unsafeAtomicAdd(dst + pp.Co + n0 + tid, (double)b);
-                if (!bn_bwd && m0 == grp_m0 && (blockIdx.z == 0 || pp.multi))   // snapshot of the shift for the BN that consumes the sums
+                if (!bn_bwd && grp_first && (blockIdx.z == 0 || pp.multi))   // snapshot of the shift for the BN that consumes the sums
                     reinterpret_cast<float*>(acc_blk + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = shift_p ? shift_p[n0 + tid] : 0.f;
             } else {
                 const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
@@ -741,7 +744,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 pp.stats[((int64_t)1 * pp.Co + n0 + tid) * G + slot] = b;
             }
         }
+        if (n_pass > 1) __syncthreads();         // the second pass reuses the per-wave partial sums' LDS
     }
+    }   // group passes
 }
 
 // The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward
@@ -912,14 +917,17 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
 #undef AFAN_CONV_GO
 }
 
-// groups = 2: rows of the two half-batches must fall into different row tiles (largest tile: 128 rows), and the sums go
-// to per-group f64 accumulator blocks (the slab form has no group dimension)
+// groups = 2: the sums go to per-group f64 accumulator blocks (the slab form has no group dimension)
+static bool small_groups_ok(const ConvP& p) {
+    return p.groups != 2 || ((int64_t)(p.N / 2) * p.cls[0].Hg * p.cls[0].Wg) % 128 == 0;
+}
 int set_groups(ConvP& p, int groups, int64_t n, int64_t positions_per_image, int64_t channels, bool have_acc) {
     p.groups = 1;
     p.acc_stride = 0;
     if (groups <= 1) return AFAN_OK;
     if (groups != 2 || (n & 1) || !have_acc) return AFAN_ESHAPE;
-    if (((n / 2) * positions_per_image) % 128 != 0) return AFAN_ESHAPE;
+    // (the tiled kernel takes half-batches of any size: its one straddling tile sums per row; the small-channel kernel walks whole
+    // 128-row tiles per group: small_groups_ok)
     p.groups = 2;
     p.acc_stride = (int)((afan_nhwc::acc_doubles(channels) + 1) & ~(int64_t)1);
     return AFAN_OK;
@@ -1008,7 +1016,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
                 const int t = r * k + s;
                 c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
             }
-        if (small_eligible(p)) return p.aff ? AFAN_ESHAPE : small_launch(p, st);
+        if (small_eligible(p)) return (p.aff || !small_groups_ok(p)) ? AFAN_ESHAPE : small_launch(p, st);
         if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
         return dispatch(p, st, true);
     }
@@ -1043,7 +1051,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
             ++nc;
         }
     p.n_classes = nc;
-    if (!dy_sc && small_eligible(p)) return p.aff ? AFAN_ESHAPE : small_launch(p, st);
+    if (!dy_sc && small_eligible(p)) return (p.aff || !small_groups_ok(p)) ? AFAN_ESHAPE : small_launch(p, st);
     if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
     return dispatch(p, st, true);
 }
@@ -1108,7 +1116,7 @@ int afan_conv_fwd_nhwc_bf16(const void* x, const void* w, void* y, int64_t n, in
     const double M = (double)n * p.Ho * p.Wo;
     AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * (M * co + (double)n * hi * wi * ci + (double)co * k * k * ci),
                     2.0 * M * co * k * k * ci, st);
-    if (small_eligible(p)) return small_launch(p, st);
+    if (small_eligible(p)) return small_groups_ok(p) ? small_launch(p, st) : AFAN_ESHAPE;
     if (ci % 8 != 0 || co % 8 != 0 || ci < 40 || co < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab statistics)
     if (!stats_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, ci, co, k, stride)) {   // weights-in-registers kernel
         afan_c64::Params q{};

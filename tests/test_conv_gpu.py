@@ -288,7 +288,12 @@ def test_halo_form_equals_per_tap_form(pkg, gpu, n, ci, co, h, w):
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,stride", [(8, 64, 128, 16, 3, 2), (16, 128, 128, 8, 3, 1), (64, 256, 512, 4, 1, 2),
-                                                 (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1), (256, 128, 128, 16, 3, 1)])
+                                                 (32, 256, 256, 8, 3, 1), (64, 512, 512, 4, 3, 1), (256, 128, 128, 16, 3, 1),
+                                                 # half-batches that are NOT a whole number of row tiles (DeepLab's 33 x 33 maps at
+                                                 # 2 + 2 images, one image per half, a stride-2 launch's parity classes): the one
+                                                 # tile that holds rows of both halves sums per row
+                                                 (4, 256, 256, 33, 3, 1), (4, 1024, 256, 33, 1, 1), (2, 256, 1024, 33, 1, 1),
+                                                 (6, 64, 128, 18, 3, 2), (2, 512, 512, 7, 3, 1)])
 def test_grouped_statistics_equal_separate_launches(pkg, gpu, n, ci, co, h, k, stride):
     """groups = 2 (two concatenated half-batches, BatchNorm statistics per half): one launch over [a | b] must equal the
     two launches over a and over b — outputs bit for bit (row tiles are independent), sums to accumulation-order noise."""
