@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     ap.add_argument("--no_batch_final", action="store_true", help="run the adv and clean final passes separately (A/B)")
     ap.add_argument("--no_fold_clean", action="store_true", help="separate first PGD pass and final clean pass (A/B)")
+    ap.add_argument("--no_batch_tails", action="store_true", help="DeepLab: the two sample-point forwards as two passes instead of one concatenated pass (A/B)")
     ap.add_argument("--no_fold_pgd0", action="store_true", help="DeepLab: keep the first pass of both PGD loops separate from the clean pass (A/B)")
     ap.add_argument("--dropout", type=float, default=None, help="DeepLab: override the head's nn.Dropout p (reference: 0.1)")
     ap.add_argument("--force_fold_clean", action="store_true", help="one clean tail pass regardless of the size heuristic (A/B)")
@@ -327,7 +328,8 @@ def main():
                                              mix_layer="11", mix_sd=True, lr=0.01, use_graph=not args.no_graph,
                                              dual_bn=args.dual_bn,
                                              fold_clean=False if args.no_fold_clean else None,
-                                             fold_pgd0=False if (args.no_fold_clean or args.no_fold_pgd0) else None)
+                                             fold_pgd0=False if (args.no_fold_clean or args.no_fold_pgd0) else None,
+                                             batch_tails=False if args.no_batch_tails else None)
         if args.dropout is not None:               # (the reference's DeepLab head has nn.Dropout(0.1), _deeplab.py:185)
             for m_ in model.modules():
                 if isinstance(m_, nn.Dropout):
@@ -497,12 +499,13 @@ def main():
             # pass (:167) + K SE + K SD PGD passes + clean / SE1 / SE2 / SD forwards (:193-209)
             K_ = args.pgd_steps
             drop_p = max([m_.p for m_ in model.modules() if isinstance(m_, nn.Dropout)] + [0.0])
+            se12 = "SE1 + SE2 as ONE concatenated pass (BatchNorm statistics and dropout per half)" if r.get("batch_tails") else "SE1 / SE2"
             if r.get("fold_pgd0"):
                 sched = (f"ONE clean pass standing for :166, :167, :193 AND the first pass of both PGD loops (dropout p = {drop_p}: "
-                         f"identical passes), {K_ - 1} SE + {K_ - 1} SD PGD passes, SE1 / SE2 / SD forwards, one joint backward")
+                         f"identical passes), {K_ - 1} SE + {K_ - 1} SD PGD passes, {se12} / SD forwards, one joint backward")
             elif r.get("fold_clean"):
                 sched = (f"ONE clean pass standing for :166, :167 and :193 (two dropout draws on its ASPP output, p = {drop_p}), "
-                         f"{K_} SE + {K_} SD PGD passes, SE1 / SE2 / SD forwards, one joint backward")
+                         f"{K_} SE + {K_} SD PGD passes, {se12} / SD forwards, one joint backward")
             else:
                 sched = (f"main_aug_final.py:158-232 as written: head pass + clean decoder-head pass, {K_} SE + {K_} SD PGD passes, "
                          "clean / SE1 / SE2 / SD forwards, one joint backward")

@@ -389,6 +389,11 @@ class Dropout(nn.Dropout):
         mask = self.mask
         if mask is not None:
             mask = _match(mask.to(x.device, torch.uint8), _dense(x))
+        G = _Flags.bn_groups
+        if G != 1 and mask is None:
+            # two concatenated passes (resnet_s.bn_groups): each is its own model(...) call in the reference, with its own draw
+            n = x.shape[0] // G
+            return torch.cat([_DropoutFn.apply(x[g * n:(g + 1) * n], float(self.p), None) for g in range(G)], dim=0)
         return _DropoutFn.apply(x, float(self.p), mask)
 
 
@@ -608,7 +613,7 @@ class ASPP(nn.Module):
     def forward(self, x, pre_dropout=False):
         x = _to_compute(x, self.convs[0][0].compute_dtype)
         atrous = [m for m in list(self.convs)[1:] if isinstance(m, ASPPConv)]
-        if ASPP.MULTI and 2 <= len(atrous) <= 4 and len(atrous) == len(self.convs) - 2 and _multi_branch_ok(x, atrous):
+        if ASPP.MULTI and _Flags.bn_groups == 1 and 2 <= len(atrous) <= 4 and len(atrous) == len(self.convs) - 2 and _multi_branch_ok(x, atrous):
             # the atrous branches in one launch: at 2 images per GPU each fills a quarter of the chip for 92 us
             convs, bns = [m[0] for m in atrous], [m[1] for m in atrous]
             reqs = [[b.running_mean, None] for b in bns]

@@ -184,8 +184,12 @@ class _ConvFn(torch.autograd.Function):
         if ctx.own:
             ctx.save_for_backward(x, w_lp)
             if stats_req is not None:   # [shift tensor | None, reusable partials buffer | None] -> filled with ConvStats
+                G = _Flags.bn_groups
+                if G != 1 and not ops._conv_acc_ok(w_lp.shape[0]):
+                    stats_req.append(None)                   # (no accumulator form for this channel count: the BatchNorm sums per half itself)
+                    return ops.conv_fwd(x, w_lp, stride[0], dilation=dilation[0])
                 y, st = ops.conv_fwd(x, w_lp, stride[0], stats_shift=stats_req[0], want_stats=True,
-                                     stats_buf=stats_req[1], dilation=dilation[0])
+                                     stats_buf=stats_req[1], dilation=dilation[0], groups=G)
                 stats_req.append(st)
                 return y
             return ops.conv_fwd(x, w_lp, stride[0], dilation=dilation[0])
@@ -443,15 +447,28 @@ def _own_conv_ok(x, w, stride, padding, dilation=(1, 1)):
 
 
 class _BNTrainFn(torch.autograd.Function):
-    """y = [relu](bn_train(x) [+ residual]) via afan_bn_train_forward / afan_bn_backward."""
+    """y = [relu](bn_train(x) [+ residual]) via afan_bn_train_forward / afan_bn_backward.  groups = 2 (resnet_s.bn_groups): x
+    is two concatenated half-batches normalised separately, running statistics updated half by half in order — one launch
+    where the producing convolution summed per half (conv_stats with accumulators), else one launch per half."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad, conv_stats=None):
+    def forward(ctx, x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, want_pgrad, conv_stats=None, groups=1):
         x = _dense(x)
         if residual is not None:
             residual = _like_layout(residual, x)
-        y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, conv_stats)
-        ctx.relu, ctx.has_res, ctx.want_pgrad = relu, residual is not None, want_pgrad
+        if groups == 1:
+            y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, conv_stats)
+        elif conv_stats is not None and conv_stats.acc is not None:
+            y, stats = ops.bn_train_forward(x, weight, bias, residual, relu, eps, momentum, rmean, rvar, nbt, conv_stats, groups=groups)
+        else:
+            n = x.shape[0] // groups
+            y = torch.empty_like(x)
+            stats = torch.empty(groups, 4, x.shape[1], dtype=torch.float32, device=x.device)
+            for g in range(groups):
+                sl = slice(g * n, (g + 1) * n)
+                ops.bn_train_forward(x[sl], weight, bias, None if residual is None else residual[sl], relu, eps, momentum, rmean, rvar,
+                                     nbt, None, out=y[sl], stats_out=stats[g])
+        ctx.relu, ctx.has_res, ctx.want_pgrad, ctx.groups = relu, residual is not None, want_pgrad, groups
         # the ReLU mask is recomputed from x when there is no residual; otherwise y carries it
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, stats, weight, bias)
         return y
@@ -471,11 +488,21 @@ class _BNTrainFn(torch.autograd.Function):
             else:
                 dwb = torch.empty(2, x.shape[1], dtype=torch.float32, device=x.device)
                 dw, db = dwb[0], dwb[1]
-        dx, dres = ops.bn_backward(_like_layout(gy, x), x, y, stats, weight, bias, ctx.relu,
-                                   ctx.has_res and ctx.needs_input_grad[3], dw, db, accumulate=direct)
+        want_dres = ctx.has_res and ctx.needs_input_grad[3]
+        gy = _like_layout(gy, x)
+        if ctx.groups == 1:
+            dx, dres = ops.bn_backward(gy, x, y, stats, weight, bias, ctx.relu, want_dres, dw, db, accumulate=direct)
+        else:
+            G, n = ctx.groups, x.shape[0] // ctx.groups
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if want_dres else None
+            for g in range(G):                     # (both halves' parameter gradients: the second launch adds to the first's)
+                sl = slice(g * n, (g + 1) * n)
+                ops.bn_backward(gy[sl], x[sl], None if y is None else y[sl], stats[g], weight, bias, ctx.relu, want_dres, dw, db,
+                                accumulate=direct or g > 0, dx_out=dx[sl], dres_out=dres[sl] if want_dres else None)
         if direct:
             dw = db = None
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 class _BlockFn(torch.autograd.Function):
@@ -801,12 +828,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         self._branch = branch
 
     def fused(self, x, residual=None, relu=False, conv_stats=None):
-        if _Flags.bn_groups != 1 and self.training:
-            raise NotImplementedError("grouped BatchNorm statistics are implemented by the one-node residual blocks only")
         if self.training:
             mom = self.momentum if self.momentum is not None else 0.1
+            G = _Flags.bn_groups
+            if G != 1 and (x.shape[0] % G or not x.is_cuda):
+                raise ValueError("grouped BatchNorm statistics: the batch must split into equal half-batches on the GPU")
             return _BNTrainFn.apply(x, self.weight, self.bias, residual, relu, self.eps, mom, self.running_mean,
-                                    self.running_var, self.num_batches_tracked, _Flags.param_grads, conv_stats)
+                                    self.running_var, self.num_batches_tracked, _Flags.param_grads, conv_stats, G)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad and _Flags.param_grads):
             if x.requires_grad:
                 raise NotImplementedError("eval-mode BatchNorm backward is not on the A-FAN path (the reference "

@@ -55,6 +55,16 @@ def _f32_logits(o):
     return o.is_cuda and o.dtype == torch.float32
 
 
+def _halves(o):
+    """The two passes' logits out of one concatenated pass (deeplab.LowResLogits or a plain tensor)."""
+    from .deeplab import LowResLogits
+    if isinstance(o, LowResLogits):
+        n = o.logits.shape[0] // 2
+        return LowResLogits(o.logits[:n], o.size), LowResLogits(o.logits[n:], o.size)
+    n = o.shape[0] // 2
+    return o[:n], o[n:]
+
+
 def _first_step(x_adv, grad0, gamma, x, eps, clip):
     """The first ascent step from a gradient the caller already has (a positive multiple of d(loss)/d(x) at x itself)."""
     g = grad0.detach()
@@ -134,7 +144,7 @@ def seg_train_step(model, optimizer, criterion, images, labels, **kw):
 
 def seg_train_phases(model, optimizer, criterion, images, labels, out, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5,
                      pertub_idx_se=3, pertub_idx_sd="aspp", mix_layer="11", mix_sd=True, noise_sd=0.0, randinit=False,
-                     clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None):
+                     clip=False, dual_bn=False, fold_clean=None, defer_step=False, fold_pgd0=None, batch_tails=None):
     """The iteration as a generator (data-parallel callers, seg_trainer.SegTrainer): with the folded clean pass the graph is
     cut at the SE point and at the low-level feature, the joint backward runs in two parts — everything behind the cuts
     (layer4, ASPP, decoder: 53 % of the parameters), then the head — and the generator yields "tail" in between: those
@@ -187,7 +197,7 @@ def seg_train_phases(model, optimizer, criterion, images, labels, out, *, steps=
         fm_se = out_se["out"].detach().float()
     # dual_bn (option, no reference counterpart): every pass over adversarial features — the two PGD loops and the three
     # perturbed forwards — normalises with the auxiliary BatchNorm set (resnet_s.enable_dual_bn); no-op otherwise
-    from .resnet_s import bn_branch
+    from .resnet_s import bn_branch, bn_groups
     adv_bn = (lambda: bn_branch(model, "adv")) if dual_bn else contextlib.nullcontext
     with adv_bn():
         adv_se = PGD(x=fm_se, image_batch=images, low_level_feat=low, criterion=criterion, y=labels, model=model, steps=steps,
@@ -212,8 +222,19 @@ def seg_train_phases(model, optimizer, criterion, images, labels, out, *, steps=
         o0 = model({"x": images, "adv": None, "out_idx": 0, "flag": "clean"})
     with adv_bn():
         lr = _low_res(criterion)        # the perturbed forwards' full-resolution logits are never looked at: loss only
-        o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
-        o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
+        # batch_tails (None: whenever the model offers it): the two sample-point forwards (:206-209) run the same layers with the
+        # same weights on two feature maps — ONE pass over their concatenation [point 1 | point 2] with BatchNorm statistics,
+        # running updates (point 1 first) and dropout draws per half (resnet_s.bn_groups(2)): the reference's two calls, half
+        # the launches of a part of the step that is bound by their count (2 images on 256 CUs)
+        bt = fold if batch_tails is None else (bool(batch_tails) and getattr(model, "fold_ok", None) is not None and model.fold_ok(images))
+        if bt:
+            with bn_groups(2):
+                o12 = model({"x": images, "adv": torch.cat([pts[1], pts[2]], dim=0), "out_idx": pertub_idx_se, "flag": "tail",
+                             "low_level_feat": torch.cat([low, low], dim=0), "low_res": lr})
+            o1, o2 = _halves(o12)
+        else:
+            o1 = model({"x": images, "adv": pts[1], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
+            o2 = model({"x": images, "adv": pts[2], "out_idx": pertub_idx_se, "flag": "tail", "low_level_feat": low, "low_res": lr})
         o3 = model({"x": images, "adv": adv_sd_dict, "out_idx": pertub_idx_sd + "_tail", "flag": "clean", "low_res": lr})
     one = ops.one(images.device) if images.is_cuda else None
     if pgd0:
@@ -247,4 +268,4 @@ def seg_train_phases(model, optimizer, criterion, images, labels, out, *, steps=
         optimizer.step()
     out.update({"loss": loss.detach(), "losses": torch.stack([l0, l1, l2, l3]).detach(), "adv_se": adv_se.detach(),
             "adv_sd": adv_sd.detach(), "fm_se": fm_se, "fm_sd": fm_sd, "out_clean": o0.detach(),
-            "fold_clean": bool(fold), "fold_pgd0": bool(pgd0)})         # (which schedule ran: bench.py reports it)
+            "fold_clean": bool(fold), "fold_pgd0": bool(pgd0), "batch_tails": bool(bt)})         # (which schedule ran: bench.py reports it)

@@ -22,14 +22,14 @@ class SegTrainer:
                  pertub_idx_sd="aspp", mix_layer="11", mix_sd=False, noise_sd=0.0, randinit=False, clip=False, lr=0.01,
                  momentum=0.9, weight_decay=1e-4, total_itrs=30000, lr_policy="poly", step_size=10000,
                  backbone_bn_momentum=0.01, use_graph=True, graph_warmup=2, dual_bn=False, fold_clean=None, group=None,
-                 allreduce_chunks=4, fold_pgd0=None, segmented=None, wgrad_stream=None):
+                 allreduce_chunks=4, fold_pgd0=None, segmented=None, wgrad_stream=None, batch_tails=None):
         self.model = model
         if dual_bn:      # BASELINE configs[3] "+ dual-BN": an option the reference does not have (resnet_s.enable_dual_bn); default off
             resnet_s.enable_dual_bn(model)
         self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss(ignore_index=255, reduction="mean")
         self.kw = dict(steps=steps, eps=eps, gamma_se=gamma_se, gamma_sd=gamma_sd, pertub_idx_se=pertub_idx_se,
                        pertub_idx_sd=pertub_idx_sd, mix_layer=mix_layer, mix_sd=mix_sd, noise_sd=noise_sd, randinit=randinit,
-                       clip=clip, dual_bn=bool(dual_bn), fold_clean=fold_clean, fold_pgd0=fold_pgd0)
+                       clip=clip, dual_bn=bool(dual_bn), fold_clean=fold_clean, fold_pgd0=fold_pgd0, batch_tails=batch_tails)
         if backbone_bn_momentum is not None:
             set_bn_momentum(model.backbone, backbone_bn_momentum)
         self.arena = ParamArena(model, skip=())

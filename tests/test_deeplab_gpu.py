@@ -444,3 +444,45 @@ def test_deeplab_folded_clean_forward_equals_three_passes(pkg, gpu, case, dtype)
                                        #  passes' batch moments — at momentum 0.01 that is ~1e-4 of a running mean)
                                        **((dict(rtol=1e-4, atol=1e-5) if "damped" in case else dict(rtol=1e-3, atol=2e-4)) if exact
                                           else dict(rtol=5e-2, atol=5e-3)))
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_batched_sample_point_tails_equal_two_passes(pkg, gpu, dropout):
+    """seg_train_phases(batch_tails=True): the two sample-point forwards (main_aug_final.py:197-203) as ONE pass over their
+    concatenation, BatchNorm statistics / running updates / dropout draws per half (resnet_s.bn_groups(2)) — against the two
+    passes, on ONE iteration's losses, gradients and BatchNorm buffers.  The first half is the same arithmetic launch for
+    launch; the second half's BatchNorm moments are summed around the running mean BEFORE the first half's update instead of
+    after it (a rounding-level difference in the statistics, a bf16 ulp here and there in the activations), and the halves'
+    weight-gradient sums are added in another order.  Scale of that against the step's own sensitivity (tools/
+    diag_dl_batch_tails.py, same model): gradient cosine 0.99997 between the two schedules, 0.17 between two runs of ONE schedule
+    whose images differ by 1e-6 (the sign steps of the PGD loops are discontinuous) — hence one iteration, not several."""
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(8, 3, 65, 65, generator=g).to(gpu)
+    labels = torch.randint(0, 21, (8, 65, 65), generator=g).to(gpu)
+    res = {}
+    for batched in (False, True):
+        torch.manual_seed(3)
+        model = pkg.deeplab.deeplabv3plus_resnet50(num_classes=21, output_stride=16)
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = dropout
+        model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+        tr = pkg.seg_trainer.SegTrainer(model, steps=2, lr=0.0, momentum=0.0, weight_decay=0.0, use_graph=False, batch_tails=batched)
+        torch.manual_seed(9)
+        pkg.ops._dropout_state.clear()              # the device-side dropout generator is re-seeded from torch's CPU generator
+        r = tr.step(images, labels)
+        torch.cuda.synchronize()
+        assert r["batch_tails"] is batched
+        res[batched] = (r["losses"].float().cpu().numpy(), torch.cat([p.grad.float().flatten() for p in tr.arena.params]),
+                        {n: b.float().clone() for n, b in model.named_buffers()})
+    a, b = res[True], res[False]
+    assert a[0][0] == b[0][0] and a[0][3] == b[0][3]                              # the clean and the decoder-point losses: the same numbers
+    np.testing.assert_allclose(a[0], b[0], rtol=0, atol=2e-3)
+    cos = float(torch.dot(a[1], b[1]) / (a[1].norm() * b[1].norm()))
+    rel = float((a[1] - b[1]).norm() / b[1].norm())
+    assert cos > 0.9995 and rel < 0.03, (cos, rel)
+    for n in b[2]:
+        if "num_batches_tracked" in n:
+            assert torch.equal(a[2][n], b[2][n]), n         # the same number of BatchNorm updates, layer by layer
+        else:
+            assert torch.allclose(a[2][n], b[2][n], rtol=5e-3, atol=5e-3), n
