@@ -55,7 +55,7 @@ SIGNATURES = {
     "afan_conv_supported": (_i, [_l, _l, _i, _i]),
     "afan_conv_fwd_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _p, _p, _i, _p]),
     "afan_conv_fwd_affine_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _i, _p]),
-    "afan_conv_fwd_multi_nhwc_bf16": (_i, [_p, _p, _p, _i, _l, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p]),
+    "afan_conv_fwd_multi_nhwc_bf16": (_i, [_p, _p, _p, _i, _l, _l, _l, _l, _l, _p, _i, _p, _p, _p, _i, _p]),
     "afan_conv_fwd_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_bn_train_forward_partials": (_i, [_p, _p, _p, _i, _l, _l, _l, _f, _f, _p, _p, _i, _p, _l, _p, _p, _p, _p, _p, _p]),
     "afan_conv_dgrad_nhwc_bf16": (_i, [_p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p]),

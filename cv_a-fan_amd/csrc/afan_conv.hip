@@ -1169,11 +1169,12 @@ int afan_conv_fwd_affine_nhwc_bf16(const void* x, const void* w, void* y, int64_
 // branch is 70 workgroups with a 288-step K loop (92 us on 256 CUs), three branches in one grid take the same 92 us — and
 // a BasicBlock's first 3x3 convolution with its 1x1 projection shortcut (Classification/resnet_s.py:52-77 option B: both
 // read x at stride 2 and write [N, planes, H/2, W/2]).  ksize[b] in {1, 3}, padding dilation[b] * (ksize[b] / 2).
-// BatchNorm moments go to f64 accumulator blocks (one per problem) or nowhere.
+// BatchNorm moments go to f64 accumulator blocks (one per problem; groups = 2: two consecutive ones, one per half-batch) or nowhere.
 int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
                                   int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
-                                  const float* const* stats_shift, double* const* stats_acc, afan_stream_t stream) {
+                                  const float* const* stats_shift, double* const* stats_acc, int groups, afan_stream_t stream) {
     if (nb < 1 || nb > 4) return AFAN_ESHAPE;
+    if (groups != 1 && (groups != 2 || !stats_acc || (n & 1))) return AFAN_ESHAPE;
     if (!w || !y || !dilation || !ksize) return AFAN_ENULL;
     if ((stats_acc != nullptr) != (stats_shift != nullptr)) return AFAN_ESHAPE;
     int dmax = 1;
@@ -1199,9 +1200,13 @@ int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* con
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
     p.Ho = (int)ho; p.Wo = (int)wo; p.Co = (int)co;
     p.in_s = stride; p.out_s = 1; p.w_row_stride = (int)(ksize[0] * ksize[0] * ci); p.n_classes = nb;
-    p.multi = 1; p.groups = 1;
+    p.multi = 1;
     p.acc = stats_acc ? stats_acc[0] : nullptr; p.shift = stats_shift ? stats_shift[0] : nullptr;
     p.acc_ns = afan_nhwc::acc_slot_count(co);
+    {   // groups = 2: the batch is two half-batches, each problem's accumulator block is two consecutive blocks (one per half)
+        const int e = set_groups(p, groups, n, ho * wo, co, stats_acc != nullptr);
+        if (e) return e;
+    }
     double flops = 0, wbytes = 0;
     for (int b = 0; b < nb; ++b) {
         const int k = ksize[b], pad = k / 2;

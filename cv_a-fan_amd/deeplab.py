@@ -529,7 +529,7 @@ class _ConvMultiFn(torch.autograd.Function):
         ctx.convs, ctx.want_wgrad = convs, want_wgrad
         ws = [c.lp_weight().detach() for c in convs]
         ys, sts = ops.conv_fwd_multi(x, ws, convs[0].stride[0], [c.dilation[0] for c in convs],
-                                     None if reqs is None else [r[0] for r in reqs])
+                                     None if reqs is None else [r[0] for r in reqs], groups=_Flags.bn_groups if reqs is not None else 1)
         if reqs is not None:
             for r, st in zip(reqs, sts):
                 r.append(st)
@@ -613,7 +613,7 @@ class ASPP(nn.Module):
     def forward(self, x, pre_dropout=False):
         x = _to_compute(x, self.convs[0][0].compute_dtype)
         atrous = [m for m in list(self.convs)[1:] if isinstance(m, ASPPConv)]
-        if ASPP.MULTI and _Flags.bn_groups == 1 and 2 <= len(atrous) <= 4 and len(atrous) == len(self.convs) - 2 and _multi_branch_ok(x, atrous):
+        if ASPP.MULTI and 2 <= len(atrous) <= 4 and len(atrous) == len(self.convs) - 2 and _multi_branch_ok(x, atrous):
             # the atrous branches in one launch: at 2 images per GPU each fills a quarter of the chip for 92 us
             convs, bns = [m[0] for m in atrous], [m[1] for m in atrous]
             reqs = [[b.running_mean, None] for b in bns]

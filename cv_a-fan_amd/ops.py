@@ -858,9 +858,9 @@ def conv_fwd_multi_ok(x, ws, stride):
             and all(bool(lib.afan_conv_supported(w.shape[1], w.shape[0], w.shape[2], stride)) for w in ws))
 
 
-def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
+def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None, groups=1):
     """[conv2d(x, w_b, padding=d_b*(k_b//2), stride, dilation=d_b) for b] in ONE launch (afan_conv_fwd_multi_nhwc_bf16).
-    Returns ([y_b], [ConvStats_b | None])."""
+    Returns ([y_b], [ConvStats_b | None]).  groups = 2: moments per half-batch (ConvStats.group)."""
     lib = _lib.load()
     nb = len(ws)
     CALLS["conv_fwd"] += nb
@@ -875,12 +875,13 @@ def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None):
     arr_p = C.c_void_p * nb
     shifts = accs = None
     if stats_shifts is not None:
-        sts = [ConvStats(None, 0, stats_shifts[b], acc_take(x.device, co)) for b in range(nb)]
+        sts = [ConvStats(None, 0, stats_shifts[b], acc_take(x.device, co, groups)) for b in range(nb)]
         shifts = arr_p(*[t.data_ptr() for t in stats_shifts])
         accs = arr_p(*[st.acc.data_ptr() for st in sts])
     check(lib.afan_conv_fwd_multi_nhwc_bf16(_ptr(x), arr_p(*[w.data_ptr() for w in ws]), arr_p(*[y.data_ptr() for y in ys]), nb,
                                             n, hi, wi, ci, co, (C.c_int * nb)(*[int(w.shape[2]) for w in ws]), stride,
-                                            (C.c_int * nb)(*[int(d) for d in dilations]), shifts, accs, _stream(x)),
+                                            (C.c_int * nb)(*[int(d) for d in dilations]), shifts, accs, int(groups if accs is not None else 1),
+                                            _stream(x)),
           "afan_conv_fwd_multi_nhwc_bf16")
     return ys, sts
 

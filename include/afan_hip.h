@@ -273,7 +273,7 @@ int afan_conv_fwd_affine_nhwc_bf16(const void* x, const void* w, void* y, int64_
  * (Classification/resnet_s.py:52-77, option B). */
 int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi,
                                   int64_t wi, int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
-                                  const float* const* stats_shift, double* const* stats_acc, afan_stream_t stream);
+                                  const float* const* stats_shift, double* const* stats_acc, int groups, afan_stream_t stream);
 /* Fusion of the following train-mode BatchNorm's moments into the convolution epilogue: when stats_partials != NULL
  * the forward also writes, per row tile g and output channel c, sum(y - shift[c]) at [(0*Co + c)*G + g] and
  * sum((y - shift[c])^2) at [(1*Co + c)*G + g], G = afan_conv_fwd_tiles(...), over the bf16 values it stores

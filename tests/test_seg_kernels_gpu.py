@@ -346,6 +346,34 @@ def test_conv_fwd_multi_equals_separate_launches(pkg, gpu, n, ci, co, h, w, dils
     assert sts2 == [None] * len(dils) and all(torch.equal(a, b_) for a, b_ in zip(ys2, ys))
 
 
+def test_conv_fwd_multi_with_half_batch_moments(pkg, gpu):
+    """The multi-problem launch over two concatenated half-batches (groups = 2: the two sample-point passes of a Segmentation
+    iteration as one): outputs bit-identical to the ungrouped launch, each problem's two accumulator blocks equal to the moments a
+    grouped single-problem launch sums (33 x 33 maps: the halves are not whole row tiles)."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(4)
+    n, ci, co, h, w, dils = 4, 512, 256, 33, 33, (6, 12, 18)
+    x = (torch.randn(n, ci, h, w, generator=g) * 0.5).to(gpu).bfloat16().contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * 0.02).to(gpu).bfloat16().contiguous(memory_format=torch.channels_last) for _ in dils]
+    shifts = [torch.randn(co, generator=g).to(gpu) * 0.1 for _ in dils]
+    ops.acc_reset(gpu)
+    ys, sts = ops.conv_fwd_multi(x, ws, 1, dils, shifts, groups=2)
+    ys = [y.clone() for y in ys]
+    k = int(pkg._lib.load().afan_bn_acc_doubles(co))
+    for b, d in enumerate(dils):
+        y1, st1 = ops.conv_fwd(x, ws[b], 1, stats_shift=shifts[b], want_stats=True, dilation=d, groups=2)
+        assert torch.equal(y1, ys[b]), f"branch {b}"
+        for grp in range(2):
+            a1, a2 = st1.group(grp, co).acc.double()[:k], sts[b].group(grp, co).acc.double()[:k]
+            torch.testing.assert_close(a1.sum(), a2.sum(), rtol=2e-7, atol=1e-6)
+        # and a BatchNorm over the grouped accumulators normalises each half by its own statistics
+        gamma, beta = torch.ones(co, device=gpu), torch.zeros(co, device=gpu)
+        o, s_ = ops.bn_train_forward(ys[b], gamma, beta, None, False, 1e-5, 0.1, None, None, None, sts[b], groups=2)
+        for grp in range(2):
+            half = o[grp * 2:(grp + 1) * 2].float()
+            assert abs(float(half.mean())) < 2e-2 and abs(float(half.var(unbiased=False)) - 1) < 5e-2
+
+
 def test_aspp_multi_launch_equals_per_branch_path(pkg, gpu):
     dl = pkg.deeplab
     res = {}
