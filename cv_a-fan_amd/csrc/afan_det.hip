@@ -58,8 +58,9 @@ __device__ __forceinline__ bool iou_over(const float* a, float sa, const float* 
 constexpr int SC_D = AFAN_SC_D;
 
 // grid (col_blocks, col_blocks), one wave per tile.  The diagonal tile and the SC_D tiles right of it store the TRANSPOSED
-// tile into bandT[row block][0 = diagonal, 1..SC_D][column] — the comparison's wave-wide ballot IS the column's word — and
-// no row form: the scan reads rows only of the tiles further right.
+// tile into bandT[COLUMN block][k = column block - row block: 0 = diagonal, 1..SC_D][column] — the comparison's wave-wide ballot
+// IS the column's word; everything the scan needs to settle column block j against the SC_D blocks before it is one contiguous
+// (SC_D + 1) x 512 bytes — and no row form: the scan reads rows only of the tiles further right.
 __global__ __launch_bounds__(W64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ order, int n,
                                                        float thresh, int inclusive, unsigned long long* __restrict__ mask,
                                                        unsigned long long* __restrict__ bandT, int col_blocks) {
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(W64) void nms_mask_kernel(const float* __restrict__
             const unsigned long long col = __ballot(hit);
             if ((int)threadIdx.x == j) tw = col;
         }
-        bandT[((int64_t)rb * (SC_D + 1) + (cb - rb)) * W64 + threadIdx.x] = tw;
+        bandT[((int64_t)cb * (SC_D + 1) + (cb - rb)) * W64 + threadIdx.x] = tw;
     } else if (valid) {
         unsigned long long t = 0;
         for (int j = 0; j < col_size; ++j) {
@@ -106,20 +107,21 @@ __global__ __launch_bounds__(W64) void nms_mask_kernel(const float* __restrict__
 // One workgroup of 16 waves in three roles that meet only through LDS words (no workgroup barrier inside the loop; every
 // wave of the one workgroup is resident, so a spin always has someone to wait for):
 //   SCANNER (wave 0), per block b: removed[b] and the block's SC_D + 1 transposed tiles in ONE LDS round trip (flags first,
-//     the data they guard behind them) -> the greedy recurrence on the diagonal tile, by rounds -> the keep word; then the
-//     band: lane c of tile k asks (column word & keep) != 0 and the ballot is removed[b + k]'s update.  It touches no global
-//     memory: what it needs sits in a ring of SC_R prefetched blocks.
+//     the data they guard behind them), requested one block ahead -> lane c asks whether a kept row of the SC_D blocks before
+//     b strikes column c (tile_k[c] & keep[b - k], keep words in scalar registers) -> the greedy recurrence on the diagonal
+//     tile, by rounds -> the keep word.  It touches no global memory and writes nothing but its keep word and position.
 //   PREFETCHERS (waves 4, 8, 12 — the scanner's SIMD, where they mostly sleep on memory): the transposed tiles of the
-//     blocks up to SC_R ahead of the scanner into the ring.
+//     blocks up to SC_R ahead of the scanner into a ring.
 //   WORKERS (the other 12 waves), block p to worker p mod 12: the kept rows' words of the column blocks from p + SC_D + 1
-//     on, OR-ed into removed[] — due only when the scanner reaches block p + SC_D + 1, so a worker's memory round trips
-//     (1.5 - 3 us) hide behind SC_D + 1 scanner iterations.  The owner of block p also writes its kept flags.
-// removed[j] is complete when the scanner reads it: blocks j - SC_D .. j - 1 by its own band updates (same wave, LDS in
-// order), block j - SC_D - 1 by the worker it waits for, older blocks by the waits of earlier iterations.  ORs commute:
-// the result does not depend on timing.
+//     on, OR-ed into removed[] — due only when the scanner asks for block p + SC_D + 1, so a worker's memory round trips
+//     (1.5 - 3 us) hide behind SC_D scanner iterations.  The owner of block p also writes its kept flags.
+// removed[j] is complete when the scanner reads it: blocks j - SC_D .. j - 1 are the scanner's own band, block j - SC_D - 1
+// is the worker it waits for, older blocks the waits of earlier iterations.  ORs commute: the result does not depend on timing.
 // History (12 000 boxes, the headline step's proposals, ~1 800 survivors, all 188 blocks scanned): one wave doing everything
-// 1.42 ms; 16 waves between two barriers per block, a scalar step per kept box, 283 us; this form 108 us — the scanner's
-// ~250 instructions per block are what is left (SC_D 6 .. 12 and SC_R 8 .. 12 within 3 %: tools/probe/nms_time.py).
+// 1.42 ms; 16 waves between two barriers per block, a scalar step per kept box, 283 us; barrier-free with the band pushed
+// forward by LDS atomics 117 us; this form (band pulled, no atomics, reads one block ahead) 116 us with a third fewer
+// instructions — what is left is ~1 300 cycles per block of DEPENDENT hops of one wave (LDS -> VALU -> ballot -> SALU -> VALU
+// ...), not instruction count, not waiting (the scanner's spins: ~10 per call).  SC_D 6 .. 12, SC_R 8 .. 12: within 3 %.
 constexpr int SCAN_WAVES = 16;
 #ifndef AFAN_SC_R
 #define AFAN_SC_R 8
@@ -155,20 +157,6 @@ __device__ __forceinline__ unsigned long long to_scalar(unsigned long long v) {
 // no s_waitcnt between them, the round trips overlap.
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
-// tiles K .. SC_D of the band: the ballot of "a kept row strikes this lane's column" is tile K's update of removed[b + K];
-// v_writelane drops it into lane K - 1 (no clang builtin for it)
-template <int K>
-__device__ __forceinline__ void band_verdicts(const unsigned long long (&bw)[SC_D + 1], unsigned long long keep, int& ulo, int& uhi) {
-    if constexpr (K <= SC_D) {
-        const unsigned long long hit = __ballot((bw[K] & keep) != 0ULL);
-        // (s_nop 1: gfx950 wants two wait states between a VALU writing an SGPR — the compare behind the ballot — and a VALU
-        // reading it; the compiler pads its own code, not this)
-        asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                     : "+v"(ulo), "+v"(uhi) : "s"((int)hit), "s"((int)(hit >> 32)), "n"(K - 1));
-        band_verdicts<K + 1>(bw, keep, ulo, uhi);
-    }
-}
-
 __global__ __launch_bounds__(W64 * SCAN_WAVES) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                                     const unsigned long long* __restrict__ bandT,
                                                                     const int64_t* __restrict__ order, int n, int col_blocks,
@@ -184,43 +172,57 @@ __global__ __launch_bounds__(W64 * SCAN_WAVES) void nms_scan_kernel(const unsign
 
     if (wave == 0) {
         // ---- scanner ----
-        int kept_total = 0;
-        for (int b = 0; b < col_blocks; ++b) {
-            const int slot = b % SC_R;
+        // Block b's verdict needs: removed[b] (the workers' share: kept rows of blocks <= b - SC_D - 1), the keep words of the SC_D
+        // blocks before it (kept here, in scalar registers) against the band tiles (b - k, b) in column form — lane c asks
+        // OR_k (tile_k[c] & keep[b - k]) != 0, two v_and_or per tile — and the diagonal tile for the recurrence.  The scanner
+        // writes nothing the next block reads from LDS, so block b + 1's words are requested BEFORE block b's work (two
+        // register sets, the loop unrolled by two) and the LDS round trip hides behind it.
+        struct Regs { unsigned long long bw[SC_D + 1], rem_v; int r1, r2; };
+        auto issue = [&](int b, Regs& R) {
             const int need = b - SC_D - 1;
-            const int wslot = need >= 0 ? need % SC_NW : 0;
-            unsigned long long bw[SC_D + 1], rem_v;
-            // one LDS round trip on the optimistic path: the two flags first, then everything they guard
-            for (;;) {
-                LDS_ORDER();                                       // (what a retry read before is stale)
-                const int r1 = S.pf_ready[slot], r2 = S.work_done[wslot];
-                LDS_ORDER();
-                rem_v = removed[b];
+            LDS_ORDER();                                           // flags first, then what they guard: the LDS unit keeps the order
+            R.r1 = S.pf_ready[b % SC_R];
+            R.r2 = S.work_done[need >= 0 ? need % SC_NW : 0];
+            LDS_ORDER();
+            R.rem_v = removed[b];
 #pragma unroll
-                for (int k = 0; k <= SC_D; ++k) bw[k] = S.bt[slot][k][lane];
-                LDS_ORDER();                                       // (issued before the branch on the flags, not after it)
-                if (__builtin_amdgcn_readfirstlane(r1) == b + 1 && (need < 0 || __builtin_amdgcn_readfirstlane(r2) > need)) break;
+            for (int k = 0; k <= SC_D; ++k) R.bw[k] = S.bt[b % SC_R][k][lane];
+            LDS_ORDER();
+        };
+        unsigned long long kh[SC_D + 1];                           // kh[k]: keep word of block b - k (k = 1 .. SC_D)
+#pragma unroll
+        for (int k = 0; k <= SC_D; ++k) kh[k] = 0;
+        int kept_total = 0;
+        auto step = [&](int b, Regs& cur, Regs& nxt) -> bool {
+            const int need = b - SC_D - 1;
+            while (!(__builtin_amdgcn_readfirstlane(cur.r1) == b + 1 && (need < 0 || __builtin_amdgcn_readfirstlane(cur.r2) > need))) {
                 __builtin_amdgcn_s_sleep(1);
+                issue(b, cur);
+            }
+            if (b + 1 < col_blocks) issue(b + 1, nxt);
+            unsigned acc_lo = 0, acc_hi = 0;
+#pragma unroll
+            for (int k = 1; k <= SC_D; ++k) {
+                acc_lo |= (unsigned)cur.bw[k] & (unsigned)kh[k];
+                acc_hi |= (unsigned)(cur.bw[k] >> 32) & (unsigned)(kh[k] >> 32);
             }
             const int size = min(n - b * W64, W64);
-            unsigned long long alive = ~to_scalar(rem_v);
+            unsigned long long alive = ~(to_scalar(cur.rem_v) | __ballot((acc_lo | acc_hi) != 0u));
             if (size < W64) alive &= ~(~0ULL << size);             // rows beyond n: never kept
             // the greedy recurrence by ROUNDS on the diagonal tile in column form (bw[0]: bit r = earlier box r strikes this
             // lane's box): an undecided box no undecided earlier box overlaps is kept — every earlier overlapping box is
             // decided, and a kept one would have struck it — so all such boxes are kept at once and strike theirs.  The
-            // first undecided box always qualifies; a block takes as many rounds as its longest chain of overlaps (2 - 4),
+            // first undecided box always qualifies; a block takes as many rounds as its longest chain of overlaps (1 - 4),
             // not one scalar step per kept box.
             unsigned long long keep = 0;
             while (alive) {
-                const unsigned long long newly = __ballot((bw[0] & alive) == 0ULL) & alive;
+                const unsigned long long newly = __ballot((cur.bw[0] & alive) == 0ULL) & alive;
                 keep |= newly;
-                alive &= ~(newly | __ballot((bw[0] & newly) != 0ULL));
+                alive &= ~(newly | __ballot((cur.bw[0] & newly) != 0ULL));
             }
-            // the band: lane k - 1 collects tile k's 64 column verdicts
-            int ulo = 0, uhi = 0;
-            band_verdicts<1>(bw, keep, ulo, uhi);
-            const unsigned long long upd = ((unsigned long long)(unsigned)uhi << 32) | (unsigned)ulo;
-            if (lane < SC_D && upd && b + 1 + lane < col_blocks) atomicOr(&removed[b + 1 + lane], upd);
+#pragma unroll
+            for (int k = SC_D; k > 1; --k) kh[k] = kh[k - 1];
+            kh[1] = keep;
             kept_total += __popcll(keep);
             const bool fin = max_keep > 0 && kept_total >= max_keep;
             LDS_ORDER();
@@ -232,7 +234,13 @@ __global__ __launch_bounds__(W64 * SCAN_WAVES) void nms_scan_kernel(const unsign
                 if (fin) S.stop = 1;                               // after scan_pos: who sees stop sees the last block too
             }
             LDS_ORDER();
-            if (fin) break;
+            return fin;
+        };
+        Regs ra, rb;
+        issue(0, ra);
+        for (int b = 0; b < col_blocks; b += 2) {
+            if (step(b, ra, rb)) break;
+            if (b + 1 < col_blocks && step(b + 1, rb, ra)) break;
         }
     } else if ((wave & 3) == 0) {
         // ---- prefetchers ----
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(W64 * SCAN_WAVES) void nms_scan_kernel(const unsign
                 const int blk = b0 + t;
 #pragma unroll
                 for (int k = 0; k <= SC_D; ++k)
-                    w[t][k] = (blk + k < col_blocks) ? bandT[((int64_t)blk * (SC_D + 1) + k) * W64 + lane] : 0ULL;
+                    w[t][k] = (blk < col_blocks && k <= blk) ? bandT[((int64_t)blk * (SC_D + 1) + k) * W64 + lane] : 0ULL;
             }
 #pragma unroll
             for (int t = 0; t < SC_G; ++t) {

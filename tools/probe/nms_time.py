@@ -33,7 +33,7 @@ real = pkg.det_model.nms
 
 
 def spy(b, s, thr, **kw):
-    seen.append((b.detach().clone(), s.detach().clone(), thr, dict(kw)))
+    seen.append((b.detach().clone(), None if s is None else s.detach().clone(), thr, dict(kw)))
     return real(b, s, thr, **kw)
 
 
