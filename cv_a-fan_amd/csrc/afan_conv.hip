@@ -70,7 +70,11 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // linear position in the UNPADDED raster (n*H*W + y*W + x, also for border pixels): 16 consecutive output pixels at any
 // tap are 16 consecutive v, and j - v is even everywhere, so (j & 1, (v >> 1) & 7) takes 16 distinct values — conflict-free
 // ds_read_b128 for image rows of 4, 8, 16 or 33 pixels alike (round 1's halo kernel lost to exactly those conflicts).
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>   // WM x WN waves: pixels x channels
+// GS: the instantiation for launches whose image groups (two half-batches with separate BatchNorm sums) are NOT whole row
+// tiles: the one tile holding rows of both halves runs the epilogue once per group.  A separate instantiation because the
+// pass loop costs the 768- and 1 024-thread variants their last free registers (scratch in the K loop: ResNet-18's step
+// 8.8 -> 11.6 ms when every launch carried it); launch<> picks it only for such launches.
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>   // WM x WN waves: pixels x channels
 __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
@@ -586,8 +590,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
     const uint16_t* addp = pp.aff ? pp.aff_res : pp.addend;     // the one extra output-shaped operand of either fusion
+    // Image groups (two half-batches with their own BatchNorm sums): a tile belongs to the half its rows are in; the ONE tile
+    // of a launch that holds rows of both (half-batches of any size: the row count need not be a multiple of the tile) walks
+    // its rows twice, once per group, each row fetched, stored and summed in the pass of its own group (the whole epilogue,
+    // operand requests included, sits inside the pass: nothing but a few scalars lives across it — kept in registers for a
+    // second pass, the requests' 128 registers spill in the 768-thread variants).
+    const uint32_t half = pp.groups == 2 ? (uint32_t)(pp.N / 2) * Hg * Wg : 0u;
+    const bool straddle = GS && pp.groups == 2 && m0 < half && m0 + BM > half;      // (GS = false: n_pass is the constant 1)
+    const int n_pass = straddle ? 2 : 1;
+    const float* shift_p = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
+    uint16_t* y_p = pp.y + pp.y_off[blockIdx.z];
+    for (int gpass = 0; gpass < n_pass; ++gpass) {
+    const int grp = straddle ? gpass : ((pp.groups == 2 && m0 >= half) ? 1 : 0);
+    const bool grp_first = grp == 0 ? m0 == 0 : (straddle || m0 == half);     // this tile holds the group's first row
     const bool dual = pp.aff && pp.aff_bwd == 2;
-    u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS], pre_d[EPI_ROWS];
+    u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];      // (pre_x: the BN input — or, dual form (never both), the addend)
     {
         const int out_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), 0, addp ? out_bytes : 0, 0x00020000);
@@ -596,11 +613,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         const __amdgpu_buffer_rsrc_t byr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pp.bny), 0, (bn_bwd && pp.bny) ? out_bytes : 0, 0x00020000);
 #pragma unroll
         for (int q = 0; q < EPI_ROWS; ++q) {
-            const int off = epi_on ? out_off[pr + q * ROWS_PER_PASS] : -1;
+            const int r_ = pr + q * ROWS_PER_PASS;
+            const int off = (epi_on && (!straddle || ((m0 + (uint32_t)r_ >= half) == (grp == 1)))) ? out_off[r_] : -1;
             const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
             if (addp) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
-            if (dual && pp.addend) pre_d[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)bo, 0, 0));
-            if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
+            if (dual && pp.addend) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)bo, 0, 0));
+            else if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
             if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
         }
     }
@@ -608,18 +626,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     //  * addend: y += addend (the other branch of a residual gradient), rounded to bf16 like a separate add would;
     //  * moments of y for a following train-mode BN forward (one partial per (tile, channel), summed by its finalize);
     //  * or, when y is the gradient entering a BN backward, that backward's reduction pass (sum g, sum g*(x - mean)).
-    // image group of this row tile (tiles never straddle the two halves: checked on the host)
-    // Image groups (two half-batches with their own BatchNorm sums): a tile belongs to the half its rows are in; the ONE tile
-    // of a launch that holds rows of both (half-batches of any size: the row count need not be a multiple of the tile) walks
-    // its rows twice, once per group, each row stored and summed in the pass of its own group.
-    const uint32_t half = pp.groups == 2 ? (uint32_t)(pp.N / 2) * Hg * Wg : 0u;
-    const bool straddle = pp.groups == 2 && m0 < half && m0 + BM > half;
-    const int n_pass = straddle ? 2 : 1;
-    const float* shift_p = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
-    uint16_t* y_p = pp.y + pp.y_off[blockIdx.z];
-    for (int gpass = 0; gpass < n_pass; ++gpass) {
-    const int grp = straddle ? gpass : ((pp.groups == 2 && m0 >= half) ? 1 : 0);
-    const bool grp_first = grp == 0 ? m0 == 0 : (straddle || m0 == half);     // this tile holds the group's first row
     const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
     double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
@@ -643,7 +649,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 // dgrad-with-addend launch rounds it), masked by the block's stored output, leaves twice — as it is for the
                 // shortcut, times alpha for the last convolution's frozen BatchNorm (affine_bwd_kernel's two outputs)
                 const u16x8 a = __builtin_bit_cast(u16x8, pre_a[q]);
-                const u16x8 d = __builtin_bit_cast(u16x8, pre_d[q]);
+                const u16x8 d = __builtin_bit_cast(u16x8, pre_x[q]);
                 u16x8 m;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -752,13 +758,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 // The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward
 // launches from the input-gradient launches: bench.py's roofline names whichever is the larger and profiles/ can be
 // checked against it symbol by symbol.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_fwd_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS>(pp);
 }
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_dgrad_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS>(pp);
 }
 
 static int64_t max_rows(const ConvP& p) {
@@ -770,8 +776,8 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
-int launch(const ConvP& p, hipStream_t st, bool dgrad) {
+template <int BM, int BN, int PF, int WM, int WN, int PW, int FBT, int HL, bool GS>
+int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);
@@ -782,18 +788,34 @@ int launch(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL>,
+            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL><<<grid, THREADS, lds, st>>>(p);
-    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL><<<grid, THREADS, lds, st>>>(p);
+    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS><<<grid, THREADS, lds, st>>>(p);
+    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
+}
+
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0>
+int launch(const ConvP& p, hipStream_t st, bool dgrad) {
+    // image groups whose halves are not whole row tiles of THIS variant: the instantiation whose epilogue walks the straddling
+    // tile once per group (not built for the 256-row and the 16-wave variants: no register to spare; dispatch() never sends them
+    // such a launch — its halo256 / 256 x 64 guards ask for whole 256-row tiles per half)
+    bool gs = false;
+    if (p.groups == 2)
+        for (int z = 0; z < p.n_classes; ++z) gs = gs || ((int64_t)(p.N / 2) * p.cls[z].Hg * p.cls[z].Wg) % BM != 0;
+    constexpr bool GS_BUILT = BM <= 128 && WM * WN + PW <= 12;
+    if (gs) {
+        if constexpr (GS_BUILT) return launch_gs<BM, BN, PF, WM, WN, PW, FBT, HL, true>(p, st, dgrad);
+        else return AFAN_ESHAPE;
+    }
+    return launch_gs<BM, BN, PF, WM, WN, PW, FBT, HL, false>(p, st, dgrad);
 }
 
 static int env_int(const char* name, int dflt) {
