@@ -115,11 +115,18 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
     if hasattr(model, "begin_iteration"):
         model.begin_iteration()
     adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
-    if hasattr(model, "head_features"):      # the three head passes (:78-80) are prefixes of one another: one pass, no graph
-        fm = model.train().head_features(image_batch, (1, 2, 3))
+    if getattr(model, "collects_head_features", False):
+        # the three head passes (:78-80) and the clean ROI-head pass (:81) run the same backbone on the same images (frozen
+        # BatchNorm, no dropout, no random draw before the RPN): the head passes' values are that pass's stage outputs
+        col = {}
+        rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean", "collect": col})
+        fm = [col[i] for i in (1, 2, 3)]
     else:
-        fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
-    rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
+        if hasattr(model, "head_features"):      # prefixes of one another: one pass, no graph
+            fm = model.train().head_features(image_batch, (1, 2, 3))
+        else:
+            fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
+        rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
     clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
     adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
     adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)

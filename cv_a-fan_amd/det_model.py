@@ -532,8 +532,11 @@ class ResNet101(nn.Module):
             last = 3 if flag == "clean" else input_dict["out_idx"]
             assert last in (1, 2, 3)
             x = self._stem(input_dict["x"])
-            for st in stages[:last]:
+            col = input_dict.get("collect")           # {}: filled with {stage index: that stage's output, detached} on the way
+            for i, st in enumerate(stages[:last], start=1):
                 x = _run_stage(st, x)
+                if col is not None:
+                    col[i] = x.detach().clone() if _StageGraphs.ON else x.detach()
             return x
         assert flag == "tail" and input_dict["out_idx"] in (1, 2, 3)
         x = _enter(input_dict["adv"], self.conv1.compute_dtype, self.normal.channels_last)
@@ -736,6 +739,10 @@ class Model(nn.Module):
     def head_features(self, x, idxs=(1, 2, 3)):
         """[forward({'x': x, 'flag': 'head', 'out_idx': i}).detach() for i in idxs] from one backbone pass."""
         return self.features.head_features(x, idxs)
+
+    # A 'clean' forward whose dict carries "collect": {} also leaves the three head passes' values there (the backbone's stage
+    # outputs, detached): the same numbers as head_features(x) — same images, frozen BatchNorm, no dropout — without the pass.
+    collects_head_features = True
 
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):

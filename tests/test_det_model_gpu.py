@@ -255,6 +255,15 @@ def test_head_features_equal_the_three_head_forwards(pkg, gpu):
     for i, f in zip((1, 2, 3), one):
         ref = m.train().forward({"x": x, "adv": None, "out_idx": i, "flag": "head"}).detach()
         assert not f.requires_grad and torch.equal(f, ref), i
+    # ... and as a by-product of the clean ROI-head pass (:81), which runs the same backbone on the same images WITH a graph:
+    # det_train_phases takes them from there (dict key "collect")
+    bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("bboxes", "labels"))
+    col = {}
+    torch.manual_seed(3)
+    rr = m.train().forward({"x": x, "adv": None, "out_idx": "roi_head", "flag": "clean", "collect": col}, bboxes, labels)
+    assert sorted(col) == [1, 2, 3] and "roi_output_dict" in rr
+    for i, f in zip((1, 2, 3), one):
+        assert not col[i].requires_grad and torch.equal(col[i], f), i
 
 
 def test_frozen_bottleneck_node_equals_layer_by_layer_path(pkg, gpu):
