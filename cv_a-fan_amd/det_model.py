@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
-from .det_ops import box_assign, box_decode_clip, fg_bg_sample, nms, per_image_losses, roi_align
+from .det_ops import box_assign, box_decode_clip, fg_bg_draw, fg_bg_sample, nms, per_image_losses, roi_align, sample_lists
 from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear,
                        _own_conv_ok, _to_compute, _WgradStream)
 
@@ -579,7 +579,7 @@ class RegionProposalNetwork(nn.Module):
         return outs
 
     # -- training targets (:58-105; the reference repeats this block in its 'clean' and 'tail' branches)
-    def _losses(self, objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height):
+    def _losses(self, objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=False):
         """Labels (:66-82), sampling (:84-90), regression targets (:92-100) and the two per-image losses (:163-185) on the anchors
         inside the image: four launches and one host read (det_ops.box_assign / fg_bg_sample / per_image_losses) where the
         reference's tensor operations are about a hundred."""
@@ -597,8 +597,41 @@ class RegionProposalNetwork(nn.Module):
             hit = self._inside_cache[ikey] = (in_boxes, flat, anchor_bboxes)      # (holding the grid keeps its address from being reused)
         in_boxes, flat = hit[0], hit[1]
         labels, assign = box_assign(in_boxes, gt_bboxes_batch, "anchor", 0.3, 0.7)
+        if pending:                     # launches only: the caller reads the two list lengths together with its other counts
+            return (sample_lists(labels), labels, assign, in_boxes, flat, gt_bboxes_batch, objectnesses, transformers, b)
         sel, _, lab, gt_deltas, bi = fg_bg_sample(labels, assign, in_boxes, gt_bboxes_batch, 128 * b, 256 * b)
         return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
+
+    def _losses_finish(self, pend, nf, nb):
+        lists, labels, assign, in_boxes, flat, gt, objectnesses, transformers, b = pend
+        sel, _, lab, gt_deltas, bi = fg_bg_draw(lists, nf, nb, labels, assign, in_boxes, gt, 128 * b, 256 * b)
+        return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
+
+    def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean"):
+        """`forward(...)` (training) followed by `generate_proposals(...)` — the order model.py:95-100 calls them in — with ONE host
+        read for both: the anchor sampling's two list lengths and every image's NMS survivor count travel together (the label /
+        list launches and the decode / sort / NMS launches are all queued before it).  The host's random draws keep their order
+        (the anchor sampling's three; the proposal layer draws nothing).  Returns (objectnesses, transformers, ce, sl1, proposals)."""
+        trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
+        objectnesses, transformers = self._heads(trunk)
+        pend = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=True)
+        boxes = box_decode_clip(anchor_bboxes, transformers.float(), image_width, image_height)
+        probs = F.softmax(objectnesses.float()[:, :, 1], dim=-1)
+        _, order = torch.sort(probs, dim=-1, descending=True)
+        cand, keeps = [], []
+        for b in range(anchor_bboxes.shape[0]):
+            sb = boxes[b][order[b][:self._pre_nms_top_n]]
+            keeps.append(nms(sb, None, 0.7, max_keep=self._post_nms_top_n, presorted=True, padded=True))
+            cand.append(sb)
+        counts = torch.cat([pend[0][2]] + [c for _, c in keeps]).tolist()            # the one read
+        ce, sl1 = self._losses_finish(pend, counts[0], counts[1])
+        kept = [sb[k[:n]][:self._post_nms_top_n] for sb, (k, _), n in zip(cand, keeps, counts[2:])]
+        if len(kept) == 1:
+            proposals = kept[0].unsqueeze(0)
+        else:
+            longest = max(len(k) for k in kept)
+            proposals = torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
+        return objectnesses, transformers, ce, sl1, proposals.detach()
 
     def forward(self, features, anchor_bboxes=None, gt_bboxes_batch=None, image_width=None, image_height=None, return_type="clean"):
         if return_type == "head":
@@ -797,7 +830,7 @@ class Model(nn.Module):
             d = input_dict["adv"]
             features, anchors = d["features"], d["anchor_bboxes"]
             iw, ih = _int_of(d["image_width"]), _int_of(d["image_height"])
-            obj, tr, ao, at = self.rpn.forward(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
+            obj, tr, ao, at, proposals = self.rpn.forward_and_propose(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
         else:
             features = self._cut(self.features(input_dict))
             anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
@@ -806,8 +839,7 @@ class Model(nn.Module):
                         "image_width": _int_tensor(iw, features.device), "anchor_bboxes": anchors,
                         "rpn_feature_map_dict": self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih, return_type="head")}
             assert type(idx) == int or idx == "roi_head"
-            obj, tr, ao, at = self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih)
-        proposals = self.rpn.generate_proposals(anchors, obj.float(), tr.float(), iw, ih).detach()
+            obj, tr, ao, at, proposals = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih)
         if idx == "roi_head":
             return {"anchor_objectness_losses": ao, "anchor_transformer_losses": at,
                     "roi_output_dict": self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, return_type="head")}

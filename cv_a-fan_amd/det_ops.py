@@ -123,23 +123,24 @@ def box_assign(boxes, gt_bboxes, mode, lo, hi=0.0, gt_classes=None):
     return labels, assign
 
 
-def fg_bg_sample(labels, assign, boxes, gt_bboxes, n_fg, n_total):
-    """The reference's sampling (region_proposal_network.py:84-90, model.py:277-282) and what is gathered at the sample right
-    after it: three `torch.randperm` draws on the HOST generator (foreground subset, background subset, shuffle) over the
-    `nonzero()` lists of labels > 0 / == 0.  One launch builds both lists, ONE host read brings their lengths, the three draws
-    are composed on the host into a position list, one launch gathers.  Returns (sel [S] flat positions in [B * N), boxes [S, 4],
-    labels [S], regression targets [S, 4] = calc_transformer(box, its ground truth) (bbox.py:41-52), batch indices [S])."""
+def sample_lists(labels):
+    """The `nonzero()` lists of labels > 0 / == 0 in one launch, nothing read: (fg [M], bg [M], counts [2]) on the device."""
+    lib = _lib.load()
+    M = labels.numel()
+    lists = torch.empty(2 * M + 2, dtype=torch.int64, device=labels.device)
+    fg, bg, counts = lists[:M], lists[M:2 * M], lists[2 * M:]
+    check(lib.afan_sample_lists(_ptr(labels), M, _ptr(fg), _ptr(bg), _ptr(counts), _stream(labels.device)), "afan_sample_lists")
+    return fg, bg, counts
+
+
+def fg_bg_draw(lists, nf, nb, labels, assign, boxes, gt_bboxes, n_fg, n_total):
+    """The three `torch.randperm` draws on the HOST generator over lists of known lengths (nf, nb), composed on the host into
+    one position list, and the gather of the sampled rows (see fg_bg_sample)."""
     lib = _lib.load()
     dev = labels.device
-    B, N = labels.shape
-    G = gt_bboxes.shape[1]
+    fg, bg, _ = lists
+    N, G = labels.shape[1], gt_bboxes.shape[1]
     boxes, gt = _f32c(boxes, "fg_bg_sample"), _f32c(gt_bboxes, "fg_bg_sample")
-    M = B * N
-    lists = torch.empty(2 * M + 2, dtype=torch.int64, device=dev)
-    fg, bg, counts = lists[:M], lists[M:2 * M], lists[2 * M:]
-    st = _stream(dev)
-    check(lib.afan_sample_lists(_ptr(labels), M, _ptr(fg), _ptr(bg), _ptr(counts), st), "afan_sample_lists")
-    nf, nb = counts.tolist()                                     # the iteration's host read for this sampling
     p1 = torch.randperm(nf)[:min(nf, n_fg)]
     p2 = torch.randperm(nb)[:n_total - len(p1)]
     pos = torch.cat([p1, -(p2 + 1)])
@@ -152,8 +153,20 @@ def fg_bg_sample(labels, assign, boxes, gt_bboxes, n_fg, n_total):
     out_d = torch.empty((S, 4), dtype=torch.float32, device=dev)
     if S:
         check(lib.afan_sample_gather(_ptr(fg), _ptr(bg), _ptr(pos), S, _ptr(boxes), _ptr(gt), _ptr(assign), _ptr(labels), N, G, _ptr(sel),
-                                     _ptr(out_b), _ptr(out_l), _ptr(out_d), _ptr(out_bi), st), "afan_sample_gather")
+                                     _ptr(out_b), _ptr(out_l), _ptr(out_d), _ptr(out_bi), _stream(dev)), "afan_sample_gather")
     return sel, out_b, out_l, out_d, out_bi
+
+
+def fg_bg_sample(labels, assign, boxes, gt_bboxes, n_fg, n_total):
+    """The reference's sampling (region_proposal_network.py:84-90, model.py:277-282) and what is gathered at the sample right
+    after it: three `torch.randperm` draws on the HOST generator (foreground subset, background subset, shuffle) over the
+    `nonzero()` lists of labels > 0 / == 0.  One launch builds both lists (sample_lists), ONE host read brings their lengths, the
+    three draws are composed on the host into a position list, one launch gathers (fg_bg_draw).  Returns (sel [S] flat positions
+    in [B * N), boxes [S, 4], labels [S], regression targets [S, 4] = calc_transformer(box, its ground truth) (bbox.py:41-52),
+    batch indices [S])."""
+    lists = sample_lists(labels)
+    nf, nb = lists[2].tolist()                                   # the iteration's host read for this sampling
+    return fg_bg_draw(lists, nf, nb, labels, assign, boxes, gt_bboxes, n_fg, n_total)
 
 
 class _DetLoss(torch.autograd.Function):

@@ -59,16 +59,16 @@ def test_faster_rcnn_fp32_matches_reference_model(pkg, gpu, nhwc, mode):
     fm3 = fm
     # (2) one training forward: RPN logits, proposals, the four per-image losses (model.py:54-72)
     seen = {}
-    real = m.rpn.generate_proposals
+    real = m.rpn.forward_and_propose             # (the training forward's RPN pass + proposal layer: one host read for both)
 
-    def spy(anchors, obj, tr, iw, ih):
-        out = real(anchors, obj, tr, iw, ih)
-        seen.update(obj=obj.detach().clone(), tr=tr.detach().clone(), proposals=out.detach().clone())
+    def spy(*a, **k):
+        out = real(*a, **k)
+        seen.update(obj=out[0].detach().float().clone(), tr=out[1].detach().float().clone(), proposals=out[4].detach().clone())
         return out
-    m.rpn.generate_proposals = spy
+    m.rpn.forward_and_propose = spy
     torch.manual_seed(100)
     losses = m.train().forward({"x": images, "adv": None, "out_idx": 0, "flag": "clean"}, bboxes, labels)
-    m.rpn.generate_proposals = real
+    m.rpn.forward_and_propose = real
     np.testing.assert_allclose(seen["obj"].cpu().numpy(), g["rpn_obj"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(seen["tr"].cpu().numpy(), g["rpn_tr"], rtol=1e-4, atol=2e-5)
     assert seen["proposals"].shape == g["proposals"].shape
