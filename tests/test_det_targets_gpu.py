@@ -1,7 +1,6 @@
 """Single-launch training targets / losses of the Faster-RCNN step (afan_det_targets.hip through det_ops) against the
 reference's tensor-operation forms (tests/det_torch_ref.py): boxes, IoU decisions, labels, samples and regression targets bit for
 bit; the two loss sums and their gradients to 1e-6 (another summation order)."""
-import numpy as np
 import pytest
 import torch
 
