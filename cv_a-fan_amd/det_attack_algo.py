@@ -14,6 +14,8 @@ behaviour of the reference's `Detection/attack_algo.py`, and the loop body of `D
 (flag 'head') or the ROI dict ('roi_head').  The sign step / projection / noise / clamp / mix / sample-point arithmetic runs in
 libafan_hip.so; NMS and ROIAlign for the model's own layers are in det_ops.py.  The Faster-RCNN model itself is out of
 scope; the Faster-RCNN model is det_model.py."""
+import os
+
 import torch
 
 from . import ops
@@ -48,6 +50,34 @@ def _ascend(x_adv, loss_of, gamma, x, eps, clip):
     if grad.stride() != x_adv.stride():
         grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
     ops.pgd_step_(x_adv, grad, gamma, x, eps if eps is not None else 0.0, clip)     # one launch: sign step (+ projection)
+
+
+def _pgd1_from_clean(model, col, idx, image_batch, y, eps, gamma):
+    """`PGD(fm[idx - 1], ..., steps=1, idx=idx)` without a random start (:84-86) when the clean pass's own activations are at hand:
+    its one forward runs the backbone's remaining stages on the CLEAN feature map — the numbers the clean ROI-head pass already
+    computed — so only the part behind the backbone is run again (RPN, proposals, ROI head: their sampling draws are this call's
+    own, as in the reference), and its gradient is carried back through the clean pass's stored activations with the
+    input-gradient-only launches (det_model.stage_input_gradient).  Same values as PGD(); None where the stages did not run in the
+    one-node form (fp32, NCHW: PGD() itself then runs)."""
+    from . import det_model
+    stages = [model.features.layer1, model.features.layer2, model.features.layer3]
+    outs = [col.get(("out", i)) for i in (1, 2, 3)]
+    if not all(det_model.stage_input_gradient(stages[i - 1], outs[i - 1]) for i in range(idx + 1, 4)):
+        return None                  # (decided before anything is drawn from the host generator)
+    x = col[idx].detach().float()
+    x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))) else x.contiguous()
+    x_adv = x.clone()
+    xin = col[3].detach().requires_grad_(True)
+    with dgrad_only():
+        l1, l2, l3, l4 = model.train().forward({"x": image_batch, "adv": xin, "out_idx": 3, "flag": "tail"}, y["bb"], y["lb"])
+        g = torch.autograd.grad(l1.mean() + l2.mean() + l3.mean() + l4.mean(), xin, only_inputs=True)[0]
+    for i in range(3, idx, -1):
+        g = det_model.stage_input_gradient(stages[i - 1], outs[i - 1], g)
+    grad = g.float()
+    if grad.stride() != x_adv.stride():
+        grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
+    ops.pgd_step_(x_adv, grad, gamma, x, eps, False)
+    return x_adv.requires_grad_(True)
 
 
 def rpn_roi_PGD(layer="roi", rpn_roi_output_dict=None, y=None, model=None, steps=1, eps=None, gamma=None, randinit=False,
@@ -115,6 +145,7 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
     if hasattr(model, "begin_iteration"):
         model.begin_iteration()
     adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+    col = None
     if getattr(model, "collects_head_features", False):
         # the three head passes (:78-80) and the clean ROI-head pass (:81) run the same backbone on the same images (frozen
         # BatchNorm, no dropout, no random draw before the RPN): the head passes' values are that pass's stage outputs
@@ -128,8 +159,13 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
             fm = [fwd({"x": image_batch, "adv": None, "out_idx": i, "flag": "head"}).detach() for i in (1, 2, 3)]
         rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
     clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
-    adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
-    adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+    fold = col is not None and os.environ.get("AFAN_DET_FOLD_PGD", "1") != "0"      # 0: PGD() as written (A/B, tests)
+    adv1 = _pgd1_from_clean(model, col, 1, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
+    adv2 = _pgd1_from_clean(model, col, 2, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
+    if adv1 is None:
+        adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+    if adv2 is None:
+        adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
     adv3 = PGD(fm[2], image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
     pts = sample_points_mixed(fm[2].float(), adv3.detach(), 5, (True, True, False, False))       # :95-97 in one launch
     adv_rr = rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)

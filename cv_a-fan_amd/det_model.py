@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from . import ops
 from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
 from .det_ops import box_assign, box_decode_clip, fg_bg_draw, fg_bg_sample, nms, per_image_losses, roi_align, sample_lists
-from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear,
+from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear, dgrad_only,
                        _own_conv_ok, _to_compute, _WgradStream)
 
 __all__ = ["Model", "ResNet101", "RegionProposalNetwork", "FrozenBatchNorm2d", "fasterrcnn_resnet101"]
@@ -245,6 +245,41 @@ def _stage_backward(plans, saved, g, want_dx):
     return g
 
 
+def _dgrad_plans(stage, out):
+    """The input-gradient-only launch plans of `stage` for the activations a one-node forward left on `out`, or None."""
+    saved = getattr(out, "_afan_stage_saved", None)
+    if saved is None or len(saved) != 4 * len(stage):
+        return None
+    with dgrad_only():
+        plans, probe = [], saved[0]
+        for blk in stage:
+            plan = _block_plan(blk, probe)
+            if not plan:
+                return None
+            plans.append(plan)
+            probe = _ShapeOnly((plan.n, plan.co, plan.ho, plan.wo), saved[0])
+    return plans
+
+
+def stage_input_gradient(stage, out, g=None):
+    """d(loss)/d(stage input) from g = d(loss)/d(stage output) and the activations a forward of `stage` left on its output tensor
+    `out` (`_FrozenStageFn`), with no parameter gradient touched (the dgrad-only launch plans) — what back-propagating g through
+    a SECOND forward of the same stage on the same input under `resnet_s.dgrad_only()` would give, bit for bit, without that
+    forward.  g None: only answers whether that is possible (True / False); None when it is not."""
+    plans = _dgrad_plans(stage, out)
+    if g is None:
+        return plans is not None
+    if plans is None:
+        return None
+    saved = out._afan_stage_saved
+    last = saved[-1]
+    g = _like_layout(g, last)
+    if g.dtype != last.dtype:
+        g = g.to(last.dtype)
+    with torch.no_grad():
+        return _stage_backward(plans, saved, g, True)
+
+
 class _FrozenStageFn(torch.autograd.Function):
     """A whole stage (layer1 .. layer4: 3 / 4 / 23 / 3 frozen-BatchNorm bottlenecks) as ONE autograd node: the same native calls
     as one `_FrozenBlockFn` per block, issued in a loop — the per-node cost of `Function.apply` and of the engine's scheduling
@@ -260,6 +295,7 @@ class _FrozenStageFn(torch.autograd.Function):
             x = out
         ctx.plans = plans
         ctx.save_for_backward(*saved)
+        x._afan_stage_saved = tuple(saved)        # (references only: stage_input_gradient reuses a clean pass's activations)
         return x
 
     @staticmethod
@@ -537,6 +573,7 @@ class ResNet101(nn.Module):
                 x = _run_stage(st, x)
                 if col is not None:
                     col[i] = x.detach().clone() if _StageGraphs.ON else x.detach()
+                    col["out", i] = x                 # (the graph tensor: carries the stage's activations, see stage_input_gradient)
             return x
         assert flag == "tail" and input_dict["out_idx"] in (1, 2, 3)
         x = _enter(input_dict["adv"], self.conv1.compute_dtype, self.normal.channels_last)

@@ -11,6 +11,8 @@ that forward, the signs of the one-step feature PGD.  Held loosely, and said so:
 train_aug_sat_muti_advt.py:70-172 — its adversarial image is five sign() steps on 61 440 pixels; a flipped pixel moves every
 anchor's logit by ~1e-3, which reorders proposals of nearly equal score, and `randperm` then samples by POSITION: two correct
 fp32 implementations leave that iteration a per cent apart."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -261,7 +263,7 @@ def test_head_features_equal_the_three_head_forwards(pkg, gpu):
     col = {}
     torch.manual_seed(3)
     rr = m.train().forward({"x": x, "adv": None, "out_idx": "roi_head", "flag": "clean", "collect": col}, bboxes, labels)
-    assert sorted(col) == [1, 2, 3] and "roi_output_dict" in rr
+    assert sorted(k for k in col if isinstance(k, int)) == [1, 2, 3] and "roi_output_dict" in rr
     for i, f in zip((1, 2, 3), one):
         assert not col[i].requires_grad and torch.equal(col[i], f), i
 
@@ -328,3 +330,35 @@ def test_stage_backward_chain_equals_block_by_block(pkg, gpu):
     assert a[1].keys() == b[1].keys()
     for n in a[1]:
         assert torch.equal(a[1][n], b[1][n]), n
+
+
+def test_feature_pgd_folded_into_the_clean_pass_changes_no_bit(pkg, gpu):
+    """det_train_phases takes the two one-step feature PGDs at out_idx 1 / 2 (train_aug_sat_muti_advt.py:84-85: no random start,
+    so their one forward runs the rest of the backbone on the CLEAN feature map) from the clean ROI-head pass's own activations:
+    only the part behind the backbone runs again, the gradient goes back through the stored activations with the
+    input-gradient-only launches (det_attack_algo._pgd1_from_clean, det_model.stage_input_gradient).  Against PGD() as written
+    (AFAN_DET_FOLD_PGD=0), same seed: the two adversarial feature maps, every loss, the gradient arena — the same bits; and the
+    fold really ran (fewer convolution launches)."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    res, old = {}, os.environ.get("AFAN_DET_FOLD_PGD")
+    try:
+        for fold in ("1", "0"):
+            os.environ["AFAN_DET_FOLD_PGD"] = fold
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m)
+            torch.manual_seed(102)
+            before = pkg.ops.CALLS["conv_fwd"]
+            r = tr.step(images, bboxes, labels)
+            torch.cuda.synchronize()
+            res[fold] = (r, tr.arena.grad.clone(), pkg.ops.CALLS["conv_fwd"] - before)
+    finally:
+        if old is None:
+            os.environ.pop("AFAN_DET_FOLD_PGD", None)
+        else:
+            os.environ["AFAN_DET_FOLD_PGD"] = old
+    a, b = res["1"], res["0"]
+    assert a[2] < b[2] - 100                              # stages 2 + 3 and stage 3 once less: ~150 convolution launches
+    for k in ("adv1", "adv2", "adv3", "adv_image", "losses", "loss"):
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert torch.equal(a[1], b[1])
