@@ -295,7 +295,8 @@ class _FrozenStageFn(torch.autograd.Function):
             x = out
         ctx.plans = plans
         ctx.save_for_backward(*saved)
-        x._afan_stage_saved = tuple(saved)        # (references only: stage_input_gradient reuses a clean pass's activations)
+        if any(ctx.needs_input_grad):             # (references only, and only where a graph keeps them alive anyway:
+            x._afan_stage_saved = tuple(saved)    #  stage_input_gradient reuses a clean pass's activations)
         return x
 
     @staticmethod
