@@ -76,6 +76,9 @@ def parse():
                     "reference does not have; the headline line is measured without it)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_literal", action="store_true", help="skip the after-the-fact run of the reference's literal schedule "
+                    "(main_perturb.py:173,195-196 as written: two head passes, separate first PGD pass and final clean pass)")
+    ap.add_argument("--literal_steps", type=int, default=12)
     ap.add_argument("--cpu_steps", type=int, default=None, help="timed CPU-oracle steps (default 3; 1 for the DeepLab workload)")
     return ap.parse_args()
 
@@ -205,6 +208,61 @@ def pmc_traffic(kernel_name, arch):
             return (round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024),
                     os.path.relpath(f, ROOT), stale, meta.get("command"))
     return None
+
+
+def pmc_mfma(kernel_name, arch):
+    """MFMA utilisation of `kernel_name` (all its variants, weighted by launches) from the newest profiles/r*_pmc_mfma.json taken on
+    this workload (tools/gpu_pmc_mfma.sh): SQ_VALU_MFMA_BUSY_CYCLES / (GPU-active cycles x 4 SIMDs x 256 CUs)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), reverse=True):
+        try:
+            pmc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        meta = pmc.get("_meta", {})
+        cmd = meta.get("command") or ""
+        f_arch = cmd.split("--arch", 1)[1].split()[0] if "--arch" in cmd else "resnet18"
+        if f_arch != arch:
+            continue
+        vs = [(k, e) for k, e in pmc.items() if not k.startswith("_") and k.split("<")[0] == kernel_name and e.get("mfma_util") is not None]
+        n = sum(e["launches"] for _, e in vs)
+        if n:
+            w = lambda key: round(sum((e.get(key) or 0.0) * e["launches"] for _, e in vs) / n, 4)
+            return {"mfma_util": w("mfma_util"), "wait_any": w("wait_any"), "wait_inst": w("wait_inst"), "lds_issue": w("lds_issue"),
+                    "variants": {k: e["mfma_util"] for k, e in vs}, "source": os.path.relpath(f, ROOT),
+                    "stale": meta.get("kernel_sources_sha") != kernel_sources_sha()}
+    return None
+
+
+def literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys):
+    """The reference's schedule as written (main_perturb.py:173,195-196: head forward for PGD AND inside the clean forward, K PGD
+    passes, adversarial + clean final passes), on a fresh model of the same architecture, hipGraph replay, after the timed region."""
+    ctor, _ = pkg.resnet_s.ARCHS[args.arch]
+    torch.manual_seed(3)
+    model = ctor()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
+    tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.1,
+                                    use_graph=not args.no_graph, share_head=False, fold_clean=False)
+    nb = len(xs)
+    for i in range(6):
+        tr.step(xs[i % nb], ys[i % nb])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.literal_steps):
+        r = tr.step(xs[i % nb], ys[i % nb])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pkg.ops.profile_enable(True)
+    tr._step_eager(xs[0], ys[0])
+    torch.cuda.synchronize()
+    prof = pkg.ops.profile_collect()
+    pkg.ops.profile_enable(False)
+    cf = sum(q["flops"] for k, q in prof.items() if k.startswith("conv_"))
+    return {"images_per_s": round(args.batch * args.literal_steps / dt, 1), "ms_per_step": round(dt / args.literal_steps * 1e3, 3),
+            "steps": args.literal_steps, "executed_GFLOP_per_step": round(cf / 1e9, 1), "hipgraph": tr._graph is not None,
+            "final_loss": round(float(r["loss"]), 4),
+            "schedule": "2 head passes, %d PGD passes + adversarial and clean final passes%s (bench.py --no_fold_clean --no_share_head)"
+                        % (args.pgd_steps, " (one grouped pass over the tail)" if getattr(tr, "_groupable", False) else "")}
 
 
 def launch_ranks(args):
@@ -424,6 +482,7 @@ def main():
             peak = F32_MFMA_PEAK_TFLOPS if f32k else BF16_DENSE_PEAK_TFLOPS
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": peak,
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                    "frac_raw": round(v["flops"] / (v["ms_raw"] * 1e-3) / 1e12 / peak, 4),
                     "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                     "algo_flops_per_launch": round(v["flops"] / v["launches"]),
                     "handwritten_ms_per_step": hand_ms, "event_overhead_us": round(ev_us, 2),
@@ -440,6 +499,7 @@ def main():
             ach = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac_raw": round(v["bytes"] / (v["ms_raw"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                     "algo_bytes_per_launch": round(v["bytes"] / v["launches"]), "handwritten_ms_per_step": hand_ms,
                     "event_overhead_us": round(ev_us, 2), "avg_launch_us_raw": round(v["ms_raw"] * 1e3 / v["launches"], 2)}
@@ -450,6 +510,10 @@ def main():
             roof["traffic"], roof["traffic_source"], roof["traffic_stale"] = tr[0], tr[1], tr[2]
             roof["traffic_note"] = ("rocprofv3 --pmc, 2*FETCH_SIZE+WRITE_SIZE per launch; stale = the kernel sources changed "
                                     "since that summary was taken" + (f"; measured on: {tr[3]}" if tr[3] else ""))
+        mu = pmc_mfma(name, args.arch) if roof["bound"] == "mfma" else None
+        if mu is not None:
+            roof["mfma_util"] = mu.pop("mfma_util")
+            roof["mfma_counters"] = mu
         # executed convolution FLOPs of one step: every conv launch records its own 2*M*N*K
         cf = sum(q["flops"] for k, q in prof.items() if k.startswith("conv_")) / NP
         conv_ms = sum(q["ms"] for k, q in prof.items() if k.startswith("conv_")) / NP
@@ -469,8 +533,30 @@ def main():
                 hbm[k] = {"achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
                           "algo_bytes_per_launch": round(prof[k]["bytes"] / prof[k]["launches"]),
                           "avg_us": round(prof[k]["ms"] * 1e3 / prof[k]["launches"], 2)}
+    # ---- N > 1: three more steps with every exchange bracketed by events (not part of `value`) ----
+    ddp_diag = None
+    red = getattr(trainer, "reducer", None)
+    if world > 1 and red is not None:
+        red.diag = True
+        steps_ = []
+        for i in range(3):
+            one(i)
+            torch.cuda.synchronize()
+            d_ = red.last_diag()
+            if d_ is not None:
+                steps_.append(d_)
+        red.diag = False
+        if rank == 0 and steps_:
+            ddp_diag = {"steps": steps_, "note": "rank 0, three steps after the timed region: per announced gradient range the bytes, the wait "
+                        "behind earlier ranges on the exchange stream (queued_ms) and the all-reduce's own duration; exposed_allreduce_ms = "
+                        "how long the compute stream stood waiting for the exchange stream before SGD; host_gap_us = host time spent "
+                        "launching the exchange between two graph replays"}
     if world > 1:
         dist.barrier()
+
+    literal = None
+    if rank == 0 and world == 1 and not (seg or det) and not args.no_literal and trainer._fold_ok(xs[0]):
+        literal = literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -540,6 +626,10 @@ def main():
         }
         if ranks_seen is not None:
             line["ranks_seen"] = ranks_seen
+        if ddp_diag is not None:
+            line["ddp_diag"] = ddp_diag
+        if literal is not None:
+            line["literal_schedule"] = literal
         if conv_exec is not None:
             gf = REF_GFLOP_PER_IMAGE.get((args.arch, args.pgd_steps))
             if gf is not None:      # secondary: what the same img/s would mean at the reference schedule's FLOP count

@@ -248,7 +248,7 @@ def _stage_backward(plans, saved, g, want_dx):
 def _dgrad_plans(stage, out):
     """The input-gradient-only launch plans of `stage` for the activations a one-node forward left on `out`, or None."""
     saved = getattr(out, "_afan_stage_saved", None)
-    if saved is None or len(saved) != 4 * len(stage):
+    if saved is None or len(saved) != 4 * len(stage) - 1:          # (every activation but `out` itself: no reference cycle)
         return None
     with dgrad_only():
         plans, probe = [], saved[0]
@@ -271,7 +271,7 @@ def stage_input_gradient(stage, out, g=None):
         return plans is not None
     if plans is None:
         return None
-    saved = out._afan_stage_saved
+    saved = out._afan_stage_saved + (out,)
     last = saved[-1]
     g = _like_layout(g, last)
     if g.dtype != last.dtype:
@@ -296,7 +296,10 @@ class _FrozenStageFn(torch.autograd.Function):
         ctx.plans = plans
         ctx.save_for_backward(*saved)
         if any(ctx.needs_input_grad):             # (references only, and only where a graph keeps them alive anyway:
-            x._afan_stage_saved = tuple(saved)    #  stage_input_gradient reuses a clean pass's activations)
+            # stage_input_gradient reuses a clean pass's activations.)  Everything BUT the output itself: a tuple holding
+            # `x` on `x.__dict__` is a cycle that only the cyclic collector frees — the stage's activations would outlive
+            # their graph by however long that takes (~4 GB resident in a CPU simulation)
+            x._afan_stage_saved = tuple(saved[:-1])
         return x
 
     @staticmethod
@@ -487,6 +490,14 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     _plans, _plan_epoch, _params, _ver = None, -1, None, None
+
+    def __getstate__(self):
+        # launch-plan caches hold ctypes pointer objects (not picklable, and meaningless in a copy): a deepcopy / torch.save of
+        # the module starts without them and rebuilds them on its first forward
+        d = dict(self.__dict__)
+        for k in ("_plans", "_plan_epoch", "_params", "_ver"):
+            d.pop(k, None)
+        return d
 
     def _block_params(self):
         if self._params is None:

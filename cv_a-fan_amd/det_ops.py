@@ -48,6 +48,8 @@ def nms(bboxes, scores, threshold, inclusive=False, padded=False, max_keep=0, pr
         raise ops.AfanLibraryError("nms: tensors must live on the MI355X (no CPU path in this build)")
     n = bboxes.shape[0] if bboxes.dim() > 0 else 0
     if bboxes.numel() == 0:
+        if padded:                                         # the padded contract holds for an empty set too: (keep, count) on the device
+            return (torch.empty(0, dtype=torch.int64, device=bboxes.device), torch.zeros(1, dtype=torch.int64, device=bboxes.device))
         return torch.empty(0, dtype=torch.int64)          # nms.h:17-18 returns an empty CPU tensor
     lib = _lib.load()
     boxes = bboxes.detach().float().contiguous()

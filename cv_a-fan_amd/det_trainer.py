@@ -14,9 +14,12 @@ import torch
 from .arena import ArenaSGD, ParamArena
 from .det_attack_algo import det_train_phases
 
-# everything behind the conv4 feature map: layer4 (= detection.hidden), the backbone's unused ImageNet classifier (it sits between
-# them in the reference's parameter order and never receives a gradient: zeros ride along), the RPN and the two heads
+# everything behind the conv4 feature map: layer4 (= detection.hidden), the RPN and the two heads.  The backbone's unused ImageNet
+# classifier `features.fc` sits between them in the reference's parameter order and never receives a gradient: optim.SGD skips a
+# tensor whose .grad is None (no weight decay, no momentum: it keeps its values), so it stays OUTSIDE the arena (UNUSED_PARAMS) —
+# the prefix is kept for arenas built with skip=() by callers that want the reference's full parameter list.
 TAIL_PREFIXES = ("features.layer4.", "features.fc.", "rpn.", "detection.")
+UNUSED_PARAMS = ("features.fc.weight", "features.fc.bias")
 
 
 class DetTrainer:
@@ -24,7 +27,7 @@ class DetTrainer:
                  segmented=None, arena=None):
         import torch.distributed as dist
         self.model, self.loss_settings, self.group = model, int(loss_settings), group
-        self.arena = arena if arena is not None else ParamArena(model, skip=())
+        self.arena = arena if arena is not None else ParamArena(model, skip=UNUSED_PARAMS)
         self.optimizer = ArenaSGD(self.arena, lr, momentum, weight_decay)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.reducer = None

@@ -44,6 +44,10 @@ class GradAllReducer:
         self._pending = []
         self._hooks = []
         self._need, self._done = [], []
+        # diag = True: every exchange is bracketed by events on the exchange stream and the compute stream's wait for it in
+        # finish() by events on the compute stream; last_diag() turns them into milliseconds (bench.py's N > 1 line)
+        self.diag = False
+        self._diag_ranges, self._diag_wait, self._diag_host = [], None, []
         if self.world > 1:
             # a chunk is ready when EVERY parameter in it has its final gradient (head parameters finish during the
             # clean pass, tail parameters only after the adv pass too), so count completions per chunk.
@@ -72,6 +76,7 @@ class GradAllReducer:
         self.enabled = not explicit
         self._done = [0] * len(self.chunks)
         self._covered = []
+        self._diag_ranges, self._diag_wait, self._diag_host = [], None, []
 
     def launch_params(self, p_lo, p_hi):
         """Start the exchange of the gradients of parameters [p_lo, p_hi) (arena order) NOW, on the side stream: the
@@ -88,11 +93,19 @@ class GradAllReducer:
     def _launch(self, start, end):
         buf = self.arena.grad[start:end]
         if self.on_cuda:
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.diag)
             ev.record(torch.cuda.current_stream(buf.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                if self.diag:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.diag:
+                    if self.world > 1 and dist.get_backend(self.group) != "nccl":
+                        w.wait()                   # (gloo on device tensors: the copy back is host-driven; bracket it whole)
+                    e1.record(self.stream)
+                    self._diag_ranges.append((start, end, ev, e0, e1))
         else:
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append(w)
@@ -114,11 +127,35 @@ class GradAllReducer:
             for ci, (start, end, _) in enumerate(self.chunks):  # parameters that got no gradient this step
                 if self._done[ci] < self._need[ci]:
                     self._launch(start, end)
+        cur = torch.cuda.current_stream(self.arena.grad.device) if self.on_cuda else None
+        if self.diag and self.on_cuda:
+            wa, wb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            wa.record(cur)
         for w in self._pending:
             w.wait()
         self._pending.clear()
         if self.on_cuda:
-            torch.cuda.current_stream(self.arena.grad.device).wait_stream(self.stream)
+            cur.wait_stream(self.stream)
+            if self.diag:
+                wb.record(cur)
+                self._diag_wait = (wa, wb)
+
+    def note_host_gap(self, seconds):
+        """(diag) host time between two graph replays around an exchange launch."""
+        if self.diag:
+            self._diag_host.append(seconds)
+
+    def last_diag(self):
+        """After a synchronize: the last step's exchanges — per announced range its bytes, the time from the compute stream's
+        announcement to the exchange's start on its stream (queueing behind earlier ranges) and the exchange's own duration;
+        `exposed_allreduce_ms` = how long the compute stream stood in finish() before the optimizer could run; `host_gap_us`
+        = host time between consecutive graph replays (the RCCL launch sits in it)."""
+        if not (self.diag and self.on_cuda and self._diag_wait):
+            return None
+        rs = [{"bytes": (end - start) * 4, "queued_ms": round(ev.elapsed_time(e0), 3), "allreduce_ms": round(e0.elapsed_time(e1), 3)}
+              for start, end, ev, e0, e1 in self._diag_ranges]
+        return {"ranges": rs, "exposed_allreduce_ms": round(self._diag_wait[0].elapsed_time(self._diag_wait[1]), 3),
+                "host_gap_us": [round(h * 1e6, 1) for h in self._diag_host]}
 
 
 def _cut_chunks(arena, n_chunks):
@@ -573,10 +610,13 @@ class AfanTrainer:
         if self._pieces is not None:
             if self.reducer is not None:
                 self.reducer.begin(explicit=True)
+            import time as _time
             for g, rng in self._pieces:
                 g.replay()
+                t_ = _time.perf_counter()
                 if self.reducer is not None:
                     self.reducer.launch_params(*rng)
+                    self.reducer.note_host_gap(_time.perf_counter() - t_)
             if self.reducer is not None:
                 self.reducer.finish()
             self.optimizer.step()

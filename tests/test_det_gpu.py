@@ -352,3 +352,10 @@ def test_nms_top_stops_at_the_first_survivors(pkg, gpu, n, spread):
         assert top.numel() <= max(full.numel(), 0) and (top.numel() < k + 64 or full.numel() < k + 64), (n, k, top.numel(), full.numel())
         if full.numel() >= k:
             assert top.numel() >= k
+
+
+def test_padded_nms_of_an_empty_set_is_a_pair_on_the_device(pkg, gpu):
+    """det_ops.nms(padded=True) answers (keep, count) for every input, the empty set included (RegionProposalNetwork unpacks it)."""
+    keep, count = pkg.det_ops.nms(torch.zeros(0, 4, device=gpu), torch.zeros(0, device=gpu), 0.7, padded=True)
+    assert keep.is_cuda and count.is_cuda and keep.numel() == 0 and keep.dtype == torch.int64 and int(count.item()) == 0
+    assert pkg.det_ops.nms(torch.zeros(0, 4, device=gpu), torch.zeros(0, device=gpu), 0.7).numel() == 0

@@ -201,9 +201,12 @@ def test_faster_rcnn_full_size_iteration_properties(pkg, gpu):
         wh = 60 + torch.rand(1, 6, 2, generator=gen) * 200
         bboxes = torch.cat([x0, y0, x0 + wh[..., :1], y0 + wh[..., 1:]], dim=-1).to(gpu)
         labels = torch.randint(1, 21, (1, 6), generator=gen).to(gpu)
+        fc0 = m.features.fc.weight.detach().clone()
         torch.manual_seed(1)
         r = tr.step(images, bboxes, labels)
         torch.cuda.synchronize()
+        # the backbone's unused ImageNet classifier never receives a gradient: the reference's optim.SGD leaves it alone
+        assert torch.equal(m.features.fc.weight.detach(), fc0) and not any(n.startswith("features.fc.") for n in tr.arena.names)
         return tr, images, r
     tr, images, r = run()
     assert torch.isfinite(r["losses"]).all() and np.isfinite(float(r["loss"])) and r["losses"].shape == (8,)
@@ -362,3 +365,40 @@ def test_feature_pgd_folded_into_the_clean_pass_changes_no_bit(pkg, gpu):
     for k in ("adv1", "adv2", "adv3", "adv_image", "losses", "loss"):
         assert torch.equal(a[0][k], b[0][k]), k
     assert torch.equal(a[1], b[1])
+
+
+def test_stage_activations_are_freed_with_their_graph(pkg, gpu):
+    """A one-node stage leaves references to its activations on its output tensor (det_model.stage_input_gradient reuses them).  The
+    output itself must not be among them: `x.__dict__ -> tuple -> x` is a cycle only the cyclic collector frees, and the caching
+    allocator does not run it when memory is short.  With the collector OFF: allocated memory is back at its baseline as soon as
+    the graph and the output are dropped; and the stored tuple + the output still give the input gradient the backward gives."""
+    import gc
+    g = golden("det_frcnn_r101")
+    m = _build(pkg, g, gpu, torch.bfloat16, True, "pooling")
+    stage = m.features.layer2
+    x = (torch.randn(1, 256, 40, 56, device=gpu) * 0.5).bfloat16().contiguous(memory_format=torch.channels_last)
+    for _ in range(2):                                   # workspaces and launch plans exist after the first pass
+        o = pkg.det_model._run_stage(stage, x.clone().requires_grad_(True))
+        o.backward(torch.ones_like(o))
+        del o
+    gc.collect()
+    torch.cuda.synchronize()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated(gpu)
+        xin = x.clone().requires_grad_(True)
+        out = pkg.det_model._run_stage(stage, xin)
+        assert hasattr(out, "_afan_stage_saved") and not any(t is out for t in out._afan_stage_saved)
+        go = torch.ones_like(out)
+        dx2 = pkg.det_model.stage_input_gradient(stage, out, go)
+        out.backward(go)
+        assert dx2 is not None and torch.equal(dx2, xin.grad)
+        held = torch.cuda.memory_allocated(gpu)
+        del out, go, dx2, xin
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_allocated(gpu)
+    finally:
+        if was:
+            gc.enable()
+    assert held > base + (1 << 20) and after <= base, (base, held, after)

@@ -204,3 +204,28 @@ def test_tiled_convolution_kernels_use_no_scratch():
     kernels = re.findall(r"\.set (\S+)\.private_seg_size, (\d+)", isa)
     assert len(kernels) > 40
     assert [k for k in kernels if int(k[1]) > 0] == []
+
+
+def test_detection_bottleneck_copies_without_its_launch_plans(pkg):
+    """det_model.Bottleneck caches launch plans (ctypes pointer objects) on the module; copy.deepcopy / pickling must still work
+    (EMA copies, torch.save of a module) and the copy must start without the cache."""
+    import copy
+    import ctypes
+    import pickle
+    blk = pkg.det_model.Bottleneck(64, 16)
+    blk._plans, blk._plan_epoch = {"key": ctypes.c_void_p(1234)}, 7
+    blk._params = tuple(blk.parameters())
+    c = copy.deepcopy(blk)
+    assert c._plans is None and c._plan_epoch == -1 and c._params is None
+    assert [tuple(p.shape) for p in c.parameters()] == [tuple(p.shape) for p in blk.parameters()]
+    assert pickle.loads(pickle.dumps(blk))._plans is None
+    assert blk._plans is not None                      # the original keeps its cache
+
+
+def test_padded_nms_contract_rejects_cpu_and_device_is_checked_first(pkg):
+    """det_ops.nms has no CPU path; the padded form's empty-set answer is a (keep, count) pair like every other padded answer
+    (checked on the GPU in tests/test_det_gpu.py)."""
+    import pytest
+    import torch
+    with pytest.raises(pkg.ops.AfanLibraryError):
+        pkg.det_ops.nms(torch.zeros(0, 4), torch.zeros(0), 0.7, padded=True)
