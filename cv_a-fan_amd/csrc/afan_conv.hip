@@ -28,6 +28,9 @@
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
+#ifndef AFAN_CONV_HPIPE
+#define AFAN_CONV_HPIPE 0        // halo form: operand fragments requested one group (two k16-slices) ahead of their MFMAs, across the barrier (0: A/B)
+#endif
 #ifndef AFAN_CONV_FRAG_BATCH
 #define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
 #endif
@@ -38,6 +41,7 @@ using namespace afan_conv;
 namespace afan_nhwc {   // afan_bn_nhwc.hip: accumulator copies per channel / doubles per accumulator block
 int acc_slot_count(int64_t C);
 int64_t acc_doubles(int64_t C);
+int set_running_updates(int n);
 }
 
 namespace {
@@ -55,6 +59,64 @@ constexpr int LDK = BK + 8;      // padded LDS row (elements): 144 bytes (regist
 
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
 constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
+#ifdef AFAN_CONV_STAMP
+// diagnostic build (tools/build_stamp.sh): per-tap cycle stamps of workgroup (0,0,0)'s first MFMA wave and first producer wave in
+// the halo form, parked in LDS during the loop (a global store would join the producers' counted vmcnt) and written out once
+__device__ unsigned long long afan_stamps[2][96][3];
+#define AFAN_STAMP(role, idx, k) do { if (stamp_on && (idx) < 96) st_lds[role][idx][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AFAN_STAMP(role, idx, k) do { } while (0)
+#endif
+
+// ---- grid-wide barrier for the in-launch BatchNorm (ConvP::bnf): every workgroup of the launch is resident (dispatch_bnf checks),
+// what the barrier orders — the f64 column sums — travels through memory-side atomics that each workgroup has drained
+// (s_waitcnt vmcnt(0)) before it arrives, so RELAXED agent-scope atomics suffice: no L2 write-back / invalidate (release +
+// acquire at agent scope cost 8-24 us here, tools/probe/grid_barrier.hip; this form 2-3 us, tools/probe/grid_barrier2.hip).
+// Sense-reversing, sharded over 8 arrival counters (workgroup id & 7), self-resetting: reusable by the next launch without a
+// memset node.  The spin is BOUNDED (0.2 s of the 100 MHz clock): a launch whose workgroups are not all resident (another
+// process's kernels holding CUs) flags bar[ERR] and goes on with wrong totals instead of hanging the GPU; ops.py checks the flag.
+struct GridBar {                       // words 64 bytes apart
+    unsigned shard_cnt[8][16];
+    unsigned global_cnt[16];
+    unsigned flag[8][16];
+    unsigned err[16];
+};
+static_assert(sizeof(GridBar) <= 2048, "afan_grid_barrier_bytes()");
+// arrive / wait are separate so that a workgroup can store its raw tile while the others still arrive.  Per-shard arrival counters
+// (reset by the shard's last arriver, fire and forget: the next episode is a later launch, ordered behind this one by the stream)
+// and ONE monotonic release counter that every shard's last arriver bumps: a workgroup's episode number is that counter / 8 read
+// BEFORE its own arrival (its shard cannot have completed yet), it leaves when the counter reaches 8 * (episode + 1).  The last
+// arriver's path is two dependent atomics, a waiter's one poll round trip behind them.
+__device__ __forceinline__ unsigned grid_arrive(unsigned* words, unsigned id, unsigned nwg) {
+    GridBar* b = reinterpret_cast<GridBar*>(words);
+    const unsigned sh = id & 7u;
+    const unsigned per = nwg / 8u + (sh < (nwg & 7u) ? 1u : 0u);            // (nwg >= 8: launch_gs checks)
+    const unsigned target = (__hip_atomic_load(&b->global_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / 8u + 1u) * 8u;
+    const unsigned a = __hip_atomic_fetch_add(&b->shard_cnt[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1 == per) {
+        __hip_atomic_store(&b->shard_cnt[sh][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&b->global_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return target;
+}
+__device__ __forceinline__ void grid_wait(unsigned* words, unsigned id, unsigned target) {
+    GridBar* b = reinterpret_cast<GridBar*>(words);
+    if (__hip_atomic_load(&b->err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // a spin already gave up: do not stack 0.2 s waits
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(&b->global_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 20000000LL) {
+            __hip_atomic_store(&b->err[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+// a memory-side total (the accumulators are only ever touched by device-scope atomics): a load that passes this XCD's L2 (sc1)
+__device__ __forceinline__ double ld_total(const __amdgpu_buffer_rsrc_t& r, int byte_off) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16));
+}
 
 // PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
 // the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
@@ -74,8 +136,10 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // tiles: the one tile holding rows of both halves runs the epilogue once per group.  A separate instantiation because the
 // pass loop costs the 768- and 1 024-thread variants their last free registers (scratch in the K loop: ResNet-18's step
 // 8.8 -> 11.6 ms when every launch carried it); launch<> picks it only for such launches.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>   // WM x WN waves: pixels x channels
+// BF: the instantiation with the in-launch BatchNorm behind a grid barrier (ConvP::bnf; afan_conv_bnf.hip).
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false, bool BF = false>   // WM x WN waves: pixels x channels
 __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
+    static_assert(!(BF && GS), "in-launch BatchNorm: one image group");
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
     constexpr int STG = PW ? 64 * PW : THREADS;       // threads that stage operands
@@ -336,8 +400,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             jrow[i] = p0(m) - Pb;
             vrow[i] = (int)m;
         }
+#ifdef AFAN_CONV_STAMP
+        __shared__ unsigned long long st_lds[2][96][3];
+        const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW);
+#endif
         __syncthreads();                                      // htab (and out_off) are written
 
+#if !AFAN_CONV_HPIPE
         auto compute_h = [&](int buf, int hb, int tjt, int tvt) {
             const uint16_t* B = lds + buf * STAGE;
             const uint16_t* Hh = Hbase + hb * (HPM * BK);
@@ -374,6 +443,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 if (FB > 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
+#endif
+
+        // ---- software-pipelined form of the same products (AFAN_CONV_HPIPE).  Per-tap stamps of the loop above (tools/probe/
+        // conv_stamps.py, profiles/r05b_conv_stamps.txt) showed where a tap's cycles went: after each barrier every MFMA wave requested
+        // its fragments and waited for the first of them with the matrix pipe idle (12 reads + ~150 cycles of LDS latency in front of 8
+        // MFMAs = 256 cycles: 610 cycles per tap for the one-wave-per-SIMD tiles), then all waves met again.  Here a tap's fragments are
+        // requested in two groups of two k16-slices, each ONE GROUP AHEAD of its MFMAs: the second group at the top of the tap, the
+        // next tap's first group — from the next weight tile, which the producers now have in LDS one barrier earlier (they leave
+        // one tile in flight instead of two), and from the resident halo — between the tap's two MFMA groups.  Behind a barrier the
+        // matrix pipe starts at once.  The products are added in the same order: the same bits.
+#if AFAN_CONV_HPIPE
+        constexpr int PB = 2;                                  // k16-slices per group (two groups per tap: static register sets)
+        auto load_h = [&](int buf, int hb, int tjt, int tvt, int g, bf16x8 (&fx)[PB][MI], bf16x8 (&fw)[PB][NI]) {
+            const uint16_t* B = lds + buf * STAGE;
+            const uint16_t* Hh = Hbase + hb * (HPM * BK);
+            const int frow = lane & 31;
+            const int sw = (frow >> 1) & 7;
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const int c2 = (g * PB + b) * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    fx[b][i] = *reinterpret_cast<const bf16x8*>(Hh + (jrow[i] + tjt) * BK + ((c2 ^ (((vrow[i] + tvt) >> 1) & 7)) * 8));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + ((c2 ^ sw) * 8));
+            }
+        };
+        auto mfma_h = [&](const bf16x8 (&fx)[PB][MI], const bf16x8 (&fw)[PB][NI]) {
+#pragma unroll
+            for (int b = 0; b < PB; ++b)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
+        };
+#endif
 
         // Every K-step's issue is exactly LPT = B_ROWS + 2 DMA instructions per producer wave (the counted vmcnt waits
         // need a fixed number): the weight tile and two halo groups of the NEXT chunk; a slot with no group left is a
@@ -411,10 +518,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     // tiles after (q, t): min(that, 2) of them are in flight behind it
+                    AFAN_STAMP(1, q * 9 + t, 0);
+#if AFAN_CONV_HPIPE
+                    // (pipelined fragments: tile (q, t) + 1 must be in LDS as well — the MFMA waves request it during tap (q, t) —
+                    // so only the newest tile stays in flight behind the wait)
+                    if (t <= 6 || more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
+                    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+#else
                     if (t <= 6 || more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * 2));
                     else if (t == 7) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
                     else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+#endif
+                    AFAN_STAMP(1, q * 9 + t, 1);
                     __builtin_amdgcn_s_barrier();              // tile (q, t) is in LDS for everyone; the buffer of the tile before is free
+                    AFAN_STAMP(1, q * 9 + t, 2);
                     const int nb = (q + t + 3) & 3;            // 9 = 1 (mod 4): tile 9 q + t lives in weight buffer (q + t) & 3
                     if (t + 3 < 9 || more) {
                         bdma(nb, two[(t + 3) % 9], t + 3 < 9 ? q : q + 1);
@@ -426,6 +543,47 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 }
             }
         } else {
+#if AFAN_CONV_HPIPE
+            bf16x8 fx0[PB][MI], fw0[PB][NI], fx1[PB][MI], fw1[PB][NI];
+            __builtin_amdgcn_s_barrier();                      // tiles 0 and 1 and chunk 0's halo are in LDS
+            load_h(0, 0, tj[0], tv[0], 0, fx0, fw0);
+            for (int q = 0; q < chunks; ++q) {
+                const bool more = q + 1 < chunks;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    AFAN_STAMP(0, q * 9 + t, 1);
+                    load_h((q + t) & 3, q & 1, tj[t], tv[t], 1, fx1, fw1);
+                    mfma_h(fx0, fw0);
+                    __builtin_amdgcn_sched_barrier(0);          // (set 0 is rewritten below: its MFMAs stay above)
+                    if (t < 8 || more)                          // the next tap's first group: tile k + 1 landed with this tap's barrier
+                        load_h((q + t + 1) & 3, t < 8 ? (q & 1) : ((q + 1) & 1), tj[(t + 1) % 9], tv[(t + 1) % 9], 0, fx0, fw0);
+                    mfma_h(fx1, fw1);
+#if AFAN_CONV_HPIPE >= 2
+                    // the issue order inside each half of the tap: one MFMA, then the address arithmetic and fragment requests that
+                    // fit its 32-cycle shadow (the compiler's own order runs the requests, then the MFMAs, then ~20 address
+                    // instructions with the matrix pipe idle: 600 cycles per tap for 256 of MFMA on the one-wave-per-SIMD tiles)
+#pragma unroll
+                    for (int hg = 0; hg < 2; ++hg) {
+#pragma unroll
+                        for (int m = 0; m < PB * NI * MI; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, (PB * (MI + NI) * 5 + PB * NI * MI - 1) / (PB * NI * MI), 0);   // VALU
+                            __builtin_amdgcn_sched_group_barrier(0x100, (PB * (MI + NI) + PB * NI * MI - 1) / (PB * NI * MI), 0);       // DS read
+                        }
+                        if (hg == 0) __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    AFAN_STAMP(0, q * 9 + t, 2);
+                    if (t < 8 || more) {
+                        AFAN_STAMP(0, q * 9 + t + 1, 0);
+                        __builtin_amdgcn_s_barrier();
+                    }
+                }
+            }
+#else
             for (int q = 0; q < chunks; ++q) {
                 // (opaque per chunk: otherwise the nine taps' fragment addresses are hoisted out of the chunk loop as
                 // 40-odd loop-invariant registers, which the 168-register variant spills)
@@ -433,12 +591,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
+                    AFAN_STAMP(0, q * 9 + t, 0);
                     __builtin_amdgcn_s_barrier();
+                    AFAN_STAMP(0, q * 9 + t, 1);
                     compute_h((q + t) & 3, q & 1, tj[t], tv[t]);
+                    AFAN_STAMP(0, q * 9 + t, 2);
                 }
             }
+#endif
         }
         __syncthreads();
+#ifdef AFAN_CONV_STAMP
+        if (stamp_on)
+            for (int i = 0; i < 96; ++i)
+                for (int k = 0; k < 3; ++k) afan_stamps[wave == 0 ? 0 : 1][i][k] = i < chunks * 9 ? st_lds[wave == 0 ? 0 : 1][i][k] : 0ull;
+        __syncthreads();
+#endif
     } else if constexpr (PW > 0) {
         static_assert(GLDS, "producer waves: LDS-DMA only");
         constexpr int LPT = A_ROWS + B_ROWS;
@@ -559,6 +727,27 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // ---- epilogue: fp32 accumulators -> packed bf16 tile [pixel][channel] in LDS -> 16-byte channels-last stores ------
     constexpr int LDC = BN + 8;
     uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
+    // (in-launch BatchNorm backward with the projection shortcut's: that BatchNorm's input tile is staged in LDS behind the output
+    // tile by DMA — no registers, in flight while the accumulators are rounded into C; the barrier below drains it)
+    uint16_t* const Z = lds + BM * LDC;
+    // (not in the 768-thread variant: at its 168-register cap the third sum's state spills in the prefetch phase; launch_gs refuses)
+    constexpr bool BSC_OK = BF && !(THREADS > 512 && BN >= 128);
+    bool have_bsc = false;
+    if constexpr (BF) {
+        have_bsc = BSC_OK && pp.bnf == 2 && pp.bsc.x != nullptr;
+        if (have_bsc) {
+            constexpr int PIECES_Z = BN / 8, NZ = BM * BN * 2 / 1024;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint16_t*>(pp.bsc.x), 0, (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2), 0x00020000);
+            typedef __attribute__((address_space(3))) void* lptr_z;
+            for (int k = wave; k < NZ; k += THREADS / 64) {
+                const int pos = k * 64 + lane, r = pos / PIECES_Z, pcz = pos % PIECES_Z;
+                const int off = out_off[r];
+                const uint32_t vo = (off >= 0 && n0 + pcz * 8 < pp.Co) ? (uint32_t)(off + n0 + pcz * 8) * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(zr, (lptr_z)(Z + k * 512), 16, (int)vo, 0, 0, 0);
+            }
+        }
+    }
     if (!producer)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
@@ -589,7 +778,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool ch_ok = n0 + pc * 8 < pp.Co;      // this thread's 8 output channels exist (Co % 8 == 0)
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
-    const uint16_t* addp = pp.aff ? pp.aff_res : pp.addend;     // the one extra output-shaped operand of either fusion
+    const bool bf_fwd = BF && pp.bnf == 1, bf_bwd = BF && pp.bnf == 2;
+    const uint16_t* addp = bf_fwd ? pp.bnf_res : (pp.aff ? pp.aff_res : pp.addend);     // the one extra output-shaped operand of either fusion
     // Image groups (two half-batches with their own BatchNorm sums): a tile belongs to the half its rows are in; the ONE tile
     // of a launch that holds rows of both (half-batches of any size: the row count need not be a multiple of the tile) walks
     // its rows twice, once per group, each row fetched, stored and summed in the pass of its own group (the whole epilogue,
@@ -629,6 +819,29 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
     double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
+    float s3[8], shz[8];                                          // (BF, projection shortcut's BatchNorm: third sum, its mean)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s3[j] = 0.f;
+        shz[j] = (BF && have_bsc) ? pp.bsc.stats[ch_ok ? n0 + pc * 8 + j : 0] : 0.f;
+    }
+    // (BF: the stored-output mask as bits — the 768-thread variant has no registers to keep the prefetched output tile, the
+    // BatchNorm input tile AND the other branch's gradient through the row loop: 73 scratch accesses in its epilogue otherwise)
+    uint32_t ymask[(EPI_ROWS + 3) / 4];
+#pragma unroll
+    for (int q4 = 0; q4 < (EPI_ROWS + 3) / 4; ++q4) ymask[q4] = 0u;
+    if constexpr (BF) {
+        if (bn_bwd && pp.bny) {
+#pragma unroll
+            for (int q = 0; q < EPI_ROWS; ++q) {
+                const u16x8 yv = __builtin_bit_cast(u16x8, pre_y[q]);
+                uint32_t m = 0u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m |= (bf2f(yv[j]) > 0.f ? 1u : 0u) << j;
+                ymask[q / 4] |= m << (8 * (q % 4));
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
@@ -686,19 +899,30 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(a[j]));
             }
-            *reinterpret_cast<u16x8*>(y_p + go) = v;
+            // (in-launch BatchNorm: the backward never writes the unnormalised gradient; the forward stores its raw tile later,
+            // between its arrival at the grid barrier and its wait there)
+            if (!BF) *reinterpret_cast<u16x8*>(y_p + go) = v;
             if (bn_bwd) {
                 const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
                 u16x8 yv = xv;
-                if (pp.bny) yv = __builtin_bit_cast(u16x8, pre_y[q]);
+                if constexpr (!BF) if (pp.bny) yv = __builtin_bit_cast(u16x8, pre_y[q]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float xf = bf2f(xv[j]);
                     float g = bf2f(v[j]);
-                    if (pp.bny) g = (bf2f(yv[j]) > 0.f) ? g : 0.f;                       // mask from the stored activation
+                    if (pp.bny) g = (BF ? ((ymask[q / 4] >> (8 * (q % 4) + j)) & 1u) != 0u : bf2f(yv[j]) > 0.f) ? g : 0.f;   // mask from the stored activation
                     else if (pp.bn_relu) g = (fmaf(xf, al[j], be[j]) > 0.f) ? g : 0.f;   // mask recomputed exactly as the forward
                     s1[j] += g;
                     s2[j] += g * (xf - sh[j]);
+                    if constexpr (BF) v[j] = f2bf(g);                                    // (exact: g is v[j] or 0)
+                }
+                if constexpr (BF) {     // the masked gradient waits in the tile (this thread's own elements) for the totals
+                    if (bf_bwd) *reinterpret_cast<u16x8*>(C + r * LDC + pc * 8) = v;
+                    if (have_bsc) {
+                        const u16x8 zv = *reinterpret_cast<const u16x8*>(Z + r * BN + pc * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s3[j] += bf2f(v[j]) * (bf2f(zv[j]) - shz[j]);
+                    }
                 }
             } else if (want_stats) {
 #pragma unroll
@@ -710,6 +934,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         }
     }
+    float bf_shift = 0.f;
     if (want_stats) {
         // lanes l, l+PIECES, l+2*PIECES, ... of a wave hold the same 8 columns: butterfly over those, then over waves
 #pragma unroll
@@ -723,6 +948,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         __shared__ float red_static[HL ? 1 : THREADS / 64][2][BN];
         float (*red)[2][BN] = red_static;
         if constexpr (HL > 0) red = reinterpret_cast<float (*)[2][BN]>(lds + ((PF - 1) * BN * BK + HL * BK));
+        __shared__ float red3[BF ? THREADS / 64 : 1][BF ? BN : 1];      // the projection BatchNorm's third sum, per wave
+        if constexpr (BF && HL > 0) {                                    // (behind the staged Z tile, which the halo-form spot overlaps)
+            static_assert((size_t)(BM * LDC + BM * BN) * 2 + (size_t)(THREADS / 64) * 2 * BN * 4 <=
+                          (size_t)(PF - 1) * BN * BK * 2 + (size_t)2 * HL * BK * 2 + 1024, "in-launch BatchNorm: LDS behind the two tiles");
+            red = reinterpret_cast<float (*)[2][BN]>(lds + (BM * LDC + BM * BN));
+        }
+        if constexpr (BF) {
+            if (have_bsc) {
+#pragma unroll
+                for (int o = PIECES; o < 64; o <<= 1)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s3[j] += __shfl_xor(s3[j], o, 64);
+                if (lane < PIECES)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) red3[wave][lane * 8 + j] = s3[j];
+            }
+        }
         if (lane < PIECES) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -744,6 +986,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 unsafeAtomicAdd(dst + pp.Co + n0 + tid, (double)b);
                 if (!bn_bwd && grp_first && (blockIdx.z == 0 || pp.multi))   // snapshot of the shift for the BN that consumes the sums
                     reinterpret_cast<float*>(acc_blk + (int64_t)2 * pp.acc_ns * pp.Co)[n0 + tid] = shift_p ? shift_p[n0 + tid] : 0.f;
+                if constexpr (BF) {
+                    bf_shift = shift_p ? shift_p[n0 + tid] : 0.f;   // read BEFORE the barrier: tile 0 updates the running mean behind it
+                    if (have_bsc) {
+                        float b3 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < THREADS / 64; ++w) b3 += red3[w][tid];
+                        double* dz = pp.bsc.acc + (int64_t)((blockIdx.y + blockIdx.z) & (pp.acc_ns - 1)) * 2 * pp.Co;
+                        unsafeAtomicAdd(dz + n0 + tid, (double)a);
+                        unsafeAtomicAdd(dz + pp.Co + n0 + tid, (double)b3);
+                    }
+                }
             } else {
                 const int64_t G = (int64_t)gridDim.y * gridDim.z, slot = (int64_t)blockIdx.z * gridDim.y + blockIdx.y;
                 pp.stats[((int64_t)0 * pp.Co + n0 + tid) * G + slot] = a;
@@ -751,6 +1004,183 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         }
         if (n_pass > 1) __syncthreads();         // the second pass reuses the per-wave partial sums' LDS
+        if constexpr (BF) {
+            // ---- the BatchNorm itself, inside this launch: every workgroup's sums are in the accumulators once all have passed the
+            // barrier; each then derives the coefficients of its own BN channels from the totals (the expressions of apply_acc_kernel /
+            // apply_acc_dual_kernel / bwd_apply_acc_kernel, term for term) and finishes its tile from LDS.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's accumulator atomics have been performed
+            __syncthreads();
+            const unsigned wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            unsigned bar_gen = 0;
+            if (tid == 0) bar_gen = grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * gridDim.z);
+            if (bf_fwd) {                                             // the raw tile leaves while the other workgroups arrive
+#pragma unroll
+                for (int q = 0; q < EPI_ROWS; ++q) {
+                    const int r = pr + q * ROWS_PER_PASS;
+                    const int off = epi_on ? out_off[r] : -1;
+                    if (off >= 0 && ch_ok)
+                        *reinterpret_cast<u16x8*>(y_p + (int64_t)off + n0 + pc * 8) = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+                }
+            }
+            if (tid == 0) grid_wait(pp.bar, wg_id, bar_gen);
+            __syncthreads();
+            float* cf = &red[0][0][0];                                // [4][BN] coefficients of the second pass (the partial sums are consumed)
+            const bool have_sc = bf_fwd && pp.bnf_sc.acc != nullptr;
+            if (tid < BN && n0 + tid < pp.Co) {
+                const int c = n0 + tid, NSl = pp.acc_ns;
+                const bool pub = blockIdx.y == 0 && blockIdx.z == 0;  // the row tile that publishes statistics / parameter gradients
+                double av[16], bv[16];
+                const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(acc_blk, 0, (int)(2 * NSl * pp.Co * 8), 0x00020000);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {                        // fold_slots' order; all requests in flight together
+                    av[s] = s < NSl ? ld_total(accr, ((2 * s) * pp.Co + c) * 8) : 0.0;
+                    bv[s] = s < NSl ? ld_total(accr, ((2 * s + 1) * pp.Co + c) * 8) : 0.0;
+                }
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    a += av[s];
+                    b += bv[s];
+                }
+                if (bf_fwd) {
+                    const float wv = pp.bnf_w ? pp.bnf_w[c] : 1.f, bsv = pp.bnf_b ? pp.bnf_b[c] : 0.f;
+                    const double dm = a * pp.bnf_inv_m;
+                    const double m2 = fmax(b - a * dm, 0.0);
+                    const float mean = (float)((double)bf_shift + dm);
+                    const float varb = (float)(m2 * pp.bnf_inv_m);
+                    const float is = 1.0f / sqrtf(varb + pp.bnf_eps);
+                    const float alpha = is * wv, beta = fmaf(-mean, alpha, bsv);
+                    cf[tid] = alpha;
+                    cf[BN + tid] = beta;
+                    if (pub) {
+                        pp.bnf_stats[c] = mean;
+                        pp.bnf_stats[pp.Co + c] = is;
+                        pp.bnf_stats[2 * pp.Co + c] = alpha;
+                        pp.bnf_stats[3 * pp.Co + c] = beta;
+                        if (pp.bnf_rmean)
+                            for (int u = 0; u < pp.bnf_updates; ++u) {
+                                pp.bnf_rmean[c] = (1.0f - pp.bnf_mom) * pp.bnf_rmean[c] + pp.bnf_mom * mean;
+                                pp.bnf_rvar[c] = (1.0f - pp.bnf_mom) * pp.bnf_rvar[c] + pp.bnf_mom * (varb * pp.bnf_unbias);
+                            }
+                        if (c == 0 && pp.bnf_nbt) *pp.bnf_nbt += pp.bnf_updates;
+                    }
+                    if (have_sc) {                                    // the projection shortcut's BatchNorm: sums of an earlier launch
+                        const ConvP::Sc& P = pp.bnf_sc;
+                        double a2 = 0.0, b2 = 0.0;
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            av[s] = s < NSl ? P.acc[(int64_t)(2 * s) * pp.Co + c] : 0.0;
+                            bv[s] = s < NSl ? P.acc[(int64_t)(2 * s + 1) * pp.Co + c] : 0.0;
+                        }
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            a2 += av[s];
+                            b2 += bv[s];
+                        }
+                        const float w2 = P.w ? P.w[c] : 1.f, bs2 = P.b ? P.b[c] : 0.f;
+                        const float sh2 = reinterpret_cast<const float*>(P.acc + (int64_t)2 * NSl * pp.Co)[c];
+                        const double dm2 = a2 * pp.bnf_inv_m;
+                        const double m22 = fmax(b2 - a2 * dm2, 0.0);
+                        const float mean2 = (float)((double)sh2 + dm2);
+                        const float var2 = (float)(m22 * pp.bnf_inv_m);
+                        const float is2 = 1.0f / sqrtf(var2 + P.eps);
+                        const float alpha2 = is2 * w2, beta2 = fmaf(-mean2, alpha2, bs2);
+                        cf[2 * BN + tid] = alpha2;
+                        cf[3 * BN + tid] = beta2;
+                        if (pub) {
+                            P.stats[c] = mean2;
+                            P.stats[pp.Co + c] = is2;
+                            P.stats[2 * pp.Co + c] = alpha2;
+                            P.stats[3 * pp.Co + c] = beta2;
+                            if (P.rmean)
+                                for (int u = 0; u < pp.bnf_updates; ++u) {
+                                    P.rmean[c] = (1.0f - P.mom) * P.rmean[c] + P.mom * mean2;
+                                    P.rvar[c] = (1.0f - P.mom) * P.rvar[c] + P.mom * (var2 * pp.bnf_unbias);
+                                }
+                            if (c == 0 && P.nbt) *P.nbt += pp.bnf_updates;
+                        }
+                    }
+                } else {
+                    const float is = bn_stats[pp.Co + c], alpha = bn_stats[2 * pp.Co + c];
+                    const float sum_g = (float)a;
+                    const float sum_gx = (float)b * is;
+                    cf[tid] = -alpha * is * (float)((double)sum_gx * pp.bnf_inv_m);
+                    cf[BN + tid] = -alpha * (float)((double)sum_g * pp.bnf_inv_m);
+                    if (pub) {
+                        if (pp.bnf_db) pp.bnf_db[c] = pp.bnf_accum ? pp.bnf_db[c] + sum_g : sum_g;
+                        if (pp.bnf_dw) pp.bnf_dw[c] = pp.bnf_accum ? pp.bnf_dw[c] + sum_gx : sum_gx;
+                    }
+                    if (have_bsc) {
+                        const __amdgpu_buffer_rsrc_t zr2 = __builtin_amdgcn_make_buffer_rsrc(pp.bsc.acc, 0, (int)(2 * NSl * pp.Co * 8), 0x00020000);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            av[s] = s < NSl ? ld_total(zr2, ((2 * s) * pp.Co + c) * 8) : 0.0;
+                            bv[s] = s < NSl ? ld_total(zr2, ((2 * s + 1) * pp.Co + c) * 8) : 0.0;
+                        }
+                        double a2 = 0.0, b2 = 0.0;
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) {
+                            a2 += av[s];
+                            b2 += bv[s];
+                        }
+                        const float is2 = pp.bsc.stats[pp.Co + c], alpha2 = pp.bsc.stats[2 * pp.Co + c];
+                        const float sg2 = (float)a2;
+                        const float sgx2 = (float)b2 * is2;
+                        cf[2 * BN + tid] = -alpha2 * is2 * (float)((double)sgx2 * pp.bnf_inv_m);
+                        cf[3 * BN + tid] = -alpha2 * (float)((double)sg2 * pp.bnf_inv_m);
+                        if (pub) {
+                            if (pp.bsc.db) pp.bsc.db[c] = pp.bnf_accum ? pp.bsc.db[c] + sg2 : sg2;
+                            if (pp.bsc.dw) pp.bsc.dw[c] = pp.bnf_accum ? pp.bsc.dw[c] + sgx2 : sgx2;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            float k0[8], k1[8], k2[8], k3[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                k0[j] = cf[pc * 8 + j];
+                k1[j] = cf[BN + pc * 8 + j];
+                k2[j] = (have_sc || have_bsc) ? cf[2 * BN + pc * 8 + j] : 0.f;
+                k3[j] = (have_sc || have_bsc) ? cf[3 * BN + pc * 8 + j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < EPI_ROWS; ++q) {
+                const int r = pr + q * ROWS_PER_PASS;
+                const int off = epi_on ? out_off[r] : -1;
+                if (off >= 0 && ch_ok) {
+                    u16x8 v = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+                    const int64_t go = (int64_t)off + n0 + pc * 8;
+                    if (bf_fwd) {
+                        const u16x8 rv = __builtin_bit_cast(u16x8, pre_a[q]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float t = fmaf(bf2f(v[j]), k0[j], k1[j]);
+                            if (have_sc) t = t + fmaf(bf2f(rv[j]), k2[j], k3[j]);
+                            else if (pp.bnf_res) t += bf2f(rv[j]);
+                            if (pp.bnf_relu) t = (t > 0.f) ? t : ((t != t) ? t : 0.f);
+                            v[j] = f2bf(t);
+                        }
+                        *reinterpret_cast<u16x8*>(pp.y2 + go) = v;
+                    } else {
+                        const u16x8 xv = __builtin_bit_cast(u16x8, pre_x[q]);
+                        u16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            o[j] = f2bf(fmaf(bf2f(v[j]), al[j], fmaf(bf2f(xv[j]) - sh[j], k0[j], k1[j])));
+                        *reinterpret_cast<u16x8*>(y_p + go) = o;
+                        if (pp.y2) *reinterpret_cast<u16x8*>(pp.y2 + go) = v;
+                        if (have_bsc) {
+                            const u16x8 zv = *reinterpret_cast<const u16x8*>(Z + r * BN + pc * 8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                o[j] = f2bf(fmaf(bf2f(v[j]), pp.bsc.stats[2 * pp.Co + n0 + pc * 8 + j], fmaf(bf2f(zv[j]) - shz[j], k2[j], k3[j])));
+                            *reinterpret_cast<u16x8*>(pp.bsc.y3 + go) = o;
+                        }
+                    }
+                }
+            }
+        }
     }
     }   // group passes
 }
@@ -758,13 +1188,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 // The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward
 // launches from the input-gradient launches: bench.py's roofline names whichever is the larger and profiles/ can be
 // checked against it symbol by symbol.
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_fwd_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>(pp);
 }
-template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false>
+template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + PW)) void conv_igemm_dgrad_kernel(const ConvP pp) {
-    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS>(pp);
+    conv_igemm_body<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>(pp);
 }
 
 static int64_t max_rows(const ConvP& p) {
@@ -776,7 +1206,7 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
-template <int BM, int BN, int PF, int WM, int WN, int PW, int FBT, int HL, bool GS>
+template <int BM, int BN, int PF, int WM, int WN, int PW, int FBT, int HL, bool GS, bool BF = false>
 int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
@@ -788,16 +1218,33 @@ int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
     constexpr size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS>,
+            e = hipFuncSetAttribute((const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS><<<grid, THREADS, lds, st>>>(p);
-    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS><<<grid, THREADS, lds, st>>>(p);
+    if constexpr (BF) {
+        // the in-launch BatchNorm's grid barrier needs EVERY workgroup of the launch resident at once: CUs x the occupancy of
+        // this instantiation (the smaller of the two entry points'), asked once; a launch beyond it is refused before anything runs
+        static int max_resident = -1;
+        if (max_resident < 0) {
+            int dev = 0, cus = 0, of = 0, od = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, (const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>, THREADS, lds) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&od, (const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>, THREADS, lds) != hipSuccess)
+                return AFAN_ESHAPE;
+            max_resident = cus * (of < od ? of : od);
+        }
+        if (p.bsc.x && THREADS > 512 && BN >= 128) return AFAN_ESHAPE;   // (no projection-BatchNorm form in the 768-thread x 128-column variant)
+        if ((int64_t)grid.x * grid.y * grid.z > max_resident || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
+            p.n_classes != 1)
+            return AFAN_ESHAPE;
+    }
+    if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
+    else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }
@@ -873,6 +1320,7 @@ static bool halo_ok(const ConvP& p, int bm, int cap = HALO_PIXELS) {
     return ok;
 }
 
+#ifndef AFAN_CONV_BNF_TU      // (afan_conv_bnf.hip includes everything above for its own instantiations)
 int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
     // staging variant: 3 = LDS-DMA (global_load_lds), 1 = global -> VGPR -> LDS, 2 = same with two register sets
     static const int mode = env_int("AFAN_CONV_MODE", 3);
@@ -974,7 +1422,8 @@ int check_dims(int64_t n, int64_t hi, int64_t wi, int64_t ci, int64_t co, int k,
 static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* dx, int64_t n, int64_t hi, int64_t wi,
                       int64_t ci, int64_t co, int k, int stride, int dilation, const void* addend, const void* bn_x,
                       const float* bn_stats, int bn_relu, const void* bn_y, float* bn_partials, double* bn_acc, int groups,
-                      afan_stream_t stream, const float* aff_alpha = nullptr, const void* aff_act = nullptr, void* dx2 = nullptr) {
+                      afan_stream_t stream, const float* aff_alpha = nullptr, const void* aff_act = nullptr, void* dx2 = nullptr,
+                      const ConvP* bnf = nullptr) {
     int e = check_dims(n, hi, wi, co, ci, k, stride, dilation);   // reduction runs over co here
     if (e) return e;
     if (!dy || !wt || !dx) return AFAN_ENULL;
@@ -1017,6 +1466,13 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
         p.stats = bn_partials; p.acc = bn_acc; p.acc_ns = afan_nhwc::acc_slot_count(ci);
         p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
+    if (bnf) {      // the BatchNorm backward itself behind a grid barrier in this launch (afan_conv_dgrad_bn_nhwc_bf16)
+        if (!bn_acc || stride != 1 || k != 3 || dilation != 1 || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
+        if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;          // (that kernel has no such epilogue)
+        p.bnf = 2; p.bar = bnf->bar; p.y2 = bnf->y2; p.bnf_dw = bnf->bnf_dw; p.bnf_db = bnf->bnf_db; p.bnf_accum = bnf->bnf_accum;
+        p.bsc = bnf->bsc;
+        p.bnf_inv_m = 1.0 / ((double)n * hi * wi);
+    }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
     AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes + (dy_sc ? 2.0 * ((double)n * ho * wo * co + (double)co * ci) : 0.0),
                     2.0 * (double)n * ho * wo * co * (k * k + (dy_sc ? 1 : 0)) * ci, st);
@@ -1038,6 +1494,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
                 const int t = r * k + s;
                 c0.dh[t] = (pad - r) * dilation; c0.dw[t] = (pad - s) * dilation; c0.wofs[t] = (int)(t * co);
             }
+        if (bnf) return small_eligible(p) ? AFAN_ESHAPE : dispatch_bnf(p, st, true);
         if (small_eligible(p)) return (p.aff || !small_groups_ok(p)) ? AFAN_ESHAPE : small_launch(p, st);
         if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;   // (small shape asked for the partial-slab sums)
         return dispatch(p, st, true);
@@ -1081,6 +1538,13 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
 }  // namespace
 
 extern "C" {
+
+#ifdef AFAN_CONV_STAMP
+// diagnostic build only: the last halo-form launch's per-tap stamps, [2 roles][96 taps][3] cycle counters
+int afan_conv_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(afan_stamps), sizeof(unsigned long long) * 2 * 96 * 3);
+}
+#endif
 
 int afan_conv_supported(int64_t ci, int64_t co, int k, int stride) {
     if (ci == 3) return afan_stem::eligible(1, 1, 32, ci, co, k, stride) ? 1 : 0;   // image stem (forward only; width % 32 == 0)
@@ -1325,6 +1789,99 @@ int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* 
     return dgrad_impl(dy, dy_sc, wt10, dx, n, hi, wi, ci, co, 3, 2, 1, nullptr, bn_x, bn_stats, bn_relu, bn_y, bn_partials,
                       bn_acc, 1, stream);
 }
+// ---- round 5: convolution + train-mode BatchNorm in ONE launch (ConvP::bnf; kernels in afan_conv_bnf.hip) -------------------------
+// The BatchNorm's batch statistics need every tile of the launch, so the epilogue meets the launch's other workgroups at a grid-wide
+// barrier between its sums and its second pass; only launches whose workgroups are all resident take it (3x3 / stride 1 on whole
+// 64-channel chunks in the LDS-resident halo form, <= one workgroup per CU: the ResNet tails at batch 256).  AFAN_ESHAPE = "not this
+// launch": nothing has run, the caller issues the two launches it replaces (same bits).  `barrier`: afan_grid_barrier_bytes() of
+// device memory, zeroed once, shared by every such launch of one stream; word afan_grid_barrier_error_word() turns non-zero if a
+// barrier's bounded spin gave up (workgroups not co-resident: another process's kernels on the GPU) — results are then invalid.
+int afan_grid_barrier_bytes(void) { return 2048; }
+int afan_grid_barrier_error_word(void) { return (int)(offsetof(GridBar, err) / sizeof(unsigned)); }
+
+// y_raw = conv(x, w) (3x3, stride 1, padding 1) AND y_act = [relu](bn(y_raw) [+ residual]) with the batch statistics of y_raw —
+// afan_conv_fwd_nhwc_bf16(stats_acc) followed by afan_bn_train_forward_acc (or, sc_raw != NULL, afan_bn_train_forward_acc_dual:
+// y_act = relu(bn(y_raw) + bn_sc(sc_raw)), the projection shortcut's BatchNorm from ITS accumulators sc_acc, filled by an earlier
+// launch), term for term.  acc: this launch's accumulator block (zeroed by the caller); shift: the running mean (moments are taken
+// around it).  stats [4][co] out; running buffers updated afan_bn_set_running_updates() times like the stand-alone launches.
+int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* y_act, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                               int64_t co, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
+                               float momentum, float* stats, float* running_mean, float* running_var, int64_t* num_batches,
+                               const void* residual, int relu, const void* sc_raw, const double* sc_acc, const float* sc_weight,
+                               const float* sc_bias, float sc_eps, float sc_momentum, float* sc_stats, float* sc_running_mean,
+                               float* sc_running_var, int64_t* sc_num_batches, void* barrier, afan_stream_t stream) {
+    const int k = 3, stride = 1, pad = 1;
+    int e = check_dims(n, hi, wi, ci, co, k, stride, 1);
+    if (e) return e;
+    if (!x || !w || !y_raw || !y_act || !acc || !stats || !barrier) return AFAN_ENULL;
+    if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y_raw, 16) || !aligned(y_act, 16) || !aligned(acc, 16) || !aligned(barrier, 64) ||
+        (residual && !aligned(residual, 16)) || (sc_raw && !aligned(sc_raw, 16)))
+        return AFAN_EALIGN;
+    if (sc_raw && (residual || !sc_acc || !sc_stats || !relu)) return AFAN_ESHAPE;
+    if (ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
+    ConvP p{};
+    p.max_pad = 1;
+    p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y_raw; p.y2 = (uint16_t*)y_act;
+    p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
+    p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)co;
+    p.in_s = 1; p.out_s = 1; p.w_row_stride = (int)(k * k * ci); p.n_classes = 1;
+    p.shift = shift; p.acc = acc; p.acc_ns = afan_nhwc::acc_slot_count(co);
+    p.groups = 1;
+    ConvClass& c0 = p.cls[0];
+    c0.Hg = p.Ho; c0.Wg = p.Wo; c0.T = 9;
+    for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 3; ++q) {
+            const int t = r * 3 + q;
+            c0.dh[t] = r - pad; c0.dw[t] = q - pad; c0.wofs[t] = (int)(t * ci);
+        }
+    const int64_t M = n * hi * wi;
+    const int pending = afan_nhwc::set_running_updates(1);
+    afan_nhwc::set_running_updates(pending);
+    p.bnf = 1; p.bar = (unsigned*)barrier;
+    p.bnf_w = bn_weight; p.bnf_b = bn_bias; p.bnf_eps = eps; p.bnf_mom = momentum;
+    p.bnf_rmean = running_mean; p.bnf_rvar = running_var; p.bnf_nbt = num_batches; p.bnf_updates = pending;
+    p.bnf_stats = stats; p.bnf_relu = relu ? 1 : 0;
+    p.bnf_res = (const uint16_t*)(sc_raw ? sc_raw : residual);
+    p.bnf_inv_m = 1.0 / (double)M;
+    p.bnf_unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+    if (sc_raw) {
+        p.bnf_sc.acc = sc_acc; p.bnf_sc.w = sc_weight; p.bnf_sc.b = sc_bias; p.bnf_sc.eps = sc_eps; p.bnf_sc.mom = sc_momentum;
+        p.bnf_sc.rmean = sc_running_mean; p.bnf_sc.rvar = sc_running_var; p.bnf_sc.nbt = sc_num_batches; p.bnf_sc.stats = sc_stats;
+    }
+    if (small_eligible(p) || afan_c64::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * ((double)M * co * (p.bnf_res ? 3 : 2) + (double)M * ci + (double)co * 9 * ci),
+                    2.0 * (double)M * co * 9 * ci, st);
+    return dispatch_bnf(p, st, false);
+}
+
+// dx = the gradient entering the INPUT of the BatchNorm in front of this convolution (afan_conv_dgrad_nhwc_bf16 with its bn_x /
+// bn_stats / bn_acc sums, followed by afan_bn_backward_acc on its result: the same bits), dres (optional) = that backward's second
+// output, the ReLU-masked gradient (a residual block's shortcut share).  The unnormalised input gradient is never written.
+// dweight / dbias [ci]: the BatchNorm's parameter gradients (NULL: not wanted), added to when accumulate != 0.
+// sc_x != NULL (block-output form only): the producing block's projection shortcut's BatchNorm (no ReLU; input sc_x, statistics
+// sc_stats [4][ci], zeroed accumulators sc_acc) receives the masked gradient too — d_sc = the gradient entering ITS input
+// (afan_bn_backward_acc(dres, sc_x, relu = 0)'s result up to the summation order of its two sums), sc_dweight / sc_dbias optional.
+int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
+                                 int64_t co, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
+                                 double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
+                                 double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream) {
+    if (!barrier || !bn_acc) return AFAN_ENULL;
+    if (!aligned(barrier, 64) || (dres && !aligned(dres, 16))) return AFAN_EALIGN;
+    if (ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
+    ConvP b{};
+    b.bar = (unsigned*)barrier; b.y2 = (uint16_t*)dres; b.bnf_dw = dweight; b.bnf_db = dbias; b.bnf_accum = accumulate;
+    if (sc_x) {
+        if (!sc_stats || !sc_acc || !d_sc) return AFAN_ENULL;
+        if (!aligned(sc_x, 16) || !aligned(d_sc, 16) || !aligned(sc_acc, 16)) return AFAN_EALIGN;
+        if (!bn_y) return AFAN_ESHAPE;                      // (the block-output form: the masked gradient is what the projection's BatchNorm receives)
+        b.bsc.x = (const uint16_t*)sc_x; b.bsc.stats = sc_stats; b.bsc.acc = sc_acc; b.bsc.y3 = (uint16_t*)d_sc;
+        b.bsc.dw = sc_dweight; b.bsc.db = sc_dbias;
+    }
+    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, 3, 1, 1, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
+                      nullptr, nullptr, nullptr, &b);
+}
+
 // ---- batched KRSC -> CRSK transpose of every convolution weight (dgrad operands), once per SGD step -------------------
 // desc[i] = {src_off, dst_off, K, RS, C, first_tile, dst_RS, rs0}; tiles of 64(k) x 64(c) at fixed rs,
 // ceil(K/64)*RS*ceil(C/64) of them per tensor (partial tiles are masked); K % 8 == 0, C % 8 == 0.  The destination rows hold
@@ -1381,3 +1938,4 @@ int afan_transpose_weights(const void* src_arena, void* dst_arena, const int64_t
 }
 
 }  // extern "C"
+#endif  // AFAN_CONV_BNF_TU

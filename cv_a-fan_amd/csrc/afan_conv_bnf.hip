@@ -1,0 +1,41 @@
+// The tiled convolution's instantiations with a train-mode BatchNorm applied INSIDE the launch (ConvP::bnf, conv_igemm_body<..., BF>):
+// forward  — raw output + batch sums -> grid barrier -> totals -> normalised (+ residual / projection BatchNorm) (+ ReLU) output;
+// backward — input gradient (+ other branch) + the BatchNorm backward's two sums -> grid barrier -> totals -> the gradient entering
+//            the BatchNorm's input (and the masked gradient for the shortcut).
+// Reference chain: Classification/resnet_s.py:72-77 (conv - bn - relu - conv - bn - (+shortcut) - relu), PGD's K tail passes
+// (attack_algo.py:48-56).  Round 4 ran each BatchNorm as its own 8-16 us launch behind the convolution that had already summed
+// its moments: ~150 launches, 2.2 ms of an 8.6 ms step (profiles/r04f_r18_kernel_stats.csv).  A separate translation unit so that
+// the two sets of instantiations compile in parallel; the kernel body is afan_conv.hip's (included below, up to its dispatch).
+#define AFAN_CONV_BNF_TU 1
+#include "afan_conv.hip"
+
+}  // namespace   (afan_conv.hip's anonymous namespace: its tail, which closes it, is not compiled in this unit)
+
+namespace afan_conv {
+
+// dispatch()'s halo-form choices, with the BF instantiations; any other launch: AFAN_ESHAPE (the caller issues two launches)
+int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
+    static const int halo = env_int("AFAN_CONV_HALO", 1);
+    if (!halo || p.Co % 128 != 0 || p.n_classes != 1 || p.stats || !p.acc || p.groups != 1) return AFAN_ESHAPE;
+    const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
+    const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
+    constexpr int deep_max = 384;
+    if (bm == 128 && wgs > deep_max && wgs <= 2 * deep_max && halo_ok(p, 256, HALO_PIXELS_256))
+        return launch_gs<256, 128, 5, 4, 2, 4, 2, HALO_PIXELS_256, false, true>(p, st, dgrad);
+    if (bm == 64 && p.Ci >= 256) {
+        const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 127) / 128) * p.n_classes;
+        if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 128))
+            return launch_gs<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad);
+    }
+    if (bm == 128 && wgs <= deep_max && p.Ci >= 256) {
+        const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 255) / 256) * p.n_classes;
+        if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 256, HALO_PIXELS_256N))
+            return launch_gs<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad);
+    }
+    if (wgs <= deep_max && halo_ok(p, bm))
+        return bm == 64 ? launch_gs<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad)
+                        : launch_gs<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad);
+    return AFAN_ESHAPE;
+}
+
+}  // namespace afan_conv

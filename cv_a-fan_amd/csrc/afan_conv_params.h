@@ -58,7 +58,54 @@ struct ConvP {
     int64_t shift_off[4];
     int w_rs[4];                 //   and its weight rows are w_rs[z] elements apart (problems may differ in kernel size)
     ConvClass cls[4];
+    // ---- round 5: the BatchNorm behind (forward) / in front of (backward) this convolution applied INSIDE the launch.  Batch
+    // statistics need every tile of the launch, so the epilogue meets all other workgroups at a grid-wide barrier between its
+    // sums and its stores: only for launches whose workgroups are all resident (dispatch_bnf checks), `acc` sums only.
+    int bnf;                     // 0: off
+                                 // 1 (forward):  y = the raw convolution output as always; after the barrier y2 = [relu](alpha*y + beta
+                                 //    [+ bnf_res] [+ alpha_s*bnf_res + beta_s: the projection shortcut's BatchNorm, bnf_sc != NULL]) with the
+                                 //    coefficients of apply_acc_kernel / apply_acc_dual_kernel, term for term
+                                 // 2 (backward): y = the gradient entering the BatchNorm's INPUT (bwd_apply_acc_kernel's dx), y2 (optional) =
+                                 //    the masked gradient (its dres); the unnormalised gradient is never written
+    unsigned* bar;               // afan_grid_barrier_bytes() of zero-initialised device memory, reused by every launch of a stream
+    const float* bnf_w;          // forward: BatchNorm weight / bias (NULL = 1 / 0), eps, momentum, running buffers, number of
+    const float* bnf_b;          //   running-statistics updates this pass stands for, stats out [4][Co] = mean | invstd | alpha | beta
+    float bnf_eps, bnf_mom;
+    float* bnf_rmean;
+    float* bnf_rvar;
+    int64_t* bnf_nbt;
+    int bnf_updates;
+    float* bnf_stats;
+    const uint16_t* bnf_res;     // forward: residual (y's shape) added after the affine, or the projection's raw output (bnf_sc)
+    int bnf_relu;
+    double bnf_inv_m;            // 1 / (N * Ho * Wo)
+    float bnf_unbias;
+    struct Sc {                  // forward, projection shortcut (Classification/resnet_s.py option B): its BatchNorm, sums complete in
+        const double* acc;       //   acc (an EARLIER launch filled them, shift snapshot behind the slots)
+        const float* w;
+        const float* b;
+        float eps, mom;
+        float* rmean;
+        float* rvar;
+        int64_t* nbt;
+        float* stats;
+    } bnf_sc;
+    float* bnf_dw;               // backward: BatchNorm weight / bias gradients [Co] (NULL: not wanted), accumulate flag
+    float* bnf_db;
+    int bnf_accum;
+    struct BSc {                 // backward, block-output form (y2 = the masked gradient m): the producing block's PROJECTION shortcut's
+        const uint16_t* x;       //   BatchNorm (no ReLU) receives m as well — its whole backward here too: x = that BatchNorm's input (the
+        const float* stats;      //   projection's raw output, y's shape; staged in LDS by DMA), stats its [4][Co] block, acc a second zeroed
+        double* acc;             //   accumulator block (sum m, sum m*(x - mean)), y3 = the gradient entering its input
+        uint16_t* y3;            //   (bwd_apply_acc_kernel<RELU = false>'s expression), dw / db its parameter gradients
+        float* dw;
+        float* db;
+    } bsc;
 };
+
+// afan_conv_bnf.hip: the tiled kernel's instantiations with the in-launch BatchNorm (ConvP::bnf != 0); AFAN_ESHAPE when no such
+// instantiation takes the problem or its workgroups would not all be resident (nothing is launched then)
+int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad);
 
 
 // small-channel kernel (afan_conv_small.hip): reduction channels in {16, 32, 64}, output channels a multiple of 16, at

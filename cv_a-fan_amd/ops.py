@@ -18,7 +18,7 @@ _tls = threading.local()
 # entry points' logs use it to show which path a configuration really takes)
 # ("vendor_conv" stays in the table as the invariant the tests assert: the package holds no vendor convolution any more;
 # "conv_general" counts passes of the fp32-arithmetic general kernels, afan_conv_f32.hip)
-CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "conv_general": 0, "vendor_conv": 0}
+CALLS = {"conv_fwd": 0, "conv_dgrad": 0, "conv_wgrad": 0, "conv_general": 0, "vendor_conv": 0, "conv_bn_fused": 0}
 
 
 def _need(t, name, dtype=None):
@@ -822,6 +822,175 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
                                       _ptr(st.partials) if st else None, _ptr(stats_shift) if st else None,
                                       _ptr(st.acc) if st else None, int(groups), _stream(x)), "afan_conv_fwd_nhwc_bf16")
     return (y, st) if want_stats else y
+
+
+# ---- convolution + train-mode BatchNorm in one launch (afan_conv_fwd_bn_nhwc_bf16 / afan_conv_dgrad_bn_nhwc_bf16) ----------------
+# The launch's workgroups meet at a grid-wide barrier, so they must all be resident: ONE such launch at a time per device — never
+# from two streams, never from two processes sharing a GPU (AFAN_GRID_BN=0, or grid_bn(False) around the region, e.g. while an RCCL
+# exchange is in flight on another stream: its resident kernels would make the barrier wait for the exchange to end).
+GRID_BN = os.environ.get("AFAN_GRID_BN", "1") != "0" and not os.environ.get("AFAN_BENCH_ONE_DEVICE")
+_grid_bars = {}
+_grid_refused = set()
+
+
+class grid_bn:
+    """Context: switch the in-launch BatchNorm on / off for the launches issued inside (by this process)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global GRID_BN
+        self.old, GRID_BN = GRID_BN, self.on and GRID_BN_ALLOWED
+        return self
+
+    def __exit__(self, *exc):
+        global GRID_BN
+        GRID_BN = self.old
+        return False
+
+
+GRID_BN_ALLOWED = GRID_BN
+
+
+def _grid_barrier(device):
+    b = _grid_bars.get(device.index)
+    if b is None:
+        b = _grid_bars[device.index] = torch.zeros(int(_lib.load().afan_grid_barrier_bytes()) // 4, dtype=torch.int32, device=device)
+    return b
+
+
+def grid_barrier_error(device=None):
+    """True if a grid barrier's bounded spin gave up since the last call (synchronises; results since then are invalid).  Resets."""
+    bad = False
+    for idx, b in _grid_bars.items():
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        w = int(_lib.load().afan_grid_barrier_error_word())
+        if int(b[w].item()) != 0:
+            bad = True
+            b.zero_()
+    return bad
+
+
+def _acc_untake(device, blk):
+    a = _acc_arena(device)
+    if a.off >= blk.numel() and a.buf.data_ptr() + 8 * (a.off - blk.numel()) == blk.data_ptr():
+        a.off -= blk.numel()
+
+
+def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None):
+    """(raw, act, stats) = conv3x3(x, w) with the train-mode BatchNorm `bn` (module: weight, bias, eps, running buffers) behind it,
+    + residual, + ReLU, in ONE launch; sc = (raw_sc, bn_sc, ConvStats_sc, momentum_sc): act = relu(bn(raw) + bn_sc(raw_sc)) and a
+    fourth result stats_sc — the bits of conv_fwd(want_stats) + bn_train_forward[_dual].  None when the launch is not eligible
+    (nothing has run: the caller issues the two launches)."""
+    if not (GRID_BN and x.is_cuda and BN_ACC):
+        return None
+    n, ci, hi, wi = x.shape
+    co, ci2, k, k2 = w.shape
+    key = ("f", n, ci, hi, wi, co, x.device.index)
+    if k != 3 or k2 != 3 or ci2 != ci or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co):
+        return None
+    lib = _lib.load()
+    _cl4(x, "x"), _cl4(w, "w")
+    cl = torch.channels_last
+    y = torch.empty((n, co, hi, wi), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    a = torch.empty((n, co, hi, wi), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    stats = torch.empty((2, 4, co) if sc is not None else (4, co), dtype=torch.float32, device=x.device)
+    st_a = stats[0] if sc is not None else stats
+    acc = acc_take(x.device, co)
+    if residual is not None:
+        _cl4(residual, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("residual must have the output's shape")
+    scp = [None] * 10
+    if sc is not None:
+        raw_sc, bsc, stc, mom_sc = sc
+        _cl4(raw_sc, "raw_sc")
+        if raw_sc.shape != y.shape or stc.acc is None or residual is not None or not relu:
+            raise ValueError("projection form: same-shape raw_sc with accumulator sums, no residual, ReLU")
+        scp = [_ptr(raw_sc), _ptr(stc.acc), _ptr(bsc.weight), _ptr(bsc.bias), float(bsc.eps), float(mom_sc), _ptr(stats[1]),
+               _ptr(bsc.running_mean), _ptr(bsc.running_var), _ptr(bsc.num_batches_tracked)]
+    else:
+        scp[4] = scp[5] = 0.0
+    rc = lib.afan_conv_fwd_bn_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), _ptr(a), n, hi, wi, ci, co, _ptr(acc), _ptr(bn.running_mean),
+                                        _ptr(bn.weight), _ptr(bn.bias), float(bn.eps), float(momentum), _ptr(st_a),
+                                        _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked), _ptr(residual),
+                                        int(bool(relu)), *scp, _ptr(_grid_barrier(x.device)), _stream(x))
+    if rc == -3:                                # AFAN_ESHAPE: not this launch — remembered per shape
+        _grid_refused.add(key)
+        _acc_untake(x.device, acc)
+        return None
+    check(rc, "afan_conv_fwd_bn_nhwc_bf16")
+    CALLS["conv_fwd"] += 1
+    CALLS["conv_bn_fused"] += 1
+    if sc is not None:
+        _bn_record(sc[1].running_mean, sc[1].running_var, sc[1].num_batches_tracked, stats[1], n * hi * wi, sc[1].eps, sc[3], 1)
+    _bn_record(bn.running_mean, bn.running_var, bn.num_batches_tracked, st_a, n * hi * wi, bn.eps, momentum, 1)
+    return (y, a, st_a, stats[1]) if sc is not None else (y, a, st_a)
+
+
+GRID_BN_SC = os.environ.get("AFAN_GRID_BN", "2") not in ("0", "1")   # ... and the projection shortcut's BatchNorm backward in that launch
+
+
+def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, want_dres=False, dweight=None, dbias=None,
+                  accumulate=False, dx_out=None, sc=None):
+    """(dx, dres) = the gradient entering the INPUT of the BatchNorm (+ ReLU) in front of the 3x3 / stride-1 convolution whose output
+    gradient is dy (and that backward's masked gradient, the shortcut's share, if want_dres): conv_dgrad(bn_bwd=...) + bn_backward
+    in ONE launch, the same bits.  None when the launch is not eligible (nothing has run).
+    sc = (sc_x, sc_stats, d_sc_out, sc_dweight, sc_dbias) (block-output form, bn_y given): the producing block's projection shortcut's
+    BatchNorm (no ReLU; input sc_x, statistics sc_stats) receives the masked gradient as well; its backward runs in the same launch:
+    d_sc_out (a tensor of dx's shape) takes the gradient entering its input — bn_backward(dres, sc_x, relu=False) up to the summation
+    order of its two channel sums."""
+    if not (GRID_BN and dy.is_cuda and BN_ACC):
+        return None
+    n, co, ho, wo = dy.shape
+    ci, co2, k, _ = wt.shape
+    hi, wi = in_hw
+    key = ("b" if sc is None else "bs", n, ci, hi, wi, co, dy.device.index)
+    if k != 3 or co2 != co or (hi, wi) != (ho, wo) or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(ci):
+        return None
+    lib = _lib.load()
+    _cl4(dy, "dy"), _cl4(wt, "wt"), _cl4(bn_x, "bn_x")
+    _need(bn_stats, "bn_stats", torch.float32)
+    cl = torch.channels_last
+    if dx_out is not None:
+        _cl4(dx_out, "dx_out")
+        if tuple(dx_out.shape) != (n, ci, hi, wi):
+            raise ValueError("dx_out must have dx's shape")
+    dx = dx_out if dx_out is not None else torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=cl)
+    dres = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=cl) if want_dres else None
+    if bn_x.shape != dx.shape or bn_stats.numel() != 4 * ci:
+        raise ValueError("bn_x / bn_stats do not match dx")
+    for t, nm in ((bn_y, "bn_y"), (addend, "addend")):
+        if t is not None:
+            _cl4(t, nm)
+            if t.shape != dx.shape:
+                raise ValueError(nm + " must have dx's shape")
+    scp, acc2 = [None] * 6, None
+    if sc is not None:
+        sc_x, sc_stats, d_sc, sc_dw, sc_db = sc
+        _cl4(sc_x, "sc_x"), _cl4(d_sc, "d_sc")
+        _need(sc_stats, "sc_stats", torch.float32)
+        if bn_y is None or sc_x.shape != dx.shape or d_sc.shape != dx.shape or sc_stats.numel() != 4 * ci:
+            raise ValueError("projection form: block-output launch (bn_y) with sc_x / d_sc of dx's shape")
+    acc = acc_take(dy.device, ci)
+    if sc is not None:
+        acc2 = acc_take(dy.device, ci)
+        scp = [_ptr(sc_x), _ptr(sc_stats), _ptr(acc2), _ptr(d_sc), _ptr(sc_dw), _ptr(sc_db)]
+    rc = lib.afan_conv_dgrad_bn_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), _ptr(dres), n, hi, wi, ci, co, _ptr(addend), _ptr(bn_x),
+                                          _ptr(bn_stats), int(bool(relu)), _ptr(bn_y), _ptr(acc), _ptr(dweight), _ptr(dbias),
+                                          int(bool(accumulate)), *scp, _ptr(_grid_barrier(dy.device)), _stream(dy))
+    if rc == -3:
+        _grid_refused.add(key)
+        if acc2 is not None:
+            _acc_untake(dy.device, acc2)
+        _acc_untake(dy.device, acc)
+        return None
+    check(rc, "afan_conv_dgrad_bn_nhwc_bf16")
+    CALLS["conv_dgrad"] += 1
+    CALLS["conv_bn_fused"] += 1
+    return dx, dres
 
 
 def conv_fwd_affine(x, w, stride, coefs, residual=None, relu=False):

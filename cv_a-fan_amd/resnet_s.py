@@ -551,6 +551,22 @@ class _BlockFn(torch.autograd.Function):
             res = x
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
+            last = i == n - 1
+            if (G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] == 3 and c.stride[0] == 1
+                    and c.dilation[0] == 1):
+                # convolution + BatchNorm (+ shortcut) + ReLU as ONE launch (grid barrier between the sums and the second pass:
+                # ops.conv_fwd_bn); None = this launch does not take that form, the two launches below run instead (same bits)
+                if last and dual_sc:
+                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), relu=True, sc=(rawsc, bsc, stc, mom(bsc)))
+                else:
+                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), residual=res if last else None, relu=True)
+                if fused is not None:
+                    if len(fused) == 4:
+                        raw, a, s_i, ssc = fused
+                    else:
+                        raw, a, s_i = fused
+                    saved += [raw, a, s_i]
+                    continue
             if i == 0 and first is not None:
                 raw, st = first
             else:
@@ -571,7 +587,10 @@ class _BlockFn(torch.autograd.Function):
         prev = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
         ctx.prev_bn = prev if (prev is not None and prev[2] == G) else None
         ctx.save_for_backward(x, rawsc, ssc, *saved)
-        a._afan_bn2 = (saved[-3], saved[-1], G)
+        # (raw_n, stats_n, G, bn_n, want_pgrad, the projection shortcut's (raw, stats, bn) or None): what a consumer block's first
+        # input-gradient launch needs to run this block's last-BatchNorm backward(s) inside itself
+        a._afan_bn2 = (saved[-3], saved[-1], G, chain[-1][1], want_pgrad,
+                       (rawsc, ssc, blk.shortcut[1]) if (blk._sc_kind == "conv" and ssc is not None) else None)
         return a
 
     @staticmethod
@@ -612,29 +631,45 @@ class _BlockFn(torch.autograd.Function):
         g = lambda p: p.grad if pg else None
         out = acts[-1]
         pre = getattr(gout, "_afan_bn_sums", None)     # taken by the consumer block's dgrad epilogue (same tensor object)
-        gout = _like_layout(gout, out)
+        done = getattr(gout, "_afan_bn_done", None)    # ... or this block's whole last-BatchNorm backward, done inside that launch:
         # last BN (+residual, ReLU mask from `out`): gradient to its conv output and to the shortcut branch
         bl = chain[-1][1]
-        d_raw, dres = _bn_bwd_g(gout, raws[-1], out, stats[-1], bl, True, True, pg, pre, G)
+        if done is not None:
+            d_raw, dres = done, gout                   # the tensor handed back IS the shortcut's share; the other result rides on it
+        else:
+            gout = _like_layout(gout, out)
+            d_raw, dres = _bn_bwd_g(gout, raws[-1], out, stats[-1], bl, True, True, pg, pre, G)
         # the first convolution's and the projection's output gradients side by side in one buffer: their input gradients
         # are ONE launch (afan_conv_dgrad_sc_nhwc_bf16) when the arena holds the block's combined [Ci][10][Co] operand
         c1 = chain[0][0]
         wt10 = getattr(c1, "_arena_wt10", None) if (_BlockFn.MULTI_SC and blk._sc_kind == "conv" and G == 1 and need_dx
                                                      and n >= 2) else None
         pair = None
+        # ... and the projection BatchNorm's backward too: its result sits in the second half of a pair buffer the consumer made
+        sc_done = getattr(gout, "_afan_sc_done", None) if done is not None else None
+        r0 = raws[0]
         if wt10 is not None:
-            r0 = raws[0]
-            pair = torch.empty((2 * r0.shape[0],) + tuple(r0.shape[1:]), dtype=r0.dtype, device=r0.device,
-                               memory_format=torch.channels_last)
+            pair = sc_done if sc_done is not None else torch.empty((2 * r0.shape[0],) + tuple(r0.shape[1:]), dtype=r0.dtype,
+                                                                   device=r0.device, memory_format=torch.channels_last)
         for i in range(n - 1, 0, -1):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
-            d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
-                                       bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G,
-                                       dilation=c.dilation[0])
-            c._bwd_buf = part.partials
+            fused = None
+            if G == 1 and ops.GRID_BN and c.kernel_size[0] == 3 and c.stride[0] == 1 and c.dilation[0] == 1:
+                # ... or bn_{i-1}'s whole backward (sums -> grid barrier -> the gradient entering its input): ONE launch
+                fused = ops.conv_dgrad_bn(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], raws[i - 1], stats[i - 1], True,
+                                          dweight=g(bp.weight), dbias=g(bp.bias), accumulate=pg,
+                                          dx_out=pair[:r0.shape[0]] if (pair is not None and i == 1) else None)
+            if fused is None:
+                d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
+                                           bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G,
+                                           dilation=c.dilation[0])
+                c._bwd_buf = part.partials
             if pg:
                 _wgrad_accumulate(acts[i - 1], d_raw, c)
+            if fused is not None:
+                d_raw = fused[0]
+                continue
             d_raw, _ = _bn_bwd_g(d_a, raws[i - 1], None, stats[i - 1], bp, True, False, pg, part, G,
                                  dx_out=pair[:r0.shape[0]] if (pair is not None and i == 1) else None)
         if pg:
@@ -646,8 +681,11 @@ class _BlockFn(torch.autograd.Function):
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
             if pg or need_dx:
-                d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G,
-                                       dx_out=pair[r0.shape[0]:] if pair is not None else None)
+                if sc_done is not None:
+                    d_rawsc = sc_done[r0.shape[0]:]
+                else:
+                    d_rawsc, _ = _bn_bwd_g(dres, rawsc, None, ssc, bsc, False, False, pg, None, G,
+                                           dx_out=pair[r0.shape[0]:] if pair is not None else None)
                 if pg:
                     _wgrad_accumulate(x, d_rawsc, csc)
                 if need_dx and pair is not None:
@@ -663,6 +701,33 @@ class _BlockFn(torch.autograd.Function):
                 dx_sc[:, :, ::2, ::2] = dres[:, pad:pad + x.shape[1]]
                 dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
+            fused = pair_p = None
+            if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.kernel_size[0] == 3 and c1.stride[0] == 1
+                    and c1.dilation[0] == 1 and getattr(prev[3], "_branch", "main") == ctx.branch):
+                # the gradient leaving this block is only ever read by the producing block's last-BatchNorm backward: that
+                # backward runs inside this launch and the producer's node finds its two results on the tensor handed back
+                pbn, ppg = prev[3], prev[4]
+                kw = dict(bn_y=x, addend=dres, want_dres=True, dweight=pbn.weight.grad if ppg else None,
+                          dbias=pbn.bias.grad if ppg else None, accumulate=ppg)
+                psc = prev[5] if (len(prev) > 5 and ops.GRID_BN_SC and _BlockFn.MULTI_SC) else None
+                if psc is not None and getattr(psc[2], "_branch", "main") == ctx.branch:
+                    # the producing block has a projection shortcut: its BatchNorm's backward here as well, the result in the second
+                    # half of the buffer that block's fused stride-2 input gradient reads (first half: its own first convolution's)
+                    pair_p = torch.empty((2 * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device,
+                                         memory_format=torch.channels_last)
+                    fused = ops.conv_dgrad_bn(d_raw, c1.lp_weight_t(), x.shape[2:], prev[0], prev[1], True,
+                                              sc=(psc[0], psc[1], pair_p[x.shape[0]:], psc[2].weight.grad if ppg else None,
+                                                  psc[2].bias.grad if ppg else None), **kw)
+                    if fused is None:
+                        pair_p = None
+                if fused is None:
+                    fused = ops.conv_dgrad_bn(d_raw, c1.lp_weight_t(), x.shape[2:], prev[0], prev[1], True, **kw)
+            if fused is not None:
+                dx = fused[1]
+                dx._afan_bn_done = fused[0]            # (not the pair: a tuple holding dx on dx would be a reference cycle)
+                if pair_p is not None:
+                    dx._afan_sc_done = pair_p
+                return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
             dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dres, **fuse)
         if "bn_bwd" in fuse and dx is not None:
             dx, sums = dx

@@ -404,15 +404,19 @@ class AfanTrainer:
         torch.autograd.backward(loss_adv, grad_tensors=half)                 # last segment (+ classifier head)
         resnet_s.flush_wgrad(m.sequential_model[segs[-1][0]:segs[-1][1]])
         yield self._param_range(*segs[-1])
-        for k in range(len(segs) - 2, -1, -1):
-            a_outs[k].backward(a_ins[k + 1].grad)
-            resnet_s.flush_wgrad(m.sequential_model[segs[k][0]:segs[k][1]])
-            if k == 0:
-                clean_bn.replay()                       # main_perturb.py:196's BatchNorm side effect, last in order
-            yield self._param_range(*segs[k])
-        if len(segs) == 1:
-            clean_bn.replay()
-        fm_clean.backward(g0)                           # the clean branch's gradient through the head
+        # From here on an exchange may be in flight on the reducer's stream: its resident kernels would make a grid barrier wait
+        # for the exchange to END (the in-launch BatchNorm needs every workgroup of its launch on the chip at once), so the rest of
+        # the backward takes the two-launch forms when ranks exchange gradients (ops.grid_bn; same bits either way).
+        with ops.grid_bn(self.reducer is None):
+            for k in range(len(segs) - 2, -1, -1):
+                a_outs[k].backward(a_ins[k + 1].grad)
+                resnet_s.flush_wgrad(m.sequential_model[segs[k][0]:segs[k][1]])
+                if k == 0:
+                    clean_bn.replay()                   # main_perturb.py:196's BatchNorm side effect, last in order
+                yield self._param_range(*segs[k])
+            if len(segs) == 1:
+                clean_bn.replay()
+            fm_clean.backward(g0)                       # the clean branch's gradient through the head
         with torch.no_grad():
             loss = (loss_adv + loss_clean) / 2
             prec1 = (c_outs[-1].argmax(dim=1) == target).float().sum() * (100.0 / target.shape[0])

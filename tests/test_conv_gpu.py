@@ -615,3 +615,176 @@ def test_dgrad_with_block_output_backward_epilogue_equals_two_launches(pkg, gpu,
     got = pkg.ops.conv_dgrad_dual(dy, wt, (h, w), st, add, alpha, act)
     assert got is not None
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+def _mk_bn(co, gpu, seed):
+    import torch.nn as nn
+    b = nn.BatchNorm2d(co).to(gpu)
+    with torch.no_grad():
+        gg = torch.Generator().manual_seed(seed)
+        b.weight.copy_(1 + 0.2 * torch.randn(co, generator=gg))
+        b.bias.copy_(0.1 * torch.randn(co, generator=gg))
+        b.running_mean.copy_(0.05 * torch.randn(co, generator=gg))
+        b.running_var.copy_(1 + 0.1 * torch.rand(co, generator=gg))
+    return b
+
+
+def _bn_state(b):
+    return {k: v.clone() for k, v in b.state_dict().items() if "running" in k or "num" in k}
+
+
+GRID_SHAPES = [  # n, ci, co, h: the training step's own launches (256-row, 256 x 64 and 128 x 64 halo tiles) and smaller batches
+    (256, 128, 128, 16), (256, 256, 256, 8), (256, 512, 512, 4), (64, 128, 128, 16), (32, 256, 256, 8), (100, 128, 256, 8)]
+
+
+@pytest.mark.parametrize("n,ci,co,h", GRID_SHAPES)
+@pytest.mark.parametrize("form", ["plain", "residual", "projection"])
+def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h, form):
+    """afan_conv_fwd_bn_nhwc_bf16 (sums -> grid barrier -> totals -> second pass, one launch) against afan_conv_fwd_nhwc_bf16 +
+    afan_bn_train_forward_acc[_dual]: raw output, normalised output, statistics block, running buffers — every bit; twice in a row
+    (the barrier words reset themselves) with two running-statistics updates per pass (the shared head pass's form)."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(n + ci + co + h)
+    x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(gpu).bfloat16())
+    res = _cl(torch.randn(n, co, h, h, generator=g).to(gpu).bfloat16())
+    xs = _cl(torch.randn(n, ci, 2 * h, 2 * h, generator=g).to(gpu).bfloat16())          # the projection's input (stride 2)
+    wsc = _cl((torch.randn(co, ci, 1, 1, generator=g) * 0.1).to(gpu).bfloat16())
+    out = {}
+    for mode in ("two", "one"):
+        bn, bsc = _mk_bn(co, gpu, 1), _mk_bn(co, gpu, 2)
+        got = []
+        for rep in range(2):
+            ops.acc_reset(gpu)
+            with ops.bn_running_updates(2):
+                if form == "projection":
+                    rsc, stc = ops.conv_fwd(xs, wsc, 2, stats_shift=bsc.running_mean, want_stats=True)
+                    if mode == "one":
+                        r = ops.conv_fwd_bn(x, w, bn, 0.1, relu=True, sc=(rsc, bsc, stc, 0.1))
+                        assert r is not None, "the in-launch form declined a launch of the training step's kind"
+                        raw, act, st, ssc = r
+                    else:
+                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)
+                        act, st, ssc = ops.bn_train_forward_dual(raw, bn, sta, 0.1, rsc, bsc, stc, 0.1)
+                    got.append((raw.clone(), act.clone(), st.clone(), ssc.clone(), _bn_state(bn), _bn_state(bsc)))
+                else:
+                    rr = res if form == "residual" else None
+                    if mode == "one":
+                        r = ops.conv_fwd_bn(x, w, bn, 0.1, residual=rr, relu=True)
+                        assert r is not None
+                        raw, act, st = r
+                    else:
+                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)
+                        act, st = ops.bn_train_forward(raw, bn.weight, bn.bias, rr, True, bn.eps, 0.1, bn.running_mean, bn.running_var,
+                                                       bn.num_batches_tracked, sta)
+                    got.append((raw.clone(), act.clone(), st.clone(), _bn_state(bn)))
+        out[mode] = got
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    for a, b in zip(out["one"], out["two"]):
+        for p, q in zip(a, b):
+            if isinstance(p, dict):
+                for k in p:
+                    assert torch.equal(p[k], q[k]), k
+            else:
+                assert torch.equal(p, q)
+    assert int(out["one"][1][-1]["num_batches_tracked"]) == 4
+
+
+@pytest.mark.parametrize("n,ci,co,h", GRID_SHAPES)
+@pytest.mark.parametrize("form", ["bn1", "block_output"])
+def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h, form):
+    """afan_conv_dgrad_bn_nhwc_bf16 against afan_conv_dgrad_nhwc_bf16 (BatchNorm-backward sums in its epilogue) +
+    afan_bn_backward_acc: the gradient entering the BatchNorm's input, the masked gradient (block-output form: mask from the stored
+    output, other branch's gradient added first) and the affine parameters' gradients (written, then accumulated) — every bit."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(3 * n + ci + co + h)
+    dy = _cl(torch.randn(n, co, h, h, generator=g).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, 3, 3, generator=g) / (co * 9) ** 0.5).to(gpu).bfloat16())
+    wt = _cl(w.permute(1, 0, 2, 3))
+    bn_x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    addend = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    res = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    gamma, beta = (torch.rand(ci, generator=g) + 0.5).to(gpu), (torch.randn(ci, generator=g) * 0.3).to(gpu)
+    out_block = form == "block_output"
+    y, stats = ops.bn_train_forward(bn_x, gamma, beta, res if out_block else None, True, 1e-5, 0.1, None, None, None)
+    got = {}
+    for mode in ("two", "one"):
+        dwb = torch.zeros(2, ci, device=gpu)
+        rs = []
+        for rep in range(2):                               # second pass accumulates into dweight / dbias
+            ops.acc_reset(gpu)
+            if mode == "one":
+                r = ops.conv_dgrad_bn(dy, wt, (h, h), bn_x, stats, True, bn_y=y if out_block else None,
+                                      addend=addend if out_block else None, want_dres=out_block, dweight=dwb[0], dbias=dwb[1],
+                                      accumulate=rep > 0)
+                assert r is not None, "the in-launch form declined a launch of the training step's kind"
+                dx, dres = r
+            else:
+                gsum, part = ops.conv_dgrad(dy, wt, (h, h), 1, addend=addend if out_block else None, bn_bwd=(bn_x, stats, True),
+                                            bn_y=y if out_block else None)
+                dx, dres = ops.bn_backward(gsum, bn_x, y if out_block else None, stats, gamma, beta, True, out_block, dwb[0], dwb[1],
+                                           accumulate=rep > 0, partials=part)
+            rs.append((dx.clone(), None if dres is None else dres.clone(), dwb.clone()))
+        got[mode] = rs
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    for a, b in zip(got["one"], got["two"]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+        assert (a[1] is None and b[1] is None) or torch.equal(a[1], b[1])
+
+
+def test_in_launch_batchnorm_declines_launches_it_cannot_take(pkg, gpu):
+    """More workgroups than the chip holds at once, a stride-2 / 1x1 problem, the 64 -> 64 kernel's shape: None, and nothing ran."""
+    ops = pkg.ops
+    bn = _mk_bn(128, gpu, 1)
+    before = dict(ops.CALLS)
+    x = _cl(torch.randn(1024, 128, 16, 16, device=gpu).bfloat16())                 # 2 048 row tiles of 128
+    w = _cl((torch.randn(128, 128, 3, 3, device=gpu) * 0.03).bfloat16())
+    assert ops.conv_fwd_bn(x, w, bn, 0.1) is None
+    x1 = _cl(torch.randn(8, 128, 16, 16, device=gpu).bfloat16())
+    assert ops.conv_fwd_bn(x1, _cl((torch.randn(128, 128, 1, 1, device=gpu) * 0.1).bfloat16()), bn, 0.1) is None
+    x64 = _cl(torch.randn(8, 64, 32, 32, device=gpu).bfloat16())
+    assert ops.conv_fwd_bn(x64, _cl((torch.randn(64, 64, 3, 3, device=gpu) * 0.05).bfloat16()), _mk_bn(64, gpu, 2), 0.1) is None
+    with ops.grid_bn(False):
+        assert ops.conv_fwd_bn(x1, w, bn, 0.1) is None
+    assert ops.CALLS["conv_fwd"] == before["conv_fwd"] and ops.CALLS["conv_bn_fused"] == before["conv_bn_fused"]
+    assert int(bn.num_batches_tracked) == 0
+
+
+@pytest.mark.parametrize("n,ci,co,h", [(256, 256, 256, 8), (256, 512, 512, 4), (64, 128, 128, 16), (100, 128, 256, 8)])
+def test_dgrad_with_both_batchnorm_backwards_of_a_projection_block(pkg, gpu, n, ci, co, h):
+    """The block-output form with the producing block's projection shortcut: its BatchNorm (no ReLU) receives the masked gradient
+    as well, and afan_conv_dgrad_bn_nhwc_bf16(sc_x ...) runs that backward in the same launch (third column sum, second
+    accumulator block, third output).  The main results keep their bits; the projection's input gradient and parameter gradients
+    equal afan_bn_backward's on the launch's own masked gradient up to the summation order of the two channel sums."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(5 * n + ci + co + h)
+    dy = _cl(torch.randn(n, co, h, h, generator=g).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, 3, 3, generator=g) / (co * 9) ** 0.5).to(gpu).bfloat16())
+    wt = _cl(w.permute(1, 0, 2, 3))
+    bn_x, sc_x, addend, res = (_cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16()) for _ in range(4))
+    gamma, beta = (torch.rand(ci, generator=g) + 0.5).to(gpu), (torch.randn(ci, generator=g) * 0.3).to(gpu)
+    gsc, bsc = (torch.rand(ci, generator=g) + 0.5).to(gpu), (torch.randn(ci, generator=g) * 0.3).to(gpu)
+    ysc, st_sc = ops.bn_train_forward(sc_x, gsc, bsc, None, False, 1e-5, 0.1, None, None, None)
+    y, stats = ops.bn_train_forward(bn_x, gamma, beta, ysc, True, 1e-5, 0.1, None, None, None)
+    ops.acc_reset(gpu)
+    dwb, dws = torch.zeros(2, ci, device=gpu), torch.zeros(2, ci, device=gpu)
+    pair = torch.empty(2 * n, ci, h, h, device=gpu, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = ops.conv_dgrad_bn(dy, wt, (h, h), bn_x, stats, True, bn_y=y, addend=addend, want_dres=True, dweight=dwb[0], dbias=dwb[1],
+                          sc=(sc_x, st_sc, pair[n:], dws[0], dws[1]))
+    if r is None:                      # (the 768-thread x 128-column variant has no such form: two launches, as before)
+        assert (n, ci, h) == (256, 128, 16)
+        return
+    dx, dres = r
+    plain = ops.conv_dgrad_bn(dy, wt, (h, h), bn_x, stats, True, bn_y=y, addend=addend, want_dres=True)
+    assert torch.equal(dx, plain[0]) and torch.equal(dres, plain[1])
+    ref_w = torch.zeros(2, ci, device=gpu)
+    ref, _ = ops.bn_backward(dres, sc_x, None, st_sc, gsc, bsc, False, False, ref_w[0], ref_w[1])
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    scale = max(1.0, float(ref_w.abs().max()))
+    np.testing.assert_allclose(dws.cpu().numpy(), ref_w.cpu().numpy(), rtol=2e-4, atol=2e-4 * scale)
+    a, b = pair[n:].float().cpu().numpy(), ref.float().cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-2, atol=2e-3 * max(1.0, float(np.abs(b).max())))
+    assert float(np.mean(a != b)) < 0.02          # bf16 roundings that fell the other way: a handful

@@ -950,3 +950,52 @@ def test_r18_per_step_perturbation_given_reference_iterates(pkg, orc, gpu):
         worst = max(worst, flips)
     report_flips("pgd_trace_r18_k5", "sign of one gradient from the reference's own iterate, worst step", worst)
     assert worst <= flip_bound("pgd_trace_r18_k5"), worst
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("fold", [True, False])
+@pytest.mark.parametrize("sc", [False, True])
+def test_step_with_in_launch_batchnorm_changes_no_bit(pkg, orc, gpu, graph, fold, sc):
+    """Round 5: in the ResNet tails every eligible convolution runs its BatchNorm inside its own launch (forward: raw + normalised
+    output; backward: the gradient entering the BatchNorm's input) behind a grid-wide barrier (ops.conv_fwd_bn / conv_dgrad_bn).
+    The same iterations with that form switched off (two launches per pair): losses, perturbation, every parameter, momentum
+    buffer and BatchNorm buffer identical bit for bit — at the benched shape (ResNet-18, batch 256, bf16 channels-last), eager and
+    replayed from the hipGraph, folded and literal schedule; and the fused form DID run (and no barrier spin gave up).
+    sc = True adds the projection shortcuts' BatchNorm backward to those launches: its two channel sums are then taken per row tile
+    instead of per stream block — another summation order, so those runs are held to a tolerance instead (loss 2e-3, parameters 1e-3
+    of their range after three iterations at lr 0.05)."""
+    ops = pkg.ops
+    res = {}
+    old_sc = ops.GRID_BN_SC
+    for on in (False, True):
+        ops.GRID_BN_SC = bool(sc)
+        with ops.grid_bn(on):
+            m = _build(pkg, orc, "resnet18", gpu, dtype=torch.bfloat16)
+            m.set_channels_last(True)
+            tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=3, gamma=0.5, eps=2.0, perturb_idx=6, lr=0.05,
+                                            use_graph=graph, graph_warmup=1, fold_clean=fold, share_head=fold)
+            gen = torch.Generator().manual_seed(11)
+            x, y = torch.rand(256, 3, 32, 32, generator=gen).to(gpu), torch.randint(0, 10, (256,), generator=gen).to(gpu)
+            before = ops.CALLS["conv_bn_fused"]
+            outs = []
+            for _ in range(3):
+                r = tr.step(x, y)
+                outs.append((r["loss"].clone(), r["loss_adv"].clone(), r["l2"].clone(), r["x_adv"].clone()))
+            torch.cuda.synchronize()
+            assert (tr._graph is not None) == graph
+            assert (ops.CALLS["conv_bn_fused"] > before) == on
+            assert not ops.grid_barrier_error(gpu)
+            res[on] = (outs, tr.arena.param.clone(), tr.arena.momentum_buf.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+    ops.GRID_BN_SC = old_sc
+    a, b = res[False], res[True]
+    if sc:
+        for oa, ob in zip(a[0], b[0]):
+            assert abs(float(oa[0]) - float(ob[0])) <= 2e-3 * max(1.0, abs(float(oa[0])))
+        assert float((a[1] - b[1]).abs().max()) <= 1e-3 * float(a[1].abs().max())
+        return
+    for oa, ob in zip(a[0], b[0]):
+        for p, q in zip(oa, ob):
+            assert torch.equal(p, q)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k

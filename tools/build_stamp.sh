@@ -1,0 +1,10 @@
+#!/bin/bash
+# diagnostic build: libafan_hip_stamp.so = the library with afan_conv.hip compiled -DAFAN_CONV_STAMP (per-tap cycle stamps of the
+# halo-form convolution; tools/probe/conv_stamps.py reads them).  Not shipped, not loaded by the product (AFAN_HIP_LIB selects it).
+set -e
+cd "$(dirname "$0")/../cv_a-fan_amd/csrc"
+make -j4 > /dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAFAN_CONV_STAMP -c afan_conv.hip -o /tmp/afan_conv_stamp.o
+OBJS=$(ls *.o | grep -v '^afan_conv.o$')
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS /tmp/afan_conv_stamp.o -o ../../tools/probe/_bin/libafan_hip_stamp.so
+ls -la ../../tools/probe/_bin/libafan_hip_stamp.so

@@ -1,0 +1,40 @@
+"""Where a halo-form convolution's K loop spends its cycles: per-tap stamps (diagnostic build, tools/build_stamp.sh) of workgroup
+(0,0,0)'s first MFMA wave (arrive at barrier | released | MFMAs issued) and first producer wave (loop top | data landed | released).
+  AFAN_HIP_LIB=tools/probe/_bin/libafan_hip_stamp.so python tools/probe/conv_stamps.py"""
+import ctypes as C, importlib, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+pkg = importlib.import_module("cv_a-fan_amd")
+lib = C.CDLL(pkg._lib.LIB_PATH)
+dev = torch.device("cuda:0")
+cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)):
+    x = cl(torch.randn(n, ci, h, h, device=dev).bfloat16())
+    w = cl((torch.randn(co, ci, 3, 3, device=dev) * 0.05).bfloat16())
+    for dgrad in (False,):
+        for _ in range(5):
+            y = pkg.ops.conv_fwd(x, w, 1)
+        torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(20):
+            y = pkg.ops.conv_fwd(x, w, 1)
+        t1.record(); torch.cuda.synchronize()
+        buf = (C.c_ulonglong * (2 * 96 * 3))()
+        assert lib.afan_conv_stamps(buf) == 0
+        s = np.array(buf, dtype=np.uint64).reshape(2, 96, 3).astype(np.int64)
+        taps = int((s[0, :, 0] > 0).sum())
+        m, p = s[0, :taps], s[1, :taps]
+        base = min(m[0, 0], p[0, 0])
+        print(f"== {ci}->{co} {h}x{h} batch {n}: {t0.elapsed_time(t1) / 20 * 1e3:.1f} us per launch (eager, stamped build); {taps} taps; "
+              f"loop {(m[-1, 2] - m[0, 0])} cycles = {(m[-1, 2] - m[0, 0]) / taps:.0f} per tap")
+        mw, mc = m[:, 1] - m[:, 0], m[:, 2] - m[:, 1]
+        gap = np.concatenate([[0], m[1:, 0] - m[:-1, 2]])
+        pw, pb = p[:, 1] - p[:, 0], p[:, 2] - p[:, 1]
+        pi = np.concatenate([p[1:, 0] - p[:-1, 2], [0]])
+        print(f"   MFMA wave:  barrier wait mean {mw.mean():.0f} (min {mw.min()} max {mw.max()}), reads+MFMA issue mean {mc.mean():.0f} (min {mc.min()} max {mc.max()}), between {gap.mean():.0f}")
+        print(f"   producer:   vmcnt wait mean {pw.mean():.0f} (max {pw.max()}), barrier wait mean {pb.mean():.0f}, DMA issue mean {pi.mean():.0f} (max {pi.max()})")
+        print("   tap: Mwait Mcomp | Pvmcnt Pbar Pissue")
+        for i in range(min(taps, 20)):
+            print(f"   {i:3d}: {mw[i]:6d} {mc[i]:6d} | {pw[i]:6d} {pb[i]:6d} {pi[i]:6d}   (M arrive {m[i,0]-base:7d}, P top {p[i,0]-base:7d})")
