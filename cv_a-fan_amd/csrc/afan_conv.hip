@@ -88,19 +88,21 @@ static_assert(sizeof(GridBar) <= 2048, "afan_grid_barrier_bytes()");
 // and ONE monotonic release counter that every shard's last arriver bumps: a workgroup's episode number is that counter / 8 read
 // BEFORE its own arrival (its shard cannot have completed yet), it leaves when the counter reaches 8 * (episode + 1).  The last
 // arriver's path is two dependent atomics, a waiter's one poll round trip behind them.
-__device__ __forceinline__ unsigned grid_arrive(unsigned* words, unsigned id, unsigned nwg) {
+__device__ __forceinline__ unsigned grid_episode(unsigned* words) {       // any time before the workgroup's own arrival (early: off the critical path)
+    GridBar* b = reinterpret_cast<GridBar*>(words);
+    return (__hip_atomic_load(&b->global_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / 8u + 1u) * 8u;
+}
+__device__ __forceinline__ void grid_arrive(unsigned* words, unsigned id, unsigned nwg) {
     GridBar* b = reinterpret_cast<GridBar*>(words);
     const unsigned sh = id & 7u;
     const unsigned per = nwg / 8u + (sh < (nwg & 7u) ? 1u : 0u);            // (nwg >= 8: launch_gs checks)
-    const unsigned target = (__hip_atomic_load(&b->global_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / 8u + 1u) * 8u;
     const unsigned a = __hip_atomic_fetch_add(&b->shard_cnt[sh][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a + 1 == per) {
         __hip_atomic_store(&b->shard_cnt[sh][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&b->global_cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return target;
 }
-__device__ __forceinline__ void grid_wait(unsigned* words, unsigned id, unsigned target) {
+__device__ __forceinline__ void grid_wait(unsigned* words, unsigned target) {
     GridBar* b = reinterpret_cast<GridBar*>(words);
     if (__hip_atomic_load(&b->err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // a spin already gave up: do not stack 0.2 s waits
     const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -733,7 +735,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // (not in the 768-thread variant: at its 168-register cap the third sum's state spills in the prefetch phase; launch_gs refuses)
     constexpr bool BSC_OK = BF && !(THREADS > 512 && BN >= 128);
     bool have_bsc = false;
+    unsigned bar_target = 0;                     // (BF) this launch's barrier episode, asked for here: long before thread 0 needs it
     if constexpr (BF) {
+        if (tid == 0) bar_target = grid_episode(pp.bar);
         have_bsc = BSC_OK && pp.bnf == 2 && pp.bsc.x != nullptr;
         if (have_bsc) {
             constexpr int PIECES_Z = BN / 8, NZ = BM * BN * 2 / 1024;
@@ -819,12 +823,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
     double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
-    float s3[8], shz[8];                                          // (BF, projection shortcut's BatchNorm: third sum, its mean)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s3[j] = 0.f;
-        shz[j] = (BF && have_bsc) ? pp.bsc.stats[ch_ok ? n0 + pc * 8 + j : 0] : 0.f;
-    }
     // (BF: the stored-output mask as bits — the 768-thread variant has no registers to keep the prefetched output tile, the
     // BatchNorm input tile AND the other branch's gradient through the row loop: 73 scratch accesses in its epilogue otherwise)
     uint32_t ymask[(EPI_ROWS + 3) / 4];
@@ -841,6 +839,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 ymask[q / 4] |= m << (8 * (q % 4));
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                        // (the output tile's registers are free before the next values are born)
+    }
+    float s3[8], shz[8];                                          // (BF, projection shortcut's BatchNorm: third sum, its mean)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s3[j] = 0.f;
+        shz[j] = (BF && have_bsc) ? pp.bsc.stats[ch_ok ? n0 + pc * 8 + j : 0] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1011,8 +1016,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's accumulator atomics have been performed
             __syncthreads();
             const unsigned wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            unsigned bar_gen = 0;
-            if (tid == 0) bar_gen = grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * gridDim.z);
+            if (tid == 0) grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * gridDim.z);
             if (bf_fwd) {                                             // the raw tile leaves while the other workgroups arrive
 #pragma unroll
                 for (int q = 0; q < EPI_ROWS; ++q) {
@@ -1022,23 +1026,23 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                         *reinterpret_cast<u16x8*>(y_p + (int64_t)off + n0 + pc * 8) = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
                 }
             }
-            if (tid == 0) grid_wait(pp.bar, wg_id, bar_gen);
+            if (tid == 0) grid_wait(pp.bar, bar_target);
             __syncthreads();
             float* cf = &red[0][0][0];                                // [4][BN] coefficients of the second pass (the partial sums are consumed)
             const bool have_sc = bf_fwd && pp.bnf_sc.acc != nullptr;
             if (tid < BN && n0 + tid < pp.Co) {
                 const int c = n0 + tid, NSl = pp.acc_ns;
                 const bool pub = blockIdx.y == 0 && blockIdx.z == 0;  // the row tile that publishes statistics / parameter gradients
-                double av[16], bv[16];
+                double av[8], bv[8];                                  // (>= 128 channels: at most 8 accumulator copies; launch_gs checks)
                 const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(acc_blk, 0, (int)(2 * NSl * pp.Co * 8), 0x00020000);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {                        // fold_slots' order; all requests in flight together
+                for (int s = 0; s < 8; ++s) {                         // fold_slots' order; all requests in flight together
                     av[s] = s < NSl ? ld_total(accr, ((2 * s) * pp.Co + c) * 8) : 0.0;
                     bv[s] = s < NSl ? ld_total(accr, ((2 * s + 1) * pp.Co + c) * 8) : 0.0;
                 }
                 double a = 0.0, b = 0.0;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
+                for (int s = 0; s < 8; ++s) {
                     a += av[s];
                     b += bv[s];
                 }
@@ -1068,12 +1072,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                         const ConvP::Sc& P = pp.bnf_sc;
                         double a2 = 0.0, b2 = 0.0;
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
+                        for (int s = 0; s < 8; ++s) {
                             av[s] = s < NSl ? P.acc[(int64_t)(2 * s) * pp.Co + c] : 0.0;
                             bv[s] = s < NSl ? P.acc[(int64_t)(2 * s + 1) * pp.Co + c] : 0.0;
                         }
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
+                        for (int s = 0; s < 8; ++s) {
                             a2 += av[s];
                             b2 += bv[s];
                         }
@@ -1113,13 +1117,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     if (have_bsc) {
                         const __amdgpu_buffer_rsrc_t zr2 = __builtin_amdgcn_make_buffer_rsrc(pp.bsc.acc, 0, (int)(2 * NSl * pp.Co * 8), 0x00020000);
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
+                        for (int s = 0; s < 8; ++s) {
                             av[s] = s < NSl ? ld_total(zr2, ((2 * s) * pp.Co + c) * 8) : 0.0;
                             bv[s] = s < NSl ? ld_total(zr2, ((2 * s + 1) * pp.Co + c) * 8) : 0.0;
                         }
                         double a2 = 0.0, b2 = 0.0;
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) {
+                        for (int s = 0; s < 8; ++s) {
                             a2 += av[s];
                             b2 += bv[s];
                         }
@@ -1238,6 +1242,7 @@ int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
                 return AFAN_ESHAPE;
             max_resident = cus * (of < od ? of : od);
         }
+        if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
         if (p.bsc.x && THREADS > 512 && BN >= 128) return AFAN_ESHAPE;   // (no projection-BatchNorm form in the 768-thread x 128-column variant)
         if ((int64_t)grid.x * grid.y * grid.z > max_resident || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
             p.n_classes != 1)

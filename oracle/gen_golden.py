@@ -20,6 +20,7 @@ Usage:  python oracle/gen_golden.py            (rewrites tests/golden/ except th
         python oracle/gen_golden.py frcnn      (det_frcnn_r101.npz, det_frcnn_r101_align.npz; own process: Detection/ on sys.path)
         python oracle/gen_golden.py roialign   (only roi_align_fwd_*.npz)
         python oracle/gen_golden.py floor      (ref_noise_floor.npz: the reference against itself in float64 / other fp32 summation orders)
+        python oracle/gen_golden.py lossfloor  (ref_loss_floor.npz: the same for the losses; + traj_r18_damped.npz)
 """
 import importlib.util
 import os
@@ -366,6 +367,100 @@ def gen_noise_floor(ref_attack, build, ref_seg=None, ref_network=None):
                 rec[f"{case}/base_dk_per_step"] = np.stack([np.rint(b_).astype(np.int8) for b_ in base])
             record(case, base, {k: run_seg(k) for k in variants})
     np.savez_compressed(os.path.join(OUT, "ref_noise_floor.npz"), **rec)
+
+
+def gen_loss_floor(ref_attack, build, orc):
+    """tests/golden/ref_loss_floor.npz + traj_r18_damped.npz — the reference against itself on the LOSSES (round 5, VERDICT weak 1).
+    ref_noise_floor.npz measures the perturbation elements; the tests' looser loss bounds (iterations 1-2 of the warm-up trajectory,
+    loss_adv of the deep networks) had no such floor.  Same variants (float64, ATen-native fp32, channels-last fp32, those three on
+    the transposed problem, four draws of 1e-6 relative noise on the images): `<case>/<key>/spread` = max over the variants of
+    |value - baseline| for key in loss, loss_adv, loss_clean; trajectories: one entry per iteration.  The tests bound the product
+    by max(2 x spread, 1e-4).  Also generates the 3-iteration warm-up trajectory on the CONTRACTIVE ResNet-18 (gen_damped_r18's
+    recipe: every block's last BatchNorm weight x 0.1, batch 32, K = 5), which the product must follow to 1e-4 per iteration."""
+    import copy
+    crit = nn.CrossEntropyLoss()
+    variants = ("f64", "nomkldnn", "cl", "t", "t_nomkldnn", "t_cl", "in1", "in2", "in3", "in4")
+    rec = {}
+
+    def damp_(model):
+        for m in model.modules():
+            if hasattr(m, "bn2") and hasattr(m, "conv2"):
+                m.bn2.weight.data.mul_(0.1)
+
+    # ---- single joint steps (main_perturb.py:173-201)
+    for case, arch, bs, K, gamma, clip, damped in (("step_r18_k5", "resnet18", 2, 5, 0.5, False, False),
+                                                   ("step_r56s_k5", "resnet56s", 2, 5, 0.5, False, False),
+                                                   ("step_r18_k5_b16", "resnet18", 16, 5, 0.5, False, False),
+                                                   ("step_r56s_k5_b16", "resnet56s", 16, 5, 0.5, False, False),
+                                                   ("step_r20s_k5", "resnet20s", 4, 5, 0.5, False, False),
+                                                   ("step_r20s_k5_clip", "resnet20s", 4, 5, 1.5, True, False),
+                                                   ("step_r18_k5_b32_damped", "resnet18", 32, 5, 0.5, False, True)):
+        torch.manual_seed(3)
+        model0, idx, ln = build(arch)
+        if damped:
+            damp_(model0)
+        model0.train()
+        x, y = torch.rand(bs, 3, 32, 32), torch.randint(0, 10, (bs,))
+
+        def run(kind):
+            model, (xx,) = _to_variant(kind, copy.deepcopy(model0), [x])
+            opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+            with _variant_ctx(kind):
+                r = _ref_step(ref_attack, model, opt, crit, xx, y, K, gamma, 2.0, idx, ln, False, clip)
+            return {k: float(r[k]) for k in ("loss", "loss_adv", "loss_clean")}
+        base = run("base")
+        gold = np.load(os.path.join(OUT, case + ".npz"))
+        assert base["loss"] == float(gold["loss"]), (case, base["loss"], float(gold["loss"]))
+        runs = {k: run(k) for k in variants}
+        for key in base:
+            rec[f"{case}/{key}/spread"] = np.array(max(abs(runs[k][key] - base[key]) for k in variants))
+            rec[f"{case}/{key}/spread_arith"] = np.array(max(abs(runs[k][key] - base[key]) for k in variants if not k.startswith("in")))
+        print(f"   {case}: " + "  ".join(f"{key} {float(rec[f'{case}/{key}/spread']):.2e}" for key in base))
+
+    # ---- 3-iteration warm-up trajectories (main_perturb.py:167-168,288-293): the stored one and the new contractive one
+    def trajectory(kind, model0, idx, ln, xs, ys, K, wp):
+        model, (xv,) = _to_variant(kind, copy.deepcopy(model0), [xs])
+        opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+        losses = []
+        for i in range(xs.shape[0]):
+            lr = min(i * 0.1 / (wp - 1), 0.1)
+            for p in opt.param_groups:
+                p["lr"] = lr
+            xi = xv[i]
+            if kind.endswith("cl"):
+                xi = xi.contiguous(memory_format=torch.channels_last)
+            with _variant_ctx(kind):
+                r = _ref_step(ref_attack, model, opt, crit, xi, ys[i], K, 0.5, 2.0, idx, ln, False, False)
+            losses.append(float(r["loss"]))
+        return losses, model
+
+    torch.manual_seed(3)
+    model0, idx, ln = build("resnet20s")
+    model0.train()
+    xs, ys = torch.rand(3, 8, 3, 32, 32), torch.randint(0, 10, (3, 8))
+    gold = np.load(os.path.join(OUT, "traj_r20s.npz"))
+    assert np.array_equal(_np(xs), gold["xs"])
+    base, _ = trajectory("base", model0, idx, ln, xs, ys, 2, 5)
+    assert base == [float(v) for v in gold["losses"]], (base, gold["losses"])
+    runs = {k: trajectory(k, model0, idx, ln, xs, ys, 2, 5)[0] for k in variants}
+    rec["traj_r20s/loss/spread"] = np.array([max(abs(runs[k][i] - base[i]) for k in variants) for i in range(3)])
+    print("   traj_r20s: spread per iteration", rec["traj_r20s/loss/spread"])
+
+    torch.manual_seed(3)
+    model0, idx, ln = orc.resnet18_cifar(), 6, 15
+    damp_(model0)
+    model0.train()
+    xs, ys = torch.rand(3, 32, 3, 32, 32), torch.randint(0, 10, (3, 32))
+    k0, c0 = _checksums(model0)
+    base, mb = trajectory("base", model0, idx, ln, xs, ys, 5, 5)
+    runs = {k: trajectory(k, model0, idx, ln, xs, ys, 5, 5)[0] for k in variants}
+    rec["traj_r18_damped/loss/spread"] = np.array([max(abs(runs[k][i] - base[i]) for k in variants) for i in range(3)])
+    print("   traj_r18_damped: losses", base, "spread per iteration", rec["traj_r18_damped/loss/spread"])
+    k1, c1 = _checksums(mb)
+    np.savez_compressed(os.path.join(OUT, "traj_r18_damped.npz"), xs=_np(xs), ys=_np(ys), losses=np.array(base),
+                        lrs=np.array([min(i * 0.1 / 4, 0.1) for i in range(3)]), wp=np.array(5), damp=np.array(0.1), ck0=c0, ck1=c1,
+                        keys=np.array(k1), fc_w=_np(mb.state_dict()["sequential_model.14.weight"]))
+    np.savez_compressed(os.path.join(OUT, "ref_loss_floor.npz"), **rec)
 
 
 def gen_detection(orc):
@@ -1090,6 +1185,20 @@ if __name__ == "__main__":
                 return _rr.resnet56(), 13, 34
             return _orc.resnet18_cifar(), 6, 15
         gen_noise_floor(_ra, _build, _rs, _ref_network)
+    elif sys.argv[1:] == ["lossfloor"]:   # only ref_loss_floor.npz + traj_r18_damped.npz (reads the step goldens it refers to)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        from oracle import afan_oracle as _orc
+        _ra = _load("ref_cls_attack_algo", "Classification/attack_algo.py")
+        _rr = _load("ref_cls_resnet_s", "Classification/resnet_s.py")
+
+        def _build(arch):
+            if arch == "resnet20s":
+                return _rr.ResNet(_rr.BasicBlock, [3, 3, 3]), 7, 16
+            if arch == "resnet56s":
+                return _rr.resnet56(), 13, 34
+            return _orc.resnet18_cifar(), 6, 15
+        gen_loss_floor(_ra, _build, _orc)
     elif sys.argv[1:] == ["roialign"]:    # only the ROIAlign vectors (the reference's own CPU kernel, compiled by oracle/Makefile)
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         os.makedirs(OUT, exist_ok=True)

@@ -193,6 +193,40 @@ def test_trajectory_with_warmup(orc):
     np.testing.assert_array_equal(_checks(model), g["ck"])
 
 
+def test_trajectory_contractive_resnet18(orc):
+    """traj_r18_damped.npz (gen_golden.py lossfloor: the reference's PGD and loop body on the contractive ResNet-18, three warm-up
+    iterations at batch 32, K = 5): the oracle's restatement lands on the same losses and the same state fingerprint, bit for bit."""
+    g = golden("traj_r18_damped")
+    torch.manual_seed(3)
+    model = orc.resnet18_cifar()
+    for m in model.modules():
+        if isinstance(m, orc.Block):
+            m.bn2.weight.data.mul_(float(g["damp"]))
+    model.train()
+    np.testing.assert_array_equal(_checks(model), g["ck0"])
+    opt = orc.make_optimizer(model)
+    xs, ys = torch.from_numpy(g["xs"]), torch.from_numpy(g["ys"])
+    losses = []
+    for i in range(3):
+        assert orc.warmup_lr(i, opt, int(g["wp"]), 0.1) == float(g["lrs"][i])
+        r = orc.afan_train_step(model, opt, nn.CrossEntropyLoss(), xs[i], ys[i], steps=5, gamma=0.5, eps=2.0, perturb_idx=6,
+                                layer_number=15)
+        losses.append(float(r["loss"]))
+    np.testing.assert_array_equal(np.array(losses), g["losses"])
+    np.testing.assert_array_equal(_checks(model), g["ck1"])
+
+
+def test_loss_floor_file_covers_the_cases_the_gpu_tests_bound():
+    f = golden("ref_loss_floor")
+    for case in ("step_r18_k5", "step_r56s_k5", "step_r18_k5_b16", "step_r56s_k5_b16", "step_r20s_k5", "step_r20s_k5_clip",
+                 "step_r18_k5_b32_damped"):
+        for key in ("loss", "loss_adv", "loss_clean"):
+            v = float(f[f"{case}/{key}/spread"])
+            assert 0.0 <= v < 5e-3, (case, key, v)
+    assert f["traj_r20s/loss/spread"].shape == (3,) and f["traj_r18_damped/loss/spread"].shape == (3,)
+    assert float(f["traj_r18_damped/loss/spread"].max()) < 5e-5          # the contractive trajectory: held at 1e-4 per iteration
+
+
 @pytest.mark.parametrize("case", ["pgd_trace_r20s_k3", "pgd_trace_r20s_k3_clip", "pgd_trace_r18_k5"])
 def test_pgd_step_kernels_python_and_c(orc, c_oracle, case):
     """x_adv(t+1) from x_adv(t) and the reference's gradient: python restatement and C restatement, bit-exact."""
