@@ -733,12 +733,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // tile by DMA — no registers, in flight while the accumulators are rounded into C; the barrier below drains it)
     uint16_t* const Z = lds + BM * LDC;
     // (not in the 768-thread variant: at its 168-register cap the third sum's state spills in the prefetch phase; launch_gs refuses)
-    constexpr bool BSC_OK = BF && !(THREADS > 512 && BN >= 128);
+    constexpr bool BSC_OK = BF;
     bool have_bsc = false;
+    __shared__ float zmean_s[BF ? BN : 1];       // (BF) the projection BatchNorm's mean per tile column (registers are short in the row loop)
     unsigned bar_target = 0;                     // (BF) this launch's barrier episode, asked for here: long before thread 0 needs it
     if constexpr (BF) {
         if (tid == 0) bar_target = grid_episode(pp.bar);
         have_bsc = BSC_OK && pp.bnf == 2 && pp.bsc.x != nullptr;
+        if (have_bsc && tid < BN) zmean_s[tid] = n0 + tid < pp.Co ? pp.bsc.stats[n0 + tid] : 0.f;
         if (have_bsc) {
             constexpr int PIECES_Z = BN / 8, NZ = BM * BN * 2 / 1024;
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(
@@ -799,6 +801,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool grp_first = grp == 0 ? m0 == 0 : (straddle || m0 == half);     // this tile holds the group's first row
     const bool dual = pp.aff && pp.aff_bwd == 2;
     u32x4 pre_a[EPI_ROWS], pre_x[EPI_ROWS], pre_y[EPI_ROWS];      // (pre_x: the BN input — or, dual form (never both), the addend)
+    uint32_t ymask[(EPI_ROWS + 3) / 4];
     {
         const int out_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
         const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(addp), 0, addp ? out_bytes : 0, 0x00020000);
@@ -810,10 +813,40 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             const int r_ = pr + q * ROWS_PER_PASS;
             const int off = (epi_on && (!straddle || ((m0 + (uint32_t)r_ >= half) == (grp == 1)))) ? out_off[r_] : -1;
             const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
-            if (addp) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
+            if (addp && !(BF && EPI_ROWS >= 8)) pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
             if (dual && pp.addend) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, (int)bo, 0, 0));
             else if (bn_bwd) pre_x[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bxr, (int)bo, 0, 0));
             if (bn_bwd && pp.bny) pre_y[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(byr, (int)bo, 0, 0));
+        }
+        // (BF: the stored-output mask as bits.  The 8-rows-per-thread tile (768 threads at their 168-register cap) cannot keep three
+        // prefetched operand tiles through the row loop: the output tile and the BatchNorm input are requested first, the mask is
+        // taken from the output tile as soon as it is in, and only then the other branch's gradient is requested into its place)
+#pragma unroll
+        for (int q4 = 0; q4 < (EPI_ROWS + 3) / 4; ++q4) ymask[q4] = 0u;
+        if constexpr (BF) {
+            if (bn_bwd && pp.bny) {
+                if (EPI_ROWS >= 8) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < EPI_ROWS; ++q) {
+                    const u16x8 yv = __builtin_bit_cast(u16x8, pre_y[q]);
+                    uint32_t m = 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m |= (bf2f(yv[j]) > 0.f ? 1u : 0u) << j;
+                    ymask[q / 4] |= m << (8 * (q % 4));
+                }
+                if (EPI_ROWS >= 8) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (EPI_ROWS >= 8) {
+                if (addp) {
+#pragma unroll
+                    for (int q = 0; q < EPI_ROWS; ++q) {
+                        const int r_ = pr + q * ROWS_PER_PASS;
+                        const int off = epi_on ? out_off[r_] : -1;
+                        const uint32_t bo = (off >= 0 && ch_ok) ? (uint32_t)(off + n0 + pc * 8) * 2u : OOB;
+                        pre_a[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, (int)bo, 0, 0));
+                    }
+                }
+            }
         }
     }
     // Optional fusions on the way out (same LDS reads as the stores):
@@ -823,30 +856,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const float* bn_stats = pp.bn_stats ? pp.bn_stats + (int64_t)grp * 4 * pp.Co : nullptr;
     double* acc_blk = pp.acc ? pp.acc + pp.acc_off[blockIdx.z] + (int64_t)grp * pp.acc_stride : nullptr;
     float s1[8], s2[8], sh[8], al[8], be[8];
-    // (BF: the stored-output mask as bits — the 768-thread variant has no registers to keep the prefetched output tile, the
-    // BatchNorm input tile AND the other branch's gradient through the row loop: 73 scratch accesses in its epilogue otherwise)
-    uint32_t ymask[(EPI_ROWS + 3) / 4];
+    float s3[8];                                                  // (BF, projection shortcut's BatchNorm: third sum; its mean: zmean_s)
 #pragma unroll
-    for (int q4 = 0; q4 < (EPI_ROWS + 3) / 4; ++q4) ymask[q4] = 0u;
-    if constexpr (BF) {
-        if (bn_bwd && pp.bny) {
-#pragma unroll
-            for (int q = 0; q < EPI_ROWS; ++q) {
-                const u16x8 yv = __builtin_bit_cast(u16x8, pre_y[q]);
-                uint32_t m = 0u;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) m |= (bf2f(yv[j]) > 0.f ? 1u : 0u) << j;
-                ymask[q / 4] |= m << (8 * (q % 4));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);                        // (the output tile's registers are free before the next values are born)
-    }
-    float s3[8], shz[8];                                          // (BF, projection shortcut's BatchNorm: third sum, its mean)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s3[j] = 0.f;
-        shz[j] = (BF && have_bsc) ? pp.bsc.stats[ch_ok ? n0 + pc * 8 + j : 0] : 0.f;
-    }
+    for (int j = 0; j < 8; ++j) s3[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
@@ -926,7 +938,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     if (have_bsc) {
                         const u16x8 zv = *reinterpret_cast<const u16x8*>(Z + r * BN + pc * 8);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) s3[j] += bf2f(v[j]) * (bf2f(zv[j]) - shz[j]);
+                        for (int j = 0; j < 8; ++j) s3[j] += bf2f(v[j]) * (bf2f(zv[j]) - zmean_s[pc * 8 + j]);
                     }
                 }
             } else if (want_stats) {
@@ -1178,7 +1190,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                             const u16x8 zv = *reinterpret_cast<const u16x8*>(Z + r * BN + pc * 8);
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                o[j] = f2bf(fmaf(bf2f(v[j]), pp.bsc.stats[2 * pp.Co + n0 + pc * 8 + j], fmaf(bf2f(zv[j]) - shz[j], k2[j], k3[j])));
+                                o[j] = f2bf(fmaf(bf2f(v[j]), pp.bsc.stats[2 * pp.Co + n0 + pc * 8 + j], fmaf(bf2f(zv[j]) - zmean_s[pc * 8 + j], k2[j], k3[j])));
                             *reinterpret_cast<u16x8*>(pp.bsc.y3 + go) = o;
                         }
                     }
@@ -1243,7 +1255,6 @@ int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
             max_resident = cus * (of < od ? of : od);
         }
         if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
-        if (p.bsc.x && THREADS > 512 && BN >= 128) return AFAN_ESHAPE;   // (no projection-BatchNorm form in the 768-thread x 128-column variant)
         if ((int64_t)grid.x * grid.y * grid.z > max_resident || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
             p.n_classes != 1)
             return AFAN_ESHAPE;
