@@ -191,6 +191,7 @@ def pmc_traffic(kernel_name, arch):
     """HBM bytes per launch (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes: the guide's gfx950 correction) of `kernel_name` from the
     newest profiles/*_pmc_hbm_traffic*.json collected on THIS workload (its `_meta.command` names the same --arch; summaries
     without `_meta` predate round 2 and count as the default workload) that has it; (bytes, source file, stale?, command) or None."""
+    kernel_name = kernel_name.replace("conv_bn_", "conv_igemm_")      # (the traffic summaries key the tiled kernel by its symbol)
     base = kernel_name.replace("_fwd_kernel", "_kernel").replace("_dgrad_kernel", "_kernel")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), reverse=True):
         try:
@@ -223,7 +224,10 @@ def pmc_mfma(kernel_name, arch):
         f_arch = cmd.split("--arch", 1)[1].split()[0] if "--arch" in cmd else "resnet18"
         if f_arch != arch:
             continue
-        vs = [(k, e) for k, e in pmc.items() if not k.startswith("_") and k.split("<")[0] == kernel_name and e.get("mfma_util") is not None]
+        # "conv_bn_*" = the tiled kernel's instantiations with the in-launch BatchNorm (last template argument true)
+        fused, base = kernel_name.startswith("conv_bn_"), kernel_name.replace("conv_bn_", "conv_igemm_")
+        vs = [(k, e) for k, e in pmc.items() if not k.startswith("_") and k.split("<")[0] == base and e.get("mfma_util") is not None
+              and (k.endswith(",true>") == fused or k.count(",") < 9)]
         n = sum(e["launches"] for _, e in vs)
         if n:
             w = lambda key: round(sum((e.get(key) or 0.0) * e["launches"] for _, e in vs) / n, 4)

@@ -28,9 +28,6 @@
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
-#ifndef AFAN_CONV_HPIPE
-#define AFAN_CONV_HPIPE 0        // halo form: operand fragments requested one group (two k16-slices) ahead of their MFMAs, across the barrier (0: A/B)
-#endif
 #ifndef AFAN_CONV_FRAG_BATCH
 #define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
 #endif
@@ -119,6 +116,15 @@ __device__ __forceinline__ double ld_total(const __amdgpu_buffer_rsrc_t& r, int 
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(double, (u32x2)__builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16));
 }
+
+// halo form, producer side: the next chunk's KG halo groups per producer wave ride with the first seven taps; BR weight DMAs per tap
+template <int KG, int BR> struct HaloSched {
+    static constexpr int s(int t) { return (t < 0 || t >= 7) ? 0 : KG / 7 + (t < KG % 7 ? 1 : 0); }          // groups behind tap t
+    static constexpr int g0(int t) { int g = 0; for (int i = 0; i < t; ++i) g += s(i); return g; }            // first group of tap t
+    // instructions of the issue slot behind tap tp's barrier (tp < 0: a slot of the chunk before, or of the prologue: weights only)
+    static constexpr int slot(int tp, bool more) { return tp < 0 ? BR : ((tp + 3 < 9 || more) ? BR : 0) + (more ? s(tp) : 0); }
+    static constexpr int wait(int t, bool more) { return slot(t - 1, more) + slot(t - 2, more); }             // may stay in flight at tap t's wait
+};
 
 // PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
 // the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
@@ -359,7 +365,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         static_assert(PW == 4 && GLDS && NS == 4, "halo form: FOUR producer waves (hdma's group index is k * 4 + swave), four weight stages");
         // a chunk's halo is issued two groups (of 8 pixels per producer wave: 64 pixels) per K-step from t = 0 and must be complete
         // before the next chunk's first tile waits with vmcnt(2 * LPT): all groups issued by t <= 6, i.e. at most 7 x 64 pixels
-        static_assert(HL <= 448, "halo form: the next chunk's halo must be issued within 7 K-steps (2 groups x 4 waves x 8 pixels each)");
+        static_assert(HL <= 448, "halo form: the next chunk's halo must be issued within 7 K-steps (at most 2 groups x 4 waves x 8 pixels each)");
         constexpr int HPM = HL;                              // pixels per halo buffer
         uint16_t* const Hbase = lds + NS * STAGE;            // two halo buffers of HPM x 64 channels
         uint16_t* const pad_zone = Hbase + 2 * HPM * BK;     // 1 KiB landing zone for the padding DMAs (below)
@@ -408,7 +414,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #endif
         __syncthreads();                                      // htab (and out_off) are written
 
-#if !AFAN_CONV_HPIPE
         auto compute_h = [&](int buf, int hb, int tjt, int tvt) {
             const uint16_t* B = lds + buf * STAGE;
             const uint16_t* Hh = Hbase + hb * (HPM * BK);
@@ -445,49 +450,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 if (FB > 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
-#endif
 
-        // ---- software-pipelined form of the same products (AFAN_CONV_HPIPE).  Per-tap stamps of the loop above (tools/probe/
-        // conv_stamps.py, profiles/r05b_conv_stamps.txt) showed where a tap's cycles went: after each barrier every MFMA wave requested
-        // its fragments and waited for the first of them with the matrix pipe idle (12 reads + ~150 cycles of LDS latency in front of 8
-        // MFMAs = 256 cycles: 610 cycles per tap for the one-wave-per-SIMD tiles), then all waves met again.  Here a tap's fragments are
-        // requested in two groups of two k16-slices, each ONE GROUP AHEAD of its MFMAs: the second group at the top of the tap, the
-        // next tap's first group — from the next weight tile, which the producers now have in LDS one barrier earlier (they leave
-        // one tile in flight instead of two), and from the resident halo — between the tap's two MFMA groups.  Behind a barrier the
-        // matrix pipe starts at once.  The products are added in the same order: the same bits.
-#if AFAN_CONV_HPIPE
-        constexpr int PB = 2;                                  // k16-slices per group (two groups per tap: static register sets)
-        auto load_h = [&](int buf, int hb, int tjt, int tvt, int g, bf16x8 (&fx)[PB][MI], bf16x8 (&fw)[PB][NI]) {
-            const uint16_t* B = lds + buf * STAGE;
-            const uint16_t* Hh = Hbase + hb * (HPM * BK);
-            const int frow = lane & 31;
-            const int sw = (frow >> 1) & 7;
-#pragma unroll
-            for (int b = 0; b < PB; ++b) {
-                const int c2 = (g * PB + b) * 2 + (lane >> 5);
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    fx[b][i] = *reinterpret_cast<const bf16x8*>(Hh + (jrow[i] + tjt) * BK + ((c2 ^ (((vrow[i] + tvt) >> 1) & 7)) * 8));
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    fw[b][j] = *reinterpret_cast<const bf16x8*>(B + (wc * TN + j * 32 + frow) * LDR + ((c2 ^ sw) * 8));
-            }
-        };
-        auto mfma_h = [&](const bf16x8 (&fx)[PB][MI], const bf16x8 (&fw)[PB][NI]) {
-#pragma unroll
-            for (int b = 0; b < PB; ++b)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b][j], fx[b][i], acc[j][i], 0, 0, 0);
-        };
-#endif
-
-        // Every K-step's issue is exactly LPT = B_ROWS + 2 DMA instructions per producer wave (the counted vmcnt waits
-        // need a fixed number): the weight tile and two halo groups of the NEXT chunk; a slot with no group left is a
-        // DMA of zeros into the landing zone.
-        constexpr int LPT = B_ROWS + 2;
+        // (Round 5 tried the fragments one group AHEAD of their MFMAs, across the barrier — the next weight tile in LDS one barrier
+        // earlier, address arithmetic and requests interleaved into the MFMA shadows with sched_group_barrier: per-tap stamps,
+        // tools/probe/conv_stamps.py, profiles/r05b_conv_stamps_baseline.txt / r05c_conv_stamps_hpipe2.txt, showed the MFMA waves'
+        // share of a tap falling 1010 -> 835, 724 -> 600, 610 -> 529 cycles while the launches kept their time: the tap period of the
+        // 64-column tiles is set by the producers' DMA issue, and with one tile less in flight the step's cold weights cost more
+        // than the waves gained: 9.0-9.2 ms against 8.66.  Not kept; what the stamps did pay for is the schedule below.)
+        //
+        // Issue slots: behind tap t's barrier a producer wave issues the weight tile three taps ahead (B_ROWS DMAs) and
+        // HaloSched::s(t) halo groups of the NEXT chunk; a group index beyond this tile's groups is a DMA of zeros into the landing
+        // zone (the counted waits need compile-time instruction counts).
         uint32_t b_vo[B_ROWS];
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) b_vo[i] = RPP * i < b_rows_ok ? b_off + i * b_row32 : OOB;
@@ -507,85 +480,41 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             for (int i = 0; i < B_ROWS; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lptr)(Bd + i * (RPP * 64)), 16, (int)b_vo[i], wo2 + q * (BK * 2), 0, 0);
         };
+        // The next chunk's halo rides with the first seven taps of this one: KG = ceil(HL / 32) groups per producer wave, s(t) of
+        // them behind tap t's weight tile (round 4 issued two per tap on all nine taps and filled the unused slots with padding DMAs
+        // of zeros to keep the counted waits fixed: 36 DMA instructions per wave and chunk for 26-31 of payload — and the per-tap
+        // stamps of round 5, profiles/r05b_conv_stamps_baseline.txt, show the producers' DMA issue, ~130 cycles per instruction
+        // through the CU's one address path, setting the tap period of the 64-column tiles).  The counted waits take each tap's own
+        // instruction count — compile-time constants of the unrolled tap index.
+        typedef HaloSched<(HL + 31) / 32, B_ROWS> HS;
         if (producer) {
             for (int k = 0; k * 4 < G; ++k) hdma(0, k, 0);     // chunk 0's halo (older than every counted instruction)
 #pragma unroll
-            for (int s = 0; s < NS - 1; ++s) {
-                bdma(s, two[s], 0);
-                hdma(0, 1 << 20, 0);                           // (group index beyond G: padding DMA)
-                hdma(0, 1 << 20, 0);
-            }
+            for (int s = 0; s < NS - 1; ++s) bdma(s, two[s], 0);
             for (int q = 0; q < chunks; ++q) {
                 const bool more = q + 1 < chunks;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    // tiles after (q, t): min(that, 2) of them are in flight behind it
-                    AFAN_STAMP(1, q * 9 + t, 0);
-#if AFAN_CONV_HPIPE
-                    // (pipelined fragments: tile (q, t) + 1 must be in LDS as well — the MFMA waves request it during tap (q, t) —
-                    // so only the newest tile stays in flight behind the wait)
-                    if (t <= 6 || more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
-                    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-#else
-                    if (t <= 6 || more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT * 2));
-                    else if (t == 7) __builtin_amdgcn_s_waitcnt(vmcnt_imm(LPT));
-                    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-#endif
-                    AFAN_STAMP(1, q * 9 + t, 1);
+                    // tiles after (q, t): the two newest issue slots may still be in flight behind the wait
+                    switch (t) {                               // (the builtin wants literal constants: t is one after unrolling)
+#define AFAN_HS_WAIT(T) case T: if (more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(HS::wait(T, true))); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(HS::wait(T, false))); break;
+                        AFAN_HS_WAIT(0) AFAN_HS_WAIT(1) AFAN_HS_WAIT(2) AFAN_HS_WAIT(3) AFAN_HS_WAIT(4) AFAN_HS_WAIT(5) AFAN_HS_WAIT(6) AFAN_HS_WAIT(7)
+                        AFAN_HS_WAIT(8)
+#undef AFAN_HS_WAIT
+                    }
                     __builtin_amdgcn_s_barrier();              // tile (q, t) is in LDS for everyone; the buffer of the tile before is free
-                    AFAN_STAMP(1, q * 9 + t, 2);
                     const int nb = (q + t + 3) & 3;            // 9 = 1 (mod 4): tile 9 q + t lives in weight buffer (q + t) & 3
-                    if (t + 3 < 9 || more) {
-                        bdma(nb, two[(t + 3) % 9], t + 3 < 9 ? q : q + 1);
-                        // chunk q + 1's halo goes into the buffer chunk q - 1 used (free since this chunk's first barrier),
-                        // two groups per K-step from t = 0: issued by t = 6 at the latest (HPM <= 448, asserted above; 400 pixels: t = 6), complete at chunk q + 1's first wait
-                        hdma((q + 1) & 1, more ? 2 * t : 1 << 20, q + 1);
-                        hdma((q + 1) & 1, more ? 2 * t + 1 : 1 << 20, q + 1);
+                    if (t + 3 < 9 || more) bdma(nb, two[(t + 3) % 9], t + 3 < 9 ? q : q + 1);
+                    // chunk q + 1's halo goes into the buffer chunk q - 1 used (free since this chunk's first barrier); all of it is
+                    // issued by tap 6, i.e. complete at chunk q + 1's first wait (which leaves the slots of taps 7 and 8 in flight)
+                    if (more) {
+#pragma unroll
+                        for (int j = 0; j < HS::s(t); ++j) hdma((q + 1) & 1, HS::g0(t) + j, q + 1);
                     }
                 }
             }
-        } else {
-#if AFAN_CONV_HPIPE
-            bf16x8 fx0[PB][MI], fw0[PB][NI], fx1[PB][MI], fw1[PB][NI];
-            __builtin_amdgcn_s_barrier();                      // tiles 0 and 1 and chunk 0's halo are in LDS
-            load_h(0, 0, tj[0], tv[0], 0, fx0, fw0);
-            for (int q = 0; q < chunks; ++q) {
-                const bool more = q + 1 < chunks;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    AFAN_STAMP(0, q * 9 + t, 1);
-                    load_h((q + t) & 3, q & 1, tj[t], tv[t], 1, fx1, fw1);
-                    mfma_h(fx0, fw0);
-                    __builtin_amdgcn_sched_barrier(0);          // (set 0 is rewritten below: its MFMAs stay above)
-                    if (t < 8 || more)                          // the next tap's first group: tile k + 1 landed with this tap's barrier
-                        load_h((q + t + 1) & 3, t < 8 ? (q & 1) : ((q + 1) & 1), tj[(t + 1) % 9], tv[(t + 1) % 9], 0, fx0, fw0);
-                    mfma_h(fx1, fw1);
-#if AFAN_CONV_HPIPE >= 2
-                    // the issue order inside each half of the tap: one MFMA, then the address arithmetic and fragment requests that
-                    // fit its 32-cycle shadow (the compiler's own order runs the requests, then the MFMAs, then ~20 address
-                    // instructions with the matrix pipe idle: 600 cycles per tap for 256 of MFMA on the one-wave-per-SIMD tiles)
-#pragma unroll
-                    for (int hg = 0; hg < 2; ++hg) {
-#pragma unroll
-                        for (int m = 0; m < PB * NI * MI; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x002, (PB * (MI + NI) * 5 + PB * NI * MI - 1) / (PB * NI * MI), 0);   // VALU
-                            __builtin_amdgcn_sched_group_barrier(0x100, (PB * (MI + NI) + PB * NI * MI - 1) / (PB * NI * MI), 0);       // DS read
-                        }
-                        if (hg == 0) __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    AFAN_STAMP(0, q * 9 + t, 2);
-                    if (t < 8 || more) {
-                        AFAN_STAMP(0, q * 9 + t + 1, 0);
-                        __builtin_amdgcn_s_barrier();
-                    }
-                }
-            }
-#else
+        } else
+        {
             for (int q = 0; q < chunks; ++q) {
                 // (opaque per chunk: otherwise the nine taps' fragment addresses are hoisted out of the chunk loop as
                 // 40-odd loop-invariant registers, which the 168-register variant spills)
@@ -600,7 +529,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     AFAN_STAMP(0, q * 9 + t, 2);
                 }
             }
-#endif
         }
         __syncthreads();
 #ifdef AFAN_CONV_STAMP
@@ -1490,7 +1418,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
         p.bnf_inv_m = 1.0 / ((double)n * hi * wi);
     }
     const double bytes = 2.0 * ((double)n * ho * wo * co + (double)n * hi * wi * ci + (double)co * k * k * ci);
-    AFAN_PROF_FLOPS("conv_igemm_dgrad_kernel", bytes + (dy_sc ? 2.0 * ((double)n * ho * wo * co + (double)co * ci) : 0.0),
+    AFAN_PROF_FLOPS(bnf ? "conv_bn_dgrad_kernel" : "conv_igemm_dgrad_kernel", bytes + (dy_sc ? 2.0 * ((double)n * ho * wo * co + (double)co * ci) : 0.0),
                     2.0 * (double)n * ho * wo * co * (k * k + (dy_sc ? 1 : 0)) * ci, st);
     p.in_s = 1;
     if (!dy_sc && !bn_partials && groups <= 1 && dilation == 1 && afan_c64::eligible(n, hi, wi, co, ci, k, stride)) {
@@ -1866,7 +1794,8 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
     }
     if (small_eligible(p) || afan_c64::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", 2.0 * ((double)M * co * (p.bnf_res ? 3 : 2) + (double)M * ci + (double)co * 9 * ci),
+    // (its own label: the launch does the convolution's FLOPs AND the BatchNorm's passes — bench.py prices it separately)
+    AFAN_PROF_FLOPS("conv_bn_fwd_kernel", 2.0 * ((double)M * co * (p.bnf_res ? 3 : 2) + (double)M * ci + (double)co * 9 * ci),
                     2.0 * (double)M * co * 9 * ci, st);
     return dispatch_bnf(p, st, false);
 }

@@ -196,14 +196,17 @@ def test_tiled_convolution_kernels_use_no_scratch():
     import re
     import subprocess
     import tempfile
-    src = os.path.join(ROOT, "cv_a-fan_amd", "csrc", "afan_conv.hip")
-    with tempfile.NamedTemporaryFile(suffix=".s") as f:
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w", "-S",
-                        "--cuda-device-only", "-o", f.name, src], check=True)
-        isa = open(f.name).read()
-    kernels = re.findall(r"\.set (\S+)\.private_seg_size, (\d+)", isa)
-    assert len(kernels) > 40
-    assert [k for k in kernels if int(k[1]) > 0] == []
+    # ... and the instantiations with the in-launch BatchNorm (afan_conv_bnf.hip, round 5): their epilogues hold three prefetched
+    # operand tiles and a third column sum — the 768-thread x 128-column one spilled until its prefetch went two-phase
+    for name, least in (("afan_conv.hip", 40), ("afan_conv_bnf.hip", 10)):
+        src = os.path.join(ROOT, "cv_a-fan_amd", "csrc", name)
+        with tempfile.NamedTemporaryFile(suffix=".s") as f:
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w", "-S",
+                            "--cuda-device-only", "-o", f.name, src], check=True)
+            isa = open(f.name).read()
+        kernels = re.findall(r"\.set (\S+)\.private_seg_size, (\d+)", isa)
+        assert len(kernels) >= least, (name, len(kernels))
+        assert [k for k in kernels if int(k[1]) > 0] == [], name
 
 
 def test_detection_bottleneck_copies_without_its_launch_plans(pkg):

@@ -31,6 +31,9 @@ for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)
               f"loop {(m[-1, 2] - m[0, 0])} cycles = {(m[-1, 2] - m[0, 0]) / taps:.0f} per tap")
         mw, mc = m[:, 1] - m[:, 0], m[:, 2] - m[:, 1]
         gap = np.concatenate([[0], m[1:, 0] - m[:-1, 2]])
+        if not p.any():
+            print(f"   MFMA wave:  barrier wait mean {mw[1:].mean():.0f}, reads+MFMA issue mean {mc.mean():.0f} (producer stamps: only in the AFAN_CONV_HPIPE build)")
+            continue
         pw, pb = p[:, 1] - p[:, 0], p[:, 2] - p[:, 1]
         pi = np.concatenate([p[1:, 0] - p[:-1, 2], [0]])
         print(f"   MFMA wave:  barrier wait mean {mw.mean():.0f} (min {mw.min()} max {mw.max()}), reads+MFMA issue mean {mc.mean():.0f} (min {mc.min()} max {mc.max()}), between {gap.mean():.0f}")
