@@ -447,6 +447,9 @@ def main():
     loss = float(r["loss"])
     assert loss == loss, "loss is NaN"
     step_ms = dt / args.steps * 1e3
+    # the convolution + BatchNorm launches meet at a grid-wide barrier whose spin is bounded: a spin that gave up (workgroups of a
+    # launch not co-resident) invalidates everything after it — fail loudly rather than print a number
+    assert not pkg.ops.grid_barrier_error(dev), "a grid barrier of the in-launch BatchNorm gave up (another process's kernels on this GPU?)"
 
     # ---- instrumented pass (not part of `value`): per-launch HIP-event timing of the hand-written kernels ----
     roof, kernels, conv_exec, hbm = None, None, None, None
@@ -628,6 +631,8 @@ def main():
                        "final_loss": round(loss, 4), "hipgraph": graphed, "schedule": sched},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if not (seg or det):
+            line["config"]["in_launch_batchnorm"] = bool(pkg.ops.GRID_BN) and (pkg.ops.CALLS["conv_bn_fused"] > 0)
         if ranks_seen is not None:
             line["ranks_seen"] = ranks_seen
         if ddp_diag is not None:

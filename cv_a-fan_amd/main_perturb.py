@@ -196,6 +196,10 @@ def train(train_loader, trainer, optimizer, epoch, args, log):
                 "Loss {loss.val:.4f} ({loss.avg:.4f})\t"
                 "Accuracy {top1.val:.3f} ({top1.avg:.3f})\t".format(epoch, i, len(train_loader), loss=losses, top1=top1))
     flush()
+    _ops = train_step.ops
+    if _ops.grid_barrier_error():      # (one read per epoch, behind the epoch's last sync)
+        raise _ops.AfanLibraryError("a grid barrier of the in-launch BatchNorm gave up during this epoch (another process's kernels "
+                                    "on this GPU?): results are invalid; rerun with AFAN_GRID_BN=0")
     norm_mean_l2 = torch.mean(torch.cat(norm_l2, dim=0)).cpu()
     norm_mean_linf = torch.mean(torch.cat(norm_linf, dim=0)).cpu()
     log("l2 mean = {}".format(norm_mean_l2))
