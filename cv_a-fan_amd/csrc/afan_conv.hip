@@ -61,9 +61,13 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // diagnostic build (tools/build_stamp.sh): per-tap cycle stamps of workgroup (0,0,0)'s first MFMA wave and first producer wave in
 // the halo form, parked in LDS during the loop (a global store would join the producers' counted vmcnt) and written out once
 __device__ unsigned long long afan_stamps[2][96][3];
-#define AFAN_STAMP(role, idx, k) do { if (stamp_on && (idx) < 96) st_lds[role][idx][k] = __builtin_readcyclecounter(); } while (0)
+#define AFAN_STAMP(role, idx, k) do { if ((role) == 0 && stamp_on && (idx) < 96) st_lds[idx][k] = __builtin_readcyclecounter(); } while (0)
+// phases of the launch as thread 0 of workgroup (0,0,0) passes them: entry | K loop starts | K loop done | output tile in LDS | first
+// epilogue pass done | sums added | (in-launch BatchNorm: barrier passed | second pass done) | exit  -> afan_stamps[1][p][0]
+#define AFAN_PHASE(p) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) afan_stamps[1][p][0] = __builtin_readcyclecounter(); } while (0)
 #else
 #define AFAN_STAMP(role, idx, k) do { } while (0)
+#define AFAN_PHASE(p) do { } while (0)
 #endif
 
 // ---- grid-wide barrier for the in-launch BatchNorm (ConvP::bnf): every workgroup of the launch is resident (dispatch_bnf checks),
@@ -148,6 +152,7 @@ template <int KG, int BR> struct HaloSched {
 template <int BM, int BN, int PF, int WM, int WN, int PW = 0, int FBT = AFAN_CONV_FRAG_BATCH, int HL = 0, bool GS = false, bool BF = false>   // WM x WN waves: pixels x channels
 __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     static_assert(!(BF && GS), "in-launch BatchNorm: one image group");
+    AFAN_PHASE(0);
     constexpr int NW = WM * WN;
     constexpr int THREADS = 64 * (NW + PW);
     constexpr int STG = PW ? 64 * PW : THREADS;       // threads that stage operands
@@ -409,10 +414,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             vrow[i] = (int)m;
         }
 #ifdef AFAN_CONV_STAMP
-        __shared__ unsigned long long st_lds[2][96][3];
-        const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == NW);
+        __shared__ unsigned long long st_lds[96][3];
+        const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave == 0;
 #endif
         __syncthreads();                                      // htab (and out_off) are written
+        AFAN_PHASE(1);
 
         auto compute_h = [&](int buf, int hb, int tjt, int tvt) {
             const uint16_t* B = lds + buf * STAGE;
@@ -534,7 +540,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #ifdef AFAN_CONV_STAMP
         if (stamp_on)
             for (int i = 0; i < 96; ++i)
-                for (int k = 0; k < 3; ++k) afan_stamps[wave == 0 ? 0 : 1][i][k] = i < chunks * 9 ? st_lds[wave == 0 ? 0 : 1][i][k] : 0ull;
+                for (int k = 0; k < 3; ++k) afan_stamps[0][i][k] = i < chunks * 9 ? st_lds[i][k] : 0ull;
         __syncthreads();
 #endif
     } else if constexpr (PW > 0) {
@@ -654,6 +660,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         }
     }
 
+    AFAN_PHASE(2);
     // ---- epilogue: fp32 accumulators -> packed bf16 tile [pixel][channel] in LDS -> 16-byte channels-last stores ------
     constexpr int LDC = BN + 8;
     uint16_t* C = lds;  // BM x LDC elements <= 2 * STAGE
@@ -698,6 +705,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         }
     __syncthreads();
+    AFAN_PHASE(3);
     // The epilogue's own global reads (residual addend, BN input, BN output) are requested for all of this thread's
     // output rows before the first is used.  Buffer loads: a row outside the tensor, or a fusion that is off (zero
     // records), is an out-of-range offset — no divergent branch to serialise the requests.  (Requesting them before
@@ -879,6 +887,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         }
     }
+    AFAN_PHASE(4);
     float bf_shift = 0.f;
     if (want_stats) {
         // lanes l, l+PIECES, l+2*PIECES, ... of a wave hold the same 8 columns: butterfly over those, then over waves
@@ -949,6 +958,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         }
         if (n_pass > 1) __syncthreads();         // the second pass reuses the per-wave partial sums' LDS
+        AFAN_PHASE(5);
         if constexpr (BF) {
             // ---- the BatchNorm itself, inside this launch: every workgroup's sums are in the accumulators once all have passed the
             // barrier; each then derives the coefficients of its own BN channels from the totals (the expressions of apply_acc_kernel /
@@ -968,6 +978,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
             if (tid == 0) grid_wait(pp.bar, bar_target);
             __syncthreads();
+            AFAN_PHASE(6);
             float* cf = &red[0][0][0];                                // [4][BN] coefficients of the second pass (the partial sums are consumed)
             const bool have_sc = bf_fwd && pp.bnf_sc.acc != nullptr;
             if (tid < BN && n0 + tid < pp.Co) {
@@ -1124,9 +1135,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     }
                 }
             }
+            AFAN_PHASE(7);
         }
     }
     }   // group passes
+    AFAN_PHASE(8);
 }
 
 // The one body under two entry points, so that a kernel trace (rocprofv3 --kernel-trace --stats) separates the forward

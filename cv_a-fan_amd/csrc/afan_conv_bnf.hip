@@ -39,3 +39,10 @@ int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
 }
 
 }  // namespace afan_conv
+
+#ifdef AFAN_CONV_STAMP
+// diagnostic build only: this translation unit's copy of the stamps (tools/probe/conv_stamps.py)
+extern "C" int afan_conv_bnf_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(afan_stamps), sizeof(unsigned long long) * 2 * 96 * 3);
+}
+#endif

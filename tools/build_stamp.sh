@@ -4,7 +4,10 @@
 set -e
 cd "$(dirname "$0")/../cv_a-fan_amd/csrc"
 make -j4 > /dev/null
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAFAN_CONV_STAMP -c afan_conv.hip -o /tmp/afan_conv_stamp.o
-OBJS=$(ls *.o | grep -v '^afan_conv.o$')
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS /tmp/afan_conv_stamp.o -o ../../tools/probe/_bin/libafan_hip_stamp.so
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAFAN_CONV_STAMP"
+/opt/rocm/bin/hipcc $F -c afan_conv.hip -o /tmp/afan_conv_stamp.o &
+/opt/rocm/bin/hipcc $F -c afan_conv_bnf.hip -o /tmp/afan_conv_bnf_stamp.o &
+wait
+OBJS=$(ls *.o | grep -v '^afan_conv.o$' | grep -v '^afan_conv_bnf.o$')
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJS /tmp/afan_conv_stamp.o /tmp/afan_conv_bnf_stamp.o -o ../../tools/probe/_bin/libafan_hip_stamp.so
 ls -la ../../tools/probe/_bin/libafan_hip_stamp.so

@@ -41,3 +41,53 @@ for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)
         print("   tap: Mwait Mcomp | Pvmcnt Pbar Pissue")
         for i in range(min(taps, 20)):
             print(f"   {i:3d}: {mw[i]:6d} {mc[i]:6d} | {pw[i]:6d} {pb[i]:6d} {pi[i]:6d}   (M arrive {m[i,0]-base:7d}, P top {p[i,0]-base:7d})")
+
+
+# ---- phases of whole launches (thread 0 of workgroup 0): plain / with the BatchNorm's sums / with the BatchNorm inside the launch
+PH = ("entry", "K loop starts", "K loop done", "tile in LDS", "pass 1 done", "sums added", "barrier passed", "pass 2 done", "exit")
+
+
+def phases(fn, reader):
+    for _ in range(4):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * (2 * 96 * 3))()
+    assert reader(buf) == 0
+    s = np.array(buf, dtype=np.uint64).reshape(2, 96, 3).astype(np.int64)[1, :9, 0]
+    t0 = s[0]
+    have = [(PH[i], int(s[i] - t0)) for i in range(9) if s[i] >= t0 and (i == 0 or s[i] > 0)]
+    return e0.elapsed_time(e1) / 10 * 1e3, have
+
+
+class _BN:
+    def __init__(self, c):
+        self.weight, self.bias = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        self.running_mean, self.running_var = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        self.num_batches_tracked, self.eps = torch.zeros((), dtype=torch.int64, device=dev), 1e-5
+
+
+ops = pkg.ops
+for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)):
+    x = cl(torch.randn(n, ci, h, h, device=dev).bfloat16())
+    w = cl((torch.randn(co, ci, 3, 3, device=dev) * 0.05).bfloat16())
+    wt = cl(w.permute(1, 0, 2, 3))
+    dy = cl(torch.randn(n, co, h, h, device=dev).bfloat16())
+    res = cl(torch.randn(n, ci, h, h, device=dev).bfloat16())
+    bn = _BN(co)
+    y, stats = ops.bn_train_forward(x, bn.weight[:ci] if ci <= co else torch.ones(ci, device=dev), torch.zeros(ci, device=dev), None, True, 1e-5, 0.1, None, None, None)
+    print(f"== {ci}->{co} {h}x{h} batch {n}: phases in ticks from entry (thread 0 of workgroup 0), launch time eager")
+    for name, fn, rd in (
+            ("forward, plain", lambda: ops.conv_fwd(x, w, 1), lib.afan_conv_stamps),
+            ("forward + BatchNorm sums", lambda: (ops.acc_reset(dev), ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)), lib.afan_conv_stamps),
+            ("forward + BatchNorm in the launch", lambda: (ops.acc_reset(dev), ops.conv_fwd_bn(x, w, bn, 0.1, relu=True)), lib.afan_conv_bnf_stamps),
+            ("input gradient, plain", lambda: ops.conv_dgrad(dy, wt, (h, h), 1), lib.afan_conv_stamps),
+            ("input gradient + sums (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad(dy, wt, (h, h), 1, addend=res, bn_bwd=(x, stats, True), bn_y=y)), lib.afan_conv_stamps),
+            ("input gradient + BatchNorm backward in the launch (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad_bn(dy, wt, (h, h), x, stats, True, bn_y=y, addend=res, want_dres=True)), lib.afan_conv_bnf_stamps)):
+        us, ph = phases(fn, rd)
+        print(f"   {name:72s} {us:6.1f} us   " + "  ".join(f"{k} {v}" for k, v in ph[1:]))
