@@ -361,7 +361,7 @@ def main():
         model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
         # data parallel like the reference's nn.DataParallel (train_aug_sat_muti_advt.py:36): det_trainer.DetTrainer — replicas from
         # rank 0, the fp32 gradient arena summed tail first under the backbone's backward, 1/world in the SGD launch
-        trainer = pkg.det_trainer.DetTrainer(model, lr=0.001, momentum=0.9, weight_decay=0.0005, loss_settings=1)
+        trainer = pkg.det_trainer.DetTrainer(model, lr=0.001, momentum=0.9, weight_decay=0.0005, loss_settings=1, noise_ahead=True)
         side, ncls = (600, 904), 21
         xs, ys = [], []
         for _ in range(nbuf):
@@ -582,7 +582,8 @@ def main():
                      "(frozen-BatchNorm bottlenecks, BatchNorm in the convolution epilogues) replayed from hipGraphs forward and backward, "
                      "RPN / proposal / ROI heads launched eagerly (their shapes follow the proposals)"
                      if pkg.det_model._StageGraphs.ON and pkg.det_model._StageGraphs.cache else
-                     "train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling); eager launches")
+                     "train_aug_sat_muti_advt.py:70-172 as written (eight training forwards, host-side proposal sampling; the image PGD's host noise "
+                     "draw of iteration i + 1 issued behind iteration i's backward: the same generator stream); eager launches")
         elif seg:
             metric = f"images/sec (whole node) Segmentation A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}"
             workload = (f"{args.arch} output-stride 16, VOC-shape {side}x{side} synthetic, SE (layer3) + SD (aspp) feature PGD K="

@@ -29,14 +29,33 @@ def compute_loss(loss1, loss2, loss3, loss4):
     return loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()
 
 
-def _start(x, eps, randinit):
+class NoiseAhead:
+    """The image PGD's random start (:159: `torch.rand(x.shape)` on the CPU default generator, 1.6 M numbers for a 600 x 904 image:
+    2.5 ms of host time with the device idle behind it) drawn at the END of the previous iteration instead, while the device still
+    runs that iteration's backward.  The generator's stream is unchanged as long as the caller draws nothing from it between two
+    iterations (a synthetic loop, a loader with its own generator): the iteration's first draw IS this one.  Opt-in
+    (det_trainer.DetTrainer(noise_ahead=True)); `take(shape)` hands the stored draw back, or None."""
+
+    def __init__(self):
+        self.u = None
+
+    def draw(self, shape):
+        self.u = torch.rand(tuple(shape)).pin_memory()
+
+    def take(self, shape):
+        u, self.u = self.u, None
+        return u if (u is not None and tuple(u.shape) == tuple(shape)) else None
+
+
+def _start(x, eps, randinit, ahead=None):
     if x.device.type != "cuda":
         raise ops.AfanLibraryError("x must live on the MI355X (no CPU path in this build)")
     x = x.detach().float()
     x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))) else x.contiguous()
     x_adv = x.clone()
     if randinit:   # noise from the CPU default generator, then host -> device, like the reference (:52, :159)
-        u = torch.rand(x_adv.shape).to(x.device, non_blocking=True)
+        u = ahead.take(x_adv.shape) if ahead is not None else None
+        u = (u if u is not None else torch.rand(x_adv.shape)).to(x.device, non_blocking=True)
         if u.stride() != x_adv.stride():
             u = u.contiguous(memory_format=torch.channels_last)
         ops.axpy_noise_(x_adv, u, eps)
@@ -110,9 +129,9 @@ def rpn_roi_PGD(layer="roi", rpn_roi_output_dict=None, y=None, model=None, steps
     assert False
 
 
-def adv_input(x=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False):
+def adv_input(x=None, y=None, model=None, steps=3, eps=None, gamma=None, randinit=False, clip=False, noise_ahead=None):
     """:153-178: image-space PGD under the sum of the four losses, clamped to [0, 1] at the end."""
-    x, x_adv = _start(x, eps, randinit)
+    x, x_adv = _start(x, eps, randinit, noise_ahead)
     for _ in range(steps):
         _ascend(x_adv, lambda t: compute_loss(*model.train().forward({"x": t, "adv": None, "out_idx": -1, "flag": "clean"},
                                                                      y["bb"], y["lb"])), gamma, x, eps, clip)
@@ -128,7 +147,8 @@ def det_train_step(model, optimizer, image_batch, bboxes_batch, labels_batch, lo
     return out
 
 
-def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, out, *, loss_settings=1, cut=False, defer_step=False):
+def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, out, *, loss_settings=1, cut=False, defer_step=False,
+                     noise_ahead=None):
     """One iteration of Detection/train_aug_sat_muti_advt.py:70-172 as a generator: adversarial image (5 steps, randinit,
     clip), the three backbone feature maps and the ROI dict, three one-step feature PGDs (`multi-layer`), five SAT sample
     points of the deepest one with points 1 and 2 re-normalised by mix_feature (one fused launch), the one-step ROI feature
@@ -144,7 +164,8 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
     fwd = lambda d: model.train().forward(d, bboxes_batch, labels_batch)
     if hasattr(model, "begin_iteration"):
         model.begin_iteration()
-    adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+    adv_image = adv_input(x=image_batch, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True,
+                          noise_ahead=noise_ahead)
     col = None
     if getattr(model, "collects_head_features", False):
         # the three head passes (:78-80) and the clean ROI-head pass (:81) run the same backbone on the same images (frozen
@@ -199,6 +220,8 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
         live = [(f, c.grad) for f, c in cuts if c.grad is not None]
         if live:
             torch.autograd.backward([f for f, _ in live], [g for _, g in live])         # the backbone, every pass at once
+    if noise_ahead is not None:      # every draw of this iteration is behind us; the device is busy with the backward just issued
+        noise_ahead.draw(image_batch.shape)
     if not defer_step:
         optimizer.step()
     out.update({"loss": loss.detach(), "losses": torch.stack(L).detach(), "adv_image": adv_image.detach(), "adv1": adv1.detach(),

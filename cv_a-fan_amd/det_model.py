@@ -656,11 +656,18 @@ class RegionProposalNetwork(nn.Module):
         sel, _, lab, gt_deltas, bi = fg_bg_draw(lists, nf, nb, labels, assign, in_boxes, gt, 128 * b, 256 * b)
         return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
 
-    def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean"):
+    def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean", roi_targets=None):
         """`forward(...)` (training) followed by `generate_proposals(...)` — the order model.py:95-100 calls them in — with ONE host
         read for both: the anchor sampling's two list lengths and every image's NMS survivor count travel together (the label /
         list launches and the decode / sort / NMS launches are all queued before it).  The host's random draws keep their order
-        (the anchor sampling's three; the proposal layer draws nothing).  Returns (objectnesses, transformers, ce, sl1, proposals)."""
+        (the anchor sampling's three; the proposal layer draws nothing).  Returns (objectnesses, transformers, ce, sl1, proposals, roi_t)
+        with roi_t = None unless roi_targets is given.
+        roi_targets (round 5): the ROI head's own sampling (model.py:256-282) needs the proposals' labels' list lengths — a second host
+        read right behind this one.  Given `roi_targets(padded [B, top_n, 4], limit)` -> a pending object with `.counts` (device, [2])
+        and `.finish(nf, nb)`, the label / list launches of THAT sampling are queued on the padded proposals (rows at and beyond the
+        longest image's survivor count labelled -1, shorter images zero-padded like the reference's stack) before the one read, and its
+        three draws follow the anchor sampling's on the host generator, as in the reference: a sixth return value, 16 host reads per
+        iteration fewer."""
         trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
         objectnesses, transformers = self._heads(trunk)
         pend = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=True)
@@ -672,15 +679,27 @@ class RegionProposalNetwork(nn.Module):
             sb = boxes[b][order[b][:self._pre_nms_top_n]]
             keeps.append(nms(sb, None, 0.7, max_keep=self._post_nms_top_n, presorted=True, padded=True))
             cand.append(sb)
-        counts = torch.cat([pend[0][2]] + [c for _, c in keeps]).tolist()            # the one read
+        roi_pend, nb_img = None, len(keeps)
+        if roi_targets is not None:
+            P, dev = self._post_nms_top_n, boxes.device
+            ar = torch.arange(P, device=dev)
+            cnt = torch.stack([c.reshape(()) for _, c in keeps]).clamp(max=P)         # survivors per image (the scan may report up to 63 more)
+            rows = []
+            for i, (sb, (k, _)) in enumerate(zip(cand, keeps)):
+                kk = k[:P] if k.numel() >= P else torch.cat([k, k.new_zeros(P - k.numel())])
+                ok = ar < cnt[i]
+                rows.append(sb[torch.where(ok, kk, torch.zeros_like(kk)).clamp_(0, max(sb.shape[0] - 1, 0))] * ok[:, None])
+            roi_pend = roi_targets(torch.stack(rows), cnt.max())
+        counts = torch.cat([pend[0][2]] + [c for _, c in keeps] + ([roi_pend.counts] if roi_pend is not None else [])).tolist()   # the one read
         ce, sl1 = self._losses_finish(pend, counts[0], counts[1])
-        kept = [sb[k[:n]][:self._post_nms_top_n] for sb, (k, _), n in zip(cand, keeps, counts[2:])]
+        kept = [sb[k[:n]][:self._post_nms_top_n] for sb, (k, _), n in zip(cand, keeps, counts[2:2 + nb_img])]
         if len(kept) == 1:
             proposals = kept[0].unsqueeze(0)
         else:
             longest = max(len(k) for k in kept)
             proposals = torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
-        return objectnesses, transformers, ce, sl1, proposals.detach()
+        roi_t = roi_pend.finish(counts[2 + nb_img], counts[3 + nb_img]) if roi_pend is not None else None
+        return objectnesses, transformers, ce, sl1, proposals.detach(), roi_t
 
     def forward(self, features, anchor_bboxes=None, gt_bboxes_batch=None, image_width=None, image_height=None, return_type="clean"):
         if return_type == "head":
@@ -724,6 +743,19 @@ class RegionProposalNetwork(nn.Module):
             return kept[0].unsqueeze(0)
         longest = max(len(k) for k in kept)
         return torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
+
+
+class _RoiPending:
+    """The ROI head's sampling between its label / list launches and its draws (Detection._targets_pending)."""
+
+    def __init__(self, lists, labels, assign, padded, gt):
+        self.lists, self.labels, self.assign, self.padded, self.gt = lists, labels, assign, padded, gt
+        self.counts = lists[2]
+
+    def finish(self, nf, nb):
+        b = self.padded.shape[0]
+        _, boxes, lab, deltas, bi = fg_bg_draw(self.lists, nf, nb, self.labels, self.assign, self.padded, self.gt, 32 * b, 128 * b)
+        return boxes, lab, deltas, bi
 
 
 # --------------------------------------------------------------------------------------------------------------- pooler
@@ -879,7 +911,8 @@ class Model(nn.Module):
             d = input_dict["adv"]
             features, anchors = d["features"], d["anchor_bboxes"]
             iw, ih = _int_of(d["image_width"]), _int_of(d["image_height"])
-            obj, tr, ao, at, proposals = self.rpn.forward_and_propose(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail")
+            obj, tr, ao, at, proposals, roi_t = self.rpn.forward_and_propose(d["rpn_feature_map_dict"], anchors, gt_bboxes_batch, iw, ih, return_type="tail",
+                                                                             roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch))
         else:
             features = self._cut(self.features(input_dict))
             anchors, iw, ih = self._anchors(features, input_dict["x"].shape)
@@ -888,12 +921,21 @@ class Model(nn.Module):
                         "image_width": _int_tensor(iw, features.device), "anchor_bboxes": anchors,
                         "rpn_feature_map_dict": self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih, return_type="head")}
             assert type(idx) == int or idx == "roi_head"
-            obj, tr, ao, at, proposals = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih)
+            obj, tr, ao, at, proposals, roi_t = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih,
+                                                                             roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch))
         if idx == "roi_head":
             return {"anchor_objectness_losses": ao, "anchor_transformer_losses": at,
-                    "roi_output_dict": self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, return_type="head")}
-        _, _, pc, pt = self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch)
+                    "roi_output_dict": self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, return_type="head", targets=roi_t)}
+        _, _, pc, pt = self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, targets=roi_t)
         return ao, at, pc, pt
+
+    MERGE_READS = os.environ.get("AFAN_DET_MERGE_READS", "1") != "0"       # 0: the ROI head's sampling with its own host read (A/B, tests)
+
+    def _roi_targets(self, gt_classes_batch, gt_bboxes_batch):
+        if not Model.MERGE_READS:
+            return None
+        det = self.detection
+        return lambda padded, limit: det._targets_pending(padded, limit, gt_classes_batch, gt_bboxes_batch)
 
     class Detection(nn.Module):
         """model.py:231-367."""
@@ -925,7 +967,14 @@ class Model(nn.Module):
             _, boxes, lab, deltas, bi = fg_bg_sample(labels, assign, proposal_bboxes, gt_bboxes_batch, 32 * b, 128 * b)
             return boxes, lab, deltas, bi
 
-        def forward(self, features, proposal_bboxes=None, gt_classes_batch=None, gt_bboxes_batch=None, return_type="clean"):
+        def _targets_pending(self, padded, limit, gt_classes_batch, gt_bboxes_batch):
+            """The label / list launches of `_targets` on the PADDED proposals [B, top_n, 4] (rows >= limit = the longest image's survivor
+            count are no candidates: label -1), nothing read: the caller's one host read brings `.counts`, `.finish(nf, nb)` draws."""
+            labels, assign = box_assign(padded, gt_bboxes_batch, "proposal", 0.5, gt_classes=gt_classes_batch)
+            labels.masked_fill_((torch.arange(padded.shape[1], device=padded.device) >= limit)[None, :], -1)
+            return _RoiPending(sample_lists(labels), labels, assign, padded, gt_bboxes_batch)
+
+        def forward(self, features, proposal_bboxes=None, gt_classes_batch=None, gt_bboxes_batch=None, return_type="clean", targets=None):
             if return_type == "tail":
                 d = features
                 classes, transformers = self._linears(d["roi_feature_map"])
@@ -937,7 +986,7 @@ class Model(nn.Module):
                 bi = torch.arange(end=b, dtype=torch.long, device=proposal_bboxes.device).view(-1, 1).repeat(1, proposal_bboxes.shape[1])
                 classes, transformers = self._linears(self._roi_features(features, proposal_bboxes.view(-1, 4), bi.view(-1)))
                 return classes.view(b, -1, classes.shape[-1]), transformers.view(b, -1, transformers.shape[-1])
-            boxes, gt_classes, gt_deltas, bi = self._targets(proposal_bboxes, gt_classes_batch, gt_bboxes_batch)
+            boxes, gt_classes, gt_deltas, bi = targets if targets is not None else self._targets(proposal_bboxes, gt_classes_batch, gt_bboxes_batch)
             hidden = self._roi_features(features, boxes, bi)
             if return_type == "head":
                 return {"roi_feature_map": hidden, "gt_proposal_classes": gt_classes, "gt_proposal_transformers": gt_deltas,

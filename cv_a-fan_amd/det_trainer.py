@@ -24,7 +24,7 @@ UNUSED_PARAMS = ("features.fc.weight", "features.fc.bias")
 
 class DetTrainer:
     def __init__(self, model, *, lr=0.001, momentum=0.9, weight_decay=0.0005, loss_settings=1, group=None, allreduce_chunks=4,
-                 segmented=None, arena=None):
+                 segmented=None, arena=None, noise_ahead=False):
         import torch.distributed as dist
         self.model, self.loss_settings, self.group = model, int(loss_settings), group
         self.arena = arena if arena is not None else ParamArena(model, skip=UNUSED_PARAMS)
@@ -40,6 +40,10 @@ class DetTrainer:
             for b in model.buffers():
                 dist.broadcast(b, src=0, group=group)
             self.arena.refresh_shadow()
+        # the next iteration's image-PGD noise drawn behind this iteration's backward (det_attack_algo.NoiseAhead): same generator
+        # stream provided the caller draws nothing from the host generator between iterations
+        from .det_attack_algo import NoiseAhead
+        self.noise_ahead = NoiseAhead() if noise_ahead else None
         self.segmented = bool(segmented)        # True: run the two-part backward on one GPU too (tests)
         self._graph = None                      # (bench.py asks every trainer whether its step is a hipGraph replay)
 
@@ -57,7 +61,7 @@ class DetTrainer:
         if self.reducer is not None:
             self.reducer.begin(explicit=True)
         for ph in det_train_phases(self.model, self.optimizer, images, bboxes, labels, out, loss_settings=self.loss_settings,
-                                   cut=cut, defer_step=True):
+                                   cut=cut, defer_step=True, noise_ahead=self.noise_ahead):
             if ph == "tail" and self.reducer is not None:
                 self.reducer.launch_params(*rng)
         if self.reducer is not None:

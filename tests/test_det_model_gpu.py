@@ -404,3 +404,35 @@ def test_stage_activations_are_freed_with_their_graph(pkg, gpu):
         if was:
             gc.enable()
     assert held > base + (1 << 20) and after <= base, (base, held, after)
+
+
+def test_merged_sampling_reads_and_noise_ahead_change_no_bit(pkg, gpu):
+    """Round 5, host side of the Detection iteration: (a) the ROI head's sampling (model.py:256-282) queues its label / list launches
+    on the padded proposals before the RPN's one host read and takes its two list lengths from it (Model.MERGE_READS: 16 reads per
+    iteration fewer); (b) the image PGD's noise for iteration i + 1 is drawn behind iteration i's backward (DetTrainer(noise_ahead)).
+    Both leave the host generator's stream and every number alone: two iterations from the same state and seed, each form against the
+    plain one — losses, adversarial image and parameters identical bit for bit."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    M = pkg.det_model.Model
+    old = M.MERGE_READS
+    res = {}
+    try:
+        for merge, ahead in ((False, False), (True, False), (True, True)):
+            M.MERGE_READS = merge
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m, noise_ahead=ahead)
+            torch.manual_seed(77)
+            outs = []
+            for _ in range(2):
+                r = tr.step(images, bboxes, labels)
+                outs.append((r["losses"].clone(), r["adv_image"].clone()))
+            torch.cuda.synchronize()
+            res[(merge, ahead)] = (outs, tr.arena.param.clone())
+    finally:
+        M.MERGE_READS = old
+    base = res[(False, False)]
+    for key in ((True, False), (True, True)):
+        for (la, ia), (lb, ib) in zip(res[key][0], base[0]):
+            assert torch.equal(la, lb) and torch.equal(ia, ib), key
+        assert torch.equal(res[key][1], base[1]), key
