@@ -61,7 +61,7 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >>
 // diagnostic build (tools/build_stamp.sh): per-tap cycle stamps of workgroup (0,0,0)'s first MFMA wave and first producer wave in
 // the halo form, parked in LDS during the loop (a global store would join the producers' counted vmcnt) and written out once
 __device__ unsigned long long afan_stamps[2][96][3];
-#define AFAN_STAMP(role, idx, k) do { if ((role) == 0 && stamp_on && (idx) < 96) st_lds[idx][k] = __builtin_readcyclecounter(); } while (0)
+#define AFAN_STAMP(role, idx, k) do { if ((role) == 0 && stamp_on && (idx) < 72) st_lds[idx][k] = __builtin_readcyclecounter(); } while (0)   /* (72 taps fit the stamped build's LDS) */
 // phases of the launch as thread 0 of workgroup (0,0,0) passes them: entry | K loop starts | K loop done | output tile in LDS | first
 // epilogue pass done | sums added | (in-launch BatchNorm: barrier passed | second pass done) | exit  -> afan_stamps[1][p][0]
 #define AFAN_PHASE(p) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) afan_stamps[1][p][0] = __builtin_readcyclecounter(); } while (0)
@@ -237,6 +237,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             off = (int)(((n * pp.Ho + hg * pp.out_s + cc.out_h0) * pp.Wo + wg * pp.out_s + cc.out_w0) * pp.Co);
         }
         out_off[r] = off;
+    }
+    // The epilogue's per-channel coefficients (a BatchNorm's shift / mean, alpha, beta; a frozen BatchNorm's alpha, beta) are fetched
+    // HERE, into LDS: asked for at the top of the epilogue their ~1 us of load latency stood in front of its first pass in every
+    // launch that carries one of the fusions (launch-phase stamps, profiles/r05g_conv_launch_phases.txt: a 64-row 1x1 launch's first
+    // pass 3.5 k -> 6.9 k ticks).  (The one tile that straddles two image groups reads the second group's directly.)
+    __shared__ float coef_s[3][BN];
+    if (tid < BN) {
+        const bool ws_ = pp.stats != nullptr || pp.acc != nullptr, bb_ = ws_ && pp.bnx != nullptr;
+        const uint32_t half_ = pp.groups == 2 ? (uint32_t)(pp.N / 2) * Hg * Wg : 0u;
+        const float* bs_ = pp.bn_stats ? pp.bn_stats + (int64_t)((pp.groups == 2 && m0 >= half_) ? 1 : 0) * 4 * pp.Co : nullptr;
+        const float* sp_ = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
+        const int c = n0 + tid < pp.Co ? n0 + tid : 0;
+        coef_s[0][tid] = bb_ ? bs_[c] : ((ws_ && sp_) ? sp_[c] : 0.f);
+        coef_s[1][tid] = bb_ ? bs_[2 * pp.Co + c] : (pp.aff ? pp.aff[(pp.aff_bwd ? 0 : 2 * pp.Co) + c] : 0.f);
+        coef_s[2][tid] = bb_ ? bs_[3 * pp.Co + c] : ((pp.aff && !pp.aff_bwd) ? pp.aff[3 * pp.Co + c] : 0.f);
     }
     const uint32_t b_off = ((uint32_t)(n0 + row0) * w_row_stride + piece * 8) * 2u;
     const int b_rows_ok = pp.Co - n0 - row0;                      // weight row (row0 + RPP * i) exists iff RPP * i < b_rows_ok
@@ -414,7 +429,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             vrow[i] = (int)m;
         }
 #ifdef AFAN_CONV_STAMP
-        __shared__ unsigned long long st_lds[96][3];
+        __shared__ unsigned long long st_lds[72][3];
         const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave == 0;
 #endif
         __syncthreads();                                      // htab (and out_off) are written
@@ -540,11 +555,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #ifdef AFAN_CONV_STAMP
         if (stamp_on)
             for (int i = 0; i < 96; ++i)
-                for (int k = 0; k < 3; ++k) afan_stamps[0][i][k] = i < chunks * 9 ? st_lds[i][k] : 0ull;
+                for (int k = 0; k < 3; ++k) afan_stamps[0][i][k] = (i < chunks * 9 && i < 72) ? st_lds[i][k] : 0ull;
         __syncthreads();
 #endif
     } else if constexpr (PW > 0) {
         static_assert(GLDS, "producer waves: LDS-DMA only");
+        AFAN_PHASE(1);
         constexpr int LPT = A_ROWS + B_ROWS;
         if constexpr (NS == 2) {
             // two stages (two workgroups per CU cover each other's DMA latency): the producers issue tile ks+1 while the
@@ -798,10 +814,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         s1[j] = s2[j] = 0.f;
-        const int c = ch_ok ? n0 + pc * 8 + j : 0;
-        sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && shift_p) ? shift_p[c] : 0.f);   // mean or shift
-        al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : (pp.aff ? pp.aff[(pp.aff_bwd ? 0 : 2 * pp.Co) + c] : 0.f);
-        be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : ((pp.aff && !pp.aff_bwd) ? pp.aff[3 * pp.Co + c] : 0.f);
+        if (GS && straddle && gpass > 0) {                          // (the second group's statistics: not what the prologue fetched)
+            const int c = ch_ok ? n0 + pc * 8 + j : 0;
+            sh[j] = bn_bwd ? bn_stats[c] : ((want_stats && shift_p) ? shift_p[c] : 0.f);   // mean or shift
+            al[j] = bn_bwd ? bn_stats[2 * pp.Co + c] : (pp.aff ? pp.aff[(pp.aff_bwd ? 0 : 2 * pp.Co) + c] : 0.f);
+            be[j] = bn_bwd ? bn_stats[3 * pp.Co + c] : ((pp.aff && !pp.aff_bwd) ? pp.aff[3 * pp.Co + c] : 0.f);
+        } else {
+            sh[j] = coef_s[0][pc * 8 + j];
+            al[j] = coef_s[1][pc * 8 + j];
+            be[j] = coef_s[2][pc * 8 + j];
+        }
     }
 #pragma unroll
     for (int q = 0; q < EPI_ROWS; ++q) {

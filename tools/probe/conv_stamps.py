@@ -91,3 +91,16 @@ for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)
             ("input gradient + BatchNorm backward in the launch (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad_bn(dy, wt, (h, h), x, stats, True, bn_y=y, addend=res, want_dres=True)), lib.afan_conv_bnf_stamps)):
         us, ph = phases(fn, rd)
         print(f"   {name:72s} {us:6.1f} us   " + "  ".join(f"{k} {v}" for k, v in ph[1:]))
+
+
+# ---- DeepLab's layer3 at two 513^2 images (2 x 33 x 33 = 2 178 rows: 35 row tiles of 64 on 256 CUs)
+x1 = cl(torch.randn(2, 1024, 33, 33, device=dev).bfloat16())
+x2 = cl(torch.randn(2, 256, 33, 33, device=dev).bfloat16())
+for name, xx, ci, co, k in (("1x1 1024 -> 256", x1, 1024, 256, 1), ("1x1 256 -> 1024", x2, 256, 1024, 1), ("3x3 256 -> 256", x2, 256, 256, 3)):
+    w = cl((torch.randn(co, ci, k, k, device=dev) * 0.03).bfloat16())
+    rm = torch.zeros(co, device=dev)
+    print(f"== DeepLab layer3 {name}, 2 x 33 x 33")
+    for nm, fn in (("forward, plain", lambda: ops.conv_fwd(xx, w, 1)),
+                   ("forward + BatchNorm sums", lambda: (ops.acc_reset(dev), ops.conv_fwd(xx, w, 1, stats_shift=rm, want_stats=True)))):
+        us, ph = phases(fn, lib.afan_conv_stamps)
+        print(f"   {nm:40s} {us:6.1f} us   " + "  ".join(f"{k_} {v}" for k_, v in ph[1:]))
