@@ -98,7 +98,7 @@ def test_no_convolution_leaves_the_library(pkg):
     convs = [n for n, mod in m.named_modules() if isinstance(mod, pkg.resnet_s.Conv2d) and mod.in_channels > 4]
     assert names == convs and len(names) == 18
     assert pkg.resnet_s.vendor_convs(m) == []
-    assert set(pkg.ops.CALLS) == {"conv_fwd", "conv_dgrad", "conv_wgrad", "conv_general", "vendor_conv"}
+    assert set(pkg.ops.CALLS) == {"conv_fwd", "conv_dgrad", "conv_wgrad", "conv_general", "vendor_conv", "conv_bn_fused"}
     import glob
     import os
     import re
