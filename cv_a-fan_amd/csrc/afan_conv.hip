@@ -64,7 +64,11 @@ __device__ unsigned long long afan_stamps[2][96][3];
 #define AFAN_STAMP(role, idx, k) do { if ((role) == 0 && stamp_on && (idx) < 72) st_lds[idx][k] = __builtin_readcyclecounter(); } while (0)   /* (72 taps fit the stamped build's LDS) */
 // phases of the launch as thread 0 of workgroup (0,0,0) passes them: entry | K loop starts | K loop done | output tile in LDS | first
 // epilogue pass done | sums added | (in-launch BatchNorm: barrier passed | second pass done) | exit  -> afan_stamps[1][p][0]
-#define AFAN_PHASE(p) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) afan_stamps[1][p][0] = __builtin_readcyclecounter(); } while (0)
+// ([p][1]: the same for the LAST workgroup of the grid — in a launch of several rounds per CU one that starts with the kernel's code and
+// arguments already in the caches, which workgroup (0,0,0) never does)
+#define AFAN_PHASE(p) do { if (threadIdx.x == 0 && blockIdx.z == 0) { \
+        if (blockIdx.x == 0 && blockIdx.y == 0) afan_stamps[1][p][0] = __builtin_readcyclecounter(); \
+        if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) afan_stamps[1][p][1] = __builtin_readcyclecounter(); } } while (0)
 #else
 #define AFAN_STAMP(role, idx, k) do { } while (0)
 #define AFAN_PHASE(p) do { } while (0)
@@ -189,6 +193,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const int stid = PW ? tid - 64 * NW : tid, swave = PW ? wave - NW : wave;   // index among the staging threads / waves
     const int n0 = blockIdx.x * BN;
     const int T = cc.T, Ci = pp.Ci, Hi = pp.Hi, Wi = pp.Wi;
+    // Kernel arguments come through scalar loads of ~100 cycles each, and a load the compiler finds behind a condition is issued
+    // THERE, waited for, and the next condition's only after it: the tap-validity loop (`t < T && hi >= 0 && ...`, two loads per tap
+    // and row) and the coefficient block's pointer tests made 57 such load -> wait pairs of this prologue — 5 600 of a 1x1 launch's
+    // 14 800 cycles per workgroup (launch-phase stamps, profiles/r05h_conv_launch_phases.txt).  Everything the prologue tests is
+    // therefore read HERE, unconditionally and side by side (adjacent fields merge into s_load_dwordx4/x8/x16), and the conditions
+    // below are written without short circuits.
+    int tdh[MAX_TAPS], tdw[MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < MAX_TAPS; ++t) {
+        tdh[t] = HL ? 0 : cc.dh[t];
+        tdw[t] = HL ? 0 : cc.dw[t];
+    }
+    const int tap0_w = cc.wofs[0], tap0_a = cc.aofs[0], tap0_h = cc.dh[0], tap0_d = cc.dw[0];
 
     // Buffer descriptors: out-of-range offsets read as zero in hardware, so the zero padding of the convolution (and
     // rows beyond M) costs one v_cndmask per load instead of a branch around it.  All offsets are 32-bit bytes.
@@ -220,10 +237,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             a_off[i] = (((n * Hi + hi0) * Wi + wi0) * Ci + piece * 8) * 2u;
             uint32_t v = 0;
 #pragma unroll
-            for (int t = 0; t < MAX_TAPS; ++t) {
-                const int hi = hi0 + cc.dh[t], wi = wi0 + cc.dw[t];
-                if (t < T && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v |= 1u << t;
-            }
+            for (int t = 0; t < MAX_TAPS; ++t)      // (unsigned compare: 0 <= hi < Hi in one)
+                if ((t < T) & ((uint32_t)(hi0 + tdh[t]) < (uint32_t)Hi) & ((uint32_t)(wi0 + tdw[t]) < (uint32_t)Wi)) v |= 1u << t;
             a_valid[i] = v;
         }
     }
@@ -244,14 +259,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // pass 3.5 k -> 6.9 k ticks).  (The one tile that straddles two image groups reads the second group's directly.)
     __shared__ float coef_s[3][BN];
     if (tid < BN) {
-        const bool ws_ = pp.stats != nullptr || pp.acc != nullptr, bb_ = ws_ && pp.bnx != nullptr;
-        const uint32_t half_ = pp.groups == 2 ? (uint32_t)(pp.N / 2) * Hg * Wg : 0u;
-        const float* bs_ = pp.bn_stats ? pp.bn_stats + (int64_t)((pp.groups == 2 && m0 >= half_) ? 1 : 0) * 4 * pp.Co : nullptr;
-        const float* sp_ = pp.shift ? pp.shift + pp.shift_off[blockIdx.z] : nullptr;
+        // which rows, and whether at all, the launcher has worked out (fill_coef): three unconditional loads that leave together
+        // (chosen here from the arguments' pointers they were three branches, each with its own load and its own wait)
         const int c = n0 + tid < pp.Co ? n0 + tid : 0;
-        coef_s[0][tid] = bb_ ? bs_[c] : ((ws_ && sp_) ? sp_[c] : 0.f);
-        coef_s[1][tid] = bb_ ? bs_[2 * pp.Co + c] : (pp.aff ? pp.aff[(pp.aff_bwd ? 0 : 2 * pp.Co) + c] : 0.f);
-        coef_s[2][tid] = bb_ ? bs_[3 * pp.Co + c] : ((pp.aff && !pp.aff_bwd) ? pp.aff[3 * pp.Co + c] : 0.f);
+        const int mask_ = pp.coef_mask;
+        const uint32_t half_ = (uint32_t)(pp.N / 2) * Hg * Wg;
+        const int64_t o_ = c + (m0 >= half_ ? pp.coef_gofs : 0);
+        const int64_t o0_ = o_ + ((mask_ & 8) ? pp.shift_off[blockIdx.z] : 0);
+        const float v0 = pp.coef[0][o0_], v1 = pp.coef[1][o_], v2 = pp.coef[2][o_];
+        coef_s[0][tid] = (mask_ & 1) ? v0 : 0.f;
+        coef_s[1][tid] = (mask_ & 2) ? v1 : 0.f;
+        coef_s[2][tid] = (mask_ & 4) ? v2 : 0.f;
     }
     const uint32_t b_off = ((uint32_t)(n0 + row0) * w_row_stride + piece * 8) * 2u;
     const int b_rows_ok = pp.Co - n0 - row0;                      // weight row (row0 + RPP * i) exists iff RPP * i < b_rows_ok
@@ -355,8 +373,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // chunk) position is carried from call to call (no integer division per step); the next tap's table entries are
     // requested at the end of a call and turned into the two scalar offsets at the start of the next, a K-step later.
     int dma_t = 0, dma_q = 0;
-    int tap_a = T > 0 ? (cc.dh[0] * Wi + cc.dw[0]) * Ci + cc.aofs[0] : 0;
-    int tap_b = T > 0 ? cc.wofs[0] : 0;
+    int tap_a = T > 0 ? (tap0_h * Wi + tap0_d) * Ci + tap0_a : 0;
+    int tap_b = T > 0 ? tap0_w : 0;
     auto gdma = [&](int /*ks*/, int buf) {
         const int t = dma_t;
         const int a_tap = (tap_a + dma_q * BK) * 2 + (int)A_BIAS, b_tap = (tap_b + dma_q * BK) * 2;
@@ -615,6 +633,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         __syncthreads();
         }
     } else if constexpr (GLDS && NS > 2) {
+        AFAN_PHASE(1);
         // Deep pipeline for launches of about one workgroup per CU (the 8x8 and 4x4 stages: few, long K loops): with two
         // buffers and __syncthreads() every DMA has to land within ONE step's MFMAs (a few hundred cycles against
         // 1-2 k of memory latency).  Here NS - 1 tiles are in flight; the wait is counted (vmcnt(N) leaves the younger
@@ -636,6 +655,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         }
         __syncthreads();
     } else if constexpr (GLDS) {
+        AFAN_PHASE(1);
         gdma(0, 0);
         __syncthreads();                     // (the compiler drains vmcnt before the barrier)
         for (int ks = 0; ks < KS; ++ks) {
@@ -1185,8 +1205,42 @@ static int64_t max_rows(const ConvP& p) {
     return m;
 }
 
+// ConvP::coef: the rows the kernel's prologue prefetches for its epilogue — a fused BatchNorm backward's mean | alpha | beta
+// (bn_stats rows 0, 2, 3; the second image group's block 4 * Co further), else the sums' shift in slot 0 and a frozen BatchNorm's
+// alpha | beta (forward) or alpha (backward) in slots 1 | 2
+inline void fill_coef(ConvP& p) {
+    const float* const dummy = reinterpret_cast<const float*>(p.w);
+    const bool ws = p.stats != nullptr || p.acc != nullptr, bb = ws && p.bnx != nullptr;
+    p.coef[0] = p.coef[1] = p.coef[2] = dummy;
+    p.coef_mask = 0;
+    p.coef_gofs = 0;
+    if (bb) {
+        if (!p.bn_stats) return;
+        p.coef[0] = p.bn_stats;
+        p.coef[1] = p.bn_stats + 2 * (int64_t)p.Co;
+        p.coef[2] = p.bn_stats + 3 * (int64_t)p.Co;
+        p.coef_mask = 7;
+        p.coef_gofs = p.groups == 2 ? 4 * p.Co : 0;
+        return;
+    }
+    if (ws && p.shift) {
+        p.coef[0] = p.shift;
+        p.coef_mask |= 1 | 8;
+    }
+    if (p.aff) {
+        p.coef[1] = p.aff + (p.aff_bwd ? 0 : 2 * (int64_t)p.Co);
+        p.coef_mask |= 2;
+        if (!p.aff_bwd) {
+            p.coef[2] = p.aff + 3 * (int64_t)p.Co;
+            p.coef_mask |= 4;
+        }
+    }
+}
+
 template <int BM, int BN, int PF, int WM, int WN, int PW, int FBT, int HL, bool GS, bool BF = false>
-int launch_gs(const ConvP& p, hipStream_t st, bool dgrad) {
+int launch_gs(const ConvP& p_in, hipStream_t st, bool dgrad) {
+    ConvP p = p_in;
+    fill_coef(p);
     constexpr int THREADS = 64 * (WM * WN + PW);
     const int64_t M = max_rows(p);
     dim3 grid((unsigned)((p.Co + BN - 1) / BN), (unsigned)((M + BM - 1) / BM), (unsigned)p.n_classes);

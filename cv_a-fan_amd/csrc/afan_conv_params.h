@@ -57,6 +57,12 @@ struct ConvP {
     int64_t acc_off[4];          //   otherwise.
     int64_t shift_off[4];
     int w_rs[4];                 //   and its weight rows are w_rs[z] elements apart (problems may differ in kernel size)
+    // filled by the launcher (launch_gs), not by callers: the epilogue's three per-channel coefficient rows (see coef_s in
+    // afan_conv.hip) as ready addresses — slot k reads coef[k][channel (+ coef_gofs for the second image group)]; an unused slot points at
+    // readable memory and is masked (coef_mask bit k); bit 3: slot 0 is the BatchNorm shift, displaced by shift_off[class]
+    const float* coef[3];
+    int coef_mask;
+    int coef_gofs;
     ConvClass cls[4];
     // ---- round 5: the BatchNorm behind (forward) / in front of (backward) this convolution applied INSIDE the launch.  Batch
     // statistics need every tile of the launch, so the epilogue meets all other workgroups at a grid-wide barrier between its
