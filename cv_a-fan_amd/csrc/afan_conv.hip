@@ -242,35 +242,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             a_valid[i] = v;
         }
     }
-    // output row offsets (elements) for the epilogue, -1 = row outside M
-    for (int r = tid; r < BM; r += THREADS) {
-        const uint32_t m = m0 + r;
-        int off = -1;
-        if (m < M) {
-            const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
-            const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
-            off = (int)(((n * pp.Ho + hg * pp.out_s + cc.out_h0) * pp.Wo + wg * pp.out_s + cc.out_w0) * pp.Co);
-        }
-        out_off[r] = off;
-    }
     // The epilogue's per-channel coefficients (a BatchNorm's shift / mean, alpha, beta; a frozen BatchNorm's alpha, beta) are fetched
     // HERE, into LDS: asked for at the top of the epilogue their ~1 us of load latency stood in front of its first pass in every
     // launch that carries one of the fusions (launch-phase stamps, profiles/r05g_conv_launch_phases.txt: a 64-row 1x1 launch's first
     // pass 3.5 k -> 6.9 k ticks).  (The one tile that straddles two image groups reads the second group's directly.)
+    // Which rows, and whether at all, the launcher has worked out (fill_coef): three unconditional loads that leave together
+    // (chosen here from the arguments' pointers they were three branches, each with its own load and its own wait).
     __shared__ float coef_s[3][BN];
+    float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f;
     if (tid < BN) {
-        // which rows, and whether at all, the launcher has worked out (fill_coef): three unconditional loads that leave together
-        // (chosen here from the arguments' pointers they were three branches, each with its own load and its own wait)
         const int c = n0 + tid < pp.Co ? n0 + tid : 0;
-        const int mask_ = pp.coef_mask;
         const uint32_t half_ = (uint32_t)(pp.N / 2) * Hg * Wg;
         const int64_t o_ = c + (m0 >= half_ ? pp.coef_gofs : 0);
-        const int64_t o0_ = o_ + ((mask_ & 8) ? pp.shift_off[blockIdx.z] : 0);
-        const float v0 = pp.coef[0][o0_], v1 = pp.coef[1][o_], v2 = pp.coef[2][o_];
-        coef_s[0][tid] = (mask_ & 1) ? v0 : 0.f;
-        coef_s[1][tid] = (mask_ & 2) ? v1 : 0.f;
-        coef_s[2][tid] = (mask_ & 4) ? v2 : 0.f;
+        const int64_t o0_ = o_ + ((pp.coef_mask & 8) ? pp.shift_off[blockIdx.z] : 0);
+        cv0 = pp.coef[0][o0_];
+        cv1 = pp.coef[1][o_];
+        cv2 = pp.coef[2][o_];
     }
+    // What only the EPILOGUE needs of the prologue — the output row offsets (-1 = row outside M) and the coefficients' way into
+    // LDS — runs behind the first operand requests: in the variants with producer waves on the MFMA waves while the producers
+    // compute their gather offsets and issue, in the others between the first tile's DMAs and the wait for them.
+    auto late_prologue = [&]() {
+        for (int r = tid; r < BM; r += THREADS) {
+            const uint32_t m = m0 + r;
+            int off = -1;
+            if (m < M) {
+                const uint32_t t1 = m / Wg, wg = m - t1 * Wg;
+                const uint32_t n = t1 / Hg, hg = t1 - n * Hg;
+                off = (int)(((n * pp.Ho + hg * pp.out_s + cc.out_h0) * pp.Wo + wg * pp.out_s + cc.out_w0) * pp.Co);
+            }
+            out_off[r] = off;
+        }
+        if (tid < BN) {
+            const int mask_ = pp.coef_mask;
+            coef_s[0][tid] = (mask_ & 1) ? cv0 : 0.f;
+            coef_s[1][tid] = (mask_ & 2) ? cv1 : 0.f;
+            coef_s[2][tid] = (mask_ & 4) ? cv2 : 0.f;
+        }
+    };
     const uint32_t b_off = ((uint32_t)(n0 + row0) * w_row_stride + piece * 8) * 2u;
     const int b_rows_ok = pp.Co - n0 - row0;                      // weight row (row0 + RPP * i) exists iff RPP * i < b_rows_ok
     const uint32_t b_row32 = (uint32_t)RPP * w_row_stride * 2u;
@@ -450,7 +459,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         __shared__ unsigned long long st_lds[72][3];
         const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave == 0;
 #endif
-        __syncthreads();                                      // htab (and out_off) are written
+        __syncthreads();                                      // htab is written
         AFAN_PHASE(1);
 
         auto compute_h = [&](int buf, int hb, int tjt, int tvt) {
@@ -554,6 +563,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         } else
         {
+            late_prologue();
             for (int q = 0; q < chunks; ++q) {
                 // (opaque per chunk: otherwise the nine taps' fragment addresses are hoisted out of the chunk loop as
                 // 40-odd loop-invariant registers, which the 168-register variant spills)
@@ -593,6 +603,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     __builtin_amdgcn_s_barrier();
                 }
             } else {
+                late_prologue();
                 __builtin_amdgcn_s_barrier();
                 for (int ks = 0; ks < KS; ++ks) {
                     compute(ks & 1);
@@ -623,6 +634,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #ifdef AFAN_CONV_PRIO
             __builtin_amdgcn_s_setprio(AFAN_CONV_PRIO);
 #endif
+            late_prologue();
             int buf = 0;
             for (int ks = 0; ks < KS; ++ks) {
                 __builtin_amdgcn_s_barrier();
@@ -642,6 +654,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
             if (s < KS) gdma(s, s);
+        late_prologue();
         int buf = 0;
         for (int ks = 0; ks < KS; ++ks) {
             const int rem = KS - 1 - ks;                 // tiles after this one; min(rem, NS - 2) of them are in flight
@@ -657,6 +670,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     } else if constexpr (GLDS) {
         AFAN_PHASE(1);
         gdma(0, 0);
+        late_prologue();
         __syncthreads();                     // (the compiler drains vmcnt before the barrier)
         for (int ks = 0; ks < KS; ++ks) {
             const int buf = ks & 1;
@@ -665,6 +679,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             __syncthreads();
         }
     } else if constexpr (PF == 1) {
+        late_prologue();
         gload(0, ra0, rb0);
         lstore(0, ra0, rb0);
         __syncthreads();
@@ -678,6 +693,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     } else {
         // two register sets: the loads of step k+2 are issued at the top of step k and written to LDS at the bottom of
         // step k+1, so they have a whole step (MFMAs + barrier) more to land.  Unrolled by 2: static register sets.
+        late_prologue();
         gload(0, ra0, rb0);
         lstore(0, ra0, rb0);
         if (KS > 1) gload(1, ra1, rb1);
