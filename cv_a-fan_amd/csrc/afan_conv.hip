@@ -720,7 +720,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // tile by DMA — no registers, in flight while the accumulators are rounded into C; the barrier below drains it)
     uint16_t* const Z = lds + BM * LDC;
     // (not in the 768-thread variant: at its 168-register cap the third sum's state spills in the prefetch phase; launch_gs refuses)
-    constexpr bool BSC_OK = BF;
+    constexpr bool BSC_OK = BF && HL > 0;        // (and not in the per-tap variants: their LDS has no room for the staged tile; launch_gs refuses)
     bool have_bsc = false;
     __shared__ float zmean_s[BF ? BN : 1];       // (BF) the projection BatchNorm's mean per tile column (registers are short in the row loop)
     unsigned bar_target = 0;                     // (BF) this launch's barrier episode, asked for here: long before thread 0 needs it
@@ -960,7 +960,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         __shared__ float red_static[HL ? 1 : THREADS / 64][2][BN];
         float (*red)[2][BN] = red_static;
         if constexpr (HL > 0) red = reinterpret_cast<float (*)[2][BN]>(lds + ((PF - 1) * BN * BK + HL * BK));
-        __shared__ float red3[BF ? THREADS / 64 : 1][BF ? BN : 1];      // the projection BatchNorm's third sum, per wave
+        __shared__ float red3[BSC_OK ? THREADS / 64 : 1][BSC_OK ? BN : 1];      // the projection BatchNorm's third sum, per wave
         if constexpr (BF && HL > 0) {                                    // (behind the staged Z tile, which the halo-form spot overlaps)
             static_assert((size_t)(BM * LDC + BM * BN) * 2 + (size_t)(THREADS / 64) * 2 * BN * 4 <=
                           (size_t)(PF - 1) * BN * BK * 2 + (size_t)2 * HL * BK * 2 + 1024, "in-launch BatchNorm: LDS behind the two tiles");
@@ -1288,6 +1288,7 @@ int launch_gs(const ConvP& p_in, hipStream_t st, bool dgrad) {
             max_resident = cus * (of < od ? of : od);
         }
         if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
+        if (HL == 0 && p.bsc.x) return AFAN_ESHAPE;                  // (the projection BatchNorm's backward: halo-form launches only)
         if ((int64_t)grid.x * grid.y * grid.z > max_resident || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
             p.n_classes != 1)
             return AFAN_ESHAPE;
@@ -1516,7 +1517,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
         p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
     if (bnf) {      // the BatchNorm backward itself behind a grid barrier in this launch (afan_conv_dgrad_bn_nhwc_bf16)
-        if (!bn_acc || stride != 1 || k != 3 || dilation != 1 || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
+        if (!bn_acc || stride != 1 || (k != 3 && k != 1) || dilation != 1 || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
         if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;          // (that kernel has no such epilogue)
         p.bnf = 2; p.bar = bnf->bar; p.y2 = bnf->y2; p.bnf_dw = bnf->bnf_dw; p.bnf_db = bnf->bnf_db; p.bnf_accum = bnf->bnf_accum;
         p.bsc = bnf->bsc;
@@ -1854,12 +1855,13 @@ int afan_grid_barrier_error_word(void) { return (int)(offsetof(GridBar, err) / s
 // launch), term for term.  acc: this launch's accumulator block (zeroed by the caller); shift: the running mean (moments are taken
 // around it).  stats [4][co] out; running buffers updated afan_bn_set_running_updates() times like the stand-alone launches.
 int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* y_act, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                               int64_t co, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
+                               int64_t co, int ksize, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
                                float momentum, float* stats, float* running_mean, float* running_var, int64_t* num_batches,
                                const void* residual, int relu, const void* sc_raw, const double* sc_acc, const float* sc_weight,
                                const float* sc_bias, float sc_eps, float sc_momentum, float* sc_stats, float* sc_running_mean,
                                float* sc_running_var, int64_t* sc_num_batches, void* barrier, afan_stream_t stream) {
-    const int k = 3, stride = 1, pad = 1;
+    if (ksize != 1 && ksize != 3) return AFAN_ESHAPE;
+    const int k = ksize, stride = 1, pad = k / 2;
     int e = check_dims(n, hi, wi, ci, co, k, stride, 1);
     if (e) return e;
     if (!x || !w || !y_raw || !y_act || !acc || !stats || !barrier) return AFAN_ENULL;
@@ -1877,10 +1879,10 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
     p.shift = shift; p.acc = acc; p.acc_ns = afan_nhwc::acc_slot_count(co);
     p.groups = 1;
     ConvClass& c0 = p.cls[0];
-    c0.Hg = p.Ho; c0.Wg = p.Wo; c0.T = 9;
-    for (int r = 0; r < 3; ++r)
-        for (int q = 0; q < 3; ++q) {
-            const int t = r * 3 + q;
+    c0.Hg = p.Ho; c0.Wg = p.Wo; c0.T = k * k;
+    for (int r = 0; r < k; ++r)
+        for (int q = 0; q < k; ++q) {
+            const int t = r * k + q;
             c0.dh[t] = r - pad; c0.dw[t] = q - pad; c0.wofs[t] = (int)(t * ci);
         }
     const int64_t M = n * hi * wi;
@@ -1900,8 +1902,8 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
     if (small_eligible(p) || afan_c64::eligible(n, hi, wi, ci, co, k, stride)) return AFAN_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     // (its own label: the launch does the convolution's FLOPs AND the BatchNorm's passes — bench.py prices it separately)
-    AFAN_PROF_FLOPS("conv_bn_fwd_kernel", 2.0 * ((double)M * co * (p.bnf_res ? 3 : 2) + (double)M * ci + (double)co * 9 * ci),
-                    2.0 * (double)M * co * 9 * ci, st);
+    AFAN_PROF_FLOPS("conv_bn_fwd_kernel", 2.0 * ((double)M * co * (p.bnf_res ? 3 : 2) + (double)M * ci + (double)co * k * k * ci),
+                    2.0 * (double)M * co * k * k * ci, st);
     return dispatch_bnf(p, st, false);
 }
 
@@ -1913,12 +1915,12 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
 // sc_stats [4][ci], zeroed accumulators sc_acc) receives the masked gradient too — d_sc = the gradient entering ITS input
 // (afan_bn_backward_acc(dres, sc_x, relu = 0)'s result up to the summation order of its two sums), sc_dweight / sc_dbias optional.
 int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                                 int64_t co, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
+                                 int64_t co, int ksize, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
                                  double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
                                  double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream) {
     if (!barrier || !bn_acc) return AFAN_ENULL;
     if (!aligned(barrier, 64) || (dres && !aligned(dres, 16))) return AFAN_EALIGN;
-    if (ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
+    if (ci % 64 != 0 || co % 64 != 0 || (ksize != 1 && ksize != 3)) return AFAN_ESHAPE;
     ConvP b{};
     b.bar = (unsigned*)barrier; b.y2 = (uint16_t*)dres; b.bnf_dw = dweight; b.bnf_db = dbias; b.bnf_accum = accumulate;
     if (sc_x) {
@@ -1928,7 +1930,7 @@ int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void*
         b.bsc.x = (const uint16_t*)sc_x; b.bsc.stats = sc_stats; b.bsc.acc = sc_acc; b.bsc.y3 = (uint16_t*)d_sc;
         b.bsc.dw = sc_dweight; b.bsc.db = sc_dbias;
     }
-    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, 3, 1, 1, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
+    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, ksize, 1, 1, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
                       nullptr, nullptr, nullptr, &b);
 }
 

@@ -552,7 +552,7 @@ class _BlockFn(torch.autograd.Function):
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
             last = i == n - 1
-            if (G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] == 3 and c.stride[0] == 1
+            if (G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] in (1, 3) and c.stride[0] == 1
                     and c.dilation[0] == 1):
                 # convolution + BatchNorm (+ shortcut) + ReLU as ONE launch (grid barrier between the sums and the second pass:
                 # ops.conv_fwd_bn); None = this launch does not take that form, the two launches below run instead (same bits)
@@ -655,7 +655,7 @@ class _BlockFn(torch.autograd.Function):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
             fused = None
-            if G == 1 and ops.GRID_BN and c.kernel_size[0] == 3 and c.stride[0] == 1 and c.dilation[0] == 1:
+            if G == 1 and ops.GRID_BN and c.kernel_size[0] in (1, 3) and c.stride[0] == 1 and c.dilation[0] == 1:
                 # ... or bn_{i-1}'s whole backward (sums -> grid barrier -> the gradient entering its input): ONE launch
                 fused = ops.conv_dgrad_bn(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], raws[i - 1], stats[i - 1], True,
                                           dweight=g(bp.weight), dbias=g(bp.bias), accumulate=pg,
@@ -702,7 +702,7 @@ class _BlockFn(torch.autograd.Function):
                 dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], addend=dx_sc, **fuse)
         elif need_dx:
             fused = pair_p = None
-            if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.kernel_size[0] == 3 and c1.stride[0] == 1
+            if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.kernel_size[0] in (1, 3) and c1.stride[0] == 1
                     and c1.dilation[0] == 1 and getattr(prev[3], "_branch", "main") == ctx.branch):
                 # the gradient leaving this block is only ever read by the producing block's last-BatchNorm backward: that
                 # backward runs inside this launch and the producer's node finds its two results on the tensor handed back

@@ -633,20 +633,24 @@ def _bn_state(b):
     return {k: v.clone() for k, v in b.state_dict().items() if "running" in k or "num" in k}
 
 
-GRID_SHAPES = [  # n, ci, co, h: the training step's own launches (256-row, 256 x 64 and 128 x 64 halo tiles) and smaller batches
-    (256, 128, 128, 16), (256, 256, 256, 8), (256, 512, 512, 4), (64, 128, 128, 16), (32, 256, 256, 8), (100, 128, 256, 8)]
+GRID_SHAPES = [  # n, ci, co, h, k: the training step's own launches (256-row, 256 x 64 and 128 x 64 halo tiles) and smaller batches;
+    # k = 1: the bottleneck blocks' 1x1 convolutions on the per-tap variants (ResNet-50's layer3 / layer4 at 64 images: four-stage
+    # 128- and 64-row tiles, two-stage tiles at two workgroups per CU), and a 3x3 whose halo does not fit (33 x 33 images)
+    (256, 128, 128, 16, 3), (256, 256, 256, 8, 3), (256, 512, 512, 4, 3), (64, 128, 128, 16, 3), (32, 256, 256, 8, 3),
+    (100, 128, 256, 8, 3), (64, 1024, 256, 14, 1), (64, 512, 2048, 7, 1), (32, 256, 1024, 14, 1), (16, 2048, 512, 7, 1),
+    (2, 256, 256, 33, 3)]
 
 
-@pytest.mark.parametrize("n,ci,co,h", GRID_SHAPES)
+@pytest.mark.parametrize("n,ci,co,h,k", GRID_SHAPES)
 @pytest.mark.parametrize("form", ["plain", "residual", "projection"])
-def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h, form):
+def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h, form, k):
     """afan_conv_fwd_bn_nhwc_bf16 (sums -> grid barrier -> totals -> second pass, one launch) against afan_conv_fwd_nhwc_bf16 +
     afan_bn_train_forward_acc[_dual]: raw output, normalised output, statistics block, running buffers — every bit; twice in a row
     (the barrier words reset themselves) with two running-statistics updates per pass (the shared head pass's form)."""
     ops = pkg.ops
     g = torch.Generator().manual_seed(n + ci + co + h)
     x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
-    w = _cl((torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(gpu).bfloat16())
     res = _cl(torch.randn(n, co, h, h, generator=g).to(gpu).bfloat16())
     xs = _cl(torch.randn(n, ci, 2 * h, 2 * h, generator=g).to(gpu).bfloat16())          # the projection's input (stride 2)
     wsc = _cl((torch.randn(co, ci, 1, 1, generator=g) * 0.1).to(gpu).bfloat16())
@@ -691,16 +695,18 @@ def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, 
     assert int(out["one"][1][-1]["num_batches_tracked"]) == 4
 
 
-@pytest.mark.parametrize("n,ci,co,h", GRID_SHAPES)
+@pytest.mark.parametrize("n,ci,co,h,k", GRID_SHAPES)
 @pytest.mark.parametrize("form", ["bn1", "block_output"])
-def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h, form):
+def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h, form, k):
     """afan_conv_dgrad_bn_nhwc_bf16 against afan_conv_dgrad_nhwc_bf16 (BatchNorm-backward sums in its epilogue) +
     afan_bn_backward_acc: the gradient entering the BatchNorm's input, the masked gradient (block-output form: mask from the stored
     output, other branch's gradient added first) and the affine parameters' gradients (written, then accumulated) — every bit."""
     ops = pkg.ops
+    if k == 1:
+        ci, co = co, ci                # (the input gradient's GEMM writes ci channels: the listed launches' workgroup counts, mirrored)
     g = torch.Generator().manual_seed(3 * n + ci + co + h)
     dy = _cl(torch.randn(n, co, h, h, generator=g).to(gpu).bfloat16())
-    w = _cl((torch.randn(co, ci, 3, 3, generator=g) / (co * 9) ** 0.5).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, k, k, generator=g) / (co * k * k) ** 0.5).to(gpu).bfloat16())
     wt = _cl(w.permute(1, 0, 2, 3))
     bn_x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
     addend = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
@@ -735,15 +741,17 @@ def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n
 
 
 def test_in_launch_batchnorm_declines_launches_it_cannot_take(pkg, gpu):
-    """More workgroups than the chip holds at once, a stride-2 / 1x1 problem, the 64 -> 64 kernel's shape: None, and nothing ran."""
+    """More workgroups than the chip holds at once (3x3 and 1x1), fewer than eight, the 64 -> 64 kernel's shape: None, and nothing ran."""
     ops = pkg.ops
     bn = _mk_bn(128, gpu, 1)
     before = dict(ops.CALLS)
     x = _cl(torch.randn(1024, 128, 16, 16, device=gpu).bfloat16())                 # 2 048 row tiles of 128
     w = _cl((torch.randn(128, 128, 3, 3, device=gpu) * 0.03).bfloat16())
     assert ops.conv_fwd_bn(x, w, bn, 0.1) is None
+    assert ops.conv_fwd_bn(x, _cl((torch.randn(128, 128, 1, 1, device=gpu) * 0.1).bfloat16()), bn, 0.1) is None
     x1 = _cl(torch.randn(8, 128, 16, 16, device=gpu).bfloat16())
-    assert ops.conv_fwd_bn(x1, _cl((torch.randn(128, 128, 1, 1, device=gpu) * 0.1).bfloat16()), bn, 0.1) is None
+    xs = _cl(torch.randn(1, 128, 16, 16, device=gpu).bfloat16())                   # 2 row tiles: fewer than the barrier's 8 shards
+    assert ops.conv_fwd_bn(xs, _cl((torch.randn(128, 128, 1, 1, device=gpu) * 0.1).bfloat16()), bn, 0.1) is None
     x64 = _cl(torch.randn(8, 64, 32, 32, device=gpu).bfloat16())
     assert ops.conv_fwd_bn(x64, _cl((torch.randn(64, 64, 3, 3, device=gpu) * 0.05).bfloat16()), _mk_bn(64, gpu, 2), 0.1) is None
     with ops.grid_bn(False):
