@@ -1517,7 +1517,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
         p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
     if (bnf) {      // the BatchNorm backward itself behind a grid barrier in this launch (afan_conv_dgrad_bn_nhwc_bf16)
-        if (!bn_acc || stride != 1 || (k != 3 && k != 1) || dilation != 1 || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
+        if (!bn_acc || stride != 1 || (k != 3 && k != 1) || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
         if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;          // (that kernel has no such epilogue)
         p.bnf = 2; p.bar = bnf->bar; p.y2 = bnf->y2; p.bnf_dw = bnf->bnf_dw; p.bnf_db = bnf->bnf_db; p.bnf_accum = bnf->bnf_accum;
         p.bsc = bnf->bsc;
@@ -1855,14 +1855,14 @@ int afan_grid_barrier_error_word(void) { return (int)(offsetof(GridBar, err) / s
 // launch), term for term.  acc: this launch's accumulator block (zeroed by the caller); shift: the running mean (moments are taken
 // around it).  stats [4][co] out; running buffers updated afan_bn_set_running_updates() times like the stand-alone launches.
 int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* y_act, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                               int64_t co, int ksize, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
+                               int64_t co, int ksize, int dilation, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
                                float momentum, float* stats, float* running_mean, float* running_var, int64_t* num_batches,
                                const void* residual, int relu, const void* sc_raw, const double* sc_acc, const float* sc_weight,
                                const float* sc_bias, float sc_eps, float sc_momentum, float* sc_stats, float* sc_running_mean,
                                float* sc_running_var, int64_t* sc_num_batches, void* barrier, afan_stream_t stream) {
-    if (ksize != 1 && ksize != 3) return AFAN_ESHAPE;
+    if ((ksize != 1 && ksize != 3) || dilation < 1 || (ksize == 1 && dilation != 1)) return AFAN_ESHAPE;
     const int k = ksize, stride = 1, pad = k / 2;
-    int e = check_dims(n, hi, wi, ci, co, k, stride, 1);
+    int e = check_dims(n, hi, wi, ci, co, k, stride, dilation);
     if (e) return e;
     if (!x || !w || !y_raw || !y_act || !acc || !stats || !barrier) return AFAN_ENULL;
     if (!aligned(x, 16) || !aligned(w, 16) || !aligned(y_raw, 16) || !aligned(y_act, 16) || !aligned(acc, 16) || !aligned(barrier, 64) ||
@@ -1871,7 +1871,7 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
     if (sc_raw && (residual || !sc_acc || !sc_stats || !relu)) return AFAN_ESHAPE;
     if (ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
     ConvP p{};
-    p.max_pad = 1;
+    p.max_pad = dilation;
     p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.y = (uint16_t*)y_raw; p.y2 = (uint16_t*)y_act;
     p.N = (int)n; p.Hi = (int)hi; p.Wi = (int)wi; p.Ci = (int)ci;
     p.Ho = (int)hi; p.Wo = (int)wi; p.Co = (int)co;
@@ -1883,7 +1883,7 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
     for (int r = 0; r < k; ++r)
         for (int q = 0; q < k; ++q) {
             const int t = r * k + q;
-            c0.dh[t] = r - pad; c0.dw[t] = q - pad; c0.wofs[t] = (int)(t * ci);
+            c0.dh[t] = (r - pad) * dilation; c0.dw[t] = (q - pad) * dilation; c0.wofs[t] = (int)(t * ci);
         }
     const int64_t M = n * hi * wi;
     const int pending = afan_nhwc::set_running_updates(1);
@@ -1915,12 +1915,12 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
 // sc_stats [4][ci], zeroed accumulators sc_acc) receives the masked gradient too — d_sc = the gradient entering ITS input
 // (afan_bn_backward_acc(dres, sc_x, relu = 0)'s result up to the summation order of its two sums), sc_dweight / sc_dbias optional.
 int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                                 int64_t co, int ksize, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
+                                 int64_t co, int ksize, int dilation, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
                                  double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
                                  double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream) {
     if (!barrier || !bn_acc) return AFAN_ENULL;
     if (!aligned(barrier, 64) || (dres && !aligned(dres, 16))) return AFAN_EALIGN;
-    if (ci % 64 != 0 || co % 64 != 0 || (ksize != 1 && ksize != 3)) return AFAN_ESHAPE;
+    if (ci % 64 != 0 || co % 64 != 0 || (ksize != 1 && ksize != 3) || dilation < 1 || (ksize == 1 && dilation != 1)) return AFAN_ESHAPE;
     ConvP b{};
     b.bar = (unsigned*)barrier; b.y2 = (uint16_t*)dres; b.bnf_dw = dweight; b.bnf_db = dbias; b.bnf_accum = accumulate;
     if (sc_x) {
@@ -1930,7 +1930,7 @@ int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void*
         b.bsc.x = (const uint16_t*)sc_x; b.bsc.stats = sc_stats; b.bsc.acc = sc_acc; b.bsc.y3 = (uint16_t*)d_sc;
         b.bsc.dw = sc_dweight; b.bsc.db = sc_dbias;
     }
-    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, ksize, 1, 1, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
+    return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, ksize, 1, dilation, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
                       nullptr, nullptr, nullptr, &b);
 }
 

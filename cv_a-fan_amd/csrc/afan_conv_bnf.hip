@@ -38,9 +38,11 @@ int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     // per-tap operand tiles (1x1 convolutions — the bottleneck blocks' first and last — and 3x3 ones whose halo does not fit): the
     // four-stage form with producer waves up to about one workgroup per CU, the two-stage form (two workgroups per CU) beyond;
     // launch_gs refuses what is not resident at once
-    if (wgs <= deep_max)
-        return bm == 64 ? launch_gs<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad)
-                        : launch_gs<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad);
+    if (wgs <= deep_max) {
+        const int e = bm == 64 ? launch_gs<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad)
+                               : launch_gs<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad);
+        if (e != AFAN_ESHAPE) return e;          // (one workgroup per CU there: 257 .. 384 of them are resident only on the two-stage form)
+    }
     return bm == 64 ? launch_gs<64, 128, 3, 2, 4, 0, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad)
                     : launch_gs<128, 128, 3, 2, 4, 0, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad);
 }

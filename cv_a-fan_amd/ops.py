@@ -879,7 +879,7 @@ def _acc_untake(device, blk):
         a.off -= blk.numel()
 
 
-def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None):
+def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None, dilation=1):
     """(raw, act, stats) = conv(x, w) (3x3 padding 1, or 1x1; stride 1) with the train-mode BatchNorm `bn` (module: weight, bias, eps, running buffers) behind it,
     + residual, + ReLU, in ONE launch; sc = (raw_sc, bn_sc, ConvStats_sc, momentum_sc): act = relu(bn(raw) + bn_sc(raw_sc)) and a
     fourth result stats_sc — the bits of conv_fwd(want_stats) + bn_train_forward[_dual].  None when the launch is not eligible
@@ -888,8 +888,8 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None):
         return None
     n, ci, hi, wi = x.shape
     co, ci2, k, k2 = w.shape
-    key = ("f", n, ci, hi, wi, co, k, x.device.index)
-    if k not in (1, 3) or k2 != k or ci2 != ci or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co) or (k == 1 and not GRID_BN_K1):
+    key = ("f", n, ci, hi, wi, co, k, int(dilation), x.device.index)
+    if (k == 1 and dilation != 1) or k not in (1, 3) or k2 != k or ci2 != ci or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co) or (k == 1 and not GRID_BN_K1):
         return None
     lib = _lib.load()
     _cl4(x, "x"), _cl4(w, "w")
@@ -913,7 +913,7 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None):
                _ptr(bsc.running_mean), _ptr(bsc.running_var), _ptr(bsc.num_batches_tracked)]
     else:
         scp[4] = scp[5] = 0.0
-    rc = lib.afan_conv_fwd_bn_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), _ptr(a), n, hi, wi, ci, co, k, _ptr(acc), _ptr(bn.running_mean),
+    rc = lib.afan_conv_fwd_bn_nhwc_bf16(_ptr(x), _ptr(w), _ptr(y), _ptr(a), n, hi, wi, ci, co, k, int(dilation), _ptr(acc), _ptr(bn.running_mean),
                                         _ptr(bn.weight), _ptr(bn.bias), float(bn.eps), float(momentum), _ptr(st_a),
                                         _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(bn.num_batches_tracked), _ptr(residual),
                                         int(bool(relu)), *scp, _ptr(_grid_barrier(x.device)), _stream(x))
@@ -935,7 +935,7 @@ GRID_BN_SC = os.environ.get("AFAN_GRID_BN", "2") not in ("0", "1")   # ... and t
 
 
 def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, want_dres=False, dweight=None, dbias=None,
-                  accumulate=False, dx_out=None, sc=None):
+                  accumulate=False, dx_out=None, sc=None, dilation=1):
     """(dx, dres) = the gradient entering the INPUT of the BatchNorm (+ ReLU) in front of the 3x3 or 1x1 stride-1 convolution whose output
     gradient is dy (and that backward's masked gradient, the shortcut's share, if want_dres): conv_dgrad(bn_bwd=...) + bn_backward
     in ONE launch, the same bits.  None when the launch is not eligible (nothing has run).
@@ -948,8 +948,8 @@ def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, w
     n, co, ho, wo = dy.shape
     ci, co2, k, _ = wt.shape
     hi, wi = in_hw
-    key = ("b" if sc is None else "bs", n, ci, hi, wi, co, k, dy.device.index)
-    if (k not in (1, 3) or co2 != co or (hi, wi) != (ho, wo) or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(ci)
+    key = ("b" if sc is None else "bs", n, ci, hi, wi, co, k, int(dilation), dy.device.index)
+    if ((k == 1 and dilation != 1) or k not in (1, 3) or co2 != co or (hi, wi) != (ho, wo) or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(ci)
             or (k == 1 and not GRID_BN_K1)):
         return None
     lib = _lib.load()
@@ -980,7 +980,7 @@ def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, w
     if sc is not None:
         acc2 = acc_take(dy.device, ci)
         scp = [_ptr(sc_x), _ptr(sc_stats), _ptr(acc2), _ptr(d_sc), _ptr(sc_dw), _ptr(sc_db)]
-    rc = lib.afan_conv_dgrad_bn_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), _ptr(dres), n, hi, wi, ci, co, k, _ptr(addend), _ptr(bn_x),
+    rc = lib.afan_conv_dgrad_bn_nhwc_bf16(_ptr(dy), _ptr(wt), _ptr(dx), _ptr(dres), n, hi, wi, ci, co, k, int(dilation), _ptr(addend), _ptr(bn_x),
                                           _ptr(bn_stats), int(bool(relu)), _ptr(bn_y), _ptr(acc), _ptr(dweight), _ptr(dbias),
                                           int(bool(accumulate)), *scp, _ptr(_grid_barrier(dy.device)), _stream(dy))
     if rc == -3:

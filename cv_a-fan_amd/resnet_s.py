@@ -552,14 +552,13 @@ class _BlockFn(torch.autograd.Function):
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
             last = i == n - 1
-            if (G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] in (1, 3) and c.stride[0] == 1
-                    and c.dilation[0] == 1):
+            if G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] in (1, 3) and c.stride[0] == 1:
                 # convolution + BatchNorm (+ shortcut) + ReLU as ONE launch (grid barrier between the sums and the second pass:
                 # ops.conv_fwd_bn); None = this launch does not take that form, the two launches below run instead (same bits)
                 if last and dual_sc:
-                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), relu=True, sc=(rawsc, bsc, stc, mom(bsc)))
+                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), relu=True, sc=(rawsc, bsc, stc, mom(bsc)), dilation=c.dilation[0])
                 else:
-                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), residual=res if last else None, relu=True)
+                    fused = ops.conv_fwd_bn(a, c.lp_weight(), b, mom(b), residual=res if last else None, relu=True, dilation=c.dilation[0])
                 if fused is not None:
                     if len(fused) == 4:
                         raw, a, s_i, ssc = fused
@@ -655,11 +654,11 @@ class _BlockFn(torch.autograd.Function):
             c, bp = chain[i][0], chain[i - 1][1]
             # conv_i: dgrad carries bn_{i-1}'s backward reduction in its epilogue; wgrad straight into the arena
             fused = None
-            if G == 1 and ops.GRID_BN and c.kernel_size[0] in (1, 3) and c.stride[0] == 1 and c.dilation[0] == 1:
+            if G == 1 and ops.GRID_BN and c.kernel_size[0] in (1, 3) and c.stride[0] == 1:
                 # ... or bn_{i-1}'s whole backward (sums -> grid barrier -> the gradient entering its input): ONE launch
                 fused = ops.conv_dgrad_bn(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], raws[i - 1], stats[i - 1], True,
                                           dweight=g(bp.weight), dbias=g(bp.bias), accumulate=pg,
-                                          dx_out=pair[:r0.shape[0]] if (pair is not None and i == 1) else None)
+                                          dx_out=pair[:r0.shape[0]] if (pair is not None and i == 1) else None, dilation=c.dilation[0])
             if fused is None:
                 d_a, part = ops.conv_dgrad(d_raw, c.lp_weight_t(), acts[i - 1].shape[2:], c.stride[0],
                                            bn_bwd=(raws[i - 1], stats[i - 1], True), partials_buf=c._bwd_buf, groups=G,
@@ -703,12 +702,12 @@ class _BlockFn(torch.autograd.Function):
         elif need_dx:
             fused = pair_p = None
             if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.kernel_size[0] in (1, 3) and c1.stride[0] == 1
-                    and c1.dilation[0] == 1 and getattr(prev[3], "_branch", "main") == ctx.branch):
+                    and getattr(prev[3], "_branch", "main") == ctx.branch):
                 # the gradient leaving this block is only ever read by the producing block's last-BatchNorm backward: that
                 # backward runs inside this launch and the producer's node finds its two results on the tensor handed back
                 pbn, ppg = prev[3], prev[4]
                 kw = dict(bn_y=x, addend=dres, want_dres=True, dweight=pbn.weight.grad if ppg else None,
-                          dbias=pbn.bias.grad if ppg else None, accumulate=ppg)
+                          dbias=pbn.bias.grad if ppg else None, accumulate=ppg, dilation=c1.dilation[0])
                 psc = prev[5] if (len(prev) > 5 and ops.GRID_BN_SC and _BlockFn.MULTI_SC) else None
                 if psc is not None and getattr(psc[2], "_branch", "main") == ctx.branch:
                     # the producing block has a projection shortcut: its BatchNorm's backward here as well, the result in the second

@@ -326,17 +326,17 @@ int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* 
  * buffer before the next use.  Never issue such launches concurrently on two streams of one device. */
 int afan_grid_barrier_bytes(void);
 int afan_grid_barrier_error_word(void);
-/* y_raw = conv(x, w) (ksize 3 with padding 1, or 1; stride 1) and y_act = [relu](bn(y_raw) [+ residual]) with y_raw's batch statistics (acc: zeroed accumulator block,
+/* y_raw = conv(x, w) (ksize 3 with padding = dilation, or 1; stride 1) and y_act = [relu](bn(y_raw) [+ residual]) with y_raw's batch statistics (acc: zeroed accumulator block,
  * moments taken around shift = the running mean); sc_raw != NULL: y_act = relu(bn(y_raw) + bn_sc(sc_raw)) with the projection
  * shortcut's BatchNorm derived from sc_acc (filled by the launch that produced sc_raw).  stats / sc_stats [4][co] out; running
  * statistics updated afan_bn_set_running_updates() times. */
 int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* y_act, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                               int64_t co, int ksize, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
+                               int64_t co, int ksize, int dilation, double* acc, const float* shift, const float* bn_weight, const float* bn_bias, float eps,
                                float momentum, float* stats, float* running_mean, float* running_var, int64_t* num_batches,
                                const void* residual, int relu, const void* sc_raw, const double* sc_acc, const float* sc_weight,
                                const float* sc_bias, float sc_eps, float sc_momentum, float* sc_stats, float* sc_running_mean,
                                float* sc_running_var, int64_t* sc_num_batches, void* barrier, afan_stream_t stream);
-/* dx = the gradient entering the INPUT of the BatchNorm (+ ReLU) in front of the 3x3 or 1x1 (ksize) stride-1 convolution whose output gradient
+/* dx = the gradient entering the INPUT of the BatchNorm (+ ReLU) in front of the 3x3 (dilation >= 1) or 1x1 (ksize) stride-1 convolution whose output gradient
  * is dy (bn_x, bn_stats, bn_relu, bn_y, addend as in afan_conv_dgrad_nhwc_bf16; bn_acc zeroed), dres (optional) = the masked
  * gradient (afan_bn_backward_acc's second output); dweight / dbias [ci] optional.
  * sc_x != NULL (only with bn_y: the gradient at a residual block's output): that block's projection shortcut's BatchNorm (no ReLU)
@@ -344,7 +344,7 @@ int afan_conv_fwd_bn_nhwc_bf16(const void* x, const void* w, void* y_raw, void* 
  * [4][ci] block, sc_acc a second zeroed accumulator block, d_sc = the gradient entering its input, sc_dweight / sc_dbias optional
  * (afan_bn_backward(dres, sc_x, relu = 0) up to the summation order of its two channel sums). */
 int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void* dres, int64_t n, int64_t hi, int64_t wi, int64_t ci,
-                                 int64_t co, int ksize, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
+                                 int64_t co, int ksize, int dilation, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
                                  double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
                                  double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):

@@ -633,17 +633,18 @@ def _bn_state(b):
     return {k: v.clone() for k, v in b.state_dict().items() if "running" in k or "num" in k}
 
 
-GRID_SHAPES = [  # n, ci, co, h, k: the training step's own launches (256-row, 256 x 64 and 128 x 64 halo tiles) and smaller batches;
-    # k = 1: the bottleneck blocks' 1x1 convolutions on the per-tap variants (ResNet-50's layer3 / layer4 at 64 images: four-stage
-    # 128- and 64-row tiles, two-stage tiles at two workgroups per CU), and a 3x3 whose halo does not fit (33 x 33 images)
-    (256, 128, 128, 16, 3), (256, 256, 256, 8, 3), (256, 512, 512, 4, 3), (64, 128, 128, 16, 3), (32, 256, 256, 8, 3),
-    (100, 128, 256, 8, 3), (64, 1024, 256, 14, 1), (64, 512, 2048, 7, 1), (32, 256, 1024, 14, 1), (16, 2048, 512, 7, 1),
-    (2, 256, 256, 33, 3)]
+GRID_SHAPES = [  # n, ci, co, h, k, dilation: the training step's own launches (256-row, 256 x 64 and 128 x 64 halo tiles) and smaller
+    # batches; k = 1: the bottleneck blocks' 1x1 convolutions on the per-tap variants (ResNet-50's layer3 / layer4 at 64 images: four-
+    # stage 128- and 64-row tiles, two-stage tiles at two workgroups per CU; DeepLab's at two 513^2 images: 280 workgroups, beyond the
+    # four-stage form's one per CU), a 3x3 whose halo does not fit (33 x 33 images) and DeepLab's atrous 3x3 (dilation 2)
+    (256, 128, 128, 16, 3, 1), (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1), (64, 128, 128, 16, 3, 1), (32, 256, 256, 8, 3, 1),
+    (100, 128, 256, 8, 3, 1), (64, 1024, 256, 14, 1, 1), (64, 512, 2048, 7, 1, 1), (32, 256, 1024, 14, 1, 1), (16, 2048, 512, 7, 1, 1),
+    (2, 256, 256, 33, 3, 1), (2, 256, 1024, 33, 1, 1), (2, 512, 512, 33, 3, 2)]
 
 
-@pytest.mark.parametrize("n,ci,co,h,k", GRID_SHAPES)
+@pytest.mark.parametrize("n,ci,co,h,k,d", GRID_SHAPES)
 @pytest.mark.parametrize("form", ["plain", "residual", "projection"])
-def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h, form, k):
+def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h, form, k, d):
     """afan_conv_fwd_bn_nhwc_bf16 (sums -> grid barrier -> totals -> second pass, one launch) against afan_conv_fwd_nhwc_bf16 +
     afan_bn_train_forward_acc[_dual]: raw output, normalised output, statistics block, running buffers — every bit; twice in a row
     (the barrier words reset themselves) with two running-statistics updates per pass (the shared head pass's form)."""
@@ -664,21 +665,21 @@ def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, 
                 if form == "projection":
                     rsc, stc = ops.conv_fwd(xs, wsc, 2, stats_shift=bsc.running_mean, want_stats=True)
                     if mode == "one":
-                        r = ops.conv_fwd_bn(x, w, bn, 0.1, relu=True, sc=(rsc, bsc, stc, 0.1))
+                        r = ops.conv_fwd_bn(x, w, bn, 0.1, relu=True, sc=(rsc, bsc, stc, 0.1), dilation=d)
                         assert r is not None, "the in-launch form declined a launch of the training step's kind"
                         raw, act, st, ssc = r
                     else:
-                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)
+                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True, dilation=d)
                         act, st, ssc = ops.bn_train_forward_dual(raw, bn, sta, 0.1, rsc, bsc, stc, 0.1)
                     got.append((raw.clone(), act.clone(), st.clone(), ssc.clone(), _bn_state(bn), _bn_state(bsc)))
                 else:
                     rr = res if form == "residual" else None
                     if mode == "one":
-                        r = ops.conv_fwd_bn(x, w, bn, 0.1, residual=rr, relu=True)
+                        r = ops.conv_fwd_bn(x, w, bn, 0.1, residual=rr, relu=True, dilation=d)
                         assert r is not None
                         raw, act, st = r
                     else:
-                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)
+                        raw, sta = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True, dilation=d)
                         act, st = ops.bn_train_forward(raw, bn.weight, bn.bias, rr, True, bn.eps, 0.1, bn.running_mean, bn.running_var,
                                                        bn.num_batches_tracked, sta)
                     got.append((raw.clone(), act.clone(), st.clone(), _bn_state(bn)))
@@ -695,9 +696,9 @@ def test_conv_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, 
     assert int(out["one"][1][-1]["num_batches_tracked"]) == 4
 
 
-@pytest.mark.parametrize("n,ci,co,h,k", GRID_SHAPES)
+@pytest.mark.parametrize("n,ci,co,h,k,d", GRID_SHAPES)
 @pytest.mark.parametrize("form", ["bn1", "block_output"])
-def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h, form, k):
+def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h, form, k, d):
     """afan_conv_dgrad_bn_nhwc_bf16 against afan_conv_dgrad_nhwc_bf16 (BatchNorm-backward sums in its epilogue) +
     afan_bn_backward_acc: the gradient entering the BatchNorm's input, the masked gradient (block-output form: mask from the stored
     output, other branch's gradient added first) and the affine parameters' gradients (written, then accumulated) — every bit."""
@@ -723,12 +724,12 @@ def test_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n
             if mode == "one":
                 r = ops.conv_dgrad_bn(dy, wt, (h, h), bn_x, stats, True, bn_y=y if out_block else None,
                                       addend=addend if out_block else None, want_dres=out_block, dweight=dwb[0], dbias=dwb[1],
-                                      accumulate=rep > 0)
+                                      accumulate=rep > 0, dilation=d)
                 assert r is not None, "the in-launch form declined a launch of the training step's kind"
                 dx, dres = r
             else:
                 gsum, part = ops.conv_dgrad(dy, wt, (h, h), 1, addend=addend if out_block else None, bn_bwd=(bn_x, stats, True),
-                                            bn_y=y if out_block else None)
+                                            bn_y=y if out_block else None, dilation=d)
                 dx, dres = ops.bn_backward(gsum, bn_x, y if out_block else None, stats, gamma, beta, True, out_block, dwb[0], dwb[1],
                                            accumulate=rep > 0, partials=part)
             rs.append((dx.clone(), None if dres is None else dres.clone(), dwb.clone()))

@@ -1050,3 +1050,36 @@ def test_step_with_in_launch_batchnorm_changes_no_bit(pkg, orc, gpu, graph, fold
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_step_with_in_launch_batchnorm_in_bottleneck_blocks_changes_no_bit(pkg, orc, gpu):
+    """The same for ResNet-50's bottleneck blocks (BASELINE configs[2] share: 64 images of 224 x 224, K = 3, perturb_idx 8): their 1x1
+    convolutions take the in-launch form on the per-tap tile variants where the launch is resident at once (ops.GRID_BN_K1), the 3x3
+    ones on the halo form; three graph-replayed iterations against the same with the form switched off, bit for bit."""
+    ops = pkg.ops
+    res = {}
+    for on in (False, True):
+        with ops.grid_bn(on):
+            m = _build(pkg, orc, "resnet50", gpu, dtype=torch.bfloat16)
+            m.set_channels_last(True)
+            tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=3, gamma=0.5, eps=2.0, perturb_idx=8, lr=0.05,
+                                            use_graph=True, graph_warmup=1, fold_clean=True, share_head=True)
+            gen = torch.Generator().manual_seed(13)
+            x, y = torch.rand(64, 3, 224, 224, generator=gen).to(gpu), torch.randint(0, 1000, (64,), generator=gen).to(gpu)
+            before = ops.CALLS["conv_bn_fused"]
+            outs = []
+            for _ in range(3):
+                r = tr.step(x, y)
+                outs.append((r["loss"].clone(), r["loss_adv"].clone(), r["l2"].clone(), r["x_adv"].clone()))
+            torch.cuda.synchronize()
+            assert (ops.CALLS["conv_bn_fused"] > before) == on
+            assert not ops.grid_barrier_error(gpu)
+            res[on] = (outs, tr.arena.param.clone(), tr.arena.momentum_buf.clone(), {k: v.clone() for k, v in m.state_dict().items()})
+            del tr, m
+    a, b = res[False], res[True]
+    for oa, ob in zip(a[0], b[0]):
+        for p_, q_ in zip(oa, ob):
+            assert torch.equal(p_, q_)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
