@@ -1412,8 +1412,11 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         if (halo && n64 && spec && bm == 128 && wgs <= deep_max && !p.stats && p.Co % 64 == 0 && p.Ci >= 256 &&
             (p.groups != 2 || ((int64_t)(p.N / 2) * p.cls[0].Hg * p.cls[0].Wg) % 256 == 0)) {
             const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 255) / 256) * p.n_classes;
+            // (four MFMA waves of 64 x 64 instead of eight of 64 x 32: the eight re-read 96 KB of fragments per tap from LDS for 40 KB of
+            // tile — 768 cycles of the LDS port against 512 of the MFMA pipe; four read 64 KB.  ResNet-18 step 7.98 -> 7.94 ms, same box)
+            static const int w41 = env_int("AFAN_CONV_W41", 1);
             if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 256, HALO_PIXELS_256N))
-                return launch<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N>(p, st, dgrad);
+                return w41 ? launch<256, 64, 5, 4, 1, 4, 2, HALO_PIXELS_256N>(p, st, dgrad) : launch<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N>(p, st, dgrad);
         }
         if (wgs <= deep_max && spec && halo && halo_ok(p, bm))
             return bm == 64 ? launch<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
