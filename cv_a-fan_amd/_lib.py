@@ -64,6 +64,7 @@ SIGNATURES = {
     "afan_conv_dgrad_sc_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _i, _p, _p, _p, _p]),
     "afan_grid_barrier_bytes": (_i, []),
     "afan_grid_barrier_error_word": (_i, []),
+    "afan_grid_barrier_shared_gpu": (_i, [_i]),
     "afan_conv_fwd_bn_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p,
                                         _f, _f, _p, _p, _p, _p, _p, _p]),
     "afan_conv_dgrad_bn_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p,

@@ -1278,18 +1278,20 @@ int launch_gs(const ConvP& p_in, hipStream_t st, bool dgrad) {
     if constexpr (BF) {
         // the in-launch BatchNorm's grid barrier needs EVERY workgroup of the launch resident at once: CUs x the occupancy of
         // this instantiation (the smaller of the two entry points'), asked once; a launch beyond it is refused before anything runs
-        static int max_resident = -1;
+        static int max_resident = -1, n_cus = 0;
         if (max_resident < 0) {
             int dev = 0, cus = 0, of = 0, od = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&of, (const void*)conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>, THREADS, lds) != hipSuccess ||
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&od, (const void*)conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF>, THREADS, lds) != hipSuccess)
                 return AFAN_ESHAPE;
+            n_cus = cus;
             max_resident = cus * (of < od ? of : od);
         }
+        const int64_t cap = afan_conv::g_bnf_one_per_cu ? (max_resident < n_cus ? max_resident : n_cus) : max_resident;
         if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
         if (HL == 0 && p.bsc.x) return AFAN_ESHAPE;                  // (the projection BatchNorm's backward: halo-form launches only)
-        if ((int64_t)grid.x * grid.y * grid.z > max_resident || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
+        if ((int64_t)grid.x * grid.y * grid.z > cap || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
             p.n_classes != 1)
             return AFAN_ESHAPE;
     }
@@ -1850,6 +1852,13 @@ int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* 
 // device memory, zeroed once, shared by every such launch of one stream; word afan_grid_barrier_error_word() turns non-zero if a
 // barrier's bounded spin gave up (workgroups not co-resident: another process's kernels on the GPU) — results are then invalid.
 int afan_grid_barrier_bytes(void) { return 2048; }
+// on != 0: kernels of other streams may run beside the launches below (weight gradients on a side stream): only launches of at
+// most one workgroup per CU take the in-launch form (see g_bnf_one_per_cu).  Returns the previous setting.
+int afan_grid_barrier_shared_gpu(int on) {
+    const int old = afan_conv::g_bnf_one_per_cu;
+    afan_conv::g_bnf_one_per_cu = on ? 1 : 0;
+    return old;
+}
 int afan_grid_barrier_error_word(void) { return (int)(offsetof(GridBar, err) / sizeof(unsigned)); }
 
 // y_raw = conv(x, w) (3x3, stride 1, padding 1) AND y_act = [relu](bn(y_raw) [+ residual]) with the batch statistics of y_raw —

@@ -13,6 +13,8 @@
 
 namespace afan_conv {
 
+int g_bnf_one_per_cu = 0;
+
 // dispatch()'s halo-form choices, with the BF instantiations; any other launch: AFAN_ESHAPE (the caller issues two launches)
 int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     static const int halo = env_int("AFAN_CONV_HALO", 1);
@@ -40,6 +42,8 @@ int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     // per-tap operand tiles (1x1 convolutions — the bottleneck blocks' first and last — and 3x3 ones whose halo does not fit): the
     // four-stage form with producer waves up to about one workgroup per CU, the two-stage form (two workgroups per CU) beyond;
     // launch_gs refuses what is not resident at once
+    static const int tap3 = env_int("AFAN_BNF_TAP3", 1);       // 0: no 3x3 convolution on the per-tap variants (A/B)
+    if (!tap3 && p.cls[0].T == 9) return AFAN_ESHAPE;
     if (wgs <= deep_max) {
         const int e = bm == 64 ? launch_gs<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad)
                                : launch_gs<128, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad);

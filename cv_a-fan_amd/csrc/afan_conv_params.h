@@ -112,6 +112,12 @@ struct ConvP {
 // afan_conv_bnf.hip: the tiled kernel's instantiations with the in-launch BatchNorm (ConvP::bnf != 0); AFAN_ESHAPE when no such
 // instantiation takes the problem or its workgroups would not all be resident (nothing is launched then)
 int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad);
+// 1: kernels of ANOTHER stream may run beside these launches (afan_grid_barrier_shared_gpu): a launch counts as resident only at
+// one workgroup per CU.  Two per CU need two contiguous LDS ranges: beside a long-lived workgroup of another kernel the first
+// lands between its range and the end, that kernel leaves, and the two free pieces either side never again hold the second — which
+// the first, spinning at the barrier, waits for (seen: DeepLab at 8 images with weight gradients on the side stream, 276 workgroups
+// of the two-stage tile beside a 288-workgroup weight-gradient launch: 200 ms, the spin bound)
+extern int g_bnf_one_per_cu;
 
 
 // small-channel kernel (afan_conv_small.hip): reduction channels in {16, 32, 64}, output channels a multiple of 16, at

@@ -873,6 +873,28 @@ def grid_barrier_error(device=None):
     return bad
 
 
+def grid_shared(on):
+    """Tell the library that kernels of another stream may run beside the convolution + BatchNorm launches from now on (on) or no
+    longer (off): resnet_s.wgrad_stream does.  Returns the previous setting."""
+    global _GRID_SHARED
+    _GRID_SHARED = bool(on)
+    return bool(_lib.load().afan_grid_barrier_shared_gpu(int(bool(on))))
+
+
+_GRID_SHARED = False       # (part of the refused-launch memo's keys: what is declined beside other kernels is taken without them)
+
+
+_GRID_BN_CHECK = os.environ.get("AFAN_GRID_BN_CHECK", "0") == "1"     # diagnostic: synchronise after every fused launch and name the one
+                                                                        # whose barrier gave up (eager passes only)
+
+
+def _grid_check(dev, what):
+    if _GRID_BN_CHECK and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(dev)
+        if grid_barrier_error(dev):
+            raise RuntimeError("in-launch BatchNorm: the grid barrier of this launch gave up: " + repr(what))
+
+
 def _acc_untake(device, blk):
     a = _acc_arena(device)
     if a.off >= blk.numel() and a.buf.data_ptr() + 8 * (a.off - blk.numel()) == blk.data_ptr():
@@ -888,8 +910,9 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None, dilation=
         return None
     n, ci, hi, wi = x.shape
     co, ci2, k, k2 = w.shape
-    key = ("f", n, ci, hi, wi, co, k, int(dilation), x.device.index)
-    if (k == 1 and dilation != 1) or k not in (1, 3) or k2 != k or ci2 != ci or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co) or (k == 1 and not GRID_BN_K1):
+    key = ("f", n, ci, hi, wi, co, k, int(dilation), x.device.index, _GRID_SHARED)
+    if ((k == 1 and dilation != 1) or k not in (1, 3) or k2 != k or ci2 != ci or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co) or (k == 1 and not GRID_BN_K1)
+            or (dilation != 1 and not GRID_BN_DIL)):
         return None
     lib = _lib.load()
     _cl4(x, "x"), _cl4(w, "w")
@@ -922,6 +945,7 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None, dilation=
         _acc_untake(x.device, acc)
         return None
     check(rc, "afan_conv_fwd_bn_nhwc_bf16")
+    _grid_check(x.device, key)
     CALLS["conv_fwd"] += 1
     CALLS["conv_bn_fused"] += 1
     if sc is not None:
@@ -931,6 +955,7 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None, dilation=
 
 
 GRID_BN_K1 = os.environ.get("AFAN_GRID_BN_1X1", "1") != "0"            # ... and for 1x1 convolutions (0: 3x3 only — A/B)
+GRID_BN_DIL = os.environ.get("AFAN_GRID_BN_DIL", "1") != "0"           # ... and for atrous 3x3 convolutions
 GRID_BN_SC = os.environ.get("AFAN_GRID_BN", "2") not in ("0", "1")   # ... and the projection shortcut's BatchNorm backward in that launch
 
 
@@ -948,9 +973,9 @@ def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, w
     n, co, ho, wo = dy.shape
     ci, co2, k, _ = wt.shape
     hi, wi = in_hw
-    key = ("b" if sc is None else "bs", n, ci, hi, wi, co, k, int(dilation), dy.device.index)
+    key = ("b" if sc is None else "bs", n, ci, hi, wi, co, k, int(dilation), dy.device.index, _GRID_SHARED)
     if ((k == 1 and dilation != 1) or k not in (1, 3) or co2 != co or (hi, wi) != (ho, wo) or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(ci)
-            or (k == 1 and not GRID_BN_K1)):
+            or (k == 1 and not GRID_BN_K1) or (dilation != 1 and not GRID_BN_DIL)):
         return None
     lib = _lib.load()
     _cl4(dy, "dy"), _cl4(wt, "wt"), _cl4(bn_x, "bn_x")
@@ -990,6 +1015,7 @@ def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, w
         _acc_untake(dy.device, acc)
         return None
     check(rc, "afan_conv_dgrad_bn_nhwc_bf16")
+    _grid_check(dy.device, key)
     CALLS["conv_dgrad"] += 1
     CALLS["conv_bn_fused"] += 1
     return dx, dres

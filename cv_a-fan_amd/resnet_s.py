@@ -269,6 +269,8 @@ class _WgradStream:
         side = cls.streams.get(dev.index)
         if side is None:
             side = cls.streams[dev.index] = torch.cuda.Stream(device=dev)
+            if cls.FORCE == "1" and ops.GRID_BN:        # (forced on outside a wgrad_stream() context: tell the library once)
+                ops.grid_shared(True)
         main = torch.cuda.current_stream(dev)
         # one join per backward (graph task): keyed on the task id, not on `held` being empty — a backward that raised after
         # its first side launch never ran its callback, and its leftovers must not keep later backwards from queueing theirs
@@ -301,10 +303,14 @@ def wgrad_stream(on):
     """Weight gradients of the backward passes inside this context on the side stream (see _WgradStream)."""
     old = _WgradStream.ON
     _WgradStream.ON = bool(on) if _WgradStream.FORCE is None else _WgradStream.FORCE == "1"
+    # (side-stream kernels run beside the main stream's: the in-launch BatchNorm then only takes launches of one workgroup per CU)
+    old_shared = ops.grid_shared(_WgradStream.ON) if (ops.GRID_BN and torch.cuda.is_available()) else None
     try:
         yield
     finally:
         _WgradStream.ON = old
+        if old_shared is not None:
+            ops.grid_shared(old_shared)
 
 
 class _WgradBatch:

@@ -326,6 +326,11 @@ int afan_conv_dgrad_sc_nhwc_bf16(const void* dy, const void* dy_sc, const void* 
  * buffer before the next use.  Never issue such launches concurrently on two streams of one device. */
 int afan_grid_barrier_bytes(void);
 int afan_grid_barrier_error_word(void);
+/* on != 0 while kernels of ANOTHER stream of this process may run beside these launches (e.g. weight gradients on a side stream):
+ * only launches of at most one workgroup per CU then take the in-launch form — two per CU need two contiguous LDS ranges, and beside
+ * a long-lived workgroup of another kernel the second may never find its range while the first spins for it.  Returns the previous
+ * setting.  (Kernels that themselves wait for something — a collective — must not run beside these launches at all.) */
+int afan_grid_barrier_shared_gpu(int on);
 /* y_raw = conv(x, w) (ksize 3 with padding = dilation, or 1; stride 1) and y_act = [relu](bn(y_raw) [+ residual]) with y_raw's batch statistics (acc: zeroed accumulator block,
  * moments taken around shift = the running mean); sc_raw != NULL: y_act = relu(bn(y_raw) + bn_sc(sc_raw)) with the projection
  * shortcut's BatchNorm derived from sc_acc (filled by the launch that produced sc_raw).  stats / sc_stats [4][co] out; running

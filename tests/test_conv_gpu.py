@@ -761,6 +761,42 @@ def test_in_launch_batchnorm_declines_launches_it_cannot_take(pkg, gpu):
     assert int(bn.num_batches_tracked) == 0
 
 
+def test_in_launch_batchnorm_beside_side_stream_kernels_takes_one_workgroup_per_cu(pkg, gpu):
+    """Round 5 regression (DeepLab at 8 images, weight gradients on the side stream): 276 workgroups of the two-per-CU tile form beside
+    a long-lived weight-gradient launch — the first workgroup of a CU lands behind the other kernel's LDS range, that kernel leaves,
+    and the second never finds a contiguous range while the first spins for it (200 ms: the spin bound).  While kernels of another
+    stream may run (ops.grid_shared / resnet_s.wgrad_stream) only launches of one workgroup per CU take the in-launch form; the
+    same launch beside a real side-stream weight gradient then completes (two launches) and no barrier gives up."""
+    ops, rs = pkg.ops, pkg.resnet_s
+    n, ci, co, h = 8, 1024, 512, 33                         # 69 row tiles x 4 column tiles = 276 workgroups (DeepLab's layer4 conv1 at 8 images)
+    g = torch.Generator().manual_seed(5)
+    x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    w = _cl((torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5).to(gpu).bfloat16())
+    xs = _cl(torch.randn(n, 256, h, h, generator=g).to(gpu).bfloat16())
+    dys = _cl(torch.randn(n, 256, h, h, generator=g).to(gpu).bfloat16())
+    gw = _cl(torch.zeros(256, 256, 3, 3, device=gpu))
+    bn = _mk_bn(co, gpu, 1)
+    ops.acc_reset(gpu)
+    assert ops.conv_fwd_bn(x, w, bn, 0.1) is not None       # alone on the GPU: taken
+    side = torch.cuda.Stream(device=gpu)
+    with rs.wgrad_stream(True):
+        for _ in range(3):
+            side.wait_stream(torch.cuda.current_stream(gpu))
+            with torch.cuda.stream(side):
+                ops.conv_wgrad(xs, dys, 3, 1, gw, accumulate=True)      # ~288 long-lived workgroups with 40 KB of LDS each
+            ops.acc_reset(gpu)
+            assert ops.conv_fwd_bn(x, w, bn, 0.1) is None               # beside it: declined (the caller's two launches run)
+            raw, st = ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)
+            ops.bn_train_forward(raw, bn.weight, bn.bias, None, True, bn.eps, 0.1, bn.running_mean, bn.running_var, bn.num_batches_tracked, st)
+        torch.cuda.current_stream(gpu).wait_stream(side)
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    ops.acc_reset(gpu)
+    assert ops.conv_fwd_bn(x, w, bn, 0.1) is not None       # and taken again afterwards
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+
+
 @pytest.mark.parametrize("n,ci,co,h", [(256, 256, 256, 8), (256, 512, 512, 4), (64, 128, 128, 16), (100, 128, 256, 8)])
 def test_dgrad_with_both_batchnorm_backwards_of_a_projection_block(pkg, gpu, n, ci, co, h):
     """The block-output form with the producing block's projection shortcut: its BatchNorm (no ReLU) receives the masked gradient
