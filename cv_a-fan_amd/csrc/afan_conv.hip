@@ -1291,9 +1291,13 @@ int launch_gs(const ConvP& p_in, hipStream_t st, bool dgrad) {
         const int64_t cap = afan_conv::g_bnf_one_per_cu ? (max_resident < n_cus ? max_resident : n_cus) : max_resident;
         if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
         if (HL == 0 && p.bsc.x) return AFAN_ESHAPE;                  // (the projection BatchNorm's backward: halo-form launches only)
-        if ((int64_t)grid.x * grid.y * grid.z > cap || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 ||
-            p.n_classes != 1)
+        if ((int64_t)grid.x * grid.y * grid.z > cap || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 || p.multi)
             return AFAN_ESHAPE;
+        // several output-parity classes (a stride-2 input gradient): one set of sums over all of them; every tile of the grid must
+        // be a real one (a workgroup of a smaller class would leave at the top, before the barrier): classes of equal size only
+        for (int z = 1; z < p.n_classes; ++z)
+            if (p.cls[z].Hg != p.cls[0].Hg || p.cls[z].Wg != p.cls[0].Wg) return AFAN_ESHAPE;
+        if (p.n_classes != 1 && (p.bnf != 2 || p.bsc.x)) return AFAN_ESHAPE;
     }
     if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
     else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
@@ -1522,7 +1526,9 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
         p.bnx = (const uint16_t*)bn_x; p.bn_stats = bn_stats; p.bn_relu = bn_relu; p.bny = (const uint16_t*)bn_y;
     }
     if (bnf) {      // the BatchNorm backward itself behind a grid barrier in this launch (afan_conv_dgrad_bn_nhwc_bf16)
-        if (!bn_acc || stride != 1 || (k != 3 && k != 1) || dy_sc || aff_alpha || groups > 1) return AFAN_ESHAPE;
+        // stride 1 (3x3 incl. atrous, 1x1), or the stride-2 pair form (a block's first 3x3 + its projection, four output-parity classes)
+        if (!bn_acc || (k != 3 && k != 1) || aff_alpha || groups > 1) return AFAN_ESHAPE;
+        if (!((stride == 1 && !dy_sc) || (stride == 2 && dy_sc && k == 3 && dilation == 1 && !((hi | wi) & 1)))) return AFAN_ESHAPE;
         if (afan_c64::eligible(n, hi, wi, co, ci, k, stride)) return AFAN_ESHAPE;          // (that kernel has no such epilogue)
         p.bnf = 2; p.bar = bnf->bar; p.y2 = bnf->y2; p.bnf_dw = bnf->bnf_dw; p.bnf_db = bnf->bnf_db; p.bnf_accum = bnf->bnf_accum;
         p.bsc = bnf->bsc;
@@ -1585,6 +1591,7 @@ static int dgrad_impl(const void* dy, const void* dy_sc, const void* wt, void* d
             ++nc;
         }
     p.n_classes = nc;
+    if (bnf) return nc == 4 ? dispatch_bnf(p, st, true) : AFAN_ESHAPE;      // (even sizes: four classes of equal size, no idle tiles)
     if (!dy_sc && small_eligible(p)) return (p.aff || !small_groups_ok(p)) ? AFAN_ESHAPE : small_launch(p, st);
     if (co % 8 != 0 || ci % 8 != 0 || co < 40 || ci < 40) return AFAN_ESHAPE;
     return dispatch(p, st, true);
@@ -1943,6 +1950,22 @@ int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void*
         b.bsc.dw = sc_dweight; b.bsc.db = sc_dbias;
     }
     return dgrad_impl(dy, nullptr, wt, dx, n, hi, wi, ci, co, ksize, 1, dilation, addend, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
+                      nullptr, nullptr, nullptr, &b);
+}
+
+// The same for the stride-2 pair form (afan_conv_dgrad_sc_nhwc_bf16: a block's first 3x3 / 2 and its 1x1 / 2 projection, whose input
+// gradient is the gradient leaving the PREVIOUS block's output): that block's last BatchNorm's backward inside the launch (block-
+// output form: bn_y = the block's stored output, dres = the masked gradient for its shortcut).  hi, wi even.
+int afan_conv_dgrad_sc_bn_nhwc_bf16(const void* dy, const void* dy_sc, const void* wt10, void* dx, void* dres, int64_t n, int64_t hi,
+                                    int64_t wi, int64_t ci, int64_t co, const void* bn_x, const float* bn_stats, int bn_relu,
+                                    const void* bn_y, double* bn_acc, float* dweight, float* dbias, int accumulate, void* barrier,
+                                    afan_stream_t stream) {
+    if (!dy_sc || !barrier || !bn_acc) return AFAN_ENULL;
+    if (!aligned(barrier, 64) || (dres && !aligned(dres, 16))) return AFAN_EALIGN;
+    if (ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
+    ConvP b{};
+    b.bar = (unsigned*)barrier; b.y2 = (uint16_t*)dres; b.bnf_dw = dweight; b.bnf_db = dbias; b.bnf_accum = accumulate;
+    return dgrad_impl(dy, dy_sc, wt10, dx, n, hi, wi, ci, co, 3, 2, 1, nullptr, bn_x, bn_stats, bn_relu, bn_y, nullptr, bn_acc, 1, stream,
                       nullptr, nullptr, nullptr, &b);
 }
 

@@ -956,20 +956,25 @@ def conv_fwd_bn(x, w, bn, momentum, residual=None, relu=True, sc=None, dilation=
 
 GRID_BN_K1 = os.environ.get("AFAN_GRID_BN_1X1", "1") != "0"            # ... and for 1x1 convolutions (0: 3x3 only — A/B)
 GRID_BN_DIL = os.environ.get("AFAN_GRID_BN_DIL", "1") != "0"           # ... and for atrous 3x3 convolutions
+GRID_BN_PAIR = os.environ.get("AFAN_GRID_BN_PAIR", "1") != "0"         # ... and in the stride-2 pair form's input gradient
 GRID_BN_SC = os.environ.get("AFAN_GRID_BN", "2") not in ("0", "1")   # ... and the projection shortcut's BatchNorm backward in that launch
 
 
 def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, want_dres=False, dweight=None, dbias=None,
-                  accumulate=False, dx_out=None, sc=None, dilation=1):
+                  accumulate=False, dx_out=None, sc=None, dilation=1, pair=None):
     """(dx, dres) = the gradient entering the INPUT of the BatchNorm (+ ReLU) in front of the 3x3 or 1x1 stride-1 convolution whose output
     gradient is dy (and that backward's masked gradient, the shortcut's share, if want_dres): conv_dgrad(bn_bwd=...) + bn_backward
     in ONE launch, the same bits.  None when the launch is not eligible (nothing has run).
     sc = (sc_x, sc_stats, d_sc_out, sc_dweight, sc_dbias) (block-output form, bn_y given): the producing block's projection shortcut's
     BatchNorm (no ReLU; input sc_x, statistics sc_stats) receives the masked gradient as well; its backward runs in the same launch:
     d_sc_out (a tensor of dx's shape) takes the gradient entering its input — bn_backward(dres, sc_x, relu=False) up to the summation
-    order of its two channel sums."""
+    order of its two channel sums.
+    pair = (dy_sc, wt10): the stride-2 pair form (conv_dgrad's sc: a block's first 3x3 / 2 and its 1x1 / 2 projection in one launch;
+    block-output form only: bn_y given, no addend — the projection's share arrives through the tenth tap); wt is then ignored."""
     if not (GRID_BN and dy.is_cuda and BN_ACC):
         return None
+    if pair is not None:
+        return _conv_dgrad_bn_pair(dy, pair, in_hw, bn_x, bn_stats, relu, bn_y, want_dres, dweight, dbias, accumulate)
     n, co, ho, wo = dy.shape
     ci, co2, k, _ = wt.shape
     hi, wi = in_hw
@@ -1015,6 +1020,40 @@ def conv_dgrad_bn(dy, wt, in_hw, bn_x, bn_stats, relu, bn_y=None, addend=None, w
         _acc_untake(dy.device, acc)
         return None
     check(rc, "afan_conv_dgrad_bn_nhwc_bf16")
+    _grid_check(dy.device, key)
+    CALLS["conv_dgrad"] += 1
+    CALLS["conv_bn_fused"] += 1
+    return dx, dres
+
+
+def _conv_dgrad_bn_pair(dy, pair, in_hw, bn_x, bn_stats, relu, bn_y, want_dres, dweight, dbias, accumulate):
+    dy_sc, wt10 = pair
+    n, co, ho, wo = dy.shape
+    hi, wi = in_hw
+    ci = bn_x.shape[1]
+    key = ("bp", n, ci, hi, wi, co, dy.device.index, _GRID_SHARED)
+    if (not GRID_BN_PAIR or bn_y is None or (hi, wi) != (2 * ho, 2 * wo) or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(ci)
+            or wt10.numel() != ci * 10 * co or dy_sc.shape != dy.shape):
+        return None
+    lib = _lib.load()
+    _cl4(dy, "dy"), _cl4(dy_sc, "dy_sc"), _cl4(bn_x, "bn_x"), _cl4(bn_y, "bn_y")
+    _need(bn_stats, "bn_stats", torch.float32), _need(wt10, "wt10", torch.bfloat16)
+    if dy_sc.data_ptr() != dy.data_ptr() + dy.numel() * 2:
+        raise ValueError("dy_sc must sit directly behind dy in one allocation")
+    if bn_x.shape != (n, ci, hi, wi) or bn_y.shape != bn_x.shape or bn_stats.numel() != 4 * ci:
+        raise ValueError("bn_x / bn_y / bn_stats do not match dx")
+    cl = torch.channels_last
+    dx = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=cl)
+    dres = torch.empty((n, ci, hi, wi), dtype=torch.bfloat16, device=dy.device, memory_format=cl) if want_dres else None
+    acc = acc_take(dy.device, ci)
+    rc = lib.afan_conv_dgrad_sc_bn_nhwc_bf16(_ptr(dy), _ptr(dy_sc), _ptr(wt10), _ptr(dx), _ptr(dres), n, hi, wi, ci, co, _ptr(bn_x),
+                                             _ptr(bn_stats), int(bool(relu)), _ptr(bn_y), _ptr(acc), _ptr(dweight), _ptr(dbias),
+                                             int(bool(accumulate)), _ptr(_grid_barrier(dy.device)), _stream(dy))
+    if rc == -3:
+        _grid_refused.add(key)
+        _acc_untake(dy.device, acc)
+        return None
+    check(rc, "afan_conv_dgrad_sc_bn_nhwc_bf16")
     _grid_check(dy.device, key)
     CALLS["conv_dgrad"] += 1
     CALLS["conv_bn_fused"] += 1

@@ -694,6 +694,18 @@ class _BlockFn(torch.autograd.Function):
                 if pg:
                     _wgrad_accumulate(x, d_rawsc, csc)
                 if need_dx and pair is not None:
+                    if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.stride[0] == 2
+                            and getattr(prev[3], "_branch", "main") == ctx.branch):
+                        # the producing block's last-BatchNorm backward inside this launch too (the stride-2 pair form: one set of
+                        # sums over its four output-parity classes); that block's node finds its results on the tensor handed back
+                        pbn, ppg = prev[3], prev[4]
+                        fused = ops.conv_dgrad_bn(d_raw, None, x.shape[2:], prev[0], prev[1], True, bn_y=x, want_dres=True,
+                                                  dweight=pbn.weight.grad if ppg else None, dbias=pbn.bias.grad if ppg else None,
+                                                  accumulate=ppg, pair=(d_rawsc, wt10))
+                        if fused is not None:
+                            dx = fused[1]
+                            dx._afan_bn_done = fused[0]
+                            return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
                     dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], sc=(d_rawsc, wt10), **fuse)
                 elif need_dx:
                     dx_sc = ops.conv_dgrad(d_rawsc, csc.lp_weight_t(), x.shape[2:], csc.stride[0])

@@ -352,6 +352,13 @@ int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void*
                                  int64_t co, int ksize, int dilation, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
                                  double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
                                  double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream);
+/* The same for the stride-2 pair form (afan_conv_dgrad_sc_nhwc_bf16): the backward of the PREVIOUS block's last BatchNorm (block-output
+ * form: bn_y its stored output, dres the masked gradient for its shortcut) inside the launch that computes the gradient leaving
+ * that block — one set of sums over the four output-parity classes.  hi, wi even. */
+int afan_conv_dgrad_sc_bn_nhwc_bf16(const void* dy, const void* dy_sc, const void* wt10, void* dx, void* dres, int64_t n, int64_t hi,
+                                    int64_t wi, int64_t ci, int64_t co, const void* bn_x, const float* bn_stats, int bn_relu,
+                                    const void* bn_y, double* bn_acc, float* dweight, float* dbias, int accumulate, void* barrier,
+                                    afan_stream_t stream);
 /* dgrad epilogue fusions (all optional, NULL = off):
  *   addend      [N,Hi,Wi,Ci] bf16: dx = bf16(dgrad + addend) — the sum autograd would launch where a block input feeds
  *               both the main branch and the shortcut;

@@ -761,6 +761,46 @@ def test_in_launch_batchnorm_declines_launches_it_cannot_take(pkg, gpu):
     assert int(bn.num_batches_tracked) == 0
 
 
+@pytest.mark.parametrize("n,ci,co,h", [(256, 128, 256, 16), (256, 256, 512, 8), (64, 128, 256, 16), (32, 256, 512, 8)])
+def test_stride2_pair_dgrad_with_in_launch_batchnorm_backward_equals_two_launches(pkg, gpu, n, ci, co, h):
+    """afan_conv_dgrad_sc_bn_nhwc_bf16: the input gradient of a block's first 3x3 / 2 and its 1x1 / 2 projection (ONE launch, four
+    output-parity classes) with the backward of the PREVIOUS block's last BatchNorm inside it — one set of sums over the four
+    classes, then the grid barrier — against afan_conv_dgrad_sc_nhwc_bf16 (sums in its epilogue) + afan_bn_backward_acc: the
+    gradient entering the BatchNorm's input, the masked gradient and the parameter gradients (written, then accumulated), bit for bit."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(7 * n + ci + co + h)
+    both = _cl(torch.randn(2 * n, co, h // 2, h // 2, generator=g).to(gpu).bfloat16())
+    dy, dy_sc = both[:n], both[n:]
+    w1 = (torch.randn(co, ci, 3, 3, generator=g) / (co * 9) ** 0.5).to(gpu).bfloat16()
+    wsc = (torch.randn(co, ci, 1, 1, generator=g) / co ** 0.5).to(gpu).bfloat16()
+    wt10 = torch.cat([w1.permute(1, 2, 3, 0).reshape(ci, 9, co), wsc.permute(1, 2, 3, 0).reshape(ci, 1, co)], dim=1).contiguous()
+    wt1 = _cl(w1.permute(1, 0, 2, 3))
+    bn_x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    res = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    gamma, beta = (torch.rand(ci, generator=g) + 0.5).to(gpu), (torch.randn(ci, generator=g) * 0.3).to(gpu)
+    y, stats = ops.bn_train_forward(bn_x, gamma, beta, res, True, 1e-5, 0.1, None, None, None)
+    got = {}
+    for mode in ("two", "one"):
+        dwb = torch.zeros(2, ci, device=gpu)
+        rs = []
+        for rep in range(2):
+            ops.acc_reset(gpu)
+            if mode == "one":
+                r = ops.conv_dgrad_bn(dy, None, (h, h), bn_x, stats, True, bn_y=y, want_dres=True, dweight=dwb[0], dbias=dwb[1],
+                                      accumulate=rep > 0, pair=(dy_sc, wt10))
+                assert r is not None, "the in-launch form declined a launch of the training step's kind"
+                dx, dres = r
+            else:
+                gsum, part = ops.conv_dgrad(dy, wt1, (h, h), 2, sc=(dy_sc, wt10), bn_bwd=(bn_x, stats, True), bn_y=y)
+                dx, dres = ops.bn_backward(gsum, bn_x, y, stats, gamma, beta, True, True, dwb[0], dwb[1], accumulate=rep > 0, partials=part)
+            rs.append((dx.clone(), dres.clone(), dwb.clone()))
+        got[mode] = rs
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    for a, b in zip(got["one"], got["two"]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_in_launch_batchnorm_beside_side_stream_kernels_takes_one_workgroup_per_cu(pkg, gpu):
     """Round 5 regression (DeepLab at 8 images, weight gradients on the side stream): 276 workgroups of the two-per-CU tile form beside
     a long-lived weight-gradient launch — the first workgroup of a CU lands behind the other kernel's LDS range, that kernel leaves,
