@@ -69,6 +69,8 @@ SIGNATURES = {
                                         _f, _f, _p, _p, _p, _p, _p, _p]),
     "afan_conv_dgrad_bn_nhwc_bf16": (_i, [_p, _p, _p, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p,
                                           _p, _p]),
+    "afan_conv_fwd_multi_bn_nhwc_bf16": (_i, [_p, _p, _p, _i, _l, _l, _l, _l, _l, _p, _i, _p, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p,
+                                              _p]),
     "afan_conv_dgrad_sc_bn_nhwc_bf16": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p]),
     "afan_conv_dgrad_tiles": (_l, [_l, _l, _l, _l, _l, _i, _i]),
     "afan_conv_wgrad_workspace_floats": (_l, [_l, _l, _l, _l, _l, _i, _i]),

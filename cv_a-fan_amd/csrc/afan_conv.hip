@@ -772,7 +772,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     const bool ch_ok = n0 + pc * 8 < pp.Co;      // this thread's 8 output channels exist (Co % 8 == 0)
     const bool want_stats = pp.stats != nullptr || pp.acc != nullptr;
     const bool bn_bwd = want_stats && pp.bnx != nullptr;
-    const bool bf_fwd = BF && pp.bnf == 1, bf_bwd = BF && pp.bnf == 2;
+    // (multi-problem forward launch, ConvP::multi: the BatchNorm belongs to problem 0; the other problems' workgroups run the plain
+    // forward with sums — they store their raw tile and leave without touching the barrier, which counts problem 0's workgroups only)
+    const bool bf_other = BF && pp.multi && blockIdx.z != 0;
+    const bool bf_fwd = BF && pp.bnf == 1 && !bf_other, bf_bwd = BF && pp.bnf == 2;
     const uint16_t* addp = bf_fwd ? pp.bnf_res : (pp.aff ? pp.aff_res : pp.addend);     // the one extra output-shaped operand of either fusion
     // Image groups (two half-batches with their own BatchNorm sums): a tile belongs to the half its rows are in; the ONE tile
     // of a launch that holds rows of both (half-batches of any size: the row count need not be a multiple of the tile) walks
@@ -1021,10 +1024,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             // ---- the BatchNorm itself, inside this launch: every workgroup's sums are in the accumulators once all have passed the
             // barrier; each then derives the coefficients of its own BN channels from the totals (the expressions of apply_acc_kernel /
             // apply_acc_dual_kernel / bwd_apply_acc_kernel, term for term) and finishes its tile from LDS.
+            if (bf_other) {
+#pragma unroll
+                for (int q = 0; q < EPI_ROWS; ++q) {
+                    const int r = pr + q * ROWS_PER_PASS;
+                    const int off = epi_on ? out_off[r] : -1;
+                    if (off >= 0 && ch_ok)
+                        *reinterpret_cast<u16x8*>(y_p + (int64_t)off + n0 + pc * 8) = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+                }
+                return;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's accumulator atomics have been performed
             __syncthreads();
             const unsigned wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            if (tid == 0) grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * gridDim.z);
+            if (tid == 0) grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * (pp.multi ? 1u : gridDim.z));
             if (bf_fwd) {                                             // the raw tile leaves while the other workgroups arrive
 #pragma unroll
                 for (int q = 0; q < EPI_ROWS; ++q) {
@@ -1291,13 +1304,16 @@ int launch_gs(const ConvP& p_in, hipStream_t st, bool dgrad) {
         const int64_t cap = afan_conv::g_bnf_one_per_cu ? (max_resident < n_cus ? max_resident : n_cus) : max_resident;
         if (p.acc_ns > 8) return AFAN_ESHAPE;                        // (the epilogue folds at most 8 accumulator copies)
         if (HL == 0 && p.bsc.x) return AFAN_ESHAPE;                  // (the projection BatchNorm's backward: halo-form launches only)
-        if ((int64_t)grid.x * grid.y * grid.z > cap || (int64_t)grid.x * grid.y * grid.z < 8 || !p.bar || !p.acc || p.groups != 1 || p.multi)
+        // (multi-problem forward: only problem 0's workgroups meet at the barrier, and they are dispatched first — z is the slowest grid
+        // dimension — so they alone must fit; the other problems' workgroups wait for nothing)
+        const int64_t meet = (int64_t)grid.x * grid.y * (p.multi ? 1 : grid.z);
+        if (meet > cap || meet < 8 || !p.bar || !p.acc || p.groups != 1 || (p.multi && (p.bnf != 1 || p.bnf_sc.acc || p.bnf_res)))
             return AFAN_ESHAPE;
         // several output-parity classes (a stride-2 input gradient): one set of sums over all of them; every tile of the grid must
         // be a real one (a workgroup of a smaller class would leave at the top, before the barrier): classes of equal size only
         for (int z = 1; z < p.n_classes; ++z)
             if (p.cls[z].Hg != p.cls[0].Hg || p.cls[z].Wg != p.cls[0].Wg) return AFAN_ESHAPE;
-        if (p.n_classes != 1 && (p.bnf != 2 || p.bsc.x)) return AFAN_ESHAPE;
+        if (p.n_classes != 1 && !p.multi && (p.bnf != 2 || p.bsc.x)) return AFAN_ESHAPE;
     }
     if (dgrad) conv_igemm_dgrad_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
     else conv_igemm_fwd_kernel<BM, BN, PF, WM, WN, PW, FBT, HL, GS, BF><<<grid, THREADS, lds, st>>>(p);
@@ -1718,9 +1734,9 @@ int afan_conv_fwd_affine_nhwc_bf16(const void* x, const void* w, void* y, int64_
 // a BasicBlock's first 3x3 convolution with its 1x1 projection shortcut (Classification/resnet_s.py:52-77 option B: both
 // read x at stride 2 and write [N, planes, H/2, W/2]).  ksize[b] in {1, 3}, padding dilation[b] * (ksize[b] / 2).
 // BatchNorm moments go to f64 accumulator blocks (one per problem; groups = 2: two consecutive ones, one per half-batch) or nowhere.
-int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
-                                  int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
-                                  const float* const* stats_shift, double* const* stats_acc, int groups, afan_stream_t stream) {
+static int fwd_multi_impl(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
+                          int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
+                          const float* const* stats_shift, double* const* stats_acc, int groups, afan_stream_t stream, const ConvP* bnf) {
     if (nb < 1 || nb > 4) return AFAN_ESHAPE;
     if (groups != 1 && (groups != 2 || !stats_acc || (n & 1))) return AFAN_ESHAPE;
     if (!w || !y || !dilation || !ksize) return AFAN_ENULL;
@@ -1777,8 +1793,46 @@ int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* con
         wbytes += 2.0 * co * k * k * ci;
     }
     hipStream_t st = (hipStream_t)stream;
-    AFAN_PROF_FLOPS("conv_igemm_fwd_kernel", nb * 2.0 * n * ho * wo * co + wbytes + 2.0 * (double)n * hi * wi * ci, flops, st);
+    AFAN_PROF_FLOPS(bnf ? "conv_bn_fwd_kernel" : "conv_igemm_fwd_kernel", (nb + (bnf ? 1 : 0)) * 2.0 * n * ho * wo * co + wbytes + 2.0 * (double)n * hi * wi * ci, flops, st);
+    if (bnf) {         // problem 0's train-mode BatchNorm (+ ReLU) inside the launch (afan_conv_fwd_multi_bn_nhwc_bf16)
+        if (!stats_acc || groups != 1 || ci % 64 != 0 || co % 64 != 0) return AFAN_ESHAPE;
+        const int64_t M = n * ho * wo;
+        const int pending = afan_nhwc::set_running_updates(1);
+        afan_nhwc::set_running_updates(pending);
+        p.bnf = 1; p.bar = bnf->bar; p.y2 = bnf->y2;
+        p.bnf_w = bnf->bnf_w; p.bnf_b = bnf->bnf_b; p.bnf_eps = bnf->bnf_eps; p.bnf_mom = bnf->bnf_mom;
+        p.bnf_rmean = bnf->bnf_rmean; p.bnf_rvar = bnf->bnf_rvar; p.bnf_nbt = bnf->bnf_nbt; p.bnf_updates = pending;
+        p.bnf_stats = bnf->bnf_stats; p.bnf_relu = bnf->bnf_relu;
+        p.bnf_inv_m = 1.0 / (double)M;
+        p.bnf_unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+        return dispatch_bnf(p, st, false);
+    }
     return dispatch(p, st, false);
+}
+
+int afan_conv_fwd_multi_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
+                                  int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
+                                  const float* const* stats_shift, double* const* stats_acc, int groups, afan_stream_t stream) {
+    return fwd_multi_impl(x, w, y, nb, n, hi, wi, ci, co, ksize, stride, dilation, stats_shift, stats_acc, groups, stream, nullptr);
+}
+
+// The same launch with problem 0's train-mode BatchNorm (+ ReLU) applied inside it (y_act0 = relu(bn(y[0])), stats0 [4][co] out,
+// running buffers updated like afan_bn_train_forward_acc would): a residual block's first 3x3 / stride-2 convolution, whose 1x1
+// projection rides as problem 1 (its BatchNorm is applied by the block's last launch).  Only problem 0's workgroups meet at the
+// grid barrier.  AFAN_ESHAPE: nothing has run (afan_conv_fwd_multi_nhwc_bf16 + afan_bn_train_forward_acc instead).
+int afan_conv_fwd_multi_bn_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
+                                     int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
+                                     const float* const* stats_shift, double* const* stats_acc, void* y_act0, const float* bn_weight,
+                                     const float* bn_bias, float eps, float momentum, float* stats0, float* running_mean,
+                                     float* running_var, int64_t* num_batches, int relu, void* barrier, afan_stream_t stream) {
+    if (!y_act0 || !stats0 || !barrier || !stats_acc || !stats_shift) return AFAN_ENULL;
+    if (!aligned(y_act0, 16) || !aligned(barrier, 64)) return AFAN_EALIGN;
+    if (nb < 2) return AFAN_ESHAPE;
+    ConvP b{};
+    b.bar = (unsigned*)barrier; b.y2 = (uint16_t*)y_act0;
+    b.bnf_w = bn_weight; b.bnf_b = bn_bias; b.bnf_eps = eps; b.bnf_mom = momentum;
+    b.bnf_rmean = running_mean; b.bnf_rvar = running_var; b.bnf_nbt = num_batches; b.bnf_stats = stats0; b.bnf_relu = relu ? 1 : 0;
+    return fwd_multi_impl(x, w, y, nb, n, hi, wi, ci, co, ksize, stride, dilation, stats_shift, stats_acc, 1, stream, &b);
 }
 
 // number of partial slots per channel the dgrad launch of this problem writes when asked for fused BN-backward sums

@@ -18,7 +18,7 @@ int g_bnf_one_per_cu = 0;
 // dispatch()'s halo-form choices, with the BF instantiations; any other launch: AFAN_ESHAPE (the caller issues two launches)
 int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     static const int halo = env_int("AFAN_CONV_HALO", 1);
-    if (!halo || p.Co % 128 != 0 || p.multi || p.stats || !p.acc || p.groups != 1) return AFAN_ESHAPE;
+    if (!halo || p.Co % 128 != 0 || p.stats || !p.acc || p.groups != 1) return AFAN_ESHAPE;
     const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
     const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
     constexpr int deep_max = 384;

@@ -1122,6 +1122,52 @@ def conv_fwd_multi(x, ws, stride, dilations, stats_shifts=None, groups=1):
     return ys, sts
 
 
+GRID_BN_MULTI = os.environ.get("AFAN_GRID_BN_MULTI", "1") != "0"       # ... and in the two-problem forward launch (first 3x3 / 2 + projection)
+
+
+def conv_fwd_multi_bn(x, ws, stride, dilations, stats_shifts, bn0, momentum):
+    """conv_fwd_multi with problem 0's train-mode BatchNorm + ReLU inside the launch (afan_conv_fwd_multi_bn_nhwc_bf16: a residual
+    block's first 3x3 / stride-2 convolution; its projection rides as problem 1): (ys, ConvStats list, act0, stats0), the bits of
+    conv_fwd_multi + bn_train_forward on ys[0].  None when the launch is not eligible (nothing has run)."""
+    if not (GRID_BN and GRID_BN_MULTI and x.is_cuda and BN_ACC) or stats_shifts is None:
+        return None
+    nb = len(ws)
+    n, ci, hi, wi = x.shape
+    co, _, k, _ = ws[0].shape
+    key = ("fm", n, ci, hi, wi, co, nb, k, int(stride), x.device.index, _GRID_SHARED)
+    if nb < 2 or ci % 64 or co % 64 or key in _grid_refused or not _conv_acc_ok(co):
+        return None
+    lib = _lib.load()
+    _cl4(x, "x")
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    cl = torch.channels_last
+    yall = torch.empty((nb * n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    ys = [yall[b * n:(b + 1) * n] for b in range(nb)]
+    act0 = torch.empty((n, co, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=cl)
+    stats0 = torch.empty((4, co), dtype=torch.float32, device=x.device)
+    arr_p = C.c_void_p * nb
+    sts = [ConvStats(None, 0, stats_shifts[b], acc_take(x.device, co, 1)) for b in range(nb)]
+    rc = lib.afan_conv_fwd_multi_bn_nhwc_bf16(_ptr(x), arr_p(*[w.data_ptr() for w in ws]), arr_p(*[y.data_ptr() for y in ys]), nb,
+                                              n, hi, wi, ci, co, (C.c_int * nb)(*[int(w.shape[2]) for w in ws]), int(stride),
+                                              (C.c_int * nb)(*[int(d) for d in dilations]), arr_p(*[t.data_ptr() for t in stats_shifts]),
+                                              arr_p(*[st.acc.data_ptr() for st in sts]), _ptr(act0), _ptr(bn0.weight), _ptr(bn0.bias),
+                                              float(bn0.eps), float(momentum), _ptr(stats0), _ptr(bn0.running_mean),
+                                              _ptr(bn0.running_var), _ptr(bn0.num_batches_tracked), 1, _ptr(_grid_barrier(x.device)),
+                                              _stream(x))
+    if rc == -3:
+        _grid_refused.add(key)
+        for st in reversed(sts):
+            _acc_untake(x.device, st.acc)
+        return None
+    check(rc, "afan_conv_fwd_multi_bn_nhwc_bf16")
+    _grid_check(x.device, key)
+    CALLS["conv_fwd"] += nb
+    CALLS["conv_bn_fused"] += 1
+    _bn_record(bn0.running_mean, bn0.running_var, bn0.num_batches_tracked, stats0, n * ho * wo, bn0.eps, momentum, 1)
+    return ys, sts, act0, stats0
+
+
 def conv_dgrad(dy, wt, in_hw, stride, addend=None, bn_bwd=None, partials_buf=None, bn_y=None, groups=1, dilation=1, sc=None):
     """dx for y = conv2d(x, w): dy [N,Co,Ho,Wo]; wt = w.permute(1,0,2,3) as [Ci,Co,k,k] channels_last (CRSK memory).
     addend: bf16 tensor of dx's shape added in the epilogue.  bn_bwd = (bn_x, stats[4,Ci], relu): dx is the gradient

@@ -528,7 +528,7 @@ class _BlockFn(torch.autograd.Function):
         n = len(chain)
         G = _Flags.bn_groups
         mom = lambda bn: bn.momentum if bn.momentum is not None else 0.1
-        rawsc = ssc = first = None
+        rawsc = ssc = first = first_done = None
         dual_sc = False
         if blk._sc_kind == "conv":
             csc, bsc = blk.shortcut[0], blk.shortcut[1]
@@ -538,8 +538,15 @@ class _BlockFn(torch.autograd.Function):
                     and ops.conv_fwd_multi_ok(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0])):
                 # a BasicBlock's first 3x3 and its 1x1 projection read the same x at the same stride and write the same
                 # shape: one launch, two problems (afan_conv_fwd_multi_nhwc_bf16)
-                (raw1, rawsc), (st1, stc) = ops.conv_fwd_multi(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0], [1, 1],
-                                                               [b1.running_mean, bsc.running_mean])
+                # ... with the first convolution's BatchNorm + ReLU inside that launch where its workgroups fit the chip
+                fm = ops.conv_fwd_multi_bn(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0], [1, 1],
+                                           [b1.running_mean, bsc.running_mean], b1, mom(b1)) if ops.GRID_BN else None
+                if fm is not None:
+                    (raw1, rawsc), (st1, stc), act1, s1 = fm
+                    first_done = (act1, s1)
+                else:
+                    (raw1, rawsc), (st1, stc) = ops.conv_fwd_multi(x, [c1.lp_weight(), csc.lp_weight()], c1.stride[0], [1, 1],
+                                                                   [b1.running_mean, bsc.running_mean])
                 first = (raw1, st1)
             else:
                 rawsc, stc = ops.conv_fwd(x, csc.lp_weight(), csc.stride[0], stats_shift=bsc.running_mean, want_stats=True,
@@ -558,6 +565,10 @@ class _BlockFn(torch.autograd.Function):
         a, saved = x, []
         for i, (c, b) in enumerate(chain):
             last = i == n - 1
+            if i == 0 and first_done is not None and not last:
+                saved += [first[0], first_done[0], first_done[1]]
+                a = first_done[0]
+                continue
             if G == 1 and ops.GRID_BN and not (i == 0 and first is not None) and c.kernel_size[0] in (1, 3) and c.stride[0] == 1:
                 # convolution + BatchNorm (+ shortcut) + ReLU as ONE launch (grid barrier between the sums and the second pass:
                 # ops.conv_fwd_bn); None = this launch does not take that form, the two launches below run instead (same bits)

@@ -352,6 +352,15 @@ int afan_conv_dgrad_bn_nhwc_bf16(const void* dy, const void* wt, void* dx, void*
                                  int64_t co, int ksize, int dilation, const void* addend, const void* bn_x, const float* bn_stats, int bn_relu, const void* bn_y,
                                  double* bn_acc, float* dweight, float* dbias, int accumulate, const void* sc_x, const float* sc_stats,
                                  double* sc_acc, void* d_sc, float* sc_dweight, float* sc_dbias, void* barrier, afan_stream_t stream);
+/* afan_conv_fwd_multi_nhwc_bf16 with problem 0's train-mode BatchNorm (+ ReLU) applied inside the launch: y_act0 = [relu](bn(y[0])),
+ * stats0 [4][co] out, running buffers updated like afan_bn_train_forward_acc — a residual block's first 3x3 / stride-2 convolution
+ * (Classification/resnet_s.py:72) with its 1x1 projection as problem 1 (whose BatchNorm the block's last launch applies).  Only
+ * problem 0's workgroups meet at the grid barrier; stats_acc / stats_shift required for every problem. */
+int afan_conv_fwd_multi_bn_nhwc_bf16(const void* x, const void* const* w, void* const* y, int nb, int64_t n, int64_t hi, int64_t wi,
+                                     int64_t ci, int64_t co, const int* ksize, int stride, const int* dilation,
+                                     const float* const* stats_shift, double* const* stats_acc, void* y_act0, const float* bn_weight,
+                                     const float* bn_bias, float eps, float momentum, float* stats0, float* running_mean,
+                                     float* running_var, int64_t* num_batches, int relu, void* barrier, afan_stream_t stream);
 /* The same for the stride-2 pair form (afan_conv_dgrad_sc_nhwc_bf16): the backward of the PREVIOUS block's last BatchNorm (block-output
  * form: bn_y its stored output, dres the masked gradient for its shortcut) inside the launch that computes the gradient leaving
  * that block — one set of sums over the four output-parity classes.  hi, wi even. */

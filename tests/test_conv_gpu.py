@@ -801,6 +801,46 @@ def test_stride2_pair_dgrad_with_in_launch_batchnorm_backward_equals_two_launche
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("n,ci,co,h", [(256, 64, 128, 32), (256, 128, 256, 16), (256, 256, 512, 8), (32, 128, 256, 16)])
+def test_two_problem_forward_with_in_launch_batchnorm_equals_two_launches(pkg, gpu, n, ci, co, h):
+    """afan_conv_fwd_multi_bn_nhwc_bf16: a block's first 3x3 / stride-2 convolution and its 1x1 / stride-2 projection as ONE launch
+    with the first one's BatchNorm + ReLU inside it (only problem 0's workgroups meet at the barrier; the projection's leave after
+    their sums) against afan_conv_fwd_multi_nhwc_bf16 + afan_bn_train_forward_acc: both raw outputs, the normalised output, the
+    statistics block, the running buffers, and the projection's accumulator sums (read through its own BatchNorm) — every bit."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(11 * n + ci + co + h)
+    x = _cl(torch.randn(n, ci, h, h, generator=g).to(gpu).bfloat16())
+    w1 = _cl((torch.randn(co, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(gpu).bfloat16())
+    wsc = _cl((torch.randn(co, ci, 1, 1, generator=g) / ci ** 0.5).to(gpu).bfloat16())
+    out = {}
+    for mode in ("two", "one"):
+        bn, bsc = _mk_bn(co, gpu, 1), _mk_bn(co, gpu, 2)
+        got = []
+        for rep in range(2):
+            ops.acc_reset(gpu)
+            if mode == "one":
+                r = ops.conv_fwd_multi_bn(x, [w1, wsc], 2, [1, 1], [bn.running_mean, bsc.running_mean], bn, 0.1)
+                assert r is not None, "the in-launch form declined a launch of the training step's kind"
+                (raw1, rawsc), (st1, stc), act, st = r
+            else:
+                (raw1, rawsc), (st1, stc) = ops.conv_fwd_multi(x, [w1, wsc], 2, [1, 1], [bn.running_mean, bsc.running_mean])
+                act, st = ops.bn_train_forward(raw1, bn.weight, bn.bias, None, True, bn.eps, 0.1, bn.running_mean, bn.running_var,
+                                               bn.num_batches_tracked, st1)
+            ysc, ssc = ops.bn_train_forward(rawsc, bsc.weight, bsc.bias, None, False, bsc.eps, 0.1, bsc.running_mean, bsc.running_var,
+                                            bsc.num_batches_tracked, stc)
+            got.append((raw1.clone(), rawsc.clone(), act.clone(), st.clone(), ysc.clone(), ssc.clone(), _bn_state(bn), _bn_state(bsc)))
+        out[mode] = got
+    torch.cuda.synchronize()
+    assert not ops.grid_barrier_error(gpu)
+    for a, b in zip(out["one"], out["two"]):
+        for p_, q_ in zip(a, b):
+            if isinstance(p_, dict):
+                for k in p_:
+                    assert torch.equal(p_[k], q_[k]), k
+            else:
+                assert torch.equal(p_, q_)
+
+
 def test_in_launch_batchnorm_beside_side_stream_kernels_takes_one_workgroup_per_cu(pkg, gpu):
     """Round 5 regression (DeepLab at 8 images, weight gradients on the side stream): 276 workgroups of the two-per-CU tile form beside
     a long-lived weight-gradient launch — the first workgroup of a CU lands behind the other kernel's LDS range, that kernel leaves,

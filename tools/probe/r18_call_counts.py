@@ -1,0 +1,14 @@
+import importlib, os, sys, torch, torch.nn as nn
+sys.path.insert(0, "/root/repo")
+pkg = importlib.import_module("cv_a-fan_amd")
+ops = pkg.ops
+dev = torch.device("cuda:0")
+m = pkg.resnet_s.ARCHS["resnet18"][0]()
+m.set_compute_dtype(torch.bfloat16); m.to(dev).train(); m.set_channels_last(True)
+tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=5, gamma=0.5, eps=2.0, perturb_idx=6, lr=0.05, use_graph=False, fold_clean=True, share_head=True)
+x, y = torch.rand(256, 3, 32, 32, device=dev), torch.randint(0, 10, (256,), device=dev)
+tr.step(x, y)
+b = dict(ops.CALLS)
+tr.step(x, y)
+print({k: ops.CALLS[k] - b[k] for k in ops.CALLS if ops.CALLS[k] != b[k]})
+print(sorted(k for k in ops._grid_refused))
