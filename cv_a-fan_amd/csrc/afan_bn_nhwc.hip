@@ -482,6 +482,31 @@ __device__ __forceinline__ void fold_slots(const double* __restrict__ acc, int C
     }
 }
 
+// Many channels, few accumulator copies (NS * C <= 1024: C >= 512 has NS <= 2): a thread derives up to AHEAD_IT channels
+// (c = tid + it * BLOCK).  One channel at a time each iteration waited for its own accumulator reads — memory-side data, ~1 us —
+// before the next one's were asked for: 8 iterations at 2 048 channels, 10 of the kernel's 20 us (tools/probe/bn_apply_prologue.py:
+// 20.6 us against 9.9 us with the coefficients given).  Here every iteration's reads leave first; the sums keep fold_slots' order
+// ((0.0 + copy 0) + copy 1, the further zero terms change nothing).
+constexpr int AHEAD_IT = 8;
+__device__ __forceinline__ void fold_ahead(const double* __restrict__ acc, int C, int NS, double (&a)[AHEAD_IT], double (&b)[AHEAD_IT]) {
+    double a0[AHEAD_IT], b0[AHEAD_IT], a1[AHEAD_IT], b1[AHEAD_IT];
+#pragma unroll
+    for (int it = 0; it < AHEAD_IT; ++it) {
+        const int c = threadIdx.x + it * BLOCK;
+        const bool ok = c < C, two = ok && NS == 2;
+        a0[it] = ok ? acc[c] : 0.0;
+        b0[it] = ok ? acc[(int64_t)C + c] : 0.0;
+        a1[it] = two ? acc[(int64_t)2 * C + c] : 0.0;
+        b1[it] = two ? acc[(int64_t)3 * C + c] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < AHEAD_IT; ++it) {
+        a[it] = (0.0 + a0[it]) + a1[it];
+        b[it] = (0.0 + b0[it]) + b1[it];
+    }
+}
+__device__ __forceinline__ bool fold_ahead_ok(int C, int NS) { return C > BLOCK && C <= AHEAD_IT * BLOCK && NS <= 2; }
+
 // ---- accumulator path: coefficients derived in the prologue of the streaming kernels themselves ----------------
 // forward: acc[slot][0][c] = sum (x - shift), acc[slot][1][c] = sum (x - shift)^2 (f64); shift = given [C] floats, or
 // row 0 of x.  Each block folds the NS copies and derives alpha/beta for all C channels once (one channel per thread,
@@ -508,12 +533,7 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
     if (RES) res += (int64_t)grp * nvec * VEC;
     const double* acc_g = acc + (int64_t)grp * acc_stride;
     float* stats_g = stats + (int64_t)grp * 4 * C;
-    for (int c = threadIdx.x; c < C; c += BLOCK) {
-        const float wv = weight ? weight[c] : 1.f, bv = bias ? bias[c] : 0.f;
-        double a, b;
-        fold_slots(acc_g, C, NS, c, a, b);
-        const float sh = shift_in_acc ? reinterpret_cast<const float*>(acc_g + (int64_t)2 * NS * C)[c]
-                                      : (shift ? shift[c] : Elt<T>::ld(x + c));
+    auto derive = [&](int c, double a, double b, float wv, float bv, float sh) {
         const double dm = a * inv_m;
         const double m2 = fmax(b - a * dm, 0.0);
         const float mean = (float)((double)sh + dm);      // (not sh + (float)dm: that rounds at |sh|, not at |mean|)
@@ -550,6 +570,34 @@ __global__ __launch_bounds__(BLOCK) void apply_acc_kernel(const T* __restrict__ 
                     }
                 }
             }
+        }
+    };
+    auto shift_of = [&](int c) {
+        return shift_in_acc ? reinterpret_cast<const float*>(acc_g + (int64_t)2 * NS * C)[c] : (shift ? shift[c] : Elt<T>::ld(x + c));
+    };
+    if (fold_ahead_ok(C, NS)) {
+        double a_[AHEAD_IT], b_[AHEAD_IT];
+        float w_[AHEAD_IT], bi_[AHEAD_IT], sh_[AHEAD_IT];
+        fold_ahead(acc_g, C, NS, a_, b_);
+#pragma unroll
+        for (int it = 0; it < AHEAD_IT; ++it) {
+            const int c = threadIdx.x + it * BLOCK;
+            const bool ok = c < C;
+            w_[it] = (ok && weight) ? weight[c] : 1.f;
+            bi_[it] = (ok && bias) ? bias[c] : 0.f;
+            sh_[it] = ok ? shift_of(c) : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < AHEAD_IT; ++it) {
+            const int c = threadIdx.x + it * BLOCK;
+            if (c < C) derive(c, a_[it], b_[it], w_[it], bi_[it], sh_[it]);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += BLOCK) {
+            const float wv = weight ? weight[c] : 1.f, bv = bias ? bias[c] : 0.f;
+            double a, b;
+            fold_slots(acc_g, C, NS, c, a, b);
+            derive(c, a, b, wv, bv, shift_of(c));
         }
     }
     __syncthreads();
@@ -668,10 +716,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_apply_acc_kernel(const T* __restric
     if (DRES) dres += (int64_t)grp * nvec * VEC;
     const double* acc_g = acc + (int64_t)grp * acc_stride;
     const float* stats_g = stats + (int64_t)grp * 4 * C;
-    for (int c = threadIdx.x; c < C; c += BLOCK) {
-        double a, b;
-        fold_slots(acc_g, C, NS, c, a, b);
-        const float is = stats_g[C + c], alpha = stats_g[2 * C + c];
+    auto derive = [&](int c, double a, double b, float is, float alpha) {
         float sum_g = (float)a;
         float sum_gx = (float)b * is;
         coef[c] = -alpha * is * (float)((double)sum_gx * inv_m);
@@ -685,6 +730,28 @@ __global__ __launch_bounds__(BLOCK) void bwd_apply_acc_kernel(const T* __restric
             }
             if (dbias) dbias[c] = accumulate ? dbias[c] + sum_g : sum_g;
             if (dweight) dweight[c] = accumulate ? dweight[c] + sum_gx : sum_gx;
+        }
+    };
+    if (fold_ahead_ok(C, NS)) {
+        double a_[AHEAD_IT], b_[AHEAD_IT];
+        float is_[AHEAD_IT], al_[AHEAD_IT];
+        fold_ahead(acc_g, C, NS, a_, b_);
+#pragma unroll
+        for (int it = 0; it < AHEAD_IT; ++it) {
+            const int c = threadIdx.x + it * BLOCK;
+            is_[it] = c < C ? stats_g[C + c] : 0.f;
+            al_[it] = c < C ? stats_g[2 * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < AHEAD_IT; ++it) {
+            const int c = threadIdx.x + it * BLOCK;
+            if (c < C) derive(c, a_[it], b_[it], is_[it], al_[it]);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += BLOCK) {
+            double a, b;
+            fold_slots(acc_g, C, NS, c, a, b);
+            derive(c, a, b, stats_g[C + c], stats_g[2 * C + c]);
         }
     }
     __syncthreads();
