@@ -564,24 +564,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         } else
         {
             late_prologue();
-            // The epilogue's output-shaped operand tiles (a BatchNorm backward's input and stored output, the other branch's gradient /
-            // the residual) are asked for HERE, one 1 KiB piece per MFMA wave and tap, as DMAs into the landing zone nobody reads: all
-            // workgroups of these launches reach their epilogue together, so its 2-3 x 64 KB per workgroup moved while the MFMA pipes
-            // idled and the K loop ran while HBM idled (launch-phase stamps: the first epilogue pass of the block-output input gradient
-            // 30 k of the launch's 97 k ticks).  The pieces now cross the fabric under the K loop and wait in L2 / MALL.
-            // (Stride-1 same-size problems only — the halo form — so output row m sits at m * Co.)
-            constexpr int PF_RPI = 1024 / (BN * 2), PF_CH = BM / PF_RPI;       // tile rows per instruction, instructions per operand tile
-            const bool pf_sums = pp.stats != nullptr || pp.acc != nullptr, pf_bwd = pf_sums && pp.bnx != nullptr;
-            const uint16_t* const pf_p0 = pp.epi_pf && pf_bwd ? pp.bnx : nullptr;
-            const uint16_t* const pf_p1 = pp.epi_pf && pf_bwd ? pp.bny : nullptr;
-            const uint16_t* const pf_p2 = !pp.epi_pf ? nullptr : ((BF && pp.bnf == 1) ? pp.bnf_res : (pp.aff ? pp.aff_res : pp.addend));
-            const int pf_bytes = (int)((int64_t)pp.N * pp.Ho * pp.Wo * pp.Co * 2);
-            const __amdgpu_buffer_rsrc_t pf_r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pf_p0), 0, pf_p0 ? pf_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t pf_r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pf_p1), 0, pf_p1 ? pf_bytes : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t pf_r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pf_p2), 0, pf_p2 ? pf_bytes : 0, 0x00020000);
-            const uint32_t pf_row = m0 + (uint32_t)(lane / (BN / 8)), pf_col = (uint32_t)(n0 + (lane % (BN / 8)) * 8);
-            int pf_s = wave;                                                       // (wave-uniform) next piece of this wave: pieces wave, wave + NW, ...
-            const int pf_per = ((3 * PF_CH + NW - 1) / NW + KS - 1) / KS;          // pieces per tap so that the K loop covers them all (1 or 2)
             for (int q = 0; q < chunks; ++q) {
                 // (opaque per chunk: otherwise the nine taps' fragment addresses are hoisted out of the chunk loop as
                 // 40-odd loop-invariant registers, which the 168-register variant spills)
@@ -594,15 +576,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     AFAN_STAMP(0, q * 9 + t, 1);
                     compute_h((q + t) & 3, q & 1, tj[t], tv[t]);
                     AFAN_STAMP(0, q * 9 + t, 2);
-                    for (int u = 0; u < pf_per && pf_s < 3 * PF_CH; ++u) {
-                        const int op = pf_s / PF_CH, ch = pf_s - op * PF_CH;
-                        const uint32_t row = pf_row + (uint32_t)(ch * PF_RPI);
-                        const uint32_t vo = (row < M && pf_col < (uint32_t)pp.Co) ? (row * (uint32_t)pp.Co + pf_col) * 2u : OOB;
-                        if (op == 0) { if (pf_p0) __builtin_amdgcn_raw_ptr_buffer_load_lds(pf_r0, (lptr)pad_zone, 16, (int)vo, 0, 0, 0); }
-                        else if (op == 1) { if (pf_p1) __builtin_amdgcn_raw_ptr_buffer_load_lds(pf_r1, (lptr)pad_zone, 16, (int)vo, 0, 0, 0); }
-                        else { if (pf_p2) __builtin_amdgcn_raw_ptr_buffer_load_lds(pf_r2, (lptr)pad_zone, 16, (int)vo, 0, 0, 0); }
-                        pf_s += NW;
-                    }
                 }
             }
         }
@@ -1264,16 +1237,9 @@ static int64_t max_rows(const ConvP& p) {
 // ConvP::coef: the rows the kernel's prologue prefetches for its epilogue — a fused BatchNorm backward's mean | alpha | beta
 // (bn_stats rows 0, 2, 3; the second image group's block 4 * Co further), else the sums' shift in slot 0 and a frozen BatchNorm's
 // alpha | beta (forward) or alpha (backward) in slots 1 | 2
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 inline void fill_coef(ConvP& p) {
     const float* const dummy = reinterpret_cast<const float*>(p.w);
     const bool ws = p.stats != nullptr || p.acc != nullptr, bb = ws && p.bnx != nullptr;
-    static const int epi_pf = env_int("AFAN_CONV_EPI_PF", 1);     // 0: no epilogue-operand prefetch under the K loop (A/B)
-    p.epi_pf = epi_pf;
     p.coef[0] = p.coef[1] = p.coef[2] = dummy;
     p.coef_mask = 0;
     p.coef_gofs = 0;
@@ -1369,6 +1335,11 @@ int launch(const ConvP& p, hipStream_t st, bool dgrad) {
         else return AFAN_ESHAPE;
     }
     return launch_gs<BM, BN, PF, WM, WN, PW, FBT, HL, false>(p, st, dgrad);
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 // tile choice: fill >= ~256 workgroups when the problem allows it

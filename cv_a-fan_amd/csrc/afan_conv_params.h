@@ -63,7 +63,6 @@ struct ConvP {
     const float* coef[3];
     int coef_mask;
     int coef_gofs;
-    int epi_pf;                  // 1: the halo form's MFMA waves ask for the epilogue's operand tiles under the K loop (L2 prefetch)
     ConvClass cls[4];
     // ---- round 5: the BatchNorm behind (forward) / in front of (backward) this convolution applied INSIDE the launch.  Batch
     // statistics need every tile of the launch, so the epilogue meets all other workgroups at a grid-wide barrier between its
