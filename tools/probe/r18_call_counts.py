@@ -1,5 +1,8 @@
+"""Library calls of ONE ResNet-18 A-FAN step (batch 256, K = 5, folded schedule, eager) by kind — how many convolution launches carry a
+BatchNorm inside them (ops.CALLS["conv_bn_fused"]) — and which shapes the in-launch form declined.
+    python tools/probe/r18_call_counts.py        (AFAN_GRID_BN_MULTI=0 / AFAN_GRID_BN_PAIR=0 / AFAN_GRID_BN_1X1=0 to compare)"""
 import importlib, os, sys, torch, torch.nn as nn
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 pkg = importlib.import_module("cv_a-fan_amd")
 ops = pkg.ops
 dev = torch.device("cuda:0")
