@@ -294,6 +294,43 @@ def test_deeplab_full_size_properties(pkg, gpu):
     np.testing.assert_allclose(out["graph"], out["eager"], rtol=0, atol=5e-3)
 
 
+def test_deeplab_with_side_stream_weight_gradients_gives_up_no_barrier_and_changes_no_bit(pkg, gpu):
+    """Round 5 regression at the iteration's level (profiles/r05j_dl101b8_barrier_timeout_trace.txt): 8 images, the weight gradients
+    on the side stream (SegTrainer's own choice from 8 x 513^2 on: that size, because at 257^2 the weight-gradient workgroups are too
+    short-lived to pin a CU's LDS and the fault does not show — tools/probe/side_stream_sensitivity.py with the fix switched off:
+    no timeout at 257^2, a timeout at 513^2) — layer4's 276-workgroup launches are on the two-per-CU tile, the form that cannot share
+    CUs with another kernel's long-lived workgroups.  Beside side-stream kernels the in-launch BatchNorm takes one workgroup per CU only (the others: two launches, the
+    same bits): no grid barrier gives up, and losses, perturbations and parameters equal the iteration without the side stream."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(9)
+    images = torch.rand(8, 3, 513, 513, generator=g).to(gpu)
+    labels = torch.randint(0, 21, (8, 513, 513), generator=g).to(gpu)
+    res = {}
+    for side in (False, True):
+        torch.manual_seed(3)
+        model = pkg.deeplab.deeplabv3plus_resnet101(num_classes=21, output_stride=16)
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        model.set_compute_dtype(torch.bfloat16).set_channels_last(True).to(gpu).train()
+        tr = pkg.seg_trainer.SegTrainer(model, steps=2, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3, pertub_idx_sd="aspp",
+                                        mix_layer="11", mix_sd=True, lr=0.01, use_graph=False, wgrad_stream=side)
+        before = ops.CALLS["conv_bn_fused"]
+        outs = []
+        for _ in range(2):
+            r = tr.step(images, labels)
+            outs.append((r["loss"].clone(), r["adv_se"].clone(), r["adv_sd"].clone()))
+        torch.cuda.synchronize()
+        assert not ops.grid_barrier_error(gpu)
+        assert side or ops.CALLS["conv_bn_fused"] > before      # (beside the side stream every launch of this size is beyond one workgroup per CU)
+        res[side] = (outs, tr.arena.param.clone())
+        del tr, model
+    for a, b in zip(res[False][0], res[True][0]):
+        for p_, q_ in zip(a, b):
+            assert torch.equal(p_, q_)
+    assert torch.equal(res[False][1], res[True][1])
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_phased_iteration_equals_the_plain_one(pkg, gpu, dropout):
     """The data-parallel schedule on ONE GPU (SegTrainer(segmented=True)): the joint backward in two parts with a yield in
