@@ -9,6 +9,7 @@ pkg = importlib.import_module("cv_a-fan_amd")
 lib = C.CDLL(pkg._lib.LIB_PATH)
 dev = torch.device("cuda:0")
 cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+BNF_RD = getattr(lib, "afan_conv_bnf_stamps", None)      # (None: the stamped in-launch-BatchNorm unit did not compile, tools/build_stamp.sh)
 SEC = os.environ.get("CONV_STAMPS", "all")     # all | taps | r18 | deeplab | r50
 if SEC in ("all", "taps"):
     for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)):
@@ -90,10 +91,13 @@ if SEC in ("all", "r18"):
         for name, fn, rd in (
                 ("forward, plain", lambda: ops.conv_fwd(x, w, 1), lib.afan_conv_stamps),
                 ("forward + BatchNorm sums", lambda: (ops.acc_reset(dev), ops.conv_fwd(x, w, 1, stats_shift=bn.running_mean, want_stats=True)), lib.afan_conv_stamps),
-                ("forward + BatchNorm in the launch", lambda: (ops.acc_reset(dev), ops.conv_fwd_bn(x, w, bn, 0.1, relu=True)), lib.afan_conv_bnf_stamps),
+                ("forward + BatchNorm in the launch", lambda: (ops.acc_reset(dev), ops.conv_fwd_bn(x, w, bn, 0.1, relu=True)), BNF_RD),
                 ("input gradient, plain", lambda: ops.conv_dgrad(dy, wt, (h, h), 1), lib.afan_conv_stamps),
                 ("input gradient + sums (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad(dy, wt, (h, h), 1, addend=res, bn_bwd=(x, stats, True), bn_y=y)), lib.afan_conv_stamps),
-                ("input gradient + BatchNorm backward in the launch (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad_bn(dy, wt, (h, h), x, stats, True, bn_y=y, addend=res, want_dres=True)), lib.afan_conv_bnf_stamps)):
+                ("input gradient + BatchNorm backward in the launch (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad_bn(dy, wt, (h, h), x, stats, True, bn_y=y, addend=res, want_dres=True)), BNF_RD)):
+            if rd is None:
+                print(f"   {name:72s} (no stamps in this build)")
+                continue
             us, ph = phases(fn, rd)
             print(f"   {name:72s} {us:6.1f} us   " + "  ".join(f"{k} {v}" for k, v in ph[1:]))
 
