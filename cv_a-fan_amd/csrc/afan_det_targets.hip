@@ -262,6 +262,15 @@ __global__ __launch_bounds__(TB) void det_loss_bwd_kernel(const float* __restric
 
 }  // namespace
 
+namespace {
+__global__ void sum_scalars_kernel(const float* a, const float* b, const float* c, const float* d, float* out) {
+    float s = a[0] + b[0];
+    if (c) s = s + c[0];
+    if (d) s = s + d[0];
+    out[0] = s;
+}
+}  // namespace
+
 extern "C" {
 
 // out[n] = clip(apply_transformer(src[n], t[n])): boxes as (left, top, right, bottom) fp32, clipped to [0, right] x [0, bottom]
@@ -371,6 +380,18 @@ int afan_det_loss_bwd(const float* g_ce, const float* g_sl1, const float* save, 
     AFAN_PROF("det_loss_bwd_kernel", 8.0 * S * C + 64.0 * S, st);
     det_loss_bwd_kernel<<<(unsigned)((S + TB - 1) / TB), TB, 0, st>>>(g_ce, g_sl1, save + S * 4, (const float4*)save, save + S * 4 + S * C, rows,
                                                                       gt_labels, batch, S, (int)C, (int)K, d_logits, d_deltas);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// out[0] = ((a[0] + b[0]) + c[0]) + d[0] (c, d optional): the reference's `loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()`
+// (Detection/train_aug_sat_muti_advt.py:21-27, attack_algo.py:62) for per-image loss vectors of ONE image — the mean of one element is
+// that element, the additions keep their order; seven launches forward and as many backward become one and none
+int afan_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, afan_stream_t stream) {
+    if (!a || !b || !out || (d && !c)) return AFAN_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("det_loss_sum_kernel", 20.0, st);
+    sum_scalars_kernel<<<1, 1, 0, st>>>(a, b, c, d, out);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

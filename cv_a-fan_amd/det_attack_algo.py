@@ -20,13 +20,13 @@ import torch
 
 from . import ops
 from .attack_algo import get_sample_points, linfball_proj, mix_feature, sample_points_mixed, tensor_clamp  # noqa: F401
-from .det_ops import PGD  # noqa: F401  (Detection/attack_algo.py:48-74)
+from .det_ops import PGD, sum_of_means  # noqa: F401  (Detection/attack_algo.py:48-74)
 from .resnet_s import dgrad_only
 
 
 def compute_loss(loss1, loss2, loss3, loss4):
     """:21-27: the sum of the four means."""
-    return loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()
+    return sum_of_means(loss1, loss2, loss3, loss4)
 
 
 class NoiseAhead:
@@ -89,7 +89,7 @@ def _pgd1_from_clean(model, col, idx, image_batch, y, eps, gamma):
     xin = col[3].detach().requires_grad_(True)
     with dgrad_only():
         l1, l2, l3, l4 = model.train().forward({"x": image_batch, "adv": xin, "out_idx": 3, "flag": "tail"}, y["bb"], y["lb"])
-        g = torch.autograd.grad(l1.mean() + l2.mean() + l3.mean() + l4.mean(), xin, only_inputs=True)[0]
+        g = torch.autograd.grad(sum_of_means(l1, l2, l3, l4), xin, only_inputs=True)[0]
     for i in range(3, idx, -1):
         g = det_model.stage_input_gradient(stages[i - 1], outs[i - 1], g)
     grad = g.float()
@@ -113,7 +113,7 @@ def rpn_roi_PGD(layer="roi", rpn_roi_output_dict=None, y=None, model=None, steps
             def loss_of(t):
                 d["roi_output_dict"]["roi_feature_map"] = t
                 ao, at, pc, pt = model.train().forward({"adv": d, "out_idx": "roi_tail", "flag": "clean"}, y["bb"], y["lb"])
-                return (pc.mean() + pt.mean()) if only_roi_loss else (ao.mean() + at.mean() + pc.mean() + pt.mean())
+                return sum_of_means(pc, pt) if only_roi_loss else sum_of_means(ao, at, pc, pt)
             _ascend(x_adv, loss_of, gamma, None, 0.0, False)
             if clip:
                 raise NameError("name 'rpn_feature1' is not defined")

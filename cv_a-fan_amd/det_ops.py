@@ -11,6 +11,7 @@ The kernels live in libafan_hip.so (afan_det.hip); there is no CPU fallback.  Th
 roi/) is not part of this slice: `PGD` drives any module that follows the reference's protocol
 `model.train().forward({'x','adv','out_idx','flag'}, bboxes, labels) -> 4 loss tensors`."""
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -209,6 +210,40 @@ class _DetLoss(torch.autograd.Function):
         return d_l.to(ldt), d_d.to(ddt), None, None, None, None, None, None, None
 
 
+class _SumOfMeans1(torch.autograd.Function):
+    """`l1.mean() + l2.mean() [+ l3.mean() + l4.mean()]` for loss vectors of ONE element each (one image per GPU): the mean is the
+    element, the sum keeps the reference's left-to-right order (afan_sum_scalars_f32: one launch); backward: every loss receives the
+    incoming gradient as it is (mean of one element: g / 1) — no launch."""
+
+    @staticmethod
+    def forward(ctx, *ls):
+        lib = _lib.load()
+        out = torch.empty((), dtype=torch.float32, device=ls[0].device)
+        p = [C.c_void_p(t.data_ptr()) for t in ls] + [None] * (4 - len(ls))
+        check(lib.afan_sum_scalars_f32(p[0], p[1], p[2], p[3], C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)), "afan_sum_scalars_f32")
+        ctx.shapes = [t.shape for t in ls]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.reshape(sh) for sh in ctx.shapes)
+
+
+FUSED_LOSS_SUM = os.environ.get("AFAN_DET_LOSS_SUM", "1") != "0"
+
+
+def sum_of_means(*ls):
+    """The reference's `loss1.mean() + loss2.mean() + ...` (Detection/train_aug_sat_muti_advt.py:21-27): as one launch where every loss
+    vector holds one image's value (the per-GPU share of BASELINE configs[4]), the plain expression otherwise (same values)."""
+    if (FUSED_LOSS_SUM and 2 <= len(ls) <= 4 and all(t.is_cuda and t.dtype == torch.float32 and t.numel() == 1 and t.is_contiguous() for t in ls)):
+        return _SumOfMeans1.apply(*ls)
+    out = ls[0].mean()
+    for t in ls[1:]:
+        out = out + t.mean()
+    return out
+
+
 def per_image_losses(logits, deltas, rows, gt_labels, gt_deltas, batch_indices, batch_size, beta, norm=None):
     """region_proposal_network.py:163-185 == model.py:343-367 in one launch (and one for the backward): per image the mean
     cross-entropy of its samples and the beta-smooth-L1 of its foreground samples.  Sample s reads row rows[s] (None: s) of
@@ -305,7 +340,7 @@ def PGD(x, image_batch, y=None, model=None, steps=3, eps=None, gamma=None, idx=1
         inputs = {"x": image_batch, "adv": xin, "out_idx": idx, "flag": "tail"}
         with dgrad_only():      # only_inputs=True (:66): the library's layers skip (and must not add into) parameter gradients
             l1, l2, l3, l4 = model.train().forward(inputs, y["bb"], y["lb"])
-            loss = l1.mean() + l2.mean() + l3.mean() + l4.mean()
+            loss = sum_of_means(l1, l2, l3, l4)
             grad = torch.autograd.grad(loss, xin, only_inputs=True)[0]
         if grad.stride() != x_adv.stride():
             grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()

@@ -640,6 +640,9 @@ int afan_sample_gather(const int64_t* fg, const int64_t* bg, const int64_t* pos,
 int afan_det_loss_fwd(const float* logits, const float* deltas, const int64_t* rows, const int64_t* gt_labels, const float* gt_deltas,
                       const int64_t* batch, int64_t S, int64_t B, int64_t C, int64_t K, float beta, const float* norm, float* ce, float* sl1,
                       float* save, afan_stream_t stream);
+/* out[0] = ((a[0] + b[0]) + c[0]) + d[0] (c, d optional): `loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()`
+ * (Detection/train_aug_sat_muti_advt.py:21-27, Detection/attack_algo.py:62) for per-image loss vectors of one image. */
+int afan_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, afan_stream_t stream);
 int afan_det_loss_bwd(const float* g_ce, const float* g_sl1, const float* save, const int64_t* rows, const int64_t* gt_labels,
                       const int64_t* batch, int64_t S, int64_t B, int64_t C, int64_t K, int64_t R, float* d_logits, float* d_deltas,
                       afan_stream_t stream);

@@ -436,3 +436,40 @@ def test_merged_sampling_reads_and_noise_ahead_change_no_bit(pkg, gpu):
         for (la, ia), (lb, ib) in zip(res[key][0], base[0]):
             assert torch.equal(la, lb) and torch.equal(ia, ib), key
         assert torch.equal(res[key][1], base[1]), key
+
+
+def test_fused_loss_sums_change_no_bit(pkg, gpu):
+    """`loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()` (train_aug_sat_muti_advt.py:21-27, attack_algo.py:62) as ONE launch
+    for one-image loss vectors (det_ops.sum_of_means -> afan_sum_scalars_f32; backward: no launch) against the plain expression: two
+    iterations from the same state and seed — losses, adversarial image and parameters identical bit for bit; and the values of the
+    function itself on two-image vectors (the plain path) and on one-image ones (both paths)."""
+    dops = pkg.det_ops
+    a, b, c, d = (torch.randn(1, device=gpu, requires_grad=True) for _ in range(4))
+    fused = dops.sum_of_means(a, b, c, d)
+    plain = a.mean() + b.mean() + c.mean() + d.mean()
+    assert torch.equal(fused.detach(), plain.detach()) and fused.dim() == 0
+    ga = torch.autograd.grad(fused * 3.0, (a, b, c, d))
+    assert all(torch.equal(x_, torch.full((1,), 3.0, device=gpu)) for x_ in ga)
+    assert torch.equal(dops.sum_of_means(a, b).detach(), (a.mean() + b.mean()).detach())
+    v = [torch.randn(2, device=gpu) for _ in range(4)]
+    assert torch.equal(dops.sum_of_means(*v), v[0].mean() + v[1].mean() + v[2].mean() + v[3].mean())
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    old, res = dops.FUSED_LOSS_SUM, {}
+    try:
+        for on in (False, True):
+            dops.FUSED_LOSS_SUM = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m)
+            torch.manual_seed(77)
+            outs = []
+            for _ in range(2):
+                r = tr.step(images, bboxes, labels)
+                outs.append((r["losses"].clone(), r["adv_image"].clone(), r["loss"].clone()))
+            torch.cuda.synchronize()
+            res[on] = (outs, tr.arena.param.clone())
+    finally:
+        dops.FUSED_LOSS_SUM = old
+    for x_, y_ in zip(res[True][0], res[False][0]):
+        assert all(torch.equal(p_, q_) for p_, q_ in zip(x_, y_))
+    assert torch.equal(res[True][1], res[False][1])
