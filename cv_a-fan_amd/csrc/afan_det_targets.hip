@@ -373,8 +373,13 @@ int afan_det_loss_bwd(const float* g_ce, const float* g_sl1, const float* save, 
     if (R == 0) return AFAN_OK;
     if (!d_logits || !d_deltas || (S > 0 && (!g_ce || !g_sl1 || !save || !gt_labels || !batch))) return AFAN_ENULL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_logits, 0, (size_t)(R * C * 4), st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_deltas, 0, (size_t)(R * K * 16), st);
+    hipError_t e;
+    if (d_deltas == d_logits + R * C) {           // (one allocation, d_deltas behind d_logits: one fill)
+        e = hipMemsetAsync(d_logits, 0, (size_t)(R * C * 4 + R * K * 16), st);
+    } else {
+        e = hipMemsetAsync(d_logits, 0, (size_t)(R * C * 4), st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_deltas, 0, (size_t)(R * K * 16), st);
+    }
     if (e != hipSuccess) return (int)e;
     if (S == 0) return AFAN_OK;
     AFAN_PROF("det_loss_bwd_kernel", 8.0 * S * C + 64.0 * S, st);

@@ -203,8 +203,9 @@ class _DetLoss(torch.autograd.Function):
         S, B, C_, K, R, lshape, dshape, ldt, ddt = ctx.dims
         dev = save.device
         g_ce, g_sl = g_ce.float().contiguous(), g_sl.float().contiguous()
-        d_l = torch.empty(lshape, dtype=torch.float32, device=dev)
-        d_d = torch.empty(dshape, dtype=torch.float32, device=dev)
+        nl = R * C_
+        both = torch.empty(nl + R * K * 4, dtype=torch.float32, device=dev)      # (one allocation: the library zero-fills both with one launch)
+        d_l, d_d = both[:nl].view(lshape), both[nl:].view(dshape)
         check(_lib.load().afan_det_loss_bwd(_ptr(g_ce), _ptr(g_sl), _ptr(save), _ptr(rows), _ptr(gt_labels), _ptr(batch), S, B, C_, K, R, _ptr(d_l),
                                             _ptr(d_d), _stream(dev)), "afan_det_loss_bwd")
         return d_l.to(ldt), d_d.to(ddt), None, None, None, None, None, None, None
