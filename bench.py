@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no_literal", action="store_true", help="skip the after-the-fact run of the reference's literal schedule "
                     "(main_perturb.py:173,195-196 as written: two head passes, separate first PGD pass and final clean pass)")
     ap.add_argument("--literal_steps", type=int, default=12)
+    ap.add_argument("--no_dp_schedule", action="store_true", help="skip the after-the-fact run of the data-parallel program on this one GPU")
     ap.add_argument("--cpu_steps", type=int, default=None, help="timed CPU-oracle steps (default 3; 1 for the DeepLab workload)")
     return ap.parse_args()
 
@@ -180,11 +181,39 @@ def synth_seg(batch, side, g):
     return x, y
 
 
+def _csrc_files():
+    return sorted(glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.h")))
+
+
 def kernel_sources_sha():
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.h"))):
+    for f in _csrc_files():
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def source_shas():
+    """{source file: sha} of every kernel source: what a counter summary's `_meta.kernel_sources_sha_files` records (tools/pmc_summary.py,
+    tools/pmc_mfma_summary.py), so that staleness is judged per KERNEL (below), not by any edit anywhere in csrc/."""
+    return {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16] for f in _csrc_files()}
+
+
+# kernel label (afan_profile / rocprofv3 symbol prefix) -> the sources that kernel is compiled from; anything else: every file
+_CONV_SRC = ("afan_conv.hip", "afan_conv_bnf.hip", "afan_conv_params.h", "afan_common.h")
+KERNEL_SOURCES = {"conv_bn_": _CONV_SRC, "conv_igemm_": _CONV_SRC, "conv_wgrad": ("afan_wgrad.hip", "afan_common.h"),
+                  "wgrad_": ("afan_wgrad.hip", "afan_common.h"), "conv3x3_c64": ("afan_conv_c64.hip", "afan_conv_c64.h", "afan_common.h"),
+                  "conv_f32": ("afan_conv_f32.hip", "afan_common.h"), "pgd_": ("afan_pgd.hip", "afan_common.h"),
+                  "sgd_": ("afan_sgd.hip", "afan_common.h")}
+
+
+def summary_stale(kernel_name, meta):
+    """Has a source of `kernel_name` changed since the counter summary with this `_meta` was taken?"""
+    old = meta.get("kernel_sources_sha_files")
+    if not old:                       # (summaries of rounds 1-5: one hash over all of csrc/)
+        return meta.get("kernel_sources_sha") != kernel_sources_sha()
+    now = source_shas()
+    files = next((v for k, v in KERNEL_SOURCES.items() if kernel_name.startswith(k)), tuple(now))
+    return any(old.get(f) != now.get(f) for f in files)
 
 
 def pmc_traffic(kernel_name, arch):
@@ -205,7 +234,7 @@ def pmc_traffic(kernel_name, arch):
         key = next((k for k in pmc if not k.startswith("_") and (k == kernel_name or k == base or k in kernel_name)), None)
         if key and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
             meta = pmc.get("_meta", {})
-            stale = meta.get("kernel_sources_sha") != kernel_sources_sha()
+            stale = summary_stale(kernel_name, meta)
             return (round((2 * pmc[key]["FETCH_SIZE"]["avg"] + pmc[key]["WRITE_SIZE"]["avg"]) * 1024),
                     os.path.relpath(f, ROOT), stale, meta.get("command"))
     return None
@@ -233,40 +262,69 @@ def pmc_mfma(kernel_name, arch):
             w = lambda key: round(sum((e.get(key) or 0.0) * e["launches"] for _, e in vs) / n, 4)
             return {"mfma_util": w("mfma_util"), "wait_any": w("wait_any"), "wait_inst": w("wait_inst"), "lds_issue": w("lds_issue"),
                     "variants": {k: e["mfma_util"] for k, e in vs}, "source": os.path.relpath(f, ROOT),
-                    "stale": meta.get("kernel_sources_sha") != kernel_sources_sha()}
+                    "stale": summary_stale(kernel_name, meta)}
     return None
 
 
-def literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys):
-    """The reference's schedule as written (main_perturb.py:173,195-196: head forward for PGD AND inside the clean forward, K PGD
-    passes, adversarial + clean final passes), on a fresh model of the same architecture, hipGraph replay, after the timed region."""
+def _second_run(pkg, torch, nn, args, dev, idx, xs, ys, timed_steps, **trainer_kw):
+    """A fresh model of the same architecture from the same seed, run over EXACTLY the batches of the headline run (warm-up
+    0..W-1, then 0..K-1) so that its final loss is comparable with the headline's; the last `timed_steps` of them are timed."""
     ctor, _ = pkg.resnet_s.ARCHS[args.arch]
     torch.manual_seed(3)
     model = ctor()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_compute_dtype(dtype).set_channels_last(args.layout == "nhwc").to(dev).train()
     tr = pkg.train_step.AfanTrainer(model, nn.CrossEntropyLoss(), steps=args.pgd_steps, gamma=0.5, eps=2.0, perturb_idx=idx, lr=0.1,
-                                    use_graph=not args.no_graph, share_head=False, fold_clean=False)
+                                    use_graph=not args.no_graph, **trainer_kw)
     nb = len(xs)
-    for i in range(6):
+    seq = list(range(args.warmup)) + list(range(args.steps))
+    timed_steps = max(1, min(timed_steps, len(seq) - 1))
+    for i in seq[:-timed_steps]:
         tr.step(xs[i % nb], ys[i % nb])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.literal_steps):
+    for i in seq[-timed_steps:]:
         r = tr.step(xs[i % nb], ys[i % nb])
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return tr, r, time.perf_counter() - t0, timed_steps, len(seq)
+
+
+def literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys, folded_loss):
+    """The reference's schedule as written (main_perturb.py:173,195-196: head forward for PGD AND inside the clean forward, K PGD
+    passes, adversarial + clean final passes), on a fresh model of the same architecture, hipGraph replay, after the timed region."""
+    tr, r, dt, n_timed, n_total = _second_run(pkg, torch, nn, args, dev, idx, xs, ys, args.literal_steps, share_head=False, fold_clean=False)
+    args_literal_steps = n_timed
     pkg.ops.profile_enable(True)
     tr._step_eager(xs[0], ys[0])
     torch.cuda.synchronize()
     prof = pkg.ops.profile_collect()
     pkg.ops.profile_enable(False)
     cf = sum(q["flops"] for k, q in prof.items() if k.startswith("conv_"))
-    return {"images_per_s": round(args.batch * args.literal_steps / dt, 1), "ms_per_step": round(dt / args.literal_steps * 1e3, 3),
-            "steps": args.literal_steps, "executed_GFLOP_per_step": round(cf / 1e9, 1), "hipgraph": tr._graph is not None,
-            "final_loss": round(float(r["loss"]), 4),
+    return {"images_per_s": round(args.batch * args_literal_steps / dt, 1), "ms_per_step": round(dt / args_literal_steps * 1e3, 3),
+            "steps": args_literal_steps, "executed_GFLOP_per_step": round(cf / 1e9, 1), "hipgraph": tr._graph is not None,
+            "final_loss": round(float(r["loss"]), 4), "final_loss_folded": round(folded_loss, 4), "steps_from_seed": n_total,
+            "loss_note": "both losses after the SAME number of steps on the same batches from the same seed (value-identical schedules: "
+                         "they differ by bf16 summation noise amplified over the steps)",
             "schedule": "2 head passes, %d PGD passes + adversarial and clean final passes%s (bench.py --no_fold_clean --no_share_head)"
                         % (args.pgd_steps, " (one grouped pass over the tail)" if getattr(tr, "_groupable", False) else "")}
+
+
+def dp_schedule(pkg, torch, nn, args, dev, idx, xs, ys, folded_loss):
+    """One GPU running EXACTLY the code path of a rank of a data-parallel job (AfanTrainer(emulate_dp=True)): the backward cut into
+    phases at the tail's stage transitions, one hipGraph per phase with a host call between two replays (where RCCL's all-reduce of
+    the finished range would be started), the in-launch BatchNorm off from the first announced range on — everything but the
+    exchange itself.  The 1 -> N efficiency of a SCALE run is to be read against THIS single-GPU number: the difference to `value`
+    is what the data-parallel schedule costs before a single byte moves."""
+    tr, r, dt, n_timed, n_total = _second_run(pkg, torch, nn, args, dev, idx, xs, ys, args.literal_steps, emulate_dp=True)
+    red = tr.reducer
+    b = tr.arena.offsets + [tr.arena.numel]
+    return {"images_per_s": round(args.batch * n_timed / dt, 1), "ms_per_step": round(dt / n_timed * 1e3, 3), "steps": n_timed,
+            "final_loss": round(float(r["loss"]), 4), "final_loss_headline": round(folded_loss, 4), "steps_from_seed": n_total,
+            "graph_pieces": len(tr._pieces) if tr._pieces is not None else 0,
+            "fused_launches_per_piece": getattr(tr, "_pieces_fused", None),
+            "announced_ranges_MiB": [round((b[hi] - b[lo]) * 4 / 2 ** 20, 1) for lo, hi in red.announced],
+            "in_launch_batchnorm_while_exchange_in_flight": red.fused_while_in_flight,
+            "note": "world 1, no exchange: train_step.NullReducer stands where GradAllReducer starts RCCL; same graphs, same host calls"}
 
 
 def launch_ranks(args):
@@ -563,7 +621,11 @@ def main():
 
     literal = None
     if rank == 0 and world == 1 and not (seg or det) and not args.no_literal and trainer._fold_ok(xs[0]):
-        literal = literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys)
+        literal = literal_schedule(pkg, torch, nn, args, dev, idx, xs, ys, loss)
+    # ---- the data-parallel PROGRAM on this one GPU (train_step.NullReducer): what a rank of an N > 1 job runs, minus the exchange
+    dp_sched = None
+    if rank == 0 and world == 1 and not (seg or det) and not args.no_dp_schedule and trainer._fold_ok(xs[0]):
+        dp_sched = dp_schedule(pkg, torch, nn, args, dev, idx, xs, ys, loss)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -614,7 +676,8 @@ def main():
                       f"images/sec (whole node) A-FAN K={args.pgd_steps} train step, {args.arch} {side}x{side}")
             workload = (f"{args.arch} {'CIFAR-10' if side == 32 else 'ImageNet'}-shape A-FAN K={args.pgd_steps} {args.dtype}, batch "
                         f"{args.batch}/GPU, perturb_idx {idx}, internal layout {args.layout}, 1xMI355X per rank "
-                        f"(BASELINE configs[1])")
+                        + ("(BASELINE configs[1])" if default_cfg and args.batch == 256 else
+                           "(BASELINE configs[2], per-GPU share)" if args.arch == "resnet50" else "(not a BASELINE configuration)"))
             # which passes one iteration runs: the reference's text is 2 head passes + K PGD
             # passes + adversarial and clean final passes; value-identical passes are run once
             sched = (("1 head pass (stands for the reference's 2), " if trainer._share_head(xs[0]) else "2 head passes, ")
@@ -640,6 +703,8 @@ def main():
             line["ddp_diag"] = ddp_diag
         if literal is not None:
             line["literal_schedule"] = literal
+        if dp_sched is not None:
+            line["dp_schedule"] = dp_sched
         if conv_exec is not None:
             gf = REF_GFLOP_PER_IMAGE.get((args.arch, args.pgd_steps))
             if gf is not None:      # secondary: what the same img/s would mean at the reference schedule's FLOP count

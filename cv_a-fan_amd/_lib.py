@@ -138,6 +138,9 @@ SIGNATURES = {
     "afan_roi_align_bwd_ws": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p, _p]),
     "afan_transpose_weights": (_i, [_p, _p, _p, _i, _l, _p]),
     "afan_sgd_step": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p]),
+    "afan_sgd_step_guarded": (_i, [_p, _p, _p, _p, _l, _p, _f, _f, _f, _i, _p, _p]),
+    "afan_guarded_copy": (_i, [_p, _p, _l, _p, _p, _p]),
+    "afan_occupy_cus": (_i, [_i, _i, _i, _p]),
     "afan_cast_bf16": (_i, [_p, _p, _l, _p]),
     "afan_pgd_init": (_i, [_p, _i, _p, _p, _p, _l, _p]),
     "afan_normalize_nchw": (_i, [_p, _p, _i, _i, _l, _l, _l, _p, _p, _p]),

@@ -177,6 +177,8 @@ class ArenaSGD(torch.optim.Optimizer):
             arena.lr = torch.zeros(len(self.param_groups), dtype=torch.float32, device=arena.param.device)
         self._lr_on_device = [None] * len(self.param_groups)
         self.grad_scale = 1.0
+        if ops.GRID_BN_ALLOWED_AT_IMPORT and arena.param.is_cuda:
+            ops.grid_guard_word(arena.param.device)      # the update's device-side guard (ops.sgd_step_): allocated outside any capture
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()

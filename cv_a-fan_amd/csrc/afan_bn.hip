@@ -406,6 +406,7 @@ void launch_apply(const Plan& p, const void* x, const void* res, void* y, const 
         if (relu) AFAN_GO(false, true); else AFAN_GO(false, false);
     }
 #undef AFAN_GO
+    ++afan::prof::g_launches;       // (the caller checks the launch; the profiling scope above counts it here)
 }
 
 template <typename T>

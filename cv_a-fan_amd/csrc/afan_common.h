@@ -108,14 +108,18 @@ static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<u
 // ---- optional per-launch event timing (afan_prof.hip) ----
 namespace afan { namespace prof {
 extern int g_enabled;
+extern thread_local unsigned g_launches;     // kernel launches issued by this thread (AFAN_LAUNCH_CHECK counts them)
 void begin(const char* name, double bytes, double flops, hipStream_t st, size_t* slot);
 void end(size_t slot, hipStream_t st);
+void cancel(size_t slot);
 struct Scope {
-    size_t slot; hipStream_t st; bool on;
-    Scope(const char* name, double bytes, hipStream_t s, double flops = 0.0) : slot((size_t)-1), st(s), on(g_enabled != 0) {
+    size_t slot; hipStream_t st; bool on; unsigned launches0;
+    Scope(const char* name, double bytes, hipStream_t s, double flops = 0.0) : slot((size_t)-1), st(s), on(g_enabled != 0), launches0(g_launches) {
         if (on) begin(name, bytes, flops, st, &slot);
     }
-    ~Scope() { if (on) end(slot, st); }
+    // a scope inside which NOTHING was launched (an entry point that declined the problem: AFAN_ESHAPE, "not this launch") is not a
+    // launch: its FLOPs and bytes must not be booked against ~zero time
+    ~Scope() { if (on) { if (g_launches != launches0) end(slot, st); else cancel(slot); } }
 };
 } }
 // time the launches issued in the rest of the enclosing block as kernel `name` moving `bytes` algorithmic bytes
@@ -125,6 +129,7 @@ struct Scope {
 
 #define AFAN_LAUNCH_CHECK()                     \
     do {                                        \
+        ++afan::prof::g_launches;               \
         hipError_t e__ = hipGetLastError();     \
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)

@@ -19,6 +19,7 @@ struct Rec {
 static std::mutex g_mu;
 static std::vector<Rec> g_recs;
 int g_enabled = 0;
+thread_local unsigned g_launches = 0;
 
 void begin(const char* name, double bytes, double flops, hipStream_t st, size_t* slot) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -32,7 +33,13 @@ void begin(const char* name, double bytes, double flops, hipStream_t st, size_t*
 void end(size_t slot, hipStream_t st) {
     if (slot == (size_t)-1) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    (void)hipEventRecord(g_recs[slot].b, st);
+    if (slot < g_recs.size()) (void)hipEventRecord(g_recs[slot].b, st);
+}
+
+void cancel(size_t slot) {        // nothing was launched inside the scope: the record is dropped by collect (name == nullptr)
+    if (slot == (size_t)-1) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (slot < g_recs.size()) g_recs[slot].name = nullptr;
 }
 
 }  // namespace prof
@@ -55,6 +62,11 @@ int afan_profile_collect(char* names_out, int64_t* launches, double* total_ms, d
     std::vector<std::string> names;
     for (auto& r : g_recs) {
         float ms = 0.f;
+        if (!r.name) {                               // cancelled: nothing was launched inside the scope (event b never recorded)
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+            continue;
+        }
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
         int k = -1;
         for (size_t i = 0; i < names.size(); ++i)

@@ -13,6 +13,7 @@ import torch
 
 from .arena import ArenaSGD, ParamArena
 from .det_attack_algo import det_train_phases
+from .grid_guard import GuardedTrainer
 
 # everything behind the conv4 feature map: layer4 (= detection.hidden), the RPN and the two heads.  The backbone's unused ImageNet
 # classifier `features.fc` sits between them in the reference's parameter order and never receives a gradient: optim.SGD skips a
@@ -22,7 +23,7 @@ TAIL_PREFIXES = ("features.layer4.", "features.fc.", "rpn.", "detection.")
 UNUSED_PARAMS = ("features.fc.weight", "features.fc.bias")
 
 
-class DetTrainer:
+class DetTrainer(GuardedTrainer):      # (frozen BatchNorm: no grid barrier on this path; flush_guard() is the uniform no-op)
     def __init__(self, model, *, lr=0.001, momentum=0.9, weight_decay=0.0005, loss_settings=1, group=None, allreduce_chunks=4,
                  segmented=None, arena=None, noise_ahead=False):
         import torch.distributed as dist

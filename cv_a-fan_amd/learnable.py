@@ -10,6 +10,8 @@ blend and its d/dw reduction (`afan_mix_w*`), the whole-arena SGD.  The nine-ele
 own momentum SGD, the projection) stays on torch ops, as in the reference."""
 import torch
 
+from .grid_guard import GuardedTrainer
+
 from . import ops
 from .arena import ArenaSGD, ParamArena
 from .attack_algo import PGD
@@ -41,7 +43,7 @@ class _MixW(torch.autograd.Function):
         return dw, None, None, None, None
 
 
-class LearnableTrainer:
+class LearnableTrainer(GuardedTrainer):
     """Owns the backbone arena + SGD (sequential_model parameters only, :82-84) and the optimizer of `w` (:86-90)."""
 
     def __init__(self, model, criterion, *, steps=3, gamma=1.0, eps=2.0, idx_list=LEARNABLE_IDX, layer_number=None,
@@ -65,9 +67,34 @@ class LearnableTrainer:
         self.graph_warmup = graph_warmup
         self._graph = self._graph_failed = self._static = self._out = self._key = None
         self._eager_steps = 0
+        self._guard_init(model, self.arena.param.device)      # a grid barrier that gives up: grid_guard.py
+
+    # `w` and its optimizer are torch's own (nine floats): the device guard does not cover them, the ring keeps their clones
+    def _guard_state(self):
+        st = self.optimizer_w.state.get(self.model.w, {})
+        mb = st.get("momentum_buffer")
+        return (self.model.w.detach().clone(), None if mb is None else mb.clone())
+
+    def _guard_restore(self, state):
+        w, mb = state
+        with torch.no_grad():
+            self.model.w.copy_(w)
+        st = self.optimizer_w.state.get(self.model.w)
+        if st is not None:
+            if mb is None:
+                st.pop("momentum_buffer", None)
+            else:
+                st["momentum_buffer"].copy_(mb)
+
+    def _drop_graphs(self):
+        self._graph = self._graph_failed = self._static = self._out = self._key = None
 
     def step(self, inp, target):
-        """One iteration; returns device tensors (loss, loss_clean, loss_adv, l1, l2[9,N], linf[9,N], prec1, w)."""
+        """One iteration; returns device tensors (loss, loss_clean, loss_adv, l1, l2[9,N], linf[9,N], prec1, w).
+        `flush_guard()` at every logging interval (grid_guard.py)."""
+        return self._guarded((inp, target), self._step_once)
+
+    def _step_once(self, inp, target):
         key = (tuple(inp.shape), inp.dtype, tuple(target.shape))
         if self._graph is not None and self._key == key:
             return self._replay(inp, target)

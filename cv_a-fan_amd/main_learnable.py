@@ -70,6 +70,8 @@ def train(train_loader, trainer, epoch, args, log):
         norm_linf.append(r["linf"])
         pend.append((r["loss"].float(), r["prec1"], inp.size(0)))    # (graph replays hand out copies of the small outputs)
         if i % args.print_freq == 0:
+            if trainer.flush_guard():    # (grid_guard.py: steps that ran on a given-up grid barrier's partial totals were run again)
+                log("in-launch BatchNorm: a grid barrier gave up; the affected steps were run again on the two-launch forms")
             for lo, pr, n in pend:       # one host sync per print, every iteration counted (:263-268 update per iteration)
                 losses.update(lo.item(), n)
                 top1.update(pr.item(), n)
@@ -77,6 +79,7 @@ def train(train_loader, trainer, epoch, args, log):
             log("Epoch: [{0}][{1}/{2}]\t"
                 "Loss {loss.val:.4f} ({loss.avg:.4f})\t"
                 "Accuracy {top1.val:.3f} ({top1.avg:.3f})\t".format(epoch, i, len(train_loader), loss=losses, top1=top1))
+    trainer.flush_guard()
     for lo, pr, n in pend:
         losses.update(lo.item(), n)
         top1.update(pr.item(), n)

@@ -831,26 +831,60 @@ def conv_fwd(x, w, stride, stats_shift=None, want_stats=False, stats_buf=None, g
 GRID_BN = os.environ.get("AFAN_GRID_BN", "1") != "0" and not os.environ.get("AFAN_BENCH_ONE_DEVICE")
 _grid_bars = {}
 _grid_refused = set()
+# GRID_BN (what every call site reads) = GRID_BN_ALLOWED (the process-wide switch: environment, or grid_bn_disable() after a
+# barrier gave up) and every enclosing grid_bn(...) context and no gradient exchange in flight (exchange_in_flight)
+GRID_BN_ALLOWED = GRID_BN
+GRID_BN_ALLOWED_AT_IMPORT = GRID_BN          # (the optimizer's device-side guard is wired whenever the in-launch forms CAN run)
+_grid_ctx = True
+_grid_exchange = False
+
+
+def _grid_refresh():
+    global GRID_BN
+    GRID_BN = bool(GRID_BN_ALLOWED and _grid_ctx and not _grid_exchange)
 
 
 class grid_bn:
-    """Context: switch the in-launch BatchNorm on / off for the launches issued inside (by this process)."""
+    """Context: switch the in-launch BatchNorm OFF for the launches issued inside (by this process).  Narrowing only: grid_bn(True)
+    inside a grid_bn(False) region — or while an exchange is in flight, or after grid_bn_disable() — leaves it off."""
 
     def __init__(self, on):
         self.on = bool(on)
 
     def __enter__(self):
-        global GRID_BN
-        self.old, GRID_BN = GRID_BN, self.on and GRID_BN_ALLOWED
+        global _grid_ctx
+        self.old, _grid_ctx = _grid_ctx, _grid_ctx and self.on
+        _grid_refresh()
         return self
 
     def __exit__(self, *exc):
-        global GRID_BN
-        GRID_BN = self.old
+        global _grid_ctx
+        _grid_ctx = self.old
+        _grid_refresh()
         return False
 
 
-GRID_BN_ALLOWED = GRID_BN
+def exchange_in_flight(on):
+    """A gradient exchange (RCCL kernels on the reducer's stream) is / is no longer in flight beside the launches issued from now
+    on: its resident channel kernels hold CUs, so a grid barrier would wait for the exchange to END — the in-launch BatchNorm stays
+    off until exchange_in_flight(False).  GradAllReducer calls it from its first launch to finish(); the trainers' graph captures
+    call it where the replay will start an exchange.  Returns the previous setting."""
+    global _grid_exchange
+    old, _grid_exchange = _grid_exchange, bool(on)
+    _grid_refresh()
+    return old
+
+
+def grid_bn_disable(reason=""):
+    """Process-wide and permanent: no convolution + BatchNorm launch takes the in-launch form any more (a grid barrier gave up:
+    the launches' workgroups are not co-resident on this GPU — another process's kernels, a preempted queue)."""
+    global GRID_BN_ALLOWED
+    if GRID_BN_ALLOWED:
+        import warnings
+        warnings.warn("in-launch BatchNorm switched off for this process" + (": " + reason if reason else "") +
+                      " — the two-launch forms run from here on (same bits, ~5 % slower)")
+    GRID_BN_ALLOWED = False
+    _grid_refresh()
 
 
 def _grid_barrier(device):
@@ -858,6 +892,13 @@ def _grid_barrier(device):
     if b is None:
         b = _grid_bars[device.index] = torch.zeros(int(_lib.load().afan_grid_barrier_bytes()) // 4, dtype=torch.int32, device=device)
     return b
+
+
+def grid_guard_word(device):
+    """The grid barrier's error word of `device` as a 1-element int32 view (device memory; non-zero = a barrier's bounded spin gave
+    up since the host last cleared it).  afan_sgd_step_guarded / afan_guarded_copy read it on the device."""
+    w = int(_lib.load().afan_grid_barrier_error_word())
+    return _grid_barrier(torch.device(device))[w:w + 1]
 
 
 def grid_barrier_error(device=None):
@@ -1820,9 +1861,34 @@ def sgd_step_(param, grad, momentum_buf, lr_dev, momentum, weight_decay, grad_sc
     _need(lr_dev, "lr_dev", torch.float32)
     if shadow is not None:
         _need(shadow, "shadow", torch.bfloat16)
+    if GRID_BN_ALLOWED_AT_IMPORT and param.is_cuda:
+        # a step whose in-launch BatchNorm gave up (partial batch totals) must not reach the weights: the update is skipped on the
+        # device while the grid barrier's error word is set (sticky until the host has noticed: grid_guard.GridGuard)
+        check(lib.afan_sgd_step_guarded(_ptr(param), _ptr(grad), _ptr(momentum_buf), _ptr(shadow), param.numel(),
+                                        _ptr(lr_dev), float(momentum), float(weight_decay), float(grad_scale), 0,
+                                        _ptr(grid_guard_word(param.device)), _stream(param)), "afan_sgd_step_guarded")
+        return
     check(lib.afan_sgd_step(_ptr(param), _ptr(grad), _ptr(momentum_buf), _ptr(shadow), param.numel(),
                             _ptr(lr_dev), float(momentum), float(weight_decay), float(grad_scale), 0,
                             _stream(param)), "afan_sgd_step")
+
+
+def guarded_copy_(dst, src, counter=None):
+    """dst.copy_(src) on the device unless the grid barrier's error word is set (afan_guarded_copy); counter (1-element int32,
+    optional) += 1 when the copy happened.  Flat, same dtype and size, a multiple of 16 bytes."""
+    lib = _lib.load()
+    if dst.dtype != src.dtype or dst.numel() != src.numel() or not (dst.is_contiguous() and src.is_contiguous()):
+        raise ValueError("guarded_copy_: two contiguous tensors of one dtype and size")
+    check(lib.afan_guarded_copy(_ptr(dst), _ptr(src), dst.numel() * dst.element_size(), _ptr(grid_guard_word(dst.device)),
+                                _ptr(counter), _stream(dst)), "afan_guarded_copy")
+    return dst
+
+
+def occupy_cus(workgroups, lds_bytes, microseconds, stream=None):
+    """Test / probe aid: park `workgroups` one-wave workgroups with `lds_bytes` of LDS each on `stream` (default: the current one) for
+    `microseconds` (afan_occupy_cus)."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    check(_lib.load().afan_occupy_cus(int(workgroups), int(lds_bytes), int(microseconds), C.c_void_p(st.cuda_stream)), "afan_occupy_cus")
 
 
 def normalize_nchw(x, mean, std, out_dtype=torch.float32, channels_last=False):

@@ -602,12 +602,43 @@ class _BlockFn(torch.autograd.Function):
         # reduction sums of THAT block's last BN backward (its ReLU mask is x > 0) — see backward
         prev = getattr(x, "_afan_bn2", None) if _Flags.block_fusion else None
         ctx.prev_bn = prev if (prev is not None and prev[2] == G) else None
+        if prev is not None:
+            prev[6]["consumers"] += 1      # (block nodes reading the producer's output: the in-launch hand-off below is for exactly one)
+        ctx.handoff = {"consumers": 0, "done": 0}
         ctx.save_for_backward(x, rawsc, ssc, *saved)
         # (raw_n, stats_n, G, bn_n, want_pgrad, the projection shortcut's (raw, stats, bn) or None): what a consumer block's first
         # input-gradient launch needs to run this block's last-BatchNorm backward(s) inside itself
+        # [6]: the hand-off's bookkeeping, shared with this node's backward (see _handoff_check)
         a._afan_bn2 = (saved[-3], saved[-1], G, chain[-1][1], want_pgrad,
-                       (rawsc, ssc, blk.shortcut[1]) if (blk._sc_kind == "conv" and ssc is not None) else None)
+                       (rawsc, ssc, blk.shortcut[1]) if (blk._sc_kind == "conv" and ssc is not None) else None, ctx.handoff)
         return a
+
+    @staticmethod
+    def _handoff_check(ctx, gout):
+        """The consumer block's first input-gradient launch may have run THIS block's last-BatchNorm backward inside itself and
+        handed the results over as attributes of the gradient tensor (`_afan_bn_done`: the masked gradient IS the tensor, d_raw rides
+        on it, the BatchNorm's parameter gradients are already accumulated).  That is only right if autograd delivers that very
+        tensor, unmodified: a second consumer of the block's output makes the engine add another contribution — in place (the
+        attribute survives, the data does not match it) or into a new tensor (the attribute is lost and a recomputation would count
+        the parameter gradients twice).  Both are refused loudly here; a consumer only takes the form when it is the output's one
+        block consumer (`consumers == 1`)."""
+        st = ctx.handoff
+        done = getattr(gout, "_afan_bn_done", None)
+        mark = getattr(gout, "_afan_handoff", None)
+        was_done, st["done"] = st["done"], 0
+        if done is not None:
+            if mark != (gout.data_ptr(), gout._version):
+                raise ops.AfanLibraryError("block backward: the gradient tensor carrying an in-launch BatchNorm backward's results was "
+                                           "modified on its way (the block's output has another consumer, a hook or retain_grad): "
+                                           "run with resnet_s._Flags.block_fusion = False or AFAN_GRID_BN=0")
+        elif was_done:
+            raise ops.AfanLibraryError("block backward: a consumer block ran this block's last-BatchNorm backward inside its input-"
+                                       "gradient launch, but autograd delivered a different gradient tensor (the block's output has "
+                                       "another consumer): run with resnet_s._Flags.block_fusion = False or AFAN_GRID_BN=0")
+        pre = getattr(gout, "_afan_bn_sums", None)
+        if pre is not None and getattr(gout, "_afan_sums_mark", None) != (gout.data_ptr(), gout._version):
+            pre = None                                 # (sums of a tensor that has changed since: reduce again)
+        return pre, done
 
     @staticmethod
     def backward(ctx, gout):
@@ -646,8 +677,9 @@ class _BlockFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         g = lambda p: p.grad if pg else None
         out = acts[-1]
-        pre = getattr(gout, "_afan_bn_sums", None)     # taken by the consumer block's dgrad epilogue (same tensor object)
-        done = getattr(gout, "_afan_bn_done", None)    # ... or this block's whole last-BatchNorm backward, done inside that launch:
+        # pre: this block's last-BatchNorm backward SUMS, taken by the consumer block's dgrad epilogue (same tensor object);
+        # done: ... or that whole backward, done inside that launch:
+        pre, done = _BlockFn._handoff_check(ctx, gout)
         # last BN (+residual, ReLU mask from `out`): gradient to its conv output and to the shortcut branch
         bl = chain[-1][1]
         if done is not None:
@@ -706,7 +738,7 @@ class _BlockFn(torch.autograd.Function):
                     _wgrad_accumulate(x, d_rawsc, csc)
                 if need_dx and pair is not None:
                     if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.stride[0] == 2
-                            and getattr(prev[3], "_branch", "main") == ctx.branch):
+                            and prev[6]["consumers"] == 1 and getattr(prev[3], "_branch", "main") == ctx.branch):
                         # the producing block's last-BatchNorm backward inside this launch too (the stride-2 pair form: one set of
                         # sums over its four output-parity classes); that block's node finds its results on the tensor handed back
                         pbn, ppg = prev[3], prev[4]
@@ -716,6 +748,8 @@ class _BlockFn(torch.autograd.Function):
                         if fused is not None:
                             dx = fused[1]
                             dx._afan_bn_done = fused[0]
+                            dx._afan_handoff = (dx.data_ptr(), dx._version)
+                            prev[6]["done"] = 1
                             return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
                     dx = ops.conv_dgrad(d_raw, c1.lp_weight_t(), x.shape[2:], c1.stride[0], sc=(d_rawsc, wt10), **fuse)
                 elif need_dx:
@@ -731,7 +765,7 @@ class _BlockFn(torch.autograd.Function):
         elif need_dx:
             fused = pair_p = None
             if (prev is not None and G == 1 and ops.GRID_BN and len(prev) >= 5 and c1.kernel_size[0] in (1, 3) and c1.stride[0] == 1
-                    and getattr(prev[3], "_branch", "main") == ctx.branch):
+                    and prev[6]["consumers"] == 1 and getattr(prev[3], "_branch", "main") == ctx.branch):
                 # the gradient leaving this block is only ever read by the producing block's last-BatchNorm backward: that
                 # backward runs inside this launch and the producer's node finds its two results on the tensor handed back
                 pbn, ppg = prev[3], prev[4]
@@ -753,6 +787,8 @@ class _BlockFn(torch.autograd.Function):
             if fused is not None:
                 dx = fused[1]
                 dx._afan_bn_done = fused[0]            # (not the pair: a tuple holding dx on dx would be a reference cycle)
+                dx._afan_handoff = (dx.data_ptr(), dx._version)
+                prev[6]["done"] = 1
                 if pair_p is not None:
                     dx._afan_sc_done = pair_p
                 return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -760,6 +796,7 @@ class _BlockFn(torch.autograd.Function):
         if "bn_bwd" in fuse and dx is not None:
             dx, sums = dx
             dx._afan_bn_sums = sums
+            dx._afan_sums_mark = (dx.data_ptr(), dx._version)
         return (dx, None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 

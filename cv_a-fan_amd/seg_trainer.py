@@ -14,10 +14,11 @@ import torch.nn as nn
 from . import ops, resnet_s
 from .arena import ArenaSGD, ParamArena
 from .deeplab import PolyLR, set_bn_momentum
+from .grid_guard import GuardedTrainer
 from .seg_attack_algo import seg_train_phases, seg_train_step
 
 
-class SegTrainer:
+class SegTrainer(GuardedTrainer):
     def __init__(self, model, criterion=None, *, steps=1, eps=2.0, gamma_se=0.5, gamma_sd=0.5, pertub_idx_se=3,
                  pertub_idx_sd="aspp", mix_layer="11", mix_sd=False, noise_sd=0.0, randinit=False, clip=False, lr=0.01,
                  momentum=0.9, weight_decay=1e-4, total_itrs=30000, lr_policy="poly", step_size=10000,
@@ -57,6 +58,7 @@ class SegTrainer:
                 dist.broadcast(b, src=0, group=group)
             self.arena.refresh_shadow()
             self.kw["defer_step"] = True
+        self._guard_init(model, self.arena.param.device)      # a grid barrier that gives up: grid_guard.py
         self.use_graph = bool(use_graph) and not randinit and noise_sd == 0
         self.graph_warmup = graph_warmup
         self._graph = self._graph_failed = self._static = self._out = self._key = self._pieces = None
@@ -104,9 +106,14 @@ class SegTrainer:
                 self.reducer.launch_params(*rng)
         return out
 
+    def _drop_graphs(self):
+        self._graph = self._graph_failed = self._static = self._out = self._key = self._pieces = None
+
     def _exchange_and_step(self):
         if self.reducer is not None:
             self.reducer.finish()      # whatever no launch_params() announced is reduced here
+            if self.world > 1:
+                self._guard_sync_ranks(self.group)
             self.optimizer.step()
         elif self.segmented:
             self.optimizer.step()
@@ -132,22 +139,34 @@ class SegTrainer:
         # one hipGraph per phase (shared memory pool): between two replays the host starts the tail's all-reduce
         out, pieces, pool = {}, [], None
         gen = seg_train_phases(self.model, self.optimizer, self.criterion, self._static[0], self._static[1], out, **self.kw)
-        done = False
-        while not done:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
-                try:
-                    ph = next(gen)
-                except StopIteration:
-                    ph, done = None, True
-            pieces.append((g, ph))
-            pool = pieces[0][0].pool()
-        self._pieces = pieces
+        done, fused = False, []
+        try:
+            while not done:
+                n0 = ops.CALLS["conv_bn_fused"]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
+                    try:
+                        ph = next(gen)
+                    except StopIteration:
+                        ph, done = None, True
+                pieces.append((g, ph))
+                fused.append(ops.CALLS["conv_bn_fused"] - n0)
+                pool = pieces[0][0].pool()
+                if ph == "tail" and self.reducer is not None:
+                    # the replay starts the tail's exchange HERE: what is captured from now on runs beside RCCL's resident kernels
+                    # and must not contain a grid barrier (ops.exchange_in_flight; the eager path gets it from the reducer itself)
+                    ops.exchange_in_flight(True)
+        finally:
+            ops.exchange_in_flight(False)
+        self._pieces, self._pieces_fused = pieces, fused
         return out
 
     def step(self, images, labels):
         """One iteration (device tensors only; the scheduler is NOT stepped here — call `trainer.scheduler.step()` once
-        per iteration like main_aug_final.py:261)."""
+        per iteration like main_aug_final.py:261).  `flush_guard()` at every logging interval (grid_guard.py)."""
+        return self._guarded((images, labels), self._step_once)
+
+    def _step_once(self, images, labels):
         key = (tuple(images.shape), images.dtype, tuple(labels.shape))
         if self._graph is not None and self._key == key:
             self._static[0].copy_(images, non_blocking=True)
@@ -169,7 +188,7 @@ class SegTrainer:
                 with resnet_s.wgrad_stream(self._wgrad_side(images)):
                     out = self._capture(images, labels)
                 self._graph, self._out, self._key = self._pieces[0][0], out, key
-                return self.step(images, labels)
+                return self._step_once(images, labels)
             except Exception as e:  # noqa: BLE001 — stay correct: fall back to eager launches, loudly
                 import warnings
                 self._graph, self._graph_failed = None, e

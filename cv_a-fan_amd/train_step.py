@@ -17,6 +17,7 @@ import torch.distributed as dist
 from . import ops
 from .arena import ArenaSGD, ParamArena
 from .attack_algo import PGD, last_norms
+from .grid_guard import GuardedTrainer
 
 
 def warmup_lr(step, optimizer, warm_up_steps=200, max_lr=0.1):
@@ -77,6 +78,7 @@ class GradAllReducer:
         self._done = [0] * len(self.chunks)
         self._covered = []
         self._diag_ranges, self._diag_wait, self._diag_host = [], None, []
+        ops.exchange_in_flight(False)
 
     def launch_params(self, p_lo, p_hi):
         """Start the exchange of the gradients of parameters [p_lo, p_hi) (arena order) NOW, on the side stream: the
@@ -92,6 +94,9 @@ class GradAllReducer:
 
     def _launch(self, start, end):
         buf = self.arena.grad[start:end]
+        # from here to finish() RCCL's channel kernels may sit on CUs beside the compute stream's launches: no grid barrier may be
+        # issued meanwhile (the in-launch BatchNorm needs every workgroup of its launch resident: it would wait for the exchange to END)
+        ops.exchange_in_flight(True)
         if self.on_cuda:
             ev = torch.cuda.Event(enable_timing=self.diag)
             ev.record(torch.cuda.current_stream(buf.device))
@@ -139,6 +144,7 @@ class GradAllReducer:
             if self.diag:
                 wb.record(cur)
                 self._diag_wait = (wa, wb)
+        ops.exchange_in_flight(False)
 
     def note_host_gap(self, seconds):
         """(diag) host time between two graph replays around an exchange launch."""
@@ -156,6 +162,45 @@ class GradAllReducer:
               for start, end, ev, e0, e1 in self._diag_ranges]
         return {"ranges": rs, "exposed_allreduce_ms": round(self._diag_wait[0].elapsed_time(self._diag_wait[1]), 3),
                 "host_gap_us": [round(h * 1e6, 1) for h in self._diag_host]}
+
+
+class NullReducer:
+    """GradAllReducer's surface with no exchange behind it: `AfanTrainer(emulate_dp=True)` on ONE GPU then runs exactly the program a
+    rank of a data-parallel job runs — the backward cut into phases, one hipGraph per phase with a host call between two replays, the
+    in-launch BatchNorm off from the first announced range on — so that its cost can be timed without a second GPU (bench.py's
+    `dp_schedule`) and the multi-GPU efficiency anchored on the right single-GPU number.  Records what was announced."""
+    world = 1
+    diag = False
+    stream = None
+
+    def __init__(self, arena):
+        self.arena = arena
+        self.announced = []             # (p_lo, p_hi) of the last step, in order
+        self.fused_while_in_flight = 0  # convolution + BatchNorm launches issued between the first announcement and finish() (must stay 0)
+        self._mark = None
+
+    def begin(self, explicit=False):
+        self.announced, self._mark = [], None
+        ops.exchange_in_flight(False)
+
+    def launch_params(self, p_lo, p_hi):
+        if p_hi <= p_lo:
+            return
+        self.announced.append((p_lo, p_hi))
+        if self._mark is None:
+            self._mark = ops.CALLS["conv_bn_fused"]
+        ops.exchange_in_flight(True)
+
+    def finish(self):
+        if self._mark is not None:
+            self.fused_while_in_flight += ops.CALLS["conv_bn_fused"] - self._mark
+        ops.exchange_in_flight(False)
+
+    def note_host_gap(self, seconds):
+        pass
+
+    def last_diag(self):
+        return None
 
 
 def _cut_chunks(arena, n_chunks):
@@ -188,7 +233,7 @@ def _out_shape(mod, c, h, w):
     return c, h, w
 
 
-class AfanTrainer:
+class AfanTrainer(GuardedTrainer):
     """Owns the arena, the optimizer and the per-step schedule of one rank.
 
     use_graph=True (default): after `graph_warmup` eager iterations the whole iteration body — head forward, K PGD
@@ -201,7 +246,7 @@ class AfanTrainer:
     def __init__(self, model, criterion, *, steps=5, gamma=0.5, eps=2.0, perturb_idx=13, layer_number=None,
                  randinit=False, clip=False, lr=0.1, momentum=0.9, weight_decay=5e-4, allreduce_chunks=4,
                  group=None, use_graph=True, graph_warmup=3, batch_final=True,
-                 share_head=True, fold_clean=None, segmented=None, dual_bn=False):
+                 share_head=True, fold_clean=None, segmented=None, dual_bn=False, emulate_dp=False):
         self.model, self.criterion = model, criterion
         # dual-BN option (off = the reference's single BatchNorm set): adversarial features — every PGD pass and the
         # adversarial final pass — are normalised by an auxiliary BatchNorm set.  The first PGD pass is then no longer the
@@ -223,10 +268,15 @@ class AfanTrainer:
         if self.world > 1:
             self.optimizer.grad_scale = 1.0 / self.world
             self.sync_replicas()
+        elif emulate_dp:
+            self.reducer = NullReducer(self.arena)      # one GPU, the data-parallel program (see NullReducer)
+        # a grid barrier of the in-launch BatchNorm that gives up: detected every step without a host synchronisation, no update
+        # applied meanwhile (the optimizer's device-side guard), the lost steps run again on the two-launch forms (grid_guard.py)
+        self._guard_init(model, self.arena.param.device)
         import os
         # exchange the tail's gradients stage by stage while the rest of the backward runs (folded schedule); 0: one
         # blocking all-reduce after the backward (A/B, and the fallback if a piece-wise capture fails)
-        self.ddp_overlap = self.world > 1 and os.environ.get("AFAN_DDP_OVERLAP", "1") != "0"
+        self.ddp_overlap = self.reducer is not None and os.environ.get("AFAN_DDP_OVERLAP", "1") != "0"
         self.segmented = bool(segmented)          # True: run the segmented (piece-wise) step on one GPU too (tests)
         self._pieces = None
         self.batch_final = bool(batch_final)      # adv + clean final passes as one grouped pass over the tail
@@ -561,13 +611,26 @@ class AfanTrainer:
                     self.reducer.launch_params(*rng)
             if self.reducer is not None:
                 self.reducer.finish()
+            self._pre_sgd()
             self.optimizer.step()
             return out
         out = self._forward_backward(inp, target, overlap_allreduce=self.reducer is not None)
         if self.reducer is not None:
             self.reducer.finish()
+        self._pre_sgd()
         self.optimizer.step()
         return out
+
+    def _pre_sgd(self):
+        """Data parallel: the grid barrier's error word becomes the maximum over the ranks before the (device-guarded) optimizer
+        launch reads it — every rank skips the same updates (grid_guard.GridGuard.sync_ranks)."""
+        if self._guard is not None and self.world > 1:
+            self._guard.sync_ranks(self.group)
+
+    def _drop_graphs(self):
+        """After a grid barrier gave up: the captured graphs hold in-launch-BatchNorm launches; capture again (two-launch forms)."""
+        self._graph = self._pieces = self._static_in = self._static_out = self._shape_key = None
+        self._graph_failed = None
 
     # ----------------------------------------------------------------------------------------------- graph
     def _capture_pieces(self, inp, target):
@@ -579,15 +642,25 @@ class AfanTrainer:
         self._static_in = (inp.clone(), target.clone())
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
-        out, pieces, pool = {}, [], None
+        out, pieces, pool, fused = {}, [], None, []
         gen = self._phases_folded(self._static_in[0], self._static_in[1], out)
-        for _ in range(len(self._tail_segments()) + 1):      # one piece per tail segment + the head (nothing follows the last)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
-                rng = next(gen)
-            pieces.append((g, rng))
-            pool = pieces[0][0].pool()
+        try:
+            for _ in range(len(self._tail_segments()) + 1):      # one piece per tail segment + the head (nothing follows the last)
+                n0 = ops.CALLS["conv_bn_fused"]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
+                    rng = next(gen)
+                fused.append(ops.CALLS["conv_bn_fused"] - n0)
+                pieces.append((g, rng))
+                pool = pieces[0][0].pool()
+                if self.reducer is not None:
+                    # the replay starts an exchange HERE: whatever is captured from now on runs beside RCCL's resident kernels and
+                    # must not contain a grid barrier (the eager path gets the same switch from the reducer's own launches)
+                    ops.exchange_in_flight(True)
+        finally:
+            ops.exchange_in_flight(False)
         gen.close()
+        self._pieces_fused = fused          # convolution + BatchNorm launches captured per piece (data parallel: 0 after the first)
         self._pieces, self._static_out = pieces, out
         self._graph = pieces[0][0]
         self._shape_key = (tuple(inp.shape), inp.dtype, tuple(target.shape))
@@ -623,11 +696,13 @@ class AfanTrainer:
                     self.reducer.note_host_gap(_time.perf_counter() - t_)
             if self.reducer is not None:
                 self.reducer.finish()
+            self._pre_sgd()
             self.optimizer.step()
         else:
             self._graph.replay()
             if self.world > 1:
                 dist.all_reduce(self.arena.grad, op=dist.ReduceOp.SUM, group=self.group)
+                self._pre_sgd()
                 self.optimizer.step()
         small = ("loss", "loss_adv", "loss_clean", "prec1", "l2", "linf")
         # graph-owned outputs are overwritten by the next replay: hand out copies of the small ones
@@ -636,6 +711,9 @@ class AfanTrainer:
     def step(self, inp, target):
         """One iteration. Returns device tensors only: loss, loss_adv, loss_clean, prec1, l2[N], linf[N] (+ x_adv,
         feature_map, out_clean — in graph mode these three are views of graph-owned buffers, valid until the next step)."""
+        return self._guarded((inp, target), self._step_once)
+
+    def _step_once(self, inp, target):
         if self._graph is not None and self._shape_key == (tuple(inp.shape), inp.dtype, tuple(target.shape)):
             return self._step_graph(inp, target)
         if (self.use_graph and self._graph is None and self._graph_failed is None

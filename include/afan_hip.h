@@ -706,6 +706,23 @@ int afan_sgd_step(float* param, const float* grad, float* momentum_buf, uint16_t
                   int64_t n, const float* lr_dev, float momentum, float weight_decay,
                   float grad_scale, int first_step, afan_stream_t stream);
 
+/* The same update, skipped ON THE DEVICE when *guard != 0.  guard = the grid barrier's error word (barrier + 4 *
+ * afan_grid_barrier_error_word()): an in-launch BatchNorm (afan_conv_*_bn_*) whose bounded spin gave up went on with partial batch
+ * totals, so the step's gradients are invalid — this launch then touches neither parameters nor momentum nor the bf16 shadow, and
+ * (the word is sticky until the host clears it) neither does any later one: no corrupted update is ever applied, without a host
+ * read inside the step.  The host notices at its next look (train_step.GridGuard) and re-runs the lost steps on the two-launch forms. */
+int afan_sgd_step_guarded(float* param, const float* grad, float* momentum_buf, uint16_t* shadow_bf16,
+                          int64_t n, const float* lr_dev, float momentum, float weight_decay,
+                          float grad_scale, int first_step, const void* guard, afan_stream_t stream);
+/* dst = src (bytes a multiple of 16; 16-byte aligned) unless *guard != 0; *counter (nullable, device u32) += 1 when the copy
+ * happened.  The pre-step snapshot of the BatchNorm buffers (running statistics are updated inside the launches that may give up):
+ * once the word is set the snapshot keeps the buffers as they were at the START of the step that failed. */
+int afan_guarded_copy(void* dst, const void* src, int64_t bytes, const void* guard, void* counter, afan_stream_t stream);
+/* Test / probe aid (no reference counterpart): `workgroups` one-wave workgroups holding `lds_bytes` (256 .. 163840) of LDS each spin
+ * on `stream` for `microseconds` (<= 2 s) — stands for another stream's long-lived kernels (an RCCL channel kernel, a side-stream
+ * weight gradient) beside the step's launches: tests/test_grid_guard_gpu.py, tools/probe/cu_sharing.py. */
+int afan_occupy_cus(int workgroups, int lds_bytes, int microseconds, afan_stream_t stream);
+
 /* fp32 -> bf16 (round-to-nearest-even, NaN-preserving) and per-channel input normalisation
  * (resnet_s.py:87: (x - mean[c]) / std[c]); the input image is NCHW fp32, the output may be NHWC and/or bf16. */
 int afan_cast_bf16(const float* src, uint16_t* dst, int64_t n, afan_stream_t stream);

@@ -84,11 +84,16 @@ def _worker(rank, world, port, ret):
             reducer.begin(explicit=True)
             crit(model(x), y).backward()
             assert not reducer._pending                                   # hooks are off in explicit mode
+            assert not pkg.ops._grid_exchange                             # (no exchange yet: grid barriers may still be issued)
             for lo, hi in covered:
                 before = len(reducer._pending)
                 reducer.launch_params(lo, hi)
                 assert len(reducer._pending) == before + (1 if hi > lo else 0)   # started before finish(); empty range: nothing
+                # round 6: from the first real exchange to finish() the in-launch BatchNorm is off for the process
+                # (ops.exchange_in_flight: RCCL's resident kernels would keep a grid barrier waiting until the exchange ends)
+                assert pkg.ops._grid_exchange == bool(reducer._pending) and not (pkg.ops._grid_exchange and pkg.ops.GRID_BN)
             reducer.finish()
+            assert not pkg.ops._grid_exchange
             torch.testing.assert_close(arena.grad, ref, rtol=1e-5, atol=1e-6)
         # a chunk whose parameters got no gradient this step is still reduced by finish()
         arena.zero_grad()

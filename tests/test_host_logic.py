@@ -232,3 +232,77 @@ def test_padded_nms_contract_rejects_cpu_and_device_is_checked_first(pkg):
     import torch
     with pytest.raises(pkg.ops.AfanLibraryError):
         pkg.det_ops.nms(torch.zeros(0, 4), torch.zeros(0), 0.7, padded=True)
+
+
+def test_grid_bn_switches_compose_and_only_narrow(pkg):
+    """ops.GRID_BN = process switch AND every enclosing grid_bn() AND no exchange in flight (a nested grid_bn(True)
+    re-enabled the form inside grid_bn(False); SegTrainer's head backward ran grid barriers beside the tail's exchange)."""
+    ops = pkg.ops
+    allowed, ex = ops.GRID_BN_ALLOWED, ops._grid_exchange
+    try:
+        ops.GRID_BN_ALLOWED = True
+        ops.exchange_in_flight(False)
+        assert ops.GRID_BN
+        with ops.grid_bn(False):
+            with ops.grid_bn(True):
+                assert not ops.GRID_BN
+        assert ops.GRID_BN
+        assert ops.exchange_in_flight(True) is False and not ops.GRID_BN
+        with ops.grid_bn(True):
+            assert not ops.GRID_BN
+        assert ops.exchange_in_flight(False) is True and ops.GRID_BN
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ops.grid_bn_disable("test")
+        assert w and not ops.GRID_BN and not ops.GRID_BN_ALLOWED
+        with ops.grid_bn(True):
+            assert not ops.GRID_BN
+    finally:
+        ops.GRID_BN_ALLOWED = allowed
+        ops.exchange_in_flight(ex)
+        ops._grid_refresh()
+
+
+def test_null_reducer_flags_the_exchange(pkg):
+    """From the first announced range to finish() the process-wide switch says "exchange in flight" (no grid barrier may be issued);
+    GradAllReducer does the same around its real all-reduces (tests/test_ddp_gloo.py)."""
+    import torch
+    ops, ts = pkg.ops, pkg.train_step
+    lin = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+    arena = pkg.arena.ParamArena(lin, skip=(), allow_cpu=True)
+    red = ts.NullReducer(arena)
+    red.begin(explicit=True)
+    assert not ops._grid_exchange
+    red.launch_params(2, 4)
+    assert ops._grid_exchange and red.announced == [(2, 4)]
+    red.launch_params(3, 3)                           # an empty range announces nothing
+    assert red.announced == [(2, 4)]
+    red.finish()
+    assert not ops._grid_exchange and red.fused_while_in_flight == 0
+
+
+def test_buffer_arena_keeps_the_state_dict_contract(pkg):
+    """grid_guard.BufferArena: the BatchNorm running statistics become views of one flat tensor (one launch snapshots them); keys,
+    values, load_state_dict and the dual-BN set exchange behave as before."""
+    import torch
+    gg = pkg.grid_guard
+    m = pkg.resnet_s.resnet20()
+    for b in m.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.running_mean.uniform_(-1, 1)
+            b.running_var.uniform_(0.5, 2)
+            b.num_batches_tracked.fill_(7)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    ba = gg.BufferArena(m)
+    sd1 = m.state_dict()
+    assert list(sd1) == list(sd0) and all(torch.equal(sd1[k], sd0[k]) for k in sd0)
+    bn = next(b for b in m.modules() if isinstance(b, torch.nn.BatchNorm2d))
+    assert bn.running_mean.data_ptr() >= ba.f32.data_ptr() and bn.running_mean.data_ptr() < ba.f32.data_ptr() + ba.f32.numel() * 4
+    bn.running_mean.add_(1.0)
+    assert float(ba.f32.sum()) != float(ba.snap_f32.sum())
+    ba.restore()
+    assert all(torch.equal(m.state_dict()[k], sd0[k]) for k in sd0)
+    sd2 = {k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    m.load_state_dict(sd2)                            # in place: the views stay views
+    assert bn.running_mean.data_ptr() >= ba.f32.data_ptr() and torch.equal(bn.running_mean, sd2[[k for k in sd2 if k.endswith("running_mean")][0]])

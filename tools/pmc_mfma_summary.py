@@ -71,7 +71,9 @@ for k in sorted(A, key=lambda k: -sum(A[k].get("_duration_ns", [0]))):
 h = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.h"))):
     h.update(open(f, "rb").read())
-summary["_meta"] = {"kernel_sources_sha": h.hexdigest()[:16], "command": sys.argv[4] if len(sys.argv) > 4 else None,
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402 (stdlib-only at import time): per-file hashes, so that staleness is judged per kernel
+summary["_meta"] = {"kernel_sources_sha": h.hexdigest()[:16], "kernel_sources_sha_files": bench.source_shas(), "command": sys.argv[4] if len(sys.argv) > 4 else None,
                     "n_cus": N_CUS, "formulas": __doc__.split("Derived columns")[1].strip()}
 json.dump(summary, open(sys.argv[3], "w"), indent=1)
 for k, e in summary.items():

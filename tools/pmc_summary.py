@@ -20,7 +20,9 @@ summary = {k: {c: {"launches": len(v), "avg": sum(v) / len(v)} for c, v in cs.it
 h = hashlib.sha256()
 for f in sorted(glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "cv_a-fan_amd", "csrc", "*.h"))):
     h.update(open(f, "rb").read())
-summary["_meta"] = {"kernel_sources_sha": h.hexdigest()[:16], "command": sys.argv[3] if len(sys.argv) > 3 else None,
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402 (stdlib-only at import time): per-file hashes, so that staleness is judged per kernel
+summary["_meta"] = {"kernel_sources_sha": h.hexdigest()[:16], "kernel_sources_sha_files": bench.source_shas(), "command": sys.argv[3] if len(sys.argv) > 3 else None,
                     "unit": "KiB per launch (rocprofv3); HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950"}
 json.dump(summary, open(sys.argv[2], "w"), indent=1)
 for k, cs in summary.items():

@@ -135,3 +135,37 @@ if SEC in ("all", "r50"):
             us, ph = phases(fn, lib.afan_conv_stamps)
             print(f"   {nm:44s} {us:6.1f} us   " + "  ".join(f"{k_} {v}" for k_, v in ph[1:]))
             print(f"   {'   (the last workgroup of the grid)':44s}             " + "  ".join(f"{k_} {v}" for k_, v in phases.last[1:]))
+
+
+if SEC in ("all", "s2"):
+    # ---- round 6: the stride-2 launches of the ResNet-18 tail (a stage's first 3x3 / 2 + its 1x1 / 2 projection as a two-problem forward
+    # launch; their input gradient as the four-parity-class pair form): ~35 launches of ~40 us per step for half a stride-1 layer's FLOPs
+    for ci, co, h, n in ((64, 128, 32, 256), (128, 256, 16, 256), (256, 512, 8, 256)):
+        ho = h // 2
+        x = cl(torch.randn(n, ci, h, h, device=dev).bfloat16())
+        w3 = cl((torch.randn(co, ci, 3, 3, device=dev) * 0.05).bfloat16())
+        w1 = cl((torch.randn(co, ci, 1, 1, device=dev) * 0.05).bfloat16())
+        bn, bnsc = _BN(co), _BN(co)
+        dyall = torch.randn(2 * n, co, ho, ho, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        dy, dy_sc = dyall[:n], dyall[n:]
+        wt = cl(w3.permute(1, 0, 2, 3))
+        wt10 = torch.cat([w3.permute(1, 2, 3, 0).reshape(ci, 9, co), w1.permute(1, 2, 3, 0).reshape(ci, 1, co)], dim=1).contiguous()
+        y, stats = ops.bn_train_forward(x, torch.ones(ci, device=dev), torch.zeros(ci, device=dev), None, True, 1e-5, 0.1, None, None, None)
+        print(f"== stride 2: {ci}->{co} {h}x{h} -> {ho}x{ho} batch {n}: phases in ticks from entry (thread 0 of workgroup 0), launch time eager")
+        for name, fn, rd in (
+                ("forward 3x3/2 + projection, plain", lambda: ops.conv_fwd_multi(x, [w3, w1], 2, [1, 1]), lib.afan_conv_stamps),
+                ("forward 3x3/2 + projection + sums", lambda: (ops.acc_reset(dev), ops.conv_fwd_multi(x, [w3, w1], 2, [1, 1], stats_shifts=[bn.running_mean, bnsc.running_mean])), lib.afan_conv_stamps),
+                ("forward 3x3/2 + projection + BatchNorm in the launch", lambda: (ops.acc_reset(dev), ops.conv_fwd_multi_bn(x, [w3, w1], 2, [1, 1], [bn.running_mean, bnsc.running_mean], bn, 0.1)), BNF_RD),
+                ("input gradient pair, plain", lambda: ops.conv_dgrad(dy, wt, (h, h), 2, sc=(dy_sc, wt10)), lib.afan_conv_stamps),
+                ("input gradient pair + sums (block-output form)", lambda: (ops.acc_reset(dev), ops.conv_dgrad(dy, wt, (h, h), 2, bn_bwd=(x, stats, True), bn_y=y, sc=(dy_sc, wt10))), lib.afan_conv_stamps),
+                ("input gradient pair + BatchNorm backward in the launch", lambda: (ops.acc_reset(dev), ops.conv_dgrad_bn(dy, wt, (h, h), x, stats, True, bn_y=y, want_dres=True, pair=(dy_sc, wt10))), BNF_RD)):
+            if rd is None:
+                print(f"   {name:60s} (no stamps in this build)")
+                continue
+            try:
+                us, ph = phases(fn, rd)
+            except Exception as e:  # noqa: BLE001
+                print(f"   {name:60s} failed: {type(e).__name__}: {e}")
+                continue
+            print(f"   {name:60s} {us:6.1f} us   " + "  ".join(f"{k} {v}" for k, v in ph[1:]))
+            print(f"   {'   (the last workgroup of the grid)':60s}             " + "  ".join(f"{k_} {v}" for k_, v in phases.last[1:]))
