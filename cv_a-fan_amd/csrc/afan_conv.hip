@@ -28,6 +28,9 @@
 #include "afan_conv_params.h"
 #include <stdlib.h>
 
+#ifndef AFAN_CONV_DRES_EARLY
+#define AFAN_CONV_DRES_EARLY 1   // in-launch BatchNorm backward: the masked gradient leaves between the barrier's arrival and its wait (0: behind it, A/B)
+#endif
 #ifndef AFAN_CONV_FRAG_BATCH
 #define AFAN_CONV_FRAG_BATCH 4   // k16-slices of operand fragments in flight before their MFMAs (1: the compiler's order)
 #endif
@@ -720,6 +723,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     // tile by DMA — no registers, in flight while the accumulators are rounded into C; the barrier below drains it)
     uint16_t* const Z = lds + BM * LDC;
     // (not in the 768-thread variant: at its 168-register cap the third sum's state spills in the prefetch phase; launch_gs refuses)
+    constexpr bool DRES_EARLY = AFAN_CONV_DRES_EARLY != 0;
     constexpr bool BSC_OK = BF && HL > 0;        // (and not in the per-tap variants: their LDS has no room for the staged tile; launch_gs refuses)
     bool have_bsc = false;
     __shared__ float zmean_s[BF ? BN : 1];       // (BF) the projection BatchNorm's mean per tile column (registers are short in the row loop)
@@ -1038,13 +1042,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             __syncthreads();
             const unsigned wg_id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
             if (tid == 0) grid_arrive(pp.bar, wg_id, gridDim.x * gridDim.y * (pp.multi ? 1u : gridDim.z));
-            if (bf_fwd) {                                             // the raw tile leaves while the other workgroups arrive
+            // what is final BEFORE the totals leaves while the other workgroups arrive: the forward's raw tile; the backward's masked
+            // gradient (the shortcut's share, y2 — it waits in the tile since the first pass; round 6: was stored behind the barrier,
+            // in front of the second pass's own stores)
+            uint16_t* const early = bf_fwd ? y_p : ((bf_bwd && DRES_EARLY) ? pp.y2 : nullptr);
+            if (early) {
 #pragma unroll
                 for (int q = 0; q < EPI_ROWS; ++q) {
                     const int r = pr + q * ROWS_PER_PASS;
                     const int off = epi_on ? out_off[r] : -1;
                     if (off >= 0 && ch_ok)
-                        *reinterpret_cast<u16x8*>(y_p + (int64_t)off + n0 + pc * 8) = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
+                        *reinterpret_cast<u16x8*>(early + (int64_t)off + n0 + pc * 8) = *reinterpret_cast<const u16x8*>(C + r * LDC + pc * 8);
                 }
             }
             if (tid == 0) grid_wait(pp.bar, bar_target);
@@ -1195,7 +1203,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                         for (int j = 0; j < 8; ++j)
                             o[j] = f2bf(fmaf(bf2f(v[j]), al[j], fmaf(bf2f(xv[j]) - sh[j], k0[j], k1[j])));
                         *reinterpret_cast<u16x8*>(y_p + go) = o;
-                        if (pp.y2) *reinterpret_cast<u16x8*>(pp.y2 + go) = v;
+                        if (!DRES_EARLY && pp.y2) *reinterpret_cast<u16x8*>(pp.y2 + go) = v;
                         if (have_bsc) {
                             const u16x8 zv = *reinterpret_cast<const u16x8*>(Z + r * BN + pc * 8);
 #pragma unroll
