@@ -21,6 +21,7 @@ Usage:  python oracle/gen_golden.py            (rewrites tests/golden/ except th
         python oracle/gen_golden.py roialign   (only roi_align_fwd_*.npz)
         python oracle/gen_golden.py floor      (ref_noise_floor.npz: the reference against itself in float64 / other fp32 summation orders)
         python oracle/gen_golden.py lossfloor  (ref_loss_floor.npz: the same for the losses; + traj_r18_damped.npz)
+        python oracle/gen_golden.py detfloor   (ref_det_floor.npz: the reference's Detection iteration against itself, round 6)
 """
 import importlib.util
 import os
@@ -657,7 +658,7 @@ def _import_reference_detection_model():
             ctx.geom = (tuple(input.shape), tuple(output_size), float(spatial_scale), int(sampling_ratio))
             y = ref_fwd(input.detach().float().contiguous().numpy(), roi.detach().float().contiguous().numpy(), output_size[0],
                         output_size[1], float(spatial_scale), int(sampling_ratio))
-            return torch.from_numpy(y)
+            return torch.from_numpy(y).to(input.dtype)       # (the float64 floor variant: the kernel itself stays the reference's fp32 one)
 
         @staticmethod
         def backward(ctx, grad_output):
@@ -668,7 +669,7 @@ def _import_reference_detection_model():
             dx = np.zeros(shape, np.float32)
             lib.oracle_roi_align(dx.ctypes.data_as(_p), r.ctypes.data_as(_p), dy.ctypes.data_as(_p), len(r), shape[1], shape[2], shape[3],
                                  ph, pw, scale, sr, 1)
-            return torch.from_numpy(dx), None, None, None, None
+            return torch.from_numpy(dx).to(grad_output.dtype), None, None, None, None
 
     class ROIAlign(nn.Module):
         def __init__(self, output_size, spatial_scale, sampling_ratio):
@@ -793,6 +794,99 @@ def gen_detection_model(mode="pooling"):
     np.savez_compressed(os.path.join(OUT, fname + ".npz"), **rec)
     print(fname + ": forward losses", rec["fwd_losses"].tolist(), "iteration loss", float(loss), [round(float(v), 4) for v in L],
           "proposals", tuple(seen["proposals"].shape), "params with grad", len(named), "keys", len(k0))
+
+
+def gen_detection_floor(mode="pooling"):
+    """tests/golden/ref_det_floor.npz (round 6, VERDICT r5 weak 3 / missing 6) — the reference's OWN Detection iteration against itself.
+    The full iteration of train_aug_sat_muti_advt.py:70-172 on det_frcnn_r101[_align].npz's model and inputs is run again in other
+    arithmetics — float64, ATen-native fp32 (oneDNN off), channels-last fp32 — and on four draws of 1e-6 relative noise on the images
+    (the rounding noise ~100 fp32 layers accumulate in ANY implementation), same seeds, same host-RNG history.  Stored per variant:
+    the eight losses' relative distance from the fp32 baseline's, the iteration loss's, the fraction of adversarial-image pixels
+    (every 4th, as in the golden) that differ, the post-SGD checksums' relative distance; `<mode>/spread_*` = the maximum over the
+    variants.  tests/test_det_model_gpu.py::test_faster_rcnn_iteration_on_reference_golden bounds the product by
+    max(2 x spread, 1e-4) instead of the hand-set 2 %: one flipped sign() of the five-step image PGD reorders proposals, the positional
+    `randperm` sampling (Detection/model.py:274-277, rpn/region_proposal_network.py:87-90) then picks other boxes — in the
+    reference against itself exactly as in any port."""
+    import copy
+    ref_model, RefBackbone, RefPooler = _import_reference_detection_model()
+    ref_det = _load("ref_det_attack_algo", "Detection/attack_algo.py")
+    cfg = dict(anchor_ratios=[(1, 2), (1, 1), (2, 1)], anchor_sizes=[64], rpn_pre_nms_top_n=200, rpn_post_nms_top_n=64,
+               anchor_smooth_l1_loss_beta=1.0, proposal_smooth_l1_loss_beta=1.0)
+    torch.manual_seed(7)
+    model0 = ref_model.Model(RefBackbone(pretrained=False), 21, pooler_mode=RefPooler.Mode(mode), **cfg)
+    for m in model0.modules():
+        if hasattr(m, "bn3") and hasattr(m, "conv3"):
+            m.bn3.weight.data.mul_(0.2)
+    fname = "det_frcnn_r101" + ("" if mode == "pooling" else "_" + mode)
+    gold = np.load(os.path.join(OUT, fname + ".npz"))
+    images0, bboxes, labels = (torch.from_numpy(gold[k]) for k in ("images", "bboxes", "labels"))
+
+    def iteration(kind):
+        model, (images,) = _to_variant(kind, copy.deepcopy(model0), [images0])
+        bb = bboxes.to(images.dtype)
+        model.train()
+        y = {"bb": bb, "lb": labels}
+        optimizer = torch.optim.SGD(model.parameters(), lr=0.001, momentum=0.9, weight_decay=0.0005)
+        torch.manual_seed(102)
+        fwd = lambda d: model.train().forward(d, bb, labels)
+        with _variant_ctx(kind):
+            adv_image = ref_det.adv_input(x=images, y=y, model=model, steps=5, eps=(2.0 / 255), gamma=(0.3 / 255), randinit=True, clip=True)
+            f1 = fwd({"x": images, "adv": None, "out_idx": 1, "flag": "head"}).detach()
+            f2 = fwd({"x": images, "adv": None, "out_idx": 2, "flag": "head"}).detach()
+            f3 = fwd({"x": images, "adv": None, "out_idx": 3, "flag": "head"}).detach()
+            rr = fwd({"x": images, "adv": None, "out_idx": "roi_head", "flag": "clean"})
+            clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
+            a1 = ref_det.PGD(f1, images, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+            a2 = ref_det.PGD(f2, images, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+            a3 = ref_det.PGD(f3, images, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+            pts = ref_det.get_sample_points(f3, a3, 5)
+            pts[1] = ref_det.mix_feature(f3, pts[1])
+            pts[2] = ref_det.mix_feature(f3, pts[2])
+            arr = ref_det.rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
+            adv_sd = ref_det.mix_feature(clean_sd, arr["roi_output_dict"]["roi_feature_map"].detach())
+            arr["roi_output_dict"]["roi_feature_map"] = adv_sd
+            dicts = [{"x": adv_image, "adv": None, "out_idx": 0, "flag": "clean"}, {"x": images, "adv": a1, "out_idx": 1, "flag": "tail"},
+                     {"x": images, "adv": a2, "out_idx": 2, "flag": "tail"}] + \
+                    [{"x": images, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
+                    [{"adv": arr, "out_idx": "roi_tail", "flag": "clean"}]
+            L = [ref_det.compute_loss(*fwd(d)) for d in dicts]
+            loss = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        ck = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in model.state_dict().values()])
+        adv = adv_image.detach().contiguous(memory_format=torch.contiguous_format).double().numpy()[:, :, ::4, ::4]
+        return float(loss), np.array([float(v) for v in L], dtype=np.float64), adv, ck
+
+    b_loss, b_L, b_adv, b_ck = iteration("base")
+    assert np.float32(b_loss) == gold["step_loss"] and np.array_equal(b_L.astype(np.float32), gold["step_losses"]), (b_loss, gold["step_loss"])
+    rec = {}
+    variants = ("f64", "nomkldnn", "cl", "in1", "in2", "in3", "in4")
+    done = []
+    for kind in variants:
+        try:
+            v_loss, v_L, v_adv, v_ck = iteration(kind)
+        except Exception as e:      # noqa: BLE001 — a variant the reference's own code does not run in (dtype assumptions): recorded, skipped
+            print(f"   {fname}/{kind}: not runnable ({type(e).__name__}: {str(e)[:120]})")
+            continue
+        done.append(kind)
+        rec[f"{fname}/{kind}/losses_rel"] = np.abs(v_L - b_L) / np.abs(b_L)
+        rec[f"{fname}/{kind}/loss_rel"] = np.array(abs(v_loss - b_loss) / abs(b_loss))
+        rec[f"{fname}/{kind}/adv_pixels_off"] = np.array(float((np.abs(v_adv - b_adv) > 1e-6).mean()))
+        rec[f"{fname}/{kind}/ck_abs_rel"] = np.array(float((np.abs(v_ck[:, 1] - b_ck[:, 1]) / (np.abs(b_ck[:, 1]) + 1e-4)).max()))
+        print(f"   {fname}/{kind}: losses rel {rec[f'{fname}/{kind}/losses_rel'].max():.3e}  loss rel {float(rec[f'{fname}/{kind}/loss_rel']):.3e}  "
+              f"adv pixels off {float(rec[f'{fname}/{kind}/adv_pixels_off']):.4f}  checksums rel {float(rec[f'{fname}/{kind}/ck_abs_rel']):.3e}")
+    rec[f"{fname}/variants"] = np.array(done)
+    rec[f"{fname}/spread_losses_rel"] = np.array(max(float(rec[f"{fname}/{k}/losses_rel"].max()) for k in done))
+    rec[f"{fname}/spread_loss_rel"] = np.array(max(float(rec[f"{fname}/{k}/loss_rel"]) for k in done))
+    rec[f"{fname}/spread_adv_pixels_off"] = np.array(max(float(rec[f"{fname}/{k}/adv_pixels_off"]) for k in done))
+    rec[f"{fname}/spread_ck_abs_rel"] = np.array(max(float(rec[f"{fname}/{k}/ck_abs_rel"]) for k in done))
+    print(f"   {fname}: spread over {done}: losses {float(rec[f'{fname}/spread_losses_rel']):.3e}  loss {float(rec[f'{fname}/spread_loss_rel']):.3e}  "
+          f"adv pixels {float(rec[f'{fname}/spread_adv_pixels_off']):.4f}  checksums {float(rec[f'{fname}/spread_ck_abs_rel']):.3e}")
+    path = os.path.join(OUT, "ref_det_floor.npz")
+    old = dict(np.load(path)) if os.path.exists(path) else {}
+    old.update(rec)
+    np.savez_compressed(path, **old)
 
 
 def main():
@@ -1210,5 +1304,10 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True)
         gen_detection_model("pooling")
         gen_detection_model("align")
+    elif sys.argv[1:2] == ["detfloor"]:   # only ref_det_floor.npz (reads det_frcnn_r101[_align].npz); optional mode argument
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        for mode_ in (sys.argv[2:3] or ["pooling", "align"]):
+            gen_detection_floor(mode_)
     else:
         main()

@@ -7,10 +7,14 @@ compiled unedited) with the adjoint backward (pinned: tests/test_det_oracle.py).
 
 Held tightly: seeded construction (tests/test_host_logic.py, CPU), the three backbone feature maps, the RPN logits, the
 proposals, the four per-image losses of a training forward with the reference's host `randperm` draws, the gradients of
-that forward, the signs of the one-step feature PGD.  Held loosely, and said so: the full iteration of
-train_aug_sat_muti_advt.py:70-172 — its adversarial image is five sign() steps on 61 440 pixels; a flipped pixel moves every
-anchor's logit by ~1e-3, which reorders proposals of nearly equal score, and `randperm` then samples by POSITION: two correct
-fp32 implementations leave that iteration a per cent apart."""
+that forward, the signs of the one-step feature PGD — and, since round 6, the full iteration of
+train_aug_sat_muti_advt.py:70-172 too.  Rounds 3-5 held its eight losses to 2 % with an argument (the adversarial image is five
+sign() steps on 61 440 pixels; a flipped pixel reorders proposals of nearly equal score; `randperm` samples by position) and no
+measurement.  tests/golden/ref_det_floor.npz (oracle/gen_golden.py detfloor) is the measurement: the reference's own iteration run
+again in float64 / ATen-native fp32 / channels-last fp32 and under four draws of 1e-6 image noise moves 6.6-16.8 % of the adversarial
+image's pixels (arithmetic variants alone: 6.6-7.9 %) and the eight losses by at most 6.1e-5 relative — the argument was wrong about
+the losses — and the product sits inside that: 4.1e-5 / 1.7e-5 (pooling / align; profiles/r06_parity_measurements.txt).  The bounds
+are max(2 x the reference's own spread, 1e-4), as for the other two trainers."""
 import os
 
 import numpy as np
@@ -99,10 +103,22 @@ def test_faster_rcnn_fp32_matches_reference_model(pkg, gpu, nhwc, mode):
     assert pkg.ops.CALLS["vendor_conv"] == 0 and pkg.ops.CALLS["conv_general"] > before["conv_general"]
 
 
+_DFLOOR = golden("ref_det_floor")
+
+
+def _det_spread(mode, key, arith_only=False):
+    pre = "det_frcnn_r101" + ("" if mode == "pooling" else "_" + mode)
+    if arith_only:      # the arithmetic variants alone (float64, ATen-native fp32, channels-last fp32), without the input-noise draws
+        return max(float(np.max(_DFLOOR[f"{pre}/{k}/{key}"])) for k in ("f64", "nomkldnn", "cl"))
+    return float(_DFLOOR[pre + "/spread_" + key])
+
+
 @pytest.mark.parametrize("mode", ["pooling", "align"])
 def test_faster_rcnn_iteration_on_reference_golden(pkg, gpu, mode):
-    """One iteration of train_aug_sat_muti_advt.py:70-172 (det_attack_algo.det_train_step) on the real model: the eight losses
-    within 2 % of the reference's (see the module docstring for why not 1e-4), the weights after the SGD step by checksum."""
+    """One iteration of train_aug_sat_muti_advt.py:70-172 (det_attack_algo.det_train_step) on the real model: the eight losses and
+    the iteration loss within max(2 x the reference's own spread, 1e-4) of the reference's (ref_det_floor.npz: the reference's
+    iteration against itself in three other arithmetics and under four draws of 1e-6 image noise), the adversarial image's pixels
+    within twice the reference's own flip fraction, the weights after the SGD step by checksum."""
     g = _golden_for(mode)
     m = _build(pkg, g, gpu, torch.float32, True, mode)
     images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
@@ -112,12 +128,20 @@ def test_faster_rcnn_iteration_on_reference_golden(pkg, gpu, mode):
     torch.manual_seed(102)
     r = pkg.det_attack_algo.det_train_step(m, opt, images, bboxes, labels, loss_settings=1)
     L = r["losses"].float().cpu().numpy()
-    np.testing.assert_allclose(L, g["step_losses"], rtol=2e-2)
-    assert abs(float(r["loss"]) - float(g["step_loss"])) <= 2e-2 * float(g["step_loss"])
+    rel_L = float((np.abs(L - g["step_losses"]) / np.abs(g["step_losses"])).max())
+    rel_loss = abs(float(r["loss"]) - float(g["step_loss"])) / float(g["step_loss"])
     d = (r["adv_image"][:, :, ::4, ::4].float().cpu().numpy() - g["adv_image_sub"])
-    assert float((np.abs(d) > 1e-6).mean()) <= 0.15      # adversarial image: pixels off the reference's (5 sign() steps from a random start: measured 7.5 %)
+    off = float((np.abs(d) > 1e-6).mean())
+    b_L, b_loss = max(2 * _det_spread(mode, "losses_rel"), 1e-4), max(2 * _det_spread(mode, "loss_rel"), 1e-4)
+    b_off = 2 * _det_spread(mode, "adv_pixels_off", arith_only=True)
+    print(f"PARITY det_frcnn_r101 [{mode}, fp32 NHWC]: eight losses rel {rel_L:.2e} (reference-vs-reference spread {_det_spread(mode, 'losses_rel'):.2e}, "
+          f"bound {b_L:.2e})   iteration loss rel {rel_loss:.2e} (spread {_det_spread(mode, 'loss_rel'):.2e}, bound {b_loss:.2e})   adversarial-image "
+          f"pixels off {off:.4f} (reference-vs-reference {_det_spread(mode, 'adv_pixels_off'):.4f}, arithmetic variants only "
+          f"{_det_spread(mode, 'adv_pixels_off', True):.4f}, bound {b_off:.4f})")
+    assert rel_L <= b_L and rel_loss <= b_loss, (rel_L, b_L, rel_loss, b_loss)
+    assert off <= b_off, (off, b_off)          # five sign() steps from a random start: the reference moves as many against itself
     ck1 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in m.state_dict().values()])
-    np.testing.assert_allclose(ck1[:, 1], g["ck1"][:, 1], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(ck1[:, 1], g["ck1"][:, 1], rtol=1e-5, atol=1e-6)      # (measured 5e-7; rounds 3-5 allowed 1e-3)
     assert pkg.ops.CALLS["vendor_conv"] == 0
 
 

@@ -299,3 +299,18 @@ def test_mix_feature_and_lerp(orc, c_oracle, tag):
         # ATen's vectorised body is one FMA; its scalar tail may round twice: allow 1 ulp there
         np.testing.assert_allclose(oc, ref, rtol=1.2e-7, atol=1e-7)
         assert (oc == ref).mean() > 0.95
+
+
+def test_detection_floor_fixture_is_complete():
+    """tests/golden/ref_det_floor.npz (oracle/gen_golden.py detfloor, round 6): both pooler modes, seven variants each, the spreads
+    the GPU test bounds the Detection iteration by — and they are what makes a 1e-4 bound possible (losses move < 1e-4 relative in
+    the reference against itself although 6-17 % of the adversarial image's pixels flip)."""
+    f = golden("ref_det_floor")
+    for pre in ("det_frcnn_r101", "det_frcnn_r101_align"):
+        vs = [str(v) for v in f[pre + "/variants"]]
+        assert set(vs) >= {"f64", "nomkldnn", "cl", "in1", "in2", "in3", "in4"}, vs
+        for v in vs:
+            assert f[f"{pre}/{v}/losses_rel"].shape == (8,)
+        assert float(f[pre + "/spread_losses_rel"]) == max(float(f[f"{pre}/{v}/losses_rel"].max()) for v in vs)
+        assert 0 < float(f[pre + "/spread_losses_rel"]) < 1e-4 and 0 < float(f[pre + "/spread_loss_rel"]) < 1e-4
+        assert 0.05 < float(f[pre + "/spread_adv_pixels_off"]) < 0.25

@@ -4,6 +4,7 @@
 #   libs W "a b tree"       several BUILDS of the library on one box, interleaved twice (tools/build_variant.sh / build_prev.sh; tree = working tree)
 #   env W VAR "0 1"         one environment variable's settings, interleaved twice
 #   suite [pytest args]     the -m gpu suite + smoke()
+#   parity                  every PARITY line of the golden tests (measured delta, reference-vs-reference floor, bound) -> gpurun_out/r06/parity_measurements.txt
 #   py script.py [args]     any probe script
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/r06; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
@@ -21,6 +22,8 @@ case "$1" in
   env) W=$2; for rep in 1 2; do for V in $4; do bench1 $W "$3=$V" "$3=$V"; done; done ;;
   suite) shift; timeout 2700 python3 -m pytest tests/ -x -q -m gpu "$@" > $OUT/gpu_suite.txt 2>&1; tail -15 $OUT/gpu_suite.txt
          timeout 600 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt ;;
+  parity) timeout 2400 python3 -m pytest tests/test_train_step_gpu.py tests/test_deeplab_gpu.py tests/test_det_model_gpu.py -q -s -m gpu -k "matches_reference or trajectory or contractive or perturbation_given or golden" > $OUT/parity_raw.txt 2>&1
+          grep -o "PARITY.*\|[0-9]* passed.*\|[0-9]* failed.*" $OUT/parity_raw.txt | sort -u > $OUT/parity_measurements.txt; tail -3 $OUT/parity_raw.txt; grep -c PARITY $OUT/parity_measurements.txt; grep "det_frcnn" $OUT/parity_measurements.txt ;;
   py) shift; timeout 1500 python3 "$@" 2>&1 | tee $OUT/py_$(basename $1 .py).txt | tail -80 ;;
   *) echo "unknown: $1"; exit 2 ;;
 esac
