@@ -1,5 +1,5 @@
 #!/bin/bash
-# libafan_hip_prev.so for same-box A/Bs (tools/gpu_r5_f.sh): the library of a COMMITTED tree (default HEAD), built out of tree
+# libafan_hip_prev.so for same-box A/Bs (tools/gpu_r6.sh libs): the library of a COMMITTED tree (default HEAD), built out of tree
 #   bash tools/build_prev.sh [rev]
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)

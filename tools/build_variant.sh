@@ -1,5 +1,5 @@
 #!/bin/bash
-# The working tree's library with extra compile flags, built out of tree -> tools/probe/_bin/libafan_hip_NAME.so (for tools/gpu_r5_l.sh)
+# The working tree's library with extra compile flags, built out of tree -> tools/probe/_bin/libafan_hip_NAME.so (for tools/gpu_r6.sh libs)
 #   bash tools/build_variant.sh pprio "-DAFAN_HL_PPRIO=3"
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); D=/tmp/afan_var_$1; rm -rf $D; mkdir -p $D/pkg
