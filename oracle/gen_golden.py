@@ -21,6 +21,7 @@ Usage:  python oracle/gen_golden.py            (rewrites tests/golden/ except th
         python oracle/gen_golden.py roialign   (only roi_align_fwd_*.npz)
         python oracle/gen_golden.py floor      (ref_noise_floor.npz: the reference against itself in float64 / other fp32 summation orders)
         python oracle/gen_golden.py lossfloor  (ref_loss_floor.npz: the same for the losses; + traj_r18_damped.npz)
+        python oracle/gen_golden.py bf16floor  (ref_bf16_floor.npz: the reference's own step under bf16 autocast against its fp32 run, round 6)
         python oracle/gen_golden.py detfloor   (ref_det_floor.npz: the reference's Detection iteration against itself, round 6)
 """
 import importlib.util
@@ -889,6 +890,72 @@ def gen_detection_floor(mode="pooling"):
     np.savez_compressed(path, **old)
 
 
+def gen_bf16_floor(ref_attack, orc):
+    """tests/golden/ref_bf16_floor.npz (round 6) — what bf16 arithmetic does to the REFERENCE ITSELF.  The benched
+    configuration computes its convolutions in bf16 (BASELINE configs[1]); its perturbation differs from the reference's fp32 one on
+    14 % of the elements of the contractive golden, and the tests held that with a hand-set 0.20.  Here the reference's own code
+    (Classification/attack_algo.PGD + the loop body of main_perturb.py:173-201 on the step_r18_k5_b32_damped network and inputs) is
+    run under torch.autocast(bfloat16) — convolutions and the linear layer in bf16, BatchNorm statistics and the loss in fp32: the
+    mixed precision of the product — and compared with its own fp32 run: fraction of perturbation elements that differ (after every
+    step), the three losses, every parameter's gradient norm, the running statistics.  A second variant keeps EVERYTHING in bf16
+    (model.bfloat16(), bf16 inputs): the upper end of what "a bf16 run of the reference" can mean.  The product's bf16 path is then
+    bounded by max(2 x the autocast variant's distance, the fp32 bound)."""
+    import copy
+    crit = nn.CrossEntropyLoss()
+    gold = np.load(os.path.join(OUT, "step_r18_k5_b32_damped.npz"))
+    torch.manual_seed(3)
+    model0, idx, ln = orc.resnet18_cifar(), 6, 15
+    for m in model0.modules():
+        if isinstance(m, orc.Block):
+            m.bn2.weight.data.mul_(float(gold["damp"]))
+    model0.train()
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    K, gamma, eps = 5, 0.5, 2.0
+
+    def run(kind):
+        model = copy.deepcopy(model0)
+        xx = x
+        ctx = contextlib.nullcontext()
+        if kind == "autocast":
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16)
+        elif kind == "allbf16":
+            model, xx = model.bfloat16(), x.bfloat16()
+        opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=5e-4)
+        with ctx:
+            fm = model(xx, end_point=idx, start_point=0).detach()
+            snaps = _pgd_trace(ref_attack, model, crit, fm, y, K, gamma, eps, idx, ln, False)
+            x_adv = snaps[-1]
+            out_adv = model(x_adv, end_point=ln, start_point=idx)
+            out_clean = model(xx, end_point=ln, start_point=0)
+            la, lc = crit(out_adv.float(), y), crit(out_clean.float(), y)
+            loss = (la + lc) / 2
+            opt.zero_grad()
+            loss.backward()
+        dks = [np.rint(((s_.double() - fm.double()) / (gamma / 255)).numpy()) for s_ in snaps[1:]]
+        gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters() if p.grad is not None])
+        rs = {k: v.double().numpy() for k, v in model.state_dict().items() if "running_" in k}
+        return dict(dks=dks, loss=float(loss), loss_adv=float(la), loss_clean=float(lc), gn=gn, rs=rs, fm=fm.double().numpy())
+
+    import contextlib
+    base = run("base")
+    assert np.array_equal(base["dks"][-1].astype(np.int8), gold["dk"]) and np.float32(base["loss"]) == gold["loss"], "baseline is not the golden"
+    rec = {}
+    for kind in ("autocast", "allbf16"):
+        v = run(kind)
+        pre = f"step_r18_k5_b32_damped/{kind}/"
+        rec[pre + "flips_per_step"] = np.array([float((a != b).mean()) for a, b in zip(v["dks"], base["dks"])])
+        for k in ("loss", "loss_adv", "loss_clean"):
+            rec[pre + k + "_rel"] = np.array(abs(v[k] - base[k]) / max(1.0, abs(base[k])))
+        rec[pre + "grad_norm_rel_max"] = np.array(float((np.abs(v["gn"] - base["gn"]) / (base["gn"] + 1e-6 * base["gn"].max())).max()))
+        rec[pre + "running_stats_max"] = np.array(max(float(np.max(np.abs(v["rs"][k] - base["rs"][k]) / (np.abs(base["rs"][k]) + 1.0))) for k in base["rs"]))
+        rec[pre + "feature_map_l2_rel"] = np.array(float(np.linalg.norm((v["fm"] - base["fm"]).ravel()) / np.linalg.norm(base["fm"].ravel())))
+        print(f"   {pre}: flips per step {np.round(rec[pre + 'flips_per_step'], 4).tolist()}  losses rel "
+              f"{float(rec[pre + 'loss_rel']):.2e} / {float(rec[pre + 'loss_adv_rel']):.2e} / {float(rec[pre + 'loss_clean_rel']):.2e}  grad norms "
+              f"{float(rec[pre + 'grad_norm_rel_max']):.3f}  running stats {float(rec[pre + 'running_stats_max']):.2e}  feature map "
+              f"{float(rec[pre + 'feature_map_l2_rel']):.2e}")
+    np.savez_compressed(os.path.join(OUT, "ref_bf16_floor.npz"), **rec)
+
+
 def main():
     assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
     _shims()
@@ -1304,6 +1371,11 @@ if __name__ == "__main__":
         os.makedirs(OUT, exist_ok=True)
         gen_detection_model("pooling")
         gen_detection_model("align")
+    elif sys.argv[1:] == ["bf16floor"]:   # only ref_bf16_floor.npz (reads step_r18_k5_b32_damped.npz)
+        assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
+        _shims()
+        from oracle import afan_oracle as _orc
+        gen_bf16_floor(_load("ref_cls_attack_algo", "Classification/attack_algo.py"), _orc)
     elif sys.argv[1:2] == ["detfloor"]:   # only ref_det_floor.npz (reads det_frcnn_r101[_align].npz); optional mode argument
         assert os.path.isdir(REF), f"{REF} not found: this script only runs in the build container"
         _shims()

@@ -314,3 +314,16 @@ def test_detection_floor_fixture_is_complete():
         assert float(f[pre + "/spread_losses_rel"]) == max(float(f[f"{pre}/{v}/losses_rel"].max()) for v in vs)
         assert 0 < float(f[pre + "/spread_losses_rel"]) < 1e-4 and 0 < float(f[pre + "/spread_loss_rel"]) < 1e-4
         assert 0.05 < float(f[pre + "/spread_adv_pixels_off"]) < 0.25
+
+
+def test_bf16_floor_fixture_is_complete():
+    """tests/golden/ref_bf16_floor.npz (oracle/gen_golden.py bf16floor, round 6): the reference's own contractive ResNet-18 step with
+    its convolutions in bf16 (autocast) and with everything in bf16, against its fp32 run — what the benched arithmetic's bounds in
+    tests/test_train_step_gpu.py::test_step_matches_contractive_reference_golden are twice of."""
+    f = golden("ref_bf16_floor")
+    for kind in ("autocast", "allbf16"):
+        pre = f"step_r18_k5_b32_damped/{kind}/"
+        fl = f[pre + "flips_per_step"]
+        assert fl.shape == (5,) and 0.2 < float(fl[-1]) < 0.6          # bf16 gradients flip a third of the signs of the fp32 run's
+        for k in ("loss_rel", "loss_adv_rel", "loss_clean_rel", "grad_norm_rel_max", "running_stats_max", "feature_map_l2_rel"):
+            assert 0 < float(f[pre + k]) < 0.1, (k, float(f[pre + k]))

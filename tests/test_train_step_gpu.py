@@ -56,6 +56,17 @@ def report_flips(case, what, flips):
           f"{flip_floor(case):.5f} (arithmetic variants only {flip_floor_arith(case):.5f})   bound {flip_bound(case):.5f}")
 
 
+# ... and for the BENCHED arithmetic (round 6): tests/golden/ref_bf16_floor.npz (oracle/gen_golden.py bf16floor) holds how far the
+# reference's OWN step moves when its convolutions run in bf16 (torch.autocast: BatchNorm statistics and the loss stay fp32, the mixed
+# precision of the product) — perturbation elements, losses, gradient norms, running statistics, feature map, each against its fp32 run.
+_BFLOOR = golden("ref_bf16_floor")
+
+
+def bf16_floor(case, key, kind="autocast"):
+    v = _BFLOOR[f"{case}/{kind}/{key}"]
+    return float(v[-1]) if v.ndim else float(v)
+
+
 ARCH = {"r20s": "resnet20s", "r56s": "resnet56s", "r18": "resnet18"}
 
 
@@ -286,10 +297,13 @@ def test_step_matches_contractive_reference_golden(pkg, orc, gpu, dtype):
     """The headline network end to end at K = 5 against a golden whose network is CONTRACTIVE (step_r18_k5_b32_damped:
     every block's last-BatchNorm weight x 0.1 — weights are data —, batch 32; the reference's own PGD and the loop body of
     main_perturb.py:173-201, oracle/gen_golden.py gen_damped_r18): rounding noise is damped instead of amplified, so the
-    benched bf16 path (channels-last, tuned MFMA kernels, folded schedule) can be held to bounds that a wrong kernel breaks:
-    losses 5e-3 (measured 1.9e-3), EVERY parameter's gradient norm within 10 % (measured 5 %), BatchNorm running statistics
-    5e-3 (1.8e-3), update counts equal.  fp32 (the general f32-MFMA kernels, channels-last too): losses 1e-4, gradient norms
-    1 %, perturbation equal on >= 98 % of the elements (measured 98.8 %)."""
+    benched bf16 path (channels-last, tuned MFMA kernels, folded schedule) can be held to bounds that a wrong kernel breaks.
+    bf16 bounds (round 6) = twice what bf16 arithmetic does to the REFERENCE ITSELF (ref_bf16_floor.npz: its own step under
+    torch.autocast(bfloat16) against its fp32 run: losses 1.0e-3 / 2.1e-3 / 2.4e-4, gradient norms 3.3 %, running statistics 1.8e-3,
+    feature map 4.1e-3 — and 41 % of the perturbation's elements after five steps): losses 4.2e-3 (measured 1.9e-3), EVERY parameter's
+    gradient norm within 6.6 % (measured 5 %), running statistics 3.5e-3 (1.8e-3), feature map 8.2e-3 (4.1e-3); perturbation elements
+    off the fp32 reference's: not more than the reference's own bf16 run (0.41; measured 0.14, regression guard 0.20).  fp32 (the general
+    f32-MFMA kernels, channels-last too): losses 1e-4, gradient norms 1 %, perturbation equal on >= 98 % of the elements (measured 98.8 %)."""
     g = golden("step_r18_k5_b32_damped")
     K, idx, ln, _, _ = [int(v) for v in g["meta"]]
     gamma, eps = [float(v) for v in g["gamma_eps"]]
@@ -315,24 +329,30 @@ def test_step_matches_contractive_reference_golden(pkg, orc, gpu, dtype):
         if not value <= bound:
             bad.append(f"{name}: {value:.4g} > {bound:.4g}")
 
+    C_ = "step_r18_k5_b32_damped"
+    b_loss = max(2 * max(bf16_floor(C_, k + "_rel") for k in ("loss", "loss_clean", "loss_adv")), 1e-4)
     for k in ("loss", "loss_clean", "loss_adv"):
-        hold(k, abs(float(r[k]) - float(g[k])) / max(1.0, abs(float(g[k]))), 1e-4 if f32 else 5e-3)
+        hold(k, abs(float(r[k]) - float(g[k])) / max(1.0, abs(float(g[k]))), 1e-4 if f32 else b_loss)
     fm_sub = r["feature_map"][:, ::4, ::2, ::2].float().cpu().numpy()
     hold("feature map (l2)", np.linalg.norm((fm_sub - g["feature_map_sub"]).ravel()) / np.linalg.norm(g["feature_map_sub"].ravel()),
-         2e-5 if f32 else 6e-3)                                   # (measured 4.1e-3 in bf16: two blocks' worth of bf16 rounding)
+         2e-5 if f32 else 2 * bf16_floor(C_, "feature_map_l2_rel"))   # (measured 4.1e-3 in bf16 = the reference's own bf16 run: 4.1e-3)
     dk = torch.round((r["x_adv"].float() - r["feature_map"].float()) / np.float32(gamma / 255)).cpu().numpy().astype(np.int8)
     # K = 5 sign() steps; bf16 gradients carry 2^-9 relative rounding per element, so many more of them sit "within rounding of
     # zero" than in fp32 (measured: fp32 1.2 % of the elements differ from the reference's, bf16 14 %)
     fl = float((dk != g["dk"]).mean())
     report_flips("step_r18_k5_b32_damped", f"{'fp32' if f32 else 'bf16'} NHWC", fl)
     # fp32: the reference's own floor; bf16 is not the reference's arithmetic (compared on the loss): stated bound
-    hold("perturbation elements off the reference's", fl, flip_bound("step_r18_k5_b32_damped") if f32 else 0.20)
+    hold("perturbation elements off the reference's", fl, flip_bound("step_r18_k5_b32_damped") if f32 else min(0.20, bf16_floor(C_, "flips_per_step")))
+    if not f32:
+        print(f"PARITY {C_} [bf16 NHWC vs the reference's own bf16 run]: perturbation elements off the fp32 reference's {fl:.4f}   the reference under "
+              f"torch.autocast(bfloat16) against itself {bf16_floor(C_, 'flips_per_step'):.4f} (everything in bf16: {bf16_floor(C_, 'flips_per_step', 'allbf16'):.4f})   "
+              f"losses bound {b_loss:.2e}   gradient norms bound {2 * bf16_floor(C_, 'grad_norm_rel_max'):.3f}")
     names = [str(k) for k in g["param_names"]]
     assert tr.arena.names == names
     got = np.array([float(tr.arena.view(tr.arena.grad, i).double().norm()) for i in range(len(names))])
     ref = g["grad_norms"]
     rel = np.abs(got - ref) / (ref + 1e-6 * ref.max())
-    hold(f"worst gradient norm ({names[int(rel.argmax())]})", float(rel.max()), 1e-2 if f32 else 0.10)
+    hold(f"worst gradient norm ({names[int(rel.argmax())]})", float(rel.max()), 1e-2 if f32 else 2 * bf16_floor(C_, "grad_norm_rel_max"))
     for k in g.files:
         if k.startswith("grad/"):
             a = tr.arena.view(tr.arena.grad, names.index(k[5:])).float().cpu().numpy()
@@ -347,7 +367,7 @@ def test_step_matches_contractive_reference_golden(pkg, orc, gpu, dtype):
             else:
                 a = sd1[k[4:]].float().cpu().numpy()
                 worst_rs = max(worst_rs, float(np.max(np.abs(a - g[k]) / (np.abs(g[k]) + 1.0))))
-    hold("running statistics (|d| / (1 + |ref|))", worst_rs, 1e-4 if f32 else 5e-3)
+    hold("running statistics (|d| / (1 + |ref|))", worst_rs, 1e-4 if f32 else 2 * bf16_floor(C_, "running_stats_max"))
     print(f"contractive golden, {dtype}:", {k: f"{v:.3g}" for k, v in seen.items()})
     assert not bad, bad
 
