@@ -137,6 +137,19 @@ template <int KG, int BR> struct HaloSched {
     static constexpr int wait(int t, bool more) { return slot(t - 1, more) + slot(t - 2, more); }             // may stay in flight at tap t's wait
 };
 
+// halo form, FIVE tiles ahead (PF = 7: six weight buffers; the MFMA waves request a tap's fragments during the tap before): the next
+// chunk's KG halo groups per producer wave ride with the first FIVE taps (all of it must be in LDS at tap 8's barrier: tap 8's MFMA
+// waves already read the next chunk's first tap), BR weight DMAs per tap
+template <int KG, int BR> struct HaloSched5 {
+    static constexpr int s(int t) { return (t < 0 || t >= 5) ? 0 : KG / 5 + (t < KG % 5 ? 1 : 0); }
+    static constexpr int g0(int t) { int g = 0; for (int i = 0; i < t; ++i) g += s(i); return g; }
+    // instructions of the issue slot behind tap tp's barrier (tp < 0: a slot of the chunk before — its halo part, if any, came with its
+    // own first five taps — or of the prologue: weights only)
+    static constexpr int slot(int tp, bool more) { return tp < 0 ? BR : ((tp + 5 < 9 || more) ? BR : 0) + (more ? s(tp) : 0); }
+    // may stay in flight at tap t's wait: what was issued behind tile t + 1's own DMAs (slot t - 4): the three slots since
+    static constexpr int wait(int t, bool more) { return slot(t - 1, more) + slot(t - 2, more) + slot(t - 3, more); }
+};
+
 // PF: 1/2 = register-staged operands (1 or 2 register sets), 3 = LDS-DMA.  NW: waves per workgroup (4 = 2x2, 8 = 2x4):
 // the tile is the same, 8 waves halve the per-wave work so twice as many waves per SIMD cover each other's waits.
 // PW > 0: PW extra PRODUCER waves issue every operand DMA and the WM x WN waves only read LDS and issue MFMAs.  An LDS-DMA
@@ -412,7 +425,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
     };
 
     if constexpr (HL > 0) {
-        static_assert(PW == 4 && GLDS && NS == 4, "halo form: FOUR producer waves (hdma's group index is k * 4 + swave), four weight stages");
+        static_assert(PW == 4 && GLDS && (NS == 4 || NS == 6), "halo form: FOUR producer waves (hdma's group index is k * 4 + swave), four weight stages (or six: the one-tap-ahead form)");
         // a chunk's halo is issued two groups (of 8 pixels per producer wave: 64 pixels) per K-step from t = 0 and must be complete
         // before the next chunk's first tile waits with vmcnt(2 * LPT): all groups issued by t <= 6, i.e. at most 7 x 64 pixels
         static_assert(HL <= 448, "halo form: the next chunk's halo must be issued within 7 K-steps (at most 2 groups x 4 waves x 8 pixels each)");
@@ -537,6 +550,96 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
         // stamps of round 5, profiles/r05b_conv_stamps_baseline.txt, show the producers' DMA issue, ~130 cycles per instruction
         // through the CU's one address path, setting the tap period of the 64-column tiles).  The counted waits take each tap's own
         // instruction count — compile-time constants of the unrolled tap index.
+        if constexpr (NS == 6) {
+        // ---- round 6: the MFMA waves one tap AHEAD.  In the form below (NS == 4) a tap is, for an MFMA wave: barrier -> 12-16 fragment
+        // requests -> their latency -> 8-16 MFMAs, with one MFMA wave per SIMD and nothing to cover the requests (stamps: 833 / 1 039
+        // ticks per tap at the 512- / 256-channel stages for 256 / 512 of matrix-pipe time), and for a producer wave: wait -> barrier
+        // -> 3-5 DMA instructions of ~130 ticks each.  Round 5 moved the fragments one group ahead with four weight buffers — one tile
+        // less in flight — and the launches kept their time (NOTES 12.3); round 6 measured that neither the weights' traffic nor the
+        // barrier count is what a tap waits for (profiles/r06_kloop_experiments.txt).  Here BOTH chains get slack: six weight
+        // buffers, tile t + 1 required at tap t's barrier and tiles t + 2 .. t + 5 in flight behind it (four instead of three), and an
+        // MFMA wave requests tap t + 1's fragments slice by slice between tap t's MFMAs (two register sets, the set index a literal
+        // of the tap unrolled over a double chunk: 18 taps).  The products are added in the same order as in every other form.
+        // LDS hazards: tile t + 1's buffer is re-filled behind barrier t + 2 (slot t + 2 issues tile t + 7): every wave's requests
+        // of tile t + 1 were consumed by tap t + 1's MFMAs by then; the halo buffer of chunk q - 1 is re-filled from slot (q, 0) on:
+        // its last requests (for tap (q - 1, 8)) were consumed before barrier (q, 0).
+        typedef HaloSched5<(HL + 31) / 32, B_ROWS> HS5;
+        if (producer) {
+            for (int k = 0; k * 4 < G; ++k) hdma(0, k, 0);     // chunk 0's halo (older than every counted instruction)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) bdma(u, two[u], 0);    // tiles 0 .. 4
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 * B_ROWS)); // tile 0 (and the halo in front of it) has landed
+            __builtin_amdgcn_s_barrier();                      // the MFMA waves request tap 0's fragments behind this one
+            for (int q = 0; q < chunks; ++q) {
+                const bool more = q + 1 < chunks;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    switch (t) {                               // tile (q, t) + 1 has landed: the three newest slots may be in flight
+#define AFAN_HS_WAIT(T) case T: if (more) __builtin_amdgcn_s_waitcnt(vmcnt_imm(HS5::wait(T, true))); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(HS5::wait(T, false))); break;
+                        AFAN_HS_WAIT(0) AFAN_HS_WAIT(1) AFAN_HS_WAIT(2) AFAN_HS_WAIT(3) AFAN_HS_WAIT(4) AFAN_HS_WAIT(5) AFAN_HS_WAIT(6) AFAN_HS_WAIT(7)
+                        AFAN_HS_WAIT(8)
+#undef AFAN_HS_WAIT
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    if (more) {                                // the next chunk's halo part first: it is waited for one slot earlier than the tile behind it
+#pragma unroll
+                        for (int j = 0; j < HS5::s(t); ++j) hdma((q + 1) & 1, HS5::g0(t) + j, q + 1);
+                    }
+                    const int g5 = 9 * q + t + 5;              // tile five taps ahead -> the buffer tile (q, t) - 1 used
+                    if (t + 5 < 9 || more) bdma(g5 % 6, two[(t + 5) % 9], t + 5 < 9 ? q : q + 1);
+                }
+            }
+        } else {
+            late_prologue();
+            const int frow = lane & 31, sw = (frow >> 1) & 7;
+            bf16x8 fxs[2][BK / 16][MI], fws[2][BK / 16][NI];
+            // requests of one k16-slice of a tap's fragments into register set SET; the MFMAs of one slice from set SET
+#define AFAN_RD(SET, WBUF, HB, TJ, TV, KK)                                                                                        \
+            {                                                                                                                     \
+                const uint16_t* B_ = lds + (WBUF) * STAGE;                                                                        \
+                const uint16_t* H_ = Hbase + (HB) * (HPM * BK);                                                                   \
+                const int c2_ = (KK) * 2 + (lane >> 5);                                                                           \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                    \
+                    fxs[SET][KK][i] = *reinterpret_cast<const bf16x8*>(H_ + (jrow[i] + (TJ)) * BK + ((c2_ ^ (((vrow[i] + (TV)) >> 1) & 7)) * 8)); \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                                    \
+                    fws[SET][KK][j] = *reinterpret_cast<const bf16x8*>(B_ + (wc * TN + j * 32 + frow) * LDR + ((c2_ ^ sw) * 8));  \
+            }
+#define AFAN_MF(SET, KK)                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                                        \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                    \
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fws[SET][KK][j], fxs[SET][KK][i], acc[j][i], 0, 0, 0);
+            // tap U of the double chunk (global tap gbase + U): its MFMAs from set U & 1, the next tap's requests into the other set —
+            // weight buffer (U + 1) % 6 (18 is a multiple of 6), halo buffer = parity of the next tap's chunk
+#define AFAN_TAP(U)                                                                                                               \
+            {   /* (no condition anywhere in a tap: a branch makes the compiler copy the accumulators around it and wait for every  \
+                   outstanding request at the join; the last tap's requests read a stale buffer and are never used) */              \
+                __builtin_amdgcn_s_barrier();                                                                                     \
+                _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                                                          \
+                    AFAN_RD(((U) + 1) & 1, ((U) + 1) % 6, ((((U) + 1) % 18) >= 9 ? 1 : 0), tj[((U) + 1) % 9], tv[((U) + 1) % 9], kk) \
+                    __builtin_amdgcn_sched_barrier(0);                                                                            \
+                    AFAN_MF((U) & 1, kk)                                                                                          \
+                    __builtin_amdgcn_sched_barrier(0);                                                                            \
+                }                                                                                                                 \
+            }
+            __builtin_amdgcn_s_barrier();                      // tile 0 and chunk 0's halo are in LDS
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) AFAN_RD(0, 0, 0, tj[0], tv[0], kk)
+            for (int d = 0; d < (chunks >> 1); ++d) {          // whole double chunks: 18 taps, the register sets' parity comes back to 0
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
+                AFAN_TAP(0) AFAN_TAP(1) AFAN_TAP(2) AFAN_TAP(3) AFAN_TAP(4) AFAN_TAP(5) AFAN_TAP(6) AFAN_TAP(7) AFAN_TAP(8)
+                AFAN_TAP(9) AFAN_TAP(10) AFAN_TAP(11) AFAN_TAP(12) AFAN_TAP(13) AFAN_TAP(14) AFAN_TAP(15) AFAN_TAP(16) AFAN_TAP(17)
+            }
+            if (chunks & 1) {                                  // a last single chunk
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(jrow[i]), "+v"(vrow[i]));
+                AFAN_TAP(0) AFAN_TAP(1) AFAN_TAP(2) AFAN_TAP(3) AFAN_TAP(4) AFAN_TAP(5) AFAN_TAP(6) AFAN_TAP(7) AFAN_TAP(8)
+            }
+#undef AFAN_RD
+#undef AFAN_MF
+#undef AFAN_TAP
+        }
+        } else {
         typedef HaloSched<(HL + 31) / 32, B_ROWS> HS;
         if (producer) {
             for (int k = 0; k * 4 < G; ++k) hdma(0, k, 0);     // chunk 0's halo (older than every counted instruction)
@@ -581,6 +684,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                     AFAN_STAMP(0, q * 9 + t, 2);
                 }
             }
+        }
         }
         __syncthreads();
 #ifdef AFAN_CONV_STAMP
@@ -1432,10 +1536,12 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         // tiles — half as many row tiles read the weights, each tile's halo is read by twice as many channel tiles (it is
         // the small operand) — a third less L2 traffic per launch
         static const int n64 = env_int("AFAN_CONV_HALO_N64", 1);
+        static const int ahead = env_int("AFAN_CONV_AHEAD", 1);    // 1: the 64-column halo tiles one tap ahead on six weight buffers (PF = 7); 0: the four-buffer form (A/B)
         if (halo && n64 && spec && bm == 64 && !p.stats && p.Co % 64 == 0 && p.Ci >= 256) {
             const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 127) / 128) * p.n_classes;
             if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 128))
-                return launch<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);
+                return ahead ? launch<128, 64, 7, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
+                             : launch<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);
         }
         // and the 128-row launches of the same kind (the 8x8 stage) as 256-row x 64-channel tiles: 4 images and their borders
         // per tile (400 pixels), 8 KB weight stages
@@ -1446,7 +1552,8 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
             // tile — 768 cycles of the LDS port against 512 of the MFMA pipe; four read 64 KB.  ResNet-18 step 7.98 -> 7.94 ms, same box)
             static const int w41 = env_int("AFAN_CONV_W41", 1);
             if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 256, HALO_PIXELS_256N))
-                return w41 ? launch<256, 64, 5, 4, 1, 4, 2, HALO_PIXELS_256N>(p, st, dgrad) : launch<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N>(p, st, dgrad);
+                return !w41 ? launch<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N>(p, st, dgrad)
+                            : (ahead ? launch<256, 64, 7, 4, 1, 4, 2, HALO_PIXELS_256N>(p, st, dgrad) : launch<256, 64, 5, 4, 1, 4, 2, HALO_PIXELS_256N>(p, st, dgrad));
         }
         if (wgs <= deep_max && spec && halo && halo_ok(p, bm))
             return bm == 64 ? launch<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)

@@ -22,19 +22,22 @@ int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
     const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
     constexpr int deep_max = 384;
+    static const int ahead = env_int("AFAN_CONV_AHEAD", 1);    // (dispatch()'s switch: the same tile family in both forms — same bits)
     if (bm == 128 && wgs > deep_max && wgs <= 2 * deep_max && halo_ok(p, 256, HALO_PIXELS_256))
         return launch_gs<256, 128, 5, 4, 2, 4, 2, HALO_PIXELS_256, false, true>(p, st, dgrad);
     if (bm == 64 && p.Ci >= 256) {
         const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 127) / 128) * p.n_classes;
         if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 128))
-            return launch_gs<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad);
+            return ahead ? launch_gs<128, 64, 7, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad)
+                         : launch_gs<128, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad);
     }
     if (bm == 128 && wgs <= deep_max && p.Ci >= 256) {
         const int64_t wgs_n64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 255) / 256) * p.n_classes;
         static const int w41 = env_int("AFAN_CONV_W41", 1);
         if (wgs_n64 <= deep_max && wgs_n64 >= wgs && halo_ok(p, 256, HALO_PIXELS_256N))
-            return w41 ? launch_gs<256, 64, 5, 4, 1, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad)
-                       : launch_gs<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad);
+            return !w41 ? launch_gs<256, 64, 5, 4, 2, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad)
+                        : (ahead ? launch_gs<256, 64, 7, 4, 1, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad)
+                                 : launch_gs<256, 64, 5, 4, 1, 4, 2, HALO_PIXELS_256N, false, true>(p, st, dgrad));
     }
     if (wgs <= deep_max && halo_ok(p, bm))
         return bm == 64 ? launch_gs<64, 128, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad)
