@@ -539,6 +539,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
             }
         };
         auto bdma = [&](int buf, int wo2, int q) {
+#ifdef AFAN_EXP_NOW
+            return;
+#endif
             uint16_t* Bd = lds + buf * STAGE + swave * 512;
 #pragma unroll
             for (int i = 0; i < B_ROWS; ++i)
@@ -602,8 +605,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvP& pp) {
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                    \
                     fxs[SET][KK][i] = *reinterpret_cast<const bf16x8*>(H_ + (jrow[i] + (TJ)) * BK + ((c2_ ^ (((vrow[i] + (TV)) >> 1) & 7)) * 8)); \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                                    \
-                    fws[SET][KK][j] = *reinterpret_cast<const bf16x8*>(B_ + (wc * TN + j * 32 + frow) * LDR + ((c2_ ^ sw) * 8));  \
+                    fws[SET][KK][j] = AFAN_EXP_W(B_ + (wc * TN + j * 32 + frow) * LDR + ((c2_ ^ sw) * 8), c2_ + j);               \
             }
+#ifdef AFAN_EXP_NOW      /* timing experiment only: the weight operand out of thin air (no DMA, no LDS reads) */
+#define AFAN_EXP_W(PTR, X) __builtin_bit_cast(bf16x8, u32x4{(uint32_t)jrow[0], (uint32_t)(X), 0x3c003c00u, (uint32_t)vrow[0]})
+#else
+#define AFAN_EXP_W(PTR, X) (*reinterpret_cast<const bf16x8*>(PTR))
+#endif
 #define AFAN_MF(SET, KK)                                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                                        \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                    \
