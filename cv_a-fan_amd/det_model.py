@@ -365,7 +365,7 @@ class _StageGraphs:
         # A PRIVATE memory pool per graph: instances are replayed in any order and keep their activations from forward to backward,
         # so a temporary freed inside one capture must never be handed to another graph as something long-lived (a shared pool
         # assumes graphs replay in capture order).
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with ops.no_gc_during_capture(), torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             cur, saved = it.x, []
             for plan in plans:
                 out, a1, a2 = ops.frozen_bottleneck_fwd_plan(cur, plan)
@@ -379,7 +379,7 @@ class _StageGraphs:
         it.g = torch.empty_like(it.out)
         torch.cuda.synchronize(it.out.device)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):       # (runs on the engine's thread; private pool)
+        with ops.no_gc_during_capture(), torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):       # (runs on the engine's thread; private pool)
             cur = _stage_backward(it.plans, it.saved, it.g, it.want_dx)
         it.dx, it.bwd = cur, g
 

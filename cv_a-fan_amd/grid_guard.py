@@ -25,7 +25,7 @@ gives up sets the barrier's error word and goes on with PARTIAL batch totals.  F
   anew for a re-run step.
 
 The reference has no counterpart (its BatchNorm is cuDNN's, one launch per layer: Classification/resnet_s.py:72-77)."""
-import warnings
+import weakref
 
 import torch
 
@@ -169,8 +169,9 @@ class GridGuard:
         self._slots.zero_()
         self._ring = []
         self.lost_steps += len(lost)
-        if self.on_failure is not None:
-            self.on_failure()
+        cb = self.on_failure() if isinstance(self.on_failure, weakref.WeakMethod) else self.on_failure
+        if cb is not None:
+            cb()
         return lost
 
 
@@ -208,7 +209,10 @@ class GuardedTrainer:
     _guard = None
 
     def _guard_init(self, model, device, **kw):
-        self._guard = make(model, device, on_failure=self._drop_graphs, **kw)
+        # (a WEAK reference to the bound method: a strong one would make trainer <-> guard a reference cycle, and a trainer — its
+        # hipGraphs, streams and events — would then only die in a cyclic garbage collection at some later point, possibly in the middle
+        # of another trainer's graph capture, where destroying a graph or a stream aborts the process)
+        self._guard = make(model, device, on_failure=weakref.WeakMethod(self._drop_graphs), **kw)
 
     def _guard_state(self):
         return None

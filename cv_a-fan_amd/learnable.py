@@ -127,7 +127,7 @@ class LearnableTrainer(GuardedTrainer):
         stream.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+        with ops.no_gc_during_capture(), torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
             out = self._body(self._static[0], self._static[1])
         self._graph, self._out, self._key = g, out, key
 

@@ -914,6 +914,25 @@ def grid_barrier_error(device=None):
     return bad
 
 
+class no_gc_during_capture:
+    """Context around a hipGraph capture: Python's CYCLIC garbage collector stays off inside.  A collection in the middle of a capture
+    may free an unrelated, unreachable object that owns a hipGraph, a stream or an event (a dropped trainer caught in a reference
+    cycle, an exception's traceback): destroying those while a capture is in progress aborts the process (seen once in the -m gpu suite
+    of round 6).  Reference-counted frees are unaffected."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+        return False
+
+
 def grid_shared(on):
     """Tell the library that kernels of another stream may run beside the convolution + BatchNorm launches from now on (on) or no
     longer (off): resnet_s.wgrad_stream does.  Returns the previous setting."""

@@ -132,7 +132,7 @@ class SegTrainer(GuardedTrainer):
         self.optimizer._sync_lr()
         if not self._phased():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            with ops.no_gc_during_capture(), torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                 out = self._body(self._static[0], self._static[1])
             self._pieces = [(g, None)]
             return out
@@ -144,7 +144,7 @@ class SegTrainer(GuardedTrainer):
             while not done:
                 n0 = ops.CALLS["conv_bn_fused"]
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
+                with ops.no_gc_during_capture(), torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
                     try:
                         ph = next(gen)
                     except StopIteration:

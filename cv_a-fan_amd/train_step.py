@@ -648,7 +648,7 @@ class AfanTrainer(GuardedTrainer):
             for _ in range(len(self._tail_segments()) + 1):      # one piece per tail segment + the head (nothing follows the last)
                 n0 = ops.CALLS["conv_bn_fused"]
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
+                with ops.no_gc_during_capture(), torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
                     rng = next(gen)
                 fused.append(ops.CALLS["conv_bn_fused"] - n0)
                 pieces.append((g, rng))
@@ -673,7 +673,7 @@ class AfanTrainer(GuardedTrainer):
         self._static_in = (inp.clone(), target.clone())
         self._stream.wait_stream(torch.cuda.current_stream(dev))
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
+        with ops.no_gc_during_capture(), torch.cuda.graph(g, stream=self._stream, capture_error_mode="thread_local"):
             out = self._forward_backward(self._static_in[0], self._static_in[1], overlap_allreduce=False)
             if self.world == 1:
                 self.optimizer.step()

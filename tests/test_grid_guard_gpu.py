@@ -232,3 +232,27 @@ def test_second_consumer_of_a_block_output_is_refused(pkg, gpu, grid_restored):
     assert rel(outs[True][0], outs[False][0]) <= 2e-2, rel(outs[True][0], outs[False][0])     # (bf16 tensors, two summation orders)
     for ga, gb in zip(outs[True][1], outs[False][1]):
         assert rel(ga, gb) <= 2e-2, rel(ga, gb)
+
+
+def test_trainers_die_by_reference_count(pkg, gpu, grid_restored):
+    """A dropped trainer (its hipGraphs, streams, events) must be freed at once, not by a later cyclic garbage collection: one that
+    ran in the middle of another trainer's graph capture aborted the -m gpu suite once this round (grid_guard held a strong reference
+    to the trainer's bound method)."""
+    import gc
+    import weakref
+    gc.collect()
+    gc.disable()
+    try:
+        m = _model(pkg, gpu)
+        tr = pkg.train_step.AfanTrainer(m, nn.CrossEntropyLoss(), steps=1, gamma=0.5, eps=2.0, perturb_idx=6, lr=0.05, use_graph=True,
+                                        graph_warmup=1)
+        x, y = _batches(gpu, 1, batch=64)[0]
+        for _ in range(3):
+            tr.step(x, y)
+        torch.cuda.synchronize()
+        assert tr._graph is not None
+        probe = weakref.ref(tr)
+        del tr
+        assert probe() is None, "the trainer is only reachable through a reference cycle"
+    finally:
+        gc.enable()

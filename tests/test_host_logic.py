@@ -306,3 +306,29 @@ def test_buffer_arena_keeps_the_state_dict_contract(pkg):
     sd2 = {k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
     m.load_state_dict(sd2)                            # in place: the views stay views
     assert bn.running_mean.data_ptr() >= ba.f32.data_ptr() and torch.equal(bn.running_mean, sd2[[k for k in sd2 if k.endswith("running_mean")][0]])
+
+
+def test_trainer_and_guard_form_no_reference_cycle(pkg):
+    """A trainer must die by reference count (its hipGraphs, streams and events with it): grid_guard.GridGuard keeps only a WEAK
+    reference to the trainer's `_drop_graphs` — a strong one made every trainer wait for a cyclic garbage collection, which once ran
+    in the middle of another trainer's graph capture and aborted the process (round 6, the -m gpu suite)."""
+    import gc
+    import weakref
+    gg = pkg.grid_guard
+
+    class T(gg.GuardedTrainer):
+        def _drop_graphs(self):
+            self.dropped = True
+
+    t = T()
+    t._guard = gg.GridGuard.__new__(gg.GridGuard)                # (no device here: only the reference structure matters)
+    t._guard.on_failure = weakref.WeakMethod(t._drop_graphs)
+    probe = weakref.ref(t)
+    gc.disable()
+    try:
+        del t
+        assert probe() is None, "trainer kept alive by a reference cycle"
+    finally:
+        gc.enable()
+    import inspect
+    assert "WeakMethod(self._drop_graphs)" in inspect.getsource(gg.GuardedTrainer._guard_init)
