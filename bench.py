@@ -493,11 +493,18 @@ def main():
     for i in range(args.warmup):
         r = one(i)
     sync()
+    marks = [] if os.environ.get("AFAN_BENCH_STEP_TIMES") == "1" else None      # host time at each step's return (stderr; diagnosis only)
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = one(i)
+        if marks is not None:
+            marks.append(time.perf_counter())
     sync()
     dt = time.perf_counter() - t0
+    if marks and rank == 0:
+        import gc
+        per = [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)]
+        print("step times (ms, host clock at return):", per, " gc counts", gc.get_count(), " gc stats", gc.get_stats(), file=sys.stderr)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

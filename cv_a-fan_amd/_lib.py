@@ -131,6 +131,8 @@ SIGNATURES = {
     "afan_sample_gather": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p]),
     "afan_det_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _f, _p, _p, _p, _p, _p]),
     "afan_sum_scalars_f32": (_i, [_p, _p, _p, _p, _p, _p]),
+    "afan_proposal_rows": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p]),
+    "afan_labels_limit": (_i, [_p, _l, _l, _p, _l, _p]),
     "afan_det_loss_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _p]),
     "afan_roi_align_fwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _i, _i, _f, _i, _p]),
     "afan_roi_align_bwd": (_i, [_p, _p, _p, _i, _i, _l, _l, _l, _l, _l, _i, _i, _f, _i, _p]),

@@ -1472,7 +1472,11 @@ int choose_bm(int64_t M, int co, int n_classes) {
     // the launch back to one workgroup per CU on the four-stage one (measured +3.6 % step rate)
     static const int tall = env_int("AFAN_CONV_TALL", 1);
     const int64_t wg_64 = ((M + 63) / 64) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
-    if (tall && n128 && n_classes == 1 && wg_64 > 384 && wg_64 <= 768) return 128;
+    // (round 6) from 257 on: 257..384 workgroups of 64 rows ran the four-stage form, ONE workgroup per CU (108 KB of LDS), in two rounds —
+    // Faster-RCNN's layer3 256 -> 1024 at 38 x 57 (272 workgroups): 12.3 us for four K-steps, workgroup 0 done after 5.6
+    // (profiles/r06_det_conv_shapes.txt); 128-row tiles are one round.  DeepLab 19.08 -> 18.77 ms with AFAN_CONV_DEEPMAX's new default
+    static const int tall_lo = env_int("AFAN_CONV_TALL_LO", 256);
+    if (tall && n128 && n_classes == 1 && wg_64 > tall_lo && wg_64 <= 768) return 128;
     return 64;
 }
 
@@ -1529,7 +1533,10 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
     static const int deep = env_int("AFAN_CONV_DEEP", 1);     // 0: two LDS stages everywhere
     if (mode == 3 && nw >= 8 && n128 && deep >= 1) {
         const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
-        static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 384);
+        // (round 6: 384 -> 256.  One workgroup per CU: a launch of 257..384 is two rounds of the four-stage form; the two-stage forms hold
+        // two workgroups per CU and finish in one — Faster-RCNN's layer2 128 -> 512 at 75 x 113, 268 workgroups: 14.0 us.  Its convolution
+        // kernel time per iteration 32.9 -> 30.9 ms together with AFAN_CONV_TALL_LO, same box, A/B twice)
+        static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 256);
         static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
         static const int halo = env_int("AFAN_CONV_HALO", 1);   // 0: per-tap operand tiles everywhere (A/B)
         // 385..768 workgroups of 128 rows (ResNet-18's 16x16 stage: two per CU on the two-stage kernel): 256-row tiles

@@ -271,6 +271,35 @@ __global__ void sum_scalars_kernel(const float* a, const float* b, const float* 
 }
 }  // namespace
 
+namespace {
+// rows[j] = j < min(count, P) ? cand[clamp(keep[j])] : 0 — the kept boxes of one image in their padded row block
+__global__ void proposal_rows_kernel(const float4* cand, int64_t n_cand, const int64_t* keep, int64_t n_keep, const int64_t* count,
+                                     int64_t P, float4* rows, int64_t* kept) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t c = count[0];
+    c = c < 0 ? 0 : (c > P ? P : c);
+    if (c > n_keep) c = n_keep;
+    if (j == 0) kept[0] = c;
+    if (j >= P) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < c && n_cand > 0) {
+        int64_t k = keep[j];
+        k = k < 0 ? 0 : (k >= n_cand ? n_cand - 1 : k);
+        v = cand[k];
+    }
+    rows[j] = v;
+}
+
+// labels[b][j] = -1 for j >= max over images of kept[]
+__global__ void labels_limit_kernel(int64_t* labels, int64_t B, int64_t N, const int64_t* kept, int64_t n_kept) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    int64_t lim = kept[0];
+    for (int64_t b = 1; b < n_kept; ++b) lim = kept[b] > lim ? kept[b] : lim;
+    if (i % N >= lim) labels[i] = -1;
+}
+}  // namespace
+
 extern "C" {
 
 // out[n] = clip(apply_transformer(src[n], t[n])): boxes as (left, top, right, bottom) fp32, clipped to [0, right] x [0, bottom]
@@ -397,6 +426,35 @@ int afan_sum_scalars_f32(const float* a, const float* b, const float* c, const f
     hipStream_t st = (hipStream_t)stream;
     AFAN_PROF("det_loss_sum_kernel", 20.0, st);
     sum_scalars_kernel<<<1, 1, 0, st>>>(a, b, c, d, out);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// The proposal layer's hand-over to the ROI head's sampling without a host read (region_proposal_network.py:255-270 ->
+// model.py:256-264): rows [P, 4] = the first min(count[0], P) survivors `cand[keep[j]]` of ONE image (NMS output `keep` over the
+// score-ordered candidates `cand`, `count` on the device), zero rows behind them like the reference's padding of shorter images;
+// kept[0] = that number.  One launch for the reference's index / slice / cat / stack.
+int afan_proposal_rows(const float* cand, int64_t n_cand, const int64_t* keep, int64_t n_keep, const int64_t* count, int64_t P,
+                       float* rows, int64_t* kept, afan_stream_t stream) {
+    if (!rows || !kept || !count || (n_cand > 0 && !cand) || (n_keep > 0 && !keep)) return AFAN_ENULL;
+    if (P < 0 || n_cand < 0 || n_keep < 0) return AFAN_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("det_proposal_rows_kernel", 40.0 * P, st);
+    proposal_rows_kernel<<<(unsigned)((P > 0 ? P : 1) + TB - 1) / TB, TB, 0, st>>>((const float4*)cand, n_cand, keep, n_keep, count, P,
+                                                                                  (float4*)rows, kept);
+    AFAN_LAUNCH_CHECK();
+    return AFAN_OK;
+}
+
+// labels [B, N] int64: every column at and beyond max(kept[0..n_kept)) becomes -1 ("no candidate": neither list of the sampling
+// takes it) — the padded rows beyond the batch's longest survivor list, which the reference never builds
+int afan_labels_limit(int64_t* labels, int64_t B, int64_t N, const int64_t* kept, int64_t n_kept, afan_stream_t stream) {
+    if (!labels || !kept) return AFAN_ENULL;
+    if (B < 0 || N < 0 || n_kept < 1) return AFAN_ESHAPE;
+    if (B * N == 0) return AFAN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    AFAN_PROF("det_labels_limit_kernel", 8.0 * B * N, st);
+    labels_limit_kernel<<<(unsigned)((B * N + TB - 1) / TB), TB, 0, st>>>(labels, B, N, kept, n_kept);
     AFAN_LAUNCH_CHECK();
     return AFAN_OK;
 }

@@ -24,7 +24,8 @@ import torch.nn.functional as F
 
 from . import ops
 from .deeplab import MaxPool2d, StemConv, _MaxPoolFn, _enter
-from .det_ops import box_assign, box_decode_clip, fg_bg_draw, fg_bg_sample, nms, per_image_losses, roi_align, sample_lists
+from .det_ops import (box_assign, box_decode_clip, fg_bg_draw, fg_bg_sample, labels_limit_, nms, per_image_losses, proposal_rows,
+                      roi_align, sample_lists)
 from .resnet_s import (Conv2d, NormalizeByChannelMeanStd, _accumulates_in_place, _ConvFn, _dense, _Flags, _like_layout, _linear, dgrad_only,
                        _own_conv_ok, _to_compute, _WgradStream)
 
@@ -663,8 +664,8 @@ class RegionProposalNetwork(nn.Module):
         (the anchor sampling's three; the proposal layer draws nothing).  Returns (objectnesses, transformers, ce, sl1, proposals, roi_t)
         with roi_t = None unless roi_targets is given.
         roi_targets (round 5): the ROI head's own sampling (model.py:256-282) needs the proposals' labels' list lengths — a second host
-        read right behind this one.  Given `roi_targets(padded [B, top_n, 4], limit)` -> a pending object with `.counts` (device, [2])
-        and `.finish(nf, nb)`, the label / list launches of THAT sampling are queued on the padded proposals (rows at and beyond the
+        read right behind this one.  Given `roi_targets(padded [B, top_n, 4], kept [B] on the device)` -> a pending object with
+        `.counts` (device, [2]) and `.finish(nf, nb)`, the label / list launches of THAT sampling are queued on the padded proposals (rows at and beyond the
         longest image's survivor count labelled -1, shorter images zero-padded like the reference's stack) before the one read, and its
         three draws follow the anchor sampling's on the host generator, as in the reference: a sixth return value, 16 host reads per
         iteration fewer."""
@@ -681,15 +682,8 @@ class RegionProposalNetwork(nn.Module):
             cand.append(sb)
         roi_pend, nb_img = None, len(keeps)
         if roi_targets is not None:
-            P, dev = self._post_nms_top_n, boxes.device
-            ar = torch.arange(P, device=dev)
-            cnt = torch.stack([c.reshape(()) for _, c in keeps]).clamp(max=P)         # survivors per image (the scan may report up to 63 more)
-            rows = []
-            for i, (sb, (k, _)) in enumerate(zip(cand, keeps)):
-                kk = k[:P] if k.numel() >= P else torch.cat([k, k.new_zeros(P - k.numel())])
-                ok = ar < cnt[i]
-                rows.append(sb[torch.where(ok, kk, torch.zeros_like(kk)).clamp_(0, max(sb.shape[0] - 1, 0))] * ok[:, None])
-            roi_pend = roi_targets(torch.stack(rows), cnt.max())
+            padded, kept_n = proposal_rows(cand, keeps, self._post_nms_top_n)     # (the scan may report up to 63 survivors more: clamped there)
+            roi_pend = roi_targets(padded, kept_n)
         counts = torch.cat([pend[0][2]] + [c for _, c in keeps] + ([roi_pend.counts] if roi_pend is not None else [])).tolist()   # the one read
         ce, sl1 = self._losses_finish(pend, counts[0], counts[1])
         kept = [sb[k[:n]][:self._post_nms_top_n] for sb, (k, _), n in zip(cand, keeps, counts[2:2 + nb_img])]
@@ -968,10 +962,11 @@ class Model(nn.Module):
             return boxes, lab, deltas, bi
 
         def _targets_pending(self, padded, limit, gt_classes_batch, gt_bboxes_batch):
-            """The label / list launches of `_targets` on the PADDED proposals [B, top_n, 4] (rows >= limit = the longest image's survivor
-            count are no candidates: label -1), nothing read: the caller's one host read brings `.counts`, `.finish(nf, nb)` draws."""
+            """The label / list launches of `_targets` on the PADDED proposals [B, top_n, 4] (rows >= max(limit) = the longest image's
+            survivor count — limit [B] int64 on the device — are no candidates: label -1), nothing read: the caller's one host read
+            brings `.counts`, `.finish(nf, nb)` draws."""
             labels, assign = box_assign(padded, gt_bboxes_batch, "proposal", 0.5, gt_classes=gt_classes_batch)
-            labels.masked_fill_((torch.arange(padded.shape[1], device=padded.device) >= limit)[None, :], -1)
+            labels_limit_(labels, limit)
             return _RoiPending(sample_lists(labels), labels, assign, padded, gt_bboxes_batch)
 
         def forward(self, features, proposal_bboxes=None, gt_classes_batch=None, gt_bboxes_batch=None, return_type="clean", targets=None):

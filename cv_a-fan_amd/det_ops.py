@@ -126,6 +126,32 @@ def box_assign(boxes, gt_bboxes, mode, lo, hi=0.0, gt_classes=None):
     return labels, assign
 
 
+def proposal_rows(cands, keeps, top_n):
+    """(padded [B, top_n, 4] fp32, kept [B] int64) from each image's score-ordered candidates `cands[b]` [n, 4] and its padded NMS
+    result `keeps[b]` = (keep [n] int64, count [1] int64, both on the device): the first min(count, top_n) survivors, zero rows
+    behind them (region_proposal_network.py:255-270 with the count never read) — one launch per image."""
+    lib, dev = _lib.load(), cands[0].device
+    B = len(cands)
+    padded = torch.empty((B, top_n, 4), dtype=torch.float32, device=dev)
+    kept = torch.empty(B, dtype=torch.int64, device=dev)
+    for b, (sb, (k, c)) in enumerate(zip(cands, keeps)):
+        sb = _f32c(sb, "proposal_rows")
+        if k.dtype != torch.int64 or c.dtype != torch.int64 or not k.is_contiguous():
+            raise ValueError("proposal_rows: keep / count are contiguous int64 tensors")
+        check(lib.afan_proposal_rows(_ptr(sb), sb.shape[0], _ptr(k), k.numel(), _ptr(c), top_n, _ptr(padded[b]), _ptr(kept[b:b + 1]),
+                                     _stream(dev)), "afan_proposal_rows")
+    return padded, kept
+
+
+def labels_limit_(labels, kept):
+    """labels [B, N] int64 in place: columns >= max(kept) become -1 (kept [B] int64 on the device, never read)."""
+    if labels.dtype != torch.int64 or kept.dtype != torch.int64 or not labels.is_contiguous() or labels.dim() != 2:
+        raise ValueError("labels_limit_: labels [B, N] int64 contiguous, kept int64")
+    check(_lib.load().afan_labels_limit(_ptr(labels), labels.shape[0], labels.shape[1], _ptr(kept), kept.numel(), _stream(labels.device)),
+          "afan_labels_limit")
+    return labels
+
+
 def sample_lists(labels):
     """The `nonzero()` lists of labels > 0 / == 0 in one launch, nothing read: (fg [M], bg [M], counts [2]) on the device."""
     lib = _lib.load()

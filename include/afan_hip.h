@@ -643,6 +643,14 @@ int afan_det_loss_fwd(const float* logits, const float* deltas, const int64_t* r
 /* out[0] = ((a[0] + b[0]) + c[0]) + d[0] (c, d optional): `loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()`
  * (Detection/train_aug_sat_muti_advt.py:21-27, Detection/attack_algo.py:62) for per-image loss vectors of one image. */
 int afan_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, afan_stream_t stream);
+/* afan_proposal_rows — `sorted_bboxes[kept_indices][:post_nms_top_n]` and the zero padding of shorter images
+ * (Detection/rpn/region_proposal_network.py:255-270) for ONE image with the survivor count still on the device: rows [P,4] =
+ * cand[keep[j]] for j < min(count[0], P, n_keep), zero rows behind; kept[0] = that number.
+ * afan_labels_limit — labels [B,N]: columns >= max(kept[0..n_kept)) become -1, so that the ROI head's sampling
+ * (Detection/model.py:256-282) on the padded rows sees exactly the reference's candidates. */
+int afan_proposal_rows(const float* cand, int64_t n_cand, const int64_t* keep, int64_t n_keep, const int64_t* count, int64_t P,
+                       float* rows, int64_t* kept, afan_stream_t stream);
+int afan_labels_limit(int64_t* labels, int64_t B, int64_t N, const int64_t* kept, int64_t n_kept, afan_stream_t stream);
 int afan_det_loss_bwd(const float* g_ce, const float* g_sl1, const float* save, const int64_t* rows, const int64_t* gt_labels,
                       const int64_t* batch, int64_t S, int64_t B, int64_t C, int64_t K, int64_t R, float* d_logits, float* d_deltas,
                       afan_stream_t stream);

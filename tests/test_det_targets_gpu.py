@@ -125,6 +125,29 @@ def test_per_image_losses_of_an_image_without_samples_is_nan(pkg, gpu):
     assert torch.isnan(ce[1]) and sl1[1].item() == 0.0 and torch.isfinite(ce[[0, 2]]).all()
 
 
+@pytest.mark.parametrize("ns,counts,P", [((5000,), (1300,), 2000), ((5000, 4000), (2063, 17), 2000), ((90, 300), (90, 0), 128), ((0, 40), (0, 40), 64)])
+def test_padded_proposals_equal_the_reference_stack(pkg, gpu, ns, counts, P):
+    """region_proposal_network.py:255-270 with the counts on the device: the kept rows, the zero padding, and the -1 labels beyond the
+    longest image."""
+    g = torch.Generator().manual_seed(sum(ns) + P)
+    cands, keeps, want_rows = [], [], []
+    for n, c in zip(ns, counts):
+        sb = _boxes(g, n).to(gpu) if n else torch.zeros(0, 4, device=gpu)
+        k = torch.sort(torch.randperm(n, generator=g)[:c])[0] if n else torch.zeros(0, dtype=torch.int64)
+        keep = torch.cat([k, torch.full((n - c,), 7 if n else 0, dtype=torch.int64)]).to(gpu)        # (entries behind the count are junk)
+        cands.append(sb)
+        keeps.append((keep, torch.tensor([c], device=gpu)))
+        want_rows.append(sb[k.to(gpu)][:P])
+    padded, kept = pkg.det_ops.proposal_rows(cands, keeps, P)
+    assert kept.tolist() == [min(c, P) for c in counts]
+    longest = max(len(r) for r in want_rows)
+    want = torch.stack([torch.cat([r, torch.zeros(longest - len(r), 4).to(r)]) for r in want_rows])      # :259-270
+    assert torch.equal(padded[:, :longest], want) and not padded[:, longest:].any()
+    labels = torch.randint(0, 3, (len(ns), P), generator=g).to(gpu)
+    got = pkg.det_ops.labels_limit_(labels.clone(), kept)
+    assert torch.equal(got[:, :longest], labels[:, :longest]) and (got[:, longest:] == -1).all()
+
+
 def test_targets_need_the_gpu(pkg):
     with pytest.raises(pkg.AfanLibraryError):
         pkg.det_ops.box_decode_clip(torch.zeros(3, 4), torch.zeros(3, 4), 10, 10)
