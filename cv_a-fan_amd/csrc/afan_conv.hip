@@ -1539,6 +1539,24 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         static const int deep_max = env_int("AFAN_CONV_DEEPMAX", 256);
         static const int spec = env_int("AFAN_CONV_SPEC", 1);   // 1: four producer waves + four 64x64 (32x64) MFMA waves
         static const int halo = env_int("AFAN_CONV_HALO", 1);   // 0: per-tap operand tiles everywhere (A/B)
+        // (round 6) launches that leave half the chip idle — Faster-RCNN's layer3 at one 600 x 904 image: 2 166 rows, 1024 -> 256 on 68
+        // workgroups of 64 x 128, 256 -> 256 3x3 on 68 of 128 x 64 — run at ONE CU's LDS-DMA intake per workgroup (24.6 KB per
+        // 64-channel step of a 64 x 128 tile: ~770 cycles of the ~850 measured per step, profiles/r06_det_conv_shapes.txt) while
+        // three CUs in four do nothing: 64 x 64 tiles are twice the workgroups at 16 KB per step, the same K order (same bits)
+        static const int t64 = env_int("AFAN_CONV_T64", 1);
+        // (not with BatchNorm sums: the in-launch-BatchNorm forms choose their own tiles, and a launch pair must add a column's rows in the
+        // order of the fused launch it stands in for)
+        if (t64 && spec && !p.stats && !p.acc && p.n_classes == 1 && p.Co % 64 == 0 && p.Ci >= 128) {
+            const int64_t w64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 63) / 64);
+            if (w64 <= 256 && w64 >= 16)
+            {
+                static const int ahead64 = env_int("AFAN_CONV_AHEAD64", 1);
+                if (halo && halo_ok(p, 64))
+                    return ahead64 ? launch<64, 64, 7, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad)
+                                   : launch<64, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS>(p, st, dgrad);
+                return launch<64, 64, 5, 2, 2, 4>(p, st, dgrad);
+            }
+        }
         // 385..768 workgroups of 128 rows (ResNet-18's 16x16 stage: two per CU on the two-stage kernel): 256-row tiles
         // bring the launch to one workgroup per CU on the halo form — eight MFMA waves + four producers, a whole 16x16
         // image and its border per tile (the partial-slab statistics' slot count is tied to choose_bm(): not with those)
