@@ -131,6 +131,10 @@ SIGNATURES = {
     "afan_sample_gather": (_i, [_p, _p, _p, _l, _p, _p, _p, _p, _l, _l, _p, _p, _p, _p, _p, _p]),
     "afan_det_loss_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _f, _p, _p, _p, _p, _p]),
     "afan_sum_scalars_f32": (_i, [_p, _p, _p, _p, _p, _p]),
+    "afan_linear_pair_workspace_floats": (_l, [_i, _l, _l, _l, _l]),
+    "afan_linear_pair_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _p, _p]),
+    "afan_linear_pair_dgrad_f32": (_i, [_p, _p, _p, _p, _p, _l, _l, _l, _l, _p]),
+    "afan_linear_pair_wgrad_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _l, _l, _l, _l, _p, _p]),
     "afan_proposal_rows": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p]),
     "afan_labels_limit": (_i, [_p, _l, _l, _p, _l, _p]),
     "afan_det_loss_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _l, _l, _l, _p, _p, _p]),

@@ -596,6 +596,60 @@ class ResNet101(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------ RPN
+LINEAR_PAIR = os.environ.get("AFAN_DET_LINEAR_PAIR", "1") != "0"      # 0: each head layer on the general fp32 kernels (A/B, tests)
+
+
+class _LinearPairFn(torch.autograd.Function):
+    """(x w1^T + b1, x w2^T + b2) for the two heads that share an input — the ROI head's class / box Linear layers (model.py:255-256)
+    and the RPN's objectness / box 1x1 convolutions (region_proposal_network.py:53-54, weights [N, K, 1, 1]) — on afan_linear.hip: one
+    launch forward (two for the ROI head's 128 rows: split reduction), ONE input gradient for both layers (their sum is its reduction),
+    both layers' parameter gradients in one launch pair; fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, want_pgrad):
+        ctx.save_for_backward(x, w1, w2)
+        ctx.pg, ctx.params = want_pgrad, (w1, b1, w2, b2)
+        return ops.linear_pair_fwd(x, w1.detach().reshape(w1.shape[0], -1), None if b1 is None else b1.detach(),
+                                   w2.detach().reshape(w2.shape[0], -1), None if b2 is None else b2.detach())
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, w2 = ctx.saved_tensors
+        p1, b1, p2, b2 = ctx.params
+        n1, n2 = w1.shape[0], w2.shape[0]
+        g1 = torch.zeros((x.shape[0], n1), dtype=torch.float32, device=x.device) if g1 is None else g1.contiguous().float()
+        g2 = torch.zeros((x.shape[0], n2), dtype=torch.float32, device=x.device) if g2 is None else g2.contiguous().float()
+        gx = ops.linear_pair_dgrad(g1, g2, w1.detach().reshape(n1, -1), w2.detach().reshape(n2, -1)) if ctx.needs_input_grad[0] else None
+        gw1 = gb1 = gw2 = gb2 = None
+        if ctx.pg and (ctx.needs_input_grad[1] or ctx.needs_input_grad[3]):
+            if all(q is None or _accumulates_in_place(q) for q in (p1, b1, p2, b2)):
+                ops.linear_pair_wgrad(g1, g2, x, p1.grad, None if b1 is None else b1.grad, p2.grad, None if b2 is None else b2.grad, True)
+            else:
+                gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+                gb1 = None if b1 is None else torch.empty_like(b1)
+                gb2 = None if b2 is None else torch.empty_like(b2)
+                ops.linear_pair_wgrad(g1, g2, x, gw1, gb1, gw2, gb2, False)
+        return gx, gw1, gb1, gw2, gb2, None
+
+
+def _linear_pair(x, lin1, lin2):
+    """The two layers' outputs on afan_linear.hip, or None (the caller takes the general kernels)."""
+    w1, w2 = lin1.weight, lin2.weight
+    if not (x.is_cuda and x.dim() == 2 and (w1.dim() == 2 or w1.shape[2] * w1.shape[3] == 1) and (w2.dim() == 2 or w2.shape[2] * w2.shape[3] == 1)):
+        return None
+    if not (_dense_rows(w1) and _dense_rows(w2) and ops.linear_pair_ok(x, w1.detach().reshape(w1.shape[0], -1), w2.detach().reshape(w2.shape[0], -1))):
+        return None
+    for b in (lin1.bias, lin2.bias):
+        if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+            return None
+    return _LinearPairFn.apply(x, w1, lin1.bias, w2, lin2.bias, _Flags.param_grads)
+
+
+def _dense_rows(w):
+    """[N, K] or [N, K, 1, 1] whose rows are K consecutive elements (either memory format of a 1x1 kernel)."""
+    return w.stride(0) == w.shape[1] and w.stride(1) == 1 and w.reshape(w.shape[0], -1).data_ptr() == w.data_ptr()
+
+
 class RegionProposalNetwork(nn.Module):
     """rpn/region_proposal_network.py:13-271."""
 
@@ -621,6 +675,10 @@ class RegionProposalNetwork(nn.Module):
         """The two 1x1 heads in fp32 (18 / 36 output channels: the general kernel, bias in its epilogue)."""
         b = trunk.shape[0]
         x = trunk if trunk.dtype == torch.float32 else trunk.float()
+        if LINEAR_PAIR and (ops.layout_of(x) == ops.AFAN_NHWC or x.shape[2] * x.shape[3] == 1):      # channels-last: the map IS [pixels, 512]
+            ys = _linear_pair(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), self._anchor_objectness, self._anchor_transformer)
+            if ys is not None:
+                return [ys[0].view(b, -1, 2), ys[1].view(b, -1, 4)]
         outs = []
         for conv, k in ((self._anchor_objectness, 2), (self._anchor_transformer, 4)):
             y = _ConvFn.apply(x, conv.weight, conv.weight.detach(), None, conv.stride, conv.padding, _Flags.param_grads, None,
@@ -952,6 +1010,9 @@ class Model(nn.Module):
 
         def _linears(self, hidden):
             x = hidden.view(hidden.shape[0], -1).float()
+            ys = _linear_pair(x.contiguous(), self._proposal_class, self._proposal_transformer) if LINEAR_PAIR else None
+            if ys is not None:
+                return ys
             return _linear(x, self._proposal_class), _linear(x, self._proposal_transformer)
 
         def _targets(self, proposal_bboxes, gt_classes_batch, gt_bboxes_batch):

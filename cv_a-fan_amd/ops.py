@@ -78,6 +78,50 @@ def _workspace(ref, nfloats, tag):
     return ws
 
 
+# ---- two small linear layers on one input (afan_linear.hip): the Faster-RCNN heads
+def linear_pair_ok(x, w1, w2):
+    """x [M, K] fp32 row-major on the GPU, weights [N1, K] / [N2, K] fp32 contiguous, K % 4 == 0, N1 + N2 <= 128."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and w1.dtype == torch.float32 and w2.dtype == torch.float32
+            and w1.dim() == 2 and w2.dim() == 2 and w1.is_contiguous() and w2.is_contiguous() and w1.shape[1] == x.shape[1] == w2.shape[1]
+            and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and w1.shape[0] + w2.shape[0] <= 128 and x.data_ptr() % 16 == 0
+            and w1.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0)
+
+
+def linear_pair_fwd(x, w1, b1, w2, b2):
+    """(x w1^T + b1, x w2^T + b2), fp32, one launch (two when the reduction is split: few rows)."""
+    lib = _lib.load()
+    M, K = x.shape
+    n1, n2 = w1.shape[0], w2.shape[0]
+    y1 = torch.empty((M, n1), dtype=torch.float32, device=x.device)
+    y2 = torch.empty((M, n2), dtype=torch.float32, device=x.device)
+    nws = lib.afan_linear_pair_workspace_floats(0, M, n1, n2, K)
+    if nws < 0:
+        raise ValueError("linear_pair_fwd: shape outside the kernel's range")
+    ws = _workspace(x, nws, "linear_pair") if nws else None
+    check(lib.afan_linear_pair_fwd_f32(_ptr(x), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(y1), _ptr(y2), M, n1, n2, K, _ptr(ws), _stream(x)),
+          "afan_linear_pair_fwd_f32")
+    return y1, y2
+
+
+def linear_pair_dgrad(g1, g2, w1, w2):
+    """g1 w1 + g2 w2 [M, K], fp32, one launch."""
+    M, K = g1.shape[0], w1.shape[1]
+    gx = torch.empty((M, K), dtype=torch.float32, device=g1.device)
+    check(_lib.load().afan_linear_pair_dgrad_f32(_ptr(g1), _ptr(g2), _ptr(w1), _ptr(w2), _ptr(gx), M, w1.shape[0], w2.shape[0], K, _stream(g1)),
+          "afan_linear_pair_dgrad_f32")
+    return gx
+
+
+def linear_pair_wgrad(g1, g2, x, gw1, gb1, gw2, gb2, accumulate):
+    """gw1 (+)= g1^T x, gb1 (+)= g1's column sums, the same for layer 2 (biases optional), fp32, two launches."""
+    lib = _lib.load()
+    M, K = x.shape
+    n1, n2 = g1.shape[1], g2.shape[1]
+    ws = _workspace(x, lib.afan_linear_pair_workspace_floats(1, M, n1, n2, K), "linear_pair")
+    check(lib.afan_linear_pair_wgrad_f32(_ptr(g1), _ptr(g2), _ptr(x), _ptr(gw1), _ptr(gb1), _ptr(gw2), _ptr(gb2), int(bool(accumulate)), M, n1, n2, K,
+                                         _ptr(ws), _stream(x)), "afan_linear_pair_wgrad_f32")
+
+
 # BatchNorm sums in f64 accumulators (no partial slabs, no finalize launches) where the channel count allows it;
 # AFAN_BN_ACC=0 selects the partial-slab path everywhere (bitwise run-to-run reproducible, ~0.45 more launches per BN).
 BN_ACC = os.environ.get("AFAN_BN_ACC", "1") != "0"

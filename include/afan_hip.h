@@ -643,6 +643,21 @@ int afan_det_loss_fwd(const float* logits, const float* deltas, const int64_t* r
 /* out[0] = ((a[0] + b[0]) + c[0]) + d[0] (c, d optional): `loss1.mean() + loss2.mean() + loss3.mean() + loss4.mean()`
  * (Detection/train_aug_sat_muti_advt.py:21-27, Detection/attack_algo.py:62) for per-image loss vectors of one image. */
 int afan_sum_scalars_f32(const float* a, const float* b, const float* c, const float* d, float* out, afan_stream_t stream);
+/* afan_linear_pair_* — two small `nn.Linear` / 1x1 `nn.Conv2d` layers on ONE input, fp32, N1 + N2 <= 128 output features: the ROI head's
+ * `_proposal_class` | `_proposal_transformer` (Detection/model.py:235-236 <- :255-256, :290-291, :343-344) and the RPN's `_anchor_objectness` |
+ * `_anchor_transformer` (Detection/rpn/region_proposal_network.py:35-36 <- :53-54, :120-121; x = the channels-last trunk read as [pixels, 512]).
+ * x [M,K], w1 [N1,K], w2 [N2,K] row-major, K % 4 == 0; n2 == 0: one layer.  Deterministic (partials added in order, no float atomics).
+ *   fwd:   y1 [M,N1] = x w1^T + b1, y2 [M,N2] = x w2^T + b2 (biases optional)
+ *   dgrad: gx [M,K] = g1 w1 + g2 w2
+ *   wgrad: gw1 [N1,K] (+)= g1^T x, gb1 [N1] (+)= column sums of g1 (optional), the same for layer 2; accumulate != 0 adds into the outputs
+ * ws: afan_linear_pair_workspace_floats(op, ...) floats (op 0 forward — 0 when none is needed —, 1 parameter gradients), 16-byte aligned. */
+int64_t afan_linear_pair_workspace_floats(int op, int64_t M, int64_t n1, int64_t n2, int64_t K);
+int afan_linear_pair_fwd_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, float* y2, int64_t M,
+                             int64_t n1, int64_t n2, int64_t K, float* ws, afan_stream_t stream);
+int afan_linear_pair_dgrad_f32(const float* g1, const float* g2, const float* w1, const float* w2, float* gx, int64_t M, int64_t n1, int64_t n2,
+                               int64_t K, afan_stream_t stream);
+int afan_linear_pair_wgrad_f32(const float* g1, const float* g2, const float* x, float* gw1, float* gb1, float* gw2, float* gb2, int accumulate,
+                               int64_t M, int64_t n1, int64_t n2, int64_t K, float* ws, afan_stream_t stream);
 /* afan_proposal_rows — `sorted_bboxes[kept_indices][:post_nms_top_n]` and the zero padding of shorter images
  * (Detection/rpn/region_proposal_network.py:255-270) for ONE image with the survivor count still on the device: rows [P,4] =
  * cand[keep[j]] for j < min(count[0], P, n_keep), zero rows behind; kept[0] = that number.
