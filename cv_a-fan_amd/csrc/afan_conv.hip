@@ -1544,9 +1544,9 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
         // 64-channel step of a 64 x 128 tile: ~770 cycles of the ~850 measured per step, profiles/r06_det_conv_shapes.txt) while
         // three CUs in four do nothing: 64 x 64 tiles are twice the workgroups at 16 KB per step, the same K order (same bits)
         static const int t64 = env_int("AFAN_CONV_T64", 1);
-        // (not with BatchNorm sums: the in-launch-BatchNorm forms choose their own tiles, and a launch pair must add a column's rows in the
-        // order of the fused launch it stands in for)
-        if (t64 && spec && !p.stats && !p.acc && p.n_classes == 1 && p.Co % 64 == 0 && p.Ci >= 128) {
+        // (with BatchNorm sums too: dispatch_bnf() has the same rule — a launch pair must add a column's rows in the order of the fused
+        // launch it stands in for; DeepLab's layer3 at two 513 x 513 images: 1024 -> 256 on 70, 256 -> 256 3x3 on 72 workgroups)
+        if (t64 && spec && !p.stats && p.n_classes == 1 && p.Co % 64 == 0 && p.Ci >= 128) {
             const int64_t w64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 63) / 64);
             if (w64 <= 256 && w64 >= 16)
             {

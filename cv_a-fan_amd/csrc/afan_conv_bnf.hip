@@ -23,6 +23,18 @@ int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
     constexpr int deep_max = 384;
     static const int ahead = env_int("AFAN_CONV_AHEAD", 1);    // (dispatch()'s switch: the same tile family in both forms — same bits)
+    // (round 6) dispatch()'s 64 x 64 tiles for launches that would leave half the chip idle
+    static const int t64 = env_int("AFAN_CONV_T64", 1);
+    if (t64 && p.n_classes == 1 && p.Ci >= 128) {
+        const int64_t w64 = (int64_t)(p.Co / 64) * ((max_rows(p) + 63) / 64);
+        if (w64 <= 256 && w64 >= 16) {
+            static const int ahead64 = env_int("AFAN_CONV_AHEAD64", 1);
+            if (halo_ok(p, 64))
+                return ahead64 ? launch_gs<64, 64, 7, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad)
+                               : launch_gs<64, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, HALO_PIXELS, false, true>(p, st, dgrad);
+            return launch_gs<64, 64, 5, 2, 2, 4, AFAN_CONV_FRAG_BATCH, 0, false, true>(p, st, dgrad);
+        }
+    }
     if (bm == 128 && wgs > deep_max && wgs <= 2 * deep_max && halo_ok(p, 256, HALO_PIXELS_256))
         return launch_gs<256, 128, 5, 4, 2, 4, 2, HALO_PIXELS_256, false, true>(p, st, dgrad);
     if (bm == 64 && p.Ci >= 256) {

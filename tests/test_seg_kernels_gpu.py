@@ -407,8 +407,11 @@ def test_aspp_multi_launch_equals_per_branch_path(pkg, gpu):
     assert torch.equal(a[0], b[0])
     # the input gradient: three dgrads chained through the epilogue addend vs summed by autograd — bf16 rounding of partial sums
     assert float((a[1] - b[1]).norm() / b[1].norm()) < 6e-3
+    # parameter gradients: the per-branch launches may take other tiles than the multi-problem launch (ops: 64 x 64 for launches that
+    # leave half the chip idle), so the BatchNorm backward's column sums are added in another order and single bf16 gradients
+    # round the other way: relative to each tensor's norm
     for k in b[2]:
-        torch.testing.assert_close(a[2][k], b[2][k], rtol=1e-4, atol=1e-6, msg=k)
+        assert float((a[2][k] - b[2][k]).norm() / (b[2][k].norm() + 1e-12)) < 2e-3, k
     for k in b[3]:
         torch.testing.assert_close(a[3][k].float(), b[3][k].float(), rtol=1e-5, atol=1e-6, msg=k)
 
