@@ -1463,7 +1463,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 // tile choice: fill >= ~256 workgroups when the problem allows it
-int choose_bm(int64_t M, int co, int n_classes) {
+int choose_bm(int64_t M, int co, int n_classes, bool equal_classes = false) {
     const bool n128 = (co % 128 == 0);
     const int64_t wg_128 = ((M + 127) / 128) * ((co + (n128 ? 127 : 63)) / (n128 ? 128 : 64)) * n_classes;
     static const int thr = env_int("AFAN_CONV_THR128", 256);   // (256 vs 384: +0.3 % of the step)
@@ -1476,7 +1476,10 @@ int choose_bm(int64_t M, int co, int n_classes) {
     // Faster-RCNN's layer3 256 -> 1024 at 38 x 57 (272 workgroups): 12.3 us for four K-steps, workgroup 0 done after 5.6
     // (profiles/r06_det_conv_shapes.txt); 128-row tiles are one round.  DeepLab 19.08 -> 18.77 ms with AFAN_CONV_DEEPMAX's new default
     static const int tall_lo = env_int("AFAN_CONV_TALL_LO", 256);
-    if (tall && n128 && n_classes == 1 && wg_64 > tall_lo && wg_64 <= 768) return 128;
+    // (equal_classes: independent problems of ONE size in the grid's z — ASPP's three atrous branches; at four 513 x 513 images they
+    // are 414 workgroups of 64 rows on the two-stage form, 468 us; 210 of 128 rows on the four-stage form)
+    static const int tall_multi = env_int("AFAN_CONV_TALL_MULTI", 1);
+    if (tall && n128 && (n_classes == 1 || (equal_classes && tall_multi)) && wg_64 > tall_lo && wg_64 <= 768) return 128;
     return 64;
 }
 
@@ -1522,7 +1525,7 @@ int dispatch(const ConvP& p, hipStream_t st, bool dgrad) {
     static const int mode = env_int("AFAN_CONV_MODE", 3);
     static const int force_bm = env_int("AFAN_CONV_BM", 0);   // tuning knobs (tools/conv_bench.py A/B)
     static const int nw = env_int("AFAN_CONV_NW", 8);          // waves per workgroup where the tile allows it
-    const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes);
+    const int bm = force_bm ? force_bm : choose_bm(max_rows(p), p.Co, p.n_classes, p.multi != 0);
     const bool n128 = p.Co % 128 == 0;
     // launches of about one workgroup per CU (8x8 / 4x4 stages): deep DMA pipeline (3 or 4 LDS stages, counted vmcnt)
     // In the training step every layer's weights are cold (44 MB of bf16 weights cycle through a 32 MB L2 between two

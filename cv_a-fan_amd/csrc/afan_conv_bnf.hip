@@ -19,7 +19,7 @@ int g_bnf_one_per_cu = 0;
 int dispatch_bnf(const ConvP& p, hipStream_t st, bool dgrad) {
     static const int halo = env_int("AFAN_CONV_HALO", 1);
     if (!halo || p.Co % 128 != 0 || p.stats || !p.acc || p.groups != 1) return AFAN_ESHAPE;
-    const int bm = choose_bm(max_rows(p), p.Co, p.n_classes);
+    const int bm = choose_bm(max_rows(p), p.Co, p.n_classes, p.multi != 0);
     const int64_t wgs = (int64_t)(p.Co / 128) * ((max_rows(p) + bm - 1) / bm) * p.n_classes;
     constexpr int deep_max = 384;
     static const int ahead = env_int("AFAN_CONV_AHEAD", 1);    // (dispatch()'s switch: the same tile family in both forms — same bits)
