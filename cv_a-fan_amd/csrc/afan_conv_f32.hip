@@ -483,7 +483,15 @@ __global__ __launch_bounds__(256) void wgrad_f32_reduce_kernel(const float* __re
     const int64_t total = co * ncols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int z = 0; z < slices; ++z) s += slab[(int64_t)z * total + i];
+        int z = 0;
+        for (; z + 8 <= slices; z += 8) {                 // eight requests in flight, added in slice order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(z + u) * total + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < slices; ++z) s += slab[(int64_t)z * total + i];
         const int64_t r = i / ncols, n = i - r * ncols;
         const int64_t t = n / ci, c = n - t * ci;
         float* g = grad + r * g_sRow + t * g_sTap + c * g_sC;

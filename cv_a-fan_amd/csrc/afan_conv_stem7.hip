@@ -108,7 +108,15 @@ __global__ __launch_bounds__(BLOCK) void stem7_wgrad_reduce_kernel(const float* 
     const int i = blockIdx.x * BLOCK + threadIdx.x;      // index into [k][ch]
     if (i >= K * CO) return;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += slab[(int64_t)g * K * CO + i];
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {                          // eight requests in flight, added in slice order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(g + u) * K * CO + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; g < G; ++g) s += slab[(int64_t)g * K * CO + i];
     const int k = i >> 6, ch = i & 63;
     float* dst = grad + ch * K + k;                      // KRSC: [ch][r][s][c]
     *dst = accumulate ? *dst + s : s;

@@ -267,6 +267,23 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradP p) {
                             gridDim.x * gridDim.y * gridDim.z);
 }
 
+// 0 + p[0] + p[stride] + ... + p[(S - 1) * stride], added in THAT order, eight requests in flight: written as `for k: s += p[k * stride]`
+// the loop was one memory round trip per slice (a 64-slice reduction of an 8 K-element gradient: 32 us on 8 workgroups,
+// profiles/r06_r18_trace_by_grid.txt)
+__device__ __forceinline__ f32x4 sum_slices(const float* __restrict__ p, int64_t stride, int S) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= S; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < S; ++k) s += *reinterpret_cast<const f32x4*>(p + (int64_t)k * stride);
+    return s;
+}
+
 // Up to MAXQ independent weight-gradient problems (different layers, the same tile configuration) in ONE launch: the three
 // convolutions of a bottleneck at 33 x 33 pixels and 2 images are 35-step reductions — 13-25 us launches that do not fill the
 // chip and cost mostly their own ramp.  Workgroup `blockIdx.x` belongs to problem q with first[q] <= blockIdx.x < first[q+1]
@@ -307,8 +324,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_multi_kernel(const RedPN
         const int64_t t2 = e / Ci;
         const int co = (int)(t2 % Co);
         const int tap = (int)(t2 / Co);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slab + k * per + e);
+        f32x4 s = sum_slices(slab + e, per, S);
         float* g = grad + ((int64_t)co * taps + tap) * Ci + ci;
         if (accumulate) s += *reinterpret_cast<const f32x4*>(g);
         *reinterpret_cast<f32x4*>(g) = s;
@@ -326,8 +342,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_reduce_kernel(const float* __re
         const int64_t t2 = e / Ci;
         const int co = (int)(t2 % Co);
         const int tap = (int)(t2 / Co);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < S; ++k) s += *reinterpret_cast<const f32x4*>(slab + k * per + e);
+        f32x4 s = sum_slices(slab + e, per, S);
         float* g = grad + ((int64_t)co * taps + tap) * Ci + ci;
         if (accumulate) s += *reinterpret_cast<const f32x4*>(g);
         *reinterpret_cast<f32x4*>(g) = s;

@@ -31,4 +31,4 @@ for ci, co, h, n in ((128, 128, 16, 256), (256, 256, 8, 256), (512, 512, 4, 256)
     gf = 2.0 * n * h * h * co * ci * 9 / 1e9
     tf = timeit(lambda: ops.conv_fwd(x, w, 1))
     td = timeit(lambda: ops.conv_dgrad(dy, wt, (h, h), 1))
-    print(f"{ci:4d}->{co:4d} {h:2d}x{h:<2d}  fwd {tf:6.1f} us ({gf / tf * 1e-3:6.1f} TFLOP/s)   dgrad {td:6.1f} us ({gf / td * 1e-3:6.1f} TFLOP/s)")
+    print(f"{ci:4d}->{co:4d} {h:2d}x{h:<2d}  fwd {tf:6.1f} us ({gf / tf * 1e3:6.1f} TFLOP/s)   dgrad {td:6.1f} us ({gf / td * 1e3:6.1f} TFLOP/s)")

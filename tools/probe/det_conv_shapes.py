@@ -35,5 +35,5 @@ for name, n, h, w_, convs in SHAPES:
         gf = 2.0 * n * h * w_ * co * ci * k * k / 1e9
         tf = timeit(lambda: ops.conv_fwd(x, w, 1))
         td = timeit(lambda: ops.conv_dgrad(dy, wt, (h, w_), 1))
-        print(f"{name:18s} {n * h * w_:6d} rows {ci:4d}->{co:4d} {k}x{k}  fwd {tf:6.1f} us ({gf / tf * 1e-3:6.1f} TFLOP/s)   "
-              f"dgrad {td:6.1f} us ({gf / td * 1e-3:6.1f} TFLOP/s)")
+        print(f"{name:18s} {n * h * w_:6d} rows {ci:4d}->{co:4d} {k}x{k}  fwd {tf:6.1f} us ({gf / tf * 1e3:6.1f} TFLOP/s)   "
+              f"dgrad {td:6.1f} us ({gf / td * 1e3:6.1f} TFLOP/s)")
