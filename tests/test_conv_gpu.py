@@ -639,7 +639,8 @@ GRID_SHAPES = [  # n, ci, co, h, k, dilation: the training step's own launches (
     # four-stage form's one per CU), a 3x3 whose halo does not fit (33 x 33 images) and DeepLab's atrous 3x3 (dilation 2)
     (256, 128, 128, 16, 3, 1), (256, 256, 256, 8, 3, 1), (256, 512, 512, 4, 3, 1), (64, 128, 128, 16, 3, 1), (32, 256, 256, 8, 3, 1),
     (100, 128, 256, 8, 3, 1), (64, 1024, 256, 14, 1, 1), (64, 512, 2048, 7, 1, 1), (32, 256, 1024, 14, 1, 1), (16, 2048, 512, 7, 1, 1),
-    (2, 256, 256, 33, 3, 1), (2, 256, 1024, 33, 1, 1), (2, 512, 512, 33, 3, 2)]
+    (2, 256, 256, 33, 3, 1), (2, 256, 1024, 33, 1, 1), (2, 512, 512, 33, 3, 2),
+    (2, 1024, 256, 33, 1, 1), (3, 1024, 256, 33, 1, 1)]      # round 6: DeepLab's 70- / 104-workgroup launches on 64 x 64 tiles (dispatch_bnf's rule)
 
 
 @pytest.mark.parametrize("n,ci,co,h,k,d", GRID_SHAPES)
