@@ -83,3 +83,41 @@ def test_shapes_outside_the_kernels_are_refused(pkg, gpu):
     assert not ops.linear_pair_ok(x.cpu(), torch.randn(3, 16), torch.randn(3, 16))
     lib = pkg._lib.load()
     assert lib.afan_linear_pair_workspace_floats(0, 8, 100, 29, 16) == -1
+
+
+def test_one_layer_and_argument_errors_through_the_c_abi(pkg, gpu):
+    """n2 == 0 (one layer: w2 / y2 / g2 NULL) and the entry points' argument checks (AFAN_E* before any launch)."""
+    import ctypes as C
+    lib = pkg._lib.load()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    g = torch.Generator().manual_seed(11)
+    M, K, n1 = 70, 96, 9
+    x, w1, b1 = torch.randn(M, K, generator=g).to(gpu), torch.randn(n1, K, generator=g).to(gpu), torch.randn(n1, generator=g).to(gpu)
+    y1 = torch.empty(M, n1, device=gpu)
+    nws = lib.afan_linear_pair_workspace_floats(0, M, n1, 0, K)
+    ws = torch.empty(max(nws, 1), device=gpu)
+    assert lib.afan_linear_pair_fwd_f32(ptr(x), ptr(w1), ptr(b1), None, None, ptr(y1), None, M, n1, 0, K, ptr(ws), st) == 0
+    _close(y1, x.double() @ w1.double().t() + b1.double())
+    g1 = torch.randn(M, n1, generator=g).to(gpu)
+    gx = torch.empty(M, K, device=gpu)
+    assert lib.afan_linear_pair_dgrad_f32(ptr(g1), None, ptr(w1), None, ptr(gx), M, n1, 0, K, st) == 0
+    _close(gx, g1.double() @ w1.double())
+    gw, gb = torch.empty(n1, K, device=gpu), torch.empty(n1, device=gpu)
+    ws2 = torch.empty(lib.afan_linear_pair_workspace_floats(1, M, n1, 0, K), device=gpu)
+    assert lib.afan_linear_pair_wgrad_f32(ptr(g1), None, ptr(x), ptr(gw), ptr(gb), None, None, 0, M, n1, 0, K, ptr(ws2), st) == 0
+    _close(gw, g1.double().t() @ x.double()), _close(gb, g1.double().sum(0))
+    E_NULL, E_SHAPE, E_ALIGN = -4, -3, -2          # include/afan_hip.h: AFAN_ENULL, AFAN_ESHAPE, AFAN_EALIGN
+    assert lib.afan_linear_pair_fwd_f32(None, ptr(w1), None, None, None, ptr(y1), None, M, n1, 0, K, ptr(ws), st) == E_NULL
+    assert lib.afan_linear_pair_fwd_f32(ptr(x), ptr(w1), None, None, None, ptr(y1), None, M, n1, 3, K, ptr(ws), st) == E_NULL      # second layer announced, not given
+    assert lib.afan_linear_pair_fwd_f32(ptr(x), ptr(w1), None, None, None, ptr(y1), None, M, n1, 0, K + 2, ptr(ws), st) == E_SHAPE   # K % 4
+    assert lib.afan_linear_pair_fwd_f32(ptr(x), ptr(w1), None, None, None, ptr(y1), None, M, 129, 0, K, ptr(ws), st) == E_SHAPE
+    off = torch.empty(M * K + 1, device=gpu)[1:]                        # 4-byte aligned only
+    assert lib.afan_linear_pair_fwd_f32(ptr(off), ptr(w1), None, None, None, ptr(y1), None, M, n1, 0, K, ptr(ws), st) == E_ALIGN
+    assert lib.afan_linear_pair_wgrad_f32(ptr(g1), None, ptr(x), ptr(gw), None, None, None, 0, M, n1, 0, K, None, st) == E_NULL     # no workspace
+    # a split forward (few rows) without its workspace
+    xs = torch.randn(8, 2048, generator=g).to(gpu)
+    wl = torch.randn(n1, 2048, generator=g).to(gpu)
+    assert lib.afan_linear_pair_workspace_floats(0, 8, n1, 0, 2048) > 0
+    assert lib.afan_linear_pair_fwd_f32(ptr(xs), ptr(wl), None, None, None, ptr(torch.empty(8, n1, device=gpu)), None, 8, n1, 0, 2048, None, st) == E_NULL
+    torch.cuda.synchronize()
