@@ -363,6 +363,9 @@ def main():
     import torch.distributed as dist
     import torch.nn as nn
     pkg = importlib.import_module("cv_a-fan_amd")
+    # one process per GPU on ONE block of cores of the GPU's NUMA node, a small intra-op pool (cv_a-fan_amd/host.py): before the GPU is
+    # initialised, so that the runtime's threads inherit the mask; restored around the CPU baseline, which wants the whole machine
+    placement = pkg.host.place_rank()
     seg = args.arch in SEG_ARCHS
     det = args.arch in DET_ARCHS
     if det:
@@ -636,6 +639,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        pkg.host.restore(placement)
         cpu = (cpu_baseline_seg(args.arch, args.batch, args.pgd_steps, side, args.cpu_steps) if seg
                else cpu_baseline(args.arch, args.batch, args.pgd_steps, idx, args.cpu_steps))
 
@@ -699,7 +703,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "final_loss": round(loss, 4), "hipgraph": graphed, "schedule": sched},
+                       "final_loss": round(loss, 4), "hipgraph": graphed, "schedule": sched,
+                       "host_placement": {k: v for k, v in placement.items() if k != "restore"}},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if not (seg or det):

@@ -10,7 +10,7 @@ DeepLabv3+ split-forward network), seg_attack_algo / seg_trainer (the Segmentati
 """
 from . import _lib, ops  # noqa: F401
 from ._lib import AfanLibraryError, LIB_PATH  # noqa: F401
-from . import resnet_s, attack_algo, arena, grid_guard, train_step, learnable, seg_attack_algo, deeplab, seg_trainer, det_ops, det_attack_algo, det_model, det_trainer  # noqa: F401
+from . import resnet_s, attack_algo, arena, grid_guard, train_step, learnable, seg_attack_algo, deeplab, seg_trainer, det_ops, det_attack_algo, det_model, det_trainer, host  # noqa: F401
 from .attack_algo import PGD, get_sample_points, linfball_proj, mix_feature, tensor_clamp  # noqa: F401
 
 __version__ = "0.1.0"

@@ -596,6 +596,29 @@ class ResNet101(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------ RPN
+EARLY_READ = os.environ.get("AFAN_DET_EARLY_READ", "1") != "0"      # 0: the anchor sampling's counts travel with the iteration's one host read (A/B, tests)
+_early_ring = {}
+
+
+def _early_slot(counts_dev):
+    """Queue counts_dev ([2] int64 on the device) -> pinned host memory behind what has been launched so far; an event marks the copy."""
+    dev = counts_dev.device.index
+    ring = _early_ring.get(dev)
+    if ring is None:
+        ring = _early_ring[dev] = {"i": 0, "slots": [(torch.empty(2, dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]}
+    buf, ev = ring["slots"][ring["i"]]
+    ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+    buf.copy_(counts_dev, non_blocking=True)
+    ev.record()
+    return buf, ev
+
+
+def _early_wait(slot):
+    buf, ev = slot
+    ev.synchronize()
+    return int(buf[0]), int(buf[1])
+
+
 LINEAR_PAIR = os.environ.get("AFAN_DET_LINEAR_PAIR", "1") != "0"      # 0: each head layer on the general fp32 kernels (A/B, tests)
 
 
@@ -730,6 +753,14 @@ class RegionProposalNetwork(nn.Module):
         trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
         objectnesses, transformers = self._heads(trunk)
         pend = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=True)
+        early = None
+        if EARLY_READ and not torch.cuda.is_current_stream_capturing():
+            # (round 6) the anchor sampling's two list lengths leave for the host NOW, behind the label / list launches only: the host
+            # waits for THAT copy (an event, not a drain) while the proposal layer's decode / sort / NMS launches keep the GPU busy, and
+            # composes the anchor draws — torch.randperm over ~17 000 background anchors: ~0.16 ms of host time per pass that used to
+            # sit between the iteration's host read and the next launch.  The host generator's draws keep their order (anchor
+            # sampling's three, then the ROI sampling's three behind the second read).
+            early = _early_slot(pend[0][2])
         boxes = box_decode_clip(anchor_bboxes, transformers.float(), image_width, image_height)
         probs = F.softmax(objectnesses.float()[:, :, 1], dim=-1)
         _, order = torch.sort(probs, dim=-1, descending=True)
@@ -742,8 +773,13 @@ class RegionProposalNetwork(nn.Module):
         if roi_targets is not None:
             padded, kept_n = proposal_rows(cand, keeps, self._post_nms_top_n)     # (the scan may report up to 63 survivors more: clamped there)
             roi_pend = roi_targets(padded, kept_n)
-        counts = torch.cat([pend[0][2]] + [c for _, c in keeps] + ([roi_pend.counts] if roi_pend is not None else [])).tolist()   # the one read
-        ce, sl1 = self._losses_finish(pend, counts[0], counts[1])
+        if early is not None:
+            nf, nb_ = _early_wait(early)
+            ce, sl1 = self._losses_finish(pend, nf, nb_)                      # host draws + launches while the NMS is still running
+            counts = [nf, nb_] + torch.cat([c for _, c in keeps] + ([roi_pend.counts] if roi_pend is not None else [])).tolist()
+        else:
+            counts = torch.cat([pend[0][2]] + [c for _, c in keeps] + ([roi_pend.counts] if roi_pend is not None else [])).tolist()   # the one read
+            ce, sl1 = self._losses_finish(pend, counts[0], counts[1])
         kept = [sb[k[:n]][:self._post_nms_top_n] for sb, (k, _), n in zip(cand, keeps, counts[2:2 + nb_img])]
         if len(kept) == 1:
             proposals = kept[0].unsqueeze(0)

@@ -93,6 +93,8 @@ def train(train_loader, trainer, epoch, args, log):
 
 def main(argv=None):
     args = parser.parse_args(argv)
+    from .host import place_rank
+    place_rank(int(args.gpu))
     if not torch.cuda.is_available():
         raise RuntimeError("main_learnable.py needs an MI355X: this build has no CPU path (oracle/ is test infrastructure)")
     torch.cuda.set_device(int(args.gpu))

@@ -232,6 +232,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    from .host import place_rank
+    placement = place_rank(local)              # this rank's threads on one block of cores of its GPU's NUMA node (before the GPU is touched)
     if not torch.cuda.is_available():
         raise RuntimeError("main_perturb.py needs an MI355X: this build has no CPU path (oracle/ is test infrastructure)")
     torch.cuda.set_device(local)
@@ -244,6 +246,7 @@ def main(argv=None):
             print(*a, flush=True)
 
     log(args)
+    log("host placement:", {k: v for k, v in placement.items() if k != "restore"})
     if args.seed:
         setup_seed(args.seed)
     if args.arch == "resnet50" and not args.synthetic:

@@ -332,3 +332,33 @@ def test_trainer_and_guard_form_no_reference_cycle(pkg):
         gc.enable()
     import inspect
     assert "WeakMethod(self._drop_graphs)" in inspect.getsource(gg.GuardedTrainer._guard_init)
+
+
+def test_host_placement_picks_a_block_of_allowed_cores(pkg, monkeypatch):
+    """cv_a-fan_amd/host.py: the rank's block lies inside the process's allowed CPUs, different local ranks take different blocks when
+    the node has room, AFAN_HOST_CPUS overrides, AFAN_HOST_PIN=0 leaves everything alone; place_rank / restore round-trip."""
+    import os
+    import torch
+    host = pkg.host
+    allowed = sorted(os.sched_getaffinity(0))
+    blk = host.rank_cpus(0, cores=2)
+    if blk is not None:
+        assert len(blk) == 2 and set(blk) <= set(allowed)
+        other = host.rank_cpus(1, cores=2)
+        assert other is None or set(other) <= set(allowed)
+    assert host.rank_cpus(0, cores=10 ** 6) is None
+    monkeypatch.setenv("AFAN_HOST_CPUS", f"{allowed[0]}")
+    assert host.rank_cpus(0, cores=8) == [allowed[0]]
+    monkeypatch.delenv("AFAN_HOST_CPUS")
+    assert host._parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    monkeypatch.setenv("AFAN_HOST_PIN", "0")
+    assert host.place_rank(0) == {"pinned": False}
+    monkeypatch.delenv("AFAN_HOST_PIN")
+    n0 = torch.get_num_threads()
+    info = host.place_rank(0, cores=2, threads=1)
+    try:
+        if info["pinned"]:
+            assert sorted(os.sched_getaffinity(0)) == host.rank_cpus(0, cores=2) and torch.get_num_threads() == 1
+    finally:
+        host.restore(info)
+    assert sorted(os.sched_getaffinity(0)) == allowed and torch.get_num_threads() == n0
