@@ -26,7 +26,20 @@ def _parse_cpulist(text):
 
 
 def _gpu_numa_nodes():
-    """NUMA node of every AMD display-class PCI function, in PCI address order (the HIP runtime's default device order)."""
+    """NUMA node of every AMD GPU this process can open, in PCI address order (the HIP runtime's default device order): the render nodes
+    under /dev/dri that are accessible (a container is usually handed a subset of the machine's GPUs through them); if none can be
+    told apart that way, every AMD display / accelerator PCI function."""
+    seen = []
+    for rd in glob.glob("/sys/class/drm/renderD*"):
+        try:
+            dev = os.path.realpath(rd + "/device")
+            if open(dev + "/vendor").read().strip() != "0x1002" or not os.access("/dev/dri/" + os.path.basename(rd), os.R_OK | os.W_OK):
+                continue
+            seen.append((os.path.basename(dev), int(open(dev + "/numa_node").read().strip())))
+        except (OSError, ValueError):
+            continue
+    if seen:
+        return [n for _, n in sorted(seen)]
     nodes = []
     for dev in sorted(glob.glob("/sys/bus/pci/devices/*")):
         try:
