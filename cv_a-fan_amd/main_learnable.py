@@ -14,9 +14,9 @@ if __package__ in (None, ""):  # executed as a script: import the hyphenated pac
     import importlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _pkg = importlib.import_module("cv_a-fan_amd")
-    resnet_s, learnable, mp = _pkg.resnet_s, _pkg.learnable, importlib.import_module("cv_a-fan_amd.main_perturb")
+    resnet_s, learnable, host, mp = _pkg.resnet_s, _pkg.learnable, _pkg.host, importlib.import_module("cv_a-fan_amd.main_perturb")
 else:
-    from . import resnet_s, learnable
+    from . import host, resnet_s, learnable
     from . import main_perturb as mp
 
 parser = argparse.ArgumentParser(description="Learnable multi-layer A-FAN CIFAR-10 training on MI355X")
@@ -93,8 +93,7 @@ def train(train_loader, trainer, epoch, args, log):
 
 def main(argv=None):
     args = parser.parse_args(argv)
-    from .host import place_rank
-    place_rank(int(args.gpu))
+    host.place_rank(int(args.gpu))
     if not torch.cuda.is_available():
         raise RuntimeError("main_learnable.py needs an MI355X: this build has no CPU path (oracle/ is test infrastructure)")
     torch.cuda.set_device(int(args.gpu))

@@ -22,9 +22,9 @@ if __package__ in (None, ""):  # executed as a script (cmd/run_perturb.sh): impo
     import importlib
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     _pkg = importlib.import_module("cv_a-fan_amd")
-    resnet_s, train_step = _pkg.resnet_s, _pkg.train_step
+    resnet_s, train_step, host = _pkg.resnet_s, _pkg.train_step, _pkg.host
 else:
-    from . import resnet_s, train_step
+    from . import host, resnet_s, train_step
 
 parser = argparse.ArgumentParser(description="A-FAN CIFAR-10 training on MI355X")
 # ---- base setting (main_perturb.py:28-33)
@@ -232,8 +232,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
-    from .host import place_rank
-    placement = place_rank(local)              # this rank's threads on one block of cores of its GPU's NUMA node (before the GPU is touched)
+    placement = host.place_rank(local)         # this rank's threads on one block of cores of its GPU's NUMA node (before the GPU is touched)
     if not torch.cuda.is_available():
         raise RuntimeError("main_perturb.py needs an MI355X: this build has no CPU path (oracle/ is test infrastructure)")
     torch.cuda.set_device(local)
