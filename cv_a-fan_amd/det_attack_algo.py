@@ -29,6 +29,9 @@ def compute_loss(loss1, loss2, loss3, loss4):
     return sum_of_means(loss1, loss2, loss3, loss4)
 
 
+BATCH_LAYER3 = os.environ.get("AFAN_DET_BATCH_L3", "1") != "0"      # 0: every final pass runs its own layer3 (A/B, tests)
+
+
 class NoiseAhead:
     """The image PGD's random start (:159: `torch.rand(x.shape)` on the CPU default generator, 1.6 M numbers for a 600 x 904 image:
     2.5 ms of host time with the device idle behind it) drawn at the END of the previous iteration instead, while the device still
@@ -197,6 +200,12 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
              {"x": image_batch, "adv": adv2, "out_idx": 2, "flag": "tail"}] + \
             [{"x": image_batch, "adv": pts[j], "out_idx": 3, "flag": "tail"} for j in (1, 2, 3, 4)] + \
             [{"adv": adv_rr, "out_idx": "roi_tail", "flag": "clean"}]
+    if BATCH_LAYER3 and hasattr(getattr(model, "features", None), "forward_many"):
+        # (round 6) the three passes that reach the backbone are independent of one another until their RPN: their layer3 runs once on the
+        # three feature maps' batch (det_model backbone.forward_many), each pass then enters behind it like the sample-point passes do
+        f3 = model.train().features.forward_many(dicts[:3])
+        if f3 is not None:
+            dicts[:3] = [{"x": image_batch, "adv": f, "out_idx": 3, "flag": "tail"} for f in f3]
     cuts = []
     if cut:
         if not hasattr(model, "cut_features"):

@@ -574,6 +574,30 @@ class ResNet101(nn.Module):
                     out[i] = x.clone() if _StageGraphs.ON else x      # (a replayed stage hands out its own static buffer)
         return [out[i] for i in idxs]
 
+    def forward_many(self, dicts):
+        """The conv4 feature maps of several INDEPENDENT passes ('clean' from the image, 'tail' from a feature map entering behind layer
+        1 or 2) with layer3 — 23 of the backbone's 30 bottlenecks — run ONCE on their concatenated batch: the BatchNorms are frozen, so a
+        row of a convolution does not know its batch (every tiled variant adds a row's products in the same order: the same activations
+        and input gradients, bit for bit); the layer's launches see three images' rows instead of one's (2 166 rows per image leave the
+        chip a quarter full), and its weight gradients sum over the passes inside one reduction instead of three accumulations (fp32
+        order: the only difference).  Returns one feature map per dict, each carrying its share of the autograd graph; None with the
+        stage graphs on (AFAN_DET_GRAPHS=1: their instances are captured per pass)."""
+        if _StageGraphs.ON:
+            return None
+        stages = [self.layer1, self.layer2, self.layer3]
+        xs = []
+        for d in dicts:
+            if d["flag"] == "clean":
+                x, first = self._stem(d["x"]), 0
+            else:
+                assert d["flag"] == "tail" and d["out_idx"] in (1, 2)
+                x, first = _enter(d["adv"], self.conv1.compute_dtype, self.normal.channels_last), d["out_idx"]
+            for st in stages[first:2]:
+                x = _run_stage(st, x)
+            xs.append(x)
+        y = _run_stage(self.layer3, torch.cat(xs, dim=0) if len(xs) > 1 else xs[0])
+        return list(torch.split(y, [x.shape[0] for x in xs], dim=0))
+
     def forward(self, input_dict):
         flag = input_dict["flag"]
         stages = [self.layer1, self.layer2, self.layer3]

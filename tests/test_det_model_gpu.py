@@ -247,6 +247,32 @@ def test_faster_rcnn_full_size_iteration_properties(pkg, gpu):
     assert torch.equal(r["losses"], r2["losses"]) and torch.equal(tr.arena.grad, tr2.arena.grad) and torch.equal(tr.arena.param, tr2.arena.param)
 
 
+def test_batched_layer3_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
+    """det_attack_algo.BATCH_LAYER3: the three final passes that reach the backbone run layer3 once on their concatenated feature maps
+    (frozen BatchNorm: rows do not know their batch).  Against per-pass layer3 from the same state: the iteration's eight losses, the
+    adversarial tensors and every input-side quantity bit-equal (one K order in every tiled variant); the parameter gradients of layer3
+    are summed inside one reduction instead of three accumulations: fp32 order only."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    da = pkg.det_attack_algo
+    old, res = da.BATCH_LAYER3, {}
+    try:
+        for on in (True, False):
+            da.BATCH_LAYER3 = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m)
+            torch.manual_seed(5)
+            r = tr.step(images, bboxes, labels)
+            torch.cuda.synchronize()
+            res[on] = (r["losses"].clone(), r["adv_image"].clone(), r["adv3"].clone(), tr.arena.grad.clone())
+    finally:
+        da.BATCH_LAYER3 = old
+    for k in range(3):
+        assert torch.equal(res[True][k], res[False][k]), k
+    ga, gb = res[True][3], res[False][3]
+    assert float((ga - gb).norm() / gb.norm()) < 1e-5
+
+
 def test_backbone_stage_graphs_equal_eager_launches(pkg, gpu):
     """det_model._StageGraphs (AFAN_DET_GRAPHS=1: the backbone's stages replayed from hipGraphs forward and backward, instances with
     private pools) against the eager stage nodes over four iterations from the same state: the same launches on the same data —
@@ -255,6 +281,8 @@ def test_backbone_stage_graphs_equal_eager_launches(pkg, gpu):
     images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
     sg = pkg.det_model._StageGraphs
     old, res = sg.ON, {}
+    da = pkg.det_attack_algo
+    old_batch, da.BATCH_LAYER3 = da.BATCH_LAYER3, False      # (the graph instances are captured per pass: the eager side runs per pass too)
     try:
         for on in (False, True):
             sg.ON = on
@@ -269,6 +297,7 @@ def test_backbone_stage_graphs_equal_eager_launches(pkg, gpu):
             res[on] = (torch.stack(losses), tr.arena.param.clone(), len(sg.cache))
     finally:
         sg.ON = old
+        da.BATCH_LAYER3 = old_batch
         sg.cache.clear(), sg.warm.clear()
     assert res[True][2] > 0 and res[False][2] == 0                       # stages WERE captured and replayed
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
