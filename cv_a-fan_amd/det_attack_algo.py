@@ -30,6 +30,7 @@ def compute_loss(loss1, loss2, loss3, loss4):
 
 
 BATCH_LAYER3 = os.environ.get("AFAN_DET_BATCH_L3", "1") != "0"      # 0: every final pass runs its own layer3 (A/B, tests)
+BATCH_ROI_HEAD = os.environ.get("AFAN_DET_BATCH_ROI", "1") != "0"    # 0: every final pass runs its own ROI head (A/B, tests)
 
 
 class NoiseAhead:
@@ -207,13 +208,20 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
         if f3 is not None:
             dicts[:3] = [{"x": image_batch, "adv": f, "out_idx": 3, "flag": "tail"} for f in f3]
     cuts = []
+    def run_all():
+        # (round 6) the seven passes in front of the ROI-tail pass are independent of one another: their ROI heads run as one
+        if BATCH_ROI_HEAD and hasattr(model, "forward_heads_many"):
+            outs = model.train().forward_heads_many(dicts[:7], bboxes_batch, labels_batch)
+            return [compute_loss(*o) for o in outs] + [compute_loss(*fwd(d)) for d in dicts[7:]]
+        return [compute_loss(*fwd(d)) for d in dicts]
+
     if cut:
         if not hasattr(model, "cut_features"):
             raise ops.AfanLibraryError("det_train_phases(cut=True) needs a model with cut_features() (det_model.Model)")
         with model.cut_features(cuts):
-            L = [compute_loss(*fwd(d)) for d in dicts]
+            L = run_all()
     else:
-        L = [compute_loss(*fwd(d)) for d in dicts]
+        L = run_all()
     loss_clean_adv = 0.9 * (0.2333 * (L[0] + L[3] + L[4] + L[5] + L[6]) + 0.1 * L[7]) + 0.05 * (L[1] + L[2])
     if loss_settings == 1:
         loss = loss_clean_adv

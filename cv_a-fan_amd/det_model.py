@@ -1041,6 +1041,26 @@ class Model(nn.Module):
         _, _, pc, pt = self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, targets=roi_t)
         return ao, at, pc, pt
 
+    def forward_heads_many(self, dicts, gt_bboxes_batch=None, gt_classes_batch=None):
+        """[forward(d, gt_bboxes_batch, gt_classes_batch) for d in dicts] for training passes that are independent of one another (the
+        final passes of train_aug_sat_muti_advt.py:141-153), with the ROI head — ROIAlign, layer4, the two Linear layers — run ONCE on
+        all passes' sampled regions: pass by pass, in order, everything up to the sampling (backbone, RPN, proposals, the host
+        generator's draws in the reference's sequence); then one ROIAlign over the concatenated feature maps (a region's batch index
+        names its pass's map), one layer4 on 7 x 128 regions instead of seven on 128 (2 048 rows leave the chip half full), and each
+        pass's two losses from its rows.  Frozen BatchNorm: a region's features do not depend on its batch; the small fp32 Linear
+        layers split their reduction by row count and the parameter gradients sum in one reduction: fp32 order is the difference."""
+        pend = []
+        for d in dicts:
+            assert d["flag"] in ("tail", "clean") and type(d["out_idx"]) == int and self.training
+            features = self._cut(self.features(d))
+            anchors, iw, ih = self._anchors(features, d["x"].shape)
+            _, _, ao, at, proposals, roi_t = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih,
+                                                                          roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch))
+            if roi_t is None:
+                roi_t = self.detection._targets(proposals, gt_classes_batch, gt_bboxes_batch)
+            pend.append((features, ao, at, roi_t))
+        return self.detection.forward_many(pend)
+
     MERGE_READS = os.environ.get("AFAN_DET_MERGE_READS", "1") != "0"       # 0: the ROI head's sampling with its own host read (A/B, tests)
 
     def _roi_targets(self, gt_classes_batch, gt_bboxes_batch):
@@ -1111,6 +1131,23 @@ class Model(nn.Module):
             classes, transformers = self._linears(hidden)
             ce, sl1 = self.loss(classes, transformers, gt_classes, gt_deltas, b, bi)
             return classes, transformers, ce, sl1
+
+        def forward_many(self, pend):
+            """pend: [(features [B, C, H, W], anchor ce, anchor sl1, (boxes, gt_classes, gt_deltas, batch_indices))] of independent training
+            passes -> [(anchor ce, anchor sl1, proposal ce, proposal sl1)]: `forward(..., targets=...)` per pass with ONE `_roi_features` /
+            `_linears` over all passes' regions (Model.forward_heads_many)."""
+            b = pend[0][0].shape[0]
+            feats = torch.cat([p[0] for p in pend], dim=0) if len(pend) > 1 else pend[0][0]
+            boxes = torch.cat([p[3][0] for p in pend], dim=0)
+            bi_all = torch.cat([p[3][3] + k * b for k, p in enumerate(pend)], dim=0)
+            classes, transformers = self._linears(self._roi_features(feats, boxes, bi_all))
+            out, o = [], 0
+            for _, ao, at, (bx, gt_classes, gt_deltas, bi) in pend:
+                n = bx.shape[0]
+                ce, sl1 = self.loss(classes[o:o + n], transformers[o:o + n], gt_classes, gt_deltas, b, bi)
+                out.append((ao, at, ce, sl1))
+                o += n
+            return out
 
         def loss(self, proposal_classes, proposal_transformers, gt_proposal_classes, gt_proposal_transformers, batch_size, batch_indices):
             """:343-367: the regression output of each sample's OWN class, targets normalised by (0, 0, 0, 0) / (.1, .1, .2, .2)."""

@@ -273,6 +273,33 @@ def test_batched_layer3_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
 
 
+def test_batched_roi_head_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
+    """det_attack_algo.BATCH_ROI_HEAD: the seven final passes in front of the ROI-tail pass run their ROI heads (ROIAlign, layer4, the
+    two Linear layers) once on all passes' sampled regions (Model.forward_heads_many).  Same state, same host draws in the same order:
+    the adversarial tensors bit-equal (they are made before), the sampled regions the same, the eight losses and the gradients to fp32
+    summation order (the small Linear kernels split their reduction by row count; parameter gradients sum in one reduction)."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    da = pkg.det_attack_algo
+    old, res = da.BATCH_ROI_HEAD, {}
+    try:
+        for on in (True, False):
+            da.BATCH_ROI_HEAD = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m, segmented=True)          # (the two-part backward of the data-parallel path as well)
+            torch.manual_seed(5)
+            r = tr.step(images, bboxes, labels)
+            torch.cuda.synchronize()
+            res[on] = (r["losses"].clone(), r["adv_image"].clone(), r["adv3"].clone(), tr.arena.grad.clone(), torch.get_rng_state().clone())
+    finally:
+        da.BATCH_ROI_HEAD = old
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][4], res[False][4])                      # the host generator has made the same draws
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=2e-5, atol=1e-6)
+    ga, gb = res[True][3], res[False][3]
+    assert float((ga - gb).norm() / gb.norm()) < 2e-3                    # (bf16 activations' gradients through layer4: rounding of sums in another order)
+
+
 def test_backbone_stage_graphs_equal_eager_launches(pkg, gpu):
     """det_model._StageGraphs (AFAN_DET_GRAPHS=1: the backbone's stages replayed from hipGraphs forward and backward, instances with
     private pools) against the eager stage nodes over four iterations from the same state: the same launches on the same data —
