@@ -643,6 +643,7 @@ def _early_wait(slot):
     return int(buf[0]), int(buf[1])
 
 
+BATCH_RPN_TRUNK = os.environ.get("AFAN_DET_BATCH_RPN", "1") != "0"   # 0: forward_heads_many runs the RPN trunk and heads pass by pass (A/B, tests)
 LINEAR_PAIR = os.environ.get("AFAN_DET_LINEAR_PAIR", "1") != "0"      # 0: each head layer on the general fp32 kernels (A/B, tests)
 
 
@@ -762,7 +763,8 @@ class RegionProposalNetwork(nn.Module):
         sel, _, lab, gt_deltas, bi = fg_bg_draw(lists, nf, nb, labels, assign, in_boxes, gt, 128 * b, 256 * b)
         return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
 
-    def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean", roi_targets=None):
+    def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean", roi_targets=None,
+                            heads=None):
         """`forward(...)` (training) followed by `generate_proposals(...)` — the order model.py:95-100 calls them in — with ONE host
         read for both: the anchor sampling's two list lengths and every image's NMS survivor count travel together (the label /
         list launches and the decode / sort / NMS launches are all queued before it).  The host's random draws keep their order
@@ -774,8 +776,11 @@ class RegionProposalNetwork(nn.Module):
         longest image's survivor count labelled -1, shorter images zero-padded like the reference's stack) before the one read, and its
         three draws follow the anchor sampling's on the host generator, as in the reference: a sixth return value, 16 host reads per
         iteration fewer."""
-        trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
-        objectnesses, transformers = self._heads(trunk)
+        if heads is not None:           # (the two head outputs computed by the caller: Model.forward_heads_many runs the trunk once for several passes)
+            objectnesses, transformers = heads
+        else:
+            trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
+            objectnesses, transformers = self._heads(trunk)
         pend = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=True)
         early = None
         if EARLY_READ and not torch.cuda.is_current_stream_capturing():
@@ -1049,13 +1054,20 @@ class Model(nn.Module):
         names its pass's map), one layer4 on 7 x 128 regions instead of seven on 128 (2 048 rows leave the chip half full), and each
         pass's two losses from its rows.  Frozen BatchNorm: a region's features do not depend on its batch; the small fp32 Linear
         layers split their reduction by row count and the parameter gradients sum in one reduction: fp32 order is the difference."""
-        pend = []
+        pend, feats = [], []
         for d in dicts:
             assert d["flag"] in ("tail", "clean") and type(d["out_idx"]) == int and self.training
-            features = self._cut(self.features(d))
+            feats.append(self._cut(self.features(d)))
+        # the RPN's trunk convolution and its two 1x1 heads once for all passes (the same argument: no BatchNorm at all here)
+        heads = [None] * len(dicts)
+        if BATCH_RPN_TRUNK and len(feats) > 1 and all(f.shape == feats[0].shape for f in feats):
+            b = feats[0].shape[0]
+            obj_all, tr_all = self.rpn._heads(self.rpn._trunk(torch.cat(feats, dim=0)))
+            heads = [(obj_all[k * b:(k + 1) * b], tr_all[k * b:(k + 1) * b]) for k in range(len(feats))]
+        for d, features, hd in zip(dicts, feats, heads):
             anchors, iw, ih = self._anchors(features, d["x"].shape)
             _, _, ao, at, proposals, roi_t = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih,
-                                                                          roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch))
+                                                                          roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch), heads=hd)
             if roi_t is None:
                 roi_t = self.detection._targets(proposals, gt_classes_batch, gt_bboxes_batch)
             pend.append((features, ao, at, roi_t))
