@@ -273,12 +273,13 @@ __global__ __launch_bounds__(TB) void skinny_wgrad_reduce_kernel(const float* __
 
 // forward K slices / parameter-gradient row slices: enough workgroups for the chip, whole staging chunks
 int fwd_chunk(int NT) { return NT <= 64 ? 128 : 64; }       // reduction steps per LDS stage: 128 up to 64 features, else 64 (LDS)
+// One slice per staging chunk, whatever M is: a row's result is then the same sum — chunk partials in chunk order — in a batch of 128 rows
+// and in a batch of 896 (the Faster-RCNN passes run their heads pass by pass or several passes at once: the same bits either way), and
+// few rows still spread over K / chunk workgroups per row tile.  (Up to 64 slices; longer reductions take several chunks per slice.)
 int fwd_slices(int64_t M, int64_t K, int NT) {
-    const int64_t tiles = (M + RT - 1) / RT, kc = fwd_chunk(NT);
-    int64_t s = tiles >= 192 ? 1 : (256 + tiles - 1) / tiles;          // ~256 workgroups: a row tile's whole reduction on ONE CU is 4+ chunks in a row
-    const int64_t chunks = (K + kc - 1) / kc;
-    if (s > chunks) s = chunks;
-    return (int)(s < 1 ? 1 : s);
+    (void)M;
+    const int64_t kc = fwd_chunk(NT), chunks = (K + kc - 1) / kc;
+    return (int)(chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks));
 }
 int fwd_kslice(int64_t K, int slices, int NT) {
     const int64_t kc = fwd_chunk(NT), chunks = (K + kc - 1) / kc;

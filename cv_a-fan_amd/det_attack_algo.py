@@ -31,6 +31,7 @@ def compute_loss(loss1, loss2, loss3, loss4):
 
 BATCH_LAYER3 = os.environ.get("AFAN_DET_BATCH_L3", "1") != "0"      # 0: every final pass runs its own layer3 (A/B, tests)
 BATCH_ROI_HEAD = os.environ.get("AFAN_DET_BATCH_ROI", "1") != "0"    # 0: every final pass runs its own ROI head (A/B, tests)
+BATCH_PGD_TAILS = os.environ.get("AFAN_DET_BATCH_PGD", "1") != "0"   # 0: the three one-step feature PGDs run their tails one by one (A/B, tests)
 
 
 class NoiseAhead:
@@ -101,6 +102,44 @@ def _pgd1_from_clean(model, col, idx, image_batch, y, eps, gamma):
         grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
     ops.pgd_step_(x_adv, grad, gamma, x, eps, False)
     return x_adv.requires_grad_(True)
+
+
+def _pgd_three_from_clean(model, col, image_batch, y, specs):
+    """The three one-step feature PGDs of :84-88 — `PGD(fm[0], idx=1)`, `PGD(fm[1], idx=2)`, `PGD(fm[2], idx=3)`, no random start — in ONE
+    tail: each of them runs RPN + proposals + ROI head on the CLEAN conv4 map (their forwards differ only in the host generator's
+    sampling draws) and takes the gradient back to its own layer.  Here the three tails are `Model.forward_heads_many` on three leaves of
+    that map (the RPN trunk, ROIAlign, layer4 and the Linear pairs run once on three passes' rows; sampling pass by pass in the
+    reference's order), one backward of the three losses' sum gives each leaf its own gradient (a pass's loss depends on its leaf only),
+    and the first two are carried back through the clean pass's stored activations as in _pgd1_from_clean.  specs: [(idx, eps, gamma)]
+    for idx 1, 2, 3.  None where the one-node stages or forward_heads_many are not there (the caller runs the three calls)."""
+    from . import det_model
+    if not hasattr(model, "forward_heads_many"):
+        return None
+    stages = [model.features.layer1, model.features.layer2, model.features.layer3]
+    outs = [col.get(("out", i)) for i in (1, 2, 3)]
+    if not all(det_model.stage_input_gradient(stages[i - 1], outs[i - 1]) for i in (2, 3)):
+        return None                  # (decided before anything is drawn from the host generator)
+    xins = [col[3].detach().requires_grad_(True) for _ in specs]
+    with dgrad_only():
+        res = model.train().forward_heads_many([{"x": image_batch, "adv": xi, "out_idx": 3, "flag": "tail"} for xi in xins], y["bb"], y["lb"])
+        losses = [sum_of_means(*r) for r in res]
+        total = losses[0]
+        for l in losses[1:]:
+            total = total + l
+        grads = torch.autograd.grad(total, xins, only_inputs=True)
+    advs = []
+    for (idx, eps, gamma), g in zip(specs, grads):
+        for i in range(3, idx, -1):
+            g = det_model.stage_input_gradient(stages[i - 1], outs[i - 1], g)
+        x = col[idx].detach().float()
+        x = x if (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))) else x.contiguous()
+        x_adv = x.clone()
+        grad = g.float()
+        if grad.stride() != x_adv.stride():
+            grad = grad.contiguous(memory_format=torch.channels_last) if (x_adv.dim() == 4 and not x_adv.is_contiguous()) else grad.contiguous()
+        ops.pgd_step_(x_adv, grad, gamma, x, eps, False)
+        advs.append(x_adv.requires_grad_(True))
+    return advs
 
 
 def rpn_roi_PGD(layer="roi", rpn_roi_output_dict=None, y=None, model=None, steps=1, eps=None, gamma=None, randinit=False,
@@ -185,13 +224,18 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
         rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
     clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
     fold = col is not None and os.environ.get("AFAN_DET_FOLD_PGD", "1") != "0"      # 0: PGD() as written (A/B, tests)
-    adv1 = _pgd1_from_clean(model, col, 1, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
-    adv2 = _pgd1_from_clean(model, col, 2, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
-    if adv1 is None:
-        adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
-    if adv2 is None:
-        adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
-    adv3 = PGD(fm[2], image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
+    three = (_pgd_three_from_clean(model, col, image_batch, y, [(1, 0.1 / 255, 0.001 / 255), (2, 0.1 / 255, 0.001 / 255), (3, 2.0 / 255, 1.0 / 255)])
+             if (fold and BATCH_PGD_TAILS) else None)
+    if three is not None:
+        adv1, adv2, adv3 = three
+    else:
+        adv1 = _pgd1_from_clean(model, col, 1, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
+        adv2 = _pgd1_from_clean(model, col, 2, image_batch, y, 0.1 / 255, 0.001 / 255) if fold else None
+        if adv1 is None:
+            adv1 = PGD(fm[0], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=1)
+        if adv2 is None:
+            adv2 = PGD(fm[1], image_batch, y=y, model=model, steps=1, eps=(0.1 / 255), gamma=(0.001 / 255), idx=2)
+        adv3 = PGD(fm[2], image_batch, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(1.0 / 255), idx=3)
     pts = sample_points_mixed(fm[2].float(), adv3.detach(), 5, (True, True, False, False))       # :95-97 in one launch
     adv_rr = rpn_roi_PGD(rpn_roi_output_dict=rr, y=y, model=model, steps=1, eps=(2.0 / 255), gamma=(0.2 / 255), only_roi_loss=False)
     adv_sd = mix_feature(clean_sd.float(), adv_rr["roi_output_dict"]["roi_feature_map"].detach())

@@ -273,11 +273,37 @@ def test_batched_layer3_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
 
 
+def test_batched_feature_pgd_tails_equal_the_one_by_one_runs(pkg, gpu):
+    """det_attack_algo.BATCH_PGD_TAILS: the three one-step feature PGDs (:84-88) run their RPN + ROI-head tails on the clean conv4 map as
+    ONE forward_heads_many call and one backward of the losses' sum.  Every kernel on the way computes a row (a region, a pixel) from
+    that row alone, the sampling draws keep their order: the three adversarial feature maps, everything made from them and the
+    iteration's parameters are the same bits as with one call per PGD."""
+    g = _golden_for("align")
+    images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
+    da = pkg.det_attack_algo
+    old, res = da.BATCH_PGD_TAILS, {}
+    try:
+        for on in (True, False):
+            da.BATCH_PGD_TAILS = on
+            m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+            tr = pkg.det_trainer.DetTrainer(m)
+            torch.manual_seed(5)
+            r = tr.step(images, bboxes, labels)
+            torch.cuda.synchronize()
+            res[on] = (r["adv1"].clone(), r["adv2"].clone(), r["adv3"].clone(), r["losses"].clone(), tr.arena.param.clone(), torch.get_rng_state().clone())
+    finally:
+        da.BATCH_PGD_TAILS = old
+    for k in range(6):
+        assert torch.equal(res[True][k], res[False][k]), k
+    assert float((res[True][2] - images.new_zeros(1)).abs().sum()) > 0
+
+
 def test_batched_roi_head_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
     """det_attack_algo.BATCH_ROI_HEAD: the seven final passes in front of the ROI-tail pass run their ROI heads (ROIAlign, layer4, the
     two Linear layers) once on all passes' sampled regions (Model.forward_heads_many).  Same state, same host draws in the same order:
-    the adversarial tensors bit-equal (they are made before), the sampled regions the same, the eight losses and the gradients to fp32
-    summation order (the small Linear kernels split their reduction by row count; parameter gradients sum in one reduction)."""
+    the adversarial tensors bit-equal (they are made before), the sampled regions the same, the eight losses bit-equal (every forward
+    kernel computes a row from that row alone — the small Linear kernels split their reduction per chunk for every row count), the
+    parameter gradients to fp32 summation order (they sum over the passes inside one reduction)."""
     g = _golden_for("align")
     images, bboxes, labels = (torch.from_numpy(g[k]).to(gpu) for k in ("images", "bboxes", "labels"))
     da = pkg.det_attack_algo
@@ -295,7 +321,7 @@ def test_batched_roi_head_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu)
         da.BATCH_ROI_HEAD = old
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
     assert torch.equal(res[True][4], res[False][4])                      # the host generator has made the same draws
-    torch.testing.assert_close(res[True][0], res[False][0], rtol=2e-5, atol=1e-6)
+    assert torch.equal(res[True][0], res[False][0])                      # the eight losses: the same bits (every forward kernel is row-wise)
     ga, gb = res[True][3], res[False][3]
     assert float((ga - gb).norm() / gb.norm()) < 2e-3                    # (bf16 activations' gradients through layer4: rounding of sums in another order)
 

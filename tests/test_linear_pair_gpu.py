@@ -121,3 +121,21 @@ def test_one_layer_and_argument_errors_through_the_c_abi(pkg, gpu):
     assert lib.afan_linear_pair_workspace_floats(0, 8, n1, 0, 2048) > 0
     assert lib.afan_linear_pair_fwd_f32(ptr(xs), ptr(wl), None, None, None, ptr(torch.empty(8, n1, device=gpu)), None, 8, n1, 0, 2048, None, st) == E_NULL
     torch.cuda.synchronize()
+
+
+def test_a_rows_result_does_not_depend_on_the_batch_it_is_in(pkg, gpu):
+    """The forward splits its reduction per staging chunk for every M: rows computed alone, in a batch of 128 and in a batch of 896 are
+    the same bits (the Faster-RCNN heads run pass by pass or for several passes at once); the input gradient is a per-row sum as well."""
+    ops = pkg.ops
+    g = torch.Generator().manual_seed(2)
+    for K, n1, n2 in ((2048, 21, 84), (512, 18, 36)):
+        x = torch.randn(896, K, generator=g).to(gpu)
+        w1, w2 = (torch.randn(n1, K, generator=g) * 0.05).to(gpu), (torch.randn(n2, K, generator=g) * 0.05).to(gpu)
+        b1, b2 = torch.randn(n1, generator=g).to(gpu), torch.randn(n2, generator=g).to(gpu)
+        big = ops.linear_pair_fwd(x, w1, b1, w2, b2)
+        for lo, hi in ((0, 128), (128, 256), (640, 896), (5, 6)):
+            part = ops.linear_pair_fwd(x[lo:hi].contiguous(), w1, b1, w2, b2)
+            assert torch.equal(part[0], big[0][lo:hi]) and torch.equal(part[1], big[1][lo:hi])
+        g1, g2 = torch.randn(896, n1, generator=g).to(gpu), torch.randn(896, n2, generator=g).to(gpu)
+        gx = ops.linear_pair_dgrad(g1, g2, w1, w2)
+        assert torch.equal(ops.linear_pair_dgrad(g1[128:256].contiguous(), g2[128:256].contiguous(), w1, w2), gx[128:256])
