@@ -31,6 +31,7 @@ def compute_loss(loss1, loss2, loss3, loss4):
 
 BATCH_LAYER3 = os.environ.get("AFAN_DET_BATCH_L3", "1") != "0"      # 0: every final pass runs its own layer3 (A/B, tests)
 BATCH_ROI_HEAD = os.environ.get("AFAN_DET_BATCH_ROI", "1") != "0"    # 0: every final pass runs its own ROI head (A/B, tests)
+SHARE_PROPOSALS = os.environ.get("AFAN_DET_SHARE_PROPOSALS", "1") != "0"   # 0: every tail on the clean conv4 map computes its own labels / proposals (A/B, tests)
 BATCH_PGD_TAILS = os.environ.get("AFAN_DET_BATCH_PGD", "1") != "0"   # 0: the three one-step feature PGDs run their tails one by one (A/B, tests)
 
 
@@ -104,7 +105,7 @@ def _pgd1_from_clean(model, col, idx, image_batch, y, eps, gamma):
     return x_adv.requires_grad_(True)
 
 
-def _pgd_three_from_clean(model, col, image_batch, y, specs):
+def _pgd_three_from_clean(model, col, image_batch, y, specs, share=None):
     """The three one-step feature PGDs of :84-88 — `PGD(fm[0], idx=1)`, `PGD(fm[1], idx=2)`, `PGD(fm[2], idx=3)`, no random start — in ONE
     tail: each of them runs RPN + proposals + ROI head on the CLEAN conv4 map (their forwards differ only in the host generator's
     sampling draws) and takes the gradient back to its own layer.  Here the three tails are `Model.forward_heads_many` on three leaves of
@@ -121,7 +122,8 @@ def _pgd_three_from_clean(model, col, image_batch, y, specs):
         return None                  # (decided before anything is drawn from the host generator)
     xins = [col[3].detach().requires_grad_(True) for _ in specs]
     with dgrad_only():
-        res = model.train().forward_heads_many([{"x": image_batch, "adv": xi, "out_idx": 3, "flag": "tail"} for xi in xins], y["bb"], y["lb"])
+        res = model.train().forward_heads_many([{"x": image_batch, "adv": xi, "out_idx": 3, "flag": "tail"} for xi in xins], y["bb"], y["lb"],
+                                               share=share)
         losses = [sum_of_means(*r) for r in res]
         total = losses[0]
         for l in losses[1:]:
@@ -214,7 +216,8 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
         # the three head passes (:78-80) and the clean ROI-head pass (:81) run the same backbone on the same images (frozen
         # BatchNorm, no dropout, no random draw before the RPN): the head passes' values are that pass's stage outputs
         col = {}
-        rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean", "collect": col})
+        rpn_share = {} if SHARE_PROPOSALS else None      # the clean pass's anchor labels / proposals / candidate lists: the feature PGDs' tails see the same map
+        rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean", "collect": col, "rpn_share": rpn_share})
         fm = [col[i] for i in (1, 2, 3)]
     else:
         if hasattr(model, "head_features"):      # prefixes of one another: one pass, no graph
@@ -224,7 +227,8 @@ def det_train_phases(model, optimizer, image_batch, bboxes_batch, labels_batch, 
         rr = fwd({"x": image_batch, "adv": None, "out_idx": "roi_head", "flag": "clean"})
     clean_sd = rr["roi_output_dict"]["roi_feature_map"].detach()
     fold = col is not None and os.environ.get("AFAN_DET_FOLD_PGD", "1") != "0"      # 0: PGD() as written (A/B, tests)
-    three = (_pgd_three_from_clean(model, col, image_batch, y, [(1, 0.1 / 255, 0.001 / 255), (2, 0.1 / 255, 0.001 / 255), (3, 2.0 / 255, 1.0 / 255)])
+    three = (_pgd_three_from_clean(model, col, image_batch, y, [(1, 0.1 / 255, 0.001 / 255), (2, 0.1 / 255, 0.001 / 255), (3, 2.0 / 255, 1.0 / 255)],
+                                   share=rpn_share if SHARE_PROPOSALS else None)
              if (fold and BATCH_PGD_TAILS) else None)
     if three is not None:
         adv1, adv2, adv3 = three

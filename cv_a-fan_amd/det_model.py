@@ -764,7 +764,7 @@ class RegionProposalNetwork(nn.Module):
         return per_image_losses(objectnesses, transformers, flat[sel], lab, gt_deltas, bi, b, self._anchor_smooth_l1_loss_beta)
 
     def forward_and_propose(self, features, anchor_bboxes, gt_bboxes_batch, image_width, image_height, return_type="clean", roi_targets=None,
-                            heads=None):
+                            heads=None, share=None):
         """`forward(...)` (training) followed by `generate_proposals(...)` — the order model.py:95-100 calls them in — with ONE host
         read for both: the anchor sampling's two list lengths and every image's NMS survivor count travel together (the label /
         list launches and the decode / sort / NMS launches are all queued before it).  The host's random draws keep their order
@@ -781,6 +781,15 @@ class RegionProposalNetwork(nn.Module):
         else:
             trunk = features["rpn_feature"] if return_type == "tail" else self._trunk(features)
             objectnesses, transformers = self._heads(trunk)
+        if share is not None and "state" in share:
+            # (round 6) a pass whose RPN input holds the SAME values as an earlier pass's (the one-step feature PGDs' tails and the clean
+            # ROI-head pass all start from the clean conv4 map: :81-88): anchor labels, proposals (decode, sort, NMS) and the ROI
+            # sampling's candidate lists are that pass's — only the host generator's draws are this pass's own, in the same order
+            # (anchor sampling's three, then the ROI sampling's three), and the losses hang on THIS pass's head outputs
+            pend0, counts, proposals, roi_pend, nb_img = share["state"]
+            ce, sl1 = self._losses_finish(pend0[:6] + (objectnesses, transformers, pend0[8]), counts[0], counts[1])
+            roi_t = roi_pend.finish(counts[2 + nb_img], counts[3 + nb_img]) if roi_pend is not None else None
+            return objectnesses, transformers, ce, sl1, proposals, roi_t
         pend = self._losses(objectnesses, transformers, anchor_bboxes, gt_bboxes_batch, image_width, image_height, pending=True)
         early = None
         if EARLY_READ and not torch.cuda.is_current_stream_capturing():
@@ -816,6 +825,8 @@ class RegionProposalNetwork(nn.Module):
             longest = max(len(k) for k in kept)
             proposals = torch.stack([torch.cat([k, torch.zeros(longest - len(k), 4).to(k)]) for k in kept], dim=0)
         roi_t = roi_pend.finish(counts[2 + nb_img], counts[3 + nb_img]) if roi_pend is not None else None
+        if share is not None and (roi_pend is not None) == (roi_targets is not None):
+            share["state"] = (pend[:6] + (None, None, pend[8]), counts, proposals.detach(), roi_pend, nb_img)
         return objectnesses, transformers, ce, sl1, proposals.detach(), roi_t
 
     def forward(self, features, anchor_bboxes=None, gt_bboxes_batch=None, image_width=None, image_height=None, return_type="clean"):
@@ -1039,21 +1050,24 @@ class Model(nn.Module):
                         "rpn_feature_map_dict": self.rpn.forward(features, anchors, gt_bboxes_batch, iw, ih, return_type="head")}
             assert type(idx) == int or idx == "roi_head"
             obj, tr, ao, at, proposals, roi_t = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih,
-                                                                             roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch))
+                                                                             roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch),
+                                                                             share=input_dict.get("rpn_share"))
         if idx == "roi_head":
             return {"anchor_objectness_losses": ao, "anchor_transformer_losses": at,
                     "roi_output_dict": self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, return_type="head", targets=roi_t)}
         _, _, pc, pt = self.detection.forward(features, proposals, gt_classes_batch, gt_bboxes_batch, targets=roi_t)
         return ao, at, pc, pt
 
-    def forward_heads_many(self, dicts, gt_bboxes_batch=None, gt_classes_batch=None):
+    def forward_heads_many(self, dicts, gt_bboxes_batch=None, gt_classes_batch=None, share=None):
         """[forward(d, gt_bboxes_batch, gt_classes_batch) for d in dicts] for training passes that are independent of one another (the
         final passes of train_aug_sat_muti_advt.py:141-153), with the ROI head — ROIAlign, layer4, the two Linear layers — run ONCE on
         all passes' sampled regions: pass by pass, in order, everything up to the sampling (backbone, RPN, proposals, the host
         generator's draws in the reference's sequence); then one ROIAlign over the concatenated feature maps (a region's batch index
         names its pass's map), one layer4 on 7 x 128 regions instead of seven on 128 (2 048 rows leave the chip half full), and each
         pass's two losses from its rows.  Frozen BatchNorm: a region's features do not depend on its batch; the small fp32 Linear
-        layers split their reduction by row count and the parameter gradients sum in one reduction: fp32 order is the difference."""
+        layers split their reduction per chunk whatever the row count; the parameter gradients sum in one reduction: fp32 order is the
+        only difference.  share: a dict — the passes' RPN inputs hold the SAME values (RegionProposalNetwork.forward_and_propose): labels,
+        proposals and candidate lists are computed once (by the first pass, or by an earlier pass that left its state in the dict)."""
         pend, feats = [], []
         for d in dicts:
             assert d["flag"] in ("tail", "clean") and type(d["out_idx"]) == int and self.training
@@ -1067,7 +1081,8 @@ class Model(nn.Module):
         for d, features, hd in zip(dicts, feats, heads):
             anchors, iw, ih = self._anchors(features, d["x"].shape)
             _, _, ao, at, proposals, roi_t = self.rpn.forward_and_propose(features, anchors, gt_bboxes_batch, iw, ih,
-                                                                          roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch), heads=hd)
+                                                                          roi_targets=self._roi_targets(gt_classes_batch, gt_bboxes_batch), heads=hd,
+                                                                          share=share)
             if roi_t is None:
                 roi_t = self.detection._targets(proposals, gt_classes_batch, gt_bboxes_batch)
             pend.append((features, ao, at, roi_t))
