@@ -20,7 +20,7 @@ declare -A BARGS=( [r18]="" [fp32]="--dtype fp32 --steps 10 --warmup 4 --no_cpu_
                    [dl101]="--arch deeplabv3plus_resnet101 --steps 10 --warmup 4"
                    [dl101b8]="--arch deeplabv3plus_resnet101 --batch 8 --steps 6 --warmup 4 --no_cpu_baseline"
                    [r50]="--arch resnet50 --batch 64 --pgd_steps 3 --steps 10 --warmup 4 --cpu_steps 1 --no_literal --no_dp_schedule"
-                   [frcnn]="--arch fasterrcnn_resnet101 --steps 5 --warmup 3" )
+                   [frcnn]="--arch fasterrcnn_resnet101 --steps 30 --warmup 5" )
 case "$1" in
   bench) TAG=${2:-r06a}; shift; shift; WHICH=${@:-r18 fp32 dl101 dl101b8 r50 frcnn}; O=$R/gpurun_out/$TAG; mkdir -p $O
          for N in $WHICH; do
