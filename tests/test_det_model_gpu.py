@@ -273,6 +273,31 @@ def test_batched_layer3_of_the_final_passes_equals_the_per_pass_runs(pkg, gpu):
     assert float((ga - gb).norm() / gb.norm()) < 1e-5
 
 
+def test_anchor_label_cache_follows_the_ground_truth(pkg, gpu):
+    """det_model.ANCHOR_LABEL_CACHE: the anchors' labels / candidate lists are remembered per (anchor grid, ground-truth tensor address,
+    version, shape) and the entry keeps that tensor alive: the same tensor again is a hit (the same objects), an in-place edit or another
+    tensor is a miss with the labels of ITS boxes."""
+    g = _golden_for("align")
+    m = _build(pkg, g, gpu, torch.bfloat16, True, "align")
+    rpn = m.rpn
+    images, bboxes = torch.from_numpy(g["images"]).to(gpu), torch.from_numpy(g["bboxes"]).to(gpu)
+    feats = torch.zeros(1, 1024, 38, 57, device=gpu)
+    anchors, iw, ih = m._anchors(feats, images.shape)
+    obj, tr = torch.zeros(1, anchors.shape[1], 2, device=gpu), torch.zeros(1, anchors.shape[1], 4, device=gpu)
+    a = rpn._losses(obj, tr, anchors, bboxes, iw, ih, pending=True)
+    b = rpn._losses(obj, tr, anchors, bboxes, iw, ih, pending=True)
+    assert a[0] is b[0] and a[1] is b[1]                                  # hit: the same list / label tensors
+    moved = bboxes.clone()
+    moved[..., [0, 2]] += 200.0
+    c = rpn._losses(obj, tr, anchors, moved, iw, ih, pending=True)
+    assert c[1] is not a[1] and not torch.equal(c[1], a[1])              # another tensor: its own labels
+    want, _ = pkg.det_ops.box_assign(a[3], moved, "anchor", 0.3, 0.7)
+    assert torch.equal(c[1], want)
+    moved[..., [0, 2]] -= 200.0                                          # in-place edit: the version moves, the entry does not answer
+    d = rpn._losses(obj, tr, anchors, moved, iw, ih, pending=True)
+    assert d[1] is not c[1] and torch.equal(d[1], a[1])
+
+
 def test_batched_feature_pgd_tails_equal_the_one_by_one_runs(pkg, gpu):
     """det_attack_algo.BATCH_PGD_TAILS: the three one-step feature PGDs (:84-88) run their RPN + ROI-head tails on the clean conv4 map as
     ONE forward_heads_many call and one backward of the losses' sum.  Every kernel on the way computes a row (a region, a pixel) from
